@@ -1,0 +1,292 @@
+"""Oracle (test infrastructure): functional CPU restatement of the reference networks.
+
+Networks are pure functions of a torchvision-shaped `state_dict` (name -> tensor) so the same
+weights can be fed to the reference import (golden generation), to this oracle and to the HIP
+product.  Restated from (paths relative to /root/reference):
+
+  densenet_*      models/attn_aug_conv.py:448-517 (DenseNet), :411-446 (_Transition) and the
+                  torchvision-0.3.0 `_DenseLayer` / `_DenseBlock` it imports at :13
+                  (norm1-relu1-conv1-norm2-relu2-conv2, cat([x, new], 1))
+  resnet_*        models/attn_aug_conv.py:159-211 (Bottleneck), :214-304 (ResNet)
+  efficientnet_*  models/efficientnet.py:27-228
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from .aaconv import aaconv2d, aa_dims
+
+
+# ----------------------------------------------------------------------------- specs
+def _bn_spec(spec, p, c):
+    spec[p + ".weight"] = (c,)
+    spec[p + ".bias"] = (c,)
+    spec[p + ".running_mean"] = (c,)
+    spec[p + ".running_var"] = (c,)
+    spec[p + ".num_batches_tracked"] = ()
+
+
+def _aa_spec(spec, p, c_in, c_out, ksz, dk, dv, nh, dims):
+    H, W = dims
+    spec[p + ".key_rel_h"] = (dk // nh, 2 * H - 1)
+    spec[p + ".key_rel_w"] = (dk // nh, 2 * W - 1)
+    if c_out > dv:
+        spec[p + ".conv.weight"] = (c_out - dv, c_in, ksz, ksz)
+    spec[p + ".in_proj_qkv.weight"] = (2 * dk + dv, c_in, 1, 1)
+    spec[p + ".out_proj.weight"] = (dv, dv, 1, 1)
+
+
+def densenet_spec(num_classes, growth=32, block_config=(6, 12, 24, 16), init_features=64, bn_size=4,
+                  attn=None, input_hw=(320, 320)):
+    """name -> shape in torchvision key order.  `attn` = dict(k=, v=, nh=) enables the AA transitions
+    (attn_aug_conv.py:436-440: InstanceNorm -> ReLU -> AAConv2d(3x3, stride 2))."""
+    spec = OrderedDict()
+    spec["features.conv0.weight"] = (init_features, 3, 7, 7)
+    _bn_spec(spec, "features.norm0", init_features)
+    c = init_features
+    hw = (input_hw[0] // 4, input_hw[1] // 4)
+    for b, n_layers in enumerate(block_config, 1):
+        for l in range(1, n_layers + 1):
+            p = "features.denseblock%d.denselayer%d" % (b, l)
+            _bn_spec(spec, p + ".norm1", c)
+            spec[p + ".conv1.weight"] = (bn_size * growth, c, 1, 1)
+            _bn_spec(spec, p + ".norm2", bn_size * growth)
+            spec[p + ".conv2.weight"] = (growth, bn_size * growth, 3, 3)
+            c += growth
+        if b != len(block_config):
+            p = "features.transition%d" % b
+            if attn is None:
+                _bn_spec(spec, p + ".norm", c)
+                spec[p + ".conv.weight"] = (c // 2, c, 1, 1)
+            else:
+                dk, dv = aa_dims(c // 2, attn["k"], attn["v"], attn["nh"])
+                _aa_spec(spec, p + ".conv", c, c // 2, 3, dk, dv, attn["nh"], (hw[0] // 2, hw[1] // 2))
+            c //= 2
+            hw = (hw[0] // 2, hw[1] // 2)
+    _bn_spec(spec, "features.norm5", c)
+    spec["classifier.weight"] = (num_classes, c)
+    spec["classifier.bias"] = (num_classes,)
+    return spec
+
+
+def resnet_spec(num_classes, layers=(3, 8, 36, 3), attn=None, input_hw=(320, 320)):
+    """Bottleneck ResNet (attn_aug_conv.py:159-304); `attn` puts AAConv2d in conv2 of layers 2-4."""
+    spec = OrderedDict()
+    spec["conv1.weight"] = (64, 3, 7, 7)
+    _bn_spec(spec, "bn1", 64)
+    inplanes = 64
+    for L, (planes, n) in enumerate(zip((64, 128, 256, 512), layers), 1):
+        stride = 1 if L == 1 else 2
+        for i in range(n):
+            p = "layer%d.%d" % (L, i)
+            s = stride if i == 0 else 1
+            spec[p + ".conv1.weight"] = (planes, inplanes, 1, 1)
+            _bn_spec(spec, p + ".bn1", planes)
+            if attn is not None and L >= 2:
+                dk, dv = aa_dims(planes, attn["k"], attn["v"], attn["nh"])
+                dims = (int(input_hw[0] * 16 / planes), int(input_hw[1] * 16 / planes))
+                _aa_spec(spec, p + ".conv2", planes, planes, 3, dk, dv, attn["nh"], dims)
+            else:
+                spec[p + ".conv2.weight"] = (planes, planes, 3, 3)
+            _bn_spec(spec, p + ".bn2", planes)
+            spec[p + ".conv3.weight"] = (planes * 4, planes, 1, 1)
+            _bn_spec(spec, p + ".bn3", planes * 4)
+            if i == 0 and (s != 1 or inplanes != planes * 4):
+                spec[p + ".downsample.0.weight"] = (planes * 4, inplanes, 1, 1)
+                _bn_spec(spec, p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    spec["fc.weight"] = (num_classes, 2048)
+    spec["fc.bias"] = (num_classes,)
+    return spec
+
+
+EFFNET_SCALING = {  # width, depth, resolution, dropout  (efficientnet.py:13-21)
+    "efficientnet-b0": (1.0, 1.0, 224, 0.2), "efficientnet-b1": (1.0, 1.1, 240, 0.2),
+    "efficientnet-b2": (1.1, 1.2, 260, 0.3), "efficientnet-b3": (1.2, 1.4, 300, 0.3),
+    "efficientnet-b4": (1.4, 1.8, 380, 0.4), "efficientnet-b5": (1.6, 2.2, 456, 0.4),
+    "efficientnet-b6": (1.8, 2.6, 528, 0.5), "efficientnet-b7": (2.0, 3.1, 600, 0.5)}
+_EFFNET_B0 = [  # repeats, in, out, k, stride, expand  (efficientnet.py:149-155); se_ratio 0.25 everywhere
+    (1, 32, 16, 3, 1, 1), (2, 16, 24, 3, 2, 6), (2, 24, 40, 5, 2, 6), (3, 40, 80, 3, 2, 6),
+    (3, 80, 112, 5, 1, 6), (4, 112, 192, 5, 2, 6), (1, 192, 320, 3, 1, 6)]
+
+
+def _round_filters(f, width, div=8):
+    new = max(div, int(f * width + div / 2) // div * div)
+    if new < 0.9 * f * width:
+        new += div
+    return int(new)
+
+
+def efficientnet_arch(name):
+    """-> (stem_out, [(in, out, k, stride, expand, se_reduce, has_skip, drop_rate)] per block, dropout)."""
+    assert name in EFFNET_SCALING, "Invalid model name."
+    width, depth, _, dropout = EFFNET_SCALING[name]
+    stem = _round_filters(32, width)
+    stages = []
+    for (n, cin, cout, k, s, e) in _EFFNET_B0:
+        cin, cout, n = _round_filters(cin, width), _round_filters(cout, width), int(math.ceil(depth * n))
+        blocks = []
+        for i in range(n):
+            bi, bs = (cin, s) if i == 0 else (cout, 1)
+            blocks.append(dict(cin=bi, cout=cout, k=k, stride=bs, expand=e, se=max(1, int(bi * 0.25)),
+                               skip=(bi == cout and bs == 1), drop=0.2 * i / n))
+        stages.append(blocks)
+    return stem, stages, dropout
+
+
+def efficientnet_spec(name, num_classes):
+    stem, stages, _ = efficientnet_arch(name)
+    spec = OrderedDict()
+    spec["stem.0.weight"] = (stem, 3, 3, 3)
+    _bn_spec(spec, "stem.1", stem)
+    for si, blocks in enumerate(stages):
+        for bi, b in enumerate(blocks):
+            p = "blocks.%d.%d" % (si, bi)
+            ce = b["cin"] * b["expand"]
+            j = 0
+            if b["expand"] != 1:
+                spec["%s.0.weight" % p] = (ce, b["cin"], 1, 1)
+                _bn_spec(spec, "%s.1" % p, ce)
+                j = 3
+            spec["%s.%d.weight" % (p, j)] = (ce, 1, b["k"], b["k"])
+            _bn_spec(spec, "%s.%d" % (p, j + 1), ce)
+            spec["%s.%d.1.weight" % (p, j + 3)] = (b["se"], ce, 1, 1)
+            spec["%s.%d.1.bias" % (p, j + 3)] = (b["se"],)
+            spec["%s.%d.3.weight" % (p, j + 3)] = (ce, b["se"], 1, 1)
+            spec["%s.%d.3.bias" % (p, j + 3)] = (ce,)
+            spec["%s.%d.weight" % (p, j + 4)] = (b["cout"], ce, 1, 1)
+            _bn_spec(spec, "%s.%d" % (p, j + 5), b["cout"])
+    spec["head.0.weight"] = (1280, stages[-1][-1]["cout"], 1, 1)
+    _bn_spec(spec, "head.1", 1280)
+    spec["head.6.weight"] = (num_classes, 1280)
+    spec["head.6.bias"] = (num_classes,)
+    return spec
+
+
+def zeros_state_dict(spec, dtype=torch.float32):
+    sd = OrderedDict()
+    for k, shp in spec.items():
+        sd[k] = torch.zeros(shp, dtype=torch.int64 if k.endswith("num_batches_tracked") else dtype)
+    return sd
+
+
+def param_count(spec):
+    return sum(int(torch.Size(s).numel()) for k, s in spec.items()
+               if not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+
+
+# ----------------------------------------------------------------------------- forward passes
+def _bn(sd, p, x, train, eps=1e-5, momentum=0.1):
+    if train:
+        sd[p + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
+                        sd[p + ".bias"], train, momentum, eps)
+
+
+def _aa(sd, p, x, stride, nh, return_weights=False):
+    qkv_w, out_w = sd[p + ".in_proj_qkv.weight"], sd[p + ".out_proj.weight"]
+    dv = out_w.shape[0]
+    dk = (qkv_w.shape[0] - dv) // 2
+    return aaconv2d(x, sd.get(p + ".conv.weight"), qkv_w, out_w, sd[p + ".key_rel_h"], sd[p + ".key_rel_w"],
+                    stride=stride, dk=dk, dv=dv, nh=nh, return_weights=return_weights)
+
+
+def densenet_features(sd, x, block_config=(6, 12, 24, 16), train=True, nh=None, taps=None):
+    """features(x) up to and including norm5 (pre-ReLU).  `nh` != None => AA transitions."""
+    x = F.conv2d(x, sd["features.conv0.weight"], stride=2, padding=3)
+    x = F.relu(_bn(sd, "features.norm0", x, train))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for b, n_layers in enumerate(block_config, 1):
+        for l in range(1, n_layers + 1):
+            p = "features.denseblock%d.denselayer%d" % (b, l)
+            y = F.conv2d(F.relu(_bn(sd, p + ".norm1", x, train)), sd[p + ".conv1.weight"])
+            y = F.conv2d(F.relu(_bn(sd, p + ".norm2", y, train)), sd[p + ".conv2.weight"], padding=1)
+            x = torch.cat([x, y], 1)
+        if taps is not None:
+            taps["block%d" % b] = x
+        if b != len(block_config):
+            p = "features.transition%d" % b
+            if nh is None:
+                x = F.conv2d(F.relu(_bn(sd, p + ".norm", x, train)), sd[p + ".conv.weight"])
+                x = F.avg_pool2d(x, 2, 2)
+            else:
+                x = _aa(sd, p + ".conv", F.relu(F.instance_norm(x, eps=1e-5)), 2, nh)
+    return _bn(sd, "features.norm5", x, train)
+
+
+def densenet_forward(sd, x, block_config=(6, 12, 24, 16), train=True, nh=None, taps=None):
+    f = densenet_features(sd, x, block_config, train, nh, taps)
+    if taps is not None:
+        taps["norm5"] = f
+    pooled = F.relu(f).mean((2, 3))
+    return F.linear(pooled, sd["classifier.weight"], sd["classifier.bias"])
+
+
+def resnet_forward(sd, x, layers=(3, 8, 36, 3), train=True, nh=None, taps=None):
+    x = F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)
+    x = F.max_pool2d(F.relu(_bn(sd, "bn1", x, train)), 3, 2, 1)
+    for L, n in enumerate(layers, 1):
+        for i in range(n):
+            p = "layer%d.%d" % (L, i)
+            s = 2 if (L > 1 and i == 0) else 1
+            y = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"]), train))
+            if p + ".conv2.weight" in sd:
+                y = F.conv2d(y, sd[p + ".conv2.weight"], stride=s, padding=1)
+            else:
+                y = _aa(sd, p + ".conv2", y, s, nh)
+            y = F.relu(_bn(sd, p + ".bn2", y, train))
+            y = _bn(sd, p + ".bn3", F.conv2d(y, sd[p + ".conv3.weight"]), train)
+            if p + ".downsample.0.weight" in sd:
+                x = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], stride=s), train)
+            x = F.relu(y + x)
+    if taps is not None:
+        taps["layer4"] = x
+    return F.linear(x.mean((2, 3)), sd["fc.weight"], sd["fc.bias"])
+
+
+def _same_pad_conv(x, w, stride, groups):
+    """PaddedConv2d (efficientnet.py:53-64): symmetric ceil(total/2) padding, width pad computed
+    from h_in (the reference's quirk; identical for square inputs)."""
+    h_in = x.shape[2]
+    k = w.shape[-1]
+    h_out = math.ceil(h_in / stride)
+    w_out = math.ceil(x.shape[3] / stride)
+    ph = math.ceil(max((h_out - 1) * stride - h_in + (k - 1) + 1, 0) / 2)
+    pw = math.ceil(max((w_out - 1) * stride - h_in + (k - 1) + 1, 0) / 2)
+    if ph > 0 or pw > 0:
+        x = F.pad(x, [pw, pw, ph, ph])
+    return F.conv2d(x, w, stride=stride, groups=groups)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def efficientnet_forward(sd, x, name, train=True, taps=None):
+    """Deterministic part only: DropConnect / Dropout act as identity (their masks depend on the
+    framework RNG)."""
+    _, stages, _ = efficientnet_arch(name)
+    bn = lambda p, t: _bn(sd, p, t, train, eps=1e-3, momentum=0.01)
+    x = _swish(bn("stem.1", _same_pad_conv(x, sd["stem.0.weight"], 2, 1)))
+    for si, blocks in enumerate(stages):
+        for bi, b in enumerate(blocks):
+            p = "blocks.%d.%d" % (si, bi)
+            y, j = x, 0
+            if b["expand"] != 1:
+                y = _swish(bn("%s.1" % p, F.conv2d(y, sd["%s.0.weight" % p])))
+                j = 3
+            wd = sd["%s.%d.weight" % (p, j)]
+            y = _swish(bn("%s.%d" % (p, j + 1), _same_pad_conv(y, wd, b["stride"], wd.shape[0])))
+            se = y.mean((2, 3), keepdim=True)
+            se = _swish(F.conv2d(se, sd["%s.%d.1.weight" % (p, j + 3)], sd["%s.%d.1.bias" % (p, j + 3)]))
+            se = torch.sigmoid(F.conv2d(se, sd["%s.%d.3.weight" % (p, j + 3)], sd["%s.%d.3.bias" % (p, j + 3)]))
+            y = y * se
+            y = bn("%s.%d" % (p, j + 5), F.conv2d(y, sd["%s.%d.weight" % (p, j + 4)]))
+            x = y + x if y.shape == x.shape else y
+    f = bn("head.1", F.conv2d(x, sd["head.0.weight"]))
+    if taps is not None:
+        taps["head1"] = f
+    pooled = _swish(f).mean((2, 3))
+    return F.linear(pooled, sd["head.6.weight"], sd["head.6.bias"])

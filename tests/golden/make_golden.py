@@ -1,0 +1,318 @@
+#!/usr/bin/env python
+"""Generate tests/golden/* by running the REAL reference (/root/reference) on CPU.
+
+Run in the build container only (the reference does not travel to the GPU box):
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py aaconv     # a subset
+
+What it does
+  * provides a build-owned stand-in for the four torchvision-0.3.0 symbols the reference imports
+    (`conv1x1`, `conv3x3`, `_DenseLayer`, `_DenseBlock`; torchvision is not installed here) and
+    empty stubs for `torchvision.transforms`, `torchvision.models.{densenet121,resnet152}` and
+    `tensorboardX.SummaryWriter` so that `chexpert.py` imports;
+  * builds the reference models, loads hash-filled state_dicts (`chexpert_amd.synth`, strict=True,
+    which also pins the state_dict key names / shapes of SURVEY.md section 8b), runs them on hash-made
+    inputs and records small outputs: logits, loss, per-parameter grad norms + leading elements,
+    BN running stats, AAConv outputs / grads / attention rows, Grad-CAM maps, AUROC cases,
+    parameter counts;
+  * prints the deviation of `oracle/` from the reference on the same inputs (informational; the
+    committed check is tests/test_oracle_golden.py against the fixtures written here).
+
+Only data (inputs' seeds and expected outputs) is written; no reference source text is stored.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from chexpert_amd import synth  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- stand-ins
+def install_standins():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvr = types.ModuleType("torchvision.models.resnet")
+    tvd = types.ModuleType("torchvision.models.densenet")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    def conv3x3(cin, cout, stride=1, groups=1, dilation=1):
+        return nn.Conv2d(cin, cout, 3, stride, dilation, dilation, groups, bias=False)
+
+    def conv1x1(cin, cout, stride=1):
+        return nn.Conv2d(cin, cout, 1, stride, bias=False)
+
+    class _DenseLayer(nn.Sequential):          # torchvision 0.3.0 semantics
+        def __init__(self, num_input_features, growth_rate, bn_size, drop_rate):
+            super().__init__()
+            mid = bn_size * growth_rate
+            self.add_module("norm1", nn.BatchNorm2d(num_input_features))
+            self.add_module("relu1", nn.ReLU(inplace=True))
+            self.add_module("conv1", nn.Conv2d(num_input_features, mid, 1, 1, bias=False))
+            self.add_module("norm2", nn.BatchNorm2d(mid))
+            self.add_module("relu2", nn.ReLU(inplace=True))
+            self.add_module("conv2", nn.Conv2d(mid, growth_rate, 3, 1, 1, bias=False))
+            self.drop_rate = drop_rate
+
+        def forward(self, x):
+            new = super().forward(x)
+            if self.drop_rate > 0:
+                new = nn.functional.dropout(new, self.drop_rate, self.training)
+            return torch.cat([x, new], 1)
+
+    class _DenseBlock(nn.Sequential):
+        def __init__(self, num_layers, num_input_features, bn_size, growth_rate, drop_rate):
+            super().__init__()
+            for i in range(num_layers):
+                self.add_module("denselayer%d" % (i + 1),
+                                _DenseLayer(num_input_features + i * growth_rate, growth_rate, bn_size, drop_rate))
+
+    tvr.conv1x1, tvr.conv3x3 = conv1x1, conv3x3
+    tvd._DenseLayer, tvd._DenseBlock = _DenseLayer, _DenseBlock
+    tvm.resnet, tvm.densenet = tvr, tvd
+    tvm.densenet121 = tvm.resnet152 = None
+    tv.models, tv.transforms = tvm, tvt
+    tbx = types.ModuleType("tensorboardX")
+    tbx.SummaryWriter = object
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr,
+                        "torchvision.models.densenet": tvd, "torchvision.transforms": tvt, "tensorboardX": tbx})
+    sys.path.insert(0, REF)
+
+
+# ----------------------------------------------------------------------------- helpers
+def summarise(t: torch.Tensor):
+    """Small, layout-sensitive summary of a tensor: l2, sum, first 8, 8 strided samples."""
+    f = t.detach().double().flatten()
+    n = f.numel()
+    idx = (torch.arange(8) * max(1, n // 8) + (n // 16)).clamp(max=n - 1)
+    return {"l2": float(f.norm()), "sum": float(f.sum()), "head": f[:8].tolist(), "samples": f[idx].tolist(),
+            "n": int(n)}
+
+
+def filled_sd(spec, seed):
+    from oracle import nets
+    return synth.fill_state_dict_(nets.zeros_state_dict(spec), seed)
+
+
+def run_net(model, sd, x, target, tag, out, oracle_fwd, taps_ref=None):
+    """Reference eval logits, then one reference train step (chexpert.py:159-163); compare oracle."""
+    from oracle import step as ostep
+    model.load_state_dict(sd, strict=True)
+    rec = {}
+    model.eval()
+    with torch.no_grad():
+        rec["logits_eval"] = model(x).tolist()
+    model.train()
+    logits = model(x)
+    loss = nn.BCEWithLogitsLoss(reduction="none")(logits, target).sum(1).mean(0)
+    model.zero_grad()
+    loss.backward()
+    rec["logits_train"] = logits.tolist()
+    rec["loss"] = float(loss)
+    rec["grads"] = {k: summarise(p.grad) for k, p in model.named_parameters()}
+    after = model.state_dict()
+    rec["running"] = {k: summarise(v) for k, v in after.items() if k.endswith(("running_mean", "running_var"))
+                      and (k.count(".") <= 2 or "norm5" in k or "denselayer1." in k)}
+    rec["n_params"] = sum(p.numel() for p in model.parameters())
+    rec["keys"] = len(after)
+    out[tag] = rec
+    # oracle deviation (informational)
+    sd_e = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        le = oracle_fwd(sd_e, x, train=False)
+    sd_t = {k: v.clone() for k, v in sd.items()}
+    lo, lg, grads = ostep.train_step(lambda s, xx: oracle_fwd(s, xx, train=True), sd_t, x, target)
+    gmax = max(rec["grads"][k]["l2"] for k in grads)
+    dev_g = max(abs(float(grads[k].double().norm()) - rec["grads"][k]["l2"]) / (rec["grads"][k]["l2"] + 1e-3 * gmax)
+                for k in grads)
+    print("[%s] oracle-vs-reference: eval %.2e train %.2e loss %.2e grad-l2(rel) %.2e | logits absmax %.3f" % (
+        tag, (le - torch.tensor(rec["logits_eval"])).abs().max(), (lg - logits).abs().max(),
+        abs(float(lo) - rec["loss"]), dev_g, logits.abs().max()))
+
+
+# ----------------------------------------------------------------------------- fixtures
+def gen_aaconv(out_dir):
+    from models.attn_aug_conv import AAConv2d
+    from oracle.aaconv import aaconv2d
+    cases = {
+        "small_s2": dict(B=2, cin=16, cout=24, k=3, stride=2, dk=8, dv=8, nh=4, hin=(10, 14)),
+        "small_s1": dict(B=2, cin=8, cout=16, k=3, stride=1, dk=16, dv=4, nh=2, hin=(6, 5)),
+        "t1_like": dict(B=1, cin=256, cout=128, k=3, stride=2, dk=160, dv=8, nh=8, hin=(16, 16)),
+        "attn_only": dict(B=1, cin=8, cout=8, k=1, stride=1, dk=8, dv=8, nh=2, hin=(4, 6)),
+    }
+    arrays, meta = {}, {}
+    for name, c in cases.items():
+        H, W = c["hin"][0] // c["stride"], c["hin"][1] // c["stride"]
+        torch.manual_seed(0)
+        m = AAConv2d(c["cin"], c["cout"], c["k"], c["stride"], c["dk"], c["dv"], c["nh"], True, (H, W))
+        sd = m.state_dict()
+        synth.fill_state_dict_(sd, 7)
+        m.load_state_dict(sd)
+        x = synth.uniform(11, (c["B"], c["cin"]) + tuple(c["hin"]), -1.5, 1.5).requires_grad_(True)
+        gy = synth.uniform(13, (c["B"], c["cout"], H, W), -1, 1)
+        y = m(x)
+        (y * gy).sum().backward()
+        arrays[name + ".y"] = y.detach().numpy()
+        arrays[name + ".dx"] = x.grad.numpy()
+        for k, p in m.named_parameters():
+            arrays[name + ".d_" + k] = p.grad.numpy()
+        arrays[name + ".weights_rows"] = m.weights.detach()[:, :, :3].numpy()     # first 3 query rows / head
+        meta[name] = dict(c, keys={k: list(v.shape) for k, v in sd.items()})
+        # oracle deviation
+        x2 = x.detach().clone().requires_grad_(True)
+        sd2 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        y2, P = aaconv2d(x2, sd2.get("conv.weight"), sd2["in_proj_qkv.weight"], sd2["out_proj.weight"],
+                         sd2["key_rel_h"], sd2["key_rel_w"], stride=c["stride"], dk=c["dk"], dv=c["dv"], nh=c["nh"],
+                         return_weights=True)
+        (y2 * gy).sum().backward()
+        print("[aaconv %s] oracle-vs-reference: y %.2e dx %.2e P %.2e d_rel_h %.2e" % (
+            name, (y2 - y).abs().max(), (x2.grad - x.grad).abs().max(), (P - m.weights).abs().max(),
+            (sd2["key_rel_h"].grad - m.key_rel_h.grad).abs().max()))
+    np.savez_compressed(os.path.join(out_dir, "aaconv.npz"), **arrays)
+    json.dump(meta, open(os.path.join(out_dir, "aaconv.json"), "w"), indent=1)
+
+
+def gen_nets(out_dir, which):
+    from models.attn_aug_conv import DenseNet, ResNet, Bottleneck
+    from models.efficientnet import construct_model
+    from oracle import nets
+    out = {}
+    path = os.path.join(out_dir, "nets.json")
+    if os.path.exists(path):
+        out = json.load(open(path))
+    n_cls = 5
+    attn = dict(k=0.2, v=0.1, nh=8)
+
+    def ref_attn(hw):
+        return {"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": hw}   # chexpert.py:476
+
+    jobs = {
+        "densenet121_320_b2": lambda: (DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls),
+                                       nets.densenet_spec(n_cls), 2, 320,
+                                       lambda s, x, train: nets.densenet_forward(s, x, train=train)),
+        "densenet_tiny_64_b3": lambda: (DenseNet(32, (2, 2, 2, 2), 64, num_classes=n_cls),
+                                        nets.densenet_spec(n_cls, block_config=(2, 2, 2, 2)), 3, 64,
+                                        lambda s, x, train: nets.densenet_forward(s, x, (2, 2, 2, 2), train=train)),
+        "aadensenet121_320_b1": lambda: (DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls, attn_params=ref_attn((320, 320))),
+                                         nets.densenet_spec(n_cls, attn=attn), 1, 320,
+                                         lambda s, x, train: nets.densenet_forward(s, x, train=train, nh=8)),
+        "aadensenet_tiny_64_b2": lambda: (DenseNet(32, (6, 4, 2, 2), 64, num_classes=n_cls, attn_params=ref_attn((64, 64))),
+                                          nets.densenet_spec(n_cls, block_config=(6, 4, 2, 2), attn=attn, input_hw=(64, 64)), 2, 64,
+                                          lambda s, x, train: nets.densenet_forward(s, x, (6, 4, 2, 2), train=train, nh=8)),
+        "resnet152_320_b2": lambda: (ResNet(Bottleneck, [3, 8, 36, 3], num_classes=n_cls),
+                                     nets.resnet_spec(n_cls), 2, 320,
+                                     lambda s, x, train: nets.resnet_forward(s, x, train=train)),
+        "resnet_tiny_64_b2": lambda: (ResNet(Bottleneck, [1, 1, 1, 1], num_classes=n_cls),
+                                      nets.resnet_spec(n_cls, layers=(1, 1, 1, 1)), 2, 64,
+                                      lambda s, x, train: nets.resnet_forward(s, x, (1, 1, 1, 1), train=train)),
+        "efficientnet-b0_224_b2": lambda: (construct_model("efficientnet-b0", n_cls),
+                                           nets.efficientnet_spec("efficientnet-b0", n_cls), 2, 224,
+                                           lambda s, x, train: nets.efficientnet_forward(s, x, "efficientnet-b0", train=train)),
+        "efficientnet-b4_380_b2": lambda: (construct_model("efficientnet-b4", n_cls),
+                                           nets.efficientnet_spec("efficientnet-b4", n_cls), 2, 380,
+                                           lambda s, x, train: nets.efficientnet_forward(s, x, "efficientnet-b4", train=train)),
+    }
+    for tag, job in jobs.items():
+        if which and not any(w in tag for w in which):
+            continue
+        model, spec, B, S, fwd = job()
+        if "efficientnet" in tag:       # deterministic part only: DropConnect / Dropout masks are RNG-bound
+            for m in model.modules():
+                if isinstance(m, (nn.Dropout, nn.Dropout3d)):
+                    m.p = 0.0
+        sd = filled_sd(spec, 21)
+        x = synth.xray_batch(1234, B, S)
+        t = synth.targets(99, B, n_cls)
+        run_net(model, sd, x, t, tag, out, fwd)
+        out[tag].update(B=B, S=S, n_classes=n_cls, sd_seed=21, x_seed=1234, t_seed=99)
+        json.dump(out, open(path, "w"))
+    # parameter counts pinned by the reference constructors
+    counts = {}
+    counts["densenet121@14"] = sum(p.numel() for p in DenseNet(32, (6, 12, 24, 16), 64, num_classes=14).parameters())
+    counts["densenet121@1000"] = sum(p.numel() for p in DenseNet(32, (6, 12, 24, 16), 64).parameters())
+    counts["aaresnet152@5"] = sum(p.numel() for p in ResNet(Bottleneck, [3, 8, 36, 3], num_classes=5,
+                                                            attn_params=ref_attn((320, 320))).parameters())
+    json.dump(counts, open(os.path.join(out_dir, "param_counts.json"), "w"), indent=1)
+
+
+def gen_gradcam(out_dir):
+    """Runs the reference `grad_cam` itself.  torch 2.10 rejects its in-place normalisation of an
+    autograd view (chexpert.py:290-294), so `chexpert.F.relu` alone is wrapped to hand back a detached
+    tensor at :285 -- the values are unchanged and every other statement is the reference's own."""
+    import chexpert as ref
+    from models.attn_aug_conv import DenseNet
+    from oracle import nets, gradcam
+
+    class _F:
+        def __getattr__(self, k):
+            return getattr(torch.nn.functional, k)
+
+        @staticmethod
+        def relu(t, *a, **kw):
+            return torch.nn.functional.relu(t, *a, **kw).detach()
+    ref.F = _F()
+    cfg = (2, 2, 2, 2)
+    model = DenseNet(32, cfg, 64, num_classes=5)
+    sd = filled_sd(nets.densenet_spec(5, block_config=cfg), 21)
+    model.load_state_dict(sd)
+    x = synth.xray_batch(77, 3, 64)
+    cam = ref.grad_cam(model, x, {"forward": model.features.norm5, "backward": model.classifier})
+    np.savez_compressed(os.path.join(out_dir, "gradcam.npz"), cam=cam.detach().numpy())
+    taps = {}
+    with torch.no_grad():
+        nets.densenet_forward({k: v.clone() for k, v in sd.items()}, x, cfg, train=False, taps=taps)
+    mine = gradcam.grad_cam_from_features(torch.relu(taps["norm5"]), 5, x.shape[2:])
+    print("[gradcam] oracle-vs-reference: %.2e (cam max %.3f)" % ((mine - cam).abs().max(), cam.max()))
+
+
+def gen_auroc(out_dir):
+    import chexpert as ref
+    from oracle import metrics
+    cases = {}
+    rng = [(50, 5, 3), (200, 5, 4), (64, 5, 5), (30, 3, 6)]
+    for i, (n, c, seed) in enumerate(rng):
+        logits = synth.uniform(seed, (n, c), -3, 3).numpy().astype(np.float64)
+        tg = synth.targets(seed + 100, n, c, p=0.35).numpy()
+        if i == 1:
+            logits = np.round(logits)            # heavy ties
+        if i == 2:
+            tg[:, 1] = 0                         # one class only -> nan (sklearn warns)
+            tg[:, 3] = 1
+        if i == 3:
+            logits[:, 0] = 0.25                  # all scores tied -> 0.5
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = ref.compute_metrics(torch.from_numpy(logits), torch.from_numpy(tg), torch.zeros(n, c))
+        aucs = [float(m["aucs"][k]) for k in range(c)]
+        cases["case%d" % i] = dict(n=n, c=c, seed=seed, variant=i, aucs=[None if np.isnan(a) else a for a in aucs],
+                                   nanmean=None if np.all(np.isnan(aucs)) else float(np.nanmean(aucs)))
+        mine, _ = metrics.per_class_auc(logits, tg)
+        print("[auroc case%d] oracle-vs-sklearn: %.2e" % (i, np.nanmax(np.abs(np.array(list(mine.values())) - np.array(aucs)))))
+    json.dump(cases, open(os.path.join(out_dir, "auroc.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference is only present in the build container"
+    install_standins()
+    torch.set_num_threads(8)
+    which = sys.argv[1:]
+    if not which or "aaconv" in which:
+        gen_aaconv(HERE)
+    if not which or "auroc" in which:
+        gen_auroc(HERE)
+    if not which or "gradcam" in which:
+        gen_gradcam(HERE)
+    net_sel = [w for w in which if w not in ("aaconv", "auroc", "gradcam", "nets")]
+    if not which or "nets" in which or net_sel:
+        gen_nets(HERE, net_sel)
