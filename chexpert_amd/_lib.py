@@ -1,0 +1,110 @@
+"""ctypes binding of libchexpert_hip.so (include/chexpert_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  `lib()` raises if the shared object
+is missing, and every wrapper raises `RuntimeError` on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchexpert_hip.so")
+
+PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE2 = 0, 1, 2
+MODE_CONV, MODE_POOL2, MODE_STEM = 0, 1, 2
+EPI_STORE, EPI_MASK = 0, 1
+
+_vp, _fp, _i32 = C.c_void_p, C.c_void_p, C.c_int32
+
+
+class CxConv(C.Structure):
+    _fields_ = [("x", _vp), ("x2", _vp), ("w", _vp), ("y", _vp),
+                ("pa", _fp), ("pb", _fp), ("pc", _fp),
+                ("stat_sum", _fp), ("stat_sq", _fp),
+                ("ex", _vp), ("e_sc", _fp), ("e_sh", _fp), ("e_mu", _fp), ("e_r", _fp), ("e_scale", _fp),
+                ("B", _i32), ("H", _i32), ("W", _i32), ("Ho", _i32), ("Wo", _i32),
+                ("K", _i32), ("N", _i32),
+                ("ldx", _i32), ("ldx2", _i32), ("ldy", _i32), ("ldex", _i32),
+                ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
+                ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32)]
+
+
+class CxWgrad(C.Structure):
+    _fields_ = [("g", _vp), ("g2", _vp), ("x", _vp), ("dw", _fp),
+                ("ga", _fp), ("gb", _fp), ("gc", _fp), ("pa", _fp), ("pb", _fp),
+                ("B", _i32), ("H", _i32), ("W", _i32), ("Ho", _i32), ("Wo", _i32), ("K", _i32), ("N", _i32),
+                ("ldg", _i32), ("ldg2", _i32), ("ldx", _i32),
+                ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
+                ("g_prologue", _i32), ("x_prologue", _i32), ("mode", _i32), ("splits", _i32)]
+
+
+# name -> argtypes (return type is int unless noted); kept in one table so the symbol-export test can
+# check it against include/chexpert_hip.h
+_f, _sz, _i = C.c_float, C.c_size_t, C.c_int
+SIGNATURES = {
+    "cx_abi_version": [],
+    "cx_error_string": [_i],
+    "cx_conv_gemm": [C.POINTER(CxConv), _vp],
+    "cx_conv_wgrad": [C.POINTER(CxWgrad), _vp],
+    "cx_pack_weights": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_nchw3_to_nhwc4": [_vp, _vp, _i, _i, _i, _vp],
+    "cx_bn_coef": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "cx_bn_coef_eval": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],
+    "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "cx_bn_bwd_slice_coef": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "cx_bnrelu_maxpool_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cx_bnrelu_maxpool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_head_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cx_bce_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp],
+    "cx_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cx_gap_relu_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cx_unpool2_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_affine2_inplace": [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_adam_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp],
+    "cx_sgd_nesterov_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _f, _vp],
+    "cx_rmsprop_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp],
+    "cx_fill_f32": [_vp, _f, _sz, _vp],
+    "cx_bf16_to_f32_nchw": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "chexpert_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = C.c_char_p if name == "cx_error_string" else C.c_int
+        if l.cx_abi_version() != 1:
+            raise RuntimeError("chexpert_amd: ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (code %d)" % (what, lib().cx_error_string(rc).decode(), rc))
+
+
+def ptr(t):
+    """data pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("chexpert_amd kernels run on the GPU only (got a %s tensor); there is no CPU fallback"
+                               % t.device)

@@ -1,0 +1,400 @@
+// Implicit-GEMM convolution (forward and input-gradient) for NHWC bf16 on gfx950.
+//
+//   Y[m][n] = sum_{tap,c} A(m, tap, c) * W[tap][n][c]        m = (b, oy, ox) flattened
+//
+// A is never stored: it is produced in the staging pass from the raw dense-block buffer by the fused
+// prologue (BN scale/shift + ReLU, 2x2 average, or the two-tensor affine form of BN backward).
+// Tile: 128 output pixels x BN channels x 32 input channels per step, 4 waves, MFMA 32x32x16 bf16 with
+// fp32 accumulation; LDS double buffered (one barrier per step), global loads for step s+1 are in
+// flight while step s is multiplied.  LDS rows are padded to 80 B so the ds_read_b128 fragment reads
+// are bank-conflict free (MI355X_MICROARCH.md LDS table).  The epilogue stages the fp32 tile through
+// LDS so that global stores / mask loads are 16 B per lane along the channel axis.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int PITCH = 80;              // bytes per LDS row: 32 bf16 + 16 B pad
+constexpr int A_BYTES = BM * PITCH;
+
+template <int BN>
+struct Geo {
+  static constexpr int WAVES_N = (BN >= 64) ? 2 : 1;
+  static constexpr int WAVES_M = 4 / WAVES_N;
+  static constexpr int TM = BM / (WAVES_M * 32);
+  static constexpr int TN = BN / (WAVES_N * 32);
+  static constexpr int B_BYTES = BN * PITCH;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int EPITCH = BN + 4;                       // floats per epilogue row
+  static constexpr int EPI_BYTES = 64 * EPITCH * 4;
+  static constexpr int MAIN_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+};
+
+template <int PRO>
+struct NCoef {
+  static constexpr int v = (PRO == CX_PRO_NONE) ? 0 : (PRO == CX_PRO_AFFINE_RELU ? 2 : 3);
+};
+
+template <int BN, int PRO, int MODE, int EPI>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const int M, const int n_tiles) {
+  using G = Geo<BN>;
+  constexpr int NSRC = (MODE == CX_MODE_POOL2) ? 4 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);                       // [NCoef][K]
+  char* tiles = smem + NCoef<PRO>::v * p.K * 4;
+  float* lstat = reinterpret_cast<float*>(tiles + G::MAIN_BYTES);     // [2][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
+  const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = wgid / n_tiles, nt = wgid % n_tiles;
+  const int n0 = nt * BN;
+
+  // ---- coefficient table + stat zeroing
+  if (PRO != CX_PRO_NONE) {
+    for (int i = tid; i < p.K; i += 256) {
+      coef[i] = p.pa[i];
+      coef[p.K + i] = p.pb[i];
+      if (PRO == CX_PRO_AFFINE2) coef[2 * p.K + i] = p.pc[i];
+    }
+  }
+  if (tid < 2 * BN) lstat[tid] = 0.f;
+
+  // ---- per-thread A rows
+  const int qa = tid & 3;                 // 8-channel chunk inside the 32-wide K step
+  int rb[2], riy[2], rix[2];
+  bool rvalid[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = mt * BM + (tid >> 2) + 64 * i;
+    rvalid[i] = m < M;
+    const int mm = rvalid[i] ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    rb[i] = mm / hw;
+    const int rem = mm - rb[i] * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    if (MODE == CX_MODE_CONV) {
+      riy[i] = oy * p.stride - p.pad;
+      rix[i] = ox * p.stride - p.pad;
+    } else if (MODE == CX_MODE_POOL2) {
+      riy[i] = 2 * oy;
+      rix[i] = 2 * ox;
+    } else {                              // STEM: row taps ky, 8 pixels starting at 2*ox-4
+      riy[i] = 2 * oy - 3;
+      rix[i] = 2 * ox - 4 + 2 * qa;
+    }
+  }
+  const int kpt = (MODE == CX_MODE_STEM) ? 1 : p.K / BK;         // K steps per tap
+  const int taps = (MODE == CX_MODE_STEM) ? 7 : p.kh * p.kw;
+  const int nsteps = taps * kpt;
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const bf16* __restrict__ X2 = reinterpret_cast<const bf16*>(p.x2);
+  const bf16* __restrict__ Wp = reinterpret_cast<const bf16*>(p.w);
+
+  uint4 ra[2][NSRC], ra2[2], rbw[2];
+  bool av[2];
+
+  auto issue_loads = [&](int s) {
+    const int tap = s / kpt, kc = s - tap * kpt;
+    const int dy = (MODE == CX_MODE_CONV) ? tap / p.kw : tap;
+    const int dx = (MODE == CX_MODE_CONV) ? tap - dy * p.kw : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (MODE == CX_MODE_STEM) {
+        const int iy = riy[i] + dy, ix = rix[i];
+        av[i] = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        if (av[i]) ra[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(rb[i] * p.H + iy) * p.W + ix) * 4);
+      } else if (MODE == CX_MODE_POOL2) {
+        av[i] = rvalid[i];
+        if (av[i]) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const size_t pix = (size_t)(rb[i] * p.H + riy[i] + (a >> 1)) * p.W + rix[i] + (a & 1);
+            ra[i][a] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
+          }
+        }
+      } else {
+        const int iy = riy[i] + dy, ix = rix[i] + dx;
+        av[i] = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        if (av[i]) {
+          const size_t pix = (size_t)(rb[i] * p.H + iy) * p.W + ix;
+          ra[i][0] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
+          if (PRO == CX_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(X2 + pix * p.ldx2 + kc * BK + qa * 8);
+        }
+      }
+    }
+    // weights: rows n = tid>>2 (+64), chunk qa
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nb = (tid >> 2) + 64 * i;
+      if (nb < BN) {
+        const int n = n0 + nb;
+        if (n < p.N) {
+          const size_t off = ((size_t)tap * p.N + n) * (size_t)(MODE == CX_MODE_STEM ? BK : p.K) + kc * BK + qa * 8;
+          rbw[i] = *reinterpret_cast<const uint4*>(Wp + off);
+        } else {
+          rbw[i] = make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  auto write_stage = [&](int s, int buf) {
+    const int tap = s / kpt, kc = s - tap * kpt;
+    char* A = tiles + buf * G::STAGE;
+    char* Bt = A + A_BYTES;
+    const int c0 = kc * BK + qa * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      U128 o;
+      if (!av[i]) {
+        o.u = make_uint4(0, 0, 0, 0);
+      } else if (PRO == CX_PRO_NONE) {
+        o.u = ra[i][0];
+      } else if (PRO == CX_PRO_AFFINE_RELU) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int a = 0; a < NSRC; ++a) {
+          U128 v;
+          v.u = ra[i][a];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            acc[j] += fmaxf(fmaf(bf2f(v.e[j]), coef[c0 + j], coef[p.K + c0 + j]), 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(NSRC == 4 ? acc[j] * 0.25f : acc[j]);
+      } else {
+        U128 u, v;
+        u.u = ra[i][0];
+        v.u = ra2[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o.e[j] = f2bf(fmaf(bf2f(u.e[j]), coef[c0 + j], fmaf(bf2f(v.e[j]), coef[p.K + c0 + j], coef[2 * p.K + c0 + j])));
+      }
+      *reinterpret_cast<uint4*>(A + ((tid >> 2) + 64 * i) * PITCH + qa * 16) = o.u;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nb = (tid >> 2) + 64 * i;
+      if (nb < BN) *reinterpret_cast<uint4*>(Bt + nb * PITCH + qa * 16) = rbw[i];
+    }
+    (void)tap;
+  };
+
+  f32x16 acc[G::TM][G::TN];
+#pragma unroll
+  for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue_loads(0);
+  __syncthreads();                       // coefficient table visible
+  write_stage(0, 0);
+  __syncthreads();
+
+  const int lrow = lane & 31, lh = lane >> 5;
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) issue_loads(s + 1);
+    const char* A = tiles + buf * G::STAGE;
+    const char* Bt = A + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[G::TM], bfr[G::TN];
+#pragma unroll
+      for (int i = 0; i < G::TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(A + ((wm * G::TM + i) * 32 + lrow) * PITCH + kk * 32 + lh * 16);
+#pragma unroll
+      for (int j = 0; j < G::TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bt + ((wn * G::TN + j) * 32 + lrow) * PITCH + kk * 32 + lh * 16);
+#pragma unroll
+      for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) write_stage(s + 1, buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue (two 64-row halves)
+  constexpr int CPR = BN / 8;              // 16-byte chunks per row
+  constexpr int RPP = 256 / CPR;           // rows per pass
+  const int cq = tid % CPR, rr = tid / CPR;
+  const int nch = n0 + cq * 8;             // first channel of this thread's chunk
+  const bool nvalid = nch < p.N;
+  float* etile = reinterpret_cast<float*>(tiles);
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+  const bf16* __restrict__ EX = reinterpret_cast<const bf16*>(p.ex);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  float esc[8], esh[8], emu[8], er[8], escale[8];
+  if (EPI == CX_EPI_MASK && nvalid) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      esc[j] = p.e_sc[nch + j];
+      esh[j] = p.e_sh[nch + j];
+      emu[j] = p.e_mu[nch + j];
+      er[j] = p.e_r[nch + j];
+      escale[j] = p.e_scale[nch + j];
+    }
+  }
+  const bool want_stats = p.stat_sum != nullptr;
+
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm / (G::WAVES_M / 2) == half) {
+      const int wml = wm % (G::WAVES_M / 2);
+#pragma unroll
+      for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (wml * G::TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int col = (wn * G::TN + j) * 32 + lrow;
+            etile[row * G::EPITCH + col] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 64 / RPP; ++pass) {
+      const int row = pass * RPP + rr;
+      const int m = mt * BM + half * 64 + row;
+      if (m < M && nvalid) {
+        const float4 v0 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        U128 o;
+        if (EPI == CX_EPI_STORE) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            o.e[j] = f2bf(v[j]);
+            const float rv = bf2f(o.e[j]);
+            s1[j] += rv;
+            s2[j] += rv * rv;
+          }
+        } else {
+          U128 xv, old;
+          xv.u = *reinterpret_cast<const uint4*>(EX + (size_t)m * p.ldex + nch);
+          if (p.accumulate) old.u = *reinterpret_cast<const uint4*>(Y + (size_t)m * p.ldy + nch);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xf = bf2f(xv.e[j]);
+            const float dz = (fmaf(xf, esc[j], esh[j]) > 0.f) ? v[j] : 0.f;
+            s1[j] += dz;
+            s2[j] += dz * (xf - emu[j]) * er[j];
+            float out = escale[j] * dz;
+            if (p.accumulate) out += bf2f(old.e[j]);
+            o.e[j] = f2bf(out);
+          }
+        }
+        *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + nch) = o.u;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (want_stats) {
+    // lanes sharing a channel chunk inside a wave are CPR apart
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int d = CPR; d < 64; d <<= 1) {
+        s1[j] += __shfl_xor(s1[j], d);
+        s2[j] += __shfl_xor(s2[j], d);
+      }
+    }
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&lstat[cq * 8 + j], s1[j]);
+        atomicAdd(&lstat[BN + cq * 8 + j], s2[j]);
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      atomicAdd(&p.stat_sum[n0 + tid], lstat[tid]);
+      atomicAdd(&p.stat_sq[n0 + tid], lstat[BN + tid]);
+    }
+  }
+}
+
+template <int BN, int PRO, int MODE, int EPI>
+int launch(const CxConv& p, hipStream_t st) {
+  using G = Geo<BN>;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + BM - 1) / BM);
+  const int n_tiles = (p.N + BN - 1) / BN;
+  const size_t smem = (size_t)NCoef<PRO>::v * p.K * 4 + G::MAIN_BYTES + 2 * BN * 4;
+  if (smem > 160 * 1024) return CX_ESHAPE;
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BN, PRO, MODE, EPI>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_kernel<BN, PRO, MODE, EPI>), dim3(m_tiles * n_tiles), dim3(256), smem, st, p, (int)M,
+                     n_tiles);
+  return launch_status();
+}
+
+template <int PRO, int MODE, int EPI>
+int launch_bn(const CxConv& p, hipStream_t st) {
+  if (p.N % 128 == 0) return launch<128, PRO, MODE, EPI>(p, st);
+  if (p.N == 32) return launch<32, PRO, MODE, EPI>(p, st);
+  return launch<64, PRO, MODE, EPI>(p, st);
+}
+
+}  // namespace
+
+extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
+  if (!pp) return CX_EINVAL;
+  const CxConv& p = *pp;
+  if (!p.x || !p.w || !p.y) return CX_EINVAL;
+  if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
+  if (p.K <= 0 || p.N <= 0 || (p.K % 32) || (p.N % 32)) return CX_ESHAPE;
+  if ((p.ldx % 8) || (p.ldy % 8) || !aligned16(p.x) || !aligned16(p.y) || !aligned16(p.w)) return CX_EALIGN;
+  if ((long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;
+  if (p.prologue != CX_PRO_NONE && (!p.pa || !p.pb)) return CX_EINVAL;
+  if (p.prologue == CX_PRO_AFFINE2 && (!p.x2 || !p.pc || (p.ldx2 % 8) || !aligned16(p.x2))) return CX_EINVAL;
+  if (p.epilogue == CX_EPI_MASK) {
+    if (!p.ex || !p.e_sc || !p.e_sh || !p.e_mu || !p.e_r || !p.e_scale || !p.stat_sum || !p.stat_sq) return CX_EINVAL;
+    if ((p.ldex % 8) || !aligned16(p.ex)) return CX_EALIGN;
+  }
+  if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return CX_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (p.mode == CX_MODE_CONV) {
+    if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return CX_ESHAPE;
+    if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) return CX_ESHAPE;
+    if (p.ldx < p.K) return CX_ESHAPE;
+    if (p.epilogue == CX_EPI_STORE) {
+      if (p.prologue == CX_PRO_NONE) return launch_bn<CX_PRO_NONE, CX_MODE_CONV, CX_EPI_STORE>(p, st);
+      if (p.prologue == CX_PRO_AFFINE_RELU) return launch_bn<CX_PRO_AFFINE_RELU, CX_MODE_CONV, CX_EPI_STORE>(p, st);
+      if (p.prologue == CX_PRO_AFFINE2) return launch_bn<CX_PRO_AFFINE2, CX_MODE_CONV, CX_EPI_STORE>(p, st);
+    } else if (p.epilogue == CX_EPI_MASK) {
+      if (p.prologue == CX_PRO_AFFINE2) return launch_bn<CX_PRO_AFFINE2, CX_MODE_CONV, CX_EPI_MASK>(p, st);
+      if (p.prologue == CX_PRO_NONE) return launch_bn<CX_PRO_NONE, CX_MODE_CONV, CX_EPI_MASK>(p, st);
+    }
+    return CX_EUNSUPPORTED;
+  }
+  if (p.mode == CX_MODE_POOL2) {
+    if (p.prologue != CX_PRO_AFFINE_RELU || p.epilogue != CX_EPI_STORE) return CX_EUNSUPPORTED;
+    if ((p.H & 1) || (p.W & 1) || p.Ho != p.H / 2 || p.Wo != p.W / 2 || p.ldx < p.K) return CX_ESHAPE;
+    return launch_bn<CX_PRO_AFFINE_RELU, CX_MODE_POOL2, CX_EPI_STORE>(p, st);
+  }
+  if (p.mode == CX_MODE_STEM) {
+    if (p.prologue != CX_PRO_NONE || p.epilogue != CX_EPI_STORE) return CX_EUNSUPPORTED;
+    if (p.K != 32 || (p.W & 1) || p.Ho != (p.H + 6 - 7) / 2 + 1 || p.Wo != (p.W + 6 - 7) / 2 + 1) return CX_ESHAPE;
+    return launch_bn<CX_PRO_NONE, CX_MODE_STEM, CX_EPI_STORE>(p, st);
+  }
+  return CX_EUNSUPPORTED;
+}

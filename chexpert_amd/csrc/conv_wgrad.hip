@@ -1,0 +1,323 @@
+// Weight gradient of the implicit-GEMM convolutions:
+//
+//   dW[n][c][tap] += sum_m G(m, n) * A(m @ tap, c)          (reduction over output pixels m)
+//
+// Both MFMA operands are contracted over the SLOW (pixel) axis of the NHWC tensors, so their
+// fragments are read from LDS with the gfx950 transposing read ds_read_b64_tr_b16
+// (cdna_hip_programming.md T10): tiles are staged [32 pixels][channels] exactly as they lie in
+// memory and every 16-lane group pulls a 4-pixel x 16-channel block transposed.  Row pitches are
+// chosen == 64 B (mod 256 B) so the four pixel rows of a half-wave fall on disjoint bank quarters.
+// G and A are produced by the same fused prologues as the forward kernel (BN backward as a
+// two-tensor affine form; BN scale/shift + ReLU (+2x2 average) recomputed from the raw buffer).
+// Each workgroup owns an (n-tile, c-tile, tap) and a contiguous pixel range; partial sums are added
+// to the fp32 OIHW gradient with global_atomic_add_f32 (consecutive lanes = consecutive c).
+#include "common.h"
+
+namespace {
+
+constexpr int PX = 32;   // pixels per step
+
+template <int BNW, int BCW>
+struct WGeo {
+  static constexpr int WAVES_N = (BNW >= 64) ? 2 : 1;
+  static constexpr int WAVES_C = (BCW / 32 < 4 / WAVES_N) ? BCW / 32 : 4 / WAVES_N;
+  static constexpr int WAVES_K = 4 / (WAVES_N * WAVES_C);     // leftover waves split the two k16 sub-steps
+  static constexpr int TN = BNW / (WAVES_N * 32);
+  static constexpr int TC = BCW / (WAVES_C * 32);
+  static constexpr int GP = (BNW == 32) ? 64 : BNW * 2 + 64;    // bytes; == 64 (mod 128) keeps rows on disjoint banks
+  static constexpr int XP = (BCW == 32) ? 64 : BCW * 2 + 64;
+  static constexpr int G_BYTES = PX * GP;
+  static constexpr int X_BYTES = PX * XP;
+  static constexpr int STAGE = G_BYTES + X_BYTES;
+  static constexpr int G_CHUNKS = PX * BNW / 8;
+  static constexpr int X_CHUNKS = PX * BCW / 8;
+  static constexpr int G_PER = (G_CHUNKS + 255) / 256;
+  static constexpr int X_PER = (X_CHUNKS + 255) / 256;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int k0, int ch0, int lane) {
+  // fragment of the 32x32x16 MFMA: this lane gets channel ch0 + (lane&31), pixels k0 + 8*(lane>>5) + 0..7
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const char* base = tile + (k0 + 8 * (g >> 1) + q) * pitch + (ch0 + 16 * (g & 1) + 4 * pp) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  U64 lo, hi;
+  lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+  hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch));
+  bf16x8 r;
+  r[0] = lo.e[0]; r[1] = lo.e[1]; r[2] = lo.e[2]; r[3] = lo.e[3];
+  r[4] = hi.e[0]; r[5] = hi.e[1]; r[6] = hi.e[2]; r[7] = hi.e[3];
+  return r;
+}
+
+template <int BNW, int BCW, int GPRO, int XPRO, int MODE>
+__global__ __launch_bounds__(256) void wgrad_kernel(const CxWgrad p, const int M, const int n_tiles, const int c_tiles,
+                                                    const int taps, const int splits, const int steps_per_split) {
+  using G = WGeo<BNW, BCW>;
+  constexpr int NSRC = (MODE == CX_MODE_POOL2) ? 4 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (G::WAVES_N * G::WAVES_C);
+  const int wn = (wave / G::WAVES_C) % G::WAVES_N, wc = wave % G::WAVES_C;
+
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id % splits;  id /= splits;
+  const int ct = id % c_tiles;    id /= c_tiles;
+  const int nt = id % n_tiles;    id /= n_tiles;
+  const int tap = id;
+  const int n0 = nt * BNW, c0 = ct * BCW;
+  const int dy = (MODE == CX_MODE_CONV) ? tap / p.kw : tap;
+  const int dx = (MODE == CX_MODE_CONV) ? tap - dy * p.kw : 0;
+
+  const bf16* __restrict__ Gp = reinterpret_cast<const bf16*>(p.g);
+  const bf16* __restrict__ G2 = reinterpret_cast<const bf16*>(p.g2);
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+
+  // per-thread chunk coordinates (fixed channel chunk per thread)
+  int grow[G::G_PER], gcq[G::G_PER], xrow[G::X_PER], xcq[G::X_PER];
+  float ga[G::G_PER][8], gb[G::G_PER][8], gc[G::G_PER][8], xa[G::X_PER][8], xb[G::X_PER][8];
+  bool gact[G::G_PER], xact[G::X_PER];
+#pragma unroll
+  for (int i = 0; i < G::G_PER; ++i) {
+    const int ci = tid + 256 * i;
+    gact[i] = ci < G::G_CHUNKS;
+    grow[i] = ci / (BNW / 8);
+    gcq[i] = ci % (BNW / 8);
+    const int n = n0 + gcq[i] * 8;
+    gact[i] = gact[i] && n < p.N;
+    if (GPRO == CX_PRO_AFFINE2 && gact[i]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ga[i][j] = p.ga[n + j]; gb[i][j] = p.gb[n + j]; gc[i][j] = p.gc[n + j]; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < G::X_PER; ++i) {
+    const int ci = tid + 256 * i;
+    xact[i] = ci < G::X_CHUNKS;
+    xrow[i] = ci / (BCW / 8);
+    xcq[i] = ci % (BCW / 8);
+    const int c = c0 + xcq[i] * 8;
+    xact[i] = xact[i] && c < ((MODE == CX_MODE_STEM) ? 32 : p.K);
+    if (XPRO == CX_PRO_AFFINE_RELU && xact[i]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { xa[i][j] = p.pa[c + j]; xb[i][j] = p.pb[c + j]; }
+    }
+  }
+
+  uint4 rg[G::G_PER], rg2[G::G_PER], rx[G::X_PER][NSRC];
+  bool gv[G::G_PER], xv[G::X_PER];
+  const int hw = p.Ho * p.Wo;
+  const int step0 = split * steps_per_split;
+  int nsteps = (M + PX - 1) / PX - step0;
+  if (nsteps > steps_per_split) nsteps = steps_per_split;
+
+  auto issue_loads = [&](int s) {
+    const int mbase = (step0 + s) * PX;
+#pragma unroll
+    for (int i = 0; i < G::G_PER; ++i) {
+      const int m = mbase + grow[i];
+      gv[i] = gact[i] && m < M;
+      if (gv[i]) {
+        rg[i] = *reinterpret_cast<const uint4*>(Gp + (size_t)m * p.ldg + n0 + gcq[i] * 8);
+        if (GPRO == CX_PRO_AFFINE2) rg2[i] = *reinterpret_cast<const uint4*>(G2 + (size_t)m * p.ldg2 + n0 + gcq[i] * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::X_PER; ++i) {
+      const int m = mbase + xrow[i];
+      xv[i] = xact[i] && m < M;
+      if (xv[i]) {
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        if (MODE == CX_MODE_STEM) {
+          const int iy = 2 * oy - 3 + dy, ix = 2 * ox - 4 + 2 * xcq[i];
+          xv[i] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          if (xv[i]) rx[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * p.H + iy) * p.W + ix) * 4);
+        } else if (MODE == CX_MODE_POOL2) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const size_t pix = (size_t)(b * p.H + 2 * oy + (a >> 1)) * p.W + 2 * ox + (a & 1);
+            rx[i][a] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + c0 + xcq[i] * 8);
+          }
+        } else {
+          const int iy = oy * p.stride - p.pad + dy, ix = ox * p.stride - p.pad + dx;
+          xv[i] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          if (xv[i]) rx[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * p.H + iy) * p.W + ix) * p.ldx + c0 + xcq[i] * 8);
+        }
+      }
+    }
+  };
+
+  auto write_stage = [&](int buf) {
+    char* Gt = smem + buf * G::STAGE;
+    char* Xt = Gt + G::G_BYTES;
+#pragma unroll
+    for (int i = 0; i < G::G_PER; ++i) {
+      if (tid + 256 * i < G::G_CHUNKS) {
+        U128 o;
+        if (!gv[i]) {
+          o.u = make_uint4(0, 0, 0, 0);
+        } else if (GPRO == CX_PRO_NONE) {
+          o.u = rg[i];
+        } else {
+          U128 u, v;
+          u.u = rg[i];
+          v.u = rg2[i];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), ga[i][j], fmaf(bf2f(v.e[j]), gb[i][j], gc[i][j])));
+        }
+        *reinterpret_cast<uint4*>(Gt + grow[i] * G::GP + gcq[i] * 16) = o.u;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::X_PER; ++i) {
+      if (tid + 256 * i < G::X_CHUNKS) {
+        U128 o;
+        if (!xv[i]) {
+          o.u = make_uint4(0, 0, 0, 0);
+        } else if (XPRO == CX_PRO_NONE) {
+          o.u = rx[i][0];
+        } else {
+          float acc[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+          for (int a = 0; a < NSRC; ++a) {
+            U128 v;
+            v.u = rx[i][a];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf(bf2f(v.e[j]), xa[i][j], xb[i][j]), 0.f);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(NSRC == 4 ? acc[j] * 0.25f : acc[j]);
+        }
+        *reinterpret_cast<uint4*>(Xt + xrow[i] * G::XP + xcq[i] * 16) = o.u;
+      }
+    }
+  };
+
+  f32x16 acc[G::TN][G::TC];
+#pragma unroll
+  for (int i = 0; i < G::TN; ++i)
+#pragma unroll
+    for (int j = 0; j < G::TC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nsteps > 0) {
+    issue_loads(0);
+    write_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nsteps) issue_loads(s + 1);
+      const char* Gt = smem + buf * G::STAGE;
+      const char* Xt = Gt + G::G_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (G::WAVES_K == 2 && kk != wk) continue;
+        bf16x8 af[G::TN], bfr[G::TC];
+#pragma unroll
+        for (int i = 0; i < G::TN; ++i) af[i] = tr_frag(Gt, G::GP, kk * 16, (wn * G::TN + i) * 32, lane);
+#pragma unroll
+        for (int j = 0; j < G::TC; ++j) bfr[j] = tr_frag(Xt, G::XP, kk * 16, (wc * G::TC + j) * 32, lane);
+#pragma unroll
+        for (int i = 0; i < G::TN; ++i)
+#pragma unroll
+          for (int j = 0; j < G::TC; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      if (s + 1 < nsteps) write_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- atomics into the OIHW gradient
+  const int lrow = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < G::TN; ++i)
+#pragma unroll
+    for (int j = 0; j < G::TC; ++j) {
+      const int c = c0 + (wc * G::TC + j) * 32 + lrow;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (wn * G::TN + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n >= p.N) continue;
+        if (MODE == CX_MODE_STEM) {
+          const int kx = (c >> 2) - 1, ch = c & 3;
+          if (c < 32 && kx >= 0 && ch < 3) atomicAdd(p.dw + ((size_t)(n * 3 + ch) * 7 + tap) * 7 + kx, acc[i][j][r]);
+        } else if (c < p.K) {
+          atomicAdd(p.dw + ((size_t)n * p.K + c) * taps + tap, acc[i][j][r]);
+        }
+      }
+    }
+}
+
+template <int BNW, int BCW, int GPRO, int XPRO, int MODE>
+int launch(const CxWgrad& p, hipStream_t st) {
+  using G = WGeo<BNW, BCW>;
+  const int M = p.B * p.Ho * p.Wo;
+  const int taps = (MODE == CX_MODE_STEM) ? 7 : p.kh * p.kw;
+  const int Kc = (MODE == CX_MODE_STEM) ? 32 : p.K;
+  const int n_tiles = (p.N + BNW - 1) / BNW, c_tiles = (Kc + BCW - 1) / BCW;
+  const int total_steps = (M + PX - 1) / PX;
+  int splits = p.splits;
+  if (splits <= 0) {
+    splits = 1024 / (n_tiles * c_tiles * taps);
+    if (splits < 1) splits = 1;
+  }
+  if (splits > total_steps) splits = total_steps;
+  const int sps = (total_steps + splits - 1) / splits;
+  splits = (total_steps + sps - 1) / sps;
+  const size_t smem = 2 * G::STAGE;
+  hipLaunchKernelGGL((wgrad_kernel<BNW, BCW, GPRO, XPRO, MODE>), dim3(n_tiles * c_tiles * taps * splits), dim3(256), smem,
+                     st, p, M, n_tiles, c_tiles, taps, splits, sps);
+  return launch_status();
+}
+
+template <int GPRO, int XPRO, int MODE>
+int launch_tile(const CxWgrad& p, hipStream_t st) {
+  if (MODE == CX_MODE_STEM) return launch<64, 32, GPRO, XPRO, MODE>(p, st);
+  if (p.N == 32) return launch<32, 128, GPRO, XPRO, MODE>(p, st);
+  if (p.N % 128 == 0) return launch<128, 64, GPRO, XPRO, MODE>(p, st);
+  return launch<64, 64, GPRO, XPRO, MODE>(p, st);
+}
+
+}  // namespace
+
+extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
+  if (!pp) return CX_EINVAL;
+  const CxWgrad& p = *pp;
+  if (!p.g || !p.x || !p.dw) return CX_EINVAL;
+  if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
+  if (p.K <= 0 || p.N <= 0 || (p.K % 32) || (p.N % 32)) return CX_ESHAPE;
+  if ((long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;
+  if ((p.ldg % 8) || (p.ldx % 8) || !aligned16(p.g) || !aligned16(p.x)) return CX_EALIGN;
+  if (p.g_prologue == CX_PRO_AFFINE2 && (!p.g2 || !p.ga || !p.gb || !p.gc || (p.ldg2 % 8) || !aligned16(p.g2))) return CX_EINVAL;
+  if (p.x_prologue == CX_PRO_AFFINE_RELU && (!p.pa || !p.pb)) return CX_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const bool g2 = p.g_prologue == CX_PRO_AFFINE2;
+  if (p.g_prologue != CX_PRO_NONE && !g2) return CX_EUNSUPPORTED;
+  if (p.mode == CX_MODE_CONV) {
+    if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return CX_ESHAPE;
+    if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) return CX_ESHAPE;
+    if (p.x_prologue == CX_PRO_AFFINE_RELU)
+      return g2 ? launch_tile<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU, CX_MODE_CONV>(p, st)
+                : launch_tile<CX_PRO_NONE, CX_PRO_AFFINE_RELU, CX_MODE_CONV>(p, st);
+    if (p.x_prologue == CX_PRO_NONE)
+      return g2 ? launch_tile<CX_PRO_AFFINE2, CX_PRO_NONE, CX_MODE_CONV>(p, st)
+                : launch_tile<CX_PRO_NONE, CX_PRO_NONE, CX_MODE_CONV>(p, st);
+    return CX_EUNSUPPORTED;
+  }
+  if (p.mode == CX_MODE_POOL2) {
+    if (p.x_prologue != CX_PRO_AFFINE_RELU) return CX_EUNSUPPORTED;
+    if ((p.H & 1) || (p.W & 1) || p.Ho != p.H / 2 || p.Wo != p.W / 2) return CX_ESHAPE;
+    return g2 ? launch_tile<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU, CX_MODE_POOL2>(p, st)
+              : launch_tile<CX_PRO_NONE, CX_PRO_AFFINE_RELU, CX_MODE_POOL2>(p, st);
+  }
+  if (p.mode == CX_MODE_STEM) {
+    if (p.x_prologue != CX_PRO_NONE || p.K != 32 || p.N != 64 || g2) return CX_EUNSUPPORTED;
+    return launch_tile<CX_PRO_NONE, CX_PRO_NONE, CX_MODE_STEM>(p, st);
+  }
+  return CX_EUNSUPPORTED;
+}

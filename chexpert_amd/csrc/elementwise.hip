@@ -1,0 +1,673 @@
+// HBM-bound glue kernels of the DenseNet hot path: layout conversion, weight packing, BatchNorm
+// coefficient bookkeeping, stem pooling, head, loss, un-pooling and the fused optimisers.
+// All activation traffic is 16 B per lane along the channel axis (NHWC bf16).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// per-channel statistic reduction shared by the elementwise kernels: each thread owns one 8-channel
+// chunk `cq` (constant over its grid-stride loop) and 2x8 partial sums.
+__device__ __forceinline__ void block_stats_flush(const float (&s1)[8], const float (&s2)[8], int cq, int C,
+                                                  float* lds, float* g1, float* g2) {
+  // lds: [2][C] zeroed by the caller before the main loop (followed by a barrier)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&lds[cq * 8 + j], s1[j]);
+    atomicAdd(&lds[C + cq * 8 + j], s2[j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(&g1[c], lds[c]);
+    atomicAdd(&g2[c], lds[C + c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, bf16* __restrict__ out, int O, int I, int kh, int kw,
+                                    int transpose, int stem) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (stem) {
+    const size_t total = (size_t)7 * O * 32;
+    if (idx >= total) return;
+    const int k = idx % 32, o = (idx / 32) % O, ky = idx / (32 * (size_t)O);
+    const int kx = (k >> 2) - 1, ch = k & 3;
+    float v = 0.f;
+    if (kx >= 0 && ch < 3) v = w[((size_t)(o * 3 + ch) * 7 + ky) * 7 + kx];
+    out[idx] = f2bf(v);
+    return;
+  }
+  const int taps = kh * kw;
+  const size_t total = (size_t)taps * O * I;
+  if (idx >= total) return;
+  if (!transpose) {                  // [tap][o][i]
+    const int i = idx % I, o = (idx / I) % O, tap = idx / ((size_t)I * O);
+    out[idx] = f2bf(w[((size_t)o * I + i) * taps + tap]);
+  } else {                           // [tap'][i][o], taps rotated by 180 degrees
+    const int o = idx % O, i = (idx / O) % I, tp = idx / ((size_t)I * O);
+    out[idx] = f2bf(w[((size_t)o * I + i) * taps + (taps - 1 - tp)]);
+  }
+}
+
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t hw, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t b = idx / hw, p = idx - b * hw;
+  const float* src = x + b * 3 * hw + p;
+  U64 o;
+  o.e[0] = f2bf(src[0]);
+  o.e[1] = f2bf(src[hw]);
+  o.e[2] = f2bf(src[2 * hw]);
+  o.e[3] = f2bf(0.f);
+  *reinterpret_cast<uint2*>(y + idx * 4) = o.u;
+}
+
+__global__ void bn_coef_kernel(const float* sum, const float* sq, float count, const float* gamma, const float* beta,
+                               float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
+                               float* mean, float* rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = (double)sum[c] / count;
+  double v = (double)sq[c] / count - m * m;
+  if (v < 0) v = 0;
+  const float r = (float)(1.0 / sqrt(v + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * r;
+  if (scale) scale[c] = sc;
+  if (shift) shift[c] = b - (float)m * sc;
+  if (mean) mean[c] = (float)m;
+  if (rstd) rstd[c] = r;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.f ? v * count / (count - 1.0) : v);
+}
+
+__global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const float* gamma, const float* beta,
+                                    float eps, float* scale, float* shift, float* mean, float* rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float r = 1.f / sqrtf(rvar[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  if (scale) scale[c] = g * r;
+  if (shift) shift[c] = b - rmean[c] * g * r;
+  if (mean) mean[c] = rmean[c];
+  if (rstd) rstd[c] = r;
+}
+
+__global__ void bn_bwd_coef_kernel(const float* S1, const float* S2, float count, const float* gamma, const float* mean,
+                                   const float* rstd, float* dgamma, float* dbeta, float* A, float* Bc, float* pa,
+                                   float* pb, float* pc, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s1 = S1[c], s2 = S2[c], g = gamma ? gamma[c] : 1.f, r = rstd[c], mu = mean[c];
+  if (dgamma) dgamma[c] += s2;
+  if (dbeta) dbeta[c] += s1;
+  const float inv = 1.f / count;
+  if (A) A[c] += r * g * s1 * inv;
+  if (Bc) Bc[c] += r * g * s2 * inv;
+  if (pa) {
+    pa[c] = g * r;
+    pb[c] = -g * r * r * s2 * inv;
+    pc[c] = g * r * (mu * r * s2 - s1) * inv;
+  }
+}
+
+__global__ void bn_bwd_slice_coef_kernel(const float* A, const float* Bc, const float* mean, const float* rstd,
+                                         float* pa, float* pb, float* pc, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rb = rstd[c] * Bc[c];
+  pa[c] = 1.f;
+  pb[c] = -rb;
+  pc[c] = mean[c] * rb - A[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: BN0 + ReLU + maxpool 3x3 s2 p1, arg-max recorded (uint8, window position 0..8)
+__global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ sc,
+                                                                 const float* __restrict__ sh, bf16* __restrict__ y,
+                                                                 uint8_t* __restrict__ amax, float* g1, float* g2, int B,
+                                                                 int H, int W, int C, int ldy) {
+  extern __shared__ float lds[];
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const int cq = threadIdx.x % CP;
+  float fsc[8], fsh[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; s1[j] = s2[j] = 0.f; }
+  const size_t npix = (size_t)B * Ho * Wo;
+  const size_t ppb = blockDim.x / CP;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int b = pix / ((size_t)Ho * Wo);
+    const int rem = pix - (size_t)b * Ho * Wo;
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -1.f; bi[j] = 0; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = 2 * oy - 1 + t / 3, ix = 2 * ox - 1 + t % 3;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      U128 v;
+      v.u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = fmaxf(fmaf(bf2f(v.e[j]), fsc[j], fsh[j]), 0.f);
+        if (a > best[j]) { best[j] = a; bi[j] = t; }
+      }
+    }
+    U128 o;
+    uint8_t idx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o.e[j] = f2bf(best[j]);
+      const float rv = bf2f(o.e[j]);
+      s1[j] += rv;
+      s2[j] += rv * rv;
+      idx[j] = (uint8_t)bi[j];
+    }
+    *reinterpret_cast<uint4*>(y + pix * ldy + cq * 8) = o.u;
+    *reinterpret_cast<uint2*>(amax + pix * C + cq * 8) = *reinterpret_cast<const uint2*>(idx);
+  }
+  if (g1) block_stats_flush(s1, s2, cq, C, lds, g1, g2);
+}
+
+__global__ __launch_bounds__(256) void bnrelu_maxpool_bwd_kernel(
+    const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const uint8_t* __restrict__ amax, const bf16* __restrict__ g, const bf16* __restrict__ gx,
+    const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc, bf16* __restrict__ dz, float* S1,
+    float* S2, int B, int H, int W, int C, int ldg, int ldgx) {
+  extern __shared__ float lds[];
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const int cq = threadIdx.x % CP;
+  float fsc[8], fsh[8], fmu[8], fr[8], fa[8], fb[8], fc[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cq * 8 + j;
+    fsc[j] = sc[c]; fsh[j] = sh[c]; fmu[j] = mean[c]; fr[j] = rstd[c];
+    fa[j] = ga[c]; fb[j] = gb[c]; fc[j] = gc[c];
+    s1[j] = s2[j] = 0.f;
+  }
+  const size_t npix = (size_t)B * H * W;
+  const size_t ppb = blockDim.x / CP;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int b = pix / ((size_t)H * W);
+    const int rem = pix - (size_t)b * H * W;
+    const int iy = rem / W, ix = rem - iy * W;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // windows (oy,ox) containing (iy,ix): 2*oy-1 <= iy <= 2*oy+1
+    const int oy_lo = (iy + 0) / 2, oy_hi = (iy + 1) / 2;      // iy even: {iy/2}; odd: {(iy-1)/2... (iy+1)/2}
+    const int ox_lo = (ix + 0) / 2, ox_hi = (ix + 1) / 2;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (oy >= Ho) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (ox >= Wo) continue;
+        const int t = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+        const size_t op = ((size_t)b * Ho + oy) * Wo + ox;
+        const uint2 iv = *reinterpret_cast<const uint2*>(amax + op * C + cq * 8);
+        const uint8_t* idx = reinterpret_cast<const uint8_t*>(&iv);
+        U128 gv, xv;
+        gv.u = *reinterpret_cast<const uint4*>(g + op * ldg + cq * 8);
+        xv.u = *reinterpret_cast<const uint4*>(gx + op * ldgx + cq * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (idx[j] == t) acc[j] += fmaf(bf2f(gv.e[j]), fa[j], fmaf(bf2f(xv.e[j]), fb[j], fc[j]));
+      }
+    }
+    U128 xin, o;
+    xin.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = bf2f(xin.e[j]);
+      const float d = (fmaf(xf, fsc[j], fsh[j]) > 0.f) ? acc[j] : 0.f;
+      s1[j] += d;
+      s2[j] += d * (xf - fmu[j]) * fr[j];
+      o.e[j] = f2bf(d);
+    }
+    *reinterpret_cast<uint4*>(dz + pix * C + cq * 8) = o.u;
+  }
+  block_stats_flush(s1, s2, cq, C, lds, S1, S2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// head
+__global__ void gap_bnrelu_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                  float* __restrict__ pooled, int B, int HW, int C, int ldx) {
+  const int CP = C / 8;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * CP) return;
+  const int b = idx / CP, cq = idx % CP;
+  float fsc[8], fsh[8], acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; acc[j] = 0.f; }
+  for (int p = 0; p < HW; ++p) {
+    U128 v;
+    v.u = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * ldx + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf(bf2f(v.e[j]), fsc[j], fsh[j]), 0.f);
+  }
+  const float inv = 1.f / HW;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pooled[(size_t)b * C + cq * 8 + j] = acc[j] * inv;
+}
+
+__global__ void linear_kernel(const float* __restrict__ pooled, const float* __restrict__ w, const float* __restrict__ bias,
+                              float* __restrict__ logits, int C, int n_classes) {
+  // one block per batch element; wave w handles classes w, w+4, ...
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < n_classes; k += blockDim.x / 64) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += pooled[(size_t)b * C + c] * w[(size_t)k * C + c];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) logits[(size_t)b * n_classes + k] = acc + (bias ? bias[k] : 0.f);
+  }
+}
+
+__global__ void bce_kernel(const float* __restrict__ logits, const float* __restrict__ target, float* loss, float* loss_elem,
+                           float* dlogits, float grad_scale, int B, int n) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  const float invB = 1.f / B;
+  for (int i = threadIdx.x; i < B * n; i += blockDim.x) {
+    const float x = logits[i], t = target[i];
+    const float l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    acc += l;
+    if (loss_elem) loss_elem[i] = l;
+    if (dlogits) dlogits[i] = (1.f / (1.f + expf(-x)) - t) * invB * grad_scale;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss) *loss = red[0] * invB;
+}
+
+__global__ void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ pooled, const float* __restrict__ w,
+                                float* dw, float* db, float* __restrict__ dpooled, int B, int C, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    for (int k = 0; k < n; ++k) {
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) acc += dlogits[b * n + k] * pooled[(size_t)b * C + c];
+      dw[(size_t)k * C + c] += acc;
+    }
+    for (int b = 0; b < B; ++b) {
+      float acc = 0.f;
+      for (int k = 0; k < n; ++k) acc += dlogits[b * n + k] * w[(size_t)k * C + c];
+      dpooled[(size_t)b * C + c] = acc;
+    }
+  }
+  if (c < n && db) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += dlogits[b * n + c];
+    db[c] += acc;
+  }
+}
+
+__global__ void gap_relu_bn_bwd_kernel(const float* __restrict__ dpooled, const bf16* __restrict__ x, const float* __restrict__ sc,
+                                       const float* __restrict__ sh, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       const float* __restrict__ escale, bf16* __restrict__ g, float* S1, float* S2, int B, int HW,
+                                       int C, int ldx, int ldg) {
+  const int CP = C / 8;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * CP) return;
+  const int b = idx / CP, cq = idx % CP;
+  float fsc[8], fsh[8], fmu[8], fr[8], fe[8], dp[8], s1[8], s2[8];
+  const float inv = 1.f / HW;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cq * 8 + j;
+    fsc[j] = sc[c]; fsh[j] = sh[c]; fmu[j] = mean[c]; fr[j] = rstd[c]; fe[j] = escale[c];
+    dp[j] = dpooled[(size_t)b * C + c] * inv;
+    s1[j] = s2[j] = 0.f;
+  }
+  for (int p = 0; p < HW; ++p) {
+    U128 v, o;
+    v.u = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * ldx + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = bf2f(v.e[j]);
+      const float d = (fmaf(xf, fsc[j], fsh[j]) > 0.f) ? dp[j] : 0.f;
+      s1[j] += d;
+      s2[j] += d * (xf - fmu[j]) * fr[j];
+      o.e[j] = f2bf(fe[j] * d);
+    }
+    *reinterpret_cast<uint4*>(g + ((size_t)b * HW + p) * ldg + cq * 8) = o.u;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&S1[cq * 8 + j], s1[j]);
+    atomicAdd(&S2[cq * 8 + j], s2[j]);
+  }
+}
+
+// transition backward glue: un-pool + ReLU/BN mask
+__global__ __launch_bounds__(256) void unpool2_mask_kernel(const bf16* __restrict__ d, const bf16* __restrict__ x,
+                                                           const float* __restrict__ sc, const float* __restrict__ sh,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ escale, bf16* __restrict__ g, float* S1,
+                                                           float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg) {
+  extern __shared__ float lds[];
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CP;
+  float fsc[8], fsh[8], fmu[8], fr[8], fe[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cq * 8 + j;
+    fsc[j] = sc[c]; fsh[j] = sh[c]; fmu[j] = mean[c]; fr[j] = rstd[c]; fe[j] = escale[c];
+    s1[j] = s2[j] = 0.f;
+  }
+  const size_t npix = (size_t)B * H * W;
+  const size_t ppb = blockDim.x / CP;
+  const int Ho = H / 2, Wo = W / 2;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int b = pix / ((size_t)H * W);
+    const int rem = pix - (size_t)b * H * W;
+    const int iy = rem / W, ix = rem - iy * W;
+    const size_t op = ((size_t)b * Ho + (iy >> 1)) * Wo + (ix >> 1);
+    U128 dv, xv, o;
+    dv.u = *reinterpret_cast<const uint4*>(d + op * ldd + cq * 8);
+    xv.u = *reinterpret_cast<const uint4*>(x + pix * ldx + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = bf2f(xv.e[j]);
+      const float dzv = (fmaf(xf, fsc[j], fsh[j]) > 0.f) ? 0.25f * bf2f(dv.e[j]) : 0.f;
+      s1[j] += dzv;
+      s2[j] += dzv * (xf - fmu[j]) * fr[j];
+      o.e[j] = f2bf(fe[j] * dzv);
+    }
+    *reinterpret_cast<uint4*>(g + pix * ldg + cq * 8) = o.u;
+  }
+  block_stats_flush(s1, s2, cq, C, lds, S1, S2);
+}
+
+__global__ void affine2_inplace_kernel(bf16* __restrict__ dz, const bf16* __restrict__ x, const float* __restrict__ pa,
+                                       const float* __restrict__ pb, const float* __restrict__ pc, size_t rows, int C) {
+  const int CP = C / 8;
+  const size_t total = rows * CP;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cq = idx % CP;
+    U128 u, v, o;
+    u.u = *reinterpret_cast<const uint4*>(dz + idx * 8);
+    v.u = *reinterpret_cast<const uint4*>(x + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cq * 8 + j;
+      o.e[j] = f2bf(fmaf(bf2f(u.e[j]), pa[c], fmaf(bf2f(v.e[j]), pb[c], pc[c])));
+    }
+    *reinterpret_cast<uint4*>(dz + idx * 8) = o.u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimisers (flat fp32 buffers)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                            float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+__global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n,
+                                    float lr, float mom, float wd, int first, float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float bi = first ? gi : mom * buf[i] + gi;
+    buf[i] = bi;
+    p[i] = pi - lr * (gi + mom * bi);
+  }
+}
+
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ buf,
+                               size_t n, float lr, float alpha, float eps, float mom, float wd, float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float si = alpha * sq[i] + (1.f - alpha) * gi * gi;
+    sq[i] = si;
+    const float avg = sqrtf(si) + eps;
+    if (mom > 0.f) {
+      const float bi = mom * buf[i] + gi / avg;
+      buf[i] = bi;
+      p[i] = pi - lr * bi;
+    } else {
+      p[i] = pi - lr * gi / avg;
+    }
+  }
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void bf16_to_f32_nchw_kernel(const bf16* __restrict__ x, float* __restrict__ y, int HW, int C, int ldx, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // over (b, c, p) output order
+  if (idx >= total) return;
+  const int p = idx % HW;
+  const int c = (idx / HW) % C;
+  const size_t b = idx / ((size_t)HW * C);
+  y[idx] = bf2f(x[(b * HW + p) * ldx + c]);
+}
+
+inline int grid_for(size_t n, int block, int cap = 4096) {
+  size_t g = (n + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cx_abi_version(void) { return CX_ABI_VERSION; }
+
+const char* cx_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case CX_EINVAL: return "invalid argument (null pointer or inconsistent options)";
+    case CX_EALIGN: return "pointer or pitch not 16-byte aligned";
+    case CX_ESHAPE: return "unsupported shape";
+    case CX_EUNSUPPORTED: return "unsupported prologue/epilogue/mode combination";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown";
+  }
+}
+
+int cx_pack_weights(const float* w, void* packed, int O, int I, int kh, int kw, int transpose, int stem, void* stream) {
+  if (!w || !packed || O <= 0 || I <= 0) return CX_EINVAL;
+  if (stem && (I != 3 || kh != 7 || kw != 7)) return CX_ESHAPE;
+  const size_t total = stem ? (size_t)7 * O * 32 : (size_t)kh * kw * O * I;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), w, (bf16*)packed, O, I, kh,
+                     kw, transpose, stem);
+  return launch_status();
+}
+
+int cx_nchw3_to_nhwc4(const float* x, void* y, int B, int H, int W, void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0) return CX_EINVAL;
+  const size_t hw = (size_t)H * W, total = hw * B;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y, hw, total);
+  return launch_status();
+}
+
+int cx_bn_coef(const float* sum, const float* sq, float count, const float* gamma, const float* beta, float eps, float momentum,
+               float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd, int C,
+               void* stream) {
+  if (!sum || !sq || C <= 0 || count <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(bn_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sum, sq, count, gamma, beta, eps,
+                     momentum, running_mean, running_var, scale, shift, mean, rstd, C);
+  return launch_status();
+}
+
+int cx_bn_coef_eval(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, float* scale,
+                    float* shift, float* mean, float* rstd, int C, void* stream) {
+  if (!rm || !rv || C <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(bn_coef_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), rm, rv, gamma, beta, eps,
+                     scale, shift, mean, rstd, C);
+  return launch_status();
+}
+
+int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* gamma, const float* mean, const float* rstd,
+                   float* dgamma, float* dbeta, float* A, float* Bc, float* pa, float* pb, float* pc, int C, void* stream) {
+  if (!S1 || !S2 || !mean || !rstd || C <= 0 || count <= 0) return CX_EINVAL;
+  if (pa && (!pb || !pc)) return CX_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), S1, S2, count, gamma, mean,
+                     rstd, dgamma, dbeta, A, Bc, pa, pb, pc, C);
+  return launch_status();
+}
+
+int cx_bn_bwd_slice_coef(const float* A, const float* Bc, const float* mean, const float* rstd, float* pa, float* pb, float* pc,
+                         int C, void* stream) {
+  if (!A || !Bc || !mean || !rstd || !pa || !pb || !pc || C <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_slice_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), A, Bc, mean, rstd, pa, pb,
+                     pc, C);
+  return launch_status();
+}
+
+int cx_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax, float* stat_sum,
+                          float* stat_sq, int B, int H, int W, int C, int ldy, void* stream) {
+  if (!x || !scale || !shift || !y || !argmax) return CX_EINVAL;
+  if (C % 8 || C > 256 || 256 % (C / 8) || (H & 1) || (W & 1) || (ldy % 8)) return CX_ESHAPE;
+  const size_t npix = (size_t)B * (H / 2) * (W / 2);
+  const int ppb = 256 / (C / 8);
+  hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel, dim3(grid_for(npix, ppb, 2048)), dim3(256), 2 * C * sizeof(float), as_stream(stream),
+                     (const bf16*)x, scale, shift, (bf16*)y, argmax, stat_sum, stat_sq, B, H, W, C, ldy);
+  return launch_status();
+}
+
+int cx_bnrelu_maxpool_bwd(const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                          const uint8_t* argmax, const void* g, const void* gx, const float* ga, const float* gb, const float* gc,
+                          void* dz, float* S1, float* S2, int B, int H, int W, int C, int ldg, int ldgx, void* stream) {
+  if (!x || !scale || !shift || !mean || !rstd || !argmax || !g || !gx || !ga || !gb || !gc || !dz || !S1 || !S2) return CX_EINVAL;
+  if (C % 8 || C > 256 || 256 % (C / 8) || (H & 1) || (W & 1) || (ldg % 8) || (ldgx % 8)) return CX_ESHAPE;
+  const size_t npix = (size_t)B * H * W;
+  const int ppb = 256 / (C / 8);
+  hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel, dim3(grid_for(npix, ppb, 2048)), dim3(256), 2 * C * sizeof(float), as_stream(stream),
+                     (const bf16*)x, scale, shift, mean, rstd, argmax, (const bf16*)g, (const bf16*)gx, ga, gb, gc, (bf16*)dz, S1,
+                     S2, B, H, W, C, ldg, ldgx);
+  return launch_status();
+}
+
+int cx_head_fwd(const void* x, const float* scale, const float* shift, const float* w, const float* bias, float* pooled,
+                float* logits, int B, int HW, int C, int ldx, int n_classes, void* stream) {
+  if (!x || !scale || !shift || !w || !pooled || !logits) return CX_EINVAL;
+  if (C % 8 || ldx % 8 || n_classes <= 0) return CX_ESHAPE;
+  const size_t n = (size_t)B * (C / 8);
+  hipLaunchKernelGGL(gap_bnrelu_kernel, dim3((n + 127) / 128), dim3(128), 0, as_stream(stream), (const bf16*)x, scale, shift, pooled,
+                     B, HW, C, ldx);
+  hipLaunchKernelGGL(linear_kernel, dim3(B), dim3(256), 0, as_stream(stream), pooled, w, bias, logits, C, n_classes);
+  return launch_status();
+}
+
+int cx_bce_fwd_bwd(const float* logits, const float* target, float* loss, float* loss_elem, float* dlogits, float grad_scale,
+                   int B, int n_classes, void* stream) {
+  if (!logits || !target || B <= 0 || n_classes <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, target, loss, loss_elem, dlogits, grad_scale, B,
+                     n_classes);
+  return launch_status();
+}
+
+int cx_head_bwd(const float* dlogits, const float* pooled, const float* w, float* dw, float* db, float* dpooled, int B, int C,
+                int n_classes, void* stream) {
+  if (!dlogits || !pooled || !w || !dw || !dpooled) return CX_EINVAL;
+  if (n_classes > C) return CX_ESHAPE;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), dlogits, pooled, w, dw, db, dpooled, B, C,
+                     n_classes);
+  return launch_status();
+}
+
+int cx_gap_relu_bn_bwd(const float* dpooled, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int HW, int C, int ldx,
+                       int ldg, void* stream) {
+  if (!dpooled || !x || !scale || !shift || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
+  if (C % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
+  const size_t n = (size_t)B * (C / 8);
+  hipLaunchKernelGGL(gap_relu_bn_bwd_kernel, dim3((n + 127) / 128), dim3(128), 0, as_stream(stream), dpooled, (const bf16*)x, scale,
+                     shift, mean, rstd, e_scale, (bf16*)g, S1, S2, B, HW, C, ldx, ldg);
+  return launch_status();
+}
+
+int cx_unpool2_mask(const void* d, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd,
+                    const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg,
+                    void* stream) {
+  if (!d || !x || !sc || !sh || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
+  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || (H & 1) || (W & 1) || ldd % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
+  if (C / 8 > 256) return CX_ESHAPE;
+  const size_t npix = (size_t)B * H * W;
+  const int ppb = 256 / (C / 8);
+  hipLaunchKernelGGL(unpool2_mask_kernel, dim3(grid_for(npix, ppb, 2048)), dim3(256), 2 * C * sizeof(float), as_stream(stream),
+                     (const bf16*)d, (const bf16*)x, sc, sh, mean, rstd, e_scale, (bf16*)g, S1, S2, B, H, W, C, ldd, ldx, ldg);
+  return launch_status();
+}
+
+int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb, const float* pc, size_t rows, int C, void* stream) {
+  if (!dz || !x || !pa || !pb || !pc || C % 8) return CX_EINVAL;
+  hipLaunchKernelGGL(affine2_inplace_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (bf16*)dz,
+                     (const bf16*)x, pa, pb, pc, rows, C);
+  return launch_status();
+}
+
+int cx_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || step < 1) return CX_EINVAL;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2s, grad_scale);
+  return launch_status();
+}
+
+int cx_sgd_nesterov_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
+                         int first_step, float grad_scale, void* stream) {
+  if (!p || !g || !buf) return CX_EINVAL;
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, g, buf, n, lr, momentum,
+                     weight_decay, first_step, grad_scale);
+  return launch_status();
+}
+
+int cx_rmsprop_step(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha, float eps, float momentum,
+                    float weight_decay, float grad_scale, void* stream) {
+  if (!p || !g || !sq || (momentum > 0.f && !buf)) return CX_EINVAL;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, g, sq, buf, n, lr, alpha, eps,
+                     momentum, weight_decay, grad_scale);
+  return launch_status();
+}
+
+int cx_fill_f32(float* p, float v, size_t n, void* stream) {
+  if (!p) return CX_EINVAL;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, v, n);
+  return launch_status();
+}
+
+int cx_bf16_to_f32_nchw(const void* x, float* y, int B, int H, int W, int C, int ldx, void* stream) {
+  if (!x || !y) return CX_EINVAL;
+  const size_t total = (size_t)B * H * W * C;
+  hipLaunchKernelGGL(bf16_to_f32_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), (const bf16*)x, y, H * W, C,
+                     ldx, total);
+  return launch_status();
+}
+
+}  // extern "C"

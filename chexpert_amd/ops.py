@@ -1,0 +1,188 @@
+"""Thin tensor-level wrappers over the C ABI (one call = one kernel launch on the current stream).
+
+Tensors: activations are torch.bfloat16 NHWC views (B,H,W,C) whose channel pitch may exceed C (a
+slice of a dense-block buffer); statistics / coefficient vectors / parameter gradients are fp32.
+"""
+import torch
+
+from . import _lib as L
+from ._lib import (EPI_MASK, EPI_STORE, MODE_CONV, MODE_POOL2, MODE_STEM, PRO_AFFINE2, PRO_AFFINE_RELU, PRO_NONE,
+                   CxConv, CxWgrad, check, lib, ptr, require_cuda, stream_ptr)
+import ctypes as C
+
+
+def _nhwc(t):
+    """(B,H,W,C) view -> (B,H,W,C,pitch)."""
+    assert t.dtype == torch.bfloat16 and t.dim() == 4, "expected a bf16 NHWC tensor"
+    B, H, W, Cc = t.shape
+    sb, sh, sw, sc = t.stride()
+    assert sc == 1 and sh == W * sw and sb == H * sh, "NHWC slice must be dense in (B,H,W) with a channel pitch"
+    return B, H, W, Cc, sw
+
+
+def conv_gemm(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
+              pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
+              e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None):
+    require_cuda(x, w_packed, y)
+    p = CxConv()
+    B, H, W, Cx, ldx = _nhwc(x)
+    By, Ho, Wo, Cy, ldy = _nhwc(y)
+    assert By == B and Cy == N
+    p.x, p.w, p.y = ptr(x), ptr(w_packed), ptr(y)
+    p.B, p.H, p.W, p.Ho, p.Wo = B, H, W, Ho, Wo
+    p.K = (32 if mode == MODE_STEM else Cx) if K is None else K
+    p.N = N
+    p.ldx, p.ldy = ldx, ldy
+    p.kh, p.kw, p.stride, p.pad = kh, kw, stride, pad
+    p.prologue, p.mode, p.epilogue, p.accumulate = prologue, mode, epilogue, int(accumulate)
+    p.pa, p.pb, p.pc = ptr(pa), ptr(pb), ptr(pc)
+    if x2 is not None:
+        assert x2.shape == x.shape
+        p.x2, p.ldx2 = ptr(x2), _nhwc(x2)[4]
+    p.stat_sum, p.stat_sq = ptr(stat_sum), ptr(stat_sq)
+    if ex is not None:
+        assert ex.shape == y.shape
+        p.ex, p.ldex = ptr(ex), _nhwc(ex)[4]
+    p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale = ptr(e_sc), ptr(e_sh), ptr(e_mu), ptr(e_r), ptr(e_scale)
+    check(lib().cx_conv_gemm(C.byref(p), stream_ptr()), "cx_conv_gemm")
+
+
+def conv_wgrad(g, x, dw, *, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, g_prologue=PRO_NONE, g2=None, ga=None, gb=None,
+               gc=None, x_prologue=PRO_NONE, pa=None, pb=None, splits=0, K=None):
+    require_cuda(g, x, dw)
+    p = CxWgrad()
+    B, Ho, Wo, N, ldg = _nhwc(g)
+    Bx, H, W, Cx, ldx = _nhwc(x)
+    assert Bx == B and dw.dtype == torch.float32 and dw.is_contiguous()
+    p.g, p.x, p.dw = ptr(g), ptr(x), ptr(dw)
+    p.B, p.H, p.W, p.Ho, p.Wo = B, H, W, Ho, Wo
+    p.K = (32 if mode == MODE_STEM else Cx) if K is None else K
+    p.N = N
+    p.ldg, p.ldx = ldg, ldx
+    if g2 is not None:
+        assert g2.shape == g.shape
+        p.g2, p.ldg2 = ptr(g2), _nhwc(g2)[4]
+    p.ga, p.gb, p.gc, p.pa, p.pb = ptr(ga), ptr(gb), ptr(gc), ptr(pa), ptr(pb)
+    p.kh, p.kw, p.stride, p.pad = kh, kw, stride, pad
+    p.g_prologue, p.x_prologue, p.mode, p.splits = g_prologue, x_prologue, mode, splits
+    check(lib().cx_conv_wgrad(C.byref(p), stream_ptr()), "cx_conv_wgrad")
+
+
+def pack_weights(w, transpose=False, stem=False, out=None):
+    """OIHW fp32 -> packed bf16 (see cx_pack_weights)."""
+    require_cuda(w)
+    O, I, kh, kw = w.shape
+    n = 7 * O * 32 if stem else kh * kw * O * I
+    if out is None:
+        out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    assert w.is_contiguous() and w.dtype == torch.float32 and out.numel() >= n
+    check(lib().cx_pack_weights(ptr(w), ptr(out), O, I, kh, kw, int(transpose), int(stem), stream_ptr()), "cx_pack_weights")
+    return out
+
+
+def nchw3_to_nhwc4(x, out=None):
+    require_cuda(x)
+    B, Cc, H, W = x.shape
+    assert Cc == 3 and x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.empty(B, H, W, 4, dtype=torch.bfloat16, device=x.device)
+    check(lib().cx_nchw3_to_nhwc4(ptr(x), ptr(out), B, H, W, stream_ptr()), "cx_nchw3_to_nhwc4")
+    return out
+
+
+def bn_coef(s, q, count, gamma, beta, eps, momentum, rmean, rvar, scale, shift, mean, rstd, Cn=None):
+    Cn = Cn if Cn is not None else s.numel()
+    check(lib().cx_bn_coef(ptr(s), ptr(q), float(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),
+                           ptr(scale), ptr(shift), ptr(mean), ptr(rstd), Cn, stream_ptr()), "cx_bn_coef")
+
+
+def bn_coef_eval(rmean, rvar, gamma, beta, eps, scale, shift, mean, rstd, Cn=None):
+    Cn = Cn if Cn is not None else rmean.numel()
+    check(lib().cx_bn_coef_eval(ptr(rmean), ptr(rvar), ptr(gamma), ptr(beta), eps, ptr(scale), ptr(shift), ptr(mean),
+                                ptr(rstd), Cn, stream_ptr()), "cx_bn_coef_eval")
+
+
+def bn_bwd_coef(S1, S2, count, gamma, mean, rstd, dgamma, dbeta, A, Bc, pa, pb, pc, Cn):
+    check(lib().cx_bn_bwd_coef(ptr(S1), ptr(S2), float(count), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta),
+                               ptr(A), ptr(Bc), ptr(pa), ptr(pb), ptr(pc), Cn, stream_ptr()), "cx_bn_bwd_coef")
+
+
+def bn_bwd_slice_coef(A, Bc, mean, rstd, pa, pb, pc, Cn):
+    check(lib().cx_bn_bwd_slice_coef(ptr(A), ptr(Bc), ptr(mean), ptr(rstd), ptr(pa), ptr(pb), ptr(pc), Cn, stream_ptr()),
+          "cx_bn_bwd_slice_coef")
+
+
+def bnrelu_maxpool_fwd(x, scale, shift, y, argmax, stat_sum, stat_sq):
+    B, H, W, Cc, ldx = _nhwc(x)
+    assert ldx == Cc
+    ldy = _nhwc(y)[4]
+    check(lib().cx_bnrelu_maxpool_fwd(ptr(x), ptr(scale), ptr(shift), ptr(y), ptr(argmax), ptr(stat_sum), ptr(stat_sq),
+                                      B, H, W, Cc, ldy, stream_ptr()), "cx_bnrelu_maxpool_fwd")
+
+
+def bnrelu_maxpool_bwd(x, scale, shift, mean, rstd, argmax, g, gx, ga, gb, gc, dz, S1, S2):
+    B, H, W, Cc, ldx = _nhwc(x)
+    assert ldx == Cc and _nhwc(dz)[4] == Cc
+    check(lib().cx_bnrelu_maxpool_bwd(ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(argmax), ptr(g), ptr(gx),
+                                      ptr(ga), ptr(gb), ptr(gc), ptr(dz), ptr(S1), ptr(S2), B, H, W, Cc, _nhwc(g)[4],
+                                      _nhwc(gx)[4], stream_ptr()), "cx_bnrelu_maxpool_bwd")
+
+
+def head_fwd(x, scale, shift, w, bias, pooled, logits):
+    B, H, W, Cc, ldx = _nhwc(x)
+    check(lib().cx_head_fwd(ptr(x), ptr(scale), ptr(shift), ptr(w), ptr(bias), ptr(pooled), ptr(logits), B, H * W, Cc, ldx,
+                            logits.shape[1], stream_ptr()), "cx_head_fwd")
+
+
+def bce_fwd_bwd(logits, target, loss, loss_elem, dlogits, grad_scale=1.0):
+    B, n = logits.shape
+    check(lib().cx_bce_fwd_bwd(ptr(logits), ptr(target), ptr(loss), ptr(loss_elem), ptr(dlogits), grad_scale, B, n,
+                               stream_ptr()), "cx_bce_fwd_bwd")
+
+
+def head_bwd(dlogits, pooled, w, dw, db, dpooled):
+    B, n = dlogits.shape
+    check(lib().cx_head_bwd(ptr(dlogits), ptr(pooled), ptr(w), ptr(dw), ptr(db), ptr(dpooled), B, pooled.shape[1], n,
+                            stream_ptr()), "cx_head_bwd")
+
+
+def gap_relu_bn_bwd(dpooled, x, scale, shift, mean, rstd, e_scale, g, S1, S2):
+    B, H, W, Cc, ldx = _nhwc(x)
+    check(lib().cx_gap_relu_bn_bwd(ptr(dpooled), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(e_scale), ptr(g),
+                                   ptr(S1), ptr(S2), B, H * W, Cc, ldx, _nhwc(g)[4], stream_ptr()), "cx_gap_relu_bn_bwd")
+
+
+def unpool2_mask(d, x, sc, sh, mean, rstd, e_scale, g, S1, S2):
+    B, H, W, Cc, ldx = _nhwc(x)
+    check(lib().cx_unpool2_mask(ptr(d), ptr(x), ptr(sc), ptr(sh), ptr(mean), ptr(rstd), ptr(e_scale), ptr(g), ptr(S1), ptr(S2),
+                                B, H, W, Cc, _nhwc(d)[4], ldx, _nhwc(g)[4], stream_ptr()), "cx_unpool2_mask")
+
+
+def affine2_inplace(dz, x, pa, pb, pc):
+    B, H, W, Cc, ld = _nhwc(dz)
+    assert ld == Cc and _nhwc(x)[4] == Cc
+    check(lib().cx_affine2_inplace(ptr(dz), ptr(x), ptr(pa), ptr(pb), ptr(pc), B * H * W, Cc, stream_ptr()),
+          "cx_affine2_inplace")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    check(lib().cx_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                             stream_ptr()), "cx_adam_step")
+
+
+def sgd_nesterov_step(p, g, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0):
+    check(lib().cx_sgd_nesterov_step(ptr(p), ptr(g), ptr(buf), p.numel(), lr, momentum, weight_decay, int(first_step),
+                                     grad_scale, stream_ptr()), "cx_sgd_nesterov_step")
+
+
+def rmsprop_step(p, g, sq, buf, lr, alpha, eps, momentum, weight_decay, grad_scale=1.0):
+    check(lib().cx_rmsprop_step(ptr(p), ptr(g), ptr(sq), ptr(buf), p.numel(), lr, alpha, eps, momentum, weight_decay,
+                                grad_scale, stream_ptr()), "cx_rmsprop_step")
+
+
+def bf16_to_f32_nchw(x, out=None):
+    B, H, W, Cc, ldx = _nhwc(x)
+    if out is None:
+        out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    check(lib().cx_bf16_to_f32_nchw(ptr(x), ptr(out), B, H, W, Cc, ldx, stream_ptr()), "cx_bf16_to_f32_nchw")
+    return out

@@ -1,0 +1,186 @@
+/*
+ * chexpert_hip.h -- C ABI of libchexpert_hip.so (gfx950 / MI355X).
+ *
+ * The reference (kamenbliznashki/chexpert) has no FFI layer: its hot path is the implicit ATen/cuDNN
+ * work behind `model(x)`, `loss.backward()` and `optimizer.step()` (chexpert.py:159-164, :204).  This
+ * library is what a maintainer binds INSTEAD of those ATen ops (see INTEGRATION.md for the ctypes
+ * stub).  Each entry point cites the reference statement whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer owned by the caller
+ *     (no ownership transfer, no allocation inside the library);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - returns 0 on success, a positive hipError_t from the launch, or a negative CX_E* validation
+ *     code; nothing is launched when validation fails;
+ *   - activations are NHWC bf16 with an explicit channel pitch (`ld*`, in elements) so a kernel can
+ *     read / write a channel slice of a wider dense-block buffer (the reference's torch.cat,
+ *     torchvision _DenseLayer.forward, is never materialised);
+ *   - statistics, coefficient vectors and gradients of parameters are fp32.
+ */
+#ifndef CHEXPERT_HIP_H
+#define CHEXPERT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CX_ABI_VERSION 1
+
+enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4 };
+
+/* A-operand prologues of the implicit GEMM (fused normalisation, never stored) */
+enum {
+  CX_PRO_NONE = 0,         /* a = x                                                              */
+  CX_PRO_AFFINE_RELU = 1,  /* a = relu(x*pa[c] + pb[c])          BN/IN (scale,shift) + ReLU       */
+  CX_PRO_AFFINE2 = 2       /* a = x*pa[c] + x2*pb[c] + pc[c]     BN backward / deferred correction */
+};
+/* addressing modes */
+enum {
+  CX_MODE_CONV = 0,   /* kh x kw taps, stride, zero padding (applied after the prologue)          */
+  CX_MODE_POOL2 = 1,  /* 1x1 on the 2x2 average of the prologue output (transition: conv o avgpool
+                         commute, attn_aug_conv.py:433-434)                                      */
+  CX_MODE_STEM = 2    /* 7x7 stride 2 pad 3 on a (B,H,W,4) bf16 image; 7 row-taps of 8px*4ch      */
+};
+/* epilogues */
+enum {
+  CX_EPI_STORE = 0,   /* y = bf16(acc); optional per-channel sum / sum of squares (fp32 atomics)   */
+  CX_EPI_MASK = 1     /* dz = acc * [ex*e_sc + e_sh > 0]; S1 += sum dz; S2 += sum dz*(ex-e_mu)*e_r;
+                         y = (accumulate ? y : 0) + e_scale*dz            (ReLU+BN backward)      */
+};
+
+typedef struct CxConv {
+  const void* x;        /* bf16 input (B,H,W,ldx)                                                 */
+  const void* x2;       /* second input for CX_PRO_AFFINE2 (same geometry, pitch ldx2) or NULL     */
+  const void* w;        /* packed bf16 weights [taps][N][K] (K contiguous), see cx_pack_weights    */
+  void* y;              /* bf16 output (B,Ho,Wo,ldy), written at channel 0 of the pointer          */
+  const float* pa; const float* pb; const float* pc;          /* prologue vectors [K]             */
+  float* stat_sum; float* stat_sq;                             /* [N] or NULL                      */
+  const void* ex;       /* CX_EPI_MASK: bf16 tensor (B,Ho,Wo,ldex) the ReLU mask / xhat come from  */
+  const float* e_sc; const float* e_sh; const float* e_mu; const float* e_r; const float* e_scale; /* [N] */
+  int32_t B, H, W, Ho, Wo;
+  int32_t K, N;         /* channels per tap in / out; both multiples of 32                         */
+  int32_t ldx, ldx2, ldy, ldex;
+  int32_t kh, kw, stride, pad;
+  int32_t prologue, mode, epilogue, accumulate;
+} CxConv;
+
+/* Weight gradient of the same convolution:  dW[n][c][ky][kx] += sum_m G[m][n] * A[m@tap][c]
+ *   G = dY (prologue NONE or AFFINE2 with vectors ga/gb/gc over N, second tensor g2)
+ *   A = the forward A operand (prologue NONE / AFFINE_RELU with pa/pb over K, any mode)          */
+typedef struct CxWgrad {
+  const void* g; const void* g2;          /* bf16 (B,Ho,Wo,ldg)                                    */
+  const void* x;                           /* bf16 forward input (B,H,W,ldx)                        */
+  float* dw;                               /* fp32 OIHW gradient, accumulated with atomics          */
+  const float* ga; const float* gb; const float* gc;   /* [N]                                       */
+  const float* pa; const float* pb;                      /* [K]                                       */
+  int32_t B, H, W, Ho, Wo, K, N;
+  int32_t ldg, ldg2, ldx;
+  int32_t kh, kw, stride, pad;
+  int32_t g_prologue, x_prologue, mode;
+  int32_t splits;                          /* pixel-range splits (0 = library picks)                */
+} CxWgrad;
+
+int cx_abi_version(void);
+const char* cx_error_string(int code);
+
+/* conv forward / input-gradient as one implicit GEMM family.
+ * Replaces F.conv2d + F.batch_norm + F.relu (+ torch.cat, avg_pool2d) forward and their autograd
+ * input-gradients: torchvision _DenseLayer (norm1-relu1-conv1-norm2-relu2-conv2), _Transition
+ * (attn_aug_conv.py:431-434), features.conv0 (:461), Bottleneck convs (:194-203).               */
+int cx_conv_gemm(const CxConv* p, void* stream);
+/* weight gradient (autograd of the same convs)                                                   */
+int cx_conv_wgrad(const CxWgrad* p, void* stream);
+
+/* OIHW fp32 -> packed bf16.  transpose=0: [tap][O][I] (forward);  transpose=1: [tap'][I][O] with
+ * taps rotated by 180 degrees (input-gradient of a stride-1 conv).  stem=1: (64,3,7,7) -> [ky][O][8*4].  */
+int cx_pack_weights(const float* w_oihw, void* packed, int O, int I, int kh, int kw, int transpose, int stem,
+                    void* stream);
+
+/* (B,3,H,W) fp32 NCHW -> (B,H,W,4) bf16 (4th channel zero).  Replaces x.to(device) layout glue
+ * ahead of features.conv0 (chexpert.py:159).                                                      */
+int cx_nchw3_to_nhwc4(const float* x, void* y, int B, int H, int W, void* stream);
+
+/* BatchNorm training statistics -> (scale, shift) of the consumer + running-stat update
+ * (F.batch_norm, momentum semantics of nn.BatchNorm2d incl. unbiased running_var).
+ * sum/sq: fp32 [C] over `count` elements.  gamma/beta may be NULL (-> 1, 0: InstanceNorm-like).
+ * running_* may be NULL.  Also emits mean / rstd when non-NULL.                                   */
+int cx_bn_coef(const float* sum, const float* sq, float count, const float* gamma, const float* beta, float eps,
+               float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+               float* rstd, int C, void* stream);
+/* eval mode: scale/shift from running statistics                                                 */
+int cx_bn_coef_eval(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                    float eps, float* scale, float* shift, float* mean, float* rstd, int C, void* stream);
+
+/* Backward bookkeeping of one consumer BatchNorm over buffer channels [0,C):
+ *   dgamma += S2, dbeta += S1 (fp32 parameter gradients);
+ *   deferred per-channel correction  A[c] += r*gamma*S1/count,  Bc[c] += r*gamma*S2/count
+ * (the -mean(dz) - xhat*mean(dz*xhat) terms of BN backward are linear in x and shared by every
+ * consumer of a dense-block channel, so they are applied once, by the channel's producer).
+ * If pa/pb/pc are non-NULL also emits the AFFINE2 vectors of a SINGLE-consumer BN (norm2):
+ *   dY = dz*pa + y*pb + pc.                                                                       */
+int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* gamma, const float* mean,
+                   const float* rstd, float* dgamma, float* dbeta, float* A, float* Bc, float* pa, float* pb,
+                   float* pc, int C, void* stream);
+/* AFFINE2 vectors that apply the deferred correction to a gradient slice:
+ *   dY_true = G*1 + x*(-r*Bc) + (mean*r*Bc - A)                                                   */
+int cx_bn_bwd_slice_coef(const float* A, const float* Bc, const float* mean, const float* rstd, float* pa,
+                         float* pb, float* pc, int C, void* stream);
+
+/* stem: y = maxpool3x3s2p1(relu(x*scale+shift)) into a channel slice + stats of the pooled output
+ * (features.norm0/relu0/pool0, attn_aug_conv.py:462-464).  argmax: (B,H/2,W/2,C) uint8 window
+ * position (0..8) of the first maximum, kept for the backward pass.                               */
+int cx_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax,
+                          float* stat_sum, float* stat_sq, int B, int H, int W, int C, int ldy, void* stream);
+/* backward of the same: routes (corrected) dY to the arg-max, applies the ReLU mask, writes dz (bf16,
+ * (B,H,W,C)) and accumulates S1 = sum dz, S2 = sum dz*xhat                                       */
+int cx_bnrelu_maxpool_bwd(const void* x, const float* scale, const float* shift, const float* mean,
+                          const float* rstd, const uint8_t* argmax, const void* g, const void* gx, const float* ga,
+                          const float* gb, const float* gc, void* dz, float* S1, float* S2, int B, int H, int W, int C,
+                          int ldg, int ldgx, void* stream);
+
+/* head: pooled[b][c] = mean_hw relu(x*scale+shift); logits = pooled @ Wt + bias
+ * (attn_aug_conv.py:514-516)                                                                      */
+int cx_head_fwd(const void* x, const float* scale, const float* shift, const float* w, const float* bias,
+                float* pooled, float* logits, int B, int HW, int C, int ldx, int n_classes, void* stream);
+/* loss = BCEWithLogits(logits,target).sum(1).mean(0); dlogits = (sigmoid - target)/B * grad_scale
+ * (chexpert.py:160, :530)                                                                         */
+int cx_bce_fwd_bwd(const float* logits, const float* target, float* loss, float* loss_elem, float* dlogits,
+                   float grad_scale, int B, int n_classes, void* stream);
+/* head backward: dW += dlogits^T pooled, db += sum dlogits, dpooled = dlogits @ W;
+ * then gradient into the block buffer through GAP + ReLU + norm5 (mask epilogue semantics):
+ * dz = dpooled/HW * [x*scale+shift>0]; S1,S2 += ...; g = e_scale*dz (written, not accumulated)   */
+int cx_head_bwd(const float* dlogits, const float* pooled, const float* w, float* dw, float* db,
+                float* dpooled, int B, int C, int n_classes, void* stream);
+int cx_gap_relu_bn_bwd(const float* dpooled, const void* x, const float* scale, const float* shift,
+                       const float* mean, const float* rstd, const float* e_scale, void* g, float* S1, float* S2,
+                       int B, int HW, int C, int ldx, int ldg, void* stream);
+
+/* transition backward glue: un-pool (each of the 4 inputs gets d/4), ReLU mask + BN mask epilogue */
+int cx_unpool2_mask(const void* d, const void* x, const float* sc, const float* sh, const float* mean,
+                    const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W,
+                    int C, int ldd, int ldx, int ldg, void* stream);
+
+/* dz (B,H,W,C) bf16 -> dY = dz*pa + x*pb + pc in place (BN0 backward ahead of the stem wgrad)      */
+int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb, const float* pc, size_t rows,
+                       int C, void* stream);
+
+/* fused optimisers on flat fp32 buffers (torch.optim.Adam / SGD(nesterov) / RMSprop(momentum) as
+ * wired at chexpert.py:470, :479, :499)                                                           */
+int cx_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float grad_scale, void* stream);
+int cx_sgd_nesterov_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum,
+                         float weight_decay, int first_step, float grad_scale, void* stream);
+int cx_rmsprop_step(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha, float eps,
+                    float momentum, float weight_decay, float grad_scale, void* stream);
+
+/* utilities */
+int cx_fill_f32(float* p, float v, size_t n, void* stream);
+int cx_bf16_to_f32_nchw(const void* x, float* y, int B, int H, int W, int C, int ldx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,368 @@
+"""GPU: every HIP kernel, through the C ABI, against a plain PyTorch fp32 reference of the same op.
+
+Inputs are rounded to bf16 first (the storage type of the path) and the reference applies the same
+intermediate roundings the kernel documents (A operand after the fused prologue, bf16 outputs), so the
+tolerances below only cover fp32 accumulation order and the final bf16 rounding (2^-9 relative)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from chexpert_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from chexpert_amd import _lib
+    _lib.lib()          # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rnd(seed, shape, lo=-1.0, hi=1.0):
+    return synth.uniform(seed, shape, lo, hi)
+
+
+def nhwc_buf(seed, B, H, W, C, dev, lo=-1.5, hi=1.5):
+    """bf16 NHWC buffer on the GPU + its fp32 NCHW value on the CPU."""
+    v = bf(rnd(seed, (B, H, W, C), lo, hi))
+    return v.to(torch.bfloat16).to(dev), v.permute(0, 3, 1, 2).contiguous()
+
+
+def to_nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, want, rel=6e-3, what=""):
+    scale = want.abs().max().item() + 1e-6
+    err = (got - want).abs().max().item()
+    assert err <= rel * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+
+
+# ------------------------------------------------------------------------------------------------ conv forward
+@pytest.mark.parametrize("B,H,W,Ctot,K,N", [(2, 9, 11, 160, 96, 128), (1, 16, 16, 64, 64, 128), (3, 5, 7, 256, 224, 96),
+                                             (2, 6, 6, 1024, 1024, 128)])
+def test_conv1x1_bnrelu_store_stats(dev, B, H, W, Ctot, K, N):
+    from chexpert_amd import ops
+    xb, x = nhwc_buf(1, B, H, W, Ctot, dev)
+    w = bf(rnd(2, (N, K, 1, 1), -0.2, 0.2))
+    pa, pb = rnd(3, (K,), -0.3, 1.5), rnd(4, (K,), -0.5, 0.5)
+    a = bf(F.relu(x[:, :K] * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1)))
+    want = F.conv2d(a, w)
+    y = torch.full((B, H, W, N + 32), 7.0, dtype=torch.bfloat16, device=dev)
+    ssum, ssq = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    ops.conv_gemm(xb[..., :K], ops.pack_weights(w.to(dev)), y[..., :N], N=N, prologue=ops.PRO_AFFINE_RELU,
+                  pa=pa.to(dev), pb=pb.to(dev), stat_sum=ssum, stat_sq=ssq)
+    got = to_nchw(y[..., :N])
+    close(got, want, what="y")
+    assert (y[..., N:].float() == 7.0).all(), "wrote outside the channel slice"
+    close(ssum.cpu(), got.sum((0, 2, 3)), rel=1e-4, what="sum")
+    close(ssq.cpu(), (got * got).sum((0, 2, 3)), rel=1e-4, what="sumsq")
+
+
+@pytest.mark.parametrize("B,H,W,K,N,stride,pro", [(2, 10, 12, 128, 32, 1, 1), (1, 7, 9, 128, 32, 1, 1), (2, 12, 12, 64, 64, 2, 0),
+                                                    (1, 8, 8, 32, 128, 1, 0)])
+def test_conv3x3_slice_output(dev, B, H, W, K, N, stride, pro):
+    from chexpert_amd import ops
+    xb, x = nhwc_buf(5, B, H, W, K, dev)
+    w = bf(rnd(6, (N, K, 3, 3), -0.1, 0.1))
+    pa, pb = rnd(7, (K,), -0.3, 1.5), rnd(8, (K,), -0.5, 0.5)
+    a = bf(F.relu(x * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1))) if pro else x
+    want = F.conv2d(a, w, stride=stride, padding=1)
+    Ho, Wo = want.shape[2:]
+    buf = torch.full((B, Ho, Wo, 96 + N), -3.0, dtype=torch.bfloat16, device=dev)
+    ssum, ssq = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    ops.conv_gemm(xb, ops.pack_weights(w.to(dev)), buf[..., 96:], N=N, kh=3, kw=3, stride=stride, pad=1,
+                  prologue=ops.PRO_AFFINE_RELU if pro else ops.PRO_NONE, pa=pa.to(dev) if pro else None,
+                  pb=pb.to(dev) if pro else None, stat_sum=ssum, stat_sq=ssq)
+    got = to_nchw(buf[..., 96:])
+    close(got, want, what="y")
+    assert (buf[..., :96].float() == -3.0).all()
+    close(ssum.cpu(), got.sum((0, 2, 3)), rel=1e-4, what="sum")
+
+
+def test_transition_pool2_commutes_with_conv(dev):
+    from chexpert_amd import ops
+    B, H, W, K, N = 2, 8, 12, 64, 96
+    xb, x = nhwc_buf(9, B, H, W, K, dev)
+    w = bf(rnd(10, (N, K, 1, 1), -0.2, 0.2))
+    pa, pb = rnd(11, (K,), -0.3, 1.5), rnd(12, (K,), -0.5, 0.5)
+    act = F.relu(x * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1))
+    # reference order of operations (attn_aug_conv.py:431-434): conv then avg-pool
+    want_ref_order = F.avg_pool2d(F.conv2d(act, w), 2, 2)
+    want = F.conv2d(bf(F.avg_pool2d(act, 2, 2)), w)
+    y = torch.zeros(B, H // 2, W // 2, N, dtype=torch.bfloat16, device=dev)
+    ops.conv_gemm(xb, ops.pack_weights(w.to(dev)), y, N=N, mode=ops.MODE_POOL2, prologue=ops.PRO_AFFINE_RELU, pa=pa.to(dev),
+                  pb=pb.to(dev))
+    close(to_nchw(y), want, what="pool2")
+    close(to_nchw(y), want_ref_order, rel=1.5e-2, what="pool2 vs reference op order")
+
+
+def test_stem_conv7x7(dev):
+    from chexpert_amd import ops
+    B, H, W = 2, 32, 48
+    x = bf(synth.xray_batch(3, B, 64)[:, :, :H, :W].contiguous() * rnd(13, (1, 3, 1, 1), 0.5, 1.0))
+    w = bf(rnd(14, (64, 3, 7, 7), -0.1, 0.1))
+    want = F.conv2d(x, w, stride=2, padding=3)
+    x4 = ops.nchw3_to_nhwc4(x.to(dev))
+    y = torch.zeros(B, H // 2, W // 2, 64, dtype=torch.bfloat16, device=dev)
+    ssum, ssq = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ops.conv_gemm(x4, ops.pack_weights(w.to(dev), stem=True), y, N=64, mode=ops.MODE_STEM, stat_sum=ssum, stat_sq=ssq)
+    got = to_nchw(y)
+    close(got, want, what="stem")
+    close(ssum.cpu(), got.sum((0, 2, 3)), rel=1e-4, what="sum")
+
+
+# ------------------------------------------------------------------------------------------------ dgrad
+@pytest.mark.parametrize("ksz,K,N,acc", [(1, 128, 96, False), (1, 128, 96, True), (3, 32, 128, False), (1, 128, 256, True)])
+def test_dgrad_affine2_mask_epilogue(dev, ksz, K, N, acc):
+    from chexpert_amd import ops
+    B, H, W = 2, 9, 10
+    ub, u = nhwc_buf(20, B, H, W, K, dev)
+    vb, v = nhwc_buf(21, B, H, W, K, dev)
+    exb, ex = nhwc_buf(22, B, H, W, N + 32, dev)
+    oldb, old = nhwc_buf(23, B, H, W, N + 32, dev)
+    w = bf(rnd(24, (K, N, ksz, ksz), -0.1, 0.1))          # forward conv weight: (O=K, I=N): dgrad maps K -> N
+    pa, pb, pc = rnd(25, (K,), 0.5, 1.5), rnd(26, (K,), -0.3, 0.3), rnd(27, (K,), -0.2, 0.2)
+    e_sc, e_sh = rnd(28, (N,), -0.3, 1.5), rnd(29, (N,), -0.5, 0.5)
+    e_mu, e_r, e_scale = rnd(30, (N,), -0.5, 0.5), rnd(31, (N,), 0.5, 2.0), rnd(32, (N,), -0.3, 1.5)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    dy = bf(u * cv(pa) + v * cv(pb) + cv(pc))
+    acc_ref = F.conv_transpose2d(dy, w, padding=ksz // 2)            # = input gradient of the forward conv
+    exs = ex[:, :N]
+    mask = (exs * cv(e_sc) + cv(e_sh)) > 0
+    dz = torch.where(mask, acc_ref, torch.zeros(()))
+    want = cv(e_scale) * dz + (old[:, :N] if acc else 0)
+    S1 = dz.sum((0, 2, 3))
+    S2 = (dz * (exs - cv(e_mu)) * cv(e_r)).sum((0, 2, 3))
+    s1, s2 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    wp = ops.pack_weights(w.to(dev), transpose=True)
+    ops.conv_gemm(ub, wp, oldb[..., :N], N=N, kh=ksz, kw=ksz, pad=ksz // 2, prologue=ops.PRO_AFFINE2, x2=vb, pa=pa.to(dev),
+                  pb=pb.to(dev), pc=pc.to(dev), epilogue=ops.EPI_MASK, ex=exb[..., :N], e_sc=e_sc.to(dev), e_sh=e_sh.to(dev),
+                  e_mu=e_mu.to(dev), e_r=e_r.to(dev), e_scale=e_scale.to(dev), stat_sum=s1, stat_sq=s2, accumulate=acc)
+    close(to_nchw(oldb[..., :N]), want, rel=8e-3, what="g")
+    assert torch.equal(to_nchw(oldb[..., N:]), old[:, N:]), "wrote outside the slice"
+    close(s1.cpu(), S1, rel=2e-3, what="S1")
+    close(s2.cpu(), S2, rel=2e-3, what="S2")
+
+
+# ------------------------------------------------------------------------------------------------ wgrad
+@pytest.mark.parametrize("ksz,K,N,gpro,xpro", [(1, 96, 128, 2, 1), (3, 128, 32, 2, 1), (1, 64, 64, 0, 0), (3, 64, 64, 0, 1),
+                                                (1, 224, 128, 2, 1)])
+def test_wgrad(dev, ksz, K, N, gpro, xpro):
+    from chexpert_amd import ops
+    B, H, W = 3, 9, 7
+    gb_, g = nhwc_buf(40, B, H, W, N + 32, dev)
+    g2b, g2 = nhwc_buf(41, B, H, W, N, dev)
+    xb, x = nhwc_buf(42, B, H, W, K + 64, dev)
+    ga, gbv, gc = rnd(43, (N,), 0.5, 1.5), rnd(44, (N,), -0.3, 0.3), rnd(45, (N,), -0.2, 0.2)
+    pa, pb = rnd(46, (K,), -0.3, 1.5), rnd(47, (K,), -0.5, 0.5)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    G = bf(g[:, :N] * cv(ga) + g2 * cv(gbv) + cv(gc)) if gpro else g[:, :N]
+    A = bf(F.relu(x[:, :K] * cv(pa) + cv(pb))) if xpro else x[:, :K]
+    want = torch.nn.grad.conv2d_weight(A, (N, K, ksz, ksz), G, padding=ksz // 2)
+    dw0 = rnd(48, (N, K, ksz, ksz), -1, 1)
+    dw = dw0.clone().to(dev)
+    ops.conv_wgrad(gb_[..., :N], xb[..., :K], dw, kh=ksz, kw=ksz, pad=ksz // 2, g_prologue=gpro, g2=g2b if gpro else None,
+                   ga=ga.to(dev), gb=gbv.to(dev), gc=gc.to(dev), x_prologue=xpro, pa=pa.to(dev), pb=pb.to(dev))
+    close(dw.cpu() - dw0, want, rel=2e-3, what="dW")
+
+
+def test_wgrad_pool2_and_stem(dev):
+    from chexpert_amd import ops
+    B, H, W, K, N = 2, 8, 12, 64, 128
+    xb, x = nhwc_buf(50, B, H, W, K, dev)
+    gb_, g = nhwc_buf(51, B, H // 2, W // 2, N, dev)
+    pa, pb = rnd(52, (K,), -0.3, 1.5), rnd(53, (K,), -0.5, 0.5)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    A = bf(F.avg_pool2d(F.relu(x * cv(pa) + cv(pb)), 2, 2))
+    want = torch.nn.grad.conv2d_weight(A, (N, K, 1, 1), g)
+    dw = torch.zeros(N, K, 1, 1, device=dev)
+    ops.conv_wgrad(gb_, xb, dw, mode=ops.MODE_POOL2, x_prologue=ops.PRO_AFFINE_RELU, pa=pa.to(dev), pb=pb.to(dev))
+    close(dw.cpu(), want, rel=2e-3, what="dW pool2")
+    # stem
+    Hs, Ws = 24, 32
+    xs = bf(rnd(54, (B, 3, Hs, Ws), -2, 2))
+    gsb, gs = nhwc_buf(55, B, Hs // 2, Ws // 2, 64, dev)
+    want = torch.nn.grad.conv2d_weight(xs, (64, 3, 7, 7), gs, stride=2, padding=3)
+    dw = torch.zeros(64, 3, 7, 7, device=dev)
+    ops.conv_wgrad(gsb, ops.nchw3_to_nhwc4(xs.to(dev)), dw, mode=ops.MODE_STEM)
+    close(dw.cpu(), want, rel=2e-3, what="dW stem")
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_pack_weights_layouts(dev):
+    from chexpert_amd import ops
+    w = bf(rnd(60, (6, 5, 3, 3)))
+    p0 = ops.pack_weights(w.to(dev)).float().cpu().view(9, 6, 5)
+    assert torch.equal(p0, w.permute(2, 3, 0, 1).reshape(9, 6, 5))
+    p1 = ops.pack_weights(w.to(dev), transpose=True).float().cpu().view(9, 5, 6)
+    assert torch.equal(p1, w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 5, 6))
+
+
+def test_bn_coef_and_running_stats(dev):
+    from chexpert_amd import ops
+    Cn, cnt = 96, 1000.0
+    x = rnd(61, (1000, Cn), -2, 3)
+    s, q = x.sum(0).to(dev), (x * x).sum(0).to(dev)
+    gamma, beta = rnd(62, (Cn,), 0.5, 1.5), rnd(63, (Cn,), -0.5, 0.5)
+    rm, rv = rnd(64, (Cn,)), rnd(65, (Cn,), 0.5, 1.5)
+    rm_d, rv_d = rm.clone().to(dev), rv.clone().to(dev)
+    out = [torch.zeros(Cn, device=dev) for _ in range(4)]
+    ops.bn_coef(s, q, cnt, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm_d, rv_d, *out)
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    close(out[0].cpu(), gamma * rstd, rel=1e-5)
+    close(out[1].cpu(), beta - mean * gamma * rstd, rel=1e-5)
+    close(out[2].cpu(), mean, rel=1e-5)
+    close(out[3].cpu(), rstd, rel=1e-5)
+    close(rm_d.cpu(), 0.9 * rm + 0.1 * mean, rel=1e-5)
+    close(rv_d.cpu(), 0.9 * rv + 0.1 * x.var(0, unbiased=True), rel=1e-5)
+
+
+def test_stem_maxpool_fwd_bwd(dev):
+    from chexpert_amd import ops
+    B, H, W, Cn = 2, 12, 16, 64
+    xb, x = nhwc_buf(70, B, H, W, Cn, dev)
+    sc, sh = rnd(71, (Cn,), -0.3, 1.5), rnd(72, (Cn,), -0.5, 0.5)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    xr = x.clone().requires_grad_(True)
+    act = F.relu(xr * cv(sc) + cv(sh))
+    pooled = F.max_pool2d(act, 3, 2, 1)
+    y = torch.zeros(B, H // 2, W // 2, Cn + 32, dtype=torch.bfloat16, device=dev)
+    amax = torch.zeros(B, H // 2, W // 2, Cn, dtype=torch.uint8, device=dev)
+    ssum, ssq = torch.zeros(Cn, device=dev), torch.zeros(Cn, device=dev)
+    ops.bnrelu_maxpool_fwd(xb, sc.to(dev), sh.to(dev), y[..., :Cn], amax, ssum, ssq)
+    got = to_nchw(y[..., :Cn])
+    close(got, pooled.detach(), rel=4e-3, what="pooled")
+    close(ssum.cpu(), got.sum((0, 2, 3)), rel=1e-4)
+    # backward: dY = g*ga + gx*gb + gc routed to the arg-max, masked by the ReLU
+    gb_, g = nhwc_buf(73, B, H // 2, W // 2, Cn, dev)
+    gxb, gx = nhwc_buf(74, B, H // 2, W // 2, Cn, dev)
+    ga, gbv, gc = rnd(75, (Cn,), 0.5, 1.5), rnd(76, (Cn,), -0.3, 0.3), rnd(77, (Cn,), -0.2, 0.2)
+    mu, r = rnd(78, (Cn,), -0.5, 0.5), rnd(79, (Cn,), 0.5, 2.0)
+    dY = g * cv(ga) + gx * cv(gbv) + cv(gc)
+    pooled.backward(dY)                      # -> gradient wrt x; divide the BN scale back out to get dz
+    # d act/d x = sc on the active set, so dz (grad wrt the BN output) = xr.grad / sc where sc != 0
+    dz_ref = torch.where(cv(sc).abs() > 1e-12, xr.grad / cv(sc), torch.zeros(()))
+    dz = torch.zeros(B, H, W, Cn, dtype=torch.bfloat16, device=dev)
+    S1, S2 = torch.zeros(Cn, device=dev), torch.zeros(Cn, device=dev)
+    ops.bnrelu_maxpool_bwd(xb, sc.to(dev), sh.to(dev), mu.to(dev), r.to(dev), amax, gb_, gxb, ga.to(dev), gbv.to(dev),
+                           gc.to(dev), dz, S1, S2)
+    close(to_nchw(dz), dz_ref, rel=6e-3, what="dz")
+    close(S1.cpu(), dz_ref.sum((0, 2, 3)), rel=4e-3, what="S1")
+    close(S2.cpu(), (dz_ref * (x - cv(mu)) * cv(r)).sum((0, 2, 3)), rel=4e-3, what="S2")
+
+
+def test_head_loss_and_backward(dev):
+    from chexpert_amd import ops
+    B, H, W, Cn, n = 3, 5, 5, 128, 5
+    xb, x = nhwc_buf(80, B, H, W, Cn + 64, dev)
+    sc, sh = rnd(81, (Cn,), -0.3, 1.5), rnd(82, (Cn,), -0.5, 0.5)
+    mu, r, es = rnd(83, (Cn,), -0.5, 0.5), rnd(84, (Cn,), 0.5, 2.0), rnd(85, (Cn,), -0.3, 1.5)
+    wl, bl = rnd(86, (n, Cn), -0.2, 0.2).requires_grad_(True), rnd(87, (n,), -0.1, 0.1).requires_grad_(True)
+    tgt = synth.targets(88, B, n)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    xs = x[:, :Cn]
+    z = (xs * cv(sc) + cv(sh)).requires_grad_(True)
+    pooled_ref = F.relu(z).mean((2, 3))
+    logits_ref = F.linear(pooled_ref, wl, bl)
+    le = F.binary_cross_entropy_with_logits(logits_ref, tgt, reduction="none")
+    loss_ref = le.sum(1).mean(0)
+    loss_ref.backward()
+    pooled, logits = torch.zeros(B, Cn, device=dev), torch.zeros(B, n, device=dev)
+    ops.head_fwd(xb[..., :Cn], sc.to(dev), sh.to(dev), wl.detach().to(dev), bl.detach().to(dev), pooled, logits)
+    close(logits.cpu(), logits_ref.detach(), rel=1e-5, what="logits")
+    loss, lel, dl = torch.zeros(1, device=dev), torch.zeros(B, n, device=dev), torch.zeros(B, n, device=dev)
+    ops.bce_fwd_bwd(logits, tgt.to(dev), loss, lel, dl)
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    close(lel.cpu(), le.detach(), rel=1e-5)
+    dw, db, dp = torch.zeros(n, Cn, device=dev), torch.zeros(n, device=dev), torch.zeros(B, Cn, device=dev)
+    ops.head_bwd(dl, pooled, wl.detach().to(dev), dw, db, dp)
+    close(dw.cpu(), wl.grad, rel=1e-4, what="dW")
+    close(db.cpu(), bl.grad, rel=1e-4, what="db")
+    g = torch.full((B, H, W, Cn + 32), 5.0, dtype=torch.bfloat16, device=dev)
+    S1, S2 = torch.zeros(Cn, device=dev), torch.zeros(Cn, device=dev)
+    ops.gap_relu_bn_bwd(dp, xb[..., :Cn], sc.to(dev), sh.to(dev), mu.to(dev), r.to(dev), es.to(dev), g[..., :Cn], S1, S2)
+    dz_ref = z.grad
+    close(to_nchw(g[..., :Cn]), cv(es) * dz_ref, rel=6e-3, what="g")
+    close(S1.cpu(), dz_ref.sum((0, 2, 3)), rel=1e-4)
+    close(S2.cpu(), (dz_ref * (xs - cv(mu)) * cv(r)).sum((0, 2, 3)), rel=1e-4)
+
+
+def test_unpool_mask_and_affine2(dev):
+    from chexpert_amd import ops
+    B, H, W, Cn = 2, 8, 6, 256
+    db_, d = nhwc_buf(90, B, H // 2, W // 2, Cn, dev)
+    xb, x = nhwc_buf(91, B, H, W, Cn, dev)
+    sc, sh = rnd(92, (Cn,), -0.3, 1.5), rnd(93, (Cn,), -0.5, 0.5)
+    mu, r, es = rnd(94, (Cn,), -0.5, 0.5), rnd(95, (Cn,), 0.5, 2.0), rnd(96, (Cn,), -0.3, 1.5)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    up = F.interpolate(d, scale_factor=2, mode="nearest") * 0.25
+    dz = torch.where((x * cv(sc) + cv(sh)) > 0, up, torch.zeros(()))
+    g = torch.zeros(B, H, W, Cn, dtype=torch.bfloat16, device=dev)
+    S1, S2 = torch.zeros(Cn, device=dev), torch.zeros(Cn, device=dev)
+    ops.unpool2_mask(db_, xb, sc.to(dev), sh.to(dev), mu.to(dev), r.to(dev), es.to(dev), g, S1, S2)
+    close(to_nchw(g), cv(es) * dz, rel=6e-3)
+    close(S1.cpu(), dz.sum((0, 2, 3)), rel=1e-4)
+    close(S2.cpu(), (dz * (x - cv(mu)) * cv(r)).sum((0, 2, 3)), rel=1e-4)
+    pa, pb, pc = rnd(97, (Cn,), 0.5, 1.5), rnd(98, (Cn,), -0.3, 0.3), rnd(99, (Cn,), -0.2, 0.2)
+    ub, u = nhwc_buf(100, B, H, W, Cn, dev)
+    ops.affine2_inplace(ub, xb, pa.to(dev), pb.to(dev), pc.to(dev))
+    close(to_nchw(ub), u * cv(pa) + x * cv(pb) + cv(pc), rel=6e-3)
+
+
+def test_bn_backward_coefficients(dev):
+    from chexpert_amd import ops
+    Cn, cnt = 64, 500.0
+    S1, S2 = rnd(101, (Cn,), -3, 3), rnd(102, (Cn,), -3, 3)
+    gamma, mu, r = rnd(103, (Cn,), -0.3, 1.5), rnd(104, (Cn,), -0.5, 0.5), rnd(105, (Cn,), 0.5, 2.0)
+    dg0, db0, A0, B0 = rnd(106, (Cn,)), rnd(107, (Cn,)), rnd(108, (Cn,)), rnd(109, (Cn,))
+    t = lambda v: v.clone().to(dev)
+    dg, db, A, Bc = t(dg0), t(db0), t(A0), t(B0)
+    pa, pb, pc = (torch.zeros(Cn, device=dev) for _ in range(3))
+    ops.bn_bwd_coef(t(S1), t(S2), cnt, t(gamma), t(mu), t(r), dg, db, A, Bc, pa, pb, pc, Cn)
+    close(dg.cpu(), dg0 + S2, rel=1e-6)
+    close(db.cpu(), db0 + S1, rel=1e-6)
+    close(A.cpu(), A0 + r * gamma * S1 / cnt, rel=1e-6)
+    close(Bc.cpu(), B0 + r * gamma * S2 / cnt, rel=1e-6)
+    # single-consumer form: dY = gamma*r*(dz - S1/n - xhat*S2/n), xhat = (y-mu)*r
+    dz, y = rnd(110, (7, Cn)), rnd(111, (7, Cn))
+    want = gamma * r * (dz - S1 / cnt - (y - mu) * r * S2 / cnt)
+    close(dz * pa.cpu() + y * pb.cpu() + pc.cpu(), want, rel=1e-5)
+    qa, qb, qc = (torch.zeros(Cn, device=dev) for _ in range(3))
+    ops.bn_bwd_slice_coef(A, Bc, t(mu), t(r), qa, qb, qc, Cn)
+    G, x = rnd(112, (7, Cn)), rnd(113, (7, Cn))
+    want = G - A.cpu() - (x - mu) * r * Bc.cpu()
+    close(G * qa.cpu() + x * qb.cpu() + qc.cpu(), want, rel=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd_nesterov", "rmsprop"])
+def test_fused_optimisers_match_torch_optim(dev, kind):
+    """chexpert.py:470 / :479 / :499 wiring, three steps, against torch.optim on the CPU."""
+    from chexpert_amd import ops
+    from oracle import step as ostep
+    n = 10007
+    p0 = rnd(120, (n,))
+    pc = p0.clone().requires_grad_(True)
+    opt, _ = ostep.make_optimizer(kind, [pc], 1e-2)
+    p = p0.clone().to(dev)
+    st = [torch.zeros(n, device=dev) for _ in range(2)]
+    for it in range(3):
+        g = rnd(121 + it, (n,))
+        pc.grad = g.clone()
+        opt.step()
+        gd = g.to(dev)
+        if kind == "adam":
+            ops.adam_step(p, gd, st[0], st[1], 1e-2, 0.9, 0.999, 1e-8, 0.0, it + 1)
+        elif kind == "sgd_nesterov":
+            ops.sgd_nesterov_step(p, gd, st[0], 1e-2, 0.9, 0.0, it == 0)
+        else:
+            ops.rmsprop_step(p, gd, st[0], st[1], 1e-2, 0.99, 1e-3, 0.9, 0.0)
+    close(p.cpu(), pc.detach(), rel=2e-6, what=kind)
