@@ -362,7 +362,8 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   if (!p.x || !p.w || !p.y) return CX_EINVAL;
   if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
   if (p.K <= 0 || p.N <= 0 || (p.K % 32) || (p.N % 32)) return CX_ESHAPE;
-  if ((p.ldx % 8) || (p.ldy % 8) || !aligned16(p.x) || !aligned16(p.y) || !aligned16(p.w)) return CX_EALIGN;
+  if (p.mode == CX_MODE_STEM ? (p.ldx != 4) : (p.ldx % 8 != 0)) return CX_EALIGN;
+  if ((p.ldy % 8) || !aligned16(p.x) || !aligned16(p.y) || !aligned16(p.w)) return CX_EALIGN;
   if ((long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;
   if (p.prologue != CX_PRO_NONE && (!p.pa || !p.pb)) return CX_EINVAL;
   if (p.prologue == CX_PRO_AFFINE2 && (!p.x2 || !p.pc || (p.ldx2 % 8) || !aligned16(p.x2))) return CX_EINVAL;

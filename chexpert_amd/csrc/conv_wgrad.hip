@@ -292,7 +292,8 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
   if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
   if (p.K <= 0 || p.N <= 0 || (p.K % 32) || (p.N % 32)) return CX_ESHAPE;
   if ((long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;
-  if ((p.ldg % 8) || (p.ldx % 8) || !aligned16(p.g) || !aligned16(p.x)) return CX_EALIGN;
+  if (p.mode == CX_MODE_STEM ? (p.ldx != 4) : (p.ldx % 8 != 0)) return CX_EALIGN;
+  if ((p.ldg % 8) || !aligned16(p.g) || !aligned16(p.x)) return CX_EALIGN;
   if (p.g_prologue == CX_PRO_AFFINE2 && (!p.g2 || !p.ga || !p.gb || !p.gc || (p.ldg2 % 8) || !aligned16(p.g2))) return CX_EINVAL;
   if (p.x_prologue == CX_PRO_AFFINE_RELU && (!p.pa || !p.pb)) return CX_EINVAL;
   hipStream_t st = as_stream(stream);
