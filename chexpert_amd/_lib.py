@@ -37,6 +37,11 @@ class CxWgrad(C.Structure):
                 ("g_prologue", _i32), ("x_prologue", _i32), ("mode", _i32), ("splits", _i32)]
 
 
+class CxPackDesc(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("O", _i32), ("I", _i32), ("kh", _i32), ("kw", _i32),
+                ("transpose", _i32), ("stem", _i32)]
+
+
 # name -> argtypes (return type is int unless noted); kept in one table so the symbol-export test can
 # check it against include/chexpert_hip.h
 _f, _sz, _i = C.c_float, C.c_size_t, C.c_int
@@ -46,6 +51,7 @@ SIGNATURES = {
     "cx_conv_gemm": [C.POINTER(CxConv), _vp],
     "cx_conv_wgrad": [C.POINTER(CxWgrad), _vp],
     "cx_pack_weights": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_pack_weights_table": [_vp, _vp, _vp, _i, _vp],
     "cx_nchw3_to_nhwc4": [_vp, _vp, _i, _i, _i, _vp],
     "cx_bn_coef": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "cx_bn_coef_eval": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],

@@ -317,8 +317,9 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
               : launch_tile<CX_PRO_NONE, CX_PRO_AFFINE_RELU, CX_MODE_POOL2>(p, st);
   }
   if (p.mode == CX_MODE_STEM) {
-    if (p.x_prologue != CX_PRO_NONE || p.K != 32 || p.N != 64 || g2) return CX_EUNSUPPORTED;
-    return launch_tile<CX_PRO_NONE, CX_PRO_NONE, CX_MODE_STEM>(p, st);
+    if (p.x_prologue != CX_PRO_NONE || p.K != 32 || p.N != 64) return CX_EUNSUPPORTED;
+    return g2 ? launch_tile<CX_PRO_AFFINE2, CX_PRO_NONE, CX_MODE_STEM>(p, st)
+              : launch_tile<CX_PRO_NONE, CX_PRO_NONE, CX_MODE_STEM>(p, st);
   }
   return CX_EUNSUPPORTED;
 }

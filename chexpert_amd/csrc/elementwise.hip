@@ -49,6 +49,30 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16* __restric
   }
 }
 
+// one launch for every conv weight of a model: blockIdx.y = descriptor, blockIdx.x strides over its elements
+__global__ void pack_table_kernel(const float* __restrict__ flat, bf16* __restrict__ packed, const CxPackDesc* __restrict__ table) {
+  const CxPackDesc d = table[blockIdx.y];
+  const float* w = flat + d.src_off;
+  bf16* out = packed + d.dst_off;
+  const int O = d.O, I = d.I, taps = d.kh * d.kw;
+  const size_t total = d.stem ? (size_t)7 * O * 32 : (size_t)taps * O * I;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    float v;
+    if (d.stem) {
+      const int k = idx % 32, o = (idx / 32) % O, ky = idx / (32 * (size_t)O);
+      const int kx = (k >> 2) - 1, ch = k & 3;
+      v = (kx >= 0 && ch < 3) ? w[((size_t)(o * 3 + ch) * 7 + ky) * 7 + kx] : 0.f;
+    } else if (!d.transpose) {
+      const int i = idx % I, o = (idx / I) % O, tap = idx / ((size_t)I * O);
+      v = w[((size_t)o * I + i) * taps + tap];
+    } else {
+      const int o = idx % O, i = (idx / O) % I, tp = idx / ((size_t)I * O);
+      v = w[((size_t)o * I + i) * taps + (taps - 1 - tp)];
+    }
+    out[idx] = f2bf(v);
+  }
+}
+
 __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t hw, size_t total) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -503,6 +527,12 @@ int cx_pack_weights(const float* w, void* packed, int O, int I, int kh, int kw, 
   const size_t total = stem ? (size_t)7 * O * 32 : (size_t)kh * kw * O * I;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), w, (bf16*)packed, O, I, kh,
                      kw, transpose, stem);
+  return launch_status();
+}
+
+int cx_pack_weights_table(const float* flat, void* packed, const CxPackDesc* table_dev, int n_desc, void* stream) {
+  if (!flat || !packed || !table_dev || n_desc <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(pack_table_kernel, dim3(16, n_desc), dim3(256), 0, as_stream(stream), flat, (bf16*)packed, table_dev);
   return launch_status();
 }
 

@@ -1,0 +1,569 @@
+"""DenseNet (torchvision-shaped) whose forward / backward run on the hand-written gfx950 kernels.
+
+Drop-in surface: constructor signature of
+/root/reference/models/attn_aug_conv.py:452-453, torchvision `state_dict` key names and OIHW fp32
+shapes, `model.features.norm5`, `model.classifier` (re-assignable), `.train()/.eval()`, autograd through
+`loss.backward()`.  What differs is *how* `model(x)` executes: not module by module through ATen, but
+as one schedule of fused kernels over NHWC bf16 buffers:
+
+  * each dense block lives in ONE (B,H,W,C_total) buffer; layers write their 32 new channels into a
+    slice (the reference's torch.cat never happens);
+  * BatchNorm batch statistics of a buffer channel are accumulated once, by the kernel that produces
+    the channel; every later norm1 over the concatenation re-uses them (same data => same mean/var),
+    only gamma/beta differ;
+  * BN + ReLU are applied in the consumer's operand prologue, never stored;
+  * transition: avg-pool is applied before the 1x1 conv (they commute), 4x fewer MACs;
+  * backward: the -mean(dz) - xhat*mean(dz*xhat) terms of every consumer BatchNorm are linear in x and
+    share xhat, so they are accumulated as two per-channel coefficients and applied once by the
+    channel's producer; the gradient buffer only receives gamma*rstd*dz contributions.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import CxPackDesc, check, lib, ptr, stream_ptr
+
+
+# --------------------------------------------------------------------------------------------- parameter containers
+class _FusedOnly:
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("chexpert_amd: this sub-module only holds parameters; call the parent model "
+                           "(the fused HIP schedule).  There is no module-by-module fallback.")
+
+
+class Conv2dParams(_FusedOnly, nn.Conv2d):
+    pass
+
+
+class BatchNorm2dParams(_FusedOnly, nn.BatchNorm2d):
+    pass
+
+
+class ReLUMarker(_FusedOnly, nn.ReLU):
+    pass
+
+
+class PoolMarker(_FusedOnly, nn.Module):
+    pass
+
+
+class _DenseLayer(nn.Sequential):
+    def __init__(self, cin, growth, bn_size):
+        super().__init__()
+        self.add_module("norm1", BatchNorm2dParams(cin))
+        self.add_module("relu1", ReLUMarker(inplace=True))
+        self.add_module("conv1", Conv2dParams(cin, bn_size * growth, 1, 1, bias=False))
+        self.add_module("norm2", BatchNorm2dParams(bn_size * growth))
+        self.add_module("relu2", ReLUMarker(inplace=True))
+        self.add_module("conv2", Conv2dParams(bn_size * growth, growth, 3, 1, 1, bias=False))
+
+
+class _DenseBlock(nn.Sequential):
+    def __init__(self, n_layers, cin, bn_size, growth):
+        super().__init__()
+        for i in range(n_layers):
+            self.add_module("denselayer%d" % (i + 1), _DenseLayer(cin + i * growth, growth, bn_size))
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("norm", BatchNorm2dParams(cin))
+        self.add_module("relu", ReLUMarker(inplace=True))
+        self.add_module("conv", Conv2dParams(cin, cout, 1, 1, bias=False))
+        self.add_module("pool", PoolMarker())
+
+
+# --------------------------------------------------------------------------------------------- workspace
+class _Vec:
+    """Carves fp32 vectors out of one flat tensor (16-byte aligned)."""
+
+    def __init__(self):
+        self.n = 0
+        self.slots = []
+
+    def take(self, n):
+        off = self.n
+        self.n += (n + 3) // 4 * 4
+        return (off, n)
+
+
+class _Workspace:
+    """Activation buffers + coefficient vectors for one (B,H,W); owned by one in-flight forward."""
+
+    def __init__(self, eng, B, H, W, dev):
+        bf, u8 = torch.bfloat16, torch.uint8
+        self.key = (B, H, W)
+        self.B, self.H, self.W = B, H, W
+        g = eng.growth
+        e = lambda *s, dtype=bf: torch.empty(*s, dtype=dtype, device=dev)
+        self.x4 = e(B, H, W, 4)
+        h, w = H // 2, W // 2
+        self.c0 = e(B, h, w, eng.c_init)
+        self.dz0 = None
+        h, w = h // 2, w // 2
+        self.amax = e(B, h, w, eng.c_init, dtype=u8)
+        self.buf, self.gbuf, self.y1, self.hw = [], [], [], []
+        for bi, (c_in, n_layers) in enumerate(eng.blocks):
+            ct = c_in + n_layers * g
+            self.buf.append(e(B, h, w, ct))
+            self.gbuf.append(None)
+            self.y1.append([e(B, h, w, eng.mid) for _ in range(n_layers)])
+            self.hw.append((h, w))
+            h, w = h // 2, w // 2
+        self.dz2 = None
+        self.dpool = None
+        self.pooled = torch.empty(B, eng.c_final, dtype=torch.float32, device=dev)
+        self.logits = torch.empty(B, eng.n_classes, dtype=torch.float32, device=dev)
+        self.vec = torch.zeros(eng.vec_size, dtype=torch.float32, device=dev)
+        self.ones = torch.ones(max(eng.mid, 64), dtype=torch.float32, device=dev)
+
+    def v(self, slot):
+        off, n = slot
+        return self.vec[off:off + n]
+
+    def alloc_backward(self, eng, dev):
+        if self.dz0 is not None:
+            return
+        bf = torch.bfloat16
+        B = self.B
+        self.dz0 = torch.empty_like(self.c0)
+        self.gbuf = [torch.empty_like(b) for b in self.buf]
+        h, w = self.hw[0]
+        self.dz2 = torch.empty(B, h, w, eng.mid, dtype=bf, device=dev)
+        if len(self.buf) > 1:
+            n = max(self.hw[i + 1][0] * self.hw[i + 1][1] * self.buf[i].shape[3] for i in range(len(self.buf) - 1))
+            self.dpool = torch.empty(B * n, dtype=bf, device=dev)
+
+
+# --------------------------------------------------------------------------------------------- engine
+class _Engine:
+    """Host-side schedule: binds the module's parameters to flat buffers, packs weights, and issues the
+    kernel sequence of forward and backward on the current stream."""
+
+    def __init__(self, model):
+        self.model = model
+        f = model.features
+        self.growth = model.growth_rate
+        self.mid = model.bn_size * model.growth_rate
+        self.c_init = f.conv0.out_channels
+        self.blocks = []
+        c = self.c_init
+        for n_layers in model.block_config:
+            self.blocks.append((c, n_layers))
+            c = c + n_layers * self.growth
+            if len(self.blocks) != len(model.block_config):
+                c //= 2
+        self.c_final = c
+        self.flat = None
+        self.flat_grad = None
+        self.device = None
+        self.n_classes = None
+        self.pool = {}
+        self._plan_vectors()
+
+    # ---- coefficient-vector layout
+    def _plan_vectors(self):
+        V = _Vec()
+        s = {}
+        s["st0"] = [V.take(self.c_init) for _ in range(2)]                # conv0 output sum, sq
+        s["bst"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
+        s["yst"] = [[[V.take(self.mid) for _ in range(2)] for _ in range(n)] for _, n in self.blocks]
+        self.fwd_zero = (0, V.n)                                           # zeroed at the start of each forward
+        s["n0"] = [V.take(self.c_init) for _ in range(4)]                  # sc, sh, mean, rstd
+        s["bmr"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]     # block mean, rstd
+        s["n1"] = [[[V.take(c + i * self.growth) for _ in range(2)] for i in range(n)] for c, n in self.blocks]
+        s["n2"] = [[[V.take(self.mid) for _ in range(4)] for _ in range(n)] for _, n in self.blocks]
+        s["nt"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]      # transition / norm5 sc, sh
+        b0 = V.n
+        s["S0"] = [V.take(self.c_init) for _ in range(2)]
+        s["S1"] = [[[V.take(c + i * self.growth) for _ in range(2)] for i in range(n)] for c, n in self.blocks]
+        s["S2"] = [[[V.take(self.mid) for _ in range(2)] for _ in range(n)] for _, n in self.blocks]
+        s["St"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
+        s["AB"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
+        self.bwd_zero = (b0, V.n - b0)
+        s["q"] = [V.take(max(self.mid, self.c_init, max(c for c, _ in self.blocks))) for _ in range(3)]   # slice AFFINE2
+        s["p"] = [V.take(max(self.mid, self.c_init)) for _ in range(3)]                                   # norm2 AFFINE2
+        s["dpooled"] = V.take(0)
+        self.slots = s
+        self.vec_size = V.n
+
+    # ---- parameter binding
+    def bind(self, dev):
+        m = self.model
+        params = [p for _, p in m.named_parameters()]
+        n_classes = m.classifier.out_features
+        ok = (self.flat is not None and self.device == dev and self.n_classes == n_classes
+              and len(params) == len(self.offsets)
+              and all(p.data_ptr() == self.flat.data_ptr() + 4 * off for p, off in zip(params, self.offsets)))
+        if ok:
+            return
+        if m.classifier.in_features != self.c_final:
+            raise RuntimeError("classifier.in_features must be %d" % self.c_final)
+        offs, total = [], 0
+        for p in params:
+            if p.dtype != torch.float32:
+                raise RuntimeError("parameters must be fp32 masters (bf16 is the kernels' storage type)")
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, off in zip(params, offs):
+            flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + p.numel()].view(p.shape)
+        for b in m.buffers():
+            if b.device != dev:
+                raise RuntimeError("module buffers are on %s, input on %s -- call model.to(device)" % (b.device, dev))
+        self.flat, self.offsets, self.params = flat, offs, params
+        self.flat_grad = torch.zeros_like(flat)
+        self.grad_views = [self.flat_grad[off:off + p.numel()].view(p.shape) for p, off in zip(params, offs)]
+        self.off_of = {id(p): off for p, off in zip(params, offs)}
+        self.device, self.n_classes = dev, n_classes
+        self.pool = {}
+        # packing table: every conv weight, forward layout (+ transposed layout for input gradients)
+        descs, cur = [], 0
+        self.wf, self.wb = {}, {}
+
+        def add(conv, transpose=False, stem=False):
+            nonlocal cur
+            O, I, kh, kw = conv.weight.shape
+            n = 7 * O * 32 if stem else O * I * kh * kw
+            d = CxPackDesc(self.off_of[id(conv.weight)], cur, O, I, kh, kw, int(transpose), int(stem))
+            descs.append(d)
+            off = cur
+            cur += (n + 7) // 8 * 8
+            return (off, n)
+        f = m.features
+        self.wf[id(f.conv0)] = add(f.conv0, stem=True)
+        for mod in f.modules():
+            if isinstance(mod, nn.Conv2d) and mod is not f.conv0:
+                self.wf[id(mod)] = add(mod)
+                self.wb[id(mod)] = add(mod, transpose=True)
+        self.packed = torch.empty(cur, dtype=torch.bfloat16, device=dev)
+        arr = (CxPackDesc * len(descs))(*descs)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.desc_dev = host.to(dev)
+        self.n_desc = len(descs)
+        self.packed_version = None
+
+    def pack(self, train):
+        # training: parameters change every step (possibly through the fused optimiser, which does not
+        # bump tensor versions) -> always repack (one launch); eval: only when a version moved
+        ver = None if train else sum(p._version for p in self.params)
+        if ver is not None and ver == self.packed_version:
+            return
+        check(lib().cx_pack_weights_table(ptr(self.flat), ptr(self.packed), ptr(self.desc_dev), self.n_desc, stream_ptr()),
+              "cx_pack_weights_table")
+        self.packed_version = ver
+
+    def w_fwd(self, conv):
+        off, n = self.wf[id(conv)]
+        return self.packed[off:off + n]
+
+    def w_bwd(self, conv):
+        off, n = self.wb[id(conv)]
+        return self.packed[off:off + n]
+
+    def grad_of(self, p):
+        off = self.off_of[id(p)]
+        return self.flat_grad[off:off + p.numel()]
+
+    # ---- workspaces
+    def acquire(self, B, H, W):
+        lst = self.pool.setdefault((B, H, W), [])
+        return lst.pop() if lst else _Workspace(self, B, H, W, self.device)
+
+    def release(self, ws):
+        lst = self.pool.setdefault(ws.key, [])
+        if len(lst) < 2:
+            lst.append(ws)
+
+    # ---- forward
+    def _bn(self, ws, sum_slot, sq_slot, count, bn, out_slots, C_, train, mean_slot=None, rstd_slot=None):
+        """scale/shift (+mean/rstd) of one BatchNorm over channels [0,C_) of the given statistics."""
+        sc, sh = ws.v(out_slots[0])[:C_], ws.v(out_slots[1])[:C_]
+        mean = ws.v(mean_slot)[:C_] if mean_slot is not None else None
+        rstd = ws.v(rstd_slot)[:C_] if rstd_slot is not None else None
+        if train:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            ops.bn_coef(ws.v(sum_slot)[:C_], ws.v(sq_slot)[:C_], count, bn.weight, bn.bias, bn.eps, mom,
+                        bn.running_mean if bn.track_running_stats else None,
+                        bn.running_var if bn.track_running_stats else None, sc, sh, mean, rstd, C_)
+        else:
+            ops.bn_coef_eval(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, sc, sh, mean, rstd, C_)
+
+    def forward(self, x, train):
+        m, f, s = self.model, self.model.features, self.slots
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("expected a (B,3,H,W) input")
+        B, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise RuntimeError("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
+        self.bind(x.device)
+        self.pack(train)
+        ws = self.acquire(B, H, W)
+        z0, zn = self.fwd_zero
+        ws.vec[z0:z0 + zn].zero_()
+        st = (lambda a: ws.v(a)) if train else (lambda a: None)
+        ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
+        ops.conv_gemm(ws.x4, self.w_fwd(f.conv0), ws.c0, N=self.c_init, mode=ops.MODE_STEM, stat_sum=st(s["st0"][0]),
+                      stat_sq=st(s["st0"][1]))
+        self._bn(ws, s["st0"][0], s["st0"][1], B * (H // 2) * (W // 2), f.norm0, s["n0"][:2], self.c_init, train,
+                 s["n0"][2], s["n0"][3])
+        ops.bnrelu_maxpool_fwd(ws.c0, ws.v(s["n0"][0]), ws.v(s["n0"][1]), ws.buf[0][..., :self.c_init], ws.amax,
+                               st(s["bst"][0][0]), st(s["bst"][0][1]))
+        nb = len(self.blocks)
+        for bi, (c0, n_layers) in enumerate(self.blocks):
+            buf = ws.buf[bi]
+            h, w = ws.hw[bi]
+            cnt = B * h * w
+            bsum, bsq = s["bst"][bi]
+            bmean, brstd = s["bmr"][bi]
+            block = getattr(f, "denseblock%d" % (bi + 1))
+            for li in range(n_layers):
+                layer = getattr(block, "denselayer%d" % (li + 1))
+                cin = c0 + li * self.growth
+                n1, n2 = s["n1"][bi][li], s["n2"][bi][li]
+                self._bn(ws, bsum, bsq, cnt, layer.norm1, n1, cin, train, bmean, brstd)
+                ysum, ysq = s["yst"][bi][li]
+                y1 = ws.y1[bi][li]
+                ops.conv_gemm(buf[..., :cin], self.w_fwd(layer.conv1), y1, N=self.mid, prologue=ops.PRO_AFFINE_RELU,
+                              pa=ws.v(n1[0]), pb=ws.v(n1[1]), stat_sum=st(ysum), stat_sq=st(ysq))
+                self._bn(ws, ysum, ysq, cnt, layer.norm2, n2[:2], self.mid, train, n2[2], n2[3])
+                off, _ = bsum
+                ops.conv_gemm(y1, self.w_fwd(layer.conv2), buf[..., cin:cin + self.growth], N=self.growth, kh=3, kw=3, pad=1,
+                              prologue=ops.PRO_AFFINE_RELU, pa=ws.v(n2[0]), pb=ws.v(n2[1]),
+                              stat_sum=st((bsum[0] + cin, self.growth)), stat_sq=st((bsq[0] + cin, self.growth)))
+            ct = c0 + n_layers * self.growth
+            nt = s["nt"][bi]
+            if bi != nb - 1:
+                tr = getattr(f, "transition%d" % (bi + 1))
+                self._bn(ws, bsum, bsq, cnt, tr.norm, nt, ct, train, bmean, brstd)
+                nsum, nsq = s["bst"][bi + 1]
+                ops.conv_gemm(buf, self.w_fwd(tr.conv), ws.buf[bi + 1][..., :ct // 2], N=ct // 2, mode=ops.MODE_POOL2,
+                              prologue=ops.PRO_AFFINE_RELU, pa=ws.v(nt[0]), pb=ws.v(nt[1]),
+                              stat_sum=st((nsum[0], ct // 2)), stat_sq=st((nsq[0], ct // 2)))
+            else:
+                self._bn(ws, bsum, bsq, cnt, f.norm5, nt, ct, train, bmean, brstd)
+                ops.head_fwd(buf, ws.v(nt[0]), ws.v(nt[1]), m.classifier.weight, m.classifier.bias, ws.pooled, ws.logits)
+        if train:
+            m._nbt_pending += 1
+        return ws
+
+    # ---- backward
+    def backward(self, ws, dlogits):
+        m, f, s = self.model, self.model.features, self.slots
+        B = ws.B
+        dev = self.device
+        ws.alloc_backward(self, dev)
+        z0, zn = self.bwd_zero
+        ws.vec[z0:z0 + zn].zero_()
+        fresh = any(p.grad is None for p in self.params)
+        if fresh:
+            self.flat_grad.zero_()
+        elif not all(p.grad.data_ptr() == gv.data_ptr() for p, gv in zip(self.params, self.grad_views)):
+            raise RuntimeError("parameter .grad tensors were replaced; call zero_grad(set_to_none=True) first")
+        nb = len(self.blocks)
+        G = self.grad_of
+        v = ws.v
+        # head
+        bi = nb - 1
+        c0, n_layers = self.blocks[bi]
+        ct = c0 + n_layers * self.growth
+        nt, (bmean, brstd), (A, Bc) = s["nt"][bi], s["bmr"][bi], s["AB"][bi]
+        dpooled = torch.empty(B, ct, dtype=torch.float32, device=dev)
+        ops.head_bwd(dlogits, ws.pooled, m.classifier.weight, G(m.classifier.weight), G(m.classifier.bias) if
+                     m.classifier.bias is not None else None, dpooled)
+        St = s["St"][bi]
+        ops.gap_relu_bn_bwd(dpooled, ws.buf[bi], v(nt[0]), v(nt[1]), v(bmean), v(brstd), v(nt[0]), ws.gbuf[bi], v(St[0]),
+                            v(St[1]))
+        h, w = ws.hw[bi]
+        ops.bn_bwd_coef(v(St[0]), v(St[1]), B * h * w, f.norm5.weight, v(bmean), v(brstd), G(f.norm5.weight), G(f.norm5.bias),
+                        v(A), v(Bc), None, None, None, ct)
+        q, pv = s["q"], s["p"]
+        for bi in range(nb - 1, -1, -1):
+            c0, n_layers = self.blocks[bi]
+            buf, gbuf = ws.buf[bi], ws.gbuf[bi]
+            h, w = ws.hw[bi]
+            cnt = B * h * w
+            (bmean, brstd), (A, Bc) = s["bmr"][bi], s["AB"][bi]
+            block = getattr(f, "denseblock%d" % (bi + 1))
+            dz2 = ws.dz2.view(-1)[:B * h * w * self.mid].view(B, h, w, self.mid)
+            sub = lambda slot, a, n: (slot[0] + a, n)
+            for li in range(n_layers - 1, -1, -1):
+                layer = getattr(block, "denselayer%d" % (li + 1))
+                cin = c0 + li * self.growth
+                g_ = self.growth
+                n1, n2 = s["n1"][bi][li], s["n2"][bi][li]
+                y1 = ws.y1[bi][li]
+                qa, qb, qc = (v(t)[:g_] for t in q)
+                ops.bn_bwd_slice_coef(v(sub(A, cin, g_)), v(sub(Bc, cin, g_)), v(sub(bmean, cin, g_)), v(sub(brstd, cin, g_)),
+                                      qa, qb, qc, g_)
+                gs, xs = gbuf[..., cin:cin + g_], buf[..., cin:cin + g_]
+                S2 = s["S2"][bi][li]
+                ops.conv_gemm(gs, self.w_bwd(layer.conv2), dz2, N=self.mid, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=xs,
+                              pa=qa, pb=qb, pc=qc, epilogue=ops.EPI_MASK, ex=y1, e_sc=v(n2[0]), e_sh=v(n2[1]), e_mu=v(n2[2]),
+                              e_r=v(n2[3]), e_scale=ws.ones[:self.mid], stat_sum=v(S2[0]), stat_sq=v(S2[1]))
+                ops.conv_wgrad(gs, y1, G(layer.conv2.weight), kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa,
+                               gb=qb, gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
+                pa, pb, pc = (v(t)[:self.mid] for t in pv)
+                ops.bn_bwd_coef(v(S2[0]), v(S2[1]), cnt, layer.norm2.weight, v(n2[2]), v(n2[3]), G(layer.norm2.weight),
+                                G(layer.norm2.bias), None, None, pa, pb, pc, self.mid)
+                S1 = s["S1"][bi][li]
+                ops.conv_gemm(dz2, self.w_bwd(layer.conv1), gbuf[..., :cin], N=cin, prologue=ops.PRO_AFFINE2, x2=y1, pa=pa,
+                              pb=pb, pc=pc, epilogue=ops.EPI_MASK, ex=buf[..., :cin], e_sc=v(n1[0]), e_sh=v(n1[1]),
+                              e_mu=v(bmean)[:cin], e_r=v(brstd)[:cin], e_scale=v(n1[0]), stat_sum=v(S1[0]), stat_sq=v(S1[1]),
+                              accumulate=True)
+                ops.conv_wgrad(dz2, buf[..., :cin], G(layer.conv1.weight), g_prologue=ops.PRO_AFFINE2, g2=y1, ga=pa, gb=pb,
+                               gc=pc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n1[0]), pb=v(n1[1]))
+                ops.bn_bwd_coef(v(S1[0]), v(S1[1]), cnt, layer.norm1.weight, v(bmean), v(brstd), G(layer.norm1.weight),
+                                G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin)
+            # the block's first c0 channels were produced by the previous transition (or the stem)
+            qa, qb, qc = (v(t)[:c0] for t in q)
+            ops.bn_bwd_slice_coef(v(A), v(Bc), v(bmean), v(brstd), qa, qb, qc, c0)
+            gs, xs = gbuf[..., :c0], buf[..., :c0]
+            if bi > 0:
+                pc0, pn = self.blocks[bi - 1]
+                cprev = pc0 + pn * self.growth
+                tr = getattr(f, "transition%d" % bi)
+                pbuf, pg = ws.buf[bi - 1], ws.gbuf[bi - 1]
+                ph, pw = ws.hw[bi - 1]
+                nt, (pmean, prstd), (pA, pB), St = s["nt"][bi - 1], s["bmr"][bi - 1], s["AB"][bi - 1], s["St"][bi - 1]
+                dpool = ws.dpool[:B * h * w * cprev].view(B, h, w, cprev)
+                ops.conv_gemm(gs, self.w_bwd(tr.conv), dpool, N=cprev, prologue=ops.PRO_AFFINE2, x2=xs, pa=qa, pb=qb, pc=qc)
+                ops.unpool2_mask(dpool, pbuf, v(nt[0]), v(nt[1]), v(pmean), v(prstd), v(nt[0]), pg, v(St[0]), v(St[1]))
+                ops.conv_wgrad(gs, pbuf, G(tr.conv.weight), mode=ops.MODE_POOL2, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa, gb=qb,
+                               gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(nt[0]), pb=v(nt[1]))
+                ops.bn_bwd_coef(v(St[0]), v(St[1]), B * ph * pw, tr.norm.weight, v(pmean), v(prstd), G(tr.norm.weight),
+                                G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev)
+            else:
+                n0, S0 = s["n0"], s["S0"]
+                ops.bnrelu_maxpool_bwd(ws.c0, v(n0[0]), v(n0[1]), v(n0[2]), v(n0[3]), ws.amax, gs, xs, qa, qb, qc, ws.dz0,
+                                       v(S0[0]), v(S0[1]))
+                pa, pb, pc = (v(t)[:self.c_init] for t in pv)
+                ops.bn_bwd_coef(v(S0[0]), v(S0[1]), B * (ws.H // 2) * (ws.W // 2), f.norm0.weight, v(n0[2]), v(n0[3]),
+                                G(f.norm0.weight), G(f.norm0.bias), None, None, pa, pb, pc, self.c_init)
+                ops.conv_wgrad(ws.dz0, ws.x4, G(f.conv0.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0,
+                               ga=pa, gb=pb, gc=pc)
+        if fresh:
+            for p, gv in zip(self.params, self.grad_views):
+                p.grad = gv
+
+
+class _Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, model):
+        eng = model._engine
+        if not model.training:
+            raise NotImplementedError("autograd through the fused DenseNet needs train() mode (batch-statistic BatchNorm "
+                                      "backward); for Grad-CAM use chexpert_amd.gradcam.grad_cam")
+        ws = eng.forward(x, True)
+        ctx.model, ctx.ws = model, ws
+        return ws.logits.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng, ws = ctx.model._engine, ctx.ws
+        if ws is None:
+            raise RuntimeError("backward through the fused DenseNet can only run once per forward")
+        eng.backward(ws, dlogits.contiguous().float())
+        eng.release(ws)
+        ctx.ws = None
+        return None, None, None
+
+
+# --------------------------------------------------------------------------------------------- module
+class DenseNet(nn.Module):
+    """Signature of /root/reference/models/attn_aug_conv.py:452-453 (torchvision DenseNet + attn_params)."""
+
+    def __init__(self, growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4, drop_rate=0,
+                 num_classes=1000, attn_params=None):
+        super().__init__()
+        if drop_rate:
+            raise NotImplementedError("drop_rate > 0 is not on the reference hot path (chexpert.py uses 0)")
+        if attn_params is not None:
+            raise NotImplementedError("attention-augmented transitions (AAConv2d) are not built yet: SURVEY.md section 8 row C")
+        if len(block_config) != 4:
+            raise NotImplementedError("only the ImageNet-style stem (4 dense blocks) is on the hot path")
+        self.growth_rate, self.block_config, self.bn_size = growth_rate, tuple(block_config), bn_size
+        self.features = nn.Sequential(OrderedDict([
+            ("conv0", Conv2dParams(3, num_init_features, 7, 2, 3, bias=False)),
+            ("norm0", BatchNorm2dParams(num_init_features)),
+            ("relu0", ReLUMarker(inplace=True)),
+            ("pool0", PoolMarker()),
+        ]))
+        c = num_init_features
+        for i, n in enumerate(block_config):
+            self.features.add_module("denseblock%d" % (i + 1), _DenseBlock(n, c, bn_size, growth_rate))
+            c += n * growth_rate
+            if i != len(block_config) - 1:
+                self.features.add_module("transition%d" % (i + 1), _Transition(c, c // 2))
+                c //= 2
+        self.features.add_module("norm5", BatchNorm2dParams(c))
+        self.classifier = nn.Linear(c, num_classes)
+        # initialisers of the reference (attn_aug_conv.py:503-510)
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight)
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.constant_(mod.weight, 1)
+                nn.init.constant_(mod.bias, 0)
+            elif isinstance(mod, nn.Linear):
+                nn.init.constant_(mod.bias, 0)
+        self._nbt_pending = 0
+        self._engine = None
+
+    # the engine is rebuilt lazily (the classifier may be replaced after construction, chexpert.py:464)
+    def _eng(self):
+        if self._engine is None or self._engine.c_final != self.classifier.in_features:
+            object.__setattr__(self, "_engine", _Engine(self))
+        return self._engine
+
+    def _flush_nbt(self):
+        if self._nbt_pending:
+            for mod in self.modules():
+                if isinstance(mod, nn.BatchNorm2d) and mod.num_batches_tracked is not None:
+                    mod.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_nbt()
+        return super().state_dict(*args, **kwargs)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("chexpert_amd.DenseNet runs on the GPU only (hand-written HIP kernels); there is no CPU "
+                               "fallback -- move the model and the input to cuda")
+        eng = self._eng()
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _Fn.apply(x, self.classifier.weight, self)
+        ws = eng.forward(x, self.training)
+        out = ws.logits.clone()
+        eng.release(ws)
+        return out
+
+    # fused training step helpers (bench / trainer fast path; same arithmetic as chexpert.py:159-163)
+    def forward_backward(self, x, target):
+        """logits = model(x); loss = BCEWithLogits(logits, target).sum(1).mean(0); loss.backward().
+        Returns (loss, logits) as device tensors without a host sync."""
+        eng = self._eng()
+        ws = eng.forward(x, self.training)
+        B, n = ws.logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dl = torch.empty(B, n, dtype=torch.float32, device=x.device)
+        ops.bce_fwd_bwd(ws.logits, target, loss, None, dl)
+        eng.backward(ws, dl)
+        logits = ws.logits.clone()
+        eng.release(ws)
+        return loss, logits
+
+
+def densenet121(pretrained=False, **kwargs):
+    """torchvision.models.densenet121 stand-in (chexpert.py:24, :462).  `pretrained` would download
+    ImageNet weights in the reference; there is no network here, load a state_dict instead."""
+    if pretrained:
+        raise RuntimeError("pretrained ImageNet weights cannot be downloaded here; use load_state_dict()")
+    return DenseNet(32, (6, 12, 24, 16), 64, **kwargs)

@@ -99,6 +99,14 @@ int cx_conv_wgrad(const CxWgrad* p, void* stream);
 int cx_pack_weights(const float* w_oihw, void* packed, int O, int I, int kh, int kw, int transpose, int stem,
                     void* stream);
 
+/* The same for every conv weight of a model in ONE launch: `flat` is the flat fp32 parameter buffer,
+ * `table_dev` a DEVICE array of descriptors (element offsets into flat / packed).                  */
+typedef struct CxPackDesc {
+  int64_t src_off, dst_off;
+  int32_t O, I, kh, kw, transpose, stem;
+} CxPackDesc;
+int cx_pack_weights_table(const float* flat, void* packed, const CxPackDesc* table_dev, int n_desc, void* stream);
+
 /* (B,3,H,W) fp32 NCHW -> (B,H,W,4) bf16 (4th channel zero).  Replaces x.to(device) layout glue
  * ahead of features.conv0 (chexpert.py:159).                                                      */
 int cx_nchw3_to_nhwc4(const float* x, void* y, int B, int H, int W, void* stream);

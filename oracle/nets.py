@@ -193,31 +193,52 @@ def _aa(sd, p, x, stride, nh, return_weights=False):
                     stride=stride, dk=dk, dv=dv, nh=nh, return_weights=return_weights)
 
 
-def densenet_features(sd, x, block_config=(6, 12, 24, 16), train=True, nh=None, taps=None):
-    """features(x) up to and including norm5 (pre-ReLU).  `nh` != None => AA transitions."""
-    x = F.conv2d(x, sd["features.conv0.weight"], stride=2, padding=3)
+class _STE(torch.autograd.Function):
+    """bf16 round with a straight-through gradient (storage-rounding model of the HIP path)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def bf16_storage(t):
+    return _STE.apply(t)
+
+
+def densenet_features(sd, x, block_config=(6, 12, 24, 16), train=True, nh=None, taps=None, q=None):
+    """features(x) up to and including norm5 (pre-ReLU).  `nh` != None => AA transitions.
+    `q` (optional) models the HIP path's storage roundings: it is applied to the input, the conv
+    weights, every stored conv / pool output and every normalised operand (q=bf16_storage); with
+    q=None this is the plain fp32 restatement of the reference."""
+    q = q or (lambda t: t)
+    w = lambda k: q(sd[k])
+    x = q(F.conv2d(q(x), w("features.conv0.weight"), stride=2, padding=3))
     x = F.relu(_bn(sd, "features.norm0", x, train))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = q(F.max_pool2d(x, 3, 2, 1))
     for b, n_layers in enumerate(block_config, 1):
         for l in range(1, n_layers + 1):
             p = "features.denseblock%d.denselayer%d" % (b, l)
-            y = F.conv2d(F.relu(_bn(sd, p + ".norm1", x, train)), sd[p + ".conv1.weight"])
-            y = F.conv2d(F.relu(_bn(sd, p + ".norm2", y, train)), sd[p + ".conv2.weight"], padding=1)
+            y = q(F.conv2d(q(F.relu(_bn(sd, p + ".norm1", x, train))), w(p + ".conv1.weight")))
+            y = q(F.conv2d(q(F.relu(_bn(sd, p + ".norm2", y, train))), w(p + ".conv2.weight"), padding=1))
             x = torch.cat([x, y], 1)
         if taps is not None:
             taps["block%d" % b] = x
         if b != len(block_config):
             p = "features.transition%d" % b
             if nh is None:
-                x = F.conv2d(F.relu(_bn(sd, p + ".norm", x, train)), sd[p + ".conv.weight"])
-                x = F.avg_pool2d(x, 2, 2)
+                x = F.conv2d(q(F.relu(_bn(sd, p + ".norm", x, train))), w(p + ".conv.weight"))
+                x = q(F.avg_pool2d(x, 2, 2))
             else:
                 x = _aa(sd, p + ".conv", F.relu(F.instance_norm(x, eps=1e-5)), 2, nh)
     return _bn(sd, "features.norm5", x, train)
 
 
-def densenet_forward(sd, x, block_config=(6, 12, 24, 16), train=True, nh=None, taps=None):
-    f = densenet_features(sd, x, block_config, train, nh, taps)
+def densenet_forward(sd, x, block_config=(6, 12, 24, 16), train=True, nh=None, taps=None, q=None):
+    f = densenet_features(sd, x, block_config, train, nh, taps, q)
     if taps is not None:
         taps["norm5"] = f
     pooled = F.relu(f).mean((2, 3))
