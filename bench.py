@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""Headline benchmark: DenseNet121 forward+backward on synthetic 320x320 X-rays, bf16 storage.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one minibatch resident in HBM: forward (batch-statistic
+BatchNorm), BCE loss, full backward into the flat fp32 gradient buffer, and (N>1) the RCCL gradient
+all-reduce.  The optimiser update is timed separately and reported in `config`.  Prints ONE JSON line
+(rank 0) with `roofline` (dominant kernel, HIP-event timed inside the timed region) and `cpu_baseline`
+(the oracle's fp32 CPU restatement of the same step on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALG_BYTES_PER_IMG = 283.1e6    # densenet121@320 bf16, fwd+bwd
+
+
+class KernelTimer:
+    """HIP events around the launches of the conv kernels (on torch's current stream, which is the
+    stream the library launches on).  Tags follow the kernel template instantiation."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.orig = (ops.conv_gemm, ops.conv_wgrad)
+        self.records = {}
+        self.only = None
+        self.enabled = False
+
+    @staticmethod
+    def _dims(t):
+        B, H, W, C = t.shape
+        return B * H * W, C
+
+    def install(self):
+        ops = self.ops
+        og, ow = self.orig
+
+        def conv_gemm(x, w, y, **kw):
+            if not self.enabled:
+                return og(x, w, y, **kw)
+            mode, kh, epi = kw.get("mode", 0), kw.get("kh", 1), kw.get("epilogue", 0)
+            N = kw["N"]
+            tag = "conv_gemm/%s/%s/N%d" % ({0: "%dx%d" % (kh, kh), 1: "pool2", 2: "stem"}[mode], {0: "store", 1: "mask"}[epi], N)
+            if self.only is not None and tag != self.only:
+                return og(x, w, y, **kw)
+            mi, ci = self._dims(x)
+            mo, co = self._dims(y)
+            alg = 2.0 * (mi * ci + mo * co)          # |X| + |Y| elements, bf16 (SURVEY 8d rule, per kernel)
+            return self._timed(tag, alg, og, x, w, y, **kw)
+
+        def conv_wgrad(g, x, dw, **kw):
+            if not self.enabled:
+                return ow(g, x, dw, **kw)
+            mode, kh = kw.get("mode", 0), kw.get("kh", 1)
+            tag = "conv_wgrad/%s/N%d" % ({0: "%dx%d" % (kh, kh), 1: "pool2", 2: "stem"}[mode], g.shape[3])
+            if self.only is not None and tag != self.only:
+                return ow(g, x, dw, **kw)
+            mg, cg = self._dims(g)
+            mx, cx = self._dims(x)
+            return self._timed(tag, 2.0 * (mg * cg + mx * cx), ow, g, x, dw, **kw)
+        ops.conv_gemm, ops.conv_wgrad = conv_gemm, conv_wgrad
+
+    def _timed(self, tag, alg, fn, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **kw)
+        e1.record()
+        self.records.setdefault(tag, []).append((e0, e1, alg))
+        return r
+
+    def summary(self):
+        out = {}
+        for tag, recs in self.records.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+            out[tag] = dict(launches=len(recs), ms=ms, alg_bytes=sum(a for _, _, a in recs))
+        return out
+
+
+def host_cores():
+    """Cores this process may actually use (cgroup / affinity aware; the GPU box gives 16 per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p_))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_baseline(n_classes, steps=3, batch=4, size=320):
+    """The reference CPU path as restated by oracle/ (fp32, all host cores): forward + loss + backward."""
+    from chexpert_amd import synth
+    from oracle import nets, step
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    spec = nets.densenet_spec(n_classes)
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(spec), 5)
+    x, t = synth.xray_batch(11, batch, size), synth.targets(12, batch, n_classes)
+    fwd = lambda s, xx: nets.densenet_forward(s, xx, train=True)
+    step.train_step(fwd, sd, x, t)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.train_step(fwd, sd, x, t)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "densenet121 fp32 CPU (oracle restatement of chexpert.py:159-163 fwd+loss+bwd), bs=%d, %d steps, %dx%d"
+                      % (batch, steps, size, size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU minibatch (BASELINE config: 256)")
+    ap.add_argument("--size", type=int, default=320)
+    ap.add_argument("--classes", type=int, default=14)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-kernel", default=None, help="kernel tag to time (default: the one with the largest share)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from chexpert_amd import ops, synth
+    from chexpert_amd.models import densenet121
+    from chexpert_amd.optim import FusedAdam
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(1234)
+    model = densenet121(num_classes=args.classes).to(dev)
+    model.train()
+    x = synth.xray_batch(1000 + rank, args.batch, args.size).to(dev)
+    t = synth.targets(2000 + rank, args.batch, args.classes).to(dev)
+    opt = FusedAdam(model, lr=1e-4)
+
+    timer = KernelTimer(ops)
+    timer.install()
+
+    def step():
+        return model.forward_backward(x, t)
+
+    log("model + data ready")
+    loss, _ = step()                           # binds the engine, allocates workspaces
+    torch.cuda.synchronize()
+    log("first step done, loss %.4f" % loss.item())
+    if world > 1:
+        from chexpert_amd.parallel import broadcast_module_state
+        broadcast_module_state(model)
+        model._eng().enable_data_parallel()
+    for _ in range(max(0, args.warmup - 1)):
+        model.zero_grad()
+        step()
+    torch.cuda.synchronize()
+
+    # one instrumented step over every conv kernel family to find the dominant one
+    only = args.roofline_kernel
+    if only is None:
+        timer.enabled, timer.only = True, None
+        model.zero_grad()
+        step()
+        torch.cuda.synchronize()
+        fam = timer.summary()
+        only = max(fam, key=lambda k: fam[k]["ms"])
+        timer.records = {}
+    timer.enabled, timer.only = True, only
+    log("warm-up done; roofline kernel = %s" % only)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.zero_grad()
+        loss, _ = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    timer.enabled = False
+    ksum = timer.summary()[only]
+    log("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
+
+    # optimiser step, timed separately (not part of `value`)
+    torch.cuda.synchronize()
+    o0 = time.perf_counter()
+    for _ in range(5):
+        opt.step()
+    torch.cuda.synchronize()
+    opt_ms = (time.perf_counter() - o0) / 5 * 1e3
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = world * args.batch * args.steps / dt
+        avg_ms = ksum["ms"] / ksum["launches"]
+        achieved = ksum["alg_bytes"] / (ksum["ms"] * 1e-3) / 1e9
+        out = {
+            "metric": "images/sec fwd+bwd DenseNet121 320x320 bf16 (per-GPU rate in config.images_per_sec_per_gpu)",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "densenet121 bf16 1xMI355X 320x320 bs=%d U-Ones labels (configs[1]); %d classes; "
+                                   "random-init weights, synthetic uint8 X-rays" % (args.batch, args.classes),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "images_per_sec_per_gpu": round(value / world, 2),
+                       "model_hbm_roofline_frac": round(value / world * ALG_BYTES_PER_IMG / (HBM_PEAK_GBS * 1e9), 4),
+                       "optimizer_step_ms": round(opt_ms, 3), "loss": round(float(loss.item()), 5)},
+            "roofline": {"bound": "hbm", "kernel": only, "launches_per_step": ksum["launches"] // args.steps,
+                         "avg_launch_ms": round(avg_ms, 4), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+        }
+        if not args.no_cpu_baseline:
+            log("cpu baseline on %d cores ..." % host_cores())
+            out["cpu_baseline"] = cpu_baseline(args.classes)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

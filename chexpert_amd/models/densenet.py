@@ -164,6 +164,7 @@ class _Engine:
         self.device = None
         self.n_classes = None
         self.pool = {}
+        self.reducer = None          # chexpert_amd.parallel.GradReducer when data-parallel
         self._plan_vectors()
 
     # ---- coefficient-vector layout
@@ -369,6 +370,10 @@ class _Engine:
         nb = len(self.blocks)
         G = self.grad_of
         v = ws.v
+        red = self.reducer
+        if red is not None:
+            red.begin()
+        done = (lambda p: red.ready(self.off_of[id(p)])) if red is not None else (lambda p: None)
         # head
         bi = nb - 1
         c0, n_layers = self.blocks[bi]
@@ -421,6 +426,7 @@ class _Engine:
                                gc=pc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n1[0]), pb=v(n1[1]))
                 ops.bn_bwd_coef(v(S1[0]), v(S1[1]), cnt, layer.norm1.weight, v(bmean), v(brstd), G(layer.norm1.weight),
                                 G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin)
+                done(layer.norm1.weight)      # every gradient from this layer to the end of the buffer is final
             # the block's first c0 channels were produced by the previous transition (or the stem)
             qa, qb, qc = (v(t)[:c0] for t in q)
             ops.bn_bwd_slice_coef(v(A), v(Bc), v(bmean), v(brstd), qa, qb, qc, c0)
@@ -439,6 +445,7 @@ class _Engine:
                                gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(nt[0]), pb=v(nt[1]))
                 ops.bn_bwd_coef(v(St[0]), v(St[1]), B * ph * pw, tr.norm.weight, v(pmean), v(prstd), G(tr.norm.weight),
                                 G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev)
+                done(tr.norm.weight)
             else:
                 n0, S0 = s["n0"], s["S0"]
                 ops.bnrelu_maxpool_bwd(ws.c0, v(n0[0]), v(n0[1]), v(n0[2]), v(n0[3]), ws.amax, gs, xs, qa, qb, qc, ws.dz0,
@@ -448,9 +455,19 @@ class _Engine:
                                 G(f.norm0.weight), G(f.norm0.bias), None, None, pa, pb, pc, self.c_init)
                 ops.conv_wgrad(ws.dz0, ws.x4, G(f.conv0.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0,
                                ga=pa, gb=pb, gc=pc)
+        if red is not None:
+            red.finish()
         if fresh:
             for p, gv in zip(self.params, self.grad_views):
                 p.grad = gv
+
+    def enable_data_parallel(self, bucket_bytes=16 << 20, group=None):
+        """Average gradients across ranks inside backward (bucketed all-reduce overlapped with the
+        remaining backward kernels).  Call after the first bind (i.e. after one forward) or it binds now."""
+        from ..parallel import GradReducer
+        if self.flat_grad is None:
+            raise RuntimeError("bind the engine first (run one forward)")
+        self.reducer = GradReducer(self.flat_grad, bucket_bytes, group)
 
 
 class _Fn(torch.autograd.Function):

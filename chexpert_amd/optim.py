@@ -1,0 +1,72 @@
+"""Fused optimisers over the engine's flat fp32 parameter / gradient buffers (one kernel per step).
+
+Same update rules and defaults as the torch.optim classes the reference wires up
+(/root/reference/chexpert.py:470 Adam(lr); :479 SGD(momentum=0.9, nesterov=True); :499
+RMSprop(momentum=0.9, eps=1e-3)), with the schedulers of :480 (MultiStepLR[40000, 60000]) and :500
+(ExponentialLR(gamma)) folded in as `scheduler_step()`.
+"""
+import torch
+
+from . import ops
+
+
+class _Flat:
+    def __init__(self, model, lr):
+        self.model = model
+        self.lr = float(lr)
+        self.base_lr = float(lr)
+        self.step_count = 0
+        self.sched_steps = 0
+        self._state = None
+
+    def _bufs(self, n):
+        eng = self.model._eng()
+        if eng.flat is None:
+            raise RuntimeError("run a forward pass first (parameters are bound to the flat buffer lazily)")
+        if self._state is None or self._state[0].numel() != eng.flat.numel() or self._state[0].device != eng.flat.device:
+            self._state = [torch.zeros_like(eng.flat) for _ in range(n)]
+        return eng.flat, eng.flat_grad, self._state
+
+    def zero_grad(self, set_to_none=True):
+        self.model.zero_grad(set_to_none=set_to_none)
+
+
+class FusedAdam(_Flat):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(model, lr)
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+
+    def step(self, grad_scale=1.0):
+        p, g, (m, v) = self._bufs(2)
+        self.step_count += 1
+        ops.adam_step(p, g, m, v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, grad_scale)
+
+
+class FusedSGDNesterov(_Flat):
+    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, milestones=(40000, 60000), gamma=0.1):
+        super().__init__(model, lr)
+        self.momentum, self.wd, self.milestones, self.gamma = momentum, weight_decay, tuple(milestones), gamma
+
+    def step(self, grad_scale=1.0):
+        p, g, (buf,) = self._bufs(1)
+        ops.sgd_nesterov_step(p, g, buf, self.lr, self.momentum, self.wd, self.step_count == 0, grad_scale)
+        self.step_count += 1
+
+    def scheduler_step(self):
+        self.sched_steps += 1
+        self.lr = self.base_lr * self.gamma ** sum(self.sched_steps >= m for m in self.milestones)
+
+
+class FusedRMSprop(_Flat):
+    def __init__(self, model, lr, alpha=0.99, eps=1e-3, momentum=0.9, weight_decay=0.0, decay=0.97):
+        super().__init__(model, lr)
+        self.alpha, self.eps, self.momentum, self.wd, self.decay = alpha, eps, momentum, weight_decay, decay
+
+    def step(self, grad_scale=1.0):
+        p, g, (sq, buf) = self._bufs(2)
+        ops.rmsprop_step(p, g, sq, buf, self.lr, self.alpha, self.eps, self.momentum, self.wd, grad_scale)
+        self.step_count += 1
+
+    def scheduler_step(self):
+        self.sched_steps += 1
+        self.lr = self.base_lr * self.decay ** self.sched_steps

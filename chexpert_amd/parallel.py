@@ -1,0 +1,72 @@
+"""Data parallelism for the fused models: one process per GPU, gradients averaged with bucketed
+all-reduce (RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for tests).
+
+The reference is single-device (chexpert.py:453); DP semantics here are DDP's: every rank holds a full
+replica and a shard of the minibatch, BatchNorm uses per-rank batch statistics, parameter gradients are
+averaged.  Gradients live in ONE flat fp32 buffer in parameter order; backward
+produces them from the end of the buffer to the start, so buckets are contiguous ranges handed to the
+communicator as soon as the kernels that fill them have been enqueued: the all-reduce of bucket k runs
+on a side stream while the compute stream continues with the earlier layers' backward kernels.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, flat_grad, bucket_bytes=16 << 20, group=None):
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket = max(1, bucket_bytes // flat_grad.element_size())
+        self.cuda = flat_grad.is_cuda
+        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.avg = self.cuda and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.hi = flat_grad.numel()
+        self.works = []
+        self.ranges = []
+
+    def begin(self):
+        self.hi = self.flat.numel()
+        self.works, self.ranges = [], []
+
+    def _launch(self, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        view = self.flat[lo:hi]
+        self.ranges.append((lo, hi))
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                if self.avg:
+                    self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                else:
+                    self.works.append(dist.all_reduce(view, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, group=self.group, async_op=True))
+
+    def ready(self, lo):
+        """Every gradient at flat offset >= lo is final."""
+        if self.hi - lo >= self.bucket or (lo == 0 and self.hi > 0):
+            self._launch(lo, self.hi)
+            self.hi = lo
+
+    def finish(self):
+        """Flush the tail and make the reduced gradients visible to the compute stream."""
+        self.ready(0)
+        for w in self.works:
+            w.wait()
+        if self.cuda and self.works:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.world > 1 and not self.avg:
+            self.flat.mul_(1.0 / self.world)
+        self.works = []
+
+
+def broadcast_module_state(module, src=0, group=None):
+    """Initial parameter / buffer broadcast from rank 0 (replicas start identical)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src, group=group)
