@@ -356,6 +356,8 @@ int launch_bn(const CxConv& p, hipStream_t st) {
 
 }  // namespace
 
+int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled);     // conv3x3_strip.hip
+
 extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   if (!pp) return CX_EINVAL;
   const CxConv& p = *pp;
@@ -377,6 +379,11 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
     if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return CX_ESHAPE;
     if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) return CX_ESHAPE;
     if (p.ldx < p.K) return CX_ESHAPE;
+    {
+      bool handled = false;
+      const int rc = cx_try_strip_fwd(p, st, &handled);
+      if (handled) return rc;
+    }
     if (p.epilogue == CX_EPI_STORE) {
       if (p.prologue == CX_PRO_NONE) return launch_bn<CX_PRO_NONE, CX_MODE_CONV, CX_EPI_STORE>(p, st);
       if (p.prologue == CX_PRO_AFFINE_RELU) return launch_bn<CX_PRO_AFFINE_RELU, CX_MODE_CONV, CX_EPI_STORE>(p, st);

@@ -285,6 +285,8 @@ int launch_tile(const CxWgrad& p, hipStream_t st) {
 
 }  // namespace
 
+int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);   // conv3x3_strip.hip
+
 extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
   if (!pp) return CX_EINVAL;
   const CxWgrad& p = *pp;
@@ -302,6 +304,11 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
   if (p.mode == CX_MODE_CONV) {
     if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return CX_ESHAPE;
     if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) return CX_ESHAPE;
+    {
+      bool handled = false;
+      const int rc = cx_try_strip_wgrad(p, st, &handled);
+      if (handled) return rc;
+    }
     if (p.x_prologue == CX_PRO_AFFINE_RELU)
       return g2 ? launch_tile<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU, CX_MODE_CONV>(p, st)
                 : launch_tile<CX_PRO_NONE, CX_PRO_AFFINE_RELU, CX_MODE_CONV>(p, st);

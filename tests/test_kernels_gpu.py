@@ -67,7 +67,11 @@ def test_conv1x1_bnrelu_store_stats(dev, B, H, W, Ctot, K, N):
 
 
 @pytest.mark.parametrize("B,H,W,K,N,stride,pro", [(2, 10, 12, 128, 32, 1, 1), (1, 7, 9, 128, 32, 1, 1), (2, 12, 12, 64, 64, 2, 0),
-                                                    (1, 8, 8, 32, 128, 1, 0)])
+                                                    (1, 8, 8, 32, 128, 1, 0),
+                                                    # strip kernel geometries: W=80 (R=1, ranges crossing images), W=40 (R=2, odd H),
+                                                    # W=20 (R=4), W=10 (R=8 > H remainder)
+                                                    (3, 10, 80, 128, 32, 1, 1), (2, 9, 40, 128, 32, 1, 1), (5, 20, 20, 128, 32, 1, 1),
+                                                    (7, 10, 10, 128, 32, 1, 1)])
 def test_conv3x3_slice_output(dev, B, H, W, K, N, stride, pro):
     from chexpert_amd import ops
     xb, x = nhwc_buf(5, B, H, W, K, dev)
@@ -153,11 +157,13 @@ def test_dgrad_affine2_mask_epilogue(dev, ksz, K, N, acc):
 
 
 # ------------------------------------------------------------------------------------------------ wgrad
-@pytest.mark.parametrize("ksz,K,N,gpro,xpro", [(1, 96, 128, 2, 1), (3, 128, 32, 2, 1), (1, 64, 64, 0, 0), (3, 64, 64, 0, 1),
-                                                (1, 224, 128, 2, 1)])
-def test_wgrad(dev, ksz, K, N, gpro, xpro):
+@pytest.mark.parametrize("ksz,K,N,gpro,xpro,B,H,W", [(1, 96, 128, 2, 1, 3, 9, 7), (3, 128, 32, 2, 1, 3, 9, 7), (1, 64, 64, 0, 0, 3, 9, 7),
+                                                      (3, 64, 64, 0, 1, 3, 9, 7), (1, 224, 128, 2, 1, 3, 9, 7),
+                                                      # strip wgrad geometries
+                                                      (3, 128, 32, 2, 1, 3, 10, 80), (3, 128, 32, 0, 1, 2, 9, 40),
+                                                      (3, 128, 32, 2, 1, 5, 20, 20), (3, 128, 32, 2, 1, 9, 10, 10)])
+def test_wgrad(dev, ksz, K, N, gpro, xpro, B, H, W):
     from chexpert_amd import ops
-    B, H, W = 3, 9, 7
     gb_, g = nhwc_buf(40, B, H, W, N + 32, dev)
     g2b, g2 = nhwc_buf(41, B, H, W, N, dev)
     xb, x = nhwc_buf(42, B, H, W, K + 64, dev)
