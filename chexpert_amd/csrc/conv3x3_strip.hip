@@ -21,7 +21,7 @@ namespace {
 
 constexpr int XP_FWD = 272;     // bytes per ring pixel, forward (128 bf16 + 16 pad): 68 banks == 4 (mod 64)
 constexpr int XP_WG = 320;      // wgrad ring pitch: == 64 B (mod 256 B) for the transposing reads
-constexpr int NCHX = 9;         // max 16-B chunks of new input rows per thread and step (forward, 192 threads)
+constexpr int NCHX = 7;         // max 16-B chunks of new input rows per thread and step (forward, 192 threads)
 
 struct StripGeo {
   int B, H, W, P, R, Q;         // P = W+2, Q = (R+2)*P ring pixels
@@ -32,26 +32,29 @@ struct StripGeo {
 __device__ __forceinline__ int wrapq(int v, int q) { return v >= q ? v - q : v; }
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(192) void conv3x3_strip_fwd_kernel(const bf16* __restrict__ x, int ldx,
+// 3 waves; wave dy keeps the weights of its three taps (dy, 0..2) in REGISTERS (24 fragments = 96 VGPRs), so
+// LDS only holds the input ring (~67 KB at W=80) and two workgroups share a CU: while one stages rows /
+// stores its tile the other feeds the matrix pipe.  The three per-row partial sums of a 32-pixel sub-tile
+// meet in a 12 KB LDS scratch, where the tile is also transposed for 16-B stores along the channel axis.
+__global__ __launch_bounds__(192, 2) void conv3x3_strip_fwd_kernel(const bf16* __restrict__ x, int ldx,
                                                                  const float* __restrict__ sc, const float* __restrict__ sh,
                                                                  const bf16* __restrict__ wpk, bf16* __restrict__ y, int ldy,
                                                                  float* stat_sum, float* stat_sq, const StripGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* wl = smem;                                             // [9][8][64][16 B] fragment-ordered weights
-  char* ring = wl + 9 * 8 * 64 * 16;                           // [(Q+2)][272 B]
-  float* coef = reinterpret_cast<float*>(ring + (size_t)(g.Q + 2) * XP_FWD);   // [2][128]
+  float* coef = reinterpret_cast<float*>(smem);                // [2][128]
   float* lstat = coef + 256;                                   // [2][32]
-  float* scratch = lstat + 64;                                 // [3 waves][32][36]
+  float* scratch = lstat + 64;                                 // [3 waves][32 px][32 ch]
+  char* ring = reinterpret_cast<char*>(scratch + 3 * 1024);    // [(Q+2)][272 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
 
-  // ---- one-time setup: weights -> fragment order, ring zero, coefficient table
-  for (int c = tid; c < 9 * 32 * 16; c += 192) {
-    const int c8 = c & 15, n = (c >> 4) & 31, tap = c >> 9;
-    const uint4 v = *reinterpret_cast<const uint4*>(wpk + ((size_t)(tap * 32 + n) * 128 + c8 * 8));
-    const int ks = c8 >> 1, h = c8 & 1;
-    *reinterpret_cast<uint4*>(wl + (((tap * 8 + ks) * 64) + n + 32 * h) * 16) = v;
-  }
+  // ---- one-time setup
+  bf16x8 wr[3][8];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      wr[dx][ks] = *reinterpret_cast<const bf16x8*>(wpk + ((size_t)((wave * 3 + dx) * 32 + (lane & 31)) * 128 + ks * 16 + (lane >> 5) * 8));
   for (int i = tid; i < (Q + 2) * (XP_FWD / 16); i += 192) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
   for (int i = tid; i < 128; i += 192) { coef[i] = sc[i]; coef[128 + i] = sh[i]; }
   if (tid < 64) lstat[tid] = 0.f;
@@ -65,43 +68,41 @@ __global__ __launch_bounds__(192) void conv3x3_strip_fwd_kernel(const bf16* __re
   uint4 pre[NCHX];
   bool pv[NCHX];
   int base_row = 0;           // image row held by ring slot 0 ... slot(y) = (y - base_row) mod (R+2)
-  // loads rows [y0, y0+n) of image b into registers (16-B chunks spread over the threads)
+  // step-invariant decomposition of this thread's chunks: row inside the group of new rows, pixel, channel chunk
+  int crow[NCHX], cpx[NCHX], cc8[NCHX];
+#pragma unroll
+  for (int i = 0; i < NCHX; ++i) {
+    const int cid = tid + 192 * i;
+    crow[i] = cid / chunks_per_row;
+    const int rem = cid - crow[i] * chunks_per_row;
+    cpx[i] = rem >> 4;
+    cc8[i] = rem & 15;
+  }
+  // loads rows [y0, y0+n) of image b into registers.  Loads are unconditional on clamped addresses
+  // (a branch around a load makes hipcc wait per load); validity is applied when the rows are staged.
   auto issue_rows = [&](int b, int y0, int n) {
 #pragma unroll
     for (int i = 0; i < NCHX; ++i) {
-      const int cid = tid + 192 * i;
-      pv[i] = false;
-      if (cid < n * chunks_per_row) {
-        const int r = cid / chunks_per_row, rem = cid - r * chunks_per_row;
-        const int px = rem >> 4, c8 = rem & 15, yy = y0 + r;
-        if (yy >= 0 && yy < H) {
-          pv[i] = true;
-          pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yy) * W + px) * ldx + c8 * 8);
-        }
-      }
+      const int yy = y0 + crow[i];
+      pv[i] = crow[i] < n && yy >= 0 && yy < H;
+      const int yc_ = min(max(yy, 0), H - 1);
+      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + cpx[i]) * ldx + cc8[i] * 8);
     }
   };
   auto write_rows = [&](int y0, int n) {
 #pragma unroll
     for (int i = 0; i < NCHX; ++i) {
-      const int cid = tid + 192 * i;
-      if (cid < n * chunks_per_row) {
-        const int r = cid / chunks_per_row, rem = cid - r * chunks_per_row;
-        const int px = rem >> 4, c8 = rem & 15;
-        int slot = (y0 + r - base_row) % (R + 2);
+      if (crow[i] < n) {
+        int slot = (y0 + crow[i] - base_row) % (R + 2);
         if (slot < 0) slot += R + 2;
-        U128 o;
-        if (pv[i]) {
-          U128 v;
-          v.u = pre[i];
+        U128 o, v;
+        v.u = pre[i];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[c8 * 8 + j], coef[128 + c8 * 8 + j]), 0.f));
-        } else {
-          o.u = make_uint4(0, 0, 0, 0);
-        }
-        const int pos = slot * P + px + 1;
-        *reinterpret_cast<uint4*>(ring + (size_t)pos * XP_FWD + c8 * 16) = o.u;
-        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * XP_FWD + c8 * 16) = o.u;   // mirror of pixels 0,1
+        for (int j = 0; j < 8; ++j)
+          o.e[j] = f2bf(pv[i] ? fmaxf(fmaf(bf2f(v.e[j]), coef[cc8[i] * 8 + j], coef[128 + cc8[i] * 8 + j]), 0.f) : 0.f);
+        const int pos = slot * P + cpx[i] + 1;
+        *reinterpret_cast<uint4*>(ring + (size_t)pos * XP_FWD + cc8[i] * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * XP_FWD + cc8[i] * 16) = o.u;   // mirror of pixels 0,1
       }
     }
   };
@@ -109,8 +110,7 @@ __global__ __launch_bounds__(192) void conv3x3_strip_fwd_kernel(const bf16* __re
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-  const int nsub = (R * P + 31) / 32;
-  float* my_scr = scratch + wave * 32 * 36;
+  const int nsub = (R * P + 31) / 32;           // <= 3
   bool have_window = false;
   int prev_b = -1, prev_yc = 0;
 
@@ -135,38 +135,42 @@ __global__ __launch_bounds__(192) void conv3x3_strip_fwd_kernel(const bf16* __re
     if (slot0 < 0) slot0 += R + 2;
     const int ws = slot0 * P;
 
-    for (int s = wave; s < nsub; s += 3) {
-      const int pix = min(s * 32 + (lane & 31), R * P - 1);
-      int aoff[3];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) aoff[dy] = wrapq(wrapq(ws + pix + dy * P, Q), Q) * XP_FWD + (lane >> 5) * 16;
+    for (int s = 0; s < nsub; ++s) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+      {
+        const int pix = min(s * 32 + (lane & 31), R * P - 1);
+        const char* ap = ring + wrapq(wrapq(ws + pix + wave * P, Q), Q) * XP_FWD + (lane >> 5) * 16;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
           for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ring + aoff[dy] + dx * XP_FWD + ks * 32);
-            const bf16x8 bw = *reinterpret_cast<const bf16x8*>(wl + ((((dy * 3 + dx) * 8 + ks) * 64) + lane) * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw, acc, 0, 0, 0);
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + dx * XP_FWD + ks * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[dx][ks], acc, 0, 0, 0);
           }
-      // ---- epilogue of the sub-tile: transpose through per-wave LDS scratch, 16-B stores along channels
+      }
+      // the three kernel-row partials meet in LDS; 128 threads sum / round / store 16 B each
+      float* my = scratch + wave * 1024;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) my_scr[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int pr = pass * 16 + (lane >> 2), c = lane & 3;
+      for (int r = 0; r < 16; ++r) my[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[r];
+      __syncthreads();
+      if (tid < 128) {
+        const int pr = tid >> 2, c = tid & 3;
         const int m = s * 32 + pr;
         const int oy = m / P, ox = m - oy * P;
         const int yy = yc + oy;
         if (m < R * P && ox < W && yy < H) {
-          const float4 v0 = *reinterpret_cast<const float4*>(my_scr + pr * 36 + c * 8);
-          const float4 v1 = *reinterpret_cast<const float4*>(my_scr + pr * 36 + c * 8 + 4);
-          const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) {
+            const float4 v0 = *reinterpret_cast<const float4*>(scratch + w3 * 1024 + pr * 32 + c * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(scratch + w3 * 1024 + pr * 32 + c * 8 + 4);
+            v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w;
+            v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
+          }
           U128 o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -178,9 +182,8 @@ __global__ __launch_bounds__(192) void conv3x3_strip_fwd_kernel(const bf16* __re
           *reinterpret_cast<uint4*>(y + ((size_t)(b * H + yy) * W + ox) * ldy + c * 8) = o.u;
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    __syncthreads();
     have_window = true;
     prev_b = b;
     prev_yc = yc;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(192) void conv3x3_strip_fwd_kernel(const bf16* __re
         s2[j] += __shfl_xor(s2[j], d);
       }
     }
-    if (lane < 4) {
+    if (lane < 4 && wave < 2) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         atomicAdd(&lstat[lane * 8 + j], s1[j]);
@@ -222,31 +225,30 @@ __device__ __forceinline__ bf16x8 tr2(const char* a0, const char* a1) {
   return r;
 }
 
-constexpr int NCHW = 4;         // 16-B chunks per thread and step, for the input rows and for the gradient rows
+constexpr int NCHW = 5;         // 16-B chunks per thread and step (192 threads), for the input rows and for the gradient rows
 constexpr int WP = 64;          // bytes per ring / strip pixel: 32 channels; rows of a half-wave hit disjoint bank quarters
 
-// Workgroup = (32-input-channel tile ct, pixel range).  The four waves split the 16-pixel k-steps of a
-// strip; each keeps 9 accumulator tiles (one per tap) of dW[32 n][32 c].  At the end the waves are summed
-// through LDS and added to the OIHW gradient with atomics over 1152-B contiguous runs per output channel.
-__global__ __launch_bounds__(256) void conv3x3_strip_wgrad_kernel(
+// Workgroup = (32-input-channel tile ct, pixel range), 3 waves: wave dy owns the three taps (dy, 0..2) of
+// dW[32 n][32 c] (48 accumulator registers), so nothing is reduced across waves and ~47 KB of LDS / ~170
+// VGPRs let 2-3 workgroups share a CU (their staging and MFMA phases overlap).  At the end the tile is
+// transposed through LDS and added to the OIHW gradient with atomics over 1152-B contiguous runs.
+__global__ __launch_bounds__(192) void conv3x3_strip_wgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
-    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const StripGeo g, const int n_splits) {
+    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const StripGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
   const int nk = (R * P + 15) / 16;
-  char* ring = smem;                                               // [(Q+2)][64 B]
+  float* coef = reinterpret_cast<float*>(smem);                    // pa[32] pb[32] ga[32] gb[32] gc[32]
+  char* ring = smem + 160 * 4;                                     // [(Q+2)][64 B]
   char* gst = ring + (size_t)(Q + 2) * WP;                         // [nk*16][64 B]
-  float* coef = reinterpret_cast<float*>(gst + (size_t)nk * 16 * WP);   // pa[32] pb[32] ga[32] gb[32] gc[32]
-  float* red = coef + 160;                                         // [9][32][32] final cross-wave sum
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* red = reinterpret_cast<float*>(ring);                     // [32 n][32 c][9] aliased on ring+strip at the end
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave = kernel row dy
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int ct = wg & 3, split = wg >> 2;                          // the 4 channel tiles of a pixel range are neighbours
   const int c0 = ct * 32;
 
-  for (int i = tid; i < (Q + 2) * (WP / 16); i += 256) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < nk * 16 * (WP / 16); i += 256) reinterpret_cast<uint4*>(gst)[i] = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < 9 * 32 * 32; i += 256) red[i] = 0.f;
+  for (int i = tid; i < ((Q + 2) + nk * 16) * (WP / 16); i += 192) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
   if (tid < 32) {
     coef[tid] = pa[c0 + tid];
     coef[32 + tid] = pb[c0 + tid];
@@ -264,92 +266,73 @@ __global__ __launch_bounds__(256) void conv3x3_strip_wgrad_kernel(
   uint4 pre[NCHW], pg[NCHW], pg2[NCHW];
   bool pv[NCHW], gv[NCHW];
   int base_row = 0;
+  int crow[NCHW], cpx[NCHW], cc8[NCHW];
+#pragma unroll
+  for (int i = 0; i < NCHW; ++i) {
+    const int cid = tid + 192 * i;
+    crow[i] = cid / cpr;
+    const int rem = cid - crow[i] * cpr;
+    cpx[i] = rem >> 2;
+    cc8[i] = rem & 3;
+  }
+  // unconditional loads on clamped addresses; validity applied when staging (see forward kernel)
   auto issue_rows = [&](int b, int y0, int n) {
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      const int cid = tid + 256 * i;
-      pv[i] = false;
-      if (cid < n * cpr) {
-        const int r = cid / cpr, rem = cid - r * cpr;
-        const int px = rem >> 2, c8 = rem & 3, yy = y0 + r;
-        if (yy >= 0 && yy < H) {
-          pv[i] = true;
-          pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yy) * W + px) * ldx + c0 + c8 * 8);
-        }
-      }
+      const int yy = y0 + crow[i];
+      pv[i] = crow[i] < n && yy >= 0 && yy < H;
+      const int yc_ = min(max(yy, 0), H - 1);
+      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + cpx[i]) * ldx + c0 + cc8[i] * 8);
     }
   };
   auto write_rows = [&](int y0, int n) {
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      const int cid = tid + 256 * i;
-      if (cid < n * cpr) {
-        const int r = cid / cpr, rem = cid - r * cpr;
-        const int px = rem >> 2, c8 = rem & 3;
-        int slot = (y0 + r - base_row) % (R + 2);
+      if (crow[i] < n) {
+        int slot = (y0 + crow[i] - base_row) % (R + 2);
         if (slot < 0) slot += R + 2;
-        U128 o;
-        if (pv[i]) {
-          U128 v;
-          v.u = pre[i];
+        U128 o, v;
+        v.u = pre[i];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[c8 * 8 + j], coef[32 + c8 * 8 + j]), 0.f));
-        } else {
-          o.u = make_uint4(0, 0, 0, 0);
-        }
-        const int pos = slot * P + px + 1;
-        *reinterpret_cast<uint4*>(ring + (size_t)pos * WP + c8 * 16) = o.u;
-        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * WP + c8 * 16) = o.u;   // mirror of pixels 0,1
+        for (int j = 0; j < 8; ++j)
+          o.e[j] = f2bf(pv[i] ? fmaxf(fmaf(bf2f(v.e[j]), coef[cc8[i] * 8 + j], coef[32 + cc8[i] * 8 + j]), 0.f) : 0.f);
+        const int pos = slot * P + cpx[i] + 1;
+        *reinterpret_cast<uint4*>(ring + (size_t)pos * WP + cc8[i] * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * WP + cc8[i] * 16) = o.u;   // mirror of pixels 0,1
       }
     }
   };
   auto issue_g = [&](int b, int yc) {
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      const int cid = tid + 256 * i;
-      gv[i] = false;
-      if (cid < R * cpr) {
-        const int r = cid / cpr, rem = cid - r * cpr;
-        const int px = rem >> 2, c8 = rem & 3, yy = yc + r;
-        if (yy < H) {
-          gv[i] = true;
-          const size_t pixel = (size_t)(b * H + yy) * W + px;
-          pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + c8 * 8);
-          if (g_affine2) pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + c8 * 8);
-        }
-      }
+      const int yy = yc + crow[i];
+      gv[i] = crow[i] < R && yy < H;
+      const int yc_ = min(yy, H - 1);
+      const size_t pixel = (size_t)(b * H + yc_) * W + cpx[i];
+      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + cc8[i] * 8);
+      if (g_affine2) pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + cc8[i] * 8);
     }
   };
   auto write_g = [&]() {
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      const int cid = tid + 256 * i;
-      if (cid < R * cpr) {
-        const int r = cid / cpr, rem = cid - r * cpr;
-        const int px = rem >> 2, c8 = rem & 3;
-        U128 o;
-        if (gv[i]) {
-          U128 u, v;
-          u.u = pg[i];
-          if (g_affine2) {
-            v.u = pg2[i];
+      if (crow[i] < R) {
+        U128 o, u, v;
+        u.u = pg[i];
+        v.u = g_affine2 ? pg2[i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              o.e[j] = f2bf(fmaf(bf2f(u.e[j]), coef[64 + c8 * 8 + j], fmaf(bf2f(v.e[j]), coef[96 + c8 * 8 + j], coef[128 + c8 * 8 + j])));
-          } else {
-            o.u = u.u;
-          }
-        } else {
-          o.u = make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < 8; ++j) {
+          const float t = fmaf(bf2f(u.e[j]), coef[64 + cc8[i] * 8 + j], fmaf(bf2f(v.e[j]), coef[96 + cc8[i] * 8 + j], coef[128 + cc8[i] * 8 + j]));
+          o.e[j] = f2bf(gv[i] ? t : 0.f);
         }
-        *reinterpret_cast<uint4*>(gst + (size_t)(r * P + px) * WP + c8 * 16) = o.u;   // pad columns / tail stay zero
+        *reinterpret_cast<uint4*>(gst + (size_t)(crow[i] * P + cpx[i]) * WP + cc8[i] * 16) = o.u;   // pad columns / tail stay zero
       }
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[3];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -383,28 +366,22 @@ __global__ __launch_bounds__(256) void conv3x3_strip_wgrad_kernel(
     int slot0 = (yc - 1 - base_row) % (R + 2);
     if (slot0 < 0) slot0 += R + 2;
     const int ws = slot0 * P;
-    // running byte offsets (pixel part) of this lane's two pixel rows for the three kernel rows dy
-    int o0[3], o1[3];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      o0[dy] = wrapq(wrapq(ws + 16 * wave + lrow + dy * P, Q), Q) * WP;
-      o1[dy] = wrapq(wrapq(ws + 16 * wave + lrow + 4 + dy * P, Q), Q) * WP;
-    }
-    for (int kk = wave; kk < nk; kk += 4) {
+    // running byte offsets of this lane's two pixel rows in kernel row dy = wave
+    int o0 = wrapq(wrapq(ws + lrow + wave * P, Q), Q) * WP;
+    int o1 = wrapq(wrapq(ws + lrow + 4 + wave * P, Q), Q) * WP;
+#pragma unroll 2
+    for (int kk = 0; kk < nk; ++kk) {
       const char* gbase = gst + (size_t)(kk * 16 + lrow) * WP + gcol;
       const bf16x8 af = tr2(gbase, gbase + 4 * WP);
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const bf16x8 bfr = tr2(ring + o0[dy] + gcol + dx * WP, ring + o1[dy] + gcol + dx * WP);
-          acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[dy * 3 + dx], 0, 0, 0);
-        }
-        o0[dy] += 64 * WP;
-        if (o0[dy] >= QB) o0[dy] -= QB;
-        o1[dy] += 64 * WP;
-        if (o1[dy] >= QB) o1[dy] -= QB;
+      for (int dx = 0; dx < 3; ++dx) {
+        const bf16x8 bfr = tr2(ring + o0 + gcol + dx * WP, ring + o1 + gcol + dx * WP);
+        acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[dx], 0, 0, 0);
       }
+      o0 += 16 * WP;
+      if (o0 >= QB) o0 -= QB;
+      o1 += 16 * WP;
+      if (o1 >= QB) o1 -= QB;
     }
     __syncthreads();
     have_window = true;
@@ -412,21 +389,19 @@ __global__ __launch_bounds__(256) void conv3x3_strip_wgrad_kernel(
     prev_yc = yc;
   }
 
-  // ---- sum the four waves through LDS, then atomics over contiguous OIHW runs
+  // ---- transpose through LDS into OIHW order, then atomics over contiguous runs (288 floats per output channel)
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      atomicAdd(&red[(t * 32 + n) * 32 + (lane & 31)], acc[t][r]);
+      red[(n * 32 + (lane & 31)) * 9 + wave * 3 + dx] = acc[dx][r];
     }
   __syncthreads();
-  for (int idx = tid; idx < 32 * 288; idx += 256) {
+  for (int idx = tid; idx < 32 * 288; idx += 192) {
     const int n = idx / 288, i = idx - n * 288;
-    const int c = i / 9, t = i - c * 9;
-    atomicAdd(dw + ((size_t)n * 128 + c0) * 9 + i, red[(t * 32 + n) * 32 + c]);
+    atomicAdd(dw + ((size_t)n * 128 + c0) * 9 + i, red[idx]);
   }
-  (void)n_splits;
 }
 
 inline StripGeo make_geo(int B, int H, int W, int target_wgs, int min_steps, int max_flat) {
@@ -453,14 +428,14 @@ int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1) return 0;
   if (p.K != 128 || p.N != 32 || p.prologue != CX_PRO_AFFINE_RELU || p.epilogue != CX_EPI_STORE) return 0;
   if (p.W + 2 > 96 || p.W < 4) return 0;
-  StripGeo g = make_geo(p.B, p.H, p.W, 256, 4, 96);
+  StripGeo g = make_geo(p.B, p.H, p.W, 512, 4, 96);      // >= 2 workgroups per CU
   if (g.R * p.W * 16 > NCHX * 192) return 0;
-  const size_t smem = 9 * 8 * 64 * 16 + (size_t)(g.Q + 2) * XP_FWD + 256 * 4 + 64 * 4 + 3 * 32 * 36 * 4;
-  if (smem > 160 * 1024) return 0;
+  const size_t smem = (256 + 64 + 3 * 1024) * 4 + (size_t)(g.Q + 2) * XP_FWD;
+  if (smem > 80 * 1024) return 0;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+                              80 * 1024);
     attr = true;
   }
   const int total = g.B * g.spi;
@@ -477,27 +452,22 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   if (p.K != 128 || p.N != 32 || p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
   if (p.g_prologue != CX_PRO_NONE && p.g_prologue != CX_PRO_AFFINE2) return 0;
   if (p.W + 2 > 128 || p.W < 4) return 0;
-  // pixel-range splits: enough workgroups to fill the chip, few enough that the final atomics stay small
+  // pixel-range splits: >= 2 workgroups per CU over the 4 channel tiles, few enough that the final atomics
+  // (147 KB per split) stay small next to the activations (384 B per pixel)
   const long long px = (long long)p.B * p.H * p.W;
-  int target = (int)(px / 12800);
-  if (target < 8) target = 8;
-  if (target > 128) target = 128;
-  StripGeo g = make_geo(p.B, p.H, p.W, target, 2, 256);
-  if (g.R * p.W * 4 > NCHW * 256 || g.Q < 64) return 0;
+  int target = (int)(px / 3200);
+  if (target < 64) target = 64;
+  if (target > 192) target = 192;
+  StripGeo g = make_geo(p.B, p.H, p.W, target, 1, 256);
+  if (g.R * p.W * 4 > NCHW * 192 || 2 * p.W * 4 > NCHW * 192 || g.Q < 16) return 0;
   const int nk = (g.R * g.P + 15) / 16;
-  const size_t smem = (size_t)(g.Q + 2) * WP + (size_t)nk * 16 * WP + 160 * 4 + 9 * 32 * 32 * 4;
-  if (smem > 160 * 1024) return 0;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr = true;
-  }
+  size_t smem = 160 * 4 + (size_t)(g.Q + 2) * WP + (size_t)nk * 16 * WP;
+  if (smem < 160 * 4 + 32 * 288 * 4) smem = 160 * 4 + 32 * 288 * 4;
+  if (smem > 64 * 1024) return 0;
   const int total = g.B * g.spi;
   const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
-  hipLaunchKernelGGL(conv3x3_strip_wgrad_kernel, dim3(splits * 4), dim3(256), smem, st, (const bf16*)p.g, p.ldg, (const bf16*)p.g2,
-                     p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx, p.pa, p.pb, p.dw, g,
-                     splits);
+  hipLaunchKernelGGL(conv3x3_strip_wgrad_kernel, dim3(splits * 4), dim3(192), smem, st, (const bf16*)p.g, p.ldg, (const bf16*)p.g2,
+                     p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx, p.pa, p.pb, p.dw, g);
   *handled = true;
   return launch_status();
 }

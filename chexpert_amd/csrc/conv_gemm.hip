@@ -95,8 +95,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
   const bf16* __restrict__ Wp = reinterpret_cast<const bf16*>(p.w);
 
   uint4 ra[2][NSRC], ra2[2], rbw[2];
-  bool av[2];
+  bool av[2], wv[2] = {false, false};
 
+  // NOTE: every global load below is UNCONDITIONAL (invalid rows read a clamped, in-bounds address and are
+  // zeroed when staged).  A branch around a load makes hipcc wait vmcnt(0) per load (cdna_hip_programming.md,
+  // "Three .s-level traps" (c)), which serialises the whole prefetch.
   auto issue_loads = [&](int s) {
     const int tap = s / kpt, kc = s - tap * kpt;
     const int dy = (MODE == CX_MODE_CONV) ? tap / p.kw : tap;
@@ -106,38 +109,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
       if (MODE == CX_MODE_STEM) {
         const int iy = riy[i] + dy, ix = rix[i];
         av[i] = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        if (av[i]) ra[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(rb[i] * p.H + iy) * p.W + ix) * 4);
+        const int cy = av[i] ? iy : 0, cx = av[i] ? ix : 0;
+        ra[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(rb[i] * p.H + cy) * p.W + cx) * 4);
       } else if (MODE == CX_MODE_POOL2) {
         av[i] = rvalid[i];
-        if (av[i]) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const size_t pix = (size_t)(rb[i] * p.H + riy[i] + (a >> 1)) * p.W + rix[i] + (a & 1);
-            ra[i][a] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
-          }
+        for (int a = 0; a < 4; ++a) {
+          const size_t pix = (size_t)(rb[i] * p.H + riy[i] + (a >> 1)) * p.W + rix[i] + (a & 1);
+          ra[i][a] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
         }
       } else {
         const int iy = riy[i] + dy, ix = rix[i] + dx;
         av[i] = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        if (av[i]) {
-          const size_t pix = (size_t)(rb[i] * p.H + iy) * p.W + ix;
-          ra[i][0] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
-          if (PRO == CX_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(X2 + pix * p.ldx2 + kc * BK + qa * 8);
-        }
+        const int cy = av[i] ? iy : 0, cx = av[i] ? ix : 0;
+        const size_t pix = (size_t)(rb[i] * p.H + cy) * p.W + cx;
+        ra[i][0] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
+        if (PRO == CX_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(X2 + pix * p.ldx2 + kc * BK + qa * 8);
       }
     }
     // weights: rows n = tid>>2 (+64), chunk qa
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int nb = (tid >> 2) + 64 * i;
-      if (nb < BN) {
+      if (nb < BN) {                       // compile-time per (i, BN) except BN=32 (uniform per wave)
         const int n = n0 + nb;
-        if (n < p.N) {
-          const size_t off = ((size_t)tap * p.N + n) * (size_t)(MODE == CX_MODE_STEM ? BK : p.K) + kc * BK + qa * 8;
-          rbw[i] = *reinterpret_cast<const uint4*>(Wp + off);
-        } else {
-          rbw[i] = make_uint4(0, 0, 0, 0);
-        }
+        wv[i] = n < p.N;
+        const int nc = wv[i] ? n : 0;
+        const size_t off = ((size_t)tap * p.N + nc) * (size_t)(MODE == CX_MODE_STEM ? BK : p.K) + kc * BK + qa * 8;
+        rbw[i] = *reinterpret_cast<const uint4*>(Wp + off);
       }
     }
   };
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int nb = (tid >> 2) + 64 * i;
-      if (nb < BN) *reinterpret_cast<uint4*>(Bt + nb * PITCH + qa * 16) = rbw[i];
+      if (nb < BN) *reinterpret_cast<uint4*>(Bt + nb * PITCH + qa * 16) = wv[i] ? rbw[i] : make_uint4(0, 0, 0, 0);
     }
     (void)tap;
   };
@@ -269,6 +268,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
     for (int pass = 0; pass < 64 / RPP; ++pass) {
       const int row = pass * RPP + rr;
       const int m = mt * BM + half * 64 + row;
+      U128 xv, old;
+      if (EPI == CX_EPI_MASK) {          // unconditional, clamped loads (no branch around a load)
+        const int mc = m < M ? m : M - 1;
+        const int ncl = nvalid ? nch : 0;
+        xv.u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl);
+        if (p.accumulate) old.u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl);
+      }
       if (m < M && nvalid) {
         const float4 v0 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8 + 4);
@@ -283,9 +289,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
             s2[j] += rv * rv;
           }
         } else {
-          U128 xv, old;
-          xv.u = *reinterpret_cast<const uint4*>(EX + (size_t)m * p.ldex + nch);
-          if (p.accumulate) old.u = *reinterpret_cast<const uint4*>(Y + (size_t)m * p.ldy + nch);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float xf = bf2f(xv.e[j]);

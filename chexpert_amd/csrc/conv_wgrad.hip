@@ -110,40 +110,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const CxWgrad p, const int M
   int nsteps = (M + PX - 1) / PX - step0;
   if (nsteps > steps_per_split) nsteps = steps_per_split;
 
+  // every load is unconditional on a clamped in-bounds address (a branch around a load serialises the prefetch)
   auto issue_loads = [&](int s) {
     const int mbase = (step0 + s) * PX;
 #pragma unroll
     for (int i = 0; i < G::G_PER; ++i) {
       const int m = mbase + grow[i];
       gv[i] = gact[i] && m < M;
-      if (gv[i]) {
-        rg[i] = *reinterpret_cast<const uint4*>(Gp + (size_t)m * p.ldg + n0 + gcq[i] * 8);
-        if (GPRO == CX_PRO_AFFINE2) rg2[i] = *reinterpret_cast<const uint4*>(G2 + (size_t)m * p.ldg2 + n0 + gcq[i] * 8);
-      }
+      const int mc = m < M ? m : M - 1;
+      const int nc = gact[i] ? n0 + gcq[i] * 8 : 0;
+      rg[i] = *reinterpret_cast<const uint4*>(Gp + (size_t)mc * p.ldg + nc);
+      if (GPRO == CX_PRO_AFFINE2) rg2[i] = *reinterpret_cast<const uint4*>(G2 + (size_t)mc * p.ldg2 + nc);
     }
 #pragma unroll
     for (int i = 0; i < G::X_PER; ++i) {
       const int m = mbase + xrow[i];
-      xv[i] = xact[i] && m < M;
-      if (xv[i]) {
-        const int b = m / hw;
-        const int rem = m - b * hw;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        if (MODE == CX_MODE_STEM) {
-          const int iy = 2 * oy - 3 + dy, ix = 2 * ox - 4 + 2 * xcq[i];
-          xv[i] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-          if (xv[i]) rx[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * p.H + iy) * p.W + ix) * 4);
-        } else if (MODE == CX_MODE_POOL2) {
+      const int mc = m < M ? m : M - 1;
+      const int b = mc / hw;
+      const int rem = mc - b * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int cc = xact[i] ? c0 + xcq[i] * 8 : 0;
+      if (MODE == CX_MODE_STEM) {
+        const int iy = 2 * oy - 3 + dy, ix = 2 * ox - 4 + 2 * xcq[i];
+        xv[i] = xact[i] && m < M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int cy = xv[i] ? iy : 0, cx = xv[i] ? ix : 0;
+        rx[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * p.H + cy) * p.W + cx) * 4);
+      } else if (MODE == CX_MODE_POOL2) {
+        xv[i] = xact[i] && m < M;
 #pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const size_t pix = (size_t)(b * p.H + 2 * oy + (a >> 1)) * p.W + 2 * ox + (a & 1);
-            rx[i][a] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + c0 + xcq[i] * 8);
-          }
-        } else {
-          const int iy = oy * p.stride - p.pad + dy, ix = ox * p.stride - p.pad + dx;
-          xv[i] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-          if (xv[i]) rx[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * p.H + iy) * p.W + ix) * p.ldx + c0 + xcq[i] * 8);
+        for (int a = 0; a < 4; ++a) {
+          const size_t pix = (size_t)(b * p.H + 2 * oy + (a >> 1)) * p.W + 2 * ox + (a & 1);
+          rx[i][a] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + cc);
         }
+      } else {
+        const int iy = oy * p.stride - p.pad + dy, ix = ox * p.stride - p.pad + dx;
+        xv[i] = xact[i] && m < M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int cy = xv[i] ? iy : 0, cx = xv[i] ? ix : 0;
+        rx[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * p.H + cy) * p.W + cx) * p.ldx + cc);
       }
     }
   };
