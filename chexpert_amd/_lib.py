@@ -68,6 +68,8 @@ SIGNATURES = {
     "cx_adam_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp],
     "cx_sgd_nesterov_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _f, _vp],
     "cx_rmsprop_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp],
+    "cx_gradcam_map": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_cam_norm_upsample": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_fill_f32": [_vp, _f, _sz, _vp],
     "cx_bf16_to_f32_nchw": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
 }

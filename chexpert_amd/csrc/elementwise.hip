@@ -497,6 +497,54 @@ __global__ void bf16_to_f32_nchw_kernel(const bf16* __restrict__ x, float* __res
   y[idx] = bf2f(x[(b * HW + p) * ldx + c]);
 }
 
+// Grad-CAM: cam[b][p] = relu(sum_c w[c] * relu(x[b][p][c]*sc[c]+sh[c]))   (chexpert.py:283-285 as executed)
+__global__ void gradcam_map_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                   const float* __restrict__ w, float* __restrict__ cam, size_t npix, int C, int ldx) {
+  const int lane = threadIdx.x & 63;
+  const size_t pix = (size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  float acc = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    U128 v;
+    v.u = *reinterpret_cast<const uint4*>(x + pix * ldx + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += w[c + j] * fmaxf(fmaf(bf2f(v.e[j]), sc[c + j], sh[c + j]), 0.f);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if (lane == 0) cam[pix] = fmaxf(acc, 0.f);
+}
+
+// per image: (t - min) / (max - min + 1e-5), then bilinear upsample with align_corners=True (chexpert.py:289-296)
+__global__ void cam_norm_upsample_kernel(const float* __restrict__ cam, float* __restrict__ out, int h, int w, int H, int W) {
+  __shared__ float smin[256], smax[256];
+  const int b = blockIdx.x;
+  const float* c = cam + (size_t)b * h * w;
+  float mn = 3.4e38f, mx = -3.4e38f;
+  for (int i = threadIdx.x; i < h * w; i += blockDim.x) { mn = fminf(mn, c[i]); mx = fmaxf(mx, c[i]); }
+  smin[threadIdx.x] = mn; smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) { smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]); smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]); }
+    __syncthreads();
+  }
+  mn = smin[0]; mx = smax[0];
+  const float inv = 1.f / (mx - mn + 1e-5f);
+  const float ry = H > 1 ? (float)(h - 1) / (H - 1) : 0.f, rx = W > 1 ? (float)(w - 1) / (W - 1) : 0.f;
+  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+    const int Y = i / W, X = i - Y * W;
+    const float fy = Y * ry, fx = X * rx;
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > h - 1) y0 = h - 1;
+    if (x0 > w - 1) x0 = w - 1;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float v00 = (c[y0 * w + x0] - mn) * inv, v01 = (c[y0 * w + x1] - mn) * inv;
+    const float v10 = (c[y1 * w + x0] - mn) * inv, v11 = (c[y1 * w + x1] - mn) * inv;
+    out[(size_t)b * H * W + i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  }
+}
+
 inline int grid_for(size_t n, int block, int cap = 4096) {
   size_t g = (n + block - 1) / block;
   if (g > (size_t)cap) g = cap;
@@ -683,6 +731,21 @@ int cx_rmsprop_step(float* p, const float* g, float* sq, float* buf, size_t n, f
   if (!p || !g || !sq || (momentum > 0.f && !buf)) return CX_EINVAL;
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, g, sq, buf, n, lr, alpha, eps,
                      momentum, weight_decay, grad_scale);
+  return launch_status();
+}
+
+int cx_gradcam_map(const void* x, const float* scale, const float* shift, const float* w, float* cam, int B, int HW, int C, int ldx,
+                   void* stream) {
+  if (!x || !scale || !shift || !w || !cam || C % 8 || ldx % 8) return CX_EINVAL;
+  const size_t npix = (size_t)B * HW;
+  hipLaunchKernelGGL(gradcam_map_kernel, dim3((npix + 3) / 4), dim3(256), 0, as_stream(stream), (const bf16*)x, scale, shift, w, cam, npix,
+                     C, ldx);
+  return launch_status();
+}
+
+int cx_cam_norm_upsample(const float* cam, float* out, int B, int h, int w, int H, int W, void* stream) {
+  if (!cam || !out || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(cam_norm_upsample_kernel, dim3(B), dim3(256), 0, as_stream(stream), cam, out, h, w, H, W);
   return launch_status();
 }
 

@@ -184,6 +184,13 @@ int cx_sgd_nesterov_step(float* p, const float* g, float* buf, size_t n, float l
 int cx_rmsprop_step(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha, float eps,
                     float momentum, float weight_decay, float grad_scale, void* stream);
 
+/* Grad-CAM as the reference code executes it (chexpert.py:260-303):
+ * cam[b][p] = relu(sum_c w[c]*relu(x*scale+shift)) with class-independent w[c] = mean_b pooled[b][c]*B/n_cls,
+ * then per-image (t-min)/(max-min+1e-5) and bilinear upsampling with align_corners=True.            */
+int cx_gradcam_map(const void* x, const float* scale, const float* shift, const float* w, float* cam, int B, int HW, int C,
+                   int ldx, void* stream);
+int cx_cam_norm_upsample(const float* cam, float* out, int B, int h, int w, int H, int W, void* stream);
+
 /* utilities */
 int cx_fill_f32(float* p, float v, size_t n, void* stream);
 int cx_bf16_to_f32_nchw(const void* x, float* y, int B, int H, int W, int C, int ldx, void* stream);

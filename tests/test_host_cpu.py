@@ -109,3 +109,49 @@ def test_gradient_reducer_world2_gloo(tmp_path):
                         "127.0.0.1", "--master-port", "29533", str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_product_auroc_matches_sklearn_fixture():
+    """chexpert_amd.metrics (product, host-side) against the sklearn outputs recorded through the reference's
+    compute_metrics (tests/golden/auroc.json)."""
+    import json
+    import warnings
+    import numpy as np
+    from chexpert_amd import metrics, synth
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "auroc.json")))
+    for c in cases.values():
+        logits = synth.uniform(c["seed"], (c["n"], c["c"]), -3, 3).numpy().astype(np.float64)
+        tg = synth.targets(c["seed"] + 100, c["n"], c["c"], p=0.35).numpy()
+        if c["variant"] == 1:
+            logits = np.round(logits)
+        if c["variant"] == 2:
+            tg[:, 1] = 0
+            tg[:, 3] = 1
+        if c["variant"] == 3:
+            logits[:, 0] = 0.25
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = metrics.compute_metrics(logits, tg, np.zeros_like(tg))
+        for i, want in enumerate(c["aucs"]):
+            assert (np.isnan(m["aucs"][i]) if want is None else abs(m["aucs"][i] - want) < 1e-12)
+        assert abs(metrics.mean_auc(m) - c["nanmean"]) < 1e-12
+        assert set(m) == {"fpr", "tpr", "aucs", "precision", "recall", "loss"}
+
+
+def test_cli_flags_and_checkpoint_tracker(tmp_path):
+    from chexpert_amd import cli
+    a = cli.build_parser().parse_args([])
+    assert (a.batch_size, a.lr, a.n_epochs, a.log_interval, a.eval_interval, a.lr_decay_factor, a.model) == \
+        (16, 1e-4, 1, 50, 300, 0.97, "densenet121")                     # defaults of chexpert.py:29-57
+    assert cli.build_parser().parse_args(["--evaluate"]).evaluate_single_model
+    # tracker keeps the 3 best by AvgAUC, re-using the evicted record's file id (chexpert.py:106-123)
+    import numpy as np
+    args = cli.build_parser().parse_args(["--output_dir", str(tmp_path)])
+    for step, aucv in enumerate([0.70, 0.80, 0.60, 0.75, 0.90, 0.50], 1):
+        args.step = step
+        cli.save_checkpoint({"global_step": step, "eval_loss": 1.0, "avg_auc": aucv, "state_dict": {}}, {}, None, args,
+                            max_records=3)
+    rec = np.loadtxt(os.path.join(str(tmp_path), "checkpoints_tracker.csv"), skiprows=1)
+    assert rec[:, 3].tolist() == [0.90, 0.80, 0.75]
+    assert sorted(rec[:, 0].astype(int).tolist()) == [0, 1, 2]
+    assert sorted(os.listdir(os.path.join(str(tmp_path), "best_checkpoints"))) == ["checkpoint_0.pt", "checkpoint_1.pt", "checkpoint_2.pt"]

@@ -177,3 +177,30 @@ def test_cpu_tensor_raises(dev):
     m = DenseNet(32, (2, 2, 2, 2), 64, num_classes=5)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 64, 64))
+
+
+def test_grad_cam_matches_reference_fixture_and_oracle(dev):
+    """Grad-CAM maps recorded by running the reference's own grad_cam (tests/golden/gradcam.npz)."""
+    import numpy as np
+    from chexpert_amd.gradcam import grad_cam
+    cam_ref = torch.from_numpy(np.load(os.path.join(G, "gradcam.npz"))["cam"])
+    cfg = (2, 2, 2, 2)
+    model, sd = _build(cfg, 5, 21, dev)
+    x = synth.xray_batch(77, 3, 64)
+    cam = grad_cam(model, x.to(dev)).cpu()
+    assert cam.shape == cam_ref.shape == (3, 1, 64, 64)
+    err = (cam - cam_ref).abs().max().item()
+    print("grad-cam max abs err vs reference fixture: %.3e" % err)
+    assert err < 3e-2                      # maps are normalised to [0,1]; bf16 feature storage
+    assert float(cam.max()) <= 1.0 + 1e-5 and float(cam.min()) >= 0.0
+
+
+def test_cli_train_eval_synthetic(dev, tmp_path):
+    from chexpert_amd import cli
+    cli.main(["--train", "--evaluate", "--visualize", "--synthetic", "16", "--batch_size", "4", "--resize", "64",
+              "--output_dir", str(tmp_path), "--eval_interval", "2", "--log_interval", "1", "--fused_optimizer"])
+    files = os.listdir(str(tmp_path))
+    assert "checkpoint_latest.pt" in files and "checkpoints_tracker.csv" in files and "config.json" in files
+    assert any(f.startswith("eval_results_step_") for f in files)
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint_latest.pt"))
+    assert set(ck) == {"global_step", "eval_loss", "avg_auc", "state_dict"} and len(ck["state_dict"]) == 727
