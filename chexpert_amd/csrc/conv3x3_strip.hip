@@ -213,6 +213,221 @@ __global__ __launch_bounds__(192, 2) void conv3x3_strip_fwd_kernel(const bf16* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------ input gradient
+// dz2[m][128] = mask(y1) * sum_taps dY2[m @ tap][32] * Wt[tap][128][32]   (K = 9 x 32, N = 128)
+// Same skeleton as the forward kernel: wave dy holds its three taps x four 32-channel output tiles in
+// registers (24 fragments), the ring holds the 32-channel gradient slice after the deferred BN correction
+// (AFFINE2 of the gradient buffer slice and the activation slice), the three partial 32 px x 128 ch tiles meet
+// in LDS where the ReLU/BN mask epilogue (CX_EPI_MASK) runs with 16-B accesses; y1 is prefetched under the MFMAs.
+constexpr int GP = 80;          // ring pitch: 32 bf16 + 16 B pad (20 banks: conflict-free ds_read_b128 over 32 pixels)
+constexpr int NCHD = 2;         // 16-B chunks of new gradient rows per thread and step (per tensor)
+
+__global__ __launch_bounds__(192, 2) void conv3x3_strip_dgrad_kernel(
+    const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
+    const float* __restrict__ gb, const float* __restrict__ gc, const bf16* __restrict__ wpk, const bf16* __restrict__ ex, int ldex,
+    const float* __restrict__ e_sc, const float* __restrict__ e_sh, const float* __restrict__ e_mu, const float* __restrict__ e_r,
+    const float* __restrict__ e_scale, bf16* __restrict__ y, int ldy, float* S1, float* S2, const StripGeo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);                // ga gb gc [32] each (96) + pad
+  float* lstat = coef + 128;                                   // [2][128]
+  float* econst = lstat + 256;                                 // e_sc, e_sh, e_mu, e_r, e_scale [128] each
+  float* scratch = econst + 640;                               // [3 waves][32 px][128 ch]
+  char* ring = reinterpret_cast<char*>(scratch + 3 * 4096);    // [(Q+2)][80 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
+
+  bf16x8 wr[3][2][4];                                          // [dx][ks][n-tile]
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        wr[dx][ks][nt] = *reinterpret_cast<const bf16x8*>(wpk + ((size_t)((wave * 3 + dx) * 128 + nt * 32 + (lane & 31)) * 32 + ks * 16 + (lane >> 5) * 8));
+  for (int i = tid; i < (Q + 2) * (GP / 16); i += 192) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 32) { coef[tid] = ga[tid]; coef[32 + tid] = gb[tid]; coef[64 + tid] = gc[tid]; }
+  for (int i = tid; i < 256; i += 192) lstat[i] = 0.f;
+  // epilogue constants of this thread's fixed 8-channel chunk
+  const int ec = (tid & 15) * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (tid < 128) {
+    econst[tid] = e_sc[tid]; econst[128 + tid] = e_sh[tid]; econst[256 + tid] = e_mu[tid]; econst[384 + tid] = e_r[tid];
+    econst[512 + tid] = e_scale[tid];
+  }
+  __syncthreads();
+
+  const int total_steps = g.B * g.spi;
+  const int u0 = blockIdx.x * g.steps_per_wg;
+  const int u1 = min(total_steps, u0 + g.steps_per_wg);
+  const int cpr = W * 4;
+
+  uint4 pg[NCHD], pg2[NCHD];
+  bool gv[NCHD];
+  int base_row = 0;
+  int crow[NCHD], cpx[NCHD], cc8[NCHD];
+#pragma unroll
+  for (int i = 0; i < NCHD; ++i) {
+    const int cid = tid + 192 * i;
+    crow[i] = cid / cpr;
+    const int rem = cid - crow[i] * cpr;
+    cpx[i] = rem >> 2;
+    cc8[i] = rem & 3;
+  }
+  auto issue_rows = [&](int b, int y0, int n) {
+#pragma unroll
+    for (int i = 0; i < NCHD; ++i) {
+      const int yy = y0 + crow[i];
+      gv[i] = crow[i] < n && yy >= 0 && yy < H;
+      const int yc_ = min(max(yy, 0), H - 1);
+      const size_t pixel = (size_t)(b * H + yc_) * W + cpx[i];
+      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + cc8[i] * 8);
+      pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + cc8[i] * 8);
+    }
+  };
+  auto write_rows = [&](int y0, int n) {
+#pragma unroll
+    for (int i = 0; i < NCHD; ++i) {
+      if (crow[i] < n) {
+        int slot = (y0 + crow[i] - base_row) % (R + 2);
+        if (slot < 0) slot += R + 2;
+        U128 o, u, v;
+        u.u = pg[i];
+        v.u = pg2[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = fmaf(bf2f(u.e[j]), coef[cc8[i] * 8 + j], fmaf(bf2f(v.e[j]), coef[32 + cc8[i] * 8 + j], coef[64 + cc8[i] * 8 + j]));
+          o.e[j] = f2bf(gv[i] ? t : 0.f);
+        }
+        const int pos = slot * P + cpx[i] + 1;
+        *reinterpret_cast<uint4*>(ring + (size_t)pos * GP + cc8[i] * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * GP + cc8[i] * 16) = o.u;
+      }
+    }
+  };
+
+  const int nsub = (R * P + 31) / 32;
+  bool have_window = false;
+  int prev_b = -1, prev_yc = 0;
+
+  for (int u = u0; u < u1; ++u) {
+    const int b = u / g.spi, yc = (u - b * g.spi) * R;
+    const bool cont = have_window && b == prev_b && yc == prev_yc + R;
+    if (!cont) {
+      __syncthreads();
+      base_row = yc - 1;
+      issue_rows(b, yc - 1, 1);
+      write_rows(yc - 1, 1);
+      issue_rows(b, yc, 1);
+      write_rows(yc, 1);
+      issue_rows(b, yc + 1, R);
+    }
+    write_rows(yc + 1, R);
+    __syncthreads();
+    const bool next_cont = (u + 1 < u1) && ((u + 1) / g.spi == b);
+    if (next_cont) issue_rows(b, yc + R + 1, R);
+    int slot0 = (yc - 1 - base_row) % (R + 2);
+    if (slot0 < 0) slot0 += R + 2;
+    const int ws = slot0 * P;
+
+    for (int s = 0; s < nsub; ++s) {
+      // prefetch the mask source (y1) of this sub-tile: 32 px x 16 chunks = 512 items over 192 threads
+      uint4 exv[3];
+      bool exok[3];
+      int eoff[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int item = tid + 192 * i;
+        const int pr = item >> 4;
+        const int m = s * 32 + pr;
+        const int oy = m / P, ox = m - oy * P;
+        const int yy = yc + oy;
+        exok[i] = item < 512 && m < R * P && ox < W && yy < H;
+        const int oyc = min(yy, H - 1), oxc = min(ox, W - 1);
+        eoff[i] = (b * H + oyc) * W + oxc;
+        exv[i] = *reinterpret_cast<const uint4*>(ex + (size_t)eoff[i] * ldex + ec);
+      }
+      f32x16 acc[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+      {
+        const int pix = min(s * 32 + (lane & 31), R * P - 1);
+        const char* ap = ring + wrapq(wrapq(ws + pix + wave * P, Q), Q) * GP + (lane >> 5) * 16;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + dx * GP + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wr[dx][ks][nt], acc[nt], 0, 0, 0);
+          }
+      }
+      float* my = scratch + wave * 4096;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 128 + nt * 32 + (lane & 31)] = acc[nt][r];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int item = tid + 192 * i;
+        const int pr = item >> 4;
+        if (exok[i]) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) {
+            const float4 v0 = *reinterpret_cast<const float4*>(scratch + w3 * 4096 + pr * 128 + ec);
+            const float4 v1 = *reinterpret_cast<const float4*>(scratch + w3 * 4096 + pr * 128 + ec + 4);
+            v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w;
+            v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
+          }
+          U128 xv, o;
+          xv.u = exv[i];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xf = bf2f(xv.e[j]);
+            const float dz = (fmaf(xf, econst[ec + j], econst[128 + ec + j]) > 0.f) ? v[j] : 0.f;
+            s1[j] += dz;
+            s2[j] += dz * (xf - econst[256 + ec + j]) * econst[384 + ec + j];
+            o.e[j] = f2bf(econst[512 + ec + j] * dz);
+          }
+          *reinterpret_cast<uint4*>(y + (size_t)eoff[i] * ldy + ec) = o.u;
+        }
+      }
+      __syncthreads();
+    }
+    have_window = true;
+    prev_b = b;
+    prev_yc = yc;
+  }
+
+  // statistics: lanes l, l+16, l+32, l+48 share a channel chunk
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s1[j] += __shfl_xor(s1[j], 16);
+    s1[j] += __shfl_xor(s1[j], 32);
+    s2[j] += __shfl_xor(s2[j], 16);
+    s2[j] += __shfl_xor(s2[j], 32);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&lstat[ec + j], s1[j]);
+      atomicAdd(&lstat[128 + ec + j], s2[j]);
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    atomicAdd(&S1[tid], lstat[tid]);
+    atomicAdd(&S2[tid], lstat[128 + tid]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 __device__ __forceinline__ bf16x8 tr2(const char* a0, const char* a1) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -442,6 +657,30 @@ int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   hipLaunchKernelGGL(conv3x3_strip_fwd_kernel, dim3(grid), dim3(192), smem, st, (const bf16*)p.x, p.ldx, p.pa, p.pb,
                      (const bf16*)p.w, (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, g);
+  *handled = true;
+  return launch_status();
+}
+
+int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1) return 0;
+  if (p.K != 32 || p.N != 128 || p.prologue != CX_PRO_AFFINE2 || p.epilogue != CX_EPI_MASK || p.accumulate) return 0;
+  if (p.W + 2 > 96 || p.W < 4) return 0;
+  StripGeo g = make_geo(p.B, p.H, p.W, 512, 4, 96);
+  if (g.R * p.W * 4 > NCHD * 192) return 0;
+  const size_t smem = (128 + 256 + 640 + 3 * 4096) * 4 + (size_t)(g.Q + 2) * GP;
+  if (smem > 80 * 1024) return 0;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
+    attr = true;
+  }
+  const int total = g.B * g.spi;
+  const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  hipLaunchKernelGGL(conv3x3_strip_dgrad_kernel, dim3(grid), dim3(192), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2, p.ldx2,
+                     p.pa, p.pb, p.pc, (const bf16*)p.w, (const bf16*)p.ex, p.ldex, p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale,
+                     (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, g);
   *handled = true;
   return launch_status();
 }

@@ -360,6 +360,7 @@ int launch_bn(const CxConv& p, hipStream_t st) {
 }  // namespace
 
 int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled);     // conv3x3_strip.hip
+int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled);
 
 extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   if (!pp) return CX_EINVAL;
@@ -384,7 +385,9 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
     if (p.ldx < p.K) return CX_ESHAPE;
     {
       bool handled = false;
-      const int rc = cx_try_strip_fwd(p, st, &handled);
+      int rc = cx_try_strip_fwd(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_strip_dgrad(p, st, &handled);
       if (handled) return rc;
     }
     if (p.epilogue == CX_EPI_STORE) {

@@ -124,10 +124,12 @@ def test_stem_conv7x7(dev):
 
 
 # ------------------------------------------------------------------------------------------------ dgrad
-@pytest.mark.parametrize("ksz,K,N,acc", [(1, 128, 96, False), (1, 128, 96, True), (3, 32, 128, False), (1, 128, 256, True)])
-def test_dgrad_affine2_mask_epilogue(dev, ksz, K, N, acc):
+@pytest.mark.parametrize("ksz,K,N,acc,B,H,W", [(1, 128, 96, False, 2, 9, 10), (1, 128, 96, True, 2, 9, 10), (3, 32, 128, False, 2, 9, 10),
+                                                (1, 128, 256, True, 2, 9, 10),
+                                                # strip dgrad geometries
+                                                (3, 32, 128, False, 3, 10, 80), (3, 32, 128, False, 2, 9, 40), (3, 32, 128, False, 5, 20, 20)])
+def test_dgrad_affine2_mask_epilogue(dev, ksz, K, N, acc, B, H, W):
     from chexpert_amd import ops
-    B, H, W = 2, 9, 10
     ub, u = nhwc_buf(20, B, H, W, K, dev)
     vb, v = nhwc_buf(21, B, H, W, K, dev)
     exb, ex = nhwc_buf(22, B, H, W, N + 32, dev)
