@@ -134,7 +134,7 @@ class _Workspace:
         self.dz0 = torch.empty_like(self.c0)
         self.gbuf = [torch.empty_like(b) for b in self.buf]
         h, w = self.hw[0]
-        self.dz2 = torch.empty(B, h, w, eng.mid, dtype=bf, device=dev)
+        self.dz2 = [torch.empty(B, h, w, eng.mid, dtype=bf, device=dev) for _ in range(2)]
         if len(self.buf) > 1:
             n = max(self.hw[i + 1][0] * self.hw[i + 1][1] * self.buf[i].shape[3] for i in range(len(self.buf) - 1))
             self.dpool = torch.empty(B * n, dtype=bf, device=dev)
@@ -165,6 +165,7 @@ class _Engine:
         self.n_classes = None
         self.pool = {}
         self.reducer = None          # chexpert_amd.parallel.GradReducer when data-parallel
+        self.side = None             # side stream for the weight-gradient kernels of the dense layers
         self._plan_vectors()
 
     # ---- coefficient-vector layout
@@ -187,6 +188,10 @@ class _Engine:
         s["St"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
         s["AB"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
         self.bwd_zero = (b0, V.n - b0)
+        # per-layer AFFINE2 vectors (the weight-gradient kernels of layer l run on a side stream while the
+        # main stream already prepares layer l-1, so these cannot be shared scratch)
+        s["ql"] = [[[V.take(self.growth) for _ in range(3)] for _ in range(n)] for _, n in self.blocks]
+        s["pl"] = [[[V.take(self.mid) for _ in range(3)] for _ in range(n)] for _, n in self.blocks]
         s["q"] = [V.take(max(self.mid, self.c_init, max(c for c, _ in self.blocks))) for _ in range(3)]   # slice AFFINE2
         s["p"] = [V.take(max(self.mid, self.c_init)) for _ in range(3)]                                   # norm2 AFFINE2
         s["dpooled"] = V.take(0)
@@ -389,6 +394,15 @@ class _Engine:
         ops.bn_bwd_coef(v(St[0]), v(St[1]), B * h * w, f.norm5.weight, v(bmean), v(brstd), G(f.norm5.weight), G(f.norm5.bias),
                         v(A), v(Bc), None, None, None, ct)
         q, pv = s["q"], s["p"]
+        # weight-gradient kernels only feed the flat gradient buffer: they run on a side stream, concurrently
+        # with the input-gradient chain of the following layers (two dz2 buffers, per-layer coefficient slots)
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        side = self.side
+        side.wait_stream(main)
+        w1_done = {}
+        k = 0
         for bi in range(nb - 1, -1, -1):
             c0, n_layers = self.blocks[bi]
             buf, gbuf = ws.buf[bi], ws.gbuf[bi]
@@ -396,7 +410,7 @@ class _Engine:
             cnt = B * h * w
             (bmean, brstd), (A, Bc) = s["bmr"][bi], s["AB"][bi]
             block = getattr(f, "denseblock%d" % (bi + 1))
-            dz2 = ws.dz2.view(-1)[:B * h * w * self.mid].view(B, h, w, self.mid)
+            dz2s = [d.view(-1)[:B * h * w * self.mid].view(B, h, w, self.mid) for d in ws.dz2]
             sub = lambda slot, a, n: (slot[0] + a, n)
             for li in range(n_layers - 1, -1, -1):
                 layer = getattr(block, "denselayer%d" % (li + 1))
@@ -404,28 +418,44 @@ class _Engine:
                 g_ = self.growth
                 n1, n2 = s["n1"][bi][li], s["n2"][bi][li]
                 y1 = ws.y1[bi][li]
-                qa, qb, qc = (v(t)[:g_] for t in q)
+                qa, qb, qc = (v(t) for t in s["ql"][bi][li])
                 ops.bn_bwd_slice_coef(v(sub(A, cin, g_)), v(sub(Bc, cin, g_)), v(sub(bmean, cin, g_)), v(sub(brstd, cin, g_)),
                                       qa, qb, qc, g_)
+                ev_q = torch.cuda.Event()
+                ev_q.record(main)
                 gs, xs = gbuf[..., cin:cin + g_], buf[..., cin:cin + g_]
                 S2 = s["S2"][bi][li]
+                dz2 = dz2s[k & 1]
+                if k - 2 in w1_done:
+                    main.wait_event(w1_done.pop(k - 2))        # the side stream has finished reading this dz2 buffer
                 ops.conv_gemm(gs, self.w_bwd(layer.conv2), dz2, N=self.mid, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=xs,
                               pa=qa, pb=qb, pc=qc, epilogue=ops.EPI_MASK, ex=y1, e_sc=v(n2[0]), e_sh=v(n2[1]), e_mu=v(n2[2]),
                               e_r=v(n2[3]), e_scale=ws.ones[:self.mid], stat_sum=v(S2[0]), stat_sq=v(S2[1]))
-                ops.conv_wgrad(gs, y1, G(layer.conv2.weight), kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa,
-                               gb=qb, gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
-                pa, pb, pc = (v(t)[:self.mid] for t in pv)
+                side.wait_event(ev_q)
+                with torch.cuda.stream(side):
+                    ops.conv_wgrad(gs, y1, G(layer.conv2.weight), kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa,
+                                   gb=qb, gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
+                pa, pb, pc = (v(t) for t in s["pl"][bi][li])
                 ops.bn_bwd_coef(v(S2[0]), v(S2[1]), cnt, layer.norm2.weight, v(n2[2]), v(n2[3]), G(layer.norm2.weight),
                                 G(layer.norm2.bias), None, None, pa, pb, pc, self.mid)
+                ev_p = torch.cuda.Event()
+                ev_p.record(main)
                 S1 = s["S1"][bi][li]
                 ops.conv_gemm(dz2, self.w_bwd(layer.conv1), gbuf[..., :cin], N=cin, prologue=ops.PRO_AFFINE2, x2=y1, pa=pa,
                               pb=pb, pc=pc, epilogue=ops.EPI_MASK, ex=buf[..., :cin], e_sc=v(n1[0]), e_sh=v(n1[1]),
                               e_mu=v(bmean)[:cin], e_r=v(brstd)[:cin], e_scale=v(n1[0]), stat_sum=v(S1[0]), stat_sq=v(S1[1]),
                               accumulate=True)
-                ops.conv_wgrad(dz2, buf[..., :cin], G(layer.conv1.weight), g_prologue=ops.PRO_AFFINE2, g2=y1, ga=pa, gb=pb,
-                               gc=pc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n1[0]), pb=v(n1[1]))
+                side.wait_event(ev_p)
+                with torch.cuda.stream(side):
+                    ops.conv_wgrad(dz2, buf[..., :cin], G(layer.conv1.weight), g_prologue=ops.PRO_AFFINE2, g2=y1, ga=pa, gb=pb,
+                                   gc=pc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n1[0]), pb=v(n1[1]))
+                    w1_done[k] = torch.cuda.Event()
+                    w1_done[k].record(side)
                 ops.bn_bwd_coef(v(S1[0]), v(S1[1]), cnt, layer.norm1.weight, v(bmean), v(brstd), G(layer.norm1.weight),
                                 G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin)
+                if red is not None:
+                    main.wait_event(w1_done[k])
+                k += 1
                 done(layer.norm1.weight)      # every gradient from this layer to the end of the buffer is final
             # the block's first c0 channels were produced by the previous transition (or the stem)
             qa, qb, qc = (v(t)[:c0] for t in q)
@@ -455,6 +485,7 @@ class _Engine:
                                 G(f.norm0.weight), G(f.norm0.bias), None, None, pa, pb, pc, self.c_init)
                 ops.conv_wgrad(ws.dz0, ws.x4, G(f.conv0.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0,
                                ga=pa, gb=pb, gc=pc)
+        main.wait_stream(side)
         if red is not None:
             red.finish()
         if fresh:
