@@ -25,7 +25,7 @@ class CxConv(C.Structure):
                 ("K", _i32), ("N", _i32),
                 ("ldx", _i32), ("ldx2", _i32), ("ldy", _i32), ("ldex", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
-                ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32)]
+                ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32), ("tstride", _i32)]
 
 
 class CxWgrad(C.Structure):
@@ -65,6 +65,8 @@ SIGNATURES = {
     "cx_gap_relu_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_unpool2_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_affine2_inplace": [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_affine2_relu": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_relu_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_adam_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp],
     "cx_sgd_nesterov_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _f, _vp],
     "cx_rmsprop_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp],

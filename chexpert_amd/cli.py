@@ -80,7 +80,13 @@ def make_model(args, device):
         else:
             opt = torch.optim.Adam(model.parameters(), lr=args.lr)
         return model, opt, None
-    if name in ("aadensenet121", "densenet121_attn_aug", "resnet152", "aaresnet152") or "efficientnet" in name:
+    if name == "resnet152":                                   # chexpert.py:481-486
+        from .models import resnet152
+        model = resnet152(pretrained=args.pretrained)
+        model.fc = nn.Linear(model.fc.in_features, args.n_classes)
+        model = model.to(device)
+        return model, torch.optim.Adam(model.parameters(), lr=args.lr), None
+    if name in ("aadensenet121", "densenet121_attn_aug", "aaresnet152") or "efficientnet" in name:
         raise RuntimeError("Model architecture not built yet on the HIP path: %s (SURVEY.md section 8 rows C-E)" % name)
     raise RuntimeError("Model architecture not supported.")
 

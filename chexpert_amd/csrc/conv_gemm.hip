@@ -119,8 +119,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
           ra[i][a] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
         }
       } else {
-        const int iy = riy[i] + dy, ix = rix[i] + dx;
-        av[i] = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        int iy = riy[i] + dy, ix = rix[i] + dx;
+        bool ok = rvalid[i] && iy >= 0 && ix >= 0;
+        if (p.tstride > 1) {          // input gradient of a strided conv: only source positions on the stride grid exist
+          ok = ok && (iy % p.tstride == 0) && (ix % p.tstride == 0);
+          iy /= p.tstride;
+          ix /= p.tstride;
+        }
+        av[i] = ok && iy < p.H && ix < p.W;
         const int cy = av[i] ? iy : 0, cx = av[i] ? ix : 0;
         const size_t pix = (size_t)(rb[i] * p.H + cy) * p.W + cx;
         ra[i][0] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
@@ -269,10 +275,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
       const int row = pass * RPP + rr;
       const int m = mt * BM + half * 64 + row;
       U128 xv, old;
-      if (EPI == CX_EPI_MASK) {          // unconditional, clamped loads (no branch around a load)
+      {                                  // unconditional, clamped loads (no branch around a load)
         const int mc = m < M ? m : M - 1;
         const int ncl = nvalid ? nch : 0;
-        xv.u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl);
+        if (EPI == CX_EPI_MASK) xv.u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl);
         if (p.accumulate) old.u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl);
       }
       if (m < M && nvalid) {
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
         if (EPI == CX_EPI_STORE) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            o.e[j] = f2bf(v[j]);
+            o.e[j] = f2bf(p.accumulate ? v[j] + bf2f(old.e[j]) : v[j]);
             const float rv = bf2f(o.e[j]);
             s1[j] += rv;
             s2[j] += rv * rv;
@@ -381,7 +387,15 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   hipStream_t st = as_stream(stream);
   if (p.mode == CX_MODE_CONV) {
     if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return CX_ESHAPE;
-    if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) return CX_ESHAPE;
+    if (p.tstride > 1) {
+      // (B,H,W) is the strided conv's OUTPUT gradient, (Ho,Wo) its input: H = (Ho + 2*fwd_pad - kh)/tstride + 1 with
+      // pad = kh-1-fwd_pad; stride of the implicit GEMM itself is 1
+      const int fpad = p.kh - 1 - p.pad;
+      if (p.stride != 1 || fpad < 0) return CX_ESHAPE;
+      if (p.H != (p.Ho + 2 * fpad - p.kh) / p.tstride + 1 || p.W != (p.Wo + 2 * fpad - p.kw) / p.tstride + 1) return CX_ESHAPE;
+    } else if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) {
+      return CX_ESHAPE;
+    }
     if (p.ldx < p.K) return CX_ESHAPE;
     {
       bool handled = false;

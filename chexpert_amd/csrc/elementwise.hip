@@ -435,6 +435,81 @@ __global__ void affine2_inplace_kernel(bf16* __restrict__ dz, const bf16* __rest
   }
 }
 
+// residual join: out = relu(a*pa + b*pb + pc)
+__global__ void affine2_relu_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const float* __restrict__ pa,
+                                    const float* __restrict__ pb, const float* __restrict__ pc, bf16* __restrict__ out, size_t rows,
+                                    int C) {
+  const int CP = C / 8;
+  const size_t total = rows * CP;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cq = idx % CP;
+    U128 u, v, o;
+    u.u = *reinterpret_cast<const uint4*>(a + idx * 8);
+    v.u = *reinterpret_cast<const uint4*>(b + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cq * 8 + j;
+      o.e[j] = f2bf(fmaxf(fmaf(bf2f(u.e[j]), pa[c], fmaf(bf2f(v.e[j]), pb[c], pc[c])), 0.f));
+    }
+    *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ a, const float* __restrict__ mu_a,
+                                                             const float* __restrict__ r_a, const bf16* __restrict__ b,
+                                                             const float* __restrict__ mu_b, const float* __restrict__ r_b,
+                                                             bf16* __restrict__ dz, float* S1, float* S2a, float* S2b, size_t rows,
+                                                             int C) {
+  extern __shared__ float lds[];          // [3][C]
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  // CP may exceed the block: thread handles chunk columns cq = tid % CP only when CP divides 256, else strided generic path
+  float s1[8], s2[8], s3[8];
+  const size_t total = rows * CP;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // stride is a multiple of CP when CP | 256 (CP in {8,16,32,64,128,256}); C <= 2048
+  const int cq = idx % CP;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
+  float ma[8], ra_[8], mb[8], rb_[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ma[j] = mu_a[cq * 8 + j]; ra_[j] = r_a[cq * 8 + j];
+    mb[j] = b ? mu_b[cq * 8 + j] : 0.f; rb_[j] = b ? r_b[cq * 8 + j] : 0.f;
+  }
+  for (; idx < total; idx += stride) {
+    U128 g, o, av, bv, d;
+    g.u = *reinterpret_cast<const uint4*>(dout + idx * 8);
+    o.u = *reinterpret_cast<const uint4*>(out + idx * 8);
+    av.u = *reinterpret_cast<const uint4*>(a + idx * 8);
+    if (b) bv.u = *reinterpret_cast<const uint4*>(b + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dzv = bf2f(o.e[j]) > 0.f ? bf2f(g.e[j]) : 0.f;
+      s1[j] += dzv;
+      s2[j] += dzv * (bf2f(av.e[j]) - ma[j]) * ra_[j];
+      if (b) s3[j] += dzv * (bf2f(bv.e[j]) - mb[j]) * rb_[j];
+      d.e[j] = f2bf(dzv);
+    }
+    *reinterpret_cast<uint4*>(dz + idx * 8) = d.u;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&lds[cq * 8 + j], s1[j]);
+    atomicAdd(&lds[C + cq * 8 + j], s2[j]);
+    if (b) atomicAdd(&lds[2 * C + cq * 8 + j], s3[j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(&S1[c], lds[c]);
+    atomicAdd(&S2a[c], lds[C + c]);
+    if (b) atomicAdd(&S2b[c], lds[2 * C + c]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // optimisers (flat fp32 buffers)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -705,6 +780,27 @@ int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb
   if (!dz || !x || !pa || !pb || !pc || C % 8) return CX_EINVAL;
   hipLaunchKernelGGL(affine2_inplace_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (bf16*)dz,
                      (const bf16*)x, pa, pb, pc, rows, C);
+  return launch_status();
+}
+
+int cx_affine2_relu(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows, int C,
+                    void* stream) {
+  if (!a || !b || !pa || !pb || !pc || !out || C % 8) return CX_EINVAL;
+  hipLaunchKernelGGL(affine2_relu_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)a,
+                     (const bf16*)b, pa, pb, pc, (bf16*)out, rows, C);
+  return launch_status();
+}
+
+int cx_relu_bwd_stats(const void* dout, const void* out, const void* a, const float* mu_a, const float* r_a, const void* b,
+                      const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b, size_t rows, int C,
+                      void* stream) {
+  if (!dout || !out || !a || !mu_a || !r_a || !dz || !S1 || !S2a) return CX_EINVAL;
+  if (b && (!mu_b || !r_b || !S2b)) return CX_EINVAL;
+  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8)) return CX_ESHAPE;
+  if (C / 8 > 256) return CX_ESHAPE;
+  hipLaunchKernelGGL(relu_bwd_stats_kernel, dim3(grid_for(rows * (C / 8), 256, 2048)), dim3(256), 3 * C * sizeof(float),
+                     as_stream(stream), (const bf16*)dout, (const bf16*)out, (const bf16*)a, mu_a, r_a, (const bf16*)b, mu_b, r_b,
+                     (bf16*)dz, S1, S2a, S2b, rows, C);
   return launch_status();
 }
 

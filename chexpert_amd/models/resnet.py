@@ -1,0 +1,515 @@
+"""Bottleneck ResNet (torchvision-shaped; resnet152 = layers [3, 8, 36, 3]) on the gfx950 kernels.
+
+Drop-in surface: constructor signature of /root/reference/models/attn_aug_conv.py:218-220, `Bottleneck` with
+stride on conv2 (:159-211), torchvision `state_dict` keys (`conv1`, `bn1`, `layerL.i.{conv1,bn1,conv2,bn2,
+conv3,bn3,downsample.0,downsample.1}`, `fc`), `model.layer4`, re-assignable `model.fc`.
+
+Schedule per bottleneck (NHWC bf16, fp32 accumulate / statistics):
+  conv1 1x1 (raw, stats)  ->  conv2 3x3 stride s with bn1+ReLU in the operand prologue (raw, stats)
+  ->  conv3 1x1 with bn2+ReLU in the prologue (raw, stats)  [-> downsample 1x1 stride s (raw, stats)]
+  ->  one residual-join kernel out = relu(bn3(y3) + bn_d(yd) | x).
+BatchNorm outputs are never stored; backward uses the two-tensor affine form of BN backward in the
+prologues of the input- and weight-gradient kernels, and the input gradient of the strided convs is the
+same implicit GEMM walking only the source positions that lie on the stride grid (`tstride`).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import CxPackDesc, check, lib, ptr, stream_ptr
+from .densenet import BatchNorm2dParams, Conv2dParams, PoolMarker, ReLUMarker, _Vec
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None,
+                 input_dims=None, attn_params=None):
+        super().__init__()
+        if attn_params is not None:
+            raise NotImplementedError("attention-augmented Bottleneck (AAConv2d) is not built yet: SURVEY.md section 8 row C")
+        if groups != 1 or base_width != 64 or dilation != 1 or norm_layer not in (None, nn.BatchNorm2d):
+            raise NotImplementedError("only the plain Bottleneck (groups=1, width 64, no dilation, BatchNorm2d) is on the hot path")
+        width = planes
+        self.conv1 = Conv2dParams(inplanes, width, 1, bias=False)
+        self.bn1 = BatchNorm2dParams(width)
+        self.conv2 = Conv2dParams(width, width, 3, stride, 1, bias=False)
+        self.bn2 = BatchNorm2dParams(width)
+        self.conv3 = Conv2dParams(width, planes * 4, 1, bias=False)
+        self.bn3 = BatchNorm2dParams(planes * 4)
+        self.relu = ReLUMarker(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):  # pragma: no cover - guard
+        raise RuntimeError("chexpert_amd: call the parent ResNet (fused HIP schedule)")
+
+
+class _BN:
+    """Vector slots of one BatchNorm."""
+
+    def __init__(self, V, C, fz, bz):
+        self.C = C
+        self.sum, self.sq = fz.take(C), fz.take(C)                    # zeroed every forward
+        self.S1, self.S2 = bz.take(C), bz.take(C)                     # zeroed every backward
+        self.sc, self.sh, self.mean, self.rstd = (V.take(C) for _ in range(4))
+        self.pa, self.pb, self.pc = (V.take(C) for _ in range(3))
+
+
+class _Region(_Vec):
+    def __init__(self, base=0):
+        super().__init__()
+        self.n = base
+
+
+class _Engine:
+    def __init__(self, model):
+        self.model = model
+        self.flat = None
+        self.device = None
+        self.pool = {}
+        self.reducer = None
+        # geometry: list of (module, inplanes, planes, stride, has_downsample)
+        self.blocks = []
+        for L in (model.layer1, model.layer2, model.layer3, model.layer4):
+            for blk in L:
+                self.blocks.append(blk)
+        # vector plan: [fwd-zero region | bwd-zero region | rest]
+        nfz = sum(2 * bn.num_features for bn in self._all_bns()) + 64
+        nbz = nfz
+        self.fz, self.bz, self.rest = _Region(0), _Region(0), _Region(0)
+        fz_tmp, bz_tmp, rest_tmp = _Region(0), _Region(0), _Region(0)
+        # two-pass: first sizes, then offsets
+        self.bn = {}
+        for bn in self._all_bns():
+            self.bn[id(bn)] = _BN(rest_tmp, bn.num_features, fz_tmp, bz_tmp)
+        nf, nb = fz_tmp.n, bz_tmp.n
+        self.fz, self.bz, self.rest = _Region(0), _Region(nf), _Region(nf + nb)
+        self.bn = {}
+        for bn in self._all_bns():
+            self.bn[id(bn)] = _BN(self.rest, bn.num_features, self.fz, self.bz)
+        self.fwd_zero, self.bwd_zero = (0, nf), (nf, nb)
+        cmax = 2048
+        self.join = [[self.rest.take(b.bn3.num_features) for _ in range(3)] for b in self.blocks]
+        self.ones, self.zeros = self.rest.take(cmax), self.rest.take(cmax)
+        self.scratch = [self.rest.take(cmax) for _ in range(2)]
+        self.vec_size = self.rest.n
+
+    def _all_bns(self):
+        m = self.model
+        yield m.bn1
+        for b in self.blocks:
+            yield b.bn1
+            yield b.bn2
+            yield b.bn3
+            if b.downsample is not None:
+                yield b.downsample[1]
+
+    # ---- binding / packing (same scheme as the DenseNet engine)
+    def bind(self, dev):
+        m = self.model
+        params = [p for _, p in m.named_parameters()]
+        ok = (self.flat is not None and self.device == dev and len(params) == len(self.offsets)
+              and all(p.data_ptr() == self.flat.data_ptr() + 4 * off for p, off in zip(params, self.offsets)))
+        if ok:
+            return
+        offs, total = [], 0
+        for p in params:
+            if p.dtype != torch.float32:
+                raise RuntimeError("parameters must be fp32 masters")
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, off in zip(params, offs):
+            flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + p.numel()].view(p.shape)
+        for b in m.buffers():
+            if b.device != dev:
+                raise RuntimeError("module buffers are on %s, input on %s -- call model.to(device)" % (b.device, dev))
+        self.flat, self.offsets, self.params = flat, offs, params
+        self.flat_grad = torch.zeros_like(flat)
+        self.grad_views = [self.flat_grad[off:off + p.numel()].view(p.shape) for p, off in zip(params, offs)]
+        self.off_of = {id(p): off for p, off in zip(params, offs)}
+        self.device = dev
+        self.n_classes = m.fc.out_features
+        self.pool = {}
+        descs, cur = [], 0
+        self.wf, self.wb = {}, {}
+
+        def add(conv, transpose=False, stem=False):
+            nonlocal cur
+            O, I, kh, kw = conv.weight.shape
+            n = 7 * O * 32 if stem else O * I * kh * kw
+            descs.append(CxPackDesc(self.off_of[id(conv.weight)], cur, O, I, kh, kw, int(transpose), int(stem)))
+            off = cur
+            cur += (n + 7) // 8 * 8
+            return (off, n)
+        self.wf[id(m.conv1)] = add(m.conv1, stem=True)
+        for mod in m.modules():
+            if isinstance(mod, nn.Conv2d) and mod is not m.conv1:
+                self.wf[id(mod)] = add(mod)
+                self.wb[id(mod)] = add(mod, transpose=True)
+        self.packed = torch.empty(cur, dtype=torch.bfloat16, device=dev)
+        arr = (CxPackDesc * len(descs))(*descs)
+        self.desc_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.n_desc = len(descs)
+        self.packed_version = None
+
+    def pack(self, train):
+        ver = None if train else sum(p._version for p in self.params)
+        if ver is not None and ver == self.packed_version:
+            return
+        check(lib().cx_pack_weights_table(ptr(self.flat), ptr(self.packed), ptr(self.desc_dev), self.n_desc, stream_ptr()),
+              "cx_pack_weights_table")
+        self.packed_version = ver
+
+    def w_fwd(self, conv):
+        off, n = self.wf[id(conv)]
+        return self.packed[off:off + n]
+
+    def w_bwd(self, conv):
+        off, n = self.wb[id(conv)]
+        return self.packed[off:off + n]
+
+    def G(self, p):
+        off = self.off_of[id(p)]
+        return self.flat_grad[off:off + p.numel()]
+
+    # ---- workspace
+    class WS:
+        pass
+
+    def acquire(self, B, H, W):
+        lst = self.pool.setdefault((B, H, W), [])
+        if lst:
+            return lst.pop()
+        dev, bf = self.device, torch.bfloat16
+        e = lambda *s, dtype=bf: torch.empty(*s, dtype=dtype, device=dev)
+        ws = _Engine.WS()
+        ws.key, ws.B, ws.H, ws.W = (B, H, W), B, H, W
+        ws.x4 = e(B, H, W, 4)
+        h, w = H // 2, W // 2
+        ws.c0 = e(B, h, w, 64)
+        h, w = h // 2, w // 2
+        ws.amax = e(B, h, w, 64, dtype=torch.uint8)
+        ws.pool0 = e(B, h, w, 64)
+        ws.blk = []
+        for b in self.blocks:
+            p_, s_ = b.conv1.out_channels, b.stride
+            ho, wo = h // s_, w // s_
+            t = dict(hin=(h, w), hout=(ho, wo), y1=e(B, h, w, p_), y2=e(B, ho, wo, p_), y3=e(B, ho, wo, 4 * p_),
+                     yd=e(B, ho, wo, 4 * p_) if b.downsample is not None else None, out=e(B, ho, wo, 4 * p_))
+            ws.blk.append(t)
+            h, w = ho, wo
+        ws.pooled = torch.empty(B, 2048, dtype=torch.float32, device=dev)
+        ws.logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=dev)
+        ws.vec = torch.zeros(self.vec_size, dtype=torch.float32, device=dev)
+        o, n = self.ones
+        ws.vec[o:o + n].fill_(1.0)
+        ws.bwd = None
+        return ws
+
+    def release(self, ws):
+        lst = self.pool.setdefault(ws.key, [])
+        if len(lst) < 2:
+            lst.append(ws)
+
+    @staticmethod
+    def _v(ws, slot, n=None):
+        off, m = slot
+        return ws.vec[off:off + (m if n is None else n)]
+
+    def _bn_coef(self, ws, bn, count, train):
+        S, v = self.bn[id(bn)], self._v
+        if train:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            ops.bn_coef(v(ws, S.sum), v(ws, S.sq), count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var,
+                        v(ws, S.sc), v(ws, S.sh), v(ws, S.mean), v(ws, S.rstd), S.C)
+        else:
+            ops.bn_coef_eval(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, v(ws, S.sc), v(ws, S.sh), v(ws, S.mean),
+                             v(ws, S.rstd), S.C)
+
+    # ---- forward
+    def forward(self, x, train):
+        m, v = self.model, self._v
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("expected a (B,3,H,W) input")
+        B, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise RuntimeError("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
+        self.bind(x.device)
+        self.pack(train)
+        ws = self.acquire(B, H, W)
+        z0, zn = self.fwd_zero
+        ws.vec[z0:z0 + zn].zero_()
+        st = (lambda s: v(ws, s)) if train else (lambda s: None)
+        S0 = self.bn[id(m.bn1)]
+        ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
+        ops.conv_gemm(ws.x4, self.w_fwd(m.conv1), ws.c0, N=64, mode=ops.MODE_STEM, stat_sum=st(S0.sum), stat_sq=st(S0.sq))
+        self._bn_coef(ws, m.bn1, B * (H // 2) * (W // 2), train)
+        ops.bnrelu_maxpool_fwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), ws.pool0, ws.amax, None, None)
+        xin = ws.pool0
+        for bi, b in enumerate(self.blocks):
+            t = ws.blk[bi]
+            s_, p_ = b.stride, b.conv1.out_channels
+            hi, wi = t["hin"]
+            ho, wo = t["hout"]
+            S1, S2, S3 = self.bn[id(b.bn1)], self.bn[id(b.bn2)], self.bn[id(b.bn3)]
+            ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, stat_sum=st(S1.sum), stat_sq=st(S1.sq))
+            self._bn_coef(ws, b.bn1, B * hi * wi, train)
+            ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=s_, pad=1, prologue=ops.PRO_AFFINE_RELU,
+                          pa=v(ws, S1.sc), pb=v(ws, S1.sh), stat_sum=st(S2.sum), stat_sq=st(S2.sq))
+            self._bn_coef(ws, b.bn2, B * ho * wo, train)
+            ops.conv_gemm(t["y2"], self.w_fwd(b.conv3), t["y3"], N=4 * p_, prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S2.sc),
+                          pb=v(ws, S2.sh), stat_sum=st(S3.sum), stat_sq=st(S3.sq))
+            self._bn_coef(ws, b.bn3, B * ho * wo, train)
+            ja, jb, jc = (v(ws, sl) for sl in self.join[bi])
+            if b.downsample is not None:
+                Sd = self.bn[id(b.downsample[1])]
+                ops.conv_gemm(xin, self.w_fwd(b.downsample[0]), t["yd"], N=4 * p_, stride=s_, stat_sum=st(Sd.sum), stat_sq=st(Sd.sq))
+                self._bn_coef(ws, b.downsample[1], B * ho * wo, train)
+                torch.add(v(ws, S3.sh), v(ws, Sd.sh), out=jc)
+                ops.affine2_relu(t["y3"], t["yd"], v(ws, S3.sc), v(ws, Sd.sc), jc, t["out"])
+            else:
+                ops.affine2_relu(t["y3"], xin, v(ws, S3.sc), v(ws, self.ones, 4 * p_), v(ws, S3.sh), t["out"])
+            xin = t["out"]
+        ops.head_fwd(xin, v(ws, self.ones), v(ws, self.zeros), m.fc.weight, m.fc.bias, ws.pooled, ws.logits)
+        if train:
+            m._nbt_pending += 1
+        return ws
+
+    # ---- backward
+    def _alloc_bwd(self, ws):
+        if ws.bwd is not None:
+            return
+        dev, bf, B = self.device, torch.bfloat16, ws.B
+        e = lambda *s: torch.empty(*s, dtype=bf, device=dev)
+        bw = {}
+        # one gradient buffer per block OUTPUT shape change (identity blocks accumulate in place)
+        bw["g"] = [None] * len(self.blocks)
+        for bi, b in enumerate(self.blocks):
+            t = ws.blk[bi]
+            if b.downsample is not None or bi == len(self.blocks) - 1:
+                pass
+        shapes = {}
+        for bi, b in enumerate(self.blocks):
+            sh = tuple(ws.blk[bi]["out"].shape)
+            if sh not in shapes:
+                shapes[sh] = e(*sh)
+            bw["g"][bi] = shapes[sh]
+        bw["g_in0"] = e(*ws.pool0.shape)
+        bw["dz2"] = torch.empty(max(t["y2"].numel() for t in ws.blk), dtype=bf, device=dev)
+        bw["dz1"] = torch.empty(max(t["y1"].numel() for t in ws.blk), dtype=bf, device=dev)
+        bw["dz0"] = torch.empty_like(ws.c0)
+        ws.bwd = bw
+
+    def backward(self, ws, dlogits):
+        m, v, G = self.model, self._v, self.G
+        B = ws.B
+        self._alloc_bwd(ws)
+        bw = ws.bwd
+        z0, zn = self.bwd_zero
+        ws.vec[z0:z0 + zn].zero_()
+        fresh = any(p.grad is None for p in self.params)
+        if fresh:
+            self.flat_grad.zero_()
+        elif not all(p.grad.data_ptr() == gv.data_ptr() for p, gv in zip(self.params, self.grad_views)):
+            raise RuntimeError("parameter .grad tensors were replaced; call zero_grad(set_to_none=True) first")
+        red = self.reducer
+        if red is not None:
+            red.begin()
+        done = (lambda p: red.ready(self.off_of[id(p)])) if red is not None else (lambda p: None)
+        ones = lambda n: v(ws, self.ones, n)
+        zeros = lambda n: v(ws, self.zeros, n)
+        last = ws.blk[-1]["out"]
+        dpooled = torch.empty(B, last.shape[3], dtype=torch.float32, device=self.device)
+        ops.head_bwd(dlogits, ws.pooled, m.fc.weight, G(m.fc.weight), G(m.fc.bias) if m.fc.bias is not None else None, dpooled)
+        g = bw["g"][-1]
+        Cl = last.shape[3]
+        ops.gap_relu_bn_bwd(dpooled, last, ones(Cl), zeros(Cl), zeros(Cl), ones(Cl), ones(Cl), g, v(ws, self.scratch[0], Cl),
+                            v(ws, self.scratch[1], Cl))
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b, t = self.blocks[bi], ws.blk[bi]
+            s_, p_ = b.stride, b.conv1.out_channels
+            hi, wi = t["hin"]
+            ho, wo = t["hout"]
+            cin = b.conv1.in_channels
+            xin = ws.blk[bi - 1]["out"] if bi > 0 else ws.pool0
+            S1, S2, S3 = self.bn[id(b.bn1)], self.bn[id(b.bn2)], self.bn[id(b.bn3)]
+            Sd = self.bn[id(b.downsample[1])] if b.downsample is not None else None
+            g = bw["g"][bi]
+            # residual join backward: dz = dOut * [out > 0] (in place), statistics for bn3 (and the downsample BN)
+            ops.relu_bwd_stats(g, t["out"], t["y3"], v(ws, S3.mean), v(ws, S3.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
+                               v(ws, Sd.rstd) if Sd else None, g, v(ws, S3.S1), v(ws, S3.S2), v(ws, Sd.S2) if Sd else None)
+            cnt_o, cnt_i = B * ho * wo, B * hi * wi
+            ops.bn_bwd_coef(v(ws, S3.S1), v(ws, S3.S2), cnt_o, b.bn3.weight, v(ws, S3.mean), v(ws, S3.rstd), G(b.bn3.weight),
+                            G(b.bn3.bias), None, None, v(ws, S3.pa), v(ws, S3.pb), v(ws, S3.pc), S3.C)
+            dz2 = bw["dz2"][:B * ho * wo * p_].view(B, ho, wo, p_)
+            ops.conv_gemm(g, self.w_bwd(b.conv3), dz2, N=p_, prologue=ops.PRO_AFFINE2, x2=t["y3"], pa=v(ws, S3.pa), pb=v(ws, S3.pb),
+                          pc=v(ws, S3.pc), epilogue=ops.EPI_MASK, ex=t["y2"], e_sc=v(ws, S2.sc), e_sh=v(ws, S2.sh), e_mu=v(ws, S2.mean),
+                          e_r=v(ws, S2.rstd), e_scale=ones(p_), stat_sum=v(ws, S2.S1), stat_sq=v(ws, S2.S2))
+            ops.conv_wgrad(g, t["y2"], G(b.conv3.weight), g_prologue=ops.PRO_AFFINE2, g2=t["y3"], ga=v(ws, S3.pa), gb=v(ws, S3.pb),
+                           gc=v(ws, S3.pc), x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S2.sc), pb=v(ws, S2.sh))
+            ops.bn_bwd_coef(v(ws, S2.S1), v(ws, S2.S2), cnt_o, b.bn2.weight, v(ws, S2.mean), v(ws, S2.rstd), G(b.bn2.weight),
+                            G(b.bn2.bias), None, None, v(ws, S2.pa), v(ws, S2.pb), v(ws, S2.pc), S2.C)
+            dz1 = bw["dz1"][:B * hi * wi * p_].view(B, hi, wi, p_)
+            ops.conv_gemm(dz2, self.w_bwd(b.conv2), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["y2"],
+                          pa=v(ws, S2.pa), pb=v(ws, S2.pb), pc=v(ws, S2.pc), epilogue=ops.EPI_MASK, ex=t["y1"], e_sc=v(ws, S1.sc),
+                          e_sh=v(ws, S1.sh), e_mu=v(ws, S1.mean), e_r=v(ws, S1.rstd), e_scale=ones(p_), stat_sum=v(ws, S1.S1),
+                          stat_sq=v(ws, S1.S2))
+            ops.conv_wgrad(dz2, t["y1"], G(b.conv2.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=t["y2"],
+                           ga=v(ws, S2.pa), gb=v(ws, S2.pb), gc=v(ws, S2.pc), x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc),
+                           pb=v(ws, S1.sh))
+            ops.bn_bwd_coef(v(ws, S1.S1), v(ws, S1.S2), cnt_i, b.bn1.weight, v(ws, S1.mean), v(ws, S1.rstd), G(b.bn1.weight),
+                            G(b.bn1.bias), None, None, v(ws, S1.pa), v(ws, S1.pb), v(ws, S1.pc), S1.C)
+            gx = (bw["g"][bi - 1] if bi > 0 else bw["g_in0"]) if Sd is not None or bi == 0 else g
+            identity = Sd is None
+            if identity and gx is not g:
+                gx.copy_(g)                      # first block of layer1 never is an identity block; defensive
+            ops.conv_gemm(dz1, self.w_bwd(b.conv1), gx, N=cin, prologue=ops.PRO_AFFINE2, x2=t["y1"], pa=v(ws, S1.pa), pb=v(ws, S1.pb),
+                          pc=v(ws, S1.pc), accumulate=identity)
+            ops.conv_wgrad(dz1, xin, G(b.conv1.weight), g_prologue=ops.PRO_AFFINE2, g2=t["y1"], ga=v(ws, S1.pa), gb=v(ws, S1.pb),
+                           gc=v(ws, S1.pc))
+            if Sd is not None:
+                bnd, convd = b.downsample[1], b.downsample[0]
+                ops.bn_bwd_coef(v(ws, S3.S1), v(ws, Sd.S2), cnt_o, bnd.weight, v(ws, Sd.mean), v(ws, Sd.rstd), G(bnd.weight),
+                                G(bnd.bias), None, None, v(ws, Sd.pa), v(ws, Sd.pb), v(ws, Sd.pc), Sd.C)
+                ops.conv_gemm(g, self.w_bwd(convd), gx, N=cin, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["yd"], pa=v(ws, Sd.pa),
+                              pb=v(ws, Sd.pb), pc=v(ws, Sd.pc), accumulate=True)
+                ops.conv_wgrad(g, xin, G(convd.weight), stride=s_, g_prologue=ops.PRO_AFFINE2, g2=t["yd"], ga=v(ws, Sd.pa),
+                               gb=v(ws, Sd.pb), gc=v(ws, Sd.pc))
+            done(b.conv1.weight)
+        # stem
+        S0 = self.bn[id(m.bn1)]
+        gx = bw["g_in0"]
+        ops.bnrelu_maxpool_bwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), v(ws, S0.mean), v(ws, S0.rstd), ws.amax, gx, gx, ones(64), zeros(64),
+                               zeros(64), bw["dz0"], v(ws, S0.S1), v(ws, S0.S2))
+        ops.bn_bwd_coef(v(ws, S0.S1), v(ws, S0.S2), B * (ws.H // 2) * (ws.W // 2), m.bn1.weight, v(ws, S0.mean), v(ws, S0.rstd),
+                        G(m.bn1.weight), G(m.bn1.bias), None, None, v(ws, S0.pa), v(ws, S0.pb), v(ws, S0.pc), 64)
+        ops.conv_wgrad(bw["dz0"], ws.x4, G(m.conv1.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0, ga=v(ws, S0.pa),
+                       gb=v(ws, S0.pb), gc=v(ws, S0.pc))
+        if red is not None:
+            red.finish()
+        if fresh:
+            for p, gv in zip(self.params, self.grad_views):
+                p.grad = gv
+
+    def enable_data_parallel(self, bucket_bytes=16 << 20, group=None):
+        from ..parallel import GradReducer
+        if self.flat_grad is None:
+            raise RuntimeError("bind the engine first (run one forward)")
+        self.reducer = GradReducer(self.flat_grad, bucket_bytes, group)
+
+
+class _Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, model):
+        if not model.training:
+            raise NotImplementedError("autograd through the fused ResNet needs train() mode")
+        ws = model._eng().forward(x, True)
+        ctx.model, ctx.ws = model, ws
+        return ws.logits.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng, ws = ctx.model._eng(), ctx.ws
+        if ws is None:
+            raise RuntimeError("backward through the fused ResNet can only run once per forward")
+        eng.backward(ws, dlogits.contiguous().float())
+        eng.release(ws)
+        ctx.ws = None
+        return None, None, None
+
+
+class ResNet(nn.Module):
+    """Signature of /root/reference/models/attn_aug_conv.py:218-220."""
+
+    def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
+                 replace_stride_with_dilation=None, norm_layer=None, attn_params=None):
+        super().__init__()
+        if block is not Bottleneck:
+            raise NotImplementedError("only Bottleneck ResNets are on the hot path (BasicBlock / WideResNet: CIFAR harness)")
+        if attn_params is not None:
+            raise NotImplementedError("aaresnet (AAConv2d in conv2) is not built yet: SURVEY.md section 8 row C")
+        if groups != 1 or width_per_group != 64 or (replace_stride_with_dilation not in (None, [False] * 3, (False,) * 3)):
+            raise NotImplementedError("groups / width / dilation variants are not on the hot path")
+        self.inplanes = 64
+        self.conv1 = Conv2dParams(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = BatchNorm2dParams(64)
+        self.relu = ReLUMarker(inplace=True)
+        self.maxpool = PoolMarker()
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        self.avgpool = PoolMarker()
+        self.fc = nn.Linear(512 * 4, num_classes)
+        for mod in self.modules():                      # initialisers of attn_aug_conv.py:248-263
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.constant_(mod.weight, 1)
+                nn.init.constant_(mod.bias, 0)
+        if zero_init_residual:
+            for mod in self.modules():
+                if isinstance(mod, Bottleneck):
+                    nn.init.constant_(mod.bn3.weight, 0)
+        self._nbt_pending = 0
+        self._engine = None
+
+    def _make_layer(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(Conv2dParams(self.inplanes, planes * 4, 1, stride, bias=False), BatchNorm2dParams(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def _eng(self):
+        if self._engine is None:
+            object.__setattr__(self, "_engine", _Engine(self))
+        return self._engine
+
+    def state_dict(self, *args, **kwargs):
+        if self._nbt_pending:
+            for mod in self.modules():
+                if isinstance(mod, nn.BatchNorm2d):
+                    mod.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+        return super().state_dict(*args, **kwargs)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("chexpert_amd.ResNet runs on the GPU only (hand-written HIP kernels); there is no CPU fallback")
+        if self.fc.in_features != 2048:
+            raise RuntimeError("fc.in_features must be 2048")
+        eng = self._eng()
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _Fn.apply(x, self.fc.weight, self)
+        ws = eng.forward(x, self.training)
+        out = ws.logits.clone()
+        eng.release(ws)
+        return out
+
+    def forward_backward(self, x, target):
+        eng = self._eng()
+        ws = eng.forward(x, self.training)
+        B, n = ws.logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dl = torch.empty(B, n, dtype=torch.float32, device=x.device)
+        ops.bce_fwd_bwd(ws.logits, target, loss, None, dl)
+        eng.backward(ws, dl)
+        logits = ws.logits.clone()
+        eng.release(ws)
+        return loss, logits
+
+
+def resnet152(pretrained=False, **kwargs):
+    """torchvision.models.resnet152 stand-in (chexpert.py:24, :482)."""
+    if pretrained:
+        raise RuntimeError("pretrained ImageNet weights cannot be downloaded here; use load_state_dict()")
+    return ResNet(Bottleneck, [3, 8, 36, 3], **kwargs)

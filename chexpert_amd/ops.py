@@ -22,7 +22,7 @@ def _nhwc(t):
 
 def conv_gemm(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
               pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
-              e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None):
+              e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1):
     require_cuda(x, w_packed, y)
     p = CxConv()
     B, H, W, Cx, ldx = _nhwc(x)
@@ -35,6 +35,7 @@ def conv_gemm(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV,
     p.ldx, p.ldy = ldx, ldy
     p.kh, p.kw, p.stride, p.pad = kh, kw, stride, pad
     p.prologue, p.mode, p.epilogue, p.accumulate = prologue, mode, epilogue, int(accumulate)
+    p.tstride = tstride
     p.pa, p.pb, p.pc = ptr(pa), ptr(pb), ptr(pc)
     if x2 is not None:
         assert x2.shape == x.shape
@@ -163,6 +164,19 @@ def affine2_inplace(dz, x, pa, pb, pc):
     assert ld == Cc and _nhwc(x)[4] == Cc
     check(lib().cx_affine2_inplace(ptr(dz), ptr(x), ptr(pa), ptr(pb), ptr(pc), B * H * W, Cc, stream_ptr()),
           "cx_affine2_inplace")
+
+
+def affine2_relu(a, b, pa, pb, pc, out):
+    B, H, W, Cc, ld = _nhwc(a)
+    assert ld == Cc and _nhwc(b)[4] == Cc and _nhwc(out)[4] == Cc
+    check(lib().cx_affine2_relu(ptr(a), ptr(b), ptr(pa), ptr(pb), ptr(pc), ptr(out), B * H * W, Cc, stream_ptr()), "cx_affine2_relu")
+
+
+def relu_bwd_stats(dout, out, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b):
+    B, H, W, Cc, ld = _nhwc(dout)
+    assert ld == Cc
+    check(lib().cx_relu_bwd_stats(ptr(dout), ptr(out), ptr(a), ptr(mu_a), ptr(r_a), ptr(b), ptr(mu_b), ptr(r_b), ptr(dz), ptr(S1),
+                                  ptr(S2a), ptr(S2b), B * H * W, Cc, stream_ptr()), "cx_relu_bwd_stats")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

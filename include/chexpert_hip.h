@@ -64,7 +64,9 @@ typedef struct CxConv {
   int32_t K, N;         /* channels per tap in / out; both multiples of 32                         */
   int32_t ldx, ldx2, ldy, ldex;
   int32_t kh, kw, stride, pad;
-  int32_t prologue, mode, epilogue, accumulate;
+  int32_t prologue, mode, epilogue, accumulate;   /* accumulate: y += result (both epilogues)             */
+  int32_t tstride;      /* > 1: input gradient of a conv with that stride (x is its output gradient,    */
+                        /* stride must be 1, pad = kh-1-forward_pad, weights packed with transpose=1)    */
 } CxConv;
 
 /* Weight gradient of the same convolution:  dW[n][c][ky][kx] += sum_m G[m][n] * A[m@tap][c]
@@ -170,6 +172,16 @@ int cx_gap_relu_bn_bwd(const float* dpooled, const void* x, const float* scale, 
 int cx_unpool2_mask(const void* d, const void* x, const float* sc, const float* sh, const float* mean,
                     const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W,
                     int C, int ldd, int ldx, int ldg, void* stream);
+
+/* residual join of a Bottleneck: out = relu(a*pa + b*pb + pc) (bn3(conv3) + identity | bn_d(downsample),
+ * attn_aug_conv.py:202-209); pa/pb/pc fp32 [C]                                                    */
+int cx_affine2_relu(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows,
+                    int C, void* stream);
+/* its backward: dz = dout * [out > 0]; S1 += sum dz; S2a += sum dz*(a-mu_a)*r_a; S2b += sum dz*(b-mu_b)*r_b
+ * (b / S2b optional).  dz may alias dout.                                                         */
+int cx_relu_bwd_stats(const void* dout, const void* out, const void* a, const float* mu_a, const float* r_a, const void* b,
+                      const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b, size_t rows, int C,
+                      void* stream);
 
 /* dz (B,H,W,C) bf16 -> dY = dz*pa + x*pb + pc in place (BN0 backward ahead of the stem wgrad)      */
 int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb, const float* pc, size_t rows,

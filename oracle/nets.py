@@ -245,23 +245,27 @@ def densenet_forward(sd, x, block_config=(6, 12, 24, 16), train=True, nh=None, t
     return F.linear(pooled, sd["classifier.weight"], sd["classifier.bias"])
 
 
-def resnet_forward(sd, x, layers=(3, 8, 36, 3), train=True, nh=None, taps=None):
-    x = F.conv2d(x, sd["conv1.weight"], stride=2, padding=3)
-    x = F.max_pool2d(F.relu(_bn(sd, "bn1", x, train)), 3, 2, 1)
+def resnet_forward(sd, x, layers=(3, 8, 36, 3), train=True, nh=None, taps=None, q=None):
+    """`q` (optional): storage-rounding model of the HIP path (see densenet_features)."""
+    q = q or (lambda t: t)
+    w = lambda k: q(sd[k])
+    x = q(F.conv2d(q(x), w("conv1.weight"), stride=2, padding=3))
+    x = q(F.max_pool2d(F.relu(_bn(sd, "bn1", x, train)), 3, 2, 1))
     for L, n in enumerate(layers, 1):
         for i in range(n):
             p = "layer%d.%d" % (L, i)
             s = 2 if (L > 1 and i == 0) else 1
-            y = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"]), train))
+            y = q(F.conv2d(x, w(p + ".conv1.weight")))
+            y = q(F.relu(_bn(sd, p + ".bn1", y, train)))
             if p + ".conv2.weight" in sd:
-                y = F.conv2d(y, sd[p + ".conv2.weight"], stride=s, padding=1)
+                y = q(F.conv2d(y, w(p + ".conv2.weight"), stride=s, padding=1))
             else:
                 y = _aa(sd, p + ".conv2", y, s, nh)
-            y = F.relu(_bn(sd, p + ".bn2", y, train))
-            y = _bn(sd, p + ".bn3", F.conv2d(y, sd[p + ".conv3.weight"]), train)
+            y = q(F.relu(_bn(sd, p + ".bn2", y, train)))
+            y = _bn(sd, p + ".bn3", q(F.conv2d(y, w(p + ".conv3.weight"))), train)
             if p + ".downsample.0.weight" in sd:
-                x = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], stride=s), train)
-            x = F.relu(y + x)
+                x = _bn(sd, p + ".downsample.1", q(F.conv2d(x, w(p + ".downsample.0.weight"), stride=s)), train)
+            x = q(F.relu(y + x))
     if taps is not None:
         taps["layer4"] = x
     return F.linear(x.mean((2, 3)), sd["fc.weight"], sd["fc.bias"])
