@@ -70,6 +70,14 @@ SIGNATURES = {
     "cx_adam_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp],
     "cx_sgd_nesterov_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _f, _vp],
     "cx_rmsprop_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp],
+    "cx_aa_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_aa_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_aa_outproj_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _vp],
+    "cx_aa_outproj_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_stats_bc": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_affine_relu_bc": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_in_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cx_f32_to_bf16": [_vp, _vp, _sz, _vp],
     "cx_gradcam_map": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_cam_norm_upsample": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_fill_f32": [_vp, _f, _sz, _vp],

@@ -1,0 +1,694 @@
+// Attention-augmented convolution (AAConv2d, /root/reference/models/attn_aug_conv.py:19-100) on gfx950.
+//
+// The reference materialises the (B, nh, HW, HW) logits, two expanded relative-logit tensors, the softmax
+// and its autograd copies (82 MB per image at HW = 1600).  Here nothing of size HW x HW ever exists:
+//
+//   S[i][j] = q~_i . k_j + rh_i[ky(j)] + rw_i[kx(j)],   rh_i[ky] = q~_i . key_rel_h[:, ky - qy + H - 1],
+//                                                        rw_i[kx] = q~_i . key_rel_w[:, kx - qx + W - 1]
+//
+// (closed form of rel_to_abs / relative_logits_1d, :43-63, :77-86).  One lane owns one query: q~ (dkh = 20
+// values) lives in registers, its two relative-logit rows (H + W values) in LDS, keys / values stream
+// through LDS tiles and are read as broadcasts, softmax is online (one exp per key).  dkh = 20 and
+// dvh in {1,3,6} make the matrix cores pointless here (hard part 3): this is VALU work
+// bounded by LDS broadcast reads.  The backward pass recomputes P from the saved log-sum-exp.
+#include "common.h"
+
+namespace {
+
+constexpr int AQ = 128;      // queries per workgroup (one per thread)
+constexpr int TK = 64;       // keys per LDS tile
+constexpr int DKH = 20;      // head dim of q/k for every AA layer of the reference (dk = max(20*nh, ...) = 160, nh = 8)
+constexpr int MAXDV = 6;
+
+struct AAGeo {
+  int B, H, W, nh, dk, dv, ldq;     // qkv tensor: (B, H*W, ldq) bf16, channels [q dk | k dk | v dv]
+};
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int DVH>
+__global__ __launch_bounds__(AQ) void aa_attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                        const float* __restrict__ rel_w, float* __restrict__ o,
+                                                        float* __restrict__ lse, const AAGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = g.H, W = g.W, HW = H * W;
+  const int LH = 2 * H - 1, LW = 2 * W - 1;
+  float* RH = lds;                       // [DKH][LH]
+  float* RW = RH + DKH * LH;             // [DKH][LW]
+  float* rh = RW + DKH * LW;             // [AQ][H+1]
+  float* rw = rh + AQ * (H + 1);         // [AQ][W+1]
+  float* Kt = rw + AQ * (W + 1);         // [TK][DKH]
+  float* Vt = Kt + TK * DKH;             // [TK][DVH]
+  const int tid = threadIdx.x;
+  const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
+  const int i = blockIdx.x * AQ + tid;
+  const bool qvalid = i < HW;
+  const int ic = qvalid ? i : HW - 1;
+  const int qy = ic / W, qx = ic - qy * W;
+  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+
+  for (int t = tid; t < DKH * LH; t += AQ) RH[t] = rel_h[t];
+  for (int t = tid; t < DKH * LW; t += AQ) RW[t] = rel_w[t];
+  float q[DKH];
+  const float scale = rsqrtf((float)DKH);
+  {
+    const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
+#pragma unroll
+    for (int d = 0; d < DKH; d += 4) {
+      U64 v;
+      v.u = *reinterpret_cast<const uint2*>(qp + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[d + e] = bf2f(v.e[e]) * scale;
+    }
+  }
+  __syncthreads();
+  for (int ky = 0; ky < H; ++ky) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RH[d * LH + ky - qy + H - 1], a);
+    rh[tid * (H + 1) + ky] = a;
+  }
+  for (int kx = 0; kx < W; ++kx) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RW[d * LW + kx - qx + W - 1], a);
+    rw[tid * (W + 1) + kx] = a;
+  }
+
+  float m = -3.0e38f, l = 0.f, acc[DVH];
+#pragma unroll
+  for (int d = 0; d < DVH; ++d) acc[d] = 0.f;
+  const int kofs = g.dk + n * DKH, vofs = 2 * g.dk + n * DVH;
+  for (int j0 = 0; j0 < HW; j0 += TK) {
+    __syncthreads();
+    // stage TK keys (20 bf16 = 5 x 8 B each) and values
+    for (int t = tid; t < TK * 5; t += AQ) {
+      const int j = t / 5, c = t - j * 5;
+      const int jj = min(j0 + j, HW - 1);
+      U64 v;
+      v.u = *reinterpret_cast<const uint2*>(base + (size_t)jj * g.ldq + kofs + c * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = bf2f(v.e[e]);
+    }
+    for (int t = tid; t < TK * DVH; t += AQ) {
+      const int j = t / DVH, d = t - j * DVH;
+      const int jj = min(j0 + j, HW - 1);
+      Vt[t] = bf2f(base[(size_t)jj * g.ldq + vofs + d]);
+    }
+    __syncthreads();
+    const int jn = min(TK, HW - j0);
+    int ky = j0 / W, kx = j0 - ky * W;
+    for (int j = 0; j < jn; ++j) {
+      float s = rh[tid * (H + 1) + ky] + rw[tid * (W + 1) + kx];
+      const float4* kp = reinterpret_cast<const float4*>(Kt + j * DKH);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const float4 kv = kp[c];
+        s = fmaf(q[4 * c], kv.x, fmaf(q[4 * c + 1], kv.y, fmaf(q[4 * c + 2], kv.z, fmaf(q[4 * c + 3], kv.w, s))));
+      }
+      if (s > m) {
+        const float c = __expf(m - s);
+        l = fmaf(l, c, 1.f);
+#pragma unroll
+        for (int d = 0; d < DVH; ++d) acc[d] = fmaf(acc[d], c, Vt[j * DVH + d]);
+        m = s;
+      } else {
+        const float p = __expf(s - m);
+        l += p;
+#pragma unroll
+        for (int d = 0; d < DVH; ++d) acc[d] = fmaf(p, Vt[j * DVH + d], acc[d]);
+      }
+      if (++kx == W) { kx = 0; ++ky; }
+    }
+  }
+  if (qvalid) {
+    const float inv = 1.f / l;
+    float* op = o + ((size_t)b * HW + i) * g.dv + n * DVH;
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) op[d] = acc[d] * inv;
+    lse[(size_t)bn * HW + i] = m + __logf(l);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// Pass Q (one lane per query): recompute P from the saved LSE, dS = P (dP - delta), accumulate
+//   dq_i = scale * sum_j dS_ij (k_j + RH[:, ky-qy+H-1] + RW[:, kx-qx+W-1])
+//   dRH / dRW : sum_{i,j} dS_ij q~_i at the relative offsets (reduced per workgroup in LDS, then atomics)
+// Pass K (one lane per key): dk_j = sum_i dS_ij q~_i, dv_j = sum_i P_ij dO_i.
+template <int DVH>
+__global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                          const float* __restrict__ rel_w, const float* __restrict__ o,
+                                                          const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                          float* __restrict__ dqkv, float* __restrict__ d_rel_h,
+                                                          float* __restrict__ d_rel_w, const AAGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = g.H, W = g.W, HW = H * W;
+  const int LH = 2 * H - 1, LW = 2 * W - 1;
+  float* RH = lds;
+  float* RW = RH + DKH * LH;
+  float* rh = RW + DKH * LW;             // [AQ][H+1]  logits rows, later re-used as d(rh)
+  float* rw = rh + AQ * (H + 1);
+  float* Kt = rw + AQ * (W + 1);
+  float* Vt = Kt + TK * DKH;
+  float* dRH = Vt + TK * DVH;            // [DKH][LH] workgroup partial
+  float* dRW = dRH + DKH * LH;
+  const int tid = threadIdx.x;
+  const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
+  const int i = blockIdx.x * AQ + tid;
+  const bool qvalid = i < HW;
+  const int ic = qvalid ? i : HW - 1;
+  const int qy = ic / W, qx = ic - qy * W;
+  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+
+  for (int t = tid; t < DKH * LH; t += AQ) { RH[t] = rel_h[t]; dRH[t] = 0.f; }
+  for (int t = tid; t < DKH * LW; t += AQ) { RW[t] = rel_w[t]; dRW[t] = 0.f; }
+  float q[DKH];
+  const float scale = rsqrtf((float)DKH);
+  {
+    const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
+#pragma unroll
+    for (int d = 0; d < DKH; d += 4) {
+      U64 v;
+      v.u = *reinterpret_cast<const uint2*>(qp + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[d + e] = bf2f(v.e[e]) * scale;
+    }
+  }
+  float dO[DVH], delta = 0.f;
+  {
+    const float* op = o + ((size_t)b * HW + ic) * g.dv + n * DVH;
+    const float* dp = d_o + ((size_t)b * HW + ic) * g.dv + n * DVH;
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) { dO[d] = qvalid ? dp[d] : 0.f; delta = fmaf(dO[d], op[d], delta); }
+  }
+  const float L = lse[(size_t)bn * HW + ic];
+  __syncthreads();
+  for (int ky = 0; ky < H; ++ky) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RH[d * LH + ky - qy + H - 1], a);
+    rh[tid * (H + 1) + ky] = a;
+  }
+  for (int kx = 0; kx < W; ++kx) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RW[d * LW + kx - qx + W - 1], a);
+    rw[tid * (W + 1) + kx] = a;
+  }
+  // per-query accumulators: dq (through k_j) and the row/column sums of dS (d rh_i[ky], d rw_i[kx]) kept in LDS
+  // as a second half of the rh/rw rows would double LDS; instead accumulate d(rw) per kx in registers-free form:
+  // d rh_i[ky] is final when the key row ky ends, d rw_i[kx] accumulates over rows in LDS (own row, no conflicts).
+  float dq[DKH];
+#pragma unroll
+  for (int d = 0; d < DKH; ++d) dq[d] = 0.f;
+  float* drw = Kt + TK * DKH + TK * DVH + DKH * (LH + LW);      // [AQ][W+1], behind dRW
+  for (int kx = 0; kx < W; ++kx) drw[tid * (W + 1) + kx] = 0.f;
+  const int kofs = g.dk + n * DKH, vofs = 2 * g.dk + n * DVH;
+  float drh_run = 0.f;
+  for (int j0 = 0; j0 < HW; j0 += TK) {
+    __syncthreads();
+    for (int t = tid; t < TK * 5; t += AQ) {
+      const int j = t / 5, c = t - j * 5;
+      const int jj = min(j0 + j, HW - 1);
+      U64 v;
+      v.u = *reinterpret_cast<const uint2*>(base + (size_t)jj * g.ldq + kofs + c * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = bf2f(v.e[e]);
+    }
+    for (int t = tid; t < TK * DVH; t += AQ) {
+      const int j = t / DVH, d = t - j * DVH;
+      const int jj = min(j0 + j, HW - 1);
+      Vt[t] = bf2f(base[(size_t)jj * g.ldq + vofs + d]);
+    }
+    __syncthreads();
+    const int jn = min(TK, HW - j0);
+    int ky = j0 / W, kx = j0 - ky * W;
+    for (int j = 0; j < jn; ++j) {
+      float s = rh[tid * (H + 1) + ky] + rw[tid * (W + 1) + kx];
+      const float4* kp = reinterpret_cast<const float4*>(Kt + j * DKH);
+      float4 kv[5];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        kv[c] = kp[c];
+        s = fmaf(q[4 * c], kv[c].x, fmaf(q[4 * c + 1], kv[c].y, fmaf(q[4 * c + 2], kv[c].z, fmaf(q[4 * c + 3], kv[c].w, s))));
+      }
+      const float p = __expf(s - L);
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < DVH; ++d) dp = fmaf(dO[d], Vt[j * DVH + d], dp);
+      const float ds = p * (dp - delta);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        dq[4 * c] = fmaf(ds, kv[c].x, dq[4 * c]);
+        dq[4 * c + 1] = fmaf(ds, kv[c].y, dq[4 * c + 1]);
+        dq[4 * c + 2] = fmaf(ds, kv[c].z, dq[4 * c + 2]);
+        dq[4 * c + 3] = fmaf(ds, kv[c].w, dq[4 * c + 3]);
+      }
+      drh_run += ds;
+      drw[tid * (W + 1) + kx] += ds;
+      if (++kx == W) {
+        // key row ky complete: fold d rh_i[ky] into dq and into the workgroup's dRH partial
+        if (qvalid) {
+          const int r = ky - qy + H - 1;
+#pragma unroll
+          for (int d = 0; d < DKH; ++d) {
+            dq[d] = fmaf(drh_run, RH[d * LH + r], dq[d]);
+            atomicAdd(&dRH[d * LH + r], drh_run * q[d]);
+          }
+        }
+        drh_run = 0.f;
+        kx = 0;
+        ++ky;
+      }
+    }
+  }
+  if (qvalid) {
+    for (int kx = 0; kx < W; ++kx) {
+      const float dsum = drw[tid * (W + 1) + kx];
+      const int r = kx - qx + W - 1;
+#pragma unroll
+      for (int d = 0; d < DKH; ++d) {
+        dq[d] = fmaf(dsum, RW[d * LW + r], dq[d]);
+        atomicAdd(&dRW[d * LW + r], dsum * q[d]);
+      }
+    }
+    float* dqp = dqkv + ((size_t)b * HW + i) * (2 * g.dk + g.dv) + n * DKH;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) dqp[d] = dq[d] * scale;       // q~ = q * scale
+  }
+  __syncthreads();
+  for (int t = tid; t < DKH * LH; t += AQ) atomicAdd(&d_rel_h[t], dRH[t]);
+  for (int t = tid; t < DKH * LW; t += AQ) atomicAdd(&d_rel_w[t], dRW[t]);
+}
+
+template <int DVH>
+__global__ __launch_bounds__(AQ) void aa_attn_bwd_k_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                          const float* __restrict__ rel_w, const float* __restrict__ o,
+                                                          const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                          float* __restrict__ dqkv, const AAGeo g) {
+  // one lane per KEY j; queries stream through LDS: q~_i, dO_i, delta_i, lse_i.  S_ij needs the relative terms
+  // q~_i . (RH[:, ky-qy+H-1] + RW[:, kx-qx+W-1]): fold them into the key: k'_j(i) is query dependent, so instead
+  // use S_ij = q~_i . k_j + rhT_j[qy] + rwT_j[qx] with rhT_j[qy] = q~_i . RH[:, ky-qy+H-1] -- still query dependent.
+  // => stage per query tile the two logit rows' entries for THIS key row/column: (rh_i[ky], rw_i[kx]) differ per key,
+  // so each lane recomputes the 2 dot products with its own offsets: 2 x 20 FMA extra per pair.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = g.H, W = g.W, HW = H * W;
+  const int LH = 2 * H - 1, LW = 2 * W - 1;
+  float* RH = lds;
+  float* RW = RH + DKH * LH;
+  float* Qt = RW + DKH * LW;             // [TK][DKH] scaled queries
+  float* Dt = Qt + TK * DKH;             // [TK][DVH] dO
+  float* Et = Dt + TK * DVH;             // [TK][2]   delta, lse
+  const int tid = threadIdx.x;
+  const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
+  const int j = blockIdx.x * AQ + tid;
+  const bool kvalid = j < HW;
+  const int jc = kvalid ? j : HW - 1;
+  const int ky = jc / W, kx = jc - ky * W;
+  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  for (int t = tid; t < DKH * LH; t += AQ) RH[t] = rel_h[t];
+  for (int t = tid; t < DKH * LW; t += AQ) RW[t] = rel_w[t];
+  float k[DKH], v[DVH], dk[DKH], dv[DVH];
+  {
+    const bf16* kp = base + (size_t)jc * g.ldq + g.dk + n * DKH;
+#pragma unroll
+    for (int d = 0; d < DKH; d += 4) {
+      U64 u;
+      u.u = *reinterpret_cast<const uint2*>(kp + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) k[d + e] = bf2f(u.e[e]);
+    }
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) v[d] = bf2f(base[(size_t)jc * g.ldq + 2 * g.dk + n * DVH + d]);
+  }
+#pragma unroll
+  for (int d = 0; d < DKH; ++d) dk[d] = 0.f;
+#pragma unroll
+  for (int d = 0; d < DVH; ++d) dv[d] = 0.f;
+  const float scale = rsqrtf((float)DKH);
+  for (int i0 = 0; i0 < HW; i0 += TK) {
+    __syncthreads();
+    for (int t = tid; t < TK * 5; t += AQ) {
+      const int ii = t / 5, c = t - ii * 5;
+      const int iq = min(i0 + ii, HW - 1);
+      U64 u;
+      u.u = *reinterpret_cast<const uint2*>(base + (size_t)iq * g.ldq + n * DKH + c * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Qt[ii * DKH + c * 4 + e] = bf2f(u.e[e]) * scale;
+    }
+    for (int t = tid; t < TK; t += AQ) {
+      const int iq = min(i0 + t, HW - 1);
+      const bool ok = i0 + t < HW;
+      float de = 0.f;
+#pragma unroll
+      for (int d = 0; d < DVH; ++d) {
+        const float dd = ok ? d_o[((size_t)b * HW + iq) * g.dv + n * DVH + d] : 0.f;
+        Dt[t * DVH + d] = dd;
+        de = fmaf(dd, o[((size_t)b * HW + iq) * g.dv + n * DVH + d], de);
+      }
+      Et[2 * t] = de;
+      Et[2 * t + 1] = ok ? lse[(size_t)bn * HW + iq] : 3.0e38f;      // p = exp(s - inf) = 0 for padding queries
+    }
+    __syncthreads();
+    const int in_ = min(TK, HW - i0);
+    int qy = i0 / W, qx = i0 - qy * W;
+    for (int ii = 0; ii < in_; ++ii) {
+      const float* qp = Qt + ii * DKH;
+      const int rhh = ky - qy + H - 1, rww = kx - qx + W - 1;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DKH; ++d) s = fmaf(qp[d], k[d] + RH[d * LH + rhh] + RW[d * LW + rww], s);
+      const float p = __expf(s - Et[2 * ii + 1]);
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < DVH; ++d) {
+        dp = fmaf(Dt[ii * DVH + d], v[d], dp);
+        dv[d] = fmaf(p, Dt[ii * DVH + d], dv[d]);
+      }
+      const float ds = p * (dp - Et[2 * ii]);
+#pragma unroll
+      for (int d = 0; d < DKH; ++d) dk[d] = fmaf(ds, qp[d], dk[d]);
+      if (++qx == W) { qx = 0; ++qy; }
+    }
+  }
+  if (kvalid) {
+    float* dp = dqkv + ((size_t)b * HW + j) * (2 * g.dk + g.dv);
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) dp[g.dk + n * DKH + d] = dk[d];
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) dp[2 * g.dk + n * DVH + d] = dv[d];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- elementwise glue
+// per-(b,c) affine + ReLU (InstanceNorm2d + ReLU ahead of the AAConv2d, attn_aug_conv.py:438-439)
+__global__ void affine_relu_bc_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                      bf16* __restrict__ y, int HW, int C, int ldx, size_t total) {
+  const int CP = C / 8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cq = idx % CP;
+    const size_t pix = idx / CP;
+    const int b = pix / HW;
+    U128 v, o;
+    v.u = *reinterpret_cast<const uint4*>(x + pix * ldx + cq * 8);
+    const float* s = sc + (size_t)b * C + cq * 8;
+    const float* h = sh + (size_t)b * C + cq * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), s[j], h[j]), 0.f));
+    *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+  }
+}
+
+// per-(b,c) sums over the pixels of an image: sum, sum of squares (InstanceNorm statistics)
+__global__ __launch_bounds__(256) void stats_bc_kernel(const bf16* __restrict__ x, float* __restrict__ sum, float* __restrict__ sq,
+                                                      int HW, int C, int ldx, int splits) {
+  extern __shared__ float lds[];          // [2][C]
+  const int CP = C / 8;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CP, rr = threadIdx.x / CP, rpp = blockDim.x / CP;
+  const int len = (HW + splits - 1) / splits;
+  const int p0 = sp * len, p1 = min(HW, p0 + len);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  for (int p = p0 + rr; p < p1; p += rpp) {
+    U128 v;
+    v.u = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * ldx + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bf2f(v.e[j]);
+      s1[j] += f;
+      s2[j] += f * f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&lds[cq * 8 + j], s1[j]);
+    atomicAdd(&lds[C + cq * 8 + j], s2[j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(&sum[(size_t)b * C + c], lds[c]);
+    atomicAdd(&sq[(size_t)b * C + c], lds[C + c]);
+  }
+}
+
+// out_proj (dv x dv 1x1 conv, :92) on the fp32 attention output, written as bf16 into the block-buffer slice
+// [+ per-channel statistics of the rounded output]
+__global__ void aa_outproj_fwd_kernel(const float* __restrict__ o, const float* __restrict__ w, bf16* __restrict__ y, int ldy,
+                                      float* stat_sum, float* stat_sq, size_t npix, int dv) {
+  __shared__ float ws[48 * 48];
+  __shared__ float st[2 * 48];
+  for (int t = threadIdx.x; t < dv * dv; t += blockDim.x) ws[t] = w[t];
+  for (int t = threadIdx.x; t < 2 * dv; t += blockDim.x) st[t] = 0.f;
+  __syncthreads();
+  // thread = (pixel, output channel)
+  const size_t total = npix * dv;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = idx / dv;
+    const int c = idx - pix * dv;
+    const float* op = o + pix * dv;
+    float a = 0.f;
+    for (int d = 0; d < dv; ++d) a = fmaf(ws[c * dv + d], op[d], a);
+    const bf16 r = f2bf(a);
+    y[pix * ldy + c] = r;
+    const float rv = bf2f(r);
+    atomicAdd(&st[c], rv);
+    atomicAdd(&st[dv + c], rv * rv);
+  }
+  __syncthreads();
+  if (stat_sum)
+    for (int t = threadIdx.x; t < dv; t += blockDim.x) {
+      atomicAdd(&stat_sum[t], st[t]);
+      atomicAdd(&stat_sq[t], st[dv + t]);
+    }
+}
+
+// backward of out_proj: dO[pix][d] = sum_c dY[pix][c] * W[c][d];  dW[c][d] += sum_pix dY[pix][c] * O[pix][d]
+// dY = g*ga + gx*gb + gc (deferred BN correction of the gradient-buffer slice)
+__global__ void aa_outproj_bwd_kernel(const bf16* __restrict__ g, int ldg, const bf16* __restrict__ gx, int ldgx,
+                                      const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc,
+                                      const float* __restrict__ o, const float* __restrict__ w, float* __restrict__ d_o,
+                                      float* __restrict__ dw, size_t npix, int dv) {
+  __shared__ float ws[48 * 48];
+  __shared__ float dws[48 * 48];
+  for (int t = threadIdx.x; t < dv * dv; t += blockDim.x) { ws[t] = w[t]; dws[t] = 0.f; }
+  __syncthreads();
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+    float dy[48];
+    for (int c = 0; c < dv; ++c) dy[c] = fmaf(bf2f(g[pix * ldg + c]), ga[c], fmaf(bf2f(gx[pix * ldgx + c]), gb[c], gc[c]));
+    const float* op = o + pix * dv;
+    for (int d = 0; d < dv; ++d) {
+      float a = 0.f;
+      for (int c = 0; c < dv; ++c) a = fmaf(dy[c], ws[c * dv + d], a);
+      d_o[pix * dv + d] = a;
+      const float od = op[d];
+      for (int c = 0; c < dv; ++c) atomicAdd(&dws[c * dv + d], dy[c] * od);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < dv * dv; t += blockDim.x) atomicAdd(&dw[t], dws[t]);
+}
+
+// fp32 (B,HW,C) -> bf16 same shape
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+
+// InstanceNorm + ReLU backward: dz = dA * [a > 0];  dx = r * (dz - mean_hw(dz) - xhat * mean_hw(dz * xhat)) per (b,c)
+// pass 1: S1[b][c] = sum dz, S2[b][c] = sum dz*xhat      pass 2: write dx
+__global__ __launch_bounds__(256) void in_relu_bwd_stats_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
+                                                               const float* __restrict__ sc, const float* __restrict__ sh,
+                                                               float* __restrict__ S1, float* __restrict__ S2, int HW, int C, int ldx,
+                                                               int splits) {
+  extern __shared__ float lds[];
+  const int CP = C / 8;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CP, rr = threadIdx.x / CP, rpp = blockDim.x / CP;
+  const int len = (HW + splits - 1) / splits;
+  const int p0 = sp * len, p1 = min(HW, p0 + len);
+  float s1[8], s2[8], fs[8], fh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; fs[j] = sc[(size_t)b * C + cq * 8 + j]; fh[j] = sh[(size_t)b * C + cq * 8 + j]; }
+  for (int p = p0 + rr; p < p1; p += rpp) {
+    U128 v, d;
+    const size_t pix = (size_t)b * HW + p;
+    v.u = *reinterpret_cast<const uint4*>(x + pix * ldx + cq * 8);
+    d.u = *reinterpret_cast<const uint4*>(da + pix * C + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = fmaf(bf2f(v.e[j]), fs[j], fh[j]);          // xhat = (x-mean)*rstd
+      const float dz = xh > 0.f ? bf2f(d.e[j]) : 0.f;
+      s1[j] += dz;
+      s2[j] += dz * xh;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&lds[cq * 8 + j], s1[j]);
+    atomicAdd(&lds[C + cq * 8 + j], s2[j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(&S1[(size_t)b * C + c], lds[c]);
+    atomicAdd(&S2[(size_t)b * C + c], lds[C + c]);
+  }
+}
+
+__global__ void in_relu_bwd_apply_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x, const float* __restrict__ sc,
+                                         const float* __restrict__ sh, const float* __restrict__ S1, const float* __restrict__ S2,
+                                         bf16* __restrict__ gout, int HW, int C, int ldx, int ldg, size_t total) {
+  const int CP = C / 8;
+  const float inv = 1.f / HW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cq = idx % CP;
+    const size_t pix = idx / CP;
+    const int b = pix / HW;
+    U128 v, d, o;
+    v.u = *reinterpret_cast<const uint4*>(x + pix * ldx + cq * 8);
+    d.u = *reinterpret_cast<const uint4*>(da + pix * C + cq * 8);
+    const size_t bc = (size_t)b * C + cq * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float r = sc[bc + j];
+      const float xh = fmaf(bf2f(v.e[j]), r, sh[bc + j]);
+      const float dz = xh > 0.f ? bf2f(d.e[j]) : 0.f;
+      o.e[j] = f2bf(r * (dz - S1[bc + j] * inv - xh * S2[bc + j] * inv));
+    }
+    *reinterpret_cast<uint4*>(gout + pix * ldg + cq * 8) = o.u;
+  }
+}
+
+inline int grid_for(size_t n, int block, int cap) {
+  size_t gsz = (n + block - 1) / block;
+  if (gsz > (size_t)cap) gsz = cap;
+  if (gsz < 1) gsz = 1;
+  return (int)gsz;
+}
+
+inline size_t attn_lds_floats(int H, int W, int dvh) { return (size_t)DKH * (2 * H - 1 + 2 * W - 1) + (size_t)AQ * (H + W + 2) + TK * (DKH + dvh); }
+
+}  // namespace
+
+extern "C" {
+
+int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w, float* o, float* lse, int B, int H, int W, int nh,
+                        int dk, int dv, int ldq, void* stream) {
+  if (!qkv || !rel_h || !rel_w || !o || !lse) return CX_EINVAL;
+  if (nh <= 0 || dk != nh * DKH || dv % nh || dv / nh > MAXDV || (ldq % 4)) return CX_ESHAPE;
+  const int dvh = dv / nh;
+  AAGeo g{B, H, W, nh, dk, dv, ldq};
+  const size_t smem = attn_lds_floats(H, W, dvh) * 4;
+  if (smem > 64 * 1024) return CX_ESHAPE;
+  dim3 grid((H * W + AQ - 1) / AQ, B * nh);
+  hipStream_t st = as_stream(stream);
+#define LAUNCH(D) hipLaunchKernelGGL(aa_attn_fwd_kernel<D>, grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, lse, g)
+  switch (dvh) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 6: LAUNCH(6); break;
+    default: return CX_EUNSUPPORTED;
+  }
+#undef LAUNCH
+  return launch_status();
+}
+
+int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w, const float* o, const float* d_o, const float* lse,
+                        float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq,
+                        void* stream) {
+  if (!qkv || !rel_h || !rel_w || !o || !d_o || !lse || !dqkv || !d_rel_h || !d_rel_w) return CX_EINVAL;
+  if (nh <= 0 || dk != nh * DKH || dv % nh || dv / nh > MAXDV || (ldq % 4)) return CX_ESHAPE;
+  const int dvh = dv / nh;
+  AAGeo g{B, H, W, nh, dk, dv, ldq};
+  const size_t smem_q = (attn_lds_floats(H, W, dvh) + (size_t)DKH * (2 * H - 1 + 2 * W - 1) + (size_t)AQ * (W + 1)) * 4;
+  const size_t smem_k = ((size_t)DKH * (2 * H - 1 + 2 * W - 1) + TK * (DKH + dvh + 2)) * 4;
+  if (smem_q > 160 * 1024) return CX_ESHAPE;
+  dim3 grid((H * W + AQ - 1) / AQ, B * nh);
+  hipStream_t st = as_stream(stream);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+#define LAUNCH(D)                                                                                                              \
+  hipLaunchKernelGGL(aa_attn_bwd_q_kernel<D>, grid, dim3(AQ), smem_q, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv,   \
+                     d_rel_h, d_rel_w, g);                                                                                    \
+  hipLaunchKernelGGL(aa_attn_bwd_k_kernel<D>, grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g)
+  switch (dvh) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 6: LAUNCH(6); break;
+    default: return CX_EUNSUPPORTED;
+  }
+#undef LAUNCH
+  return launch_status();
+}
+
+int cx_stats_bc(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream) {
+  if (!x || !sum || !sq || C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || C / 8 > 256 || ldx % 8) return CX_EINVAL;
+  int splits = 2048 / B;
+  if (splits < 1) splits = 1;
+  if (splits > HW / 32 + 1) splits = HW / 32 + 1;
+  hipLaunchKernelGGL(stats_bc_kernel, dim3(splits, B), dim3(256), 2 * C * sizeof(float), as_stream(stream), (const bf16*)x, sum, sq, HW,
+                     C, ldx, splits);
+  return launch_status();
+}
+
+int cx_affine_relu_bc(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream) {
+  if (!x || !sc || !sh || !y || C % 8 || ldx % 8) return CX_EINVAL;
+  const size_t total = (size_t)B * HW * (C / 8);
+  hipLaunchKernelGGL(affine_relu_bc_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)x, sc, sh,
+                     (bf16*)y, HW, C, ldx, total);
+  return launch_status();
+}
+
+int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
+                      void* stream) {
+  if (!o || !w || !y || dv <= 0 || dv > 48) return CX_EINVAL;
+  hipLaunchKernelGGL(aa_outproj_fwd_kernel, dim3(grid_for(npix * dv, 256, 2048)), dim3(256), 0, as_stream(stream), o, w, (bf16*)y, ldy,
+                     stat_sum, stat_sq, npix, dv);
+  return launch_status();
+}
+
+int cx_aa_outproj_bwd(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
+                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, void* stream) {
+  if (!g || !gx || !ga || !gb || !gc || !o || !w || !d_o || !dw || dv <= 0 || dv > 48) return CX_EINVAL;
+  hipLaunchKernelGGL(aa_outproj_bwd_kernel, dim3(grid_for(npix, 128, 1024)), dim3(128), 0, as_stream(stream), (const bf16*)g, ldg,
+                     (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, npix, dv);
+  return launch_status();
+}
+
+int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {
+  if (!x || !y) return CX_EINVAL;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, as_stream(stream), x, (bf16*)y, n);
+  return launch_status();
+}
+
+int cx_in_relu_bwd(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,
+                   int C, int ldx, int ldg, void* stream) {
+  if (!da || !x || !sc || !sh || !S1 || !S2 || !gout) return CX_EINVAL;
+  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || C / 8 > 256 || ldx % 8 || ldg % 8) return CX_ESHAPE;
+  int splits = 2048 / B;
+  if (splits < 1) splits = 1;
+  if (splits > HW / 32 + 1) splits = HW / 32 + 1;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(in_relu_bwd_stats_kernel, dim3(splits, B), dim3(256), 2 * C * sizeof(float), st, (const bf16*)da, (const bf16*)x,
+                     sc, sh, S1, S2, HW, C, ldx, splits);
+  const size_t total = (size_t)B * HW * (C / 8);
+  hipLaunchKernelGGL(in_relu_bwd_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, (const bf16*)da, (const bf16*)x, sc,
+                     sh, S1, S2, (bf16*)gout, HW, C, ldx, ldg, total);
+  return launch_status();
+}
+
+}  // extern "C"

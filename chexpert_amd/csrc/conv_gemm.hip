@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
       rix[i] = 2 * ox - 4 + 2 * qa;
     }
   }
-  const int kpt = (MODE == CX_MODE_STEM) ? 1 : p.K / BK;         // K steps per tap
+  const int kpt = (MODE == CX_MODE_STEM) ? 1 : (p.K + BK - 1) / BK;         // K steps per tap (last one may be partial: K % 8 == 0)
   const int taps = (MODE == CX_MODE_STEM) ? 7 : p.kh * p.kw;
   const int nsteps = taps * kpt;
   const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
@@ -126,11 +126,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
           iy /= p.tstride;
           ix /= p.tstride;
         }
-        av[i] = ok && iy < p.H && ix < p.W;
+        const bool kok = kc * BK + qa * 8 < p.K;                  // partial last K step
+        av[i] = ok && iy < p.H && ix < p.W && kok;
         const int cy = av[i] ? iy : 0, cx = av[i] ? ix : 0;
+        const int ck = kok ? kc * BK + qa * 8 : 0;
         const size_t pix = (size_t)(rb[i] * p.H + cy) * p.W + cx;
-        ra[i][0] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + kc * BK + qa * 8);
-        if (PRO == CX_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(X2 + pix * p.ldx2 + kc * BK + qa * 8);
+        ra[i][0] = *reinterpret_cast<const uint4*>(X + pix * p.ldx + ck);
+        if (PRO == CX_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const uint4*>(X2 + pix * p.ldx2 + ck);
       }
     }
     // weights: rows n = tid>>2 (+64), chunk qa
@@ -139,9 +141,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
       const int nb = (tid >> 2) + 64 * i;
       if (nb < BN) {                       // compile-time per (i, BN) except BN=32 (uniform per wave)
         const int n = n0 + nb;
-        wv[i] = n < p.N;
+        const bool kok = (MODE == CX_MODE_STEM) || (kc * BK + qa * 8 < p.K);
+        wv[i] = n < p.N && kok;
         const int nc = wv[i] ? n : 0;
-        const size_t off = ((size_t)tap * p.N + nc) * (size_t)(MODE == CX_MODE_STEM ? BK : p.K) + kc * BK + qa * 8;
+        const size_t off = ((size_t)tap * p.N + nc) * (size_t)(MODE == CX_MODE_STEM ? BK : p.K) + (kok ? kc * BK + qa * 8 : 0);
         rbw[i] = *reinterpret_cast<const uint4*>(Wp + off);
       }
     }
@@ -373,7 +376,8 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   const CxConv& p = *pp;
   if (!p.x || !p.w || !p.y) return CX_EINVAL;
   if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
-  if (p.K <= 0 || p.N <= 0 || (p.K % 32) || (p.N % 32)) return CX_ESHAPE;
+  if (p.K <= 0 || p.N <= 0 || (p.K % 8) || (p.N % 8)) return CX_ESHAPE;
+  if (p.mode == CX_MODE_POOL2 && (p.K % 32)) return CX_ESHAPE;
   if (p.mode == CX_MODE_STEM ? (p.ldx != 4) : (p.ldx % 8 != 0)) return CX_EALIGN;
   if ((p.ldy % 8) || !aligned16(p.x) || !aligned16(p.y) || !aligned16(p.w)) return CX_EALIGN;
   if ((long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;

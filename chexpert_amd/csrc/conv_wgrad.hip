@@ -295,7 +295,7 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
   const CxWgrad& p = *pp;
   if (!p.g || !p.x || !p.dw) return CX_EINVAL;
   if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
-  if (p.K <= 0 || p.N <= 0 || (p.K % 32) || (p.N % 32)) return CX_ESHAPE;
+  if (p.K <= 0 || p.N <= 0 || (p.K % 8) || (p.N % 8)) return CX_ESHAPE;
   if ((long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;
   if (p.mode == CX_MODE_STEM ? (p.ldx != 4) : (p.ldx % 8 != 0)) return CX_EALIGN;
   if ((p.ldg % 8) || !aligned16(p.g) || !aligned16(p.x)) return CX_EALIGN;

@@ -200,3 +200,49 @@ def bf16_to_f32_nchw(x, out=None):
         out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
     check(lib().cx_bf16_to_f32_nchw(ptr(x), ptr(out), B, H, W, Cc, ldx, stream_ptr()), "cx_bf16_to_f32_nchw")
     return out
+
+
+# ---- attention-augmented convolution pieces (csrc/aaconv.hip)
+def aa_attention_fwd(qkv, key_rel_h, key_rel_w, o, lse, nh, dk, dv):
+    B, H, W, Cq, ldq = _nhwc(qkv)
+    check(lib().cx_aa_attention_fwd(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(o), ptr(lse), B, H, W, nh, dk, dv, ldq, stream_ptr()),
+          "cx_aa_attention_fwd")
+
+
+def aa_attention_bwd(qkv, key_rel_h, key_rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, nh, dk, dv):
+    B, H, W, Cq, ldq = _nhwc(qkv)
+    check(lib().cx_aa_attention_bwd(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(o), ptr(d_o), ptr(lse), ptr(dqkv), ptr(d_rel_h),
+                                    ptr(d_rel_w), B, H, W, nh, dk, dv, ldq, stream_ptr()), "cx_aa_attention_bwd")
+
+
+def aa_outproj_fwd(o, w, y, stat_sum, stat_sq):
+    B, H, W, dv, ldy = _nhwc(y)
+    check(lib().cx_aa_outproj_fwd(ptr(o), ptr(w), ptr(y), ldy, ptr(stat_sum), ptr(stat_sq), B * H * W, dv, stream_ptr()), "cx_aa_outproj_fwd")
+
+
+def aa_outproj_bwd(g, gx, ga, gb, gc, o, w, d_o, dw):
+    B, H, W, dv, ldg = _nhwc(g)
+    check(lib().cx_aa_outproj_bwd(ptr(g), ldg, ptr(gx), _nhwc(gx)[4], ptr(ga), ptr(gb), ptr(gc), ptr(o), ptr(w), ptr(d_o), ptr(dw),
+                                  B * H * W, dv, stream_ptr()), "cx_aa_outproj_bwd")
+
+
+def stats_bc(x, s, q):
+    B, H, W, Cc, ldx = _nhwc(x)
+    check(lib().cx_stats_bc(ptr(x), ptr(s), ptr(q), B, H * W, Cc, ldx, stream_ptr()), "cx_stats_bc")
+
+
+def affine_relu_bc(x, sc, sh, y):
+    B, H, W, Cc, ldx = _nhwc(x)
+    assert _nhwc(y)[4] == Cc
+    check(lib().cx_affine_relu_bc(ptr(x), ptr(sc), ptr(sh), ptr(y), B, H * W, Cc, ldx, stream_ptr()), "cx_affine_relu_bc")
+
+
+def in_relu_bwd(da, x, sc, sh, S1, S2, gout):
+    B, H, W, Cc, ldx = _nhwc(x)
+    assert _nhwc(da)[4] == Cc
+    check(lib().cx_in_relu_bwd(ptr(da), ptr(x), ptr(sc), ptr(sh), ptr(S1), ptr(S2), ptr(gout), B, H * W, Cc, ldx, _nhwc(gout)[4],
+                               stream_ptr()), "cx_in_relu_bwd")
+
+
+def f32_to_bf16(x, y):
+    check(lib().cx_f32_to_bf16(ptr(x), ptr(y), x.numel(), stream_ptr()), "cx_f32_to_bf16")

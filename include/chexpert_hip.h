@@ -61,7 +61,7 @@ typedef struct CxConv {
   const void* ex;       /* CX_EPI_MASK: bf16 tensor (B,Ho,Wo,ldex) the ReLU mask / xhat come from  */
   const float* e_sc; const float* e_sh; const float* e_mu; const float* e_r; const float* e_scale; /* [N] */
   int32_t B, H, W, Ho, Wo;
-  int32_t K, N;         /* channels per tap in / out; both multiples of 32                         */
+  int32_t K, N;         /* channels per tap in / out; both multiples of 8                          */
   int32_t ldx, ldx2, ldy, ldex;
   int32_t kh, kw, stride, pad;
   int32_t prologue, mode, epilogue, accumulate;   /* accumulate: y += result (both epilogues)             */
@@ -195,6 +195,29 @@ int cx_sgd_nesterov_step(float* p, const float* g, float* buf, size_t n, float l
                          float weight_decay, int first_step, float grad_scale, void* stream);
 int cx_rmsprop_step(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha, float eps,
                     float momentum, float weight_decay, float grad_scale, void* stream);
+
+/* ---- attention-augmented convolution (AAConv2d, models/attn_aug_conv.py:19-100) --------------------
+ * qkv: bf16 (B, H*W, ldq) output of in_proj_qkv (channels [q dk | k dk | v dv], head-major), dk = 20*nh.
+ * o: fp32 (B, H*W, dv) attention output BEFORE out_proj; lse: fp32 (B*nh, H*W) log-sum-exp of the logits.
+ * Logits include the relative terms of rel_to_abs / relative_logits_1d (:43-63) in closed form; the
+ * (B,nh,HW,HW) tensors of the reference are never materialised.                                      */
+int cx_aa_attention_fwd(const void* qkv, const float* key_rel_h, const float* key_rel_w, float* o, float* lse, int B, int H, int W,
+                        int nh, int dk, int dv, int ldq, void* stream);
+/* dqkv: fp32 (B, H*W, 2dk+dv) fully written; d_rel_h / d_rel_w (dkh, 2H-1 / 2W-1) accumulated with atomics */
+int cx_aa_attention_bwd(const void* qkv, const float* key_rel_h, const float* key_rel_w, const float* o, const float* d_o,
+                        const float* lse, float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv,
+                        int ldq, void* stream);
+/* out_proj (dv x dv, :92) forward into a bf16 channel slice (+stats) and its backward (dY = g*ga+gx*gb+gc) */
+int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
+                      void* stream);
+int cx_aa_outproj_bwd(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
+                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, void* stream);
+/* InstanceNorm2d + ReLU ahead of the AAConv2d (:438-439): per-(b,c) sums, per-(b,c) affine+ReLU, and the backward */
+int cx_stats_bc(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream);
+int cx_affine_relu_bc(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream);
+int cx_in_relu_bwd(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,
+                   int C, int ldx, int ldg, void* stream);
+int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream);
 
 /* Grad-CAM as the reference code executes it (chexpert.py:260-303):
  * cam[b][p] = relu(sum_c w[c]*relu(x*scale+shift)) with class-independent w[c] = mean_b pooled[b][c]*B/n_cls,

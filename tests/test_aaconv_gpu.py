@@ -1,0 +1,111 @@
+"""GPU: attention-augmented convolution kernels against the oracle's closed form."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from chexpert_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from chexpert_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def close(got, want, rel, what=""):
+    scale = want.abs().max().item() + 1e-9
+    err = (got - want).abs().max().item()
+    assert err <= rel * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+
+
+@pytest.mark.parametrize("B,H,W,dv", [(2, 5, 7, 8), (1, 10, 10, 48), (2, 20, 20, 24), (1, 40, 40, 8)])
+def test_attention_forward_backward(dev, B, H, W, dv):
+    from chexpert_amd import ops
+    from oracle import aaconv
+    nh, dk = 8, 160
+    dkh, dvh = dk // nh, dv // nh
+    Cq = 2 * dk + dv
+    qkv = bf(synth.uniform(1, (B, H, W, Cq), -1.5, 1.5))
+    rel_h = synth.uniform(2, (dkh, 2 * H - 1), -1, 1) + dk ** -0.5
+    rel_w = synth.uniform(3, (dkh, 2 * W - 1), -1, 1) + dk ** -0.5
+    d_o = synth.uniform(4, (B, H * W, dv), -1, 1)
+    # oracle on the same (bf16-rounded) qkv
+    t = qkv.permute(0, 3, 1, 2).clone().requires_grad_(True)               # (B,Cq,H,W)
+    rh, rw = rel_h.clone().requires_grad_(True), rel_w.clone().requires_grad_(True)
+    q = t[:, :dk].reshape(B, nh, dkh, H, W) * dkh ** -0.5
+    k = t[:, dk:2 * dk].reshape(B, nh, dkh, H, W)
+    v = t[:, 2 * dk:].reshape(B, nh, dvh, H * W)
+    P = torch.softmax(aaconv.attention_logits(q, k, rh, rw).reshape(B, nh, H * W, H * W), -1)
+    o_ref = torch.einsum("bnqk,bndk->bqnd", P, v).reshape(B, H * W, dv)      # channels head-major n*dvh+d
+    (o_ref * d_o).sum().backward()
+    qd = qkv.to(torch.bfloat16).to(dev)
+    o = torch.zeros(B, H * W, dv, device=dev)
+    lse = torch.zeros(B * nh, H * W, device=dev)
+    ops.aa_attention_fwd(qd, rel_h.to(dev), rel_w.to(dev), o, lse, nh, dk, dv)
+    close(o.cpu(), o_ref.detach(), 2e-4, "o")
+    dqkv = torch.full((B, H * W, Cq), 7.0, device=dev)
+    drh, drw = torch.zeros_like(rel_h, device=dev), torch.zeros_like(rel_w, device=dev)
+    ops.aa_attention_bwd(qd, rel_h.to(dev), rel_w.to(dev), o, d_o.to(dev), lse, dqkv, drh, drw, nh, dk, dv)
+    want = t.grad.permute(0, 2, 3, 1).reshape(B, H * W, Cq)
+    close(dqkv.cpu()[..., :dk], want[..., :dk], 1e-3, "dq")
+    close(dqkv.cpu()[..., dk:2 * dk], want[..., dk:2 * dk], 1e-3, "dk")
+    close(dqkv.cpu()[..., 2 * dk:], want[..., 2 * dk:], 1e-3, "dv")
+    close(drh.cpu(), rh.grad, 1e-3, "d key_rel_h")
+    close(drw.cpu(), rw.grad, 1e-3, "d key_rel_w")
+
+
+def test_instance_norm_relu_and_backward(dev):
+    from chexpert_amd import ops
+    B, H, W, C = 3, 6, 10, 64
+    x = bf(synth.uniform(5, (B, H, W, C + 32), -2, 3))
+    xs = x[..., :C].permute(0, 3, 1, 2).clone().requires_grad_(True)
+    a_ref = F.relu(F.instance_norm(xs, eps=1e-5))
+    da = bf(synth.uniform(6, (B, H, W, C), -1, 1))
+    a_ref.backward(da.permute(0, 3, 1, 2))
+    xd = x.to(torch.bfloat16).to(dev)
+    s, q = torch.zeros(B * C, device=dev), torch.zeros(B * C, device=dev)
+    ops.stats_bc(xd[..., :C], s, q)
+    sc, sh = torch.zeros(B * C, device=dev), torch.zeros(B * C, device=dev)
+    ops.bn_coef(s, q, H * W, None, None, 1e-5, 0.0, None, None, sc, sh, None, None, B * C)
+    a = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device=dev)
+    ops.affine_relu_bc(xd[..., :C], sc, sh, a)
+    close(a.float().cpu().permute(0, 3, 1, 2), a_ref.detach(), 6e-3, "IN+ReLU")
+    g = torch.full((B, H, W, C + 32), 3.0, dtype=torch.bfloat16, device=dev)
+    S1, S2 = torch.zeros(B * C, device=dev), torch.zeros(B * C, device=dev)
+    ops.in_relu_bwd(da.to(torch.bfloat16).to(dev), xd[..., :C], sc, sh, S1, S2, g[..., :C])
+    close(g[..., :C].float().cpu().permute(0, 3, 1, 2), xs.grad, 8e-3, "IN backward")
+    assert (g[..., C:].float() == 3.0).all()
+
+
+def test_conv_partial_channel_tiles(dev):
+    """N and K that are multiples of 8 but not of 32 (AAConv branch: 120 / 232 / 464 output channels, 328 qkv)."""
+    from chexpert_amd import ops
+    B, H, W, K, N = 2, 8, 10, 64, 120
+    x = bf(synth.uniform(7, (B, H, W, K), -1, 1))
+    w = bf(synth.uniform(8, (N, K, 3, 3), -0.1, 0.1))
+    want = F.conv2d(x.permute(0, 3, 1, 2), w, stride=2, padding=1)
+    y = torch.zeros(B, H // 2, W // 2, N + 8, dtype=torch.bfloat16, device=dev)
+    ops.conv_gemm(x.to(torch.bfloat16).to(dev), ops.pack_weights(w.to(dev)), y[..., :N], N=N, kh=3, kw=3, stride=2, pad=1)
+    close(y[..., :N].float().cpu().permute(0, 3, 1, 2), want, 6e-3, "fwd N=120")
+    # input gradient of the same strided conv: K = 120 (partial last K step), transposed stride 2
+    dy = bf(synth.uniform(9, (B, H // 2, W // 2, N), -1, 1))
+    want = torch.nn.grad.conv2d_input((B, K, H, W), w, dy.permute(0, 3, 1, 2), stride=2, padding=1)
+    dx = torch.zeros(B, H, W, K, dtype=torch.bfloat16, device=dev)
+    ops.conv_gemm(dy.to(torch.bfloat16).to(dev), ops.pack_weights(w.to(dev), transpose=True), dx, N=K, kh=3, kw=3, pad=1, tstride=2)
+    close(dx.float().cpu().permute(0, 3, 1, 2), want, 6e-3, "dgrad K=120 tstride=2")
+    want = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (N, K, 3, 3), dy.permute(0, 3, 1, 2), stride=2, padding=1)
+    dw = torch.zeros(N, K, 3, 3, device=dev)
+    ops.conv_wgrad(dy.to(torch.bfloat16).to(dev), x.to(torch.bfloat16).to(dev), dw, kh=3, kw=3, stride=2, pad=1)
+    close(dw.cpu(), want, 2e-3, "wgrad N=120")
