@@ -80,13 +80,20 @@ def make_model(args, device):
         else:
             opt = torch.optim.Adam(model.parameters(), lr=args.lr)
         return model, opt, None
+    if name in ("aadensenet121", "densenet121_attn_aug"):      # chexpert.py:474-480 (README row name accepted too)
+        from .models import DenseNet
+        size = args.resize or 320
+        model = DenseNet(32, (6, 12, 24, 16), 64, num_classes=args.n_classes,
+                         attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (size, size)}).to(device)
+        opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, nesterov=True)
+        return model, opt, torch.optim.lr_scheduler.MultiStepLR(opt, [40000, 60000])
     if name == "resnet152":                                   # chexpert.py:481-486
         from .models import resnet152
         model = resnet152(pretrained=args.pretrained)
         model.fc = nn.Linear(model.fc.in_features, args.n_classes)
         model = model.to(device)
         return model, torch.optim.Adam(model.parameters(), lr=args.lr), None
-    if name in ("aadensenet121", "densenet121_attn_aug", "aaresnet152") or "efficientnet" in name:
+    if name == "aaresnet152" or "efficientnet" in name:
         raise RuntimeError("Model architecture not built yet on the HIP path: %s (SURVEY.md section 8 rows C-E)" % name)
     raise RuntimeError("Model architecture not supported.")
 

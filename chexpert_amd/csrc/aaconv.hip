@@ -399,7 +399,7 @@ __global__ void affine_relu_bc_kernel(const bf16* __restrict__ x, const float* _
 }
 
 // per-(b,c) sums over the pixels of an image: sum, sum of squares (InstanceNorm statistics)
-__global__ __launch_bounds__(256) void stats_bc_kernel(const bf16* __restrict__ x, float* __restrict__ sum, float* __restrict__ sq,
+__global__ void stats_bc_kernel(const bf16* __restrict__ x, float* __restrict__ sum, float* __restrict__ sq,
                                                       int HW, int C, int ldx, int splits) {
   extern __shared__ float lds[];          // [2][C]
   const int CP = C / 8;
@@ -498,7 +498,7 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16* __restrict
 
 // InstanceNorm + ReLU backward: dz = dA * [a > 0];  dx = r * (dz - mean_hw(dz) - xhat * mean_hw(dz * xhat)) per (b,c)
 // pass 1: S1[b][c] = sum dz, S2[b][c] = sum dz*xhat      pass 2: write dx
-__global__ __launch_bounds__(256) void in_relu_bwd_stats_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
+__global__ void in_relu_bwd_stats_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
                                                                const float* __restrict__ sc, const float* __restrict__ sh,
                                                                float* __restrict__ S1, float* __restrict__ S2, int HW, int C, int ldx,
                                                                int splits) {
@@ -636,12 +636,13 @@ int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w,
 }
 
 int cx_stats_bc(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream) {
-  if (!x || !sum || !sq || C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || C / 8 > 256 || ldx % 8) return CX_EINVAL;
+  if (!x || !sum || !sq || C % 8 || C > 2048 || ldx % 8) return CX_EINVAL;
   int splits = 2048 / B;
   if (splits < 1) splits = 1;
   if (splits > HW / 32 + 1) splits = HW / 32 + 1;
-  hipLaunchKernelGGL(stats_bc_kernel, dim3(splits, B), dim3(256), 2 * C * sizeof(float), as_stream(stream), (const bf16*)x, sum, sq, HW,
-                     C, ldx, splits);
+  const int CP = C / 8, threads = CP * (256 / CP > 0 ? 256 / CP : 1);       // a whole number of pixel rows per block
+  hipLaunchKernelGGL(stats_bc_kernel, dim3(splits, B), dim3(threads), 2 * C * sizeof(float), as_stream(stream), (const bf16*)x, sum, sq,
+                     HW, C, ldx, splits);
   return launch_status();
 }
 
@@ -678,12 +679,13 @@ int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {
 int cx_in_relu_bwd(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,
                    int C, int ldx, int ldg, void* stream) {
   if (!da || !x || !sc || !sh || !S1 || !S2 || !gout) return CX_EINVAL;
-  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || C / 8 > 256 || ldx % 8 || ldg % 8) return CX_ESHAPE;
+  if (C % 8 || C > 2048 || ldx % 8 || ldg % 8) return CX_ESHAPE;
   int splits = 2048 / B;
   if (splits < 1) splits = 1;
   if (splits > HW / 32 + 1) splits = HW / 32 + 1;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(in_relu_bwd_stats_kernel, dim3(splits, B), dim3(256), 2 * C * sizeof(float), st, (const bf16*)da, (const bf16*)x,
+  const int CP = C / 8, threads = CP * (256 / CP > 0 ? 256 / CP : 1);
+  hipLaunchKernelGGL(in_relu_bwd_stats_kernel, dim3(splits, B), dim3(threads), 2 * C * sizeof(float), st, (const bf16*)da, (const bf16*)x,
                      sc, sh, S1, S2, HW, C, ldx, splits);
   const size_t total = (size_t)B * HW * (C / 8);
   hipLaunchKernelGGL(in_relu_bwd_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, (const bf16*)da, (const bf16*)x, sc,

@@ -69,13 +69,57 @@ class _DenseBlock(nn.Sequential):
             self.add_module("denselayer%d" % (i + 1), _DenseLayer(cin + i * growth, growth, bn_size))
 
 
-class _Transition(nn.Sequential):
-    def __init__(self, cin, cout):
+class InstanceNormMarker(_FusedOnly, nn.InstanceNorm2d):
+    pass
+
+
+class AAConv2d(nn.Module):
+    """Parameter holder with the constructor / attributes of /root/reference/models/attn_aug_conv.py:19-41
+    (`dk`, `dv`, `nh`, `relative`, `conv`, `in_proj_qkv`, `out_proj`, `key_rel_h`, `key_rel_w`).  The arithmetic runs in
+    csrc/aaconv.hip + the implicit-GEMM kernels as part of the parent model's fused schedule."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, dk, dv, nh, relative, input_dims, **kwargs):
         super().__init__()
-        self.add_module("norm", BatchNorm2dParams(cin))
-        self.add_module("relu", ReLUMarker(inplace=True))
-        self.add_module("conv", Conv2dParams(cin, cout, 1, 1, bias=False))
-        self.add_module("pool", PoolMarker())
+        assert dk % nh == 0, "nh must divide dk"
+        assert dv % nh == 0, "nh must divide dv"
+        if not relative:
+            raise NotImplementedError("the reference always uses relative=True (chexpert.py:476)")
+        if dk // nh != 20 or dv // nh not in (1, 2, 3, 4, 6) or out_channels <= dv:
+            raise NotImplementedError("AAConv2d kernels are built for dk/nh = 20 and dv/nh in {1,2,3,4,6}")
+        self.dk, self.dv, self.nh, self.relative = dk, dv, nh, relative
+        padding = kwargs.pop("padding", None) or kernel_size // 2
+        self.conv = Conv2dParams(in_channels, out_channels - dv, kernel_size, stride, padding, bias=False, **kwargs)
+        self.in_proj_qkv = Conv2dParams(in_channels, 2 * dk + dv, 1, stride, bias=False)
+        self.out_proj = Conv2dParams(dv, dv, 1, bias=False)
+        H, W = input_dims
+        self.input_dims = (H, W)
+        self.key_rel_h = nn.Parameter(dk ** -0.5 + torch.randn(dk // nh, 2 * H - 1))
+        self.key_rel_w = nn.Parameter(dk ** -0.5 + torch.randn(dk // nh, 2 * W - 1))
+        self.weights = None      # the reference stores softmax(logits) (B,nh,HW,HW) here on every forward; see model.attention_weights()
+
+    def forward(self, x):  # pragma: no cover - guard
+        raise RuntimeError("chexpert_amd: AAConv2d only holds parameters; call the parent model (fused HIP schedule)")
+
+    def extra_repr(self):
+        return "dk={}, dv={}, nh={}, relative={}".format(self.dk, self.dv, self.nh, self.relative)
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, cin, cout, attn_params=None):
+        super().__init__()
+        if attn_params is None:
+            self.add_module("norm", BatchNorm2dParams(cin))
+            self.add_module("relu", ReLUMarker(inplace=True))
+            self.add_module("conv", Conv2dParams(cin, cout, 1, 1, bias=False))
+            self.add_module("pool", PoolMarker())
+        else:                                   # attn_aug_conv.py:416-440: InstanceNorm -> ReLU -> AAConv2d(3x3, stride 2)
+            nh = attn_params["nh"]
+            dk = max(20 * nh, int((attn_params["k"] * cout // nh) * nh))
+            dv = int((attn_params["v"] * cout // nh) * nh)
+            dims = (attn_params["input_dims"][0] // 2, attn_params["input_dims"][1] // 2)
+            self.add_module("norm", InstanceNormMarker(cin))
+            self.add_module("relu", ReLUMarker(inplace=True))
+            self.add_module("conv", AAConv2d(cin, cout, 3, 2, dk, dv, nh, attn_params["relative"], dims))
 
 
 # --------------------------------------------------------------------------------------------- workspace
@@ -117,6 +161,26 @@ class _Workspace:
             h, w = h // 2, w // 2
         self.dz2 = None
         self.dpool = None
+        self.aa = {}
+        f32 = torch.float32
+        for bi, (c_in, n_layers) in enumerate(eng.blocks[:-1]):
+            aa = getattr(eng.model.features, "transition%d" % (bi + 1)).conv
+            if not isinstance(aa, AAConv2d):
+                continue
+            ct = c_in + n_layers * g
+            (hh, wh), (ho, wo) = self.hw[bi], self.hw[bi + 1]
+            if (ho, wo) != tuple(aa.input_dims):
+                raise RuntimeError("AAConv2d was built for %s feature maps, the input gives %s (relative tables are size-bound, "
+                                   "attn_aug_conv.py:38-41)" % (tuple(aa.input_dims), (ho, wo)))
+            T = type("AAWs", (), {})()
+            T.stat = torch.zeros(2, B * ct, dtype=f32, device=dev)
+            T.coef = torch.zeros(2, B * ct, dtype=f32, device=dev)
+            T.A = e(B, hh, wh, ct)
+            T.QKV = e(B, ho, wo, 2 * aa.dk + aa.dv)
+            T.O = torch.empty(B, ho * wo, aa.dv, dtype=f32, device=dev)
+            T.LSE = torch.empty(B * aa.nh, ho * wo, dtype=f32, device=dev)
+            T.bwd = None
+            self.aa[bi] = T
         self.pooled = torch.empty(B, eng.c_final, dtype=torch.float32, device=dev)
         self.logits = torch.empty(B, eng.n_classes, dtype=torch.float32, device=dev)
         self.vec = torch.zeros(eng.vec_size, dtype=torch.float32, device=dev)
@@ -138,6 +202,12 @@ class _Workspace:
         if len(self.buf) > 1:
             n = max(self.hw[i + 1][0] * self.hw[i + 1][1] * self.buf[i].shape[3] for i in range(len(self.buf) - 1))
             self.dpool = torch.empty(B * n, dtype=bf, device=dev)
+        for bi, T in self.aa.items():
+            T.dO = torch.empty_like(T.O)
+            T.dQKV32 = torch.empty(T.QKV.shape, dtype=torch.float32, device=dev)
+            T.dQKV = torch.empty_like(T.QKV)
+            T.dA = torch.empty_like(T.A)
+            T.S = torch.zeros_like(T.stat)
 
 
 # --------------------------------------------------------------------------------------------- engine
@@ -345,7 +415,12 @@ class _Engine:
                               stat_sum=st((bsum[0] + cin, self.growth)), stat_sq=st((bsq[0] + cin, self.growth)))
             ct = c0 + n_layers * self.growth
             nt = s["nt"][bi]
-            if bi != nb - 1:
+            if bi != nb - 1 and isinstance(getattr(f, "transition%d" % (bi + 1)).conv, AAConv2d):
+                # block statistics are still needed by backward (mean / rstd of the buffer channels)
+                if train:
+                    ops.bn_coef(ws.v(bsum), ws.v(bsq), cnt, None, None, 1e-5, 0.0, None, None, None, None, ws.v(bmean), ws.v(brstd), ct)
+                self._aa_forward(ws, bi, getattr(f, "transition%d" % (bi + 1)).conv, st)
+            elif bi != nb - 1:
                 tr = getattr(f, "transition%d" % (bi + 1))
                 self._bn(ws, bsum, bsq, cnt, tr.norm, nt, ct, train, bmean, brstd)
                 nsum, nsq = s["bst"][bi + 1]
@@ -358,6 +433,45 @@ class _Engine:
         if train:
             m._nbt_pending += 1
         return ws
+
+    def _aa_forward(self, ws, bi, aa, st):
+        """InstanceNorm -> ReLU -> AAConv2d(3x3, stride 2) from block buffer bi into the first channels of buffer bi+1."""
+        s = self.slots
+        buf, nxt, T = ws.buf[bi], ws.buf[bi + 1], ws.aa[bi]
+        B, h, w, ct = buf.shape
+        cout = ct // 2
+        cc = cout - aa.dv
+        T.stat.zero_()
+        ops.stats_bc(buf, T.stat[0], T.stat[1])
+        ops.bn_coef(T.stat[0], T.stat[1], h * w, None, None, 1e-5, 0.0, None, None, T.coef[0], T.coef[1], None, None, B * ct)
+        ops.affine_relu_bc(buf, T.coef[0], T.coef[1], T.A)
+        nsum, nsq = s["bst"][bi + 1]
+        ops.conv_gemm(T.A, self.w_fwd(aa.conv), nxt[..., :cc], N=cc, kh=3, kw=3, stride=2, pad=1,
+                      stat_sum=st((nsum[0], cc)), stat_sq=st((nsq[0], cc)))
+        ops.conv_gemm(T.A, self.w_fwd(aa.in_proj_qkv), T.QKV, N=2 * aa.dk + aa.dv, stride=2)
+        ops.aa_attention_fwd(T.QKV, aa.key_rel_h, aa.key_rel_w, T.O, T.LSE, aa.nh, aa.dk, aa.dv)
+        ops.aa_outproj_fwd(T.O, aa.out_proj.weight, nxt[..., cc:cout], st((nsum[0] + cc, aa.dv)), st((nsq[0] + cc, aa.dv)))
+
+    def _aa_backward(self, ws, bi, aa, qa, qb, qc, G):
+        """Backward of the AA transition feeding block bi (from block bi-1); qa/qb/qc apply the deferred BN correction
+        to the gradient slice [0, c0) of block bi."""
+        buf, gbuf, pbuf, pg, T = ws.buf[bi], ws.gbuf[bi], ws.buf[bi - 1], ws.gbuf[bi - 1], ws.aa[bi - 1]
+        c0 = self.blocks[bi][0]
+        cc = c0 - aa.dv
+        Cp = pbuf.shape[3]
+        gs_c, xs_c, gs_a, xs_a = gbuf[..., :cc], buf[..., :cc], gbuf[..., cc:c0], buf[..., cc:c0]
+        ops.aa_outproj_bwd(gs_a, xs_a, qa[cc:], qb[cc:], qc[cc:], T.O, aa.out_proj.weight, T.dO, G(aa.out_proj.weight))
+        ops.aa_attention_bwd(T.QKV, aa.key_rel_h, aa.key_rel_w, T.O, T.dO, T.LSE, T.dQKV32, G(aa.key_rel_h), G(aa.key_rel_w), aa.nh,
+                             aa.dk, aa.dv)
+        ops.f32_to_bf16(T.dQKV32, T.dQKV)
+        ops.conv_gemm(T.dQKV, self.w_bwd(aa.in_proj_qkv), T.dA, N=Cp, tstride=2)
+        ops.conv_gemm(gs_c, self.w_bwd(aa.conv), T.dA, N=Cp, kh=3, kw=3, pad=1, tstride=2, prologue=ops.PRO_AFFINE2, x2=xs_c,
+                      pa=qa[:cc], pb=qb[:cc], pc=qc[:cc], accumulate=True)
+        ops.conv_wgrad(T.dQKV, T.A, G(aa.in_proj_qkv.weight), stride=2)
+        ops.conv_wgrad(gs_c, T.A, G(aa.conv.weight), kh=3, kw=3, stride=2, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs_c, ga=qa[:cc],
+                       gb=qb[:cc], gc=qc[:cc])
+        T.S.zero_()
+        ops.in_relu_bwd(T.dA, pbuf, T.coef[0], T.coef[1], T.S[0], T.S[1], pg)
 
     # ---- backward
     def backward(self, ws, dlogits):
@@ -461,7 +575,11 @@ class _Engine:
             qa, qb, qc = (v(t)[:c0] for t in q)
             ops.bn_bwd_slice_coef(v(A), v(Bc), v(bmean), v(brstd), qa, qb, qc, c0)
             gs, xs = gbuf[..., :c0], buf[..., :c0]
-            if bi > 0:
+            if bi > 0 and isinstance(getattr(f, "transition%d" % bi).conv, AAConv2d):
+                aa = getattr(f, "transition%d" % bi).conv
+                self._aa_backward(ws, bi, aa, qa, qb, qc, G)
+                done(aa.key_rel_h)
+            elif bi > 0:
                 pc0, pn = self.blocks[bi - 1]
                 cprev = pc0 + pn * self.growth
                 tr = getattr(f, "transition%d" % bi)
@@ -532,8 +650,6 @@ class DenseNet(nn.Module):
         super().__init__()
         if drop_rate:
             raise NotImplementedError("drop_rate > 0 is not on the reference hot path (chexpert.py uses 0)")
-        if attn_params is not None:
-            raise NotImplementedError("attention-augmented transitions (AAConv2d) are not built yet: SURVEY.md section 8 row C")
         if len(block_config) != 4:
             raise NotImplementedError("only the ImageNet-style stem (4 dense blocks) is on the hot path")
         self.growth_rate, self.block_config, self.bn_size = growth_rate, tuple(block_config), bn_size
@@ -544,12 +660,18 @@ class DenseNet(nn.Module):
             ("pool0", PoolMarker()),
         ]))
         c = num_init_features
+        if attn_params is not None:             # the reference mutates the caller's dict (:468, :493); a copy is used here
+            attn_params = dict(attn_params)
+            attn_params["input_dims"] = (attn_params["input_dims"][0] // 4, attn_params["input_dims"][1] // 4)
+        self.attn_params = attn_params
         for i, n in enumerate(block_config):
             self.features.add_module("denseblock%d" % (i + 1), _DenseBlock(n, c, bn_size, growth_rate))
             c += n * growth_rate
             if i != len(block_config) - 1:
-                self.features.add_module("transition%d" % (i + 1), _Transition(c, c // 2))
+                self.features.add_module("transition%d" % (i + 1), _Transition(c, c // 2, attn_params))
                 c //= 2
+            if attn_params is not None:
+                attn_params["input_dims"] = (attn_params["input_dims"][0] // 2, attn_params["input_dims"][1] // 2)
         self.features.add_module("norm5", BatchNorm2dParams(c))
         self.classifier = nn.Linear(c, num_classes)
         # initialisers of the reference (attn_aug_conv.py:503-510)
