@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALG_BYTES_PER_IMG = 283.1e6    # densenet121@320 bf16, fwd+bwd
+ALG_BYTES = {"densenet121": 283.1e6, "aadensenet121": 295.4e6, "resnet152": 555.0e6, "efficientnet-b4": 594.5e6,
+             "efficientnet-b0": 166.2e6}
 
 
 class KernelTimer:
@@ -137,6 +139,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU minibatch (BASELINE config: 256)")
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--classes", type=int, default=14)
+    ap.add_argument("--model", default="densenet121", choices=["densenet121", "aadensenet121", "resnet152", "efficientnet-b4", "efficientnet-b0"],
+                    help="densenet121 is the headline (BASELINE configs[1]); the others are reported for reference only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default=None, help="kernel tag to time (default: the one with the largest share)")
     args = ap.parse_args()
@@ -158,11 +162,22 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(1234)
-    model = densenet121(num_classes=args.classes).to(dev)
+    if args.model == "densenet121":
+        model = densenet121(num_classes=args.classes).to(dev)
+    elif args.model == "aadensenet121":
+        from chexpert_amd.models import DenseNet
+        model = DenseNet(32, (6, 12, 24, 16), 64, num_classes=args.classes,
+                         attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (args.size, args.size)}).to(dev)
+    elif args.model == "resnet152":
+        from chexpert_amd.models import resnet152
+        model = resnet152(num_classes=args.classes).to(dev)
+    else:
+        from chexpert_amd.models import construct_model
+        model = construct_model(args.model, args.classes).to(dev)
     model.train()
     x = synth.xray_batch(1000 + rank, args.batch, args.size).to(dev)
     t = synth.targets(2000 + rank, args.batch, args.classes).to(dev)
-    opt = FusedAdam(model, lr=1e-4)
+    opt = FusedAdam(model, lr=1e-4) if hasattr(model, "features") else None
 
     timer = KernelTimer(ops)
     timer.install()
@@ -220,7 +235,8 @@ def main():
     torch.cuda.synchronize()
     o0 = time.perf_counter()
     for _ in range(5):
-        opt.step()
+        if opt is not None:
+            opt.step()
     torch.cuda.synchronize()
     opt_ms = (time.perf_counter() - o0) / 5 * 1e3
 
@@ -230,21 +246,24 @@ def main():
         avg_ms = ksum["ms"] / ksum["launches"]
         achieved = ksum["alg_bytes"] / (ksum["ms"] * 1e-3) / 1e9
         out = {
-            "metric": "images/sec fwd+bwd DenseNet121 320x320 bf16 (per-GPU rate in config.images_per_sec_per_gpu)",
+            "metric": "images/sec fwd+bwd %s 320x320 bf16 (per-GPU rate in config.images_per_sec_per_gpu)" % (
+            "DenseNet121" if args.model == "densenet121" else args.model),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "densenet121 bf16 1xMI355X 320x320 bs=%d U-Ones labels (configs[1]); %d classes; "
-                                   "random-init weights, synthetic uint8 X-rays" % (args.batch, args.classes),
+            "config": {"workload": "%s bf16 1xMI355X %dx%d bs=%d U-Ones labels (%s); %d classes; "
+                                   "random-init weights, synthetic uint8 X-rays" % (
+                                       args.model, args.size, args.size, args.batch,
+                                       "BASELINE configs[1]" if args.model == "densenet121" else "not the headline config", args.classes),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "images_per_sec_per_gpu": round(value / world, 2),
-                       "model_hbm_roofline_frac": round(value / world * ALG_BYTES_PER_IMG / (HBM_PEAK_GBS * 1e9), 4),
+                       "model_hbm_roofline_frac": round(value / world * ALG_BYTES[args.model] / (HBM_PEAK_GBS * 1e9), 4),
                        "optimizer_step_ms": round(opt_ms, 3), "loss": round(float(loss.item()), 5)},
             "roofline": {"bound": "hbm", "kernel": only, "launches_per_step": ksum["launches"] // args.steps,
                          "avg_launch_ms": round(avg_ms, 4), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.model == "densenet121":
             log("cpu baseline on %d cores ..." % host_cores())
             out["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(out))

@@ -78,6 +78,19 @@ SIGNATURES = {
     "cx_affine_relu_bc": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_in_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_f32_to_bf16": [_vp, _vp, _sz, _vp],
+    "cx_nchw3_to_nhwc8": [_vp, _vp, _i, _i, _i, _vp],
+    "cx_dwconv_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_dwconv_dgrad": [_vp] * 14 + [_i] * 8 + [_vp],
+    "cx_dwconv_wgrad": [_vp] * 9 + [_i] * 7 + [_vp],
+    "cx_gap_affine_act": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_se_fwd": [_vp] * 7 + [_i, _i, _i, _vp],
+    "cx_se_bwd": [_vp] * 11 + [_i, _i, _i, _vp],
+    "cx_scale_act_bc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cx_se_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cx_se_act_bwd": [_vp] * 11 + [_i, _i, _i, _vp],
+    "cx_bn_lin_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_affine2_out": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_gradcam_map": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_cam_norm_upsample": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_fill_f32": [_vp, _f, _sz, _vp],

@@ -93,7 +93,12 @@ def make_model(args, device):
         model.fc = nn.Linear(model.fc.in_features, args.n_classes)
         model = model.to(device)
         return model, torch.optim.Adam(model.parameters(), lr=args.lr), None
-    if name == "aaresnet152" or "efficientnet" in name:
+    if "efficientnet" in name:                                # chexpert.py:496-500
+        from .models import construct_model
+        model = construct_model(name, n_classes=args.n_classes).to(device)
+        opt = torch.optim.RMSprop(model.parameters(), lr=args.lr, momentum=0.9, eps=0.001)
+        return model, opt, torch.optim.lr_scheduler.ExponentialLR(opt, args.lr_decay_factor)
+    if name == "aaresnet152":
         raise RuntimeError("Model architecture not built yet on the HIP path: %s (SURVEY.md section 8 rows C-E)" % name)
     raise RuntimeError("Model architecture not supported.")
 

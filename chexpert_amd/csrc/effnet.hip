@@ -1,0 +1,584 @@
+// EfficientNet building blocks (/root/reference/models/efficientnet.py:27-131) that are not implicit GEMMs:
+// depthwise k x k convolution (forward / input gradient / weight gradient) with the preceding BatchNorm + Swish
+// applied on load, squeeze-and-excitation (global pool, two tiny FCs, per-(b,c) scaling), Swish / BatchNorm
+// backward glue.  All of it is HBM-bound elementwise / stencil work: 16 B per lane along the channel axis,
+// per-block LDS reduction before fp32 atomics.  The 1x1 expand / project / head convolutions go through
+// cx_conv_gemm / cx_conv_wgrad on materialised bf16 activations.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+__device__ __forceinline__ float swishf_(float z) { return z * sigmoidf_(z); }
+__device__ __forceinline__ float dswishf_(float z) {
+  const float s = sigmoidf_(z);
+  return s * (1.f + z * (1.f - s));
+}
+
+inline int grid_for(size_t n, int block, int cap) {
+  size_t g = (n + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+inline int threads_for(int CP) { return CP * (256 / CP > 0 ? 256 / CP : 1); }
+
+// shared reduction of per-thread 8-channel partials (thread's chunk column cq is loop invariant)
+template <int NS>
+__device__ __forceinline__ void flush_partials(float (&s)[NS][8], int cq, int C, float* lds, float* const (&dst)[NS]) {
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&lds[k * C + cq * 8 + j], s[k][j]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (dst[k]) atomicAdd(&dst[k][c], lds[k * C + c]);
+}
+
+__global__ void nchw3_to_nhwc8_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t hw, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t b = idx / hw, p = idx - b * hw;
+  const float* src = x + b * 3 * hw + p;
+  U128 o;
+  o.e[0] = f2bf(src[0]);
+  o.e[1] = f2bf(src[hw]);
+  o.e[2] = f2bf(src[2 * hw]);
+#pragma unroll
+  for (int j = 3; j < 8; ++j) o.e[j] = f2bf(0.f);
+  *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+}
+
+// ---------------------------------------------------------------------------------------------- depthwise conv
+// forward: y[p][c] = sum_t act(x[p@t][c]) * w[c][t],  act = swish(x*sc+sh) or identity (sc == nullptr)
+__global__ void dwconv_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sc,
+                                  const float* __restrict__ sh, bf16* __restrict__ y, float* g1, float* g2, int B, int H, int W, int C,
+                                  int Ho, int Wo, int k, int stride, int pad) {
+  extern __shared__ float lds[];          // [2][C]
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CP;
+  float s[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[0][j] = s[1][j] = 0.f;
+  float fsc[8], fsh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { fsc[j] = sc ? sc[cq * 8 + j] : 1.f; fsh[j] = sc ? sh[cq * 8 + j] : 0.f; }
+  const size_t npix = (size_t)B * Ho * Wo, ppb = blockDim.x / CP;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int b = pix / ((size_t)Ho * Wo);
+    const int rem = pix - (size_t)b * Ho * Wo;
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int dy = 0; dy < k; ++dy) {
+      const int iy = oy * stride - pad + dy;
+      if (iy < 0 || iy >= H) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int ix = ox * stride - pad + dx;
+        if (ix < 0 || ix >= W) continue;
+        U128 v;
+        v.u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = bf2f(v.e[j]);
+          if (sc) a = bf2f(f2bf(swishf_(fmaf(a, fsc[j], fsh[j]))));       // same rounding as a materialised activation
+          acc[j] = fmaf(a, w[(size_t)(cq * 8 + j) * k * k + dy * k + dx], acc[j]);
+        }
+      }
+    }
+    U128 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o.e[j] = f2bf(acc[j]);
+      const float rv = bf2f(o.e[j]);
+      s[0][j] += rv;
+      s[1][j] += rv * rv;
+    }
+    *reinterpret_cast<uint4*>(y + pix * C + cq * 8) = o.u;
+  }
+  float* const dst[2] = {g1, g2};
+  if (g1) flush_partials<2>(s, cq, C, lds, dst);
+}
+
+// input gradient: da[p][c] = sum_t dY[(p + pad - t)/stride][c] * w[c][t];  dY = g*ga + g2*gb + gc
+//   dz = da * swish'(x*sc+sh) (or da when sc == nullptr);  S1 += dz, S2 += dz * (x-mean)*rstd
+__global__ void dwconv_dgrad_kernel(const bf16* __restrict__ g, const bf16* __restrict__ g2, const float* __restrict__ ga,
+                                    const float* __restrict__ gb, const float* __restrict__ gc, const float* __restrict__ w,
+                                    const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, bf16* __restrict__ dz, float* S1,
+                                    float* S2, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int accumulate) {
+  extern __shared__ float lds[];
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CP;
+  float s[2][8], fa[8], fb[8], fc[8], fsc[8], fsh[8], fmu[8], fr[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cq * 8 + j;
+    s[0][j] = s[1][j] = 0.f;
+    fa[j] = ga[c]; fb[j] = gb[c]; fc[j] = gc[c];
+    fsc[j] = sc ? sc[c] : 1.f; fsh[j] = sc ? sh[c] : 0.f; fmu[j] = sc ? mean[c] : 0.f; fr[j] = sc ? rstd[c] : 0.f;
+  }
+  const size_t npix = (size_t)B * H * W, ppb = blockDim.x / CP;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int b = pix / ((size_t)H * W);
+    const int rem = pix - (size_t)b * H * W;
+    const int iy = rem / W, ix = rem - iy * W;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int dy = 0; dy < k; ++dy) {
+      const int ny = iy + pad - dy;
+      if (ny < 0 || ny % stride) continue;
+      const int oy = ny / stride;
+      if (oy >= Ho) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int nx = ix + pad - dx;
+        if (nx < 0 || nx % stride) continue;
+        const int ox = nx / stride;
+        if (ox >= Wo) continue;
+        const size_t op = ((size_t)b * Ho + oy) * Wo + ox;
+        U128 u, v;
+        u.u = *reinterpret_cast<const uint4*>(g + op * C + cq * 8);
+        v.u = *reinterpret_cast<const uint4*>(g2 + op * C + cq * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dy_ = bf2f(f2bf(fmaf(bf2f(u.e[j]), fa[j], fmaf(bf2f(v.e[j]), fb[j], fc[j]))));
+          acc[j] = fmaf(dy_, w[(size_t)(cq * 8 + j) * k * k + dy * k + dx], acc[j]);
+        }
+      }
+    }
+    U128 o, xv, old;
+    xv.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
+    if (accumulate) old.u = *reinterpret_cast<const uint4*>(dz + pix * C + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = bf2f(xv.e[j]);
+      float d = acc[j];
+      if (sc) d *= dswishf_(fmaf(xf, fsc[j], fsh[j]));
+      s[0][j] += d;
+      s[1][j] += d * (xf - fmu[j]) * fr[j];
+      if (accumulate) d += bf2f(old.e[j]);
+      o.e[j] = f2bf(d);
+    }
+    *reinterpret_cast<uint4*>(dz + pix * C + cq * 8) = o.u;
+  }
+  float* const dst[2] = {S1, S2};
+  if (S1) flush_partials<2>(s, cq, C, lds, dst);
+}
+
+// weight gradient: dW[c][t] += sum_p dY[p][c] * act(x[p@t][c]); one tap per blockIdx.y
+__global__ void dwconv_wgrad_kernel(const bf16* __restrict__ g, const bf16* __restrict__ g2, const float* __restrict__ ga,
+                                    const float* __restrict__ gb, const float* __restrict__ gc, const bf16* __restrict__ x,
+                                    const float* __restrict__ sc, const float* __restrict__ sh, float* __restrict__ dw, int B, int H, int W,
+                                    int C, int Ho, int Wo, int k, int stride, int pad) {
+  extern __shared__ float lds[];          // [C]
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CP;
+  const int tap = blockIdx.y, dy = tap / k, dx = tap - dy * k;
+  float s[1][8], fa[8], fb[8], fc[8], fsc[8], fsh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cq * 8 + j;
+    s[0][j] = 0.f;
+    fa[j] = ga[c]; fb[j] = gb[c]; fc[j] = gc[c];
+    fsc[j] = sc ? sc[c] : 1.f; fsh[j] = sc ? sh[c] : 0.f;
+  }
+  const size_t npix = (size_t)B * Ho * Wo, ppb = blockDim.x / CP;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int b = pix / ((size_t)Ho * Wo);
+    const int rem = pix - (size_t)b * Ho * Wo;
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const int iy = oy * stride - pad + dy, ix = ox * stride - pad + dx;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    U128 u, v, xv;
+    u.u = *reinterpret_cast<const uint4*>(g + pix * C + cq * 8);
+    v.u = *reinterpret_cast<const uint4*>(g2 + pix * C + cq * 8);
+    xv.u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dy_ = bf2f(f2bf(fmaf(bf2f(u.e[j]), fa[j], fmaf(bf2f(v.e[j]), fb[j], fc[j]))));
+      float a = bf2f(xv.e[j]);
+      if (sc) a = bf2f(f2bf(swishf_(fmaf(a, fsc[j], fsh[j]))));
+      s[0][j] = fmaf(dy_, a, s[0][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(&lds[cq * 8 + j], s[0][j]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&dw[(size_t)c * k * k + tap], lds[c]);
+}
+
+// ---------------------------------------------------------------------------------------------- SE / activation glue
+// pooled[b][c] = mean_hw act(x*sc+sh), act: 0 none, 1 relu, 2 swish
+__global__ void gap_affine_act_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                      float* __restrict__ pooled, int HW, int C, int act, int splits) {
+  const int CP = C / 8;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int cq = threadIdx.x % CP, rr = threadIdx.x / CP, rpp = blockDim.x / CP;
+  const int len = (HW + splits - 1) / splits, p0 = sp * len, p1 = min(HW, p0 + len);
+  float a[8], fsc[8], fsh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = 0.f; fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; }
+  for (int p = p0 + rr; p < p1; p += rpp) {
+    U128 v;
+    v.u = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * C + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float z = fmaf(bf2f(v.e[j]), fsc[j], fsh[j]);
+      a[j] += act == 2 ? swishf_(z) : (act == 1 ? fmaxf(z, 0.f) : z);
+    }
+  }
+  const float inv = 1.f / HW;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(&pooled[(size_t)b * C + cq * 8 + j], a[j] * inv);
+}
+
+// SE excitation: h1 = W1 pooled + b1; s = sigmoid(W2 swish(h1) + b2)      one block per sample
+__global__ void se_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
+                              const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h1, float* __restrict__ s,
+                              int C, int R) {
+  extern __shared__ float lds[];          // [R] swish(h1)
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(w1[(size_t)r * C + c], pooled[(size_t)b * C + c], a);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    if (lane == 0) {
+      a += b1[r];
+      h1[(size_t)b * R + r] = a;
+      lds[r] = swishf_(a);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = b2[c];
+    for (int r = 0; r < R; ++r) a = fmaf(w2[(size_t)c * R + r], lds[r], a);
+    s[(size_t)b * C + c] = sigmoidf_(a);
+  }
+}
+
+// u = swish(x*sc+sh) * s[b][c]       (the tensor the projection conv consumes)
+__global__ void scale_act_bc_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                    const float* __restrict__ s, bf16* __restrict__ u, int HW, int C, size_t total) {
+  const int CP = C / 8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cq = idx % CP;
+    const size_t pix = idx / CP;
+    const int b = pix / HW;
+    U128 v, o;
+    v.u = *reinterpret_cast<const uint4*>(x + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cq * 8 + j;
+      o.e[j] = f2bf(swishf_(fmaf(bf2f(v.e[j]), sc[c], sh[c])) * (s ? s[(size_t)b * C + c] : 1.f));
+    }
+    *reinterpret_cast<uint4*>(u + idx * 8) = o.u;
+  }
+}
+
+// linear BatchNorm backward statistics: S1 += sum g, S2 += sum g * (y-mean)*rstd
+__global__ void bn_lin_bwd_stats_kernel(const bf16* __restrict__ g, const bf16* __restrict__ y, const float* __restrict__ mean,
+                                        const float* __restrict__ rstd, float* S1, float* S2, size_t rows, int C) {
+  extern __shared__ float lds[];
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CP;
+  float s[2][8], fmu[8], fr[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[0][j] = s[1][j] = 0.f; fmu[j] = mean[cq * 8 + j]; fr[j] = rstd[cq * 8 + j]; }
+  const size_t ppb = blockDim.x / CP;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < rows; pix += (size_t)gridDim.x * ppb) {
+    U128 u, v;
+    u.u = *reinterpret_cast<const uint4*>(g + pix * C + cq * 8);
+    v.u = *reinterpret_cast<const uint4*>(y + pix * C + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gf = bf2f(u.e[j]);
+      s[0][j] += gf;
+      s[1][j] += gf * (bf2f(v.e[j]) - fmu[j]) * fr[j];
+    }
+  }
+  float* const dst[2] = {S1, S2};
+  flush_partials<2>(s, cq, C, lds, dst);
+}
+
+// ds[b][c] = sum_hw du * swish(x*sc+sh)
+__global__ void se_bwd_reduce_kernel(const bf16* __restrict__ du, const bf16* __restrict__ x, const float* __restrict__ sc,
+                                     const float* __restrict__ sh, float* __restrict__ ds, int HW, int C, int splits) {
+  const int CP = C / 8;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int cq = threadIdx.x % CP, rr = threadIdx.x / CP, rpp = blockDim.x / CP;
+  const int len = (HW + splits - 1) / splits, p0 = sp * len, p1 = min(HW, p0 + len);
+  float a[8], fsc[8], fsh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = 0.f; fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; }
+  for (int p = p0 + rr; p < p1; p += rpp) {
+    U128 v, d;
+    const size_t pix = (size_t)b * HW + p;
+    v.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
+    d.u = *reinterpret_cast<const uint4*>(du + pix * C + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = fmaf(bf2f(d.e[j]), swishf_(fmaf(bf2f(v.e[j]), fsc[j], fsh[j])), a[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(&ds[(size_t)b * C + cq * 8 + j], a[j]);
+}
+
+// SE backward through the two FCs: one block per sample
+__global__ void se_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s, const float* __restrict__ h1,
+                              const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ w2,
+                              float* dw1, float* db1, float* dw2, float* db2, float* __restrict__ dpooled, int C, int R) {
+  extern __shared__ float lds[];          // [C] dlogit2, [R] a1 = swish(h1), [R] dh1
+  float* dl2 = lds;
+  float* a1 = lds + C;
+  float* dh1 = a1 + R;
+  const int b = blockIdx.x;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) a1[r] = swishf_(h1[(size_t)b * R + r]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float sv = s[(size_t)b * C + c];
+    dl2[c] = ds[(size_t)b * C + c] * sv * (1.f - sv);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(&db2[c], dl2[c]);
+    for (int r = 0; r < R; ++r) atomicAdd(&dw2[(size_t)c * R + r], dl2[c] * a1[r]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(w2[(size_t)c * R + r], dl2[c], a);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    if (lane == 0) {
+      const float d = a * dswishf_(h1[(size_t)b * R + r]);
+      dh1[r] = d;
+      atomicAdd(&db1[r], d);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f;
+    const float pc = pooled[(size_t)b * C + c];
+    for (int r = 0; r < R; ++r) {
+      a = fmaf(w1[(size_t)r * C + c], dh1[r], a);
+      atomicAdd(&dw1[(size_t)r * C + c], dh1[r] * pc);
+    }
+    dpooled[(size_t)b * C + c] = a;
+  }
+}
+
+// dz = (du * s[b][c] + dpooled[b][c]/HW) * swish'(x*sc+sh);  S1 += dz, S2 += dz * (x-mean)*rstd.   du / s may be null
+__global__ void se_act_bwd_kernel(const bf16* __restrict__ du, const bf16* __restrict__ x, const float* __restrict__ sc,
+                                  const float* __restrict__ sh, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                  const float* __restrict__ s, const float* __restrict__ dpooled, bf16* __restrict__ dz, float* S1,
+                                  float* S2, int B, int HW, int C) {
+  extern __shared__ float lds[];
+  const int CP = C / 8;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CP;
+  float st[2][8], fsc[8], fsh[8], fmu[8], fr[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cq * 8 + j;
+    st[0][j] = st[1][j] = 0.f;
+    fsc[j] = sc[c]; fsh[j] = sh[c]; fmu[j] = mean[c]; fr[j] = rstd[c];
+  }
+  const float inv = 1.f / HW;
+  const size_t npix = (size_t)B * HW, ppb = blockDim.x / CP;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int b = pix / HW;
+    U128 v, d, o;
+    v.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
+    if (du) d.u = *reinterpret_cast<const uint4*>(du + pix * C + cq * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cq * 8 + j;
+      const float xf = bf2f(v.e[j]);
+      float da = dpooled ? dpooled[(size_t)b * C + c] * inv : 0.f;
+      if (du) da = fmaf(bf2f(d.e[j]), s ? s[(size_t)b * C + c] : 1.f, da);
+      const float dzv = da * dswishf_(fmaf(xf, fsc[j], fsh[j]));
+      st[0][j] += dzv;
+      st[1][j] += dzv * (xf - fmu[j]) * fr[j];
+      o.e[j] = f2bf(dzv);
+    }
+    *reinterpret_cast<uint4*>(dz + pix * C + cq * 8) = o.u;
+  }
+  float* const dst[2] = {S1, S2};
+  flush_partials<2>(st, cq, C, lds, dst);
+}
+
+// out = a*pa + (b ? b : 0)*pb + pc   (BatchNorm output + optional skip, no activation)
+__global__ void affine2_out_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const float* __restrict__ pa,
+                                   const float* __restrict__ pb, const float* __restrict__ pc, bf16* __restrict__ out, size_t rows, int C) {
+  const int CP = C / 8;
+  const size_t total = rows * CP;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cq = idx % CP;
+    U128 u, v, o;
+    u.u = *reinterpret_cast<const uint4*>(a + idx * 8);
+    if (b) v.u = *reinterpret_cast<const uint4*>(b + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cq * 8 + j;
+      float r = fmaf(bf2f(u.e[j]), pa[c], pc[c]);
+      if (b) r = fmaf(bf2f(v.e[j]), pb[c], r);
+      o.e[j] = f2bf(r);
+    }
+    *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
+  }
+}
+
+__global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float* __restrict__ y, int C, int N) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < N; k += blockDim.x / 64) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(x[(size_t)b * C + c], w[(size_t)k * C + c], acc);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) y[(size_t)b * N + k] = acc + (bias ? bias[k] : 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cx_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0) return CX_EINVAL;
+  const size_t hw = (size_t)H * W, total = hw * B;
+  hipLaunchKernelGGL(nchw3_to_nhwc8_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y, hw, total);
+  return launch_status();
+}
+
+int cx_dwconv_fwd(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
+                  int W, int C, int k, int stride, int pad, void* stream) {
+  if (!x || !w || !y || C % 8 || C > 4096 || k < 1 || stride < 1 || (sc && !sh)) return CX_EINVAL;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int CP = C / 8, th = threads_for(CP);
+  if (CP > 1024) return CX_ESHAPE;
+  const size_t npix = (size_t)B * Ho * Wo;
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+                     (const bf16*)x, w, sc, sh, (bf16*)y, stat_sum, stat_sq, B, H, W, C, Ho, Wo, k, stride, pad);
+  return launch_status();
+}
+
+int cx_dwconv_dgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
+                    const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
+                    int W, int C, int k, int stride, int pad, int accumulate, void* stream) {
+  if (!g || !g2 || !ga || !gb || !gc || !w || !x || !dz || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  if (sc && (!sh || !mean || !rstd || !S1 || !S2)) return CX_EINVAL;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int CP = C / 8, th = threads_for(CP);
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+                     (const bf16*)g, (const bf16*)g2, ga, gb, gc, w, (const bf16*)x, sc, sh, mean, rstd, (bf16*)dz, S1, S2, B, H, W, C, Ho,
+                     Wo, k, stride, pad, accumulate);
+  return launch_status();
+}
+
+int cx_dwconv_wgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream) {
+  if (!g || !g2 || !ga || !gb || !gc || !x || !dw || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int CP = C / 8, th = threads_for(CP);
+  const size_t npix = (size_t)B * Ho * Wo;
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(grid_for(npix, th / CP, 256), k * k), dim3(th), C * sizeof(float), as_stream(stream),
+                     (const bf16*)g, (const bf16*)g2, ga, gb, gc, (const bf16*)x, sc, sh, dw, B, H, W, C, Ho, Wo, k, stride, pad);
+  return launch_status();
+}
+
+int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream) {
+  if (!x || !sc || !sh || !pooled || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  int splits = 1024 / B;
+  if (splits < 1) splits = 1;
+  if (splits > HW / 16 + 1) splits = HW / 16 + 1;
+  hipError_t e = hipMemsetAsync(pooled, 0, (size_t)B * C * sizeof(float), as_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gap_affine_act_kernel, dim3(splits, B), dim3(th), 0, as_stream(stream), (const bf16*)x, sc, sh, pooled, HW, C, act,
+                     splits);
+  return launch_status();
+}
+
+int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
+              int R, void* stream) {
+  if (!pooled || !w1 || !b1 || !w2 || !b2 || !h1 || !s || R <= 0 || R > 1024) return CX_EINVAL;
+  hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(256), R * sizeof(float), as_stream(stream), pooled, w1, b1, w2, b2, h1, s, C, R);
+  return launch_status();
+}
+
+int cx_scale_act_bc(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream) {
+  if (!x || !sc || !sh || !u || C % 8) return CX_EINVAL;
+  const size_t total = (size_t)B * HW * (C / 8);
+  hipLaunchKernelGGL(scale_act_bc_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)x, sc, sh, s,
+                     (bf16*)u, HW, C, total);
+  return launch_status();
+}
+
+int cx_bn_lin_bwd_stats(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
+                        void* stream) {
+  if (!g || !y || !mean || !rstd || !S1 || !S2 || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  hipLaunchKernelGGL(bn_lin_bwd_stats_kernel, dim3(grid_for(rows, th / CP, 2048)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+                     (const bf16*)g, (const bf16*)y, mean, rstd, S1, S2, rows, C);
+  return launch_status();
+}
+
+int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream) {
+  if (!du || !x || !sc || !sh || !ds || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  int splits = 1024 / B;
+  if (splits < 1) splits = 1;
+  if (splits > HW / 16 + 1) splits = HW / 16 + 1;
+  hipError_t e = hipMemsetAsync(ds, 0, (size_t)B * C * sizeof(float), as_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(splits, B), dim3(th), 0, as_stream(stream), (const bf16*)du, (const bf16*)x, sc, sh, ds, HW,
+                     C, splits);
+  return launch_status();
+}
+
+int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
+              float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, void* stream) {
+  if (!ds || !s || !h1 || !pooled || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpooled || R <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (C + 2 * R) * sizeof(float), as_stream(stream), ds, s, h1, pooled, w1, w2, dw1, db1,
+                     dw2, db2, dpooled, C, R);
+  return launch_status();
+}
+
+int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream) {
+  if (!x || !sc || !sh || !mean || !rstd || !dz || !S1 || !S2 || (!du && !dpooled) || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  hipLaunchKernelGGL(se_act_bwd_kernel, dim3(grid_for((size_t)B * HW, th / CP, 2048)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+                     (const bf16*)du, (const bf16*)x, sc, sh, mean, rstd, s, dpooled, (bf16*)dz, S1, S2, B, HW, C);
+  return launch_status();
+}
+
+int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows, int C,
+                   void* stream) {
+  if (!a || !pa || !pc || !out || (b && !pb) || C % 8) return CX_EINVAL;
+  hipLaunchKernelGGL(affine2_out_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)a,
+                     (const bf16*)b, pa, pb, pc, (bf16*)out, rows, C);
+  return launch_status();
+}
+
+int cx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int N, void* stream) {
+  if (!x || !w || !y) return CX_EINVAL;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), x, w, bias, y, C, N);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -219,6 +219,38 @@ int cx_in_relu_bwd(const void* da, const void* x, const float* sc, const float* 
                    int C, int ldx, int ldg, void* stream);
 int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream);
 
+/* ---- EfficientNet blocks (models/efficientnet.py:27-131): depthwise conv, squeeze-excitation, Swish glue ----------
+ * depthwise k x k conv on (B,H,W,C) bf16, weights fp32 (C,1,k,k); the preceding BatchNorm+Swish is applied on load
+ * when sc/sh are given (sc == NULL: raw input).  Output / statistics as cx_conv_gemm.                          */
+int cx_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, void* stream);
+int cx_dwconv_fwd(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
+                  int W, int C, int k, int stride, int pad, void* stream);
+/* dY = g*ga + g2*gb + gc;  dz = (sum_t dY w) * swish'(x*sc+sh), S1 += dz, S2 += dz*(x-mean)*rstd (sc==NULL: dz = sum) */
+int cx_dwconv_dgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
+                    const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
+                    int W, int C, int k, int stride, int pad, int accumulate, void* stream);
+int cx_dwconv_wgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream);
+/* pooled[b][c] = mean_hw act(x*sc+sh) (act 0 none / 1 relu / 2 swish): SELayer pool (:69), head pool (:162)      */
+int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream);
+/* SELayer FCs (:70-73): h1 = W1 pooled + b1, s = sigmoid(W2 swish(h1) + b2); and their backward                */
+int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
+              int R, void* stream);
+int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
+              float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, void* stream);
+/* u = swish(x*sc+sh) * s[b][c] (s NULL: no SE scaling)                                                          */
+int cx_scale_act_bc(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream);
+int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream);
+/* dz = (du*s[b][c] + dpooled[b][c]/HW) * swish'(x*sc+sh) + BN backward sums (du or dpooled may be NULL)          */
+int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream);
+int cx_bn_lin_bwd_stats(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
+                        void* stream);
+/* out = a*pa + b*pb + pc (b may be NULL): projection BatchNorm output + skip (:105-110)                         */
+int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows, int C,
+                   void* stream);
+int cx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int N, void* stream);
+
 /* Grad-CAM as the reference code executes it (chexpert.py:260-303):
  * cam[b][p] = relu(sum_c w[c]*relu(x*scale+shift)) with class-independent w[c] = mean_b pooled[b][c]*B/n_cls,
  * then per-image (t-min)/(max-min+1e-5) and bilinear upsampling with align_corners=True.            */
