@@ -246,8 +246,8 @@ def main():
         avg_ms = ksum["ms"] / ksum["launches"]
         achieved = ksum["alg_bytes"] / (ksum["ms"] * 1e-3) / 1e9
         out = {
-            "metric": "images/sec fwd+bwd %s 320x320 bf16 (per-GPU rate in config.images_per_sec_per_gpu)" % (
-            "DenseNet121" if args.model == "densenet121" else args.model),
+            "metric": "images/sec fwd+bwd %s %dx%d bf16 (per-GPU rate in config.images_per_sec_per_gpu)" % (
+            "DenseNet121" if args.model == "densenet121" else args.model, args.size, args.size),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
