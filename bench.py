@@ -207,6 +207,9 @@ def main():
         torch.cuda.synchronize()
         fam = timer.summary()
         only = max(fam, key=lambda k: fam[k]["ms"])
+        for k in sorted(fam, key=lambda k: -fam[k]["ms"]):
+            log("  %-34s %4d launches %7.2f ms  %6.0f GB/s" % (k, fam[k]["launches"], fam[k]["ms"],
+                                                             fam[k]["alg_bytes"] / fam[k]["ms"] / 1e6))
         timer.records = {}
     timer.enabled, timer.only = True, only
     log("warm-up done; roofline kernel = %s" % only)

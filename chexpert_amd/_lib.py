@@ -25,7 +25,8 @@ class CxConv(C.Structure):
                 ("K", _i32), ("N", _i32),
                 ("ldx", _i32), ("ldx2", _i32), ("ldy", _i32), ("ldex", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
-                ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32), ("tstride", _i32)]
+                ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32), ("tstride", _i32),
+                ("stat_replicas", _i32), ("stat_rstride", _i32)]
 
 
 class CxWgrad(C.Structure):
@@ -53,9 +54,9 @@ SIGNATURES = {
     "cx_pack_weights": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "cx_pack_weights_table": [_vp, _vp, _vp, _i, _vp],
     "cx_nchw3_to_nhwc4": [_vp, _vp, _i, _i, _i, _vp],
-    "cx_bn_coef": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "cx_bn_coef": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_bn_coef_eval": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],
-    "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_bn_bwd_slice_coef": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "cx_bnrelu_maxpool_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_bnrelu_maxpool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -113,7 +114,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cx_error_string" else C.c_int
-        if l.cx_abi_version() != 1:
+        if l.cx_abi_version() != 2:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l
     return _lib

@@ -257,6 +257,40 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
   }
   const bool want_stats = p.stat_sum != nullptr;
 
+  // Every mask / read-modify-write operand of the tile is requested up front: the passes below would otherwise each
+  // pay one full HBM round trip (load -> use -> store, 8 times per tile), which is what bounds the 1x1 input-gradient
+  // kernels.  Loads are unconditional on clamped in-bounds addresses.
+  constexpr int NPASS = 64 / RPP;
+  U128 xv[2][NPASS], old[2][NPASS];
+  {
+    const int ncl = nvalid ? nch : 0;
+    if (EPI == CX_EPI_MASK) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+          const int m = mt * BM + half * 64 + pass * RPP + rr;
+          const int mc = m < M ? m : M - 1;
+          xv[half][pass].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl);
+        }
+    }
+    if (p.accumulate) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+          const int m = mt * BM + half * 64 + pass * RPP + rr;
+          const int mc = m < M ? m : M - 1;
+          old[half][pass].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl);
+        }
+    } else {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) old[half][pass].u = make_uint4(0, 0, 0, 0);
+    }
+  }
+
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if (wm / (G::WAVES_M / 2) == half) {
@@ -274,16 +308,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
     }
     __syncthreads();
 #pragma unroll
-    for (int pass = 0; pass < 64 / RPP; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + rr;
       const int m = mt * BM + half * 64 + row;
-      U128 xv, old;
-      {                                  // unconditional, clamped loads (no branch around a load)
-        const int mc = m < M ? m : M - 1;
-        const int ncl = nvalid ? nch : 0;
-        if (EPI == CX_EPI_MASK) xv.u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl);
-        if (p.accumulate) old.u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl);
-      }
       if (m < M && nvalid) {
         const float4 v0 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8 + 4);
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
         if (EPI == CX_EPI_STORE) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            o.e[j] = f2bf(p.accumulate ? v[j] + bf2f(old.e[j]) : v[j]);
+            o.e[j] = f2bf(v[j] + bf2f(old[half][pass].e[j]));
             const float rv = bf2f(o.e[j]);
             s1[j] += rv;
             s2[j] += rv * rv;
@@ -300,13 +327,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float xf = bf2f(xv.e[j]);
+            const float xf = bf2f(xv[half][pass].e[j]);
             const float dz = (fmaf(xf, esc[j], esh[j]) > 0.f) ? v[j] : 0.f;
             s1[j] += dz;
             s2[j] += dz * (xf - emu[j]) * er[j];
-            float out = escale[j] * dz;
-            if (p.accumulate) out += bf2f(old.e[j]);
-            o.e[j] = f2bf(out);
+            o.e[j] = f2bf(fmaf(escale[j], dz, bf2f(old[half][pass].e[j])));
           }
         }
         *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + nch) = o.u;
@@ -334,8 +359,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
     }
     __syncthreads();
     if (tid < BN && n0 + tid < p.N) {
-      atomicAdd(&p.stat_sum[n0 + tid], lstat[tid]);
-      atomicAdd(&p.stat_sq[n0 + tid], lstat[BN + tid]);
+      const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+      atomicAdd(&p.stat_sum[rep + n0 + tid], lstat[tid]);
+      atomicAdd(&p.stat_sq[rep + n0 + tid], lstat[BN + tid]);
     }
   }
 }
@@ -388,6 +414,7 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
     if ((p.ldex % 8) || !aligned16(p.ex)) return CX_EALIGN;
   }
   if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return CX_EINVAL;
+  if (p.stat_replicas < 0 || (p.stat_replicas > 1 && p.stat_rstride < p.N)) return CX_EINVAL;
   hipStream_t st = as_stream(stream);
   if (p.mode == CX_MODE_CONV) {
     if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return CX_ESHAPE;

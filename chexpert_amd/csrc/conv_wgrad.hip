@@ -60,9 +60,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const CxWgrad p, const int M
   const int wn = (wave / G::WAVES_C) % G::WAVES_N, wc = wave % G::WAVES_C;
 
   int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = id % splits;  id /= splits;
+  // c-tiles vary fastest: the workgroups that re-read one pixel range of G run side by side on one XCD and share it in L2
   const int ct = id % c_tiles;    id /= c_tiles;
   const int nt = id % n_tiles;    id /= n_tiles;
+  const int split = id % splits;  id /= splits;
   const int tap = id;
   const int n0 = nt * BNW, c0 = ct * BCW;
   const int dy = (MODE == CX_MODE_CONV) ? tap / p.kw : tap;

@@ -88,11 +88,16 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, bf16* __restr
 
 __global__ void bn_coef_kernel(const float* sum, const float* sq, float count, const float* gamma, const float* beta,
                                float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
-                               float* mean, float* rstd, int C) {
+                               float* mean, float* rstd, int C, int replicas, int rstride) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double m = (double)sum[c] / count;
-  double v = (double)sq[c] / count - m * m;
+  double ts = 0.0, tq = 0.0;
+  for (int r = 0; r < replicas; ++r) {
+    ts += (double)sum[(size_t)r * rstride + c];
+    tq += (double)sq[(size_t)r * rstride + c];
+  }
+  const double m = ts / count;
+  double v = tq / count - m * m;
   if (v < 0) v = 0;
   const float r = (float)(1.0 / sqrt(v + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -119,10 +124,15 @@ __global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const
 
 __global__ void bn_bwd_coef_kernel(const float* S1, const float* S2, float count, const float* gamma, const float* mean,
                                    const float* rstd, float* dgamma, float* dbeta, float* A, float* Bc, float* pa,
-                                   float* pb, float* pc, int C) {
+                                   float* pb, float* pc, int C, int replicas, int rstride) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float s1 = S1[c], s2 = S2[c], g = gamma ? gamma[c] : 1.f, r = rstd[c], mu = mean[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int q = 0; q < replicas; ++q) {
+    s1 += S1[(size_t)q * rstride + c];
+    s2 += S2[(size_t)q * rstride + c];
+  }
+  const float g = gamma ? gamma[c] : 1.f, r = rstd[c], mu = mean[c];
   if (dgamma) dgamma[c] += s2;
   if (dbeta) dbeta[c] += s1;
   const float inv = 1.f / count;
@@ -668,10 +678,12 @@ int cx_nchw3_to_nhwc4(const float* x, void* y, int B, int H, int W, void* stream
 
 int cx_bn_coef(const float* sum, const float* sq, float count, const float* gamma, const float* beta, float eps, float momentum,
                float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd, int C,
-               void* stream) {
+               int replicas, int rstride, void* stream) {
   if (!sum || !sq || C <= 0 || count <= 0) return CX_EINVAL;
+  if (replicas < 1) replicas = 1;
+  if (replicas > 1 && rstride < C) return CX_EINVAL;
   hipLaunchKernelGGL(bn_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sum, sq, count, gamma, beta, eps,
-                     momentum, running_mean, running_var, scale, shift, mean, rstd, C);
+                     momentum, running_mean, running_var, scale, shift, mean, rstd, C, replicas, rstride);
   return launch_status();
 }
 
@@ -684,11 +696,14 @@ int cx_bn_coef_eval(const float* rm, const float* rv, const float* gamma, const 
 }
 
 int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* gamma, const float* mean, const float* rstd,
-                   float* dgamma, float* dbeta, float* A, float* Bc, float* pa, float* pb, float* pc, int C, void* stream) {
+                   float* dgamma, float* dbeta, float* A, float* Bc, float* pa, float* pb, float* pc, int C, int replicas,
+                   int rstride, void* stream) {
   if (!S1 || !S2 || !mean || !rstd || C <= 0 || count <= 0) return CX_EINVAL;
+  if (replicas < 1) replicas = 1;
+  if (replicas > 1 && rstride < C) return CX_EINVAL;
   if (pa && (!pb || !pc)) return CX_EINVAL;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), S1, S2, count, gamma, mean,
-                     rstd, dgamma, dbeta, A, Bc, pa, pb, pc, C);
+                     rstd, dgamma, dbeta, A, Bc, pa, pb, pc, C, replicas, rstride);
   return launch_status();
 }
 

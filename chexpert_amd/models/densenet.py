@@ -21,6 +21,7 @@ import ctypes as C
 import math
 from collections import OrderedDict
 
+import os
 import torch
 import torch.nn as nn
 
@@ -236,15 +237,18 @@ class _Engine:
         self.pool = {}
         self.reducer = None          # chexpert_amd.parallel.GradReducer when data-parallel
         self.side = None             # side stream for the weight-gradient kernels of the dense layers
+        self.stat_replicas = 16      # copies of every conv-produced statistics vector (memory-side atomic contention)
         self._plan_vectors()
 
     # ---- coefficient-vector layout
     def _plan_vectors(self):
         V = _Vec()
         s = {}
+        R = self.stat_replicas
+        take_r = lambda n: (V.take(n * R)[0], n)      # R copies, n floats apart: the conv kernels spread their atomics over them
         s["st0"] = [V.take(self.c_init) for _ in range(2)]                # conv0 output sum, sq
-        s["bst"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
-        s["yst"] = [[[V.take(self.mid) for _ in range(2)] for _ in range(n)] for _, n in self.blocks]
+        s["bst"] = [[take_r(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
+        s["yst"] = [[[take_r(self.mid) for _ in range(2)] for _ in range(n)] for _, n in self.blocks]
         self.fwd_zero = (0, V.n)                                           # zeroed at the start of each forward
         s["n0"] = [V.take(self.c_init) for _ in range(4)]                  # sc, sh, mean, rstd
         s["bmr"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]     # block mean, rstd
@@ -253,8 +257,8 @@ class _Engine:
         s["nt"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]      # transition / norm5 sc, sh
         b0 = V.n
         s["S0"] = [V.take(self.c_init) for _ in range(2)]
-        s["S1"] = [[[V.take(c + i * self.growth) for _ in range(2)] for i in range(n)] for c, n in self.blocks]
-        s["S2"] = [[[V.take(self.mid) for _ in range(2)] for _ in range(n)] for _, n in self.blocks]
+        s["S1"] = [[[take_r(c + i * self.growth) for _ in range(2)] for i in range(n)] for c, n in self.blocks]
+        s["S2"] = [[[take_r(self.mid) for _ in range(2)] for _ in range(n)] for _, n in self.blocks]
         s["St"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
         s["AB"] = [[V.take(c + n * self.growth) for _ in range(2)] for c, n in self.blocks]
         self.bwd_zero = (b0, V.n - b0)
@@ -358,7 +362,7 @@ class _Engine:
             lst.append(ws)
 
     # ---- forward
-    def _bn(self, ws, sum_slot, sq_slot, count, bn, out_slots, C_, train, mean_slot=None, rstd_slot=None):
+    def _bn(self, ws, sum_slot, sq_slot, count, bn, out_slots, C_, train, mean_slot=None, rstd_slot=None, replicas=1):
         """scale/shift (+mean/rstd) of one BatchNorm over channels [0,C_) of the given statistics."""
         sc, sh = ws.v(out_slots[0])[:C_], ws.v(out_slots[1])[:C_]
         mean = ws.v(mean_slot)[:C_] if mean_slot is not None else None
@@ -367,12 +371,14 @@ class _Engine:
             mom = bn.momentum if bn.momentum is not None else 0.1
             ops.bn_coef(ws.v(sum_slot)[:C_], ws.v(sq_slot)[:C_], count, bn.weight, bn.bias, bn.eps, mom,
                         bn.running_mean if bn.track_running_stats else None,
-                        bn.running_var if bn.track_running_stats else None, sc, sh, mean, rstd, C_)
+                        bn.running_var if bn.track_running_stats else None, sc, sh, mean, rstd, C_, replicas=replicas,
+                        rstride=sum_slot[1])
         else:
             ops.bn_coef_eval(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, sc, sh, mean, rstd, C_)
 
     def forward(self, x, train):
         m, f, s = self.model, self.model.features, self.slots
+        R = self.stat_replicas
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError("expected a (B,3,H,W) input")
         B, _, H, W = x.shape
@@ -403,32 +409,36 @@ class _Engine:
                 layer = getattr(block, "denselayer%d" % (li + 1))
                 cin = c0 + li * self.growth
                 n1, n2 = s["n1"][bi][li], s["n2"][bi][li]
-                self._bn(ws, bsum, bsq, cnt, layer.norm1, n1, cin, train, bmean, brstd)
+                self._bn(ws, bsum, bsq, cnt, layer.norm1, n1, cin, train, bmean, brstd, replicas=R)
                 ysum, ysq = s["yst"][bi][li]
                 y1 = ws.y1[bi][li]
                 ops.conv_gemm(buf[..., :cin], self.w_fwd(layer.conv1), y1, N=self.mid, prologue=ops.PRO_AFFINE_RELU,
-                              pa=ws.v(n1[0]), pb=ws.v(n1[1]), stat_sum=st(ysum), stat_sq=st(ysq))
-                self._bn(ws, ysum, ysq, cnt, layer.norm2, n2[:2], self.mid, train, n2[2], n2[3])
+                              pa=ws.v(n1[0]), pb=ws.v(n1[1]), stat_sum=st(ysum), stat_sq=st(ysq), stat_replicas=R,
+                              stat_rstride=ysum[1])
+                self._bn(ws, ysum, ysq, cnt, layer.norm2, n2[:2], self.mid, train, n2[2], n2[3], replicas=R)
                 off, _ = bsum
                 ops.conv_gemm(y1, self.w_fwd(layer.conv2), buf[..., cin:cin + self.growth], N=self.growth, kh=3, kw=3, pad=1,
                               prologue=ops.PRO_AFFINE_RELU, pa=ws.v(n2[0]), pb=ws.v(n2[1]),
-                              stat_sum=st((bsum[0] + cin, self.growth)), stat_sq=st((bsq[0] + cin, self.growth)))
+                              stat_sum=st((bsum[0] + cin, self.growth)), stat_sq=st((bsq[0] + cin, self.growth)),
+                              stat_replicas=R, stat_rstride=bsum[1])
             ct = c0 + n_layers * self.growth
             nt = s["nt"][bi]
             if bi != nb - 1 and isinstance(getattr(f, "transition%d" % (bi + 1)).conv, AAConv2d):
                 # block statistics are still needed by backward (mean / rstd of the buffer channels)
                 if train:
-                    ops.bn_coef(ws.v(bsum), ws.v(bsq), cnt, None, None, 1e-5, 0.0, None, None, None, None, ws.v(bmean), ws.v(brstd), ct)
+                    ops.bn_coef(ws.v(bsum), ws.v(bsq), cnt, None, None, 1e-5, 0.0, None, None, None, None, ws.v(bmean), ws.v(brstd), ct,
+                                replicas=R, rstride=bsum[1])
                 self._aa_forward(ws, bi, getattr(f, "transition%d" % (bi + 1)).conv, st)
             elif bi != nb - 1:
                 tr = getattr(f, "transition%d" % (bi + 1))
-                self._bn(ws, bsum, bsq, cnt, tr.norm, nt, ct, train, bmean, brstd)
+                self._bn(ws, bsum, bsq, cnt, tr.norm, nt, ct, train, bmean, brstd, replicas=R)
                 nsum, nsq = s["bst"][bi + 1]
                 ops.conv_gemm(buf, self.w_fwd(tr.conv), ws.buf[bi + 1][..., :ct // 2], N=ct // 2, mode=ops.MODE_POOL2,
                               prologue=ops.PRO_AFFINE_RELU, pa=ws.v(nt[0]), pb=ws.v(nt[1]),
-                              stat_sum=st((nsum[0], ct // 2)), stat_sq=st((nsq[0], ct // 2)))
+                              stat_sum=st((nsum[0], ct // 2)), stat_sq=st((nsq[0], ct // 2)), stat_replicas=R,
+                              stat_rstride=nsum[1])
             else:
-                self._bn(ws, bsum, bsq, cnt, f.norm5, nt, ct, train, bmean, brstd)
+                self._bn(ws, bsum, bsq, cnt, f.norm5, nt, ct, train, bmean, brstd, replicas=R)
                 ops.head_fwd(buf, ws.v(nt[0]), ws.v(nt[1]), m.classifier.weight, m.classifier.bias, ws.pooled, ws.logits)
         if train:
             m._nbt_pending += 1
@@ -476,6 +486,7 @@ class _Engine:
     # ---- backward
     def backward(self, ws, dlogits):
         m, f, s = self.model, self.model.features, self.slots
+        R = self.stat_replicas
         B = ws.B
         dev = self.device
         ws.alloc_backward(self, dev)
@@ -513,7 +524,8 @@ class _Engine:
         main = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream(device=dev)
-        side = self.side
+        # CHEXPERT_SERIAL_WGRAD=1: profiling aid, everything on one stream so per-kernel durations are not stretched by overlap
+        side = main if os.environ.get("CHEXPERT_SERIAL_WGRAD") == "1" else self.side
         side.wait_stream(main)
         w1_done = {}
         k = 0
@@ -544,21 +556,22 @@ class _Engine:
                     main.wait_event(w1_done.pop(k - 2))        # the side stream has finished reading this dz2 buffer
                 ops.conv_gemm(gs, self.w_bwd(layer.conv2), dz2, N=self.mid, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=xs,
                               pa=qa, pb=qb, pc=qc, epilogue=ops.EPI_MASK, ex=y1, e_sc=v(n2[0]), e_sh=v(n2[1]), e_mu=v(n2[2]),
-                              e_r=v(n2[3]), e_scale=ws.ones[:self.mid], stat_sum=v(S2[0]), stat_sq=v(S2[1]))
+                              e_r=v(n2[3]), e_scale=ws.ones[:self.mid], stat_sum=v(S2[0]), stat_sq=v(S2[1]),
+                              stat_replicas=R, stat_rstride=S2[0][1])
                 side.wait_event(ev_q)
                 with torch.cuda.stream(side):
                     ops.conv_wgrad(gs, y1, G(layer.conv2.weight), kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa,
                                    gb=qb, gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
                 pa, pb, pc = (v(t) for t in s["pl"][bi][li])
                 ops.bn_bwd_coef(v(S2[0]), v(S2[1]), cnt, layer.norm2.weight, v(n2[2]), v(n2[3]), G(layer.norm2.weight),
-                                G(layer.norm2.bias), None, None, pa, pb, pc, self.mid)
+                                G(layer.norm2.bias), None, None, pa, pb, pc, self.mid, replicas=R, rstride=S2[0][1])
                 ev_p = torch.cuda.Event()
                 ev_p.record(main)
                 S1 = s["S1"][bi][li]
                 ops.conv_gemm(dz2, self.w_bwd(layer.conv1), gbuf[..., :cin], N=cin, prologue=ops.PRO_AFFINE2, x2=y1, pa=pa,
                               pb=pb, pc=pc, epilogue=ops.EPI_MASK, ex=buf[..., :cin], e_sc=v(n1[0]), e_sh=v(n1[1]),
                               e_mu=v(bmean)[:cin], e_r=v(brstd)[:cin], e_scale=v(n1[0]), stat_sum=v(S1[0]), stat_sq=v(S1[1]),
-                              accumulate=True)
+                              accumulate=True, stat_replicas=R, stat_rstride=S1[0][1])
                 side.wait_event(ev_p)
                 with torch.cuda.stream(side):
                     ops.conv_wgrad(dz2, buf[..., :cin], G(layer.conv1.weight), g_prologue=ops.PRO_AFFINE2, g2=y1, ga=pa, gb=pb,
@@ -566,7 +579,7 @@ class _Engine:
                     w1_done[k] = torch.cuda.Event()
                     w1_done[k].record(side)
                 ops.bn_bwd_coef(v(S1[0]), v(S1[1]), cnt, layer.norm1.weight, v(bmean), v(brstd), G(layer.norm1.weight),
-                                G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin)
+                                G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin, replicas=R, rstride=S1[0][1])
                 if red is not None:
                     main.wait_event(w1_done[k])
                 k += 1

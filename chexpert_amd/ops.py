@@ -22,7 +22,7 @@ def _nhwc(t):
 
 def conv_gemm(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
               pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
-              e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1):
+              e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1, stat_replicas=1, stat_rstride=0):
     require_cuda(x, w_packed, y)
     p = CxConv()
     B, H, W, Cx, ldx = _nhwc(x)
@@ -41,6 +41,7 @@ def conv_gemm(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV,
         assert x2.shape == x.shape
         p.x2, p.ldx2 = ptr(x2), _nhwc(x2)[4]
     p.stat_sum, p.stat_sq = ptr(stat_sum), ptr(stat_sq)
+    p.stat_replicas, p.stat_rstride = stat_replicas, stat_rstride
     if ex is not None:
         assert ex.shape == y.shape
         p.ex, p.ldex = ptr(ex), _nhwc(ex)[4]
@@ -91,10 +92,10 @@ def nchw3_to_nhwc4(x, out=None):
     return out
 
 
-def bn_coef(s, q, count, gamma, beta, eps, momentum, rmean, rvar, scale, shift, mean, rstd, Cn=None):
+def bn_coef(s, q, count, gamma, beta, eps, momentum, rmean, rvar, scale, shift, mean, rstd, Cn=None, replicas=1, rstride=0):
     Cn = Cn if Cn is not None else s.numel()
     check(lib().cx_bn_coef(ptr(s), ptr(q), float(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),
-                           ptr(scale), ptr(shift), ptr(mean), ptr(rstd), Cn, stream_ptr()), "cx_bn_coef")
+                           ptr(scale), ptr(shift), ptr(mean), ptr(rstd), Cn, replicas, rstride, stream_ptr()), "cx_bn_coef")
 
 
 def bn_coef_eval(rmean, rvar, gamma, beta, eps, scale, shift, mean, rstd, Cn=None):
@@ -103,9 +104,9 @@ def bn_coef_eval(rmean, rvar, gamma, beta, eps, scale, shift, mean, rstd, Cn=Non
                                 ptr(rstd), Cn, stream_ptr()), "cx_bn_coef_eval")
 
 
-def bn_bwd_coef(S1, S2, count, gamma, mean, rstd, dgamma, dbeta, A, Bc, pa, pb, pc, Cn):
+def bn_bwd_coef(S1, S2, count, gamma, mean, rstd, dgamma, dbeta, A, Bc, pa, pb, pc, Cn, replicas=1, rstride=0):
     check(lib().cx_bn_bwd_coef(ptr(S1), ptr(S2), float(count), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta),
-                               ptr(A), ptr(Bc), ptr(pa), ptr(pb), ptr(pc), Cn, stream_ptr()), "cx_bn_bwd_coef")
+                               ptr(A), ptr(Bc), ptr(pa), ptr(pb), ptr(pc), Cn, replicas, rstride, stream_ptr()), "cx_bn_bwd_coef")
 
 
 def bn_bwd_slice_coef(A, Bc, mean, rstd, pa, pb, pc, Cn):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 1
+#define CX_ABI_VERSION 2
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4 };
 
@@ -67,6 +67,10 @@ typedef struct CxConv {
   int32_t prologue, mode, epilogue, accumulate;   /* accumulate: y += result (both epilogues)             */
   int32_t tstride;      /* > 1: input gradient of a conv with that stride (x is its output gradient,    */
                         /* stride must be 1, pad = kh-1-forward_pad, weights packed with transpose=1)    */
+  int32_t stat_replicas; /* R > 1: workgroup b adds its statistics to replica b % R, replica r of channel */
+  int32_t stat_rstride;  /* n lives at stat_sum[r*stat_rstride + n].  Thousands of workgroups adding to   */
+                         /* the same N floats serialise at the memory side; the consumer (cx_bn_coef /   */
+                         /* cx_bn_bwd_coef) sums the replicas.  0 or 1: a single copy                     */
 } CxConv;
 
 /* Weight gradient of the same convolution:  dW[n][c][ky][kx] += sum_m G[m][n] * A[m@tap][c]
@@ -119,7 +123,7 @@ int cx_nchw3_to_nhwc4(const float* x, void* y, int B, int H, int W, void* stream
  * running_* may be NULL.  Also emits mean / rstd when non-NULL.                                   */
 int cx_bn_coef(const float* sum, const float* sq, float count, const float* gamma, const float* beta, float eps,
                float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
-               float* rstd, int C, void* stream);
+               float* rstd, int C, int replicas, int rstride, void* stream);   /* sum/sq: `replicas` copies, `rstride` floats apart */
 /* eval mode: scale/shift from running statistics                                                 */
 int cx_bn_coef_eval(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                     float eps, float* scale, float* shift, float* mean, float* rstd, int C, void* stream);
@@ -133,7 +137,7 @@ int cx_bn_coef_eval(const float* running_mean, const float* running_var, const f
  *   dY = dz*pa + y*pb + pc.                                                                       */
 int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* gamma, const float* mean,
                    const float* rstd, float* dgamma, float* dbeta, float* A, float* Bc, float* pa, float* pb,
-                   float* pc, int C, void* stream);
+                   float* pc, int C, int replicas, int rstride, void* stream);   /* S1/S2 replicated as above */
 /* AFFINE2 vectors that apply the deferred correction to a gradient slice:
  *   dY_true = G*1 + x*(-r*Bc) + (mean*r*Bc - A)                                                   */
 int cx_bn_bwd_slice_coef(const float* A, const float* Bc, const float* mean, const float* rstd, float* pa,
