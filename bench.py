@@ -39,6 +39,31 @@ class KernelTimer:
         self.only = None
         self.enabled = False
 
+    # Tags are the names of the kernel instantiations cx_conv_gemm / cx_conv_wgrad dispatch to (conv_gemm.hip launch_bn,
+    # conv_wgrad.hip launch_tile, conv3x3_strip.hip cx_try_strip_*), i.e. what rocprofv3 --kernel-trace lists.
+    @staticmethod
+    def gemm_kernel_name(x, kw):
+        mode, kh, pro, epi, N = kw.get("mode", 0), kw.get("kh", 1), kw.get("prologue", 0), kw.get("epilogue", 0), kw["N"]
+        K = kw.get("K") or x.shape[3]
+        if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and kw.get("tstride", 1) == 1:
+            if (pro, epi, K, N) == (1, 0, 128, 32):
+                return "conv3x3_strip_fwd_kernel"
+            if (pro, epi, K, N) == (2, 1, 32, 128):
+                return "conv3x3_strip_dgrad_kernel"
+        if mode == 0 and kh == 1 and epi == 1 and K == 128 and pro in (0, 2) and kw.get("stride", 1) == 1:
+            return "pw_dgrad_kernel<%d, %s>" % (pro, "true" if kw.get("accumulate") else "false")
+        bn = 128 if N % 128 == 0 else (32 if N == 32 else 64)
+        return "conv_gemm_kernel<%d, %d, %d, %d>" % (bn, pro, mode, epi)
+
+    @staticmethod
+    def wgrad_kernel_name(g, x, kw):
+        mode, kh, gp, xp, N = kw.get("mode", 0), kw.get("kh", 1), kw.get("g_prologue", 0), kw.get("x_prologue", 0), g.shape[3]
+        K = kw.get("K") or x.shape[3]
+        if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and (gp, xp, K, N) == (2, 1, 128, 32):
+            return "conv3x3_strip_wgrad_kernel"
+        t = (64, 32) if mode == 2 else ((32, 128) if N == 32 else ((128, 64) if N % 128 == 0 else (64, 64)))
+        return "wgrad_kernel<%d, %d, %d, %d, %d>" % (t[0], t[1], gp, xp, mode)
+
     @staticmethod
     def _dims(t):
         B, H, W, C = t.shape
@@ -51,9 +76,7 @@ class KernelTimer:
         def conv_gemm(x, w, y, **kw):
             if not self.enabled:
                 return og(x, w, y, **kw)
-            mode, kh, epi = kw.get("mode", 0), kw.get("kh", 1), kw.get("epilogue", 0)
-            N = kw["N"]
-            tag = "conv_gemm/%s/%s/N%d" % ({0: "%dx%d" % (kh, kh), 1: "pool2", 2: "stem"}[mode], {0: "store", 1: "mask"}[epi], N)
+            tag = self.gemm_kernel_name(x, kw)
             if self.only is not None and tag != self.only:
                 return og(x, w, y, **kw)
             mi, ci = self._dims(x)
@@ -64,8 +87,7 @@ class KernelTimer:
         def conv_wgrad(g, x, dw, **kw):
             if not self.enabled:
                 return ow(g, x, dw, **kw)
-            mode, kh = kw.get("mode", 0), kw.get("kh", 1)
-            tag = "conv_wgrad/%s/N%d" % ({0: "%dx%d" % (kh, kh), 1: "pool2", 2: "stem"}[mode], g.shape[3])
+            tag = self.wgrad_kernel_name(g, x, kw)
             if self.only is not None and tag != self.only:
                 return ow(g, x, dw, **kw)
             mg, cg = self._dims(g)
@@ -87,6 +109,34 @@ class KernelTimer:
             ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
             out[tag] = dict(launches=len(recs), ms=ms, alg_bytes=sum(a for _, _, a in recs))
         return out
+
+
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
+    collected with rocprofv3 --pmc in their own runs); null when the workload differs from the one the counters were taken on."""
+    if (args.model, args.batch, args.size) != ("densenet121", 256, 320):
+        return None
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")) \
+        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if not files:
+        return None
+    k = json.load(open(os.path.join(ROOT, "profiles", files[-1])))["kernels"].get(kernel)
+    return None if k is None else k["hbm_bytes_per_launch"]
+
+
+def copy_bandwidth(dev):
+    """Device-to-device copy of 1 GiB (read + write = 2 GiB of HBM traffic): the measured stream rate beside the 8 TB/s spec."""
+    a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def host_cores():
@@ -243,6 +293,7 @@ def main():
     torch.cuda.synchronize()
     opt_ms = (time.perf_counter() - o0) / 5 * 1e3
 
+    copy_gbs = copy_bandwidth(dev) if rank == 0 else 0.0
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
@@ -261,10 +312,12 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "images_per_sec_per_gpu": round(value / world, 2),
                        "model_hbm_roofline_frac": round(value / world * ALG_BYTES[args.model] / (HBM_PEAK_GBS * 1e9), 4),
-                       "optimizer_step_ms": round(opt_ms, 3), "loss": round(float(loss.item()), 5)},
+                       "optimizer_step_ms": round(opt_ms, 3), "loss": round(float(loss.item()), 5),
+                       "measured_copy_GBs": round(copy_gbs, 1)},
             "roofline": {"bound": "hbm", "kernel": only, "launches_per_step": ksum["launches"] // args.steps,
                          "avg_launch_ms": round(avg_ms, 4), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(only, args), "alg_bytes_per_launch": round(ksum["alg_bytes"] / ksum["launches"])},
         }
         if not args.no_cpu_baseline and args.model == "densenet121":
             log("cpu baseline on %d cores ..." % host_cores())

@@ -279,6 +279,158 @@ int launch(const CxWgrad& p, hipStream_t st) {
   return launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------ stem (7x7 s2 p3)
+// All seven row-taps in one workgroup: the output-gradient tile G (two 64-channel tensors under AFFINE2, ~1.7 GB at
+// bs=256) is staged once per 32-pixel step and multiplied against the seven 8-pixel x 4-channel input windows, instead
+// of one workgroup per tap re-reading G seven times (measured 12.2 GB fetched per launch before).
+constexpr int ST_GP = 64 * 2 + 64;          // G tile pitch (bytes)
+constexpr int ST_XP = 64;                   // X tile pitch: 32 bf16
+constexpr int ST_G_BYTES = PX * ST_GP;
+constexpr int ST_X_BYTES = PX * ST_XP;
+constexpr int ST_STAGE = ST_G_BYTES + 7 * ST_X_BYTES;
+
+template <int GPRO>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const int M, const int steps_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16* __restrict__ Gp = reinterpret_cast<const bf16*>(p.g);
+  const bf16* __restrict__ G2 = reinterpret_cast<const bf16*>(p.g2);
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const int hw = p.Ho * p.Wo;
+
+  // G: one 16-B chunk per thread (32 px x 8 chunks); X: 7 taps x 32 px x 4 chunks = 896 chunks, 4 slots per thread
+  const int grow = tid >> 3, gcq = tid & 7;
+  float ga[8], gb[8], gc[8];
+  if (GPRO == CX_PRO_AFFINE2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ga[j] = p.ga[gcq * 8 + j]; gb[j] = p.gb[gcq * 8 + j]; gc[j] = p.gc[gcq * 8 + j]; }
+  }
+  const int step0 = blockIdx.x * steps_per_split;
+  int nsteps = (M + PX - 1) / PX - step0;
+  if (nsteps > steps_per_split) nsteps = steps_per_split;
+
+  uint4 rg, rg2, rx[4];
+  bool gv, xv[4];
+  auto issue_loads = [&](int s) {
+    const int mbase = (step0 + s) * PX;
+    {
+      const int m = mbase + grow;
+      gv = m < M;
+      const int mc = gv ? m : M - 1;
+      rg = *reinterpret_cast<const uint4*>(Gp + (size_t)mc * p.ldg + gcq * 8);
+      if (GPRO == CX_PRO_AFFINE2) rg2 = *reinterpret_cast<const uint4*>(G2 + (size_t)mc * p.ldg2 + gcq * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ci = tid + 256 * i;                // < 896 for i < 3; i == 3 only for tid < 128
+      const int cc = ci < 896 ? ci : 0;
+      const int tap = cc >> 7, row = (cc >> 2) & 31, q = cc & 3;
+      const int m = mbase + row;
+      const int mc = m < M ? m : M - 1;
+      const int b = mc / hw;
+      const int rem = mc - b * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy = 2 * oy - 3 + tap, ix = 2 * ox - 4 + 2 * q;
+      xv[i] = ci < 896 && m < M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int cy = xv[i] ? iy : 0, cx = xv[i] ? ix : 0;
+      rx[i] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * p.H + cy) * p.W + cx) * 4);
+    }
+  };
+  auto write_stage = [&](int buf) {
+    char* Gt = smem + buf * ST_STAGE;
+    char* Xt = Gt + ST_G_BYTES;
+    U128 o;
+    if (!gv) {
+      o.u = make_uint4(0, 0, 0, 0);
+    } else if (GPRO == CX_PRO_NONE) {
+      o.u = rg;
+    } else {
+      U128 u, v;
+      u.u = rg;
+      v.u = rg2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), ga[j], fmaf(bf2f(v.e[j]), gb[j], gc[j])));
+    }
+    *reinterpret_cast<uint4*>(Gt + grow * ST_GP + gcq * 16) = o.u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ci = tid + 256 * i;
+      if (ci < 896) {
+        const int tap = ci >> 7, row = (ci >> 2) & 31, q = ci & 3;
+        *reinterpret_cast<uint4*>(Xt + tap * ST_X_BYTES + row * ST_XP + q * 16) = xv[i] ? rx[i] : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+
+  // wave w owns taps w and w+4 (wave 3: tap 3 only), both 32-channel halves of N = 64
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+
+  if (nsteps > 0) {
+    issue_loads(0);
+    write_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nsteps) issue_loads(s + 1);
+      const char* Gt = smem + buf * ST_STAGE;
+      const char* Xt = Gt + ST_G_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = tr_frag(Gt, ST_GP, kk * 16, i * 32, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int tap = wave + 4 * t;
+          if (tap < 7) {
+            const bf16x8 bfr = tr_frag(Xt + tap * ST_X_BYTES, ST_XP, kk * 16, 0, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[t][i], 0, 0, 0);
+          }
+        }
+      }
+      if (s + 1 < nsteps) write_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  const int c = lane & 31, lh = lane >> 5;          // c = 4*(input pixel in the 8-wide window) + channel
+  const int kx = (c >> 2) - 1, ch = c & 3;
+  if (kx >= 0 && ch < 3) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int tap = wave + 4 * t;
+      if (tap >= 7) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          atomicAdd(p.dw + ((size_t)(n * 3 + ch) * 7 + tap) * 7 + kx, acc[t][i][r]);
+        }
+    }
+  }
+}
+
+template <int GPRO>
+int launch_stem(const CxWgrad& p, hipStream_t st) {
+  const int M = p.B * p.Ho * p.Wo;
+  const int total_steps = (M + PX - 1) / PX;
+  int splits = p.splits > 0 ? p.splits : 1024;
+  if (splits > total_steps) splits = total_steps;
+  const int sps = (total_steps + splits - 1) / splits;
+  splits = (total_steps + sps - 1) / sps;
+  hipLaunchKernelGGL((stem_wgrad_kernel<GPRO>), dim3(splits), dim3(256), 2 * ST_STAGE, st, p, M, sps);
+  return launch_status();
+}
+
 template <int GPRO, int XPRO, int MODE>
 int launch_tile(const CxWgrad& p, hipStream_t st) {
   if (MODE == CX_MODE_STEM) return launch<64, 32, GPRO, XPRO, MODE>(p, st);
@@ -329,8 +481,7 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
   }
   if (p.mode == CX_MODE_STEM) {
     if (p.x_prologue != CX_PRO_NONE || p.K != 32 || p.N != 64) return CX_EUNSUPPORTED;
-    return g2 ? launch_tile<CX_PRO_AFFINE2, CX_PRO_NONE, CX_MODE_STEM>(p, st)
-              : launch_tile<CX_PRO_NONE, CX_PRO_NONE, CX_MODE_STEM>(p, st);
+    return g2 ? launch_stem<CX_PRO_AFFINE2>(p, st) : launch_stem<CX_PRO_NONE>(p, st);
   }
   return CX_EUNSUPPORTED;
 }

@@ -125,7 +125,7 @@ def test_stem_conv7x7(dev):
 
 # ------------------------------------------------------------------------------------------------ dgrad
 @pytest.mark.parametrize("ksz,K,N,acc,B,H,W", [(1, 128, 96, False, 2, 9, 10), (1, 128, 96, True, 2, 9, 10), (3, 32, 128, False, 2, 9, 10),
-                                                (1, 128, 256, True, 2, 9, 10),
+                                                (1, 128, 256, True, 2, 9, 10), (1, 128, 72, True, 3, 7, 9), (1, 128, 8, False, 1, 5, 5),
                                                 # strip dgrad geometries
                                                 (3, 32, 128, False, 3, 10, 80), (3, 32, 128, False, 2, 9, 40), (3, 32, 128, False, 5, 20, 20)])
 def test_dgrad_affine2_mask_epilogue(dev, ksz, K, N, acc, B, H, W):
@@ -156,6 +156,41 @@ def test_dgrad_affine2_mask_epilogue(dev, ksz, K, N, acc, B, H, W):
     assert torch.equal(to_nchw(oldb[..., N:]), old[:, N:]), "wrote outside the slice"
     close(s1.cpu(), S1, rel=2e-3, what="S1")
     close(s2.cpu(), S2, rel=2e-3, what="S2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pro,acc", [(2, True), (0, False)])
+def test_dgrad_1x1_many_tiles_replicated_stats(dev, pro, acc):
+    """The dZ-resident 1x1 input-gradient kernel with several N tiles per workgroup (grid large enough for 4), a partial
+    last tile, a pixel count that is not a multiple of 128 and statistics spread over 4 replicas."""
+    from chexpert_amd import ops
+    B, H, W, K, N, R = 8, 127, 129, 128, 264, 4
+    ub, u = nhwc_buf(70, B, H, W, K, dev)
+    vb, v = nhwc_buf(71, B, H, W, K, dev)
+    exb, ex = nhwc_buf(72, B, H, W, N, dev)
+    oldb, old = nhwc_buf(73, B, H, W, N, dev)
+    w = bf(rnd(74, (K, N, 1, 1), -0.1, 0.1))
+    pa, pb, pc = rnd(75, (K,), 0.5, 1.5), rnd(76, (K,), -0.3, 0.3), rnd(77, (K,), -0.2, 0.2)
+    e_sc, e_sh = rnd(78, (N,), -0.3, 1.5), rnd(79, (N,), -0.5, 0.5)
+    e_mu, e_r, e_scale = rnd(80, (N,), -0.5, 0.5), rnd(81, (N,), 0.5, 2.0), rnd(82, (N,), -0.3, 1.5)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    dy = bf(u * cv(pa) + v * cv(pb) + cv(pc)) if pro == 2 else u
+    acc_ref = F.conv_transpose2d(dy, w)
+    mask = (ex * cv(e_sc) + cv(e_sh)) > 0
+    dz = torch.where(mask, acc_ref, torch.zeros(()))
+    want = cv(e_scale) * dz + (old if acc else 0)
+    S1 = dz.double().sum((0, 2, 3)).float()
+    S2 = (dz * (ex - cv(e_mu)) * cv(e_r)).double().sum((0, 2, 3)).float()
+    st = torch.zeros(2, R, N + 8, device=dev)
+    kw = dict(prologue=ops.PRO_AFFINE2, x2=vb, pa=pa.to(dev), pb=pb.to(dev), pc=pc.to(dev)) if pro == 2 else {}
+    ops.conv_gemm(ub, ops.pack_weights(w.to(dev), transpose=True), oldb, N=N, epilogue=ops.EPI_MASK, ex=exb, e_sc=e_sc.to(dev),
+                  e_sh=e_sh.to(dev), e_mu=e_mu.to(dev), e_r=e_r.to(dev), e_scale=e_scale.to(dev), stat_sum=st[0], stat_sq=st[1],
+                  accumulate=acc, stat_replicas=R, stat_rstride=N + 8, **kw)
+    close(to_nchw(oldb), want, rel=8e-3, what="g")
+    assert (st[:, :, :N].abs().sum(2) > 0).all(), "a replica received no statistics"
+    assert float(st[:, :, N:].abs().sum()) == 0.0
+    close(st[0].sum(0)[:N].cpu(), S1, rel=2e-3, what="S1")
+    close(st[1].sum(0)[:N].cpu(), S2, rel=2e-3, what="S2")
 
 
 # ------------------------------------------------------------------------------------------------ wgrad
@@ -374,3 +409,22 @@ def test_fused_optimisers_match_torch_optim(dev, kind):
         else:
             ops.rmsprop_step(p, gd, st[0], st[1], 1e-2, 0.99, 1e-3, 0.9, 0.0)
     close(p.cpu(), pc.detach(), rel=2e-6, what=kind)
+
+
+@pytest.mark.gpu
+def test_wgrad_stem_affine2_odd_pixel_count(dev):
+    """Stem weight gradient with the two-tensor BN-backward form of dY (conv0 under norm0) and a pixel count that is not a
+    multiple of the 32-pixel step (partial last step, splits > 1)."""
+    from chexpert_amd import ops
+    B, Hs, Ws = 3, 20, 28                                  # 3*10*14 = 420 output pixels
+    xs = bf(rnd(64, (B, 3, Hs, Ws), -2, 2))
+    ub, u = nhwc_buf(65, B, Hs // 2, Ws // 2, 64, dev)
+    vb, v = nhwc_buf(66, B, Hs // 2, Ws // 2, 64, dev)
+    ga, gb_, gc = rnd(67, (64,), 0.5, 1.5), rnd(68, (64,), -0.5, 0.5), rnd(69, (64,), -0.2, 0.2)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    gs = bf(u * cv(ga) + v * cv(gb_) + cv(gc))
+    want = torch.nn.grad.conv2d_weight(xs, (64, 3, 7, 7), gs, stride=2, padding=3)
+    dw = torch.zeros(64, 3, 7, 7, device=dev)
+    ops.conv_wgrad(ub, ops.nchw3_to_nhwc4(xs.to(dev)), dw, mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=vb, ga=ga.to(dev),
+                   gb=gb_.to(dev), gc=gc.to(dev), splits=5)
+    close(dw.cpu(), want, rel=2e-3, what="dW stem affine2")
