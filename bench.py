@@ -52,6 +52,9 @@ class KernelTimer:
                 return "conv3x3_strip_dgrad_kernel"
         if mode == 0 and kh == 1 and epi == 1 and K == 128 and pro in (0, 2) and kw.get("stride", 1) == 1:
             return "pw_dgrad_kernel<%d, %s>" % (pro, "true" if kw.get("accumulate") else "false")
+        if mode == 0 and kh == 1 and epi == 0 and N == 128 and K <= 256 and K % 32 == 0 and pro in (0, 1) and \
+                kw.get("stride", 1) == 1 and not kw.get("accumulate"):
+            return "pw_fwd_kernel<%d>" % pro
         bn = 128 if N % 128 == 0 else (32 if N == 32 else 64)
         return "conv_gemm_kernel<%d, %d, %d, %d>" % (bn, pro, mode, epi)
 

@@ -1,0 +1,269 @@
+// Forward of the dense-layer bottleneck 1x1 convolution: Y[m][0:128] = relu(X[m][0:K]*scale + shift) . W^T  (+ channel sums).
+//
+// The generic implicit-GEMM kernel spends most of a K <= 256 launch outside its K loop: a workgroup lives for 2-8 K steps,
+// pays one exposed HBM round trip to start, six barriers to transpose its tile through LDS and the statistics atomics.
+// This kernel is persistent and has no barrier on the streaming path:
+//   * MFMA operands are swapped (A = weights, B = activations).  The B fragment of mfma_f32_32x32x16_bf16 is "lane = pixel,
+//     8 consecutive k", i.e. 16 contiguous bytes of an NHWC row: the activations go global -> registers -> (BN + ReLU in
+//     registers) -> MFMA, never through LDS.  K is walked in blocks of 64 channels in a lane-private order (lane half h owns
+//     channels 64t+32h..+31, 64 contiguous bytes; the weights are read from LDS in the same order), so a pixel row is fetched
+//     in full 128-B lines.
+//   * the loads of work item (tile, K block) i+1 are issued before the MFMAs of item i, across tile boundaries: a workgroup
+//     keeps ~16 KB in flight the whole time, two workgroups per CU.
+//   * the weights (128 x K bf16, <= 64 KB for K <= 256) are staged in LDS once per workgroup; for K > 256 they are restaged
+//     per tile in 256-channel chunks (two barriers per chunk).
+//   * an accumulator lane owns one pixel and, after v_permlane32_swap, 8 consecutive channels: 16-B stores straight from
+//     registers; per-lane channel sums live in registers for the whole workgroup and are reduced once at the end.
+#include "common.h"
+
+namespace {
+
+constexpr int NO = 128;                 // output channels (bn_size * growth_rate)
+constexpr int BM = 128;                 // pixels per tile
+constexpr int KB = 64;                  // channels per K block
+constexpr int KC_MAX = 256;             // channels of weights resident in LDS
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_sum(float v) {      // sum over the 32 lanes of each wave half
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  return v + __shfl_xor(v, 16);
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void pw_fwd_kernel(const CxConv p, const int M, const int m_tiles, const int nkb,
+                                                       const int kc, const int wpitch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);                  // [2][nkb*64], zero beyond K
+  char* Wt = smem + 2 * nkb * KB * 4;                            // [128][wpitch]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int G = gridDim.x;
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const bf16* __restrict__ Wp = reinterpret_cast<const bf16*>(p.w);
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+  const bool resident = p.K <= KC_MAX;
+
+  if (PRO == CX_PRO_AFFINE_RELU) {
+    for (int i = tid; i < nkb * KB; i += 256) {
+      coef[i] = i < p.K ? p.pa[i] : 0.f;
+      coef[nkb * KB + i] = i < p.K ? p.pb[i] : 0.f;
+    }
+  }
+  // weights of channels [k0, k0 + kc) -> LDS (zero beyond K), 16-B chunks, consecutive threads along k
+  auto stage_w = [&](int k0) {
+    const int cpr = kc >> 3;                     // chunks per row
+    const int total = NO * cpr;
+    for (int base = 0; base < total; base += 1024) {
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ci = base + u * 256 + tid;
+        const int cc = ci < total ? ci : 0;
+        const int n = cc / cpr, kq = cc - n * cpr;
+        const int k = k0 + kq * 8;
+        r[u] = *reinterpret_cast<const uint4*>(Wp + (size_t)n * p.K + (k < p.K ? k : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ci = base + u * 256 + tid;
+        if (ci < total) {
+          const int n = ci / cpr, kq = ci - n * cpr;
+          *reinterpret_cast<uint4*>(Wt + n * wpitch + kq * 16) = (k0 + kq * 8 < p.K) ? r[u] : make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+  };
+  if (resident) stage_w(0);
+
+  const int my_tiles = (m_tiles - (int)blockIdx.x + G - 1) / G;       // >= 1 (grid <= m_tiles)
+  const int n_items = my_tiles * nkb;
+
+  // activation fragments of one work item: 2 pixel sub-tiles x 4 uint4 (channels kb*64 + 32*lh + 8u .. +7)
+  auto load_x = [&](uint4 (&xr)[2][4], int item) {
+    const int it = item < n_items ? item : n_items - 1;               // clamped: loads are unconditional
+    const int tl = it / nkb, kb = it - tl * nkb;
+    const int mt = blockIdx.x + tl * G;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mt * BM + (wm * 2 + i) * 32 + lrow;
+      const int mc = m < M ? m : M - 1;
+      const bf16* row = X + (size_t)mc * p.ldx;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = kb * KB + 32 * lh + 8 * u;
+        xr[i][u] = *reinterpret_cast<const uint4*>(row + (c < p.K ? c : 0));
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float s1[2][2][8], s2[2][2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[j][cc][e] = s2[j][cc][e] = 0.f;
+  const bool want_stats = p.stat_sum != nullptr;
+
+  auto compute = [&](uint4 (&xr)[2][4], int item) {
+    const int tl = item / nkb, kb = item - tl * nkb;
+    if (!resident && (kb & 3) == 0) {
+      __syncthreads();                          // every wave is done with the previous chunk
+      stage_w(kb * KB);
+      __syncthreads();
+    }
+    const int kl = resident ? kb : (kb & 3);    // K block inside the LDS chunk
+    const char* Wb = Wt + (wn * 64 + lrow) * wpitch + kl * 128 + lh * 64;
+    const float* csc = coef + kb * KB + 32 * lh;
+    const float* csh = csc + nkb * KB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bf16x8 xf[2];
+      if (PRO == CX_PRO_AFFINE_RELU) {
+        const float4 a0 = *reinterpret_cast<const float4*>(csc + 8 * u), a1 = *reinterpret_cast<const float4*>(csc + 8 * u + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(csh + 8 * u), b1 = *reinterpret_cast<const float4*>(csh + 8 * u + 4);
+        const float sc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          U128 v, o;
+          v.u = xr[i][u];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.e[e] = f2bf(fmaxf(fmaf(bf2f(v.e[e]), sc[e], sh[e]), 0.f));
+          xf[i] = o.h;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          U128 v;
+          v.u = xr[i][u];
+          xf[i] = v.h;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wb + j * 32 * wpitch + u * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kb == nkb - 1) {                        // tile finished: store it, fold its channel sums, clear the accumulators
+      const int mt = blockIdx.x + tl * G;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = mt * BM + (wm * 2 + i) * 32 + lrow;
+        const bool mv = m < M;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            // registers 8cc..8cc+3 / 8cc+4..8cc+7 of this lane: channels 16cc + 4*lh + e / 16cc + 8 + 4*lh + e; after the
+            // swap of the upper half of the first group with the lower half of the second: channels 8*(2cc+lh) .. +7
+            U128 o;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * cc + r4]),
+                                                               __float_as_uint(acc[i][j][8 * cc + 4 + r4]), false, false);
+              o.e[r4] = f2bf(__uint_as_float(sw[0]));
+              o.e[4 + r4] = f2bf(__uint_as_float(sw[1]));
+            }
+            if (want_stats) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float rv = mv ? bf2f(o.e[e]) : 0.f;
+                s1[j][cc][e] += rv;
+                s2[j][cc][e] += rv * rv;
+              }
+            }
+            if (mv) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + (wn * 2 + j) * 32 + 8 * (2 * cc + lh)) = o.u;
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+  };
+
+  uint4 xa[2][4], xb[2][4];
+  load_x(xa, 0);
+  __syncthreads();                               // coefficient table (and resident weights) visible
+  for (int it = 0; it < n_items; it += 2) {
+    load_x(xb, it + 1);
+    compute(xa, it);
+    load_x(xa, it + 2);
+    if (it + 1 < n_items) compute(xb, it + 1);
+  }
+
+  if (want_stats) {
+    const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = half_sum(s1[j][cc][e]);
+          const float b = half_sum(s2[j][cc][e]);
+          if (lrow == 8 * cc + e) { t1 = a; t2 = b; }
+        }
+      if (lrow < 16) {
+        const int n = (wn * 2 + j) * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
+        atomicAdd(&p.stat_sum[rep + n], t1);
+        atomicAdd(&p.stat_sq[rep + n], t2);
+      }
+    }
+  }
+}
+
+template <int PRO>
+int launch_fwd(const CxConv& p, hipStream_t st) {
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + BM - 1) / BM);
+  const int nkb = (p.K + KB - 1) / KB;
+  const int kc = p.K <= KC_MAX ? nkb * KB : KC_MAX;
+  const int wpitch = kc * 2 + 16;
+  const size_t smem = (size_t)2 * nkb * KB * 4 + (size_t)NO * wpitch;
+  int grid = m_tiles < 512 ? m_tiles : 512;            // two workgroups per CU, each walks m_tiles / grid tiles
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_fwd_kernel<PRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
+    attr_set = true;
+  }
+  if (smem > 80 * 1024) return CX_ESHAPE;
+  hipLaunchKernelGGL((pw_fwd_kernel<PRO>), dim3(grid), dim3(256), smem, st, p, (int)M, m_tiles, nkb, kc, wpitch);
+  return launch_status();
+}
+
+}  // namespace
+
+// Called by cx_conv_gemm after its argument validation; *handled = false leaves the call to the generic kernel.
+int cx_try_pw_fwd(const CxConv& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (p.mode != CX_MODE_CONV || p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0 || p.tstride > 1) return 0;
+  // K > 256 would restage the weights per tile (two barriers per 256-channel chunk, measured slower than the generic
+  // kernel's one-barrier K loop): those layers stay on conv_gemm_kernel
+  if (p.epilogue != CX_EPI_STORE || p.accumulate || p.N != NO || (p.K % 32) || p.K > KC_MAX) return 0;
+  if (p.prologue != CX_PRO_AFFINE_RELU && p.prologue != CX_PRO_NONE) return 0;
+  *handled = true;
+  return p.prologue == CX_PRO_AFFINE_RELU ? launch_fwd<CX_PRO_AFFINE_RELU>(p, st) : launch_fwd<CX_PRO_NONE>(p, st);
+}

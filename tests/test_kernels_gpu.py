@@ -47,7 +47,7 @@ def close(got, want, rel=6e-3, what=""):
 
 # ------------------------------------------------------------------------------------------------ conv forward
 @pytest.mark.parametrize("B,H,W,Ctot,K,N", [(2, 9, 11, 160, 96, 128), (1, 16, 16, 64, 64, 128), (3, 5, 7, 256, 224, 96),
-                                             (2, 6, 6, 1024, 1024, 128)])
+                                             (2, 6, 6, 1024, 1024, 128), (2, 9, 11, 352, 320, 128), (1, 3, 5, 32, 32, 128)])
 def test_conv1x1_bnrelu_store_stats(dev, B, H, W, Ctot, K, N):
     from chexpert_amd import ops
     xb, x = nhwc_buf(1, B, H, W, Ctot, dev)
@@ -64,6 +64,31 @@ def test_conv1x1_bnrelu_store_stats(dev, B, H, W, Ctot, K, N):
     assert (y[..., N:].float() == 7.0).all(), "wrote outside the channel slice"
     close(ssum.cpu(), got.sum((0, 2, 3)), rel=1e-4, what="sum")
     close(ssq.cpu(), (got * got).sum((0, 2, 3)), rel=1e-4, what="sumsq")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pro,K", [(1, 96), (0, 160), (1, 288)])
+def test_conv1x1_persistent_many_tiles(dev, pro, K):
+    """Bottleneck 1x1 forward (persistent kernel): more 128-pixel tiles than workgroups, a pixel count that is not a multiple
+    of 128, a partial last K block, statistics spread over replicas; K = 288 restages the weights per tile."""
+    from chexpert_amd import ops
+    B, H, W, N, R = 6, 101, 127, 128, 4                   # 76 962 pixels = 602 tiles > 512 workgroups
+    xb, x = nhwc_buf(90, B, H, W, K + 32, dev)
+    w = bf(rnd(91, (N, K, 1, 1), -0.2, 0.2))
+    pa, pb = rnd(92, (K,), -0.3, 1.5), rnd(93, (K,), -0.5, 0.5)
+    a = bf(F.relu(x[:, :K] * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1))) if pro else x[:, :K]
+    want = F.conv2d(a, w)
+    y = torch.full((B, H, W, N + 8), 7.0, dtype=torch.bfloat16, device=dev)
+    st = torch.zeros(2, R, N, device=dev)
+    kw = dict(prologue=ops.PRO_AFFINE_RELU, pa=pa.to(dev), pb=pb.to(dev)) if pro else {}
+    ops.conv_gemm(xb[..., :K], ops.pack_weights(w.to(dev)), y[..., :N], N=N, stat_sum=st[0], stat_sq=st[1], stat_replicas=R,
+                  stat_rstride=N, **kw)
+    got = to_nchw(y[..., :N])
+    close(got, want, what="y")
+    assert (y[..., N:].float() == 7.0).all(), "wrote outside the channel slice"
+    assert (st.abs().sum(2) > 0).all(), "a replica received no statistics"
+    close(st[0].sum(0).cpu(), got.double().sum((0, 2, 3)).float(), rel=1e-4, what="sum")
+    close(st[1].sum(0).cpu(), (got.double() ** 2).sum((0, 2, 3)).float(), rel=1e-4, what="sumsq")
 
 
 @pytest.mark.parametrize("B,H,W,K,N,stride,pro", [(2, 10, 12, 128, 32, 1, 1), (1, 7, 9, 128, 32, 1, 1), (2, 12, 12, 64, 64, 2, 0),
