@@ -47,7 +47,7 @@ class KernelTimer:
         K = kw.get("K") or x.shape[3]
         if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and kw.get("tstride", 1) == 1:
             if (pro, epi, K, N) == (1, 0, 128, 32):
-                return "conv3x3_strip_fwd_kernel"
+                return "conv3x3_ring_fwd_kernel"
             if (pro, epi, K, N) == (2, 1, 32, 128):
                 return "conv3x3_strip_dgrad_kernel"
         if mode == 0 and kh == 1 and epi == 1 and K == 128 and pro in (0, 2) and kw.get("stride", 1) == 1:

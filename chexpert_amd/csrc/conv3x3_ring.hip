@@ -1,0 +1,284 @@
+// 3x3 stride-1 pad-1 forward of the dense layers (K = 128 -> N = 32), second generation: one 512-thread workgroup per CU,
+// the nine 32x128 weight slices AND the input-row ring both live in LDS, every wave computes whole 32-pixel sub-tiles.
+//
+// The first strip kernel (conv3x3_strip.hip) gave each of three waves one kernel row and met the partial sums in LDS:
+// 24 MFMAs, then two barriers and a 128-thread reduction per sub-tile -- the matrix pipe idled two thirds of the time
+// (1.46 TB/s on 80x80 maps).  Here a sub-tile is 72 back-to-back MFMAs of one wave, no cross-wave reduction:
+//   * operands swapped (A = weight slice [32 out][16 k], B = ring pixels [16 k][32 px]): both fragments are one
+//     conflict-free ds_read_b128 (272-B pitches); an accumulator lane owns one pixel and, after v_permlane32_swap,
+//     8 consecutive output channels -> two 16-B stores per lane, no LDS transposition, no scratch;
+//   * per-lane channel sums stay in registers for the whole workgroup (N = 32: 32 registers), reduced once at the end;
+//   * ring layout as before: padded-flat rows of W+2 pixels with zero pad columns, tap (dy,dx) of flat pixel m is ring
+//     pixel m + dy*(W+2) + dx, two mirror pixels past the end cover the wrap;
+//   * the R new rows of the next step are requested before the MFMAs of the current one (<= 7 x 16 B per thread) and are
+//     normalised (BN + ReLU) while they are written to the ring; two barriers per step.
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+constexpr int XP = 272;                  // bytes per ring pixel / weight row: 128 bf16 + 16 pad
+constexpr int NT = 512;                  // threads
+constexpr int W_ROWS = 9 * 32;
+constexpr int W_BYTES = W_ROWS * XP;
+constexpr int RING_PX_MAX = (160 * 1024 - W_BYTES - 1024 - 256) / XP;     // 309
+
+struct RingGeo {
+  int B, H, W, P, R, Q;         // P = W+2, Q = (R+2)*P ring pixels
+  int spi;                      // steps per image = ceil(H/R)
+  int steps_per_wg;
+};
+
+__device__ __forceinline__ int wrapq(int v, int q) { return v >= q ? v - q : v; }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_sum(float v) {      // sum over the 32 lanes of each wave half
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  return v + __shfl_xor(v, 16);
+}
+
+template <int NCH, int DEPTH>
+__global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __restrict__ x, int ldx, const float* __restrict__ sc,
+                                                                const float* __restrict__ sh, const bf16* __restrict__ wpk,
+                                                                bf16* __restrict__ y, int ldy, float* stat_sum, float* stat_sq,
+                                                                int stat_replicas, int stat_rstride, const RingGeo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);                // [2][128]
+  char* wl = smem + 1024 + 256;                                // [9*32][272 B]
+  char* ring = wl + W_BYTES;                                   // [(Q+2)][272 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
+
+  // ---- one-time setup: weights [tap][n][k] -> LDS rows of 272 B, ring zeroed (pad columns stay zero), coefficients
+  for (int i = tid; i < W_ROWS * 16; i += NT) {
+    const int row = i >> 4, c = i & 15;
+    *reinterpret_cast<uint4*>(wl + row * XP + c * 16) = *reinterpret_cast<const uint4*>(wpk + (size_t)row * 128 + c * 8);
+  }
+  for (int i = tid; i < (Q + 2) * (XP / 16); i += NT) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  const int total_steps = g.B * g.spi;
+  const int u0 = blockIdx.x * g.steps_per_wg;
+  const int u1 = min(total_steps, u0 + g.steps_per_wg);
+  const int chunks_per_row = W * 16;
+
+  // DEPTH register sets of new rows: the rows of steps u+1 .. u+DEPTH are in flight while step u is multiplied (at W = 80 a
+  // step is one image row and shorter than an HBM round trip under load)
+  uint4 pre[DEPTH][NCH];
+  bool pv[DEPTH][NCH];
+  int base_row = 0;           // image row held by ring slot 0: slot(y) = (y - base_row) mod (R+2)
+  // chunk slot i of this thread: chunk id tid + NT*i -> (row inside the group of new rows, pixel, 16-B channel chunk).  NT and
+  // 16*W are multiples of 16, so the channel chunk is tid & 15 for every slot: its BN scale/shift stay in registers
+  int crow[NCH], cpx[NCH];
+  const int cc8 = tid & 15;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int cid = tid + NT * i;
+    crow[i] = cid / chunks_per_row;
+    cpx[i] = (cid - crow[i] * chunks_per_row) >> 4;
+  }
+  float csc[8], csh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { csc[j] = sc[cc8 * 8 + j]; csh[j] = sh[cc8 * 8 + j]; }
+  // rows [y0, y0+n) of image b -> registers; unconditional loads on clamped addresses, validity applied when staged
+  auto issue_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int b, int y0, int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int yy = y0 + crow[i];
+      pv[i] = crow[i] < n && yy >= 0 && yy < H;
+      const int yc_ = min(max(yy, 0), H - 1);
+      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + cpx[i]) * ldx + cc8 * 8);
+    }
+  };
+  auto write_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int y0, int n) __attribute__((always_inline)) {
+    int slot_y0 = (y0 - base_row) % (R + 2);          // wave-uniform
+    if (slot_y0 < 0) slot_y0 += R + 2;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (crow[i] < n) {
+        int slot = slot_y0 + crow[i];                   // crow <= R: one conditional subtract wraps it
+        if (slot >= R + 2) slot -= R + 2;
+        U128 o, v;
+        v.u = pre[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(pv[i] ? fmaxf(fmaf(bf2f(v.e[j]), csc[j], csh[j]), 0.f) : 0.f);
+        const int pos = slot * P + cpx[i] + 1;
+        *reinterpret_cast<uint4*>(ring + (size_t)pos * XP + cc8 * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * XP + cc8 * 16) = o.u;   // mirror of pixels 0,1
+      }
+    }
+  };
+  // new rows of step v (a continuation step of its image inside this workgroup's range), else a harmless clamped load
+  auto issue_step = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int v) __attribute__((always_inline)) {
+    const int bv = v / g.spi, sv = v - bv * g.spi;
+    const bool ok = v < u1 && sv != 0;
+    issue_rows(pre, pv, ok ? bv : 0, ok ? sv * R + 1 : 0, ok ? R : 0);
+  };
+
+  float s1[2][8], s2[2][8];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[cc][j] = s2[cc][j] = 0.f;
+  const int nsub = (R * P + 31) / 32;
+  const char* wbase = wl + lrow * XP + lh * 16;
+
+  auto step = [&](int u, auto KI) __attribute__((always_inline)) {
+    constexpr int k = decltype(KI)::value;
+    uint4 (&cur)[NCH] = pre[k];
+    bool (&cv)[NCH] = pv[k];
+    const int b = u / g.spi, yc = (u - b * g.spi) * R;
+    if (u == u0 || yc == 0) {
+      // first step of an image (or of this workgroup): build the window rows yc-1, yc synchronously, refill the pipeline
+      base_row = yc - 1;
+      issue_rows(cur, cv, b, yc - 1, 1);
+      write_rows(cur, cv, yc - 1, 1);
+      issue_rows(cur, cv, b, yc, 1);
+      write_rows(cur, cv, yc, 1);
+      issue_rows(cur, cv, b, yc + 1, R);
+#pragma unroll
+      for (int d = 1; d < DEPTH; ++d) issue_step(pre[(k + d) % DEPTH], pv[(k + d) % DEPTH], u + d);
+    }
+    write_rows(cur, cv, yc + 1, R);
+    __syncthreads();                                   // the window of this step is complete
+    issue_step(cur, cv, u + DEPTH);                    // in flight under the MFMAs of this and the next DEPTH-1 steps
+    int slot0 = (yc - 1 - base_row) % (R + 2);
+    if (slot0 < 0) slot0 += R + 2;
+    const int ws = slot0 * P;
+
+    for (int s = wave; s < nsub; s += NT / 64) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int m = s * 32 + lrow;
+      const int pix = min(m, R * P - 1);
+      // one tap per iteration (16 fragment reads, 8 MFMAs): unrolling all 72 lets the scheduler hoist every read and spill
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy) {
+        const char* ap = ring + (size_t)wrapq(wrapq(ws + pix + dy * P, Q), Q) * XP + lh * 16;
+#pragma unroll 1
+        for (int dx = 0; dx < 3; ++dx) {
+          const char* wp = wbase + (dy * 3 + dx) * 32 * XP;
+          // all 16 fragments of the tap first, then its 8 MFMAs: read-then-multiply pairs expose the LDS latency once per
+          // MFMA (measured 130 cycles per MFMA with one computing wave per SIMD)
+          bf16x8 fa[8], fb[8];
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            fa[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 32);
+            fb[ks] = *reinterpret_cast<const bf16x8*>(ap + dx * XP + ks * 32);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], acc, 0, 0, 0);     // D[row = out channel][col = pixel]
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      const int oy = m / P, ox = m - oy * P;
+      const int yy = yc + oy;
+      const bool valid = m < R * P && ox < W && yy < H;
+      bf16* yrow = y + ((size_t)(b * H + (valid ? yy : 0)) * W + (valid ? ox : 0)) * ldy;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        // registers 8cc..8cc+3 / 8cc+4..8cc+7: channels 16cc + 4*lh + e / 16cc + 8 + 4*lh + e; the swap of the upper half of
+        // the first group with the lower half of the second leaves channels 8*(2cc+lh) .. +7 of this lane's pixel
+        U128 o;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * cc + r4]), __float_as_uint(acc[8 * cc + 4 + r4]),
+                                                           false, false);
+          o.e[r4] = f2bf(__uint_as_float(sw[0]));
+          o.e[4 + r4] = f2bf(__uint_as_float(sw[1]));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float rv = valid ? bf2f(o.e[j]) : 0.f;
+          s1[cc][j] += rv;
+          s2[cc][j] += rv * rv;
+        }
+        if (valid) *reinterpret_cast<uint4*>(yrow + 8 * (2 * cc + lh)) = o.u;
+      }
+    }
+    __syncthreads();                                   // every wave is done with the oldest rows of the ring
+  };
+
+  for (int u = u0; u < u1; u += DEPTH) {
+    step(u, std::integral_constant<int, 0>());
+    if (DEPTH > 1 && u + 1 < u1) step(u + 1, std::integral_constant<int, 1 % DEPTH>());
+    if (DEPTH > 2 && u + 2 < u1) step(u + 2, std::integral_constant<int, 2 % DEPTH>());
+  }
+
+  if (stat_sum) {
+    const size_t rep = stat_replicas > 1 ? (size_t)(blockIdx.x % stat_replicas) * stat_rstride : 0;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = half_sum(s1[cc][j]);
+        const float c = half_sum(s2[cc][j]);
+        if (lrow == 8 * cc + j) { t1 = a; t2 = c; }
+      }
+    if (lrow < 16) {
+      const int n = 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
+      atomicAdd(&stat_sum[rep + n], t1);
+      atomicAdd(&stat_sq[rep + n], t2);
+    }
+  }
+}
+
+template <int NCH, int DEPTH>
+int launch_ring(const CxConv& p, hipStream_t st, const RingGeo& g) {
+  const size_t smem = 1024 + 256 + W_BYTES + (size_t)(g.Q + 2) * XP;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_fwd_kernel<NCH, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr = true;
+  }
+  const int total = g.B * g.spi;
+  const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  hipLaunchKernelGGL((conv3x3_ring_fwd_kernel<NCH, DEPTH>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, p.pa, p.pb,
+                     (const bf16*)p.w, (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, g);
+  return launch_status();
+}
+
+}  // namespace
+
+// Eligibility + launch, called from cx_conv_gemm ahead of the first-generation strip kernel.
+int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1 || p.tstride > 1) return 0;
+  if (p.K != 128 || p.N != 32 || p.prologue != CX_PRO_AFFINE_RELU || p.epilogue != CX_EPI_STORE || p.accumulate) return 0;
+  if (p.W < 4) return 0;
+  RingGeo g;
+  g.B = p.B; g.H = p.H; g.W = p.W; g.P = p.W + 2;
+  int rmax = (RING_PX_MAX - 2) / g.P - 2;
+  if (rmax < 1) return 0;
+  if (rmax > p.H) rmax = p.H;
+  g.spi = (p.H + rmax - 1) / rmax;
+  g.R = (p.H + g.spi - 1) / g.spi;                   // balanced steps
+  // at most 7 chunks of new rows per thread
+  while (g.R > 1 && g.R * p.W * 16 > 7 * NT) --g.R;
+  if (g.R * p.W * 16 > 7 * NT) return 0;
+  g.spi = (p.H + g.R - 1) / g.R;
+  g.Q = (g.R + 2) * g.P;
+  const int total = g.B * g.spi;
+  // one workgroup per CU; ranges aligned to whole images when there are enough of them (no window rebuild inside an image)
+  int spw = (total + 255) / 256;
+  if (g.B >= 256) spw = ((g.B + 255) / 256) * g.spi;
+  if (spw < 1) spw = 1;
+  g.steps_per_wg = spw;
+  const int need = (g.R * p.W * 16 + NT - 1) / NT;
+  *handled = true;
+  if (need <= 3) return launch_ring<3, 3>(p, st, g);      // short steps (one 80-pixel row): three row groups in flight
+  if (need <= 5) return launch_ring<5, 2>(p, st, g);
+  return launch_ring<7, 1>(p, st, g);
+}

@@ -394,6 +394,7 @@ int launch_bn(const CxConv& p, hipStream_t st) {
 
 }  // namespace
 
+int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled);      // conv3x3_ring.hip
 int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled);     // conv3x3_strip.hip
 int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled);
 int cx_try_pw_dgrad(const CxConv& p, hipStream_t st, bool* handled);        // conv1x1_dgrad.hip
@@ -432,7 +433,9 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
     if (p.ldx < p.K) return CX_ESHAPE;
     {
       bool handled = false;
-      int rc = cx_try_strip_fwd(p, st, &handled);
+      int rc = cx_try_ring_fwd(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_strip_fwd(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_strip_dgrad(p, st, &handled);
       if (handled) return rc;

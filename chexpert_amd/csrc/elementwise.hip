@@ -89,13 +89,21 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, bf16* __restr
 __global__ void bn_coef_kernel(const float* sum, const float* sq, float count, const float* gamma, const float* beta,
                                float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
                                float* mean, float* rstd, int C, int replicas, int rstride) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // 16 lanes per channel: lane q sums replicas q, q+16, ...; xor-shuffles fold the 16 partial sums (all lanes stay active)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 4, q = gid & 15;
+  const int cc = c < C ? c : C - 1;
   double ts = 0.0, tq = 0.0;
-  for (int r = 0; r < replicas; ++r) {
-    ts += (double)sum[(size_t)r * rstride + c];
-    tq += (double)sq[(size_t)r * rstride + c];
+  for (int r = q; r < replicas; r += 16) {
+    ts += (double)sum[(size_t)r * rstride + cc];
+    tq += (double)sq[(size_t)r * rstride + cc];
   }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    ts += __shfl_xor(ts, d);
+    tq += __shfl_xor(tq, d);
+  }
+  if (c >= C || q != 0) return;
   const double m = ts / count;
   double v = tq / count - m * m;
   if (v < 0) v = 0;
@@ -125,13 +133,20 @@ __global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const
 __global__ void bn_bwd_coef_kernel(const float* S1, const float* S2, float count, const float* gamma, const float* mean,
                                    const float* rstd, float* dgamma, float* dbeta, float* A, float* Bc, float* pa,
                                    float* pb, float* pc, int C, int replicas, int rstride) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 4, q = gid & 15;              // 16 lanes per channel over the replicas, as in bn_coef_kernel
+  const int cc = c < C ? c : C - 1;
   float s1 = 0.f, s2 = 0.f;
-  for (int q = 0; q < replicas; ++q) {
-    s1 += S1[(size_t)q * rstride + c];
-    s2 += S2[(size_t)q * rstride + c];
+  for (int r = q; r < replicas; r += 16) {
+    s1 += S1[(size_t)r * rstride + cc];
+    s2 += S2[(size_t)r * rstride + cc];
   }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    s1 += __shfl_xor(s1, d);
+    s2 += __shfl_xor(s2, d);
+  }
+  if (c >= C || q != 0) return;
   const float g = gamma ? gamma[c] : 1.f, r = rstd[c], mu = mean[c];
   if (dgamma) dgamma[c] += s2;
   if (dbeta) dbeta[c] += s1;
@@ -682,7 +697,7 @@ int cx_bn_coef(const float* sum, const float* sq, float count, const float* gamm
   if (!sum || !sq || C <= 0 || count <= 0) return CX_EINVAL;
   if (replicas < 1) replicas = 1;
   if (replicas > 1 && rstride < C) return CX_EINVAL;
-  hipLaunchKernelGGL(bn_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sum, sq, count, gamma, beta, eps,
+  hipLaunchKernelGGL(bn_coef_kernel, dim3((C * 16 + 255) / 256), dim3(256), 0, as_stream(stream), sum, sq, count, gamma, beta, eps,
                      momentum, running_mean, running_var, scale, shift, mean, rstd, C, replicas, rstride);
   return launch_status();
 }
@@ -702,7 +717,7 @@ int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* g
   if (replicas < 1) replicas = 1;
   if (replicas > 1 && rstride < C) return CX_EINVAL;
   if (pa && (!pb || !pc)) return CX_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), S1, S2, count, gamma, mean,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C * 16 + 255) / 256), dim3(256), 0, as_stream(stream), S1, S2, count, gamma, mean,
                      rstd, dgamma, dbeta, A, Bc, pa, pb, pc, C, replicas, rstride);
   return launch_status();
 }
