@@ -49,7 +49,7 @@ class KernelTimer:
             if (pro, epi, K, N) == (1, 0, 128, 32):
                 return "conv3x3_ring_fwd_kernel"
             if (pro, epi, K, N) == (2, 1, 32, 128):
-                return "conv3x3_strip_dgrad_kernel"
+                return "conv3x3_ring_dgrad_kernel"
         if mode == 0 and kh == 1 and epi == 1 and K == 128 and pro in (0, 2) and kw.get("stride", 1) == 1:
             return "pw_dgrad_kernel<%d, %s>" % (pro, "true" if kw.get("accumulate") else "false")
         if mode == 0 and kh == 1 and epi == 0 and N == 128 and K <= 256 and K % 32 == 0 and pro in (0, 1) and \

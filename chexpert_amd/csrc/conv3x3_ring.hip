@@ -250,6 +250,264 @@ int launch_ring(const CxConv& p, hipStream_t st, const RingGeo& g) {
   return launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------ input gradient
+// dz2[m][0:128] = mask(y1[m]) * sum_taps dY2[m @ tap][0:32] . Wt[tap][0:128][0:32]     (K = 9 x 32, N = 128, CX_EPI_MASK)
+// Same ring design.  The ring holds the 32-channel gradient slice after the deferred BN correction (AFFINE2 of the gradient
+// and activation slices), 80 B per pixel, so a step covers up to 256 flat pixels = 8 sub-tiles; a work item is
+// (sub-tile, half of the 128 output channels) = 36 MFMAs, and wave w always takes channel half w & 1, so the 64 per-lane
+// S1/S2 accumulators keep one meaning for the whole workgroup.
+constexpr int GP = 80;                   // bytes per ring pixel / weight row: 32 bf16 + 16 pad (5 slots: conflict-free)
+constexpr int DW_ROWS = 9 * 128;
+constexpr int DW_BYTES = DW_ROWS * GP;
+constexpr int EC_BYTES = 5 * 128 * 4 + 3 * 32 * 4;   // epilogue vectors [5][128] + AFFINE2 vectors [3][32]
+constexpr int MAX_ITEMS = 2;             // work items per wave and step
+
+template <int NCH>
+__global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
+    const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
+    const float* __restrict__ gb, const float* __restrict__ gc, const bf16* __restrict__ wpk, const bf16* __restrict__ ex, int ldex,
+    const float* __restrict__ e_sc, const float* __restrict__ e_sh, const float* __restrict__ e_mu, const float* __restrict__ e_r,
+    const float* __restrict__ e_scale, bf16* __restrict__ y, int ldy, float* S1, float* S2, int stat_replicas, int stat_rstride,
+    const RingGeo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ecoef = reinterpret_cast<float*>(smem);               // e_sc, e_sh, e_mu, e_r, e_scale [128] each
+  char* wl = smem + EC_BYTES;                                  // [9*128][80 B]
+  char* ring = wl + DW_BYTES;                                  // [(Q+2)][80 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int h2 = wave & 1;                                     // this wave's half of the output channels
+  const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
+
+  for (int i = tid; i < DW_ROWS * 4; i += NT) {
+    const int row = i >> 2, c = i & 3;
+    *reinterpret_cast<uint4*>(wl + row * GP + c * 16) = *reinterpret_cast<const uint4*>(wpk + (size_t)row * 32 + c * 8);
+  }
+  for (int i = tid; i < (Q + 2) * (GP / 16); i += NT) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 128) {
+    ecoef[tid] = e_sc[tid]; ecoef[128 + tid] = e_sh[tid]; ecoef[256 + tid] = e_mu[tid]; ecoef[384 + tid] = e_r[tid];
+    ecoef[512 + tid] = e_scale[tid];
+  }
+  if (tid < 32) { ecoef[640 + tid] = ga[tid]; ecoef[672 + tid] = gb[tid]; ecoef[704 + tid] = gc[tid]; }
+  __syncthreads();
+
+  const int total_steps = g.B * g.spi;
+  const int u0 = blockIdx.x * g.steps_per_wg;
+  const int u1 = min(total_steps, u0 + g.steps_per_wg);
+  const int cpr = W * 4;
+
+  // new gradient rows: chunk slot i of this thread = chunk id tid + NT*i -> (row, pixel); the channel chunk is tid & 3 for
+  // every slot (NT and 4*W are multiples of 4), so its AFFINE2 coefficients stay in registers
+  uint4 pg[NCH], pg2[NCH];
+  bool gv[NCH];
+  int base_row = 0;
+  int crow[NCH], cpx[NCH];
+  const int cc4 = tid & 3;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int cid = tid + NT * i;
+    crow[i] = cid / cpr;
+    cpx[i] = (cid - crow[i] * cpr) >> 2;
+  }
+  const float* kco = ecoef + 640 + cc4 * 8;          // ga | gb | gc of this thread's channel chunk (LDS)
+
+  auto issue_rows = [&](int b, int y0, int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int yy = y0 + crow[i];
+      gv[i] = crow[i] < n && yy >= 0 && yy < H;
+      const int yc_ = min(max(yy, 0), H - 1);
+      const size_t pixel = (size_t)(b * H + yc_) * W + cpx[i];
+      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + cc4 * 8);
+      pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + cc4 * 8);
+    }
+  };
+  auto write_rows = [&](int y0, int n) __attribute__((always_inline)) {
+    int slot_y0 = (y0 - base_row) % (R + 2);
+    if (slot_y0 < 0) slot_y0 += R + 2;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (crow[i] < n) {
+        int slot = slot_y0 + crow[i];
+        if (slot >= R + 2) slot -= R + 2;
+        U128 o, u, v;
+        u.u = pg[i];
+        v.u = pg2[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o.e[j] = f2bf(gv[i] ? fmaf(bf2f(u.e[j]), kco[j], fmaf(bf2f(v.e[j]), kco[32 + j], kco[64 + j])) : 0.f);
+        const int pos = slot * P + cpx[i] + 1;
+        *reinterpret_cast<uint4*>(ring + (size_t)pos * GP + cc4 * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * GP + cc4 * 16) = o.u;
+      }
+    }
+  };
+
+  float s1[2][2][8], s2[2][2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[j][cc][e] = s2[j][cc][e] = 0.f;
+  const int nsub = (R * P + 31) / 32;                 // <= 4 * MAX_ITEMS
+  const char* wbase = wl + (size_t)(h2 * 64 + lrow) * GP + lh * 16;
+
+  for (int u = u0; u < u1; ++u) {
+    const int b = u / g.spi, yc = (u - b * g.spi) * R;
+    if (u == u0 || yc == 0) {
+      base_row = yc - 1;
+      issue_rows(b, yc - 1, 1);
+      write_rows(yc - 1, 1);
+      issue_rows(b, yc, 1);
+      write_rows(yc, 1);
+      issue_rows(b, yc + 1, R);
+    }
+    write_rows(yc + 1, R);
+    __syncthreads();                                   // the window of this step is complete
+    const bool next_cont = (u + 1 < u1) && ((u + 1) / g.spi == b);
+    if (next_cont) issue_rows(b, yc + R + 1, R);
+    int slot0 = (yc - 1 - base_row) % (R + 2);
+    if (slot0 < 0) slot0 += R + 2;
+    const int ws = slot0 * P;
+
+#pragma unroll 1
+    for (int t = 0; t < MAX_ITEMS; ++t) {
+      const int s = (wave >> 1) + 4 * t;
+      if (s < nsub) {
+        // mask source of this item (256 B per pixel, the bulk of the traffic): requested ahead of the item's 36 MFMAs, 16 B
+        // per lane in the accumulator's own lane = pixel layout
+        U128 xv[2][2];
+        const int m = s * 32 + lrow;
+        const int oy = m / P, ox = m - oy * P;
+        const int yy = yc + oy;
+        const bool pok = m < R * P && ox < W && yy < H;
+        const int poff = (b * H + min(yy, H - 1)) * W + min(ox, W - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+            xv[j][cc].u = *reinterpret_cast<const uint4*>(ex + (size_t)poff * ldex + (2 * h2 + j) * 32 + 8 * (2 * cc + lh));
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const int pix = min(s * 32 + lrow, R * P - 1);
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+          const char* ap = ring + (size_t)wrapq(wrapq(ws + pix + dy * P, Q), Q) * GP + lh * 16;
+          const char* wp = wbase + (size_t)(dy * 3) * 128 * GP;
+          // one tap per iteration: 2 pixel fragments + 4 weight fragments, 4 MFMAs (the second wave of the SIMD fills the gaps)
+#pragma unroll 1
+          for (int dx = 0; dx < 3; ++dx) {
+            bf16x8 fb[2], fa[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              fb[ks] = *reinterpret_cast<const bf16x8*>(ap + dx * GP + ks * 32);
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                fa[ks][j] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(dx * 128 + j * 32) * GP + ks * 32);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][j], fb[ks], acc[j], 0, 0, 0);   // D[channel][pixel]
+          }
+        }
+        bf16* yrow = y + (size_t)poff * ldy;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const int n = (2 * h2 + j) * 32 + 8 * (2 * cc + lh);
+            float v[8];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][8 * cc + r4]),
+                                                               __float_as_uint(acc[j][8 * cc + 4 + r4]), false, false);
+              v[r4] = __uint_as_float(sw[0]);
+              v[4 + r4] = __uint_as_float(sw[1]);
+            }
+            // phased so that only two coefficient vectors are live at a time (the compiler otherwise hoists all 160 values)
+            float xf[8], dz[8];
+            {
+              asm volatile("" ::: "memory");
+              const float4 a0 = *reinterpret_cast<const float4*>(ecoef + n), a1 = *reinterpret_cast<const float4*>(ecoef + n + 4);
+              const float4 b0 = *reinterpret_cast<const float4*>(ecoef + 128 + n), b1 = *reinterpret_cast<const float4*>(ecoef + 128 + n + 4);
+              const float esc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+              const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                xf[e] = bf2f(xv[j][cc].e[e]);
+                dz[e] = (pok && fmaf(xf[e], esc[e], esh[e]) > 0.f) ? v[e] : 0.f;
+                s1[j][cc][e] += dz[e];
+              }
+            }
+            {
+              asm volatile("" ::: "memory");
+              const float4 c0 = *reinterpret_cast<const float4*>(ecoef + 256 + n), c1 = *reinterpret_cast<const float4*>(ecoef + 256 + n + 4);
+              const float4 d0 = *reinterpret_cast<const float4*>(ecoef + 384 + n), d1 = *reinterpret_cast<const float4*>(ecoef + 384 + n + 4);
+              const float emu[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+              const float er[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) s2[j][cc][e] += dz[e] * (xf[e] - emu[e]) * er[e];
+            }
+            U128 o;
+            {
+              asm volatile("" ::: "memory");
+              const float4 e0 = *reinterpret_cast<const float4*>(ecoef + 512 + n), e1 = *reinterpret_cast<const float4*>(ecoef + 512 + n + 4);
+              const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o.e[e] = f2bf(esl[e] * dz[e]);
+            }
+            if (pok) *reinterpret_cast<uint4*>(yrow + n) = o.u;
+          }
+      }
+    }
+    __syncthreads();                                   // every wave is done with the oldest rows of the ring
+  }
+
+  {
+    const size_t rep = stat_replicas > 1 ? (size_t)(blockIdx.x % stat_replicas) * stat_rstride : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = half_sum(s1[j][cc][e]);
+          const float c = half_sum(s2[j][cc][e]);
+          if (lrow == 8 * cc + e) { t1 = a; t2 = c; }
+        }
+      if (lrow < 16) {
+        const int n = (2 * h2 + j) * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
+        atomicAdd(&S1[rep + n], t1);
+        atomicAdd(&S2[rep + n], t2);
+      }
+    }
+  }
+}
+
+template <int NCH>
+int launch_ring_dgrad(const CxConv& p, hipStream_t st, const RingGeo& g) {
+  const size_t smem = EC_BYTES + DW_BYTES + (size_t)(g.Q + 2) * GP;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_dgrad_kernel<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr = true;
+  }
+  const int total = g.B * g.spi;
+  const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  hipLaunchKernelGGL((conv3x3_ring_dgrad_kernel<NCH>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2,
+                     p.ldx2, p.pa, p.pb, p.pc, (const bf16*)p.w, (const bf16*)p.ex, p.ldex, p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale,
+                     (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, g);
+  return launch_status();
+}
+
 }  // namespace
 
 // Eligibility + launch, called from cx_conv_gemm ahead of the first-generation strip kernel.
@@ -281,4 +539,30 @@ int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   if (need <= 3) return launch_ring<3, 3>(p, st, g);      // short steps (one 80-pixel row): three row groups in flight
   if (need <= 5) return launch_ring<5, 2>(p, st, g);
   return launch_ring<7, 1>(p, st, g);
+}
+
+int cx_try_ring_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1 || p.tstride > 1) return 0;
+  if (p.K != 32 || p.N != 128 || p.prologue != CX_PRO_AFFINE2 || p.epilogue != CX_EPI_MASK || p.accumulate) return 0;
+  if (p.W < 4 || p.W + 2 > 256) return 0;
+  RingGeo g;
+  g.B = p.B; g.H = p.H; g.W = p.W; g.P = p.W + 2;
+  int rmax = (32 * 4 * MAX_ITEMS) / g.P;             // at most 8 sub-tiles (16 work items over 8 waves) per step
+  if (rmax < 1) return 0;
+  if (rmax > p.H) rmax = p.H;
+  g.spi = (p.H + rmax - 1) / rmax;
+  g.R = (p.H + g.spi - 1) / g.spi;
+  g.spi = (p.H + g.R - 1) / g.R;
+  g.Q = (g.R + 2) * g.P;
+  if (EC_BYTES + DW_BYTES + (size_t)(g.Q + 2) * GP > 160 * 1024) return 0;
+  const int need = (g.R * p.W * 4 + NT - 1) / NT;
+  if (need > 2) return 0;
+  const int total = g.B * g.spi;
+  int spw = (total + 255) / 256;
+  if (g.B >= 256) spw = ((g.B + 255) / 256) * g.spi;
+  if (spw < 1) spw = 1;
+  g.steps_per_wg = spw;
+  *handled = true;
+  return need <= 1 ? launch_ring_dgrad<1>(p, st, g) : launch_ring_dgrad<2>(p, st, g);
 }

@@ -396,6 +396,7 @@ int launch_bn(const CxConv& p, hipStream_t st) {
 
 int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled);      // conv3x3_ring.hip
 int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled);     // conv3x3_strip.hip
+int cx_try_ring_dgrad(const CxConv& p, hipStream_t st, bool* handled);    // conv3x3_ring.hip
 int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled);
 int cx_try_pw_dgrad(const CxConv& p, hipStream_t st, bool* handled);        // conv1x1_dgrad.hip
 int cx_try_pw_fwd(const CxConv& p, hipStream_t st, bool* handled);          // conv1x1_fwd.hip
@@ -436,6 +437,8 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
       int rc = cx_try_ring_fwd(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_strip_fwd(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_ring_dgrad(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_strip_dgrad(p, st, &handled);
       if (handled) return rc;
