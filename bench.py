@@ -322,7 +322,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(only, args), "alg_bytes_per_launch": round(ksum["alg_bytes"] / ksum["launches"])},
         }
-        if not args.no_cpu_baseline and args.model == "densenet121":
+        if not args.no_cpu_baseline and args.model == "densenet121" and world == 1:
             log("cpu baseline on %d cores ..." % host_cores())
             out["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(out))

@@ -341,25 +341,27 @@ __global__ void bce_kernel(const float* __restrict__ logits, const float* __rest
   if (threadIdx.x == 0 && loss) *loss = red[0] * invB;
 }
 
+// grid (C/256, n + B): row y < n computes dW[y][:] (and db[y]), row y >= n computes dpooled[y-n][:]
 __global__ void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ pooled, const float* __restrict__ w,
                                 float* dw, float* db, float* __restrict__ dpooled, int B, int C, int n) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
-    for (int k = 0; k < n; ++k) {
+  const int y = blockIdx.y;
+  if (y < n) {
+    if (c < C) {
       float acc = 0.f;
-      for (int b = 0; b < B; ++b) acc += dlogits[b * n + k] * pooled[(size_t)b * C + c];
-      dw[(size_t)k * C + c] += acc;
+      for (int b = 0; b < B; ++b) acc = fmaf(dlogits[b * n + y], pooled[(size_t)b * C + c], acc);
+      dw[(size_t)y * C + c] += acc;
     }
-    for (int b = 0; b < B; ++b) {
+    if (c == 0 && db) {
       float acc = 0.f;
-      for (int k = 0; k < n; ++k) acc += dlogits[b * n + k] * w[(size_t)k * C + c];
-      dpooled[(size_t)b * C + c] = acc;
+      for (int b = 0; b < B; ++b) acc += dlogits[b * n + y];
+      db[y] += acc;
     }
-  }
-  if (c < n && db) {
+  } else if (c < C) {
+    const int b = y - n;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += dlogits[b * n + c];
-    db[c] += acc;
+    for (int k = 0; k < n; ++k) acc = fmaf(dlogits[b * n + k], w[(size_t)k * C + c], acc);
+    dpooled[(size_t)b * C + c] = acc;
   }
 }
 
@@ -777,8 +779,8 @@ int cx_head_bwd(const float* dlogits, const float* pooled, const float* w, float
                 int n_classes, void* stream) {
   if (!dlogits || !pooled || !w || !dw || !dpooled) return CX_EINVAL;
   if (n_classes > C) return CX_ESHAPE;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), dlogits, pooled, w, dw, db, dpooled, B, C,
-                     n_classes);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 255) / 256, n_classes + B), dim3(256), 0, as_stream(stream), dlogits, pooled, w, dw, db,
+                     dpooled, B, C, n_classes);
   return launch_status();
 }
 
