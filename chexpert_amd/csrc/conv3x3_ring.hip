@@ -508,6 +508,225 @@ int launch_ring_dgrad(const CxConv& p, hipStream_t st, const RingGeo& g) {
   return launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[32 n][128 c][3][3] += sum_px dY[px][n] * A[px @ tap][c]: both MFMA operands are contracted over pixels, so both are
+// read from pixel-major LDS images with the transposing ds_read_b64_tr_b16.  The first strip kernel gave a workgroup one
+// 32-channel slice (its 3 waves issued 3 MFMAs per 8 LDS reads, each input row was fetched in four 64-B pieces by four
+// workgroups and dY four times).  Here ONE 768-thread workgroup per CU keeps the whole 128-channel ring (320-B pitch:
+// == 64 B mod 256 B for the transposing reads) and the dY strip of the step; wave (cs, dy) owns the three taps (dy, 0..2)
+// of channel sub-tile cs -- 36 accumulator tiles spread over 12 waves, three waves per SIMD, nothing reduced across waves.
+constexpr int WNT = 768;
+constexpr int WXP = 320;                 // ring pitch: 128 bf16 + 64 B
+constexpr int WGP = 64;                  // dY strip pitch: 32 bf16
+constexpr int WCOEF = 352 * 4;           // prologue vectors
+
+__device__ __forceinline__ bf16x8 tr2(const char* a0, const char* a1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  U64 lo, hi;
+  lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+  hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
+  bf16x8 r;
+  r[0] = lo.e[0]; r[1] = lo.e[1]; r[2] = lo.e[2]; r[3] = lo.e[3];
+  r[4] = hi.e[0]; r[5] = hi.e[1]; r[6] = hi.e[2]; r[7] = hi.e[3];
+  return r;
+}
+
+template <int NX, int NG>
+__global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
+    const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
+    const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
+    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const RingGeo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
+  const int nk = (R * P + 15) / 16;
+  float* coef = reinterpret_cast<float*>(smem);                    // pa[128] pb[128] ga[32] gb[32] gc[32]
+  char* ring = smem + WCOEF;                                       // [(Q+2)][320 B]
+  char* gst = ring + (size_t)(Q + 2) * WXP;                        // [nk*16][64 B]
+  float* red = reinterpret_cast<float*>(ring);                     // [32 n][32 c][9], aliased on the ring at the end
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cs = wave & 3, dy = wave >> 2;                         // channel sub-tile, kernel row
+
+  for (int i = tid; i < ((Q + 2) * WXP + nk * 16 * WGP) / 16; i += WNT) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 128) { coef[tid] = pa[tid]; coef[128 + tid] = pb[tid]; }
+  if (tid < 32) {
+    coef[256 + tid] = g_affine2 ? ga[tid] : 1.f;
+    coef[288 + tid] = g_affine2 ? gb[tid] : 0.f;
+    coef[320 + tid] = g_affine2 ? gc[tid] : 0.f;
+  }
+
+  // chunk slot i of this thread: chunk id tid + 768*i; 768 is a multiple of 16 and of 4, so the channel chunk of the input
+  // rows is tid & 15 and that of the gradient rows tid & 3 for every slot (one LDS address per thread for its coefficients)
+  const int cx8 = tid & 15, cg4 = tid & 3;
+  const float* xco = coef + cx8 * 8;
+  const float* gco = coef + 256 + cg4 * 8;
+  __syncthreads();
+
+  const int total_steps = g.B * g.spi;
+  const int u0 = blockIdx.x * g.steps_per_wg;
+  const int u1 = min(total_steps, u0 + g.steps_per_wg);
+  const int xcpr = W * 16, gcpr = W * 4;
+
+  uint4 pre[NX], pg[NG], pg2[NG];
+  bool pv[NX], gv[NG];
+  int base_row = 0;
+  int xrow[NX], xpx[NX], grow[NG], gpx[NG];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int cid = tid + WNT * i;
+    xrow[i] = cid / xcpr;
+    xpx[i] = (cid - xrow[i] * xcpr) >> 4;
+  }
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int cid = tid + WNT * i;
+    grow[i] = cid / gcpr;
+    gpx[i] = (cid - grow[i] * gcpr) >> 2;
+  }
+  auto issue_rows = [&](int b, int y0, int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int yy = y0 + xrow[i];
+      pv[i] = xrow[i] < n && yy >= 0 && yy < H;
+      const int yc_ = min(max(yy, 0), H - 1);
+      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + xpx[i]) * ldx + cx8 * 8);
+    }
+  };
+  auto write_rows = [&](int y0, int n) __attribute__((always_inline)) {
+    int slot_y0 = (y0 - base_row) % (R + 2);
+    if (slot_y0 < 0) slot_y0 += R + 2;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      if (xrow[i] < n) {
+        int slot = slot_y0 + xrow[i];
+        if (slot >= R + 2) slot -= R + 2;
+        U128 o, v;
+        v.u = pre[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(pv[i] ? fmaxf(fmaf(bf2f(v.e[j]), xco[j], xco[128 + j]), 0.f) : 0.f);
+        const int pos = slot * P + xpx[i] + 1;
+        *reinterpret_cast<uint4*>(ring + (size_t)pos * WXP + cx8 * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * WXP + cx8 * 16) = o.u;   // mirror of pixels 0,1
+      }
+    }
+  };
+  auto issue_g = [&](int b, int yc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int yy = yc + grow[i];
+      gv[i] = grow[i] < R && yy < H;
+      const int yc_ = min(yy, H - 1);
+      const size_t pixel = (size_t)(b * H + yc_) * W + gpx[i];
+      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + cg4 * 8);
+      pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + cg4 * 8);      // g2 == gsl when there is no second tensor
+    }
+  };
+  auto write_g = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      if (grow[i] < R) {
+        U128 o, u, v;
+        u.u = pg[i];
+        v.u = pg2[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o.e[j] = f2bf(gv[i] ? fmaf(bf2f(u.e[j]), gco[j], fmaf(bf2f(v.e[j]), gco[32 + j], gco[64 + j])) : 0.f);
+        *reinterpret_cast<uint4*>(gst + (size_t)(grow[i] * P + gpx[i]) * WGP + cg4 * 16) = o.u;     // pad columns / tail stay zero
+      }
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // lane constants of the transposing reads: 4 pixel rows x 16 channels per 16-lane group
+  const int gq = (lane & 15) >> 2, gp = lane & 3, gg = lane >> 4;
+  const int lrow = 8 * (gg >> 1) + gq;                      // pixel row inside a 16-pixel k-step (second read: +4)
+  const int gcol = (16 * (gg & 1) + 4 * gp) * 2;            // byte offset of the channel block
+  const int xcol = cs * 64 + gcol;
+  const int QB = Q * WXP;
+
+  for (int u = u0; u < u1; ++u) {
+    const int b = u / g.spi, yc = (u - b * g.spi) * R;
+    if (u == u0 || yc == 0) {
+      base_row = yc - 1;
+      issue_rows(b, yc - 1, 1);
+      write_rows(yc - 1, 1);
+      issue_rows(b, yc, 1);
+      write_rows(yc, 1);
+      issue_rows(b, yc + 1, R);
+      issue_g(b, yc);
+    }
+    write_rows(yc + 1, R);
+    write_g();
+    __syncthreads();
+    const bool next_cont = (u + 1 < u1) && ((u + 1) / g.spi == b);
+    if (next_cont) {
+      issue_rows(b, yc + R + 1, R);
+      issue_g(b, yc + R);
+    }
+    int slot0 = (yc - 1 - base_row) % (R + 2);
+    if (slot0 < 0) slot0 += R + 2;
+    const int ws = slot0 * P;
+    int o0 = wrapq(wrapq(ws + lrow + dy * P, Q), Q) * WXP;
+    int o1 = wrapq(wrapq(ws + lrow + 4 + dy * P, Q), Q) * WXP;
+#pragma unroll 2
+    for (int kk = 0; kk < nk; ++kk) {
+      const char* gbase = gst + (size_t)(kk * 16 + lrow) * WGP + gcol;
+      const bf16x8 af = tr2(gbase, gbase + 4 * WGP);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const bf16x8 bfr = tr2(ring + o0 + xcol + dx * WXP, ring + o1 + xcol + dx * WXP);
+        acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[dx], 0, 0, 0);
+      }
+      o0 += 16 * WXP;
+      if (o0 >= QB) o0 -= QB;
+      o1 += 16 * WXP;
+      if (o1 >= QB) o1 -= QB;
+    }
+    __syncthreads();
+  }
+
+  // ---- per channel sub-tile: transpose through LDS into OIHW order, atomics over contiguous runs (288 floats per n)
+  for (int round = 0; round < 4; ++round) {
+    if (cs == round) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          red[(n * 32 + (lane & 31)) * 9 + dy * 3 + dx] = acc[dx][r];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 288; idx += WNT) {
+      const int n = idx / 288, i = idx - n * 288;
+      atomicAdd(dw + ((size_t)n * 128 + round * 32) * 9 + i, red[idx]);
+    }
+    __syncthreads();
+  }
+}
+
+template <int NX, int NG>
+int launch_ring_wgrad(const CxWgrad& p, hipStream_t st, const RingGeo& g, size_t smem) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_wgrad_kernel<NX, NG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr = true;
+  }
+  const int total = g.B * g.spi;
+  const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  const bool a2 = p.g_prologue == CX_PRO_AFFINE2;
+  hipLaunchKernelGGL((conv3x3_ring_wgrad_kernel<NX, NG>), dim3(grid), dim3(WNT), smem, st, (const bf16*)p.g, p.ldg,
+                     (const bf16*)(a2 ? p.g2 : p.g), a2 ? p.ldg2 : p.ldg, p.ga, p.gb, p.gc, (int)a2, (const bf16*)p.x, p.ldx, p.pa, p.pb,
+                     p.dw, g);
+  return launch_status();
+}
+
 }  // namespace
 
 // Eligibility + launch, called from cx_conv_gemm ahead of the first-generation strip kernel.
@@ -565,4 +784,43 @@ int cx_try_ring_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
   g.steps_per_wg = spw;
   *handled = true;
   return need <= 1 ? launch_ring_dgrad<1>(p, st, g) : launch_ring_dgrad<2>(p, st, g);
+}
+
+int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1) return 0;
+  if (p.K != 128 || p.N != 32 || p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
+  if (p.g_prologue != CX_PRO_NONE && p.g_prologue != CX_PRO_AFFINE2) return 0;
+  // every workgroup ends with 147 KB of fp32 atomics (~30 us at the per-CU atomic issue rate): pays off on large maps only
+  // (measured 337 vs 556 us at 80x80, 128 vs 118 us at 40x40); smaller maps stay on the first-generation strip kernel
+  if (p.W < 56 || (long long)p.H * p.W < 3136) return 0;
+  RingGeo g;
+  g.B = p.B; g.H = p.H; g.W = p.W; g.P = p.W + 2;
+  // largest R with: <= 16 k-steps of 16 pixels, ring + strip in 160 KB, <= 5 / 2 chunks of new rows per thread, and the
+  // 36 KB transposition buffer of the epilogue inside the ring
+  int rmax = 0;
+  for (int r = 1; r <= p.H; ++r) {
+    const int nk = (r * g.P + 15) / 16;
+    const size_t bytes = WCOEF + (size_t)((r + 2) * g.P + 2) * WXP + (size_t)nk * 16 * WGP;
+    if (nk > 16 || bytes > 160 * 1024 || r * p.W * 16 > 5 * WNT || r * p.W * 4 > 2 * WNT) break;
+    rmax = r;
+  }
+  if (rmax < 1) return 0;
+  g.spi = (p.H + rmax - 1) / rmax;
+  g.R = (p.H + g.spi - 1) / g.spi;
+  g.spi = (p.H + g.R - 1) / g.R;
+  g.Q = (g.R + 2) * g.P;
+  const int nk = (g.R * g.P + 15) / 16;
+  size_t smem = WCOEF + (size_t)(g.Q + 2) * WXP + (size_t)nk * 16 * WGP;
+  if (smem < WCOEF + 32 * 288 * 4) smem = WCOEF + 32 * 288 * 4;
+  const int total = g.B * g.spi;
+  int spw = (total + 255) / 256;
+  if (g.B >= 256) spw = ((g.B + 255) / 256) * g.spi;
+  if (spw < 1) spw = 1;
+  g.steps_per_wg = spw;
+  const int nx = (g.R * p.W * 16 + WNT - 1) / WNT, ng = (g.R * p.W * 4 + WNT - 1) / WNT;
+  *handled = true;
+  if (nx <= 2 && ng <= 1) return launch_ring_wgrad<2, 1>(p, st, g, smem);
+  if (nx <= 3) return launch_ring_wgrad<3, 2>(p, st, g, smem);
+  return launch_ring_wgrad<5, 2>(p, st, g, smem);
 }

@@ -441,6 +441,7 @@ int launch_tile(const CxWgrad& p, hipStream_t st) {
 
 }  // namespace
 
+int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);    // conv3x3_ring.hip
 int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);   // conv3x3_strip.hip
 
 extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
@@ -462,7 +463,9 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
     if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) return CX_ESHAPE;
     {
       bool handled = false;
-      const int rc = cx_try_strip_wgrad(p, st, &handled);
+      int rc = cx_try_ring_wgrad(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_strip_wgrad(p, st, &handled);
       if (handled) return rc;
     }
     if (p.x_prologue == CX_PRO_AFFINE_RELU)
