@@ -431,6 +431,162 @@ int launch_stem(const CxWgrad& p, hipStream_t st) {
   return launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------ bottleneck 1x1 (N = 128)
+// dW[128 n][K c] += sum_px dZ[px][n] * A[px][c].  The generic kernel above walks 32 pixels per barrier with 4 MFMAs per
+// wave and keeps ~20 KB per workgroup in flight; it measured 1.9-2.9 TB/s on these layers.  This variant: 512 threads, a
+// 128 x 128 tile (the dZ operand -- two tensors under AFFINE2 -- is re-read by half as many channel tiles), 64 pixels per
+// step (48 KB per workgroup in flight, two workgroups per CU), prologue vectors in LDS, 8 MFMAs per wave and step.
+constexpr int PW_PX = 64;
+constexpr int PW_PITCH = 128 * 2 + 64;                 // == 64 B (mod 256 B) for the transposing reads
+constexpr int PW_TILE = PW_PX * PW_PITCH;
+constexpr int PW_STAGE = 2 * PW_TILE;
+constexpr int PW_COEF = 5 * 128 * 4;                   // ga gb gc (dZ channels) | pa pb (this tile's input channels)
+
+template <int GPRO, int XPRO>
+__global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const int M, const int c_tiles, const int splits,
+                                                         const int steps_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);
+  char* tiles = smem + PW_COEF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 2, wc = wave & 3;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = id % c_tiles;                         // channel tiles of one pixel range are neighbours: dZ shared in L2
+  const int split = id / c_tiles;
+  const int c0 = ct * 128;
+  const bf16* __restrict__ Gp = reinterpret_cast<const bf16*>(p.g);
+  const bf16* __restrict__ G2 = reinterpret_cast<const bf16*>(p.g2);
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+
+  if (tid < 128) {
+    coef[tid] = GPRO == CX_PRO_AFFINE2 ? p.ga[tid] : 1.f;
+    coef[128 + tid] = GPRO == CX_PRO_AFFINE2 ? p.gb[tid] : 0.f;
+    coef[256 + tid] = GPRO == CX_PRO_AFFINE2 ? p.gc[tid] : 0.f;
+    const int c = c0 + tid;
+    coef[384 + tid] = (XPRO == CX_PRO_AFFINE_RELU && c < p.K) ? p.pa[c] : 0.f;
+    coef[512 + tid] = (XPRO == CX_PRO_AFFINE_RELU && c < p.K) ? p.pb[c] : 0.f;
+  }
+  __syncthreads();
+
+  // chunk slot i of this thread: row (tid >> 4) + 32 i of the 64-pixel step, 16-B channel chunk q = tid & 15 (same for all)
+  const int q = tid & 15, r0 = tid >> 4;
+  const bool xact = c0 + q * 8 < p.K;
+  const int xc = xact ? c0 + q * 8 : 0;
+  const int step0 = split * steps_per_split;
+  int nsteps = (M + PW_PX - 1) / PW_PX - step0;
+  if (nsteps > steps_per_split) nsteps = steps_per_split;
+
+  uint4 rg[2], rg2[2], rx[2];
+  bool rv[2];
+  auto issue_loads = [&](int s) __attribute__((always_inline)) {
+    const int mbase = (step0 + s) * PW_PX;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mbase + r0 + 32 * i;
+      rv[i] = m < M;
+      const int mc = rv[i] ? m : M - 1;                // unconditional loads on clamped addresses
+      rg[i] = *reinterpret_cast<const uint4*>(Gp + (size_t)mc * p.ldg + q * 8);
+      if (GPRO == CX_PRO_AFFINE2) rg2[i] = *reinterpret_cast<const uint4*>(G2 + (size_t)mc * p.ldg2 + q * 8);
+      rx[i] = *reinterpret_cast<const uint4*>(X + (size_t)mc * p.ldx + xc);
+    }
+  };
+  auto write_stage = [&](int buf) __attribute__((always_inline)) {
+    char* Gt = tiles + buf * PW_STAGE;
+    char* Xt = Gt + PW_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      U128 og, ox;
+      if (!rv[i]) {
+        og.u = make_uint4(0, 0, 0, 0);
+      } else if (GPRO == CX_PRO_NONE) {
+        og.u = rg[i];
+      } else {
+        U128 u, v;
+        u.u = rg[i];
+        v.u = rg2[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          og.e[j] = f2bf(fmaf(bf2f(u.e[j]), coef[q * 8 + j], fmaf(bf2f(v.e[j]), coef[128 + q * 8 + j], coef[256 + q * 8 + j])));
+      }
+      if (!rv[i] || !xact) {
+        ox.u = make_uint4(0, 0, 0, 0);
+      } else if (XPRO == CX_PRO_NONE) {
+        ox.u = rx[i];
+      } else {
+        U128 v;
+        v.u = rx[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ox.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[384 + q * 8 + j], coef[512 + q * 8 + j]), 0.f));
+      }
+      *reinterpret_cast<uint4*>(Gt + (r0 + 32 * i) * PW_PITCH + q * 16) = og.u;
+      *reinterpret_cast<uint4*>(Xt + (r0 + 32 * i) * PW_PITCH + q * 16) = ox.u;
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // ONE LDS stage (40 KB, so that two workgroups share a CU) and two barriers per 64-pixel step; the next step's 48 KB are in
+  // flight in registers while this one is multiplied
+  if (nsteps > 0) {
+    issue_loads(0);
+    for (int s = 0; s < nsteps; ++s) {
+      write_stage(0);
+      __syncthreads();
+      if (s + 1 < nsteps) issue_loads(s + 1);
+      const char* Gt = tiles;
+      const char* Xt = Gt + PW_TILE;
+#pragma unroll
+      for (int kk = 0; kk < PW_PX / 16; ++kk) {
+        const bf16x8 bfr = tr_frag(Xt, PW_PITCH, kk * 16, wc * 32, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 af = tr_frag(Gt, PW_PITCH, kk * 16, (wn * 2 + i) * 32, lane);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int c = c0 + wc * 32 + lrow;
+  if (c < p.K) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = (wn * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        atomicAdd(p.dw + (size_t)n * p.K + c, acc[i][r]);
+      }
+  }
+}
+
+template <int GPRO, int XPRO>
+int launch_pw_wgrad(const CxWgrad& p, hipStream_t st) {
+  const int M = p.B * p.Ho * p.Wo;
+  const int c_tiles = (p.K + 127) / 128;
+  const int total_steps = (M + PW_PX - 1) / PW_PX;
+  int splits = p.splits > 0 ? p.splits : 1024 / c_tiles;
+  if (splits < 1) splits = 1;
+  if (splits > total_steps) splits = total_steps;
+  const int sps = (total_steps + splits - 1) / splits;
+  splits = (total_steps + sps - 1) / sps;
+  const size_t smem = PW_COEF + PW_STAGE;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<GPRO, XPRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL((pw_wgrad_kernel<GPRO, XPRO>), dim3(c_tiles * splits), dim3(512), smem, st, p, M, c_tiles, splits, sps);
+  return launch_status();
+}
+
 template <int GPRO, int XPRO, int MODE>
 int launch_tile(const CxWgrad& p, hipStream_t st) {
   if (MODE == CX_MODE_STEM) return launch<64, 32, GPRO, XPRO, MODE>(p, st);
@@ -467,6 +623,15 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
       if (handled) return rc;
       rc = cx_try_strip_wgrad(p, st, &handled);
       if (handled) return rc;
+    }
+    // the dense-layer bottleneck with enough work to fill the chip with 512-thread workgroups (measured crossover against
+    // the generic kernel: 102 k pixels x 512 channels)
+    if (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && p.N == 128 && p.K >= 64 &&
+        (long long)p.B * p.Ho * p.Wo * p.K >= (1ll << 25)) {
+      if (p.x_prologue == CX_PRO_AFFINE_RELU)
+        return g2 ? launch_pw_wgrad<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU>(p, st) : launch_pw_wgrad<CX_PRO_NONE, CX_PRO_AFFINE_RELU>(p, st);
+      if (p.x_prologue == CX_PRO_NONE)
+        return g2 ? launch_pw_wgrad<CX_PRO_AFFINE2, CX_PRO_NONE>(p, st) : launch_pw_wgrad<CX_PRO_NONE, CX_PRO_NONE>(p, st);
     }
     if (p.x_prologue == CX_PRO_AFFINE_RELU)
       return g2 ? launch_tile<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU, CX_MODE_CONV>(p, st)

@@ -439,6 +439,32 @@ def test_fused_optimisers_match_torch_optim(dev, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpro,xpro,K", [(2, 1, 264), (0, 1, 320), (2, 0, 264)])
+def test_wgrad_1x1_bottleneck_large(dev, gpro, xpro, K):
+    """The 512-thread bottleneck weight-gradient kernel (taken when pixels x channels >= 2^25): partial last channel tile,
+    pixel count not a multiple of the 64-pixel step, with / without the two-tensor dY and the BN-ReLU input prologue."""
+    from chexpert_amd import ops
+    B, H, W, N = 8, 127, 129, 128
+    gb_, g = nhwc_buf(100, B, H, W, N, dev)
+    g2b, g2 = nhwc_buf(101, B, H, W, N, dev)
+    xb, x = nhwc_buf(102, B, H, W, K + 8, dev)
+    ga, gbv, gc = rnd(103, (N,), 0.5, 1.5), rnd(104, (N,), -0.5, 0.5), rnd(105, (N,), -0.2, 0.2)
+    pa, pb = rnd(106, (K,), -0.3, 1.5), rnd(107, (K,), -0.5, 0.5)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    dy = bf(g * cv(ga) + g2 * cv(gbv) + cv(gc)) if gpro else g
+    a = bf(F.relu(x[:, :K] * cv(pa) + cv(pb))) if xpro else x[:, :K]
+    want = torch.nn.grad.conv2d_weight(a, (N, K, 1, 1), dy)
+    dw = torch.zeros(N, K, 1, 1, device=dev)
+    kw = {}
+    if gpro:
+        kw.update(g_prologue=ops.PRO_AFFINE2, g2=g2b, ga=ga.to(dev), gb=gbv.to(dev), gc=gc.to(dev))
+    if xpro:
+        kw.update(x_prologue=ops.PRO_AFFINE_RELU, pa=pa.to(dev), pb=pb.to(dev))
+    ops.conv_wgrad(gb_, xb[..., :K], dw, **kw)
+    close(dw.cpu(), want, rel=2e-3, what="dW 1x1 large")
+
+
+@pytest.mark.gpu
 def test_wgrad_stem_affine2_odd_pixel_count(dev):
     """Stem weight gradient with the two-tensor BN-backward form of dY (conv0 under norm0) and a pixel count that is not a
     multiple of the 32-pixel step (partial last step, splits > 1)."""
