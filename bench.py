@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALG_BYTES_PER_IMG = 283.1e6    # densenet121@320 bf16, fwd+bwd
-ALG_BYTES = {"densenet121": 283.1e6, "aadensenet121": 295.4e6, "resnet152": 555.0e6, "efficientnet-b4": 594.5e6,
+ALG_BYTES = {"densenet121": 283.1e6, "aadensenet121": 295.4e6, "resnet152": 555.0e6, "aaresnet152": 555.0e6, "efficientnet-b4": 594.5e6,
              "efficientnet-b0": 166.2e6}
 
 
@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU minibatch (BASELINE config: 256)")
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--classes", type=int, default=14)
-    ap.add_argument("--model", default="densenet121", choices=["densenet121", "aadensenet121", "resnet152", "efficientnet-b4", "efficientnet-b0"],
+    ap.add_argument("--model", default="densenet121", choices=["densenet121", "aadensenet121", "resnet152", "aaresnet152", "efficientnet-b4", "efficientnet-b0"],
                     help="densenet121 is the headline (BASELINE configs[1]); the others are reported for reference only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default=None, help="kernel tag to time (default: the one with the largest share)")
@@ -227,6 +227,10 @@ def main():
     elif args.model == "resnet152":
         from chexpert_amd.models import resnet152
         model = resnet152(num_classes=args.classes).to(dev)
+    elif args.model == "aaresnet152":
+        from chexpert_amd.models import Bottleneck, ResNet
+        model = ResNet(Bottleneck, [3, 8, 36, 3], num_classes=args.classes,
+                       attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (args.size, args.size)}).to(dev)
     else:
         from chexpert_amd.models import construct_model
         model = construct_model(args.model, args.classes).to(dev)

@@ -98,8 +98,12 @@ def make_model(args, device):
         model = construct_model(name, n_classes=args.n_classes).to(device)
         opt = torch.optim.RMSprop(model.parameters(), lr=args.lr, momentum=0.9, eps=0.001)
         return model, opt, torch.optim.lr_scheduler.ExponentialLR(opt, args.lr_decay_factor)
-    if name == "aaresnet152":
-        raise RuntimeError("Model architecture not built yet on the HIP path: %s (SURVEY.md section 8 rows C-E)" % name)
+    if name == "aaresnet152":                                 # chexpert.py:486-494
+        from .models import Bottleneck, ResNet
+        size = args.resize or 320
+        model = ResNet(Bottleneck, [3, 8, 36, 3], num_classes=args.n_classes,
+                       attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (size, size)}).to(device)
+        return model, torch.optim.Adam(model.parameters(), lr=args.lr), None
     raise RuntimeError("Model architecture not supported.")
 
 

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import CxPackDesc, check, lib, ptr, stream_ptr
-from .densenet import BatchNorm2dParams, Conv2dParams, PoolMarker, ReLUMarker, _Vec
+from .densenet import AAConv2d, BatchNorm2dParams, Conv2dParams, PoolMarker, ReLUMarker, _Vec
 
 
 class Bottleneck(nn.Module):
@@ -28,14 +28,19 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None,
                  input_dims=None, attn_params=None):
         super().__init__()
-        if attn_params is not None:
-            raise NotImplementedError("attention-augmented Bottleneck (AAConv2d) is not built yet: SURVEY.md section 8 row C")
         if groups != 1 or base_width != 64 or dilation != 1 or norm_layer not in (None, nn.BatchNorm2d):
             raise NotImplementedError("only the plain Bottleneck (groups=1, width 64, no dilation, BatchNorm2d) is on the hot path")
         width = planes
         self.conv1 = Conv2dParams(inplanes, width, 1, bias=False)
         self.bn1 = BatchNorm2dParams(width)
-        self.conv2 = Conv2dParams(width, width, 3, stride, 1, bias=False)
+        if attn_params is None:
+            self.conv2 = Conv2dParams(width, width, 3, stride, 1, bias=False)
+        else:                                   # attn_aug_conv.py:170-183: AAConv2d(width, width, 3, stride, dk, dv, nh, ...)
+            nh = attn_params["nh"]
+            dk = max(20 * nh, int((attn_params["k"] * width // nh) * nh))
+            dv = int((attn_params["v"] * width // nh) * nh)
+            dims = (int(attn_params["input_dims"][0] * 16 / planes), int(attn_params["input_dims"][1] * 16 / planes))
+            self.conv2 = AAConv2d(width, width, 3, stride, dk, dv, nh, attn_params["relative"], dims)
         self.bn2 = BatchNorm2dParams(width)
         self.conv3 = Conv2dParams(width, planes * 4, 1, bias=False)
         self.bn3 = BatchNorm2dParams(planes * 4)
@@ -201,6 +206,14 @@ class _Engine:
             ho, wo = h // s_, w // s_
             t = dict(hin=(h, w), hout=(ho, wo), y1=e(B, h, w, p_), y2=e(B, ho, wo, p_), y3=e(B, ho, wo, 4 * p_),
                      yd=e(B, ho, wo, 4 * p_) if b.downsample is not None else None, out=e(B, ho, wo, 4 * p_))
+            if isinstance(b.conv2, AAConv2d):
+                aa = b.conv2
+                if (ho, wo) != tuple(aa.input_dims):
+                    raise RuntimeError("AAConv2d was built for %s feature maps, the input gives %s (relative tables are "
+                                       "size-bound, attn_aug_conv.py:38-41)" % (tuple(aa.input_dims), (ho, wo)))
+                t["QKV"] = e(B, ho, wo, 2 * aa.dk + aa.dv)
+                t["O"] = e(B, ho * wo, aa.dv, dtype=torch.float32)
+                t["LSE"] = e(B * aa.nh, ho * wo, dtype=torch.float32)
             ws.blk.append(t)
             h, w = ho, wo
         ws.pooled = torch.empty(B, 2048, dtype=torch.float32, device=dev)
@@ -259,8 +272,20 @@ class _Engine:
             S1, S2, S3 = self.bn[id(b.bn1)], self.bn[id(b.bn2)], self.bn[id(b.bn3)]
             ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, stat_sum=st(S1.sum), stat_sq=st(S1.sq))
             self._bn_coef(ws, b.bn1, B * hi * wi, train)
-            ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=s_, pad=1, prologue=ops.PRO_AFFINE_RELU,
-                          pa=v(ws, S1.sc), pb=v(ws, S1.sh), stat_sum=st(S2.sum), stat_sq=st(S2.sq))
+            if isinstance(b.conv2, AAConv2d):
+                # attn_aug_conv.py:65-97: 3x3 conv branch || multi-head attention over the stride-s grid, concatenated on channels
+                aa, sub = b.conv2, (lambda slot, lo, n: None if slot is None else slot[lo:lo + n])
+                cc = p_ - aa.dv
+                ops.conv_gemm(t["y1"], self.w_fwd(aa.conv), t["y2"][..., :cc], N=cc, kh=3, kw=3, stride=s_, pad=1,
+                              prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh), stat_sum=sub(st(S2.sum), 0, cc),
+                              stat_sq=sub(st(S2.sq), 0, cc))
+                ops.conv_gemm(t["y1"], self.w_fwd(aa.in_proj_qkv), t["QKV"], N=2 * aa.dk + aa.dv, stride=s_,
+                              prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh))
+                ops.aa_attention_fwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], t["LSE"], aa.nh, aa.dk, aa.dv)
+                ops.aa_outproj_fwd(t["O"], aa.out_proj.weight, t["y2"][..., cc:], sub(st(S2.sum), cc, aa.dv), sub(st(S2.sq), cc, aa.dv))
+            else:
+                ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=s_, pad=1, prologue=ops.PRO_AFFINE_RELU,
+                              pa=v(ws, S1.sc), pb=v(ws, S1.sh), stat_sum=st(S2.sum), stat_sq=st(S2.sq))
             self._bn_coef(ws, b.bn2, B * ho * wo, train)
             ops.conv_gemm(t["y2"], self.w_fwd(b.conv3), t["y3"], N=4 * p_, prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S2.sc),
                           pb=v(ws, S2.sh), stat_sum=st(S3.sum), stat_sq=st(S3.sq))
@@ -303,6 +328,11 @@ class _Engine:
         bw["dz2"] = torch.empty(max(t["y2"].numel() for t in ws.blk), dtype=bf, device=dev)
         bw["dz1"] = torch.empty(max(t["y1"].numel() for t in ws.blk), dtype=bf, device=dev)
         bw["dz0"] = torch.empty_like(ws.c0)
+        aa_t = [t for t in ws.blk if "QKV" in t]
+        if aa_t:                                 # one set of attention-backward scratch buffers, sized for the largest block
+            bw["dO"] = torch.empty(max(t["O"].numel() for t in aa_t), dtype=torch.float32, device=dev)
+            bw["dQKV32"] = torch.empty(max(t["QKV"].numel() for t in aa_t), dtype=torch.float32, device=dev)
+            bw["dQKV"] = torch.empty(max(t["QKV"].numel() for t in aa_t), dtype=bf, device=dev)
         ws.bwd = bw
 
     def backward(self, ws, dlogits):
@@ -355,13 +385,34 @@ class _Engine:
             ops.bn_bwd_coef(v(ws, S2.S1), v(ws, S2.S2), cnt_o, b.bn2.weight, v(ws, S2.mean), v(ws, S2.rstd), G(b.bn2.weight),
                             G(b.bn2.bias), None, None, v(ws, S2.pa), v(ws, S2.pb), v(ws, S2.pc), S2.C)
             dz1 = bw["dz1"][:B * hi * wi * p_].view(B, hi, wi, p_)
-            ops.conv_gemm(dz2, self.w_bwd(b.conv2), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["y2"],
-                          pa=v(ws, S2.pa), pb=v(ws, S2.pb), pc=v(ws, S2.pc), epilogue=ops.EPI_MASK, ex=t["y1"], e_sc=v(ws, S1.sc),
-                          e_sh=v(ws, S1.sh), e_mu=v(ws, S1.mean), e_r=v(ws, S1.rstd), e_scale=ones(p_), stat_sum=v(ws, S1.S1),
-                          stat_sq=v(ws, S1.S2))
-            ops.conv_wgrad(dz2, t["y1"], G(b.conv2.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=t["y2"],
-                           ga=v(ws, S2.pa), gb=v(ws, S2.pb), gc=v(ws, S2.pc), x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc),
-                           pb=v(ws, S1.sh))
+            mask1 = dict(epilogue=ops.EPI_MASK, ex=t["y1"], e_sc=v(ws, S1.sc), e_sh=v(ws, S1.sh), e_mu=v(ws, S1.mean),
+                         e_r=v(ws, S1.rstd), e_scale=ones(p_), stat_sum=v(ws, S1.S1), stat_sq=v(ws, S1.S2))
+            if isinstance(b.conv2, AAConv2d):
+                aa = b.conv2
+                cc = p_ - aa.dv
+                qa, qb, qc = v(ws, S2.pa), v(ws, S2.pb), v(ws, S2.pc)          # BN2 backward as dY2 = dz2*pa + y2*pb + pc
+                gs_c, ys_c, gs_a, ys_a = dz2[..., :cc], t["y2"][..., :cc], dz2[..., cc:], t["y2"][..., cc:]
+                dO = bw["dO"][:t["O"].numel()].view(t["O"].shape)
+                dQ32 = bw["dQKV32"][:t["QKV"].numel()].view(t["QKV"].shape)
+                dQ = bw["dQKV"][:t["QKV"].numel()].view(t["QKV"].shape)
+                ops.aa_outproj_bwd(gs_a, ys_a, qa[cc:], qb[cc:], qc[cc:], t["O"], aa.out_proj.weight, dO, G(aa.out_proj.weight))
+                ops.aa_attention_bwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], dO, t["LSE"], dQ32, G(aa.key_rel_h),
+                                     G(aa.key_rel_w), aa.nh, aa.dk, aa.dv)
+                ops.f32_to_bf16(dQ32, dQ)
+                # both branches end in the same bn1 + ReLU mask: the conv branch writes dz1, the attention branch adds to it
+                ops.conv_gemm(gs_c, self.w_bwd(aa.conv), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=ys_c,
+                              pa=qa[:cc], pb=qb[:cc], pc=qc[:cc], **mask1)
+                ops.conv_gemm(dQ, self.w_bwd(aa.in_proj_qkv), dz1, N=p_, tstride=s_, accumulate=True, **mask1)
+                ops.conv_wgrad(gs_c, t["y1"], G(aa.conv.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=ys_c,
+                               ga=qa[:cc], gb=qb[:cc], gc=qc[:cc], x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh))
+                ops.conv_wgrad(dQ, t["y1"], G(aa.in_proj_qkv.weight), stride=s_, x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc),
+                               pb=v(ws, S1.sh))
+            else:
+                ops.conv_gemm(dz2, self.w_bwd(b.conv2), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["y2"],
+                              pa=v(ws, S2.pa), pb=v(ws, S2.pb), pc=v(ws, S2.pc), **mask1)
+                ops.conv_wgrad(dz2, t["y1"], G(b.conv2.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=t["y2"],
+                               ga=v(ws, S2.pa), gb=v(ws, S2.pb), gc=v(ws, S2.pc), x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc),
+                               pb=v(ws, S1.sh))
             ops.bn_bwd_coef(v(ws, S1.S1), v(ws, S1.S2), cnt_i, b.bn1.weight, v(ws, S1.mean), v(ws, S1.rstd), G(b.bn1.weight),
                             G(b.bn1.bias), None, None, v(ws, S1.pa), v(ws, S1.pb), v(ws, S1.pc), S1.C)
             gx = (bw["g"][bi - 1] if bi > 0 else bw["g_in0"]) if Sd is not None or bi == 0 else g
@@ -431,8 +482,6 @@ class ResNet(nn.Module):
         super().__init__()
         if block is not Bottleneck:
             raise NotImplementedError("only Bottleneck ResNets are on the hot path (BasicBlock / WideResNet: CIFAR harness)")
-        if attn_params is not None:
-            raise NotImplementedError("aaresnet (AAConv2d in conv2) is not built yet: SURVEY.md section 8 row C")
         if groups != 1 or width_per_group != 64 or (replace_stride_with_dilation not in (None, [False] * 3, (False,) * 3)):
             raise NotImplementedError("groups / width / dilation variants are not on the hot path")
         self.inplanes = 64
@@ -441,9 +490,9 @@ class ResNet(nn.Module):
         self.relu = ReLUMarker(inplace=True)
         self.maxpool = PoolMarker()
         self.layer1 = self._make_layer(64, layers[0], 1)
-        self.layer2 = self._make_layer(128, layers[1], 2)
-        self.layer3 = self._make_layer(256, layers[2], 2)
-        self.layer4 = self._make_layer(512, layers[3], 2)
+        self.layer2 = self._make_layer(128, layers[1], 2, attn_params)          # attn_aug_conv.py:242-244: layers 2-4 only
+        self.layer3 = self._make_layer(256, layers[2], 2, attn_params)
+        self.layer4 = self._make_layer(512, layers[3], 2, attn_params)
         self.avgpool = PoolMarker()
         self.fc = nn.Linear(512 * 4, num_classes)
         for mod in self.modules():                      # initialisers of attn_aug_conv.py:248-263
@@ -459,14 +508,14 @@ class ResNet(nn.Module):
         self._nbt_pending = 0
         self._engine = None
 
-    def _make_layer(self, planes, blocks, stride):
+    def _make_layer(self, planes, blocks, stride, attn_params=None):
         down = None
         if stride != 1 or self.inplanes != planes * 4:
             down = nn.Sequential(Conv2dParams(self.inplanes, planes * 4, 1, stride, bias=False), BatchNorm2dParams(planes * 4))
-        layers = [Bottleneck(self.inplanes, planes, stride, down)]
+        layers = [Bottleneck(self.inplanes, planes, stride, down, attn_params=attn_params)]
         self.inplanes = planes * 4
         for _ in range(1, blocks):
-            layers.append(Bottleneck(self.inplanes, planes))
+            layers.append(Bottleneck(self.inplanes, planes, attn_params=attn_params))
         return nn.Sequential(*layers)
 
     def _eng(self):

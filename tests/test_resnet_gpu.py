@@ -120,3 +120,76 @@ def test_resnet152_matches_reference_golden_fixture(dev):
     e, eq = _rel(logits.cpu(), want), _rel(lq, want)
     print("resnet152 golden train logits (B=2): HIP vs reference %.3e; storage-rounded oracle vs reference %.3e" % (e, eq))
     assert e < max(2e-2, 2.0 * eq)
+
+
+@pytest.mark.parametrize("layers,B,S", [((1, 1, 1, 1), 8, 128), ((1, 2, 2, 1), 8, 128)])
+def test_aaresnet_matches_fp32_oracle(dev, layers, B, S):
+    """aaresnet (chexpert.py:486-494): AAConv2d in conv2 of every Bottleneck of layers 2-4 (dk 160, dv 8/24/48, 8 heads),
+    strided in the first block of each layer, against the oracle (attn_aug_conv.py:159-211, :19-100)."""
+    from chexpert_amd.models import Bottleneck, ResNet
+    from oracle import nets, step
+    n_cls = 5
+    attn = dict(k=.2, v=.1, nh=8)
+    spec = nets.resnet_spec(n_cls, layers=layers, attn=attn, input_hw=(S, S))
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(spec), 21)
+    for k in sd:                                  # the well-conditioned regime of the tests above
+        if k.endswith(".bias") and not k.startswith("fc"):
+            sd[k] = torch.full_like(sd[k], 1.0)
+        if k.endswith(".weight") and sd[k].dim() == 1:
+            sd[k] = synth.uniform(7, sd[k].shape, 0.8, 1.2)
+        # unlike the DenseNet transition (InstanceNorm in front) the attention input is relu(bn1(.)) with O(1) mean: keep the
+        # logits O(1) so that the softmax is not a near-argmax that 8-bit q/k rounding flips (that would test conditioning)
+        if k.endswith("in_proj_qkv.weight") or "key_rel_" in k:
+            sd[k] = sd[k] * 0.1
+    model = ResNet(Bottleneck, list(layers), num_classes=n_cls,
+                   attn_params={"k": .2, "v": .1, "nh": 8, "relative": True, "input_dims": (S, S)})
+    assert list(model.state_dict().keys()) == list(spec.keys())
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x, t = synth.xray_batch(1234, B, S), synth.targets(99, B, n_cls)
+    fwd = lambda s, xx, train=True: nets.resnet_forward(s, xx, layers, train=train, nh=8)
+    loss_o, logits_o, grads_o = step.train_step(fwd, {k: v.clone() for k, v in sd.items()}, x, t)
+    with torch.no_grad():
+        le_o = fwd({k: v.clone() for k, v in sd.items()}, x, train=False)
+        model.eval()
+        le = model(x.to(dev)).cpu()
+    print("aaresnet%s eval logits rel %.3e" % (layers, _rel(le, le_o)))
+    assert _rel(le, le_o) < 1e-2
+    model.train()
+    out = model(x.to(dev))
+    loss = torch.nn.BCEWithLogitsLoss(reduction="none")(out, t.to(dev)).sum(1).mean(0)
+    model.zero_grad()
+    loss.backward()
+    print("aaresnet%s train logits rel %.3e" % (layers, _rel(out.detach().cpu(), logits_o)))
+    assert _rel(out.detach().cpu(), logits_o) < 2e-2
+    assert abs(loss.item() - loss_o.item()) < 1e-2 * abs(loss_o.item())
+    gmax = max(g.norm().item() for g in grads_o.values())
+    worst = []
+    for k, p in model.named_parameters():
+        if grads_o[k].norm().item() < 1e-4 * gmax:
+            continue
+        c, n = _cos(p.grad.cpu(), grads_o[k])
+        worst.append((c, n, k))
+    worst.sort()
+    print("aaresnet%s worst (cos, norm ratio): %s" % (layers, worst[:4]))
+    print("aaresnet%s attention params: %s" % (layers, [w for w in worst if ".conv2." in w[2]][:12]))
+    is_norm = lambda k: ".bn" in k or "downsample.1" in k or k.startswith("bn1")
+    lim = lambda k: (0.90, 0.12) if is_norm(k) else (0.95, 0.10)
+    bad = [w for w in worst if w[0] < lim(w[2])[0] or abs(w[1] - 1) > lim(w[2])[1]]
+    assert not bad, "gradient mismatch (cos, norm-ratio, name): %s" % bad[:8]
+
+
+def test_aaresnet152_full_size_step_runs(dev):
+    """The full aaresnet152 of chexpert.py:486-494 at 320x320 (attention over 40x40 / 20x20 / 10x10 grids): parameter count of
+    the reference, one training step, finite outputs and gradients."""
+    from chexpert_amd.models import Bottleneck, ResNet
+    model = ResNet(Bottleneck, [3, 8, 36, 3], num_classes=5,
+                   attn_params={"k": .2, "v": .1, "nh": 8, "relative": True, "input_dims": (320, 320)})
+    assert sum(p.numel() for p in model.parameters()) == 59609421          # tests/golden/param_counts.json "aaresnet152@5"
+    model = model.to(dev).train()
+    x, t = synth.xray_batch(5, 2, 320).to(dev), synth.targets(6, 2, 5).to(dev)
+    loss, logits = model.forward_backward(x, t)
+    assert torch.isfinite(loss).item() and torch.isfinite(logits).all().item()
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all().item(), k
+    assert model.layer3[5].conv2.key_rel_h.grad.abs().sum().item() > 0
