@@ -72,6 +72,7 @@ SIGNATURES = {
     "cx_sgd_nesterov_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _f, _vp],
     "cx_rmsprop_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp],
     "cx_aa_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_aa_attention_weights": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_aa_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_aa_outproj_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _vp],
     "cx_aa_outproj_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],

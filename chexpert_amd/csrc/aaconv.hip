@@ -129,6 +129,86 @@ __global__ __launch_bounds__(AQ) void aa_attn_fwd_kernel(const bf16* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- attention maps
+// The reference keeps softmax(logits) of the last forward in AAConv2d.weights, (B, nh, HW, HW), for vis_attn
+// (chexpert.py:363-383).  The training path never materialises it; this kernel rebuilds it on request from the saved
+// log-sum-exp: one lane per query writes its row P[i][:] = exp(S[i][:] - lse[i]).  Visualisation only, not tuned.
+__global__ __launch_bounds__(AQ) void aa_attn_weights_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                            const float* __restrict__ rel_w, const float* __restrict__ lse,
+                                                            float* __restrict__ wts, const AAGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = g.H, W = g.W, HW = H * W;
+  const int LH = 2 * H - 1, LW = 2 * W - 1;
+  float* RH = lds;
+  float* RW = RH + DKH * LH;
+  float* rh = RW + DKH * LW;
+  float* rw = rh + AQ * (H + 1);
+  float* Kt = rw + AQ * (W + 1);
+  const int tid = threadIdx.x;
+  const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
+  const int i = blockIdx.x * AQ + tid;
+  const bool qvalid = i < HW;
+  const int ic = qvalid ? i : HW - 1;
+  const int qy = ic / W, qx = ic - qy * W;
+  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  for (int t = tid; t < DKH * LH; t += AQ) RH[t] = rel_h[t];
+  for (int t = tid; t < DKH * LW; t += AQ) RW[t] = rel_w[t];
+  float q[DKH];
+  const float scale = rsqrtf((float)DKH);
+  {
+    const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
+#pragma unroll
+    for (int d = 0; d < DKH; d += 4) {
+      U64 v;
+      v.u = *reinterpret_cast<const uint2*>(qp + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[d + e] = bf2f(v.e[e]) * scale;
+    }
+  }
+  __syncthreads();
+  for (int ky = 0; ky < H; ++ky) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RH[d * LH + ky - qy + H - 1], a);
+    rh[tid * (H + 1) + ky] = a;
+  }
+  for (int kx = 0; kx < W; ++kx) {
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RW[d * LW + kx - qx + W - 1], a);
+    rw[tid * (W + 1) + kx] = a;
+  }
+  const float li = lse[(size_t)bn * HW + ic];
+  float* row = wts + ((size_t)bn * HW + ic) * HW;
+  const int kofs = g.dk + n * DKH;
+  for (int j0 = 0; j0 < HW; j0 += TK) {
+    __syncthreads();
+    for (int t = tid; t < TK * 5; t += AQ) {
+      const int j = t / 5, c = t - j * 5;
+      const int jj = min(j0 + j, HW - 1);
+      U64 v;
+      v.u = *reinterpret_cast<const uint2*>(base + (size_t)jj * g.ldq + kofs + c * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = bf2f(v.e[e]);
+    }
+    __syncthreads();
+    const int jn = min(TK, HW - j0);
+    int ky = j0 / W, kx = j0 - ky * W;
+    for (int j = 0; j < jn; ++j) {
+      float sl = rh[tid * (H + 1) + ky] + rw[tid * (W + 1) + kx];
+      const float4* kp = reinterpret_cast<const float4*>(Kt + j * DKH);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const float4 kv = kp[c];
+        sl = fmaf(q[4 * c], kv.x, fmaf(q[4 * c + 1], kv.y, fmaf(q[4 * c + 2], kv.z, fmaf(q[4 * c + 3], kv.w, sl))));
+      }
+      if (qvalid) row[j0 + j] = __expf(sl - li);
+      if (++kx == W) { kx = 0; ++ky; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- backward
 // Pass Q (one lane per query): recompute P from the saved LSE, dS = P (dP - delta), accumulate
 //   dq_i = scale * sum_j dS_ij (k_j + RH[:, ky-qy+H-1] + RW[:, kx-qx+W-1])
@@ -595,6 +675,18 @@ int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w,
     default: return CX_EUNSUPPORTED;
   }
 #undef LAUNCH
+  return launch_status();
+}
+
+int cx_aa_attention_weights(const void* qkv, const float* rel_h, const float* rel_w, const float* lse, float* weights, int B, int H,
+                            int W, int nh, int dk, int dv, int ldq, void* stream) {
+  if (!qkv || !rel_h || !rel_w || !lse || !weights) return CX_EINVAL;
+  if (nh <= 0 || dk != nh * DKH || dv % nh || (ldq % 4)) return CX_ESHAPE;
+  AAGeo g{B, H, W, nh, dk, dv, ldq};
+  const size_t smem = attn_lds_floats(H, W, 0) * 4;
+  if (smem > 64 * 1024) return CX_ESHAPE;
+  hipLaunchKernelGGL(aa_attn_weights_kernel, dim3((H * W + AQ - 1) / AQ, B * nh), dim3(AQ), smem, as_stream(stream),
+                     (const bf16*)qkv, rel_h, rel_w, lse, weights, g);
   return launch_status();
 }
 

@@ -96,10 +96,20 @@ class AAConv2d(nn.Module):
         self.input_dims = (H, W)
         self.key_rel_h = nn.Parameter(dk ** -0.5 + torch.randn(dk // nh, 2 * H - 1))
         self.key_rel_w = nn.Parameter(dk ** -0.5 + torch.randn(dk // nh, 2 * W - 1))
-        self.weights = None      # the reference stores softmax(logits) (B,nh,HW,HW) here on every forward; see model.attention_weights()
+        self._last = None        # (qkv, lse) of the most recent forward, set by the parent model's engine
 
     def forward(self, x):  # pragma: no cover - guard
         raise RuntimeError("chexpert_amd: AAConv2d only holds parameters; call the parent model (fused HIP schedule)")
+
+    @property
+    def weights(self):
+        """softmax(logits) of the most recent forward, (B, nh, HW, HW) fp32 -- what the reference stores here on every forward
+        (attn_aug_conv.py:87) and `vis_attn` reads as `l.weights.data[b]` (chexpert.py:383).  The training path never builds
+        the HW x HW tensor; it is rebuilt on access from the saved q/k and log-sum-exp (82 MB per image at 40x40)."""
+        if self._last is None:
+            return None
+        qkv, lse = self._last
+        return ops.aa_attention_weights(qkv, self.key_rel_h, self.key_rel_w, lse, self.nh, self.dk, self.dv)
 
     def extra_repr(self):
         return "dk={}, dv={}, nh={}, relative={}".format(self.dk, self.dv, self.nh, self.relative)
@@ -460,6 +470,7 @@ class _Engine:
                       stat_sum=st((nsum[0], cc)), stat_sq=st((nsq[0], cc)))
         ops.conv_gemm(T.A, self.w_fwd(aa.in_proj_qkv), T.QKV, N=2 * aa.dk + aa.dv, stride=2)
         ops.aa_attention_fwd(T.QKV, aa.key_rel_h, aa.key_rel_w, T.O, T.LSE, aa.nh, aa.dk, aa.dv)
+        object.__setattr__(aa, "_last", (T.QKV, T.LSE))
         ops.aa_outproj_fwd(T.O, aa.out_proj.weight, nxt[..., cc:cout], st((nsum[0] + cc, aa.dv)), st((nsq[0] + cc, aa.dv)))
 
     def _aa_backward(self, ws, bi, aa, qa, qb, qc, G):

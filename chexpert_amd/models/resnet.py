@@ -282,6 +282,7 @@ class _Engine:
                 ops.conv_gemm(t["y1"], self.w_fwd(aa.in_proj_qkv), t["QKV"], N=2 * aa.dk + aa.dv, stride=s_,
                               prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh))
                 ops.aa_attention_fwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], t["LSE"], aa.nh, aa.dk, aa.dv)
+                object.__setattr__(aa, "_last", (t["QKV"], t["LSE"]))
                 ops.aa_outproj_fwd(t["O"], aa.out_proj.weight, t["y2"][..., cc:], sub(st(S2.sum), cc, aa.dv), sub(st(S2.sq), cc, aa.dv))
             else:
                 ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=s_, pad=1, prologue=ops.PRO_AFFINE_RELU,

@@ -210,6 +210,15 @@ def aa_attention_fwd(qkv, key_rel_h, key_rel_w, o, lse, nh, dk, dv):
           "cx_aa_attention_fwd")
 
 
+def aa_attention_weights(qkv, key_rel_h, key_rel_w, lse, nh, dk, dv):
+    """softmax(logits) (B, nh, HW, HW) fp32 of the forward that produced `qkv` / `lse` (AAConv2d.weights, attn_aug_conv.py:87)."""
+    B, H, W, Cq, ldq = _nhwc(qkv)
+    out = torch.empty(B, nh, H * W, H * W, dtype=torch.float32, device=qkv.device)
+    check(lib().cx_aa_attention_weights(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(lse), ptr(out), B, H, W, nh, dk, dv, ldq,
+                                        stream_ptr()), "cx_aa_attention_weights")
+    return out
+
+
 def aa_attention_bwd(qkv, key_rel_h, key_rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, nh, dk, dv):
     B, H, W, Cq, ldq = _nhwc(qkv)
     check(lib().cx_aa_attention_bwd(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(o), ptr(d_o), ptr(lse), ptr(dqkv), ptr(d_rel_h),

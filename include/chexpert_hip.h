@@ -207,6 +207,10 @@ int cx_rmsprop_step(float* p, const float* g, float* sq, float* buf, size_t n, f
  * (B,nh,HW,HW) tensors of the reference are never materialised.                                      */
 int cx_aa_attention_fwd(const void* qkv, const float* key_rel_h, const float* key_rel_w, float* o, float* lse, int B, int H, int W,
                         int nh, int dk, int dv, int ldq, void* stream);
+/* weights: fp32 (B, nh, H*W, H*W) = softmax(logits) rebuilt from the saved lse -- the tensor the reference leaves in
+ * AAConv2d.weights after a forward (:87) and vis_attn reads (chexpert.py:383); visualisation only                   */
+int cx_aa_attention_weights(const void* qkv, const float* key_rel_h, const float* key_rel_w, const float* lse, float* weights, int B,
+                            int H, int W, int nh, int dk, int dv, int ldq, void* stream);
 /* dqkv: fp32 (B, H*W, 2dk+dv) fully written; d_rel_h / d_rel_w (dkh, 2H-1 / 2W-1) accumulated with atomics */
 int cx_aa_attention_bwd(const void* qkv, const float* key_rel_h, const float* key_rel_w, const float* o, const float* d_o,
                         const float* lse, float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv,

@@ -55,6 +55,11 @@ def test_attention_forward_backward(dev, B, H, W, dv):
     lse = torch.zeros(B * nh, H * W, device=dev)
     ops.aa_attention_fwd(qd, rel_h.to(dev), rel_w.to(dev), o, lse, nh, dk, dv)
     close(o.cpu(), o_ref.detach(), 2e-4, "o")
+    if H * W <= 400:                  # AAConv2d.weights (attn_aug_conv.py:87): the softmax rebuilt from the saved log-sum-exp
+        wts = ops.aa_attention_weights(qd, rel_h.to(dev), rel_w.to(dev), lse, nh, dk, dv)
+        assert wts.shape == (B, nh, H * W, H * W)
+        close(wts.cpu(), P.detach(), 2e-4, "weights")
+        assert (wts.sum(-1) - 1).abs().max().item() < 1e-4
     dqkv = torch.full((B, H * W, Cq), 7.0, device=dev)
     drh, drw = torch.zeros_like(rel_h, device=dev), torch.zeros_like(rel_w, device=dev)
     ops.aa_attention_bwd(qd, rel_h.to(dev), rel_w.to(dev), o, d_o.to(dev), lse, dqkv, drh, drw, nh, dk, dv)
@@ -176,6 +181,32 @@ def test_aa_densenet_matches_oracle(dev, cfg, B, S):
     lim = lambda k: (0.84, 0.16) if ".norm" in k else ((0.95, 0.13) if "out_proj" in k else (0.95, 0.08))
     bad = [w for w in worst if w[0] < lim(w[2])[0] or abs(w[1] - 1) > lim(w[2])[1]]
     assert not bad, "gradient mismatch (cos, norm-ratio, name): %s" % bad[:8]
+
+
+def test_aaconv2d_weights_property_after_forward(dev):
+    """`model.features.transitionN.conv.weights` (chexpert.py:365, :383) after an eval forward: (B, nh, HW, HW), rows sum to 1,
+    equal to the oracle's softmax of the same layer."""
+    from oracle import nets
+    cfg, B, S, n_cls = (6, 4, 2, 2), 2, 64, 5
+    model, sd = _build_aa(cfg, S, n_cls, 21, dev, smooth=True)
+    assert model.features.transition1.conv.weights is None            # no forward yet
+    x = synth.xray_batch(77, B, S)
+    model.eval()
+    with torch.no_grad():
+        model(x.to(dev))
+    aa = model.features.transition1.conv
+    w = aa.weights
+    hw = (S // 8) ** 2
+    assert w.shape == (B, aa.nh, hw, hw) and w.dtype == torch.float32
+    assert (w.sum(-1) - 1).abs().max().item() < 1e-4
+    taps = {}
+    with torch.no_grad():
+        nets.densenet_forward({k: v.clone() for k, v in sd.items()}, x, cfg, train=False, nh=8, taps=taps)
+        a = F.relu(F.instance_norm(taps["block1"], eps=1e-5))                       # attn_aug_conv.py:438-440
+        _, w_ref = nets._aa(sd, "features.transition1.conv", a, 2, 8, return_weights=True)
+    err = (w.cpu() - w_ref).abs().max().item()
+    print("attention weights max abs err %.3e (max prob %.3f)" % (err, w_ref.max().item()))
+    assert err < 2e-2
 
 
 def test_aadensenet121_reference_golden_eval(dev):
