@@ -54,6 +54,7 @@ SIGNATURES = {
     "cx_pack_weights": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "cx_pack_weights_table": [_vp, _vp, _vp, _i, _vp],
     "cx_nchw3_to_nhwc4": [_vp, _vp, _i, _i, _i, _vp],
+    "cx_u8_to_nhwc4": [_vp, _vp, _sz, _f, _f, _vp],
     "cx_bn_coef": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_bn_coef_eval": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],
     "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

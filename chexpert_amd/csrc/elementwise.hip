@@ -86,6 +86,27 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, bf16* __restr
   *reinterpret_cast<uint2*>(y + idx * 4) = o.u;
 }
 
+// uint8 grey image -> the three identical whitened channels of the reference transform chain, NHWC4 bf16, 16 pixels per thread
+__global__ void u8_to_nhwc4_kernel(const uint8_t* __restrict__ x, bf16* __restrict__ y, float scale, float shift, size_t total16) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total16) return;
+  const uint4 v = *reinterpret_cast<const uint4*>(x + idx * 16);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    U128 o0, o1;                                     // 2 x (2 pixels x 4 channels)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bf16 g = f2bf(fmaf((float)((w[q] >> (8 * e)) & 0xffu), scale, shift));
+      U128& o = e < 2 ? o0 : o1;
+      const int k = (e & 1) * 4;
+      o.e[k] = g; o.e[k + 1] = g; o.e[k + 2] = g; o.e[k + 3] = f2bf(0.f);
+    }
+    *reinterpret_cast<uint4*>(y + (idx * 16 + q * 4) * 4) = o0.u;
+    *reinterpret_cast<uint4*>(y + (idx * 16 + q * 4 + 2) * 4) = o1.u;
+  }
+}
+
 __global__ void bn_coef_kernel(const float* sum, const float* sq, float count, const float* gamma, const float* beta,
                                float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
                                float* mean, float* rstd, int C, int replicas, int rstride) {
@@ -690,6 +711,16 @@ int cx_nchw3_to_nhwc4(const float* x, void* y, int B, int H, int W, void* stream
   if (!x || !y || B <= 0 || H <= 0 || W <= 0) return CX_EINVAL;
   const size_t hw = (size_t)H * W, total = hw * B;
   hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y, hw, total);
+  return launch_status();
+}
+
+int cx_u8_to_nhwc4(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream) {
+  if (!x || !y || std <= 0.f) return CX_EINVAL;
+  if ((npix % 16) || !aligned16(x) || !aligned16(y)) return CX_EALIGN;
+  const size_t total16 = npix / 16;
+  // ((u/255) - mean) / std = u * (1/(255 std)) - mean/std
+  hipLaunchKernelGGL(u8_to_nhwc4_kernel, dim3((total16 + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y,
+                     1.f / (255.f * std), -mean / std, total16);
   return launch_status();
 }
 

@@ -389,8 +389,9 @@ class _Engine:
     def forward(self, x, train):
         m, f, s = self.model, self.model.features, self.slots
         R = self.stat_replicas
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise RuntimeError("expected a (B,3,H,W) input")
+        u8 = x.dtype == torch.uint8             # decoded grey bytes (B,1,H,W): whitened + expanded on the GPU (cx_u8_to_nhwc4)
+        if x.dim() != 4 or x.shape[1] != (1 if u8 else 3):
+            raise RuntimeError("expected a (B,3,H,W) float input or a (B,1,H,W) uint8 image")
         B, _, H, W = x.shape
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
@@ -400,7 +401,10 @@ class _Engine:
         z0, zn = self.fwd_zero
         ws.vec[z0:z0 + zn].zero_()
         st = (lambda a: ws.v(a)) if train else (lambda a: None)
-        ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
+        if u8:
+            ops.u8_to_nhwc4(x.contiguous(), ws.x4)
+        else:
+            ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
         ops.conv_gemm(ws.x4, self.w_fwd(f.conv0), ws.c0, N=self.c_init, mode=ops.MODE_STEM, stat_sum=st(s["st0"][0]),
                       stat_sq=st(s["st0"][1]))
         self._bn(ws, s["st0"][0], s["st0"][1], B * (H // 2) * (W // 2), f.norm0, s["n0"][:2], self.c_init, train,

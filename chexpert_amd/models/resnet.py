@@ -247,8 +247,9 @@ class _Engine:
     # ---- forward
     def forward(self, x, train):
         m, v = self.model, self._v
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise RuntimeError("expected a (B,3,H,W) input")
+        u8 = x.dtype == torch.uint8             # decoded grey bytes (B,1,H,W): whitened + expanded on the GPU (cx_u8_to_nhwc4)
+        if x.dim() != 4 or x.shape[1] != (1 if u8 else 3):
+            raise RuntimeError("expected a (B,3,H,W) float input or a (B,1,H,W) uint8 image")
         B, _, H, W = x.shape
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
@@ -259,7 +260,10 @@ class _Engine:
         ws.vec[z0:z0 + zn].zero_()
         st = (lambda s: v(ws, s)) if train else (lambda s: None)
         S0 = self.bn[id(m.bn1)]
-        ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
+        if u8:
+            ops.u8_to_nhwc4(x.contiguous(), ws.x4)
+        else:
+            ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
         ops.conv_gemm(ws.x4, self.w_fwd(m.conv1), ws.c0, N=64, mode=ops.MODE_STEM, stat_sum=st(S0.sum), stat_sq=st(S0.sq))
         self._bn_coef(ws, m.bn1, B * (H // 2) * (W // 2), train)
         ops.bnrelu_maxpool_fwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), ws.pool0, ws.amax, None, None)

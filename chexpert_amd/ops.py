@@ -82,6 +82,21 @@ def pack_weights(w, transpose=False, stem=False, out=None):
     return out
 
 
+def u8_to_nhwc4(x, out=None, mean=0.5330, std=0.0349):
+    """uint8 grey images (B,1,H,W) or (B,H,W) -> whitened, channel-expanded (B,H,W,4) bf16 (chexpert.py:70-72 on the GPU)."""
+    require_cuda(x)
+    assert x.dtype == torch.uint8 and x.is_contiguous()
+    if x.dim() == 4:
+        assert x.shape[1] == 1
+        B, _, H, W = x.shape
+    else:
+        B, H, W = x.shape
+    if out is None:
+        out = torch.empty(B, H, W, 4, dtype=torch.bfloat16, device=x.device)
+    check(lib().cx_u8_to_nhwc4(ptr(x), ptr(out), B * H * W, mean, std, stream_ptr()), "cx_u8_to_nhwc4")
+    return out
+
+
 def nchw3_to_nhwc4(x, out=None):
     require_cuda(x)
     B, Cc, H, W = x.shape

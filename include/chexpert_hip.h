@@ -116,6 +116,11 @@ int cx_pack_weights_table(const float* flat, void* packed, const CxPackDesc* tab
 /* (B,3,H,W) fp32 NCHW -> (B,H,W,4) bf16 (4th channel zero).  Replaces x.to(device) layout glue
  * ahead of features.conv0 (chexpert.py:159).                                                      */
 int cx_nchw3_to_nhwc4(const float* x, void* y, int B, int H, int W, void* stream);
+/* uint8 grey image (B,H,W) -> (B,H,W,4) bf16 with the three identical whitened channels ((u/255 - mean)/std) and a zero pad:
+ * the reference transform chain `float().div(255)`, `Normalize(mean, std)`, `expand(3,-1,-1)` (chexpert.py:70-72) done on
+ * the GPU from the decoded bytes, so the host pipeline ships 1 B per pixel instead of 12.
+ * npix = B*H*W must be a multiple of 16.                                                                             */
+int cx_u8_to_nhwc4(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream);
 
 /* BatchNorm training statistics -> (scale, shift) of the consumer + running-stat update
  * (F.batch_norm, momentum semantics of nn.BatchNorm2d incl. unbiased running_var).

@@ -206,3 +206,24 @@ def test_cli_train_eval_synthetic(dev, tmp_path):
     assert any(f.startswith("eval_results_step_") for f in files)
     ck = torch.load(os.path.join(str(tmp_path), "checkpoint_latest.pt"))
     assert set(ck) == {"global_step", "eval_loss", "avg_auc", "state_dict"} and len(ck["state_dict"]) == 727
+
+
+def test_uint8_input_equals_reference_transform_chain(dev):
+    """feeding the decoded grey bytes (B,1,H,W) uint8 gives the logits of the reference transform
+    chain `float().div(255)`, `Normalize(0.5330, 0.0349)`, `expand(3,-1,-1)` (chexpert.py:70-72) fed as fp32 NCHW."""
+    from chexpert_amd import ops
+    from chexpert_amd.models import DenseNet
+    u8 = synth.xray_u8(31, 3, 64)
+    x = synth.normalise(u8)
+    a = ops.u8_to_nhwc4(u8.to(dev))
+    b = ops.nchw3_to_nhwc4(x.to(dev))
+    assert a.shape == b.shape == (3, 64, 64, 4)
+    assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -4          # one bf16 ulp at |x| <= 16 (different rounding order)
+    assert (a[..., 3].float() == 0).all() and torch.equal(a[..., 0], a[..., 1]) and torch.equal(a[..., 0], a[..., 2])
+    torch.manual_seed(0)
+    model = DenseNet(32, (2, 2, 2, 2), 64, num_classes=5).to(dev).eval()
+    with torch.no_grad():
+        l_u8, l_f = model(u8.to(dev)), model(x.to(dev))
+    assert (l_u8 - l_f).abs().max().item() <= 2e-2 * l_f.abs().max().item()
+    with pytest.raises(RuntimeError):
+        model(u8.expand(-1, 3, -1, -1).contiguous().to(dev))               # uint8 must be single-channel
