@@ -445,15 +445,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
                 s1[j][cc][e] += dz[e];
               }
             }
-            {
-              asm volatile("" ::: "memory");
-              const float4 c0 = *reinterpret_cast<const float4*>(ecoef + 256 + n), c1 = *reinterpret_cast<const float4*>(ecoef + 256 + n + 4);
-              const float4 d0 = *reinterpret_cast<const float4*>(ecoef + 384 + n), d1 = *reinterpret_cast<const float4*>(ecoef + 384 + n + 4);
-              const float emu[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-              const float er[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            // S2 = sum dz * (x - mu) * r = r * (sum dz*x - mu * S1): only sum dz*x is accumulated per element, the per-channel
+            // affine part is applied once, after the final reduction
 #pragma unroll
-              for (int e = 0; e < 8; ++e) s2[j][cc][e] += dz[e] * (xf[e] - emu[e]) * er[e];
-            }
+            for (int e = 0; e < 8; ++e) s2[j][cc][e] = fmaf(dz[e], xf[e], s2[j][cc][e]);
             U128 o;
             {
               asm volatile("" ::: "memory");
@@ -485,7 +480,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
       if (lrow < 16) {
         const int n = (2 * h2 + j) * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
         atomicAdd(&S1[rep + n], t1);
-        atomicAdd(&S2[rep + n], t2);
+        atomicAdd(&S2[rep + n], ecoef[384 + n] * (t2 - ecoef[256 + n] * t1));
       }
     }
   }

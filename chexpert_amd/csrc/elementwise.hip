@@ -272,24 +272,31 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_bwd_kernel(
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    // windows (oy,ox) containing (iy,ix): 2*oy-1 <= iy <= 2*oy+1
-    const int oy_lo = (iy + 0) / 2, oy_hi = (iy + 1) / 2;      // iy even: {iy/2}; odd: {(iy-1)/2... (iy+1)/2}
-    const int ox_lo = (ix + 0) / 2, ox_hi = (ix + 1) / 2;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      if (oy >= Ho) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        if (ox >= Wo) continue;
-        const int t = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
-        const size_t op = ((size_t)b * Ho + oy) * Wo + ox;
-        const uint2 iv = *reinterpret_cast<const uint2*>(amax + op * C + cq * 8);
-        const uint8_t* idx = reinterpret_cast<const uint8_t*>(&iv);
-        U128 gv, xv;
-        gv.u = *reinterpret_cast<const uint4*>(g + op * ldg + cq * 8);
-        xv.u = *reinterpret_cast<const uint4*>(gx + op * ldgx + cq * 8);
+    // windows (oy,ox) containing (iy,ix): 2*oy-1 <= iy <= 2*oy+1 -> oy in {iy/2, (iy+1)/2}, likewise ox: up to four windows.
+    // All twelve loads are issued up front on clamped addresses (a branch around a load serialises them); duplicates
+    // (even coordinates) and windows past the edge are masked out afterwards.
+    const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
+    uint2 wi[4];
+    U128 wg[4], wx[4];
+    int wt[4];
+    bool wok[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (idx[j] == t) acc[j] += fmaf(bf2f(gv.e[j]), fa[j], fmaf(bf2f(xv.e[j]), fb[j], fc[j]));
-      }
+    for (int k = 0; k < 4; ++k) {
+      const int oy = (k >> 1) ? oy1 : oy0, ox = (k & 1) ? ox1 : ox0;
+      wok[k] = oy < Ho && ox < Wo && !((k >> 1) && oy1 == oy0) && !((k & 1) && ox1 == ox0);
+      const int oyc = oy < Ho ? oy : Ho - 1, oxc = ox < Wo ? ox : Wo - 1;
+      wt[k] = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+      const size_t op = ((size_t)b * Ho + oyc) * Wo + oxc;
+      wi[k] = *reinterpret_cast<const uint2*>(amax + op * C + cq * 8);
+      wg[k].u = *reinterpret_cast<const uint4*>(g + op * ldg + cq * 8);
+      wx[k].u = *reinterpret_cast<const uint4*>(gx + op * ldgx + cq * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint8_t* idx = reinterpret_cast<const uint8_t*>(&wi[k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (wok[k] && idx[j] == wt[k]) acc[j] += fmaf(bf2f(wg[k].e[j]), fa[j], fmaf(bf2f(wx[k].e[j]), fb[j], fc[j]));
     }
     U128 xin, o;
     xin.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
