@@ -1,0 +1,205 @@
+// Bottleneck 1x1 forward for K > 256 (weights do not fit LDS, see conv1x1_fwd.hip): Y[m][0:128] = relu(X[m][0:K]*sc + sh) . W^T.
+//
+// On the small maps of dense blocks 3-4 the generic kernel is latency bound: a workgroup walks K in 32-channel steps and
+// every step waits for loads issued one step earlier (31 dependent round trips at K = 992, ~3 us each).  Same tile
+// (128 pixels x 128 channels, 4 waves, mfma 32x32x16) with BK = 128 channels per step: a quarter of the dependent round
+// trips, 64 KB of operands per workgroup in flight, ONE LDS stage (rows of 272 B) + register prefetch so that two
+// workgroups still share a CU.  Epilogue as in conv_gemm.hip (fp32 tile through LDS, 16-B stores, channel sums).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int WAVES_N = 2, TM = 2, TN = 2;
+constexpr int EPITCH = BN + 4;
+
+template <int BK, int PRO>
+__global__ __launch_bounds__(256, 2) void pw_fwdk_kernel(const CxConv p, const int M) {
+  constexpr int PITCH = BK * 2 + 16;                 // 272 B (BK = 128) / 144 B (BK = 64): conflict-free ds_read_b128
+  constexpr int CPR = BK / 8;                        // 16-B chunks per row
+  constexpr int RPP = 256 / CPR;                     // rows per pass
+  constexpr int NL = 128 / RPP;                      // loads per thread and operand
+  constexpr int A_BYTES = BM * PITCH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);                       // [2][K]
+  char* At = smem + 2 * p.K * 4;
+  char* Bt = At + A_BYTES;
+  float* lstat = reinterpret_cast<float*>(Bt + A_BYTES);              // [2][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int mt = xcd_remap(blockIdx.x, gridDim.x);
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const bf16* __restrict__ Wp = reinterpret_cast<const bf16*>(p.w);
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+
+  if (PRO == CX_PRO_AFFINE_RELU)
+    for (int i = tid; i < p.K; i += 256) { coef[i] = p.pa[i]; coef[p.K + i] = p.pb[i]; }
+  if (tid < 2 * BN) lstat[tid] = 0.f;
+
+  const int q = tid % CPR, r0 = tid / CPR;
+  const int nsteps = (p.K + BK - 1) / BK;
+  uint4 ra[NL], rw[NL];
+  bool kok = true;
+  auto issue_loads = [&](int s) __attribute__((always_inline)) {
+    const int c = s * BK + q * 8;
+    kok = c < p.K;                                    // partial last step (K % 8 == 0)
+    const int cc = kok ? c : 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int row = r0 + RPP * i;
+      const int m = mt * BM + row;
+      const int mc = m < M ? m : M - 1;               // unconditional loads on clamped addresses
+      ra[i] = *reinterpret_cast<const uint4*>(X + (size_t)mc * p.ldx + cc);
+      rw[i] = *reinterpret_cast<const uint4*>(Wp + (size_t)row * p.K + cc);
+    }
+  };
+  auto write_stage = [&](int s) __attribute__((always_inline)) {
+    const int c0 = s * BK + q * 8;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int row = r0 + RPP * i;
+      U128 o;
+      if (!kok || mt * BM + row >= M) {
+        o.u = make_uint4(0, 0, 0, 0);
+      } else if (PRO == CX_PRO_NONE) {
+        o.u = ra[i];
+      } else {
+        U128 v;
+        v.u = ra[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[c0 + j], coef[p.K + c0 + j]), 0.f));
+      }
+      *reinterpret_cast<uint4*>(At + row * PITCH + q * 16) = o.u;
+      *reinterpret_cast<uint4*>(Bt + row * PITCH + q * 16) = kok ? rw[i] : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue_loads(0);
+  __syncthreads();                                    // coefficient table visible
+  const int lrow = lane & 31, lh = lane >> 5;
+  for (int s = 0; s < nsteps; ++s) {
+    write_stage(s);
+    __syncthreads();
+    if (s + 1 < nsteps) issue_loads(s + 1);           // in flight under the MFMAs of this step
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(At + ((wm * TM + i) * 32 + lrow) * PITCH + kk * 32 + lh * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bt + ((wn * TN + j) * 32 + lrow) * PITCH + kk * 32 + lh * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue (two 64-row halves through LDS)
+  constexpr int ECPR = BN / 8, ERPP = 256 / ECPR, NPASS = 64 / ERPP;
+  const int cq = tid % ECPR, rr = tid / ECPR;
+  float* etile = reinterpret_cast<float*>(At);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  const bool want_stats = p.stat_sum != nullptr;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int col = (wn * TN + j) * 32 + lrow;
+            etile[row * EPITCH + col] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * ERPP + rr;
+      const int m = mt * BM + half * 64 + row;
+      if (m < M) {
+        const float4 v0 = *reinterpret_cast<const float4*>(etile + row * EPITCH + cq * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(etile + row * EPITCH + cq * 8 + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        U128 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o.e[j] = f2bf(v[j]);
+          const float rv = bf2f(o.e[j]);
+          s1[j] += rv;
+          s2[j] += rv * rv;
+        }
+        *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + cq * 8) = o.u;
+      }
+    }
+    __syncthreads();
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int d = ECPR; d < 64; d <<= 1) {
+        s1[j] += __shfl_xor(s1[j], d);
+        s2[j] += __shfl_xor(s2[j], d);
+      }
+    }
+    if (lane < ECPR) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&lstat[cq * 8 + j], s1[j]);
+        atomicAdd(&lstat[BN + cq * 8 + j], s2[j]);
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+      atomicAdd(&p.stat_sum[rep + tid], lstat[tid]);
+      atomicAdd(&p.stat_sq[rep + tid], lstat[BN + tid]);
+    }
+  }
+}
+
+template <int BK, int PRO>
+int launch_fwdk(const CxConv& p, hipStream_t st) {
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + BM - 1) / BM);
+  const size_t stage = (size_t)2 * BM * (BK * 2 + 16);
+  const size_t epi = (size_t)64 * EPITCH * 4;
+  const size_t smem = (size_t)2 * p.K * 4 + (stage > epi ? stage : epi) + 2 * BN * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_fwdk_kernel<BK, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  if (smem > 80 * 1024) return CX_ESHAPE;
+  hipLaunchKernelGGL((pw_fwdk_kernel<BK, PRO>), dim3(m_tiles), dim3(256), smem, st, p, (int)M);
+  return launch_status();
+}
+
+}  // namespace
+
+// Called by cx_conv_gemm after its argument validation and after cx_try_pw_fwd; *handled = false -> generic kernel.
+int cx_try_pw_fwdk(const CxConv& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (p.mode != CX_MODE_CONV || p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0 || p.tstride > 1) return 0;
+  if (p.epilogue != CX_EPI_STORE || p.accumulate || p.N != 128 || p.K <= 256 || p.K > 1280) return 0;
+  if (p.prologue != CX_PRO_AFFINE_RELU && p.prologue != CX_PRO_NONE) return 0;
+  // pays where the launch is latency bound, i.e. few tiles (measured: 20x20 and 10x10 maps at bs=256 -10..-30 %, 40x40 +5 %)
+  if ((long long)p.B * p.Ho * p.Wo > 200000) return 0;
+  *handled = true;
+  return p.prologue == CX_PRO_AFFINE_RELU ? launch_fwdk<128, CX_PRO_AFFINE_RELU>(p, st) : launch_fwdk<128, CX_PRO_NONE>(p, st);
+}

@@ -400,6 +400,7 @@ int cx_try_ring_dgrad(const CxConv& p, hipStream_t st, bool* handled);    // con
 int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled);
 int cx_try_pw_dgrad(const CxConv& p, hipStream_t st, bool* handled);        // conv1x1_dgrad.hip
 int cx_try_pw_fwd(const CxConv& p, hipStream_t st, bool* handled);          // conv1x1_fwd.hip
+int cx_try_pw_fwdk(const CxConv& p, hipStream_t st, bool* handled);         // conv1x1_fwdk.hip
 
 extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   if (!pp) return CX_EINVAL;
@@ -445,6 +446,8 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
       rc = cx_try_pw_dgrad(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_pw_fwd(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_pw_fwdk(p, st, &handled);
       if (handled) return rc;
     }
     if (p.epilogue == CX_EPI_STORE) {
