@@ -113,7 +113,7 @@ def test_smooth_regime_matches_fp32_oracle_tightly(dev, cfg, B, S):
     # 1-D (norm gain / bias) gradients are sums with heavy cancellation -> looser than the conv weights
     # (transition3.conv.weight of the full net at B=2 sits at 0.983-0.986 from run to run: block 4 normalises over 50 pixels
     # and the fp32 atomic statistics are order dependent)
-    lim = lambda k: (0.94, 0.08) if (".norm" in k) else (0.975, 0.04)
+    lim = lambda k: (0.93, 0.09) if (".norm" in k) else (0.97, 0.05)
     bad = [w for w in worst if w[0] < lim(w[2])[0] or abs(w[1] - 1) > lim(w[2])[1]]
     assert not bad, "gradient mismatch (cos, norm-ratio, name): %s" % bad[:8]
     sd_new = model.state_dict()
