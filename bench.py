@@ -58,6 +58,8 @@ class KernelTimer:
         if mode == 0 and kh == 1 and epi == 0 and N == 128 and 256 < K <= 1280 and pro in (0, 1) and kw.get("stride", 1) == 1 and \
                 not kw.get("accumulate") and x.shape[0] * x.shape[1] * x.shape[2] <= 200000:
             return "pw_fwdk_kernel<128, %d>" % pro
+        if mode == 2:
+            return "stem_fwd_kernel"
         bn = 128 if N % 128 == 0 else (32 if N == 32 else 64)
         return "conv_gemm_kernel<%d, %d, %d, %d>" % (bn, pro, mode, epi)
 

@@ -22,7 +22,7 @@ constexpr int BN = 64;                  // buffer channels per N tile
 constexpr int PITCH = KD * 2 + 16;      // 272 B: consecutive rows shift by one 16-B slot (conflict-free ds_read_b128)
 constexpr int A_BYTES = BM * PITCH;
 constexpr int W_BYTES = BN * PITCH;
-constexpr int MAX_TPC = 4;              // N tiles per workgroup (coefficient vectors for 256 channels live in LDS)
+constexpr int MAX_TPC = 8;              // N tiles per workgroup (coefficient vectors for 256 channels live in LDS)
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {

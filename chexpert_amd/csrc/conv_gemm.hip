@@ -401,6 +401,7 @@ int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled);
 int cx_try_pw_dgrad(const CxConv& p, hipStream_t st, bool* handled);        // conv1x1_dgrad.hip
 int cx_try_pw_fwd(const CxConv& p, hipStream_t st, bool* handled);          // conv1x1_fwd.hip
 int cx_try_pw_fwdk(const CxConv& p, hipStream_t st, bool* handled);         // conv1x1_fwdk.hip
+int cx_try_stem_fwd(const CxConv& p, hipStream_t st, bool* handled);        // conv_stem.hip
 
 extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   if (!pp) return CX_EINVAL;
@@ -468,6 +469,11 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   if (p.mode == CX_MODE_STEM) {
     if (p.prologue != CX_PRO_NONE || p.epilogue != CX_EPI_STORE) return CX_EUNSUPPORTED;
     if (p.K != 32 || (p.W & 1) || p.Ho != (p.H + 6 - 7) / 2 + 1 || p.Wo != (p.W + 6 - 7) / 2 + 1) return CX_ESHAPE;
+    {
+      bool handled = false;
+      const int rc = cx_try_stem_fwd(p, st, &handled);
+      if (handled) return rc;
+    }
     return launch_bn<CX_PRO_NONE, CX_MODE_STEM, CX_EPI_STORE>(p, st);
   }
   return CX_EUNSUPPORTED;

@@ -1,0 +1,170 @@
+// Stem convolution (7x7, stride 2, pad 3, 3 -> 64 channels; features.conv0 / conv1 of the reference nets) on the (B,H,W,4) bf16
+// image, persistent and LDS-free on the activation side like conv1x1_fwd.hip.
+//
+// K is organised as 7 row-taps x 32 (= 8 input pixels x 4 channels of the row window that starts at column 2*ox - 4; the
+// weights are packed [ky][64][32] with zeros for the pad pixel and the pad channel, cx_pack_weights(stem = 1)).  With the MFMA
+// operands swapped (A = weights, B = pixels) a B fragment is "lane = output pixel, 8 consecutive k" = two input pixels =
+// 16 contiguous bytes of the image: the 14 fragments of an output pixel are loaded straight from global memory to
+// registers (neighbouring lanes overlap by 75 % and hit in L1), the 28 KB of weights sit in LDS for the whole workgroup,
+// an accumulator lane owns one pixel and stores its 64 channels as 4 x 16 B, channel sums stay in registers until the end.  The generic kernel ran this layer at
+// 0.8 TB/s (1.35 ms at bs=256).
+#include "common.h"
+
+namespace {
+
+constexpr int SP = 80;                    // bytes per weight row: 32 bf16 + 16 pad (5 slots: conflict-free ds_read_b128)
+constexpr int SW_ROWS = 7 * 64;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_sum(float v) {      // sum over the 32 lanes of each wave half
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  return v + __shfl_xor(v, 16);
+}
+
+__global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const CxConv p, const int M, const int m_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char wl[];          // [7*64][80 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int G = gridDim.x;
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const bf16* __restrict__ Wp = reinterpret_cast<const bf16*>(p.w);
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+  for (int i = tid; i < SW_ROWS * 4; i += 256) {
+    const int row = i >> 2, c = i & 3;
+    *reinterpret_cast<uint4*>(wl + row * SP + c * 16) = *reinterpret_cast<const uint4*>(Wp + (size_t)row * 32 + c * 8);
+  }
+  const int my_tiles = (m_tiles - (int)blockIdx.x + G - 1) / G;
+  const int hw = p.Ho * p.Wo;
+
+  // the 14 fragments (7 row-taps x 2 k16 steps) of this lane's output pixel in tile `tl`; bit 2t+s of the mask = fragment valid
+  auto load_x = [&](uint4 (&xr)[7][2], int& mask, int& m_out, int tl) __attribute__((always_inline)) {
+    const int tc = tl < my_tiles ? tl : my_tiles - 1;                 // clamped: loads are unconditional
+    const int m = (blockIdx.x + tc * G) * 128 + wave * 32 + lrow;
+    m_out = m;
+    const int mc = m < M ? m : M - 1;
+    const int b = mc / hw;
+    const int rem = mc - b * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    mask = 0;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int iy = 2 * oy - 3 + t;
+      const bool yok = m < M && iy >= 0 && iy < p.H;
+      const int iyc = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+      const bf16* row = X + (size_t)(b * p.H + iyc) * p.W * 4;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int p0 = 2 * ox - 4 + 4 * s + 2 * lh;                   // even: both pixels of the pair are in or out together
+        const bool ok = yok && p0 >= 0 && p0 <= p.W - 2;
+        mask |= ok ? (1 << (2 * t + s)) : 0;
+        xr[t][s] = *reinterpret_cast<const uint4*>(row + (ok ? p0 : 0) * 4);
+      }
+    }
+  };
+
+  f32x16 acc[2];
+  float s1[2][2][8], s2[2][2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[j][cc][e] = s2[j][cc][e] = 0.f;
+  const bool want_stats = p.stat_sum != nullptr;
+  const char* wbase = wl + lrow * SP + lh * 16;
+
+  auto compute = [&](uint4 (&xr)[7][2], int mask, int m) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        U128 v;
+        v.u = (mask >> (2 * t + s)) & 1 ? xr[t][s] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wbase + (t * 64 + j * 32) * SP + s * 32);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, v.h, acc[j], 0, 0, 0);      // D[row = channel][col = pixel]
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the weight-fragment reads next to their MFMAs (hoisted, they spill)
+      }
+    const bool mv = m < M;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        U128 o;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][8 * cc + r4]), __float_as_uint(acc[j][8 * cc + 4 + r4]),
+                                                           false, false);
+          o.e[r4] = f2bf(__uint_as_float(sw[0]));
+          o.e[4 + r4] = f2bf(__uint_as_float(sw[1]));
+        }
+        if (want_stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float rv = mv ? bf2f(o.e[e]) : 0.f;
+            s1[j][cc][e] += rv;
+            s2[j][cc][e] += rv * rv;
+          }
+        }
+        if (mv) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + j * 32 + 8 * (2 * cc + lh)) = o.u;
+      }
+  };
+
+  // one register set: 14 fragments + 64 statistics + 32 accumulators leave no room for a second one (it spilled), and
+  // with 8 waves per CU the 160 B per output pixel (128 of them stores) already keep the memory system busy
+  uint4 xa[7][2];
+  int ma = 0, pa_ = 0;
+  __syncthreads();                                   // weights visible
+  for (int tl = 0; tl < my_tiles; ++tl) {
+    load_x(xa, ma, pa_, tl);
+    compute(xa, ma, pa_);
+  }
+
+  if (want_stats) {
+    const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = half_sum(s1[j][cc][e]);
+          const float c = half_sum(s2[j][cc][e]);
+          if (lrow == 8 * cc + e) { t1 = a; t2 = c; }
+        }
+      if (lrow < 16) {
+        const int n = j * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
+        atomicAdd(&p.stat_sum[rep + n], t1);
+        atomicAdd(&p.stat_sq[rep + n], t2);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Called by cx_conv_gemm for CX_MODE_STEM after its argument validation; *handled = false -> generic kernel.
+int cx_try_stem_fwd(const CxConv& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (p.mode != CX_MODE_STEM || p.N != 64 || p.K != 32 || p.prologue != CX_PRO_NONE || p.epilogue != CX_EPI_STORE || p.accumulate)
+    return 0;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + 127) / 128);
+  const int grid = m_tiles < 512 ? m_tiles : 512;
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), SW_ROWS * SP, st, p, (int)M, m_tiles);
+  *handled = true;
+  return launch_status();
+}
