@@ -339,6 +339,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                 # rank 0 is still measuring the copy bandwidth / printing: leave together
         dist.destroy_process_group()
 
 

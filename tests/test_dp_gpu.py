@@ -1,0 +1,60 @@
+"""GPU: data-parallel backward of the fused engine.  Two processes share the one GPU of the test box and
+talk over gloo (RCCL needs one device per rank; the reducer's bucketing / stream logic is backend independent): gradients
+after the overlapped all-reduce must be identical on both ranks and equal the mean of the two local gradients."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chexpert_amd import synth
+    from chexpert_amd.models import DenseNet
+    from chexpert_amd.parallel import broadcast_module_state
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = DenseNet(32, (2, 2, 2, 2), 64, num_classes=5).to(dev).train()
+    for n_, p in model.named_parameters():               # well-conditioned regime (tests/test_model_gpu.py)
+        if n_.endswith(".bias") and "classifier" not in n_:
+            p.data.fill_(2.5)
+    broadcast_module_state(model)
+    x = synth.xray_batch(100 + rank, 4, 64).to(dev)
+    t = synth.targets(200 + rank, 4, 5).to(dev)
+    model.forward_backward(x, t)                          # binds the engine; local gradient, no reducer yet
+    eng = model._eng()
+    g_local = eng.flat_grad.detach().cpu().clone()
+    gathered = [torch.empty_like(g_local) for _ in range(world)]
+    dist.all_gather(gathered, g_local)
+    want = sum(gathered) / world
+    eng.enable_data_parallel(bucket_bytes=1 << 16)        # small buckets: several all-reduces overlap the backward
+    model.zero_grad()
+    model.forward_backward(x, t)
+    torch.cuda.synchronize()
+    got = eng.flat_grad.detach().cpu().clone()
+    both = [torch.empty_like(got) for _ in range(world)]
+    dist.all_gather(both, got)
+    torch.save({"got": got, "want": want, "same": bool(torch.equal(both[0], both[1])), "n_buckets": len(eng.reducer.ranges)},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_backward_two_ranks_one_gpu(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 400)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        rec = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+        assert rec["same"], "ranks ended with different gradients"
+        assert rec["n_buckets"] >= 3
+        g, w = rec["got"].double(), rec["want"].double()
+        cos = float((g * w).sum() / (g.norm() * w.norm()))
+        rel = float((g - w).norm() / w.norm())
+        print("rank %d: cos %.6f rel %.3e buckets %d" % (r, cos, rel, rec["n_buckets"]))
+        assert cos > 0.999 and rel < 5e-2
