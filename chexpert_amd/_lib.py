@@ -94,7 +94,7 @@ SIGNATURES = {
     "cx_bn_lin_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_affine2_out": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "cx_gradcam_map": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_gradcam_map": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_cam_norm_upsample": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_fill_f32": [_vp, _f, _sz, _vp],
     "cx_bf16_to_f32_nchw": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -629,7 +629,7 @@ __global__ void bf16_to_f32_nchw_kernel(const bf16* __restrict__ x, float* __res
 
 // Grad-CAM: cam[b][p] = relu(sum_c w[c] * relu(x[b][p][c]*sc[c]+sh[c]))   (chexpert.py:283-285 as executed)
 __global__ void gradcam_map_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
-                                   const float* __restrict__ w, float* __restrict__ cam, size_t npix, int C, int ldx) {
+                                   const float* __restrict__ w, float* __restrict__ cam, size_t npix, int C, int ldx, int inner_relu) {
   const int lane = threadIdx.x & 63;
   const size_t pix = (size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
   if (pix >= npix) return;
@@ -638,7 +638,10 @@ __global__ void gradcam_map_kernel(const bf16* __restrict__ x, const float* __re
     U128 v;
     v.u = *reinterpret_cast<const uint4*>(x + pix * ldx + c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc += w[c + j] * fmaxf(fmaf(bf2f(v.e[j]), sc[c + j], sh[c + j]), 0.f);
+    for (int j = 0; j < 8; ++j) {
+      const float f = fmaf(bf2f(v.e[j]), sc[c + j], sh[c + j]);
+      acc += w[c + j] * (inner_relu ? fmaxf(f, 0.f) : f);
+    }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
@@ -901,11 +904,11 @@ int cx_rmsprop_step(float* p, const float* g, float* sq, float* buf, size_t n, f
 }
 
 int cx_gradcam_map(const void* x, const float* scale, const float* shift, const float* w, float* cam, int B, int HW, int C, int ldx,
-                   void* stream) {
+                   int inner_relu, void* stream) {
   if (!x || !scale || !shift || !w || !cam || C % 8 || ldx % 8) return CX_EINVAL;
   const size_t npix = (size_t)B * HW;
   hipLaunchKernelGGL(gradcam_map_kernel, dim3((npix + 3) / 4), dim3(256), 0, as_stream(stream), (const bf16*)x, scale, shift, w, cam, npix,
-                     C, ldx);
+                     C, ldx, inner_relu);
   return launch_status();
 }
 

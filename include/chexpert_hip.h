@@ -265,10 +265,12 @@ int cx_affine2_out(const void* a, const void* b, const float* pa, const float* p
 int cx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int N, void* stream);
 
 /* Grad-CAM as the reference code executes it (chexpert.py:260-303):
- * cam[b][p] = relu(sum_c w[c]*relu(x*scale+shift)) with class-independent w[c] = mean_b pooled[b][c]*B/n_cls,
- * then per-image (t-min)/(max-min+1e-5) and bilinear upsampling with align_corners=True.            */
+ * cam[b][p] = relu(sum_c w[c]*f(x*scale+shift)) with class-independent w[c] = mean_b pooled[b][c]*B/n_cls,
+ * then per-image (t-min)/(max-min+1e-5) and bilinear upsampling with align_corners=True.
+ * inner_relu = 1: f = relu (DenseNet: the hook on features.norm5 ends up holding the in-place ReLU'd tensor, :468);
+ * inner_relu = 0: f = identity (ResNet layer4 output, already >= 0, :484; EfficientNet head[1] = BatchNorm output, :498) */
 int cx_gradcam_map(const void* x, const float* scale, const float* shift, const float* w, float* cam, int B, int HW, int C,
-                   int ldx, void* stream);
+                   int ldx, int inner_relu, void* stream);
 int cx_cam_norm_upsample(const float* cam, float* out, int B, int h, int w, int H, int W, void* stream);
 
 /* utilities */

@@ -11,9 +11,12 @@ import torch
 import torch.nn.functional as F
 
 
-def grad_cam_from_features(feat_post_act, n_classes, out_hw):
-    """feat_post_act (B,C,h,w): the tensor the forward hook ends up holding."""
-    pooled = feat_post_act.mean((2, 3))                      # (B,C)
+def grad_cam_from_features(feat_post_act, n_classes, out_hw, pooled=None):
+    """feat_post_act (B,C,h,w): the tensor the forward hook ends up holding.  `pooled` (B,C): the input of the hooked Linear
+    when it is not the spatial mean of that tensor (EfficientNet, chexpert.py:498: the hook sits on head[1], the BatchNorm in
+    front of Swish / pool, so the map is the pre-activation BN output and the weights come from GAP(swish(.)))."""
+    if pooled is None:
+        pooled = feat_post_act.mean((2, 3))                  # (B,C)
     w = pooled.sum(0) / n_classes                            # (C,)
     cam = F.relu((feat_post_act * w.view(1, -1, 1, 1)).sum(1, keepdim=True))
     mn = cam.amin((1, 2, 3), keepdim=True)

@@ -273,6 +273,35 @@ def gen_gradcam(out_dir):
         nets.densenet_forward({k: v.clone() for k, v in sd.items()}, x, cfg, train=False, taps=taps)
     mine = gradcam.grad_cam_from_features(torch.relu(taps["norm5"]), 5, x.shape[2:])
     print("[gradcam] oracle-vs-reference: %.2e (cam max %.3f)" % ((mine - cam).abs().max(), cam.max()))
+    # the other hook targets of chexpert.py:484 (resnet: layer4 / fc) and :498 (efficientnet: head[1] / head[-1])
+    from models.attn_aug_conv import ResNet, Bottleneck
+    from models.efficientnet import construct_model
+    extra = {}
+    layers = (1, 1, 1, 1)
+    rn = ResNet(Bottleneck, list(layers), num_classes=5)
+    sd = filled_sd(nets.resnet_spec(5, layers=layers), 22)
+    rn.load_state_dict(sd)
+    x = synth.xray_batch(78, 3, 64)
+    cam = ref.grad_cam(rn, x, {"forward": rn.layer4, "backward": rn.fc})
+    extra["cam_resnet"] = cam.detach().numpy()
+    taps = {}
+    with torch.no_grad():
+        nets.resnet_forward({k: v.clone() for k, v in sd.items()}, x, layers, train=False, taps=taps)
+    mine = gradcam.grad_cam_from_features(taps["layer4"], 5, x.shape[2:])
+    print("[gradcam resnet] oracle-vs-reference: %.2e (cam max %.3f)" % ((mine - cam).abs().max(), cam.max()))
+    en = construct_model("efficientnet-b0", n_classes=5)
+    sd = filled_sd(nets.efficientnet_spec("efficientnet-b0", 5), 23)
+    en.load_state_dict(sd)
+    x = synth.xray_batch(79, 2, 96)
+    cam = ref.grad_cam(en, x, {"forward": en.head[1], "backward": en.head[-1]})
+    extra["cam_efficientnet"] = cam.detach().numpy()
+    taps = {}
+    with torch.no_grad():
+        nets.efficientnet_forward({k: v.clone() for k, v in sd.items()}, x, "efficientnet-b0", train=False, taps=taps)
+    f = taps["head1"]
+    mine = gradcam.grad_cam_from_features(f, 5, x.shape[2:], pooled=(f * torch.sigmoid(f)).mean((2, 3)))
+    print("[gradcam efficientnet] oracle-vs-reference: %.2e (cam max %.3f)" % ((mine - cam).abs().max(), cam.max()))
+    np.savez_compressed(os.path.join(out_dir, "gradcam_more.npz"), **extra)
 
 
 def gen_auroc(out_dir):

@@ -99,3 +99,22 @@ def test_efficientnet_reference_golden(dev, tag, name):
     print("%s golden train logits rel %.3e (B=2 batch statistics)" % (name, e))
     assert e < 5e-2
     assert abs(loss.item() - rec["loss"]) < 2e-2 * rec["loss"]
+
+
+def test_grad_cam_efficientnet_matches_reference_fixture(dev):
+    """Grad-CAM with the EfficientNet hook targets (head[1] / head[-1], chexpert.py:498) against the reference's own output."""
+    import numpy as np
+    import os
+    from chexpert_amd.gradcam import grad_cam
+    from chexpert_amd.models import construct_model
+    from oracle import nets
+    G_ = os.path.join(os.path.dirname(__file__), "golden")
+    cam_ref = torch.from_numpy(np.load(os.path.join(G_, "gradcam_more.npz"))["cam_efficientnet"])
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(nets.efficientnet_spec("efficientnet-b0", 5)), 23)
+    model = construct_model("efficientnet-b0", 5)
+    model.load_state_dict(sd, strict=True)
+    cam = grad_cam(model.to(dev), synth.xray_batch(79, 2, 96).to(dev)).cpu()
+    assert cam.shape == cam_ref.shape
+    err = (cam - cam_ref).abs().max().item()
+    print("efficientnet grad-cam max abs err vs reference fixture: %.3e" % err)
+    assert err < 5e-2

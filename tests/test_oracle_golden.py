@@ -135,3 +135,25 @@ def test_gradcam_against_reference_fixture():
         nets.densenet_forward(sd, x, cfg, train=False, taps=taps)
         mine = gradcam.grad_cam_from_features(torch.relu(taps["norm5"]), 5, x.shape[2:])
     np.testing.assert_allclose(mine.numpy(), cam, atol=2e-6)
+
+
+def test_gradcam_other_hook_targets_against_reference_fixture():
+    """ResNet (layer4 / fc, chexpert.py:484) and EfficientNet (head[1] / head[-1], :498) hook targets: the reference's own
+    grad_cam output recorded in tests/golden/gradcam_more.npz."""
+    rec = np.load(os.path.join(G, "gradcam_more.npz"))
+    layers = (1, 1, 1, 1)
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(nets.resnet_spec(5, layers=layers)), 22)
+    x = synth.xray_batch(78, 3, 64)
+    taps = {}
+    with torch.no_grad():
+        nets.resnet_forward(sd, x, layers, train=False, taps=taps)
+        mine = gradcam.grad_cam_from_features(taps["layer4"], 5, x.shape[2:])
+    np.testing.assert_allclose(mine.numpy(), rec["cam_resnet"], atol=2e-6)
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(nets.efficientnet_spec("efficientnet-b0", 5)), 23)
+    x = synth.xray_batch(79, 2, 96)
+    taps = {}
+    with torch.no_grad():
+        nets.efficientnet_forward(sd, x, "efficientnet-b0", train=False, taps=taps)
+        f = taps["head1"]
+        mine = gradcam.grad_cam_from_features(f, 5, x.shape[2:], pooled=(f * torch.sigmoid(f)).mean((2, 3)))
+    np.testing.assert_allclose(mine.numpy(), rec["cam_efficientnet"], atol=2e-6)

@@ -193,3 +193,21 @@ def test_aaresnet152_full_size_step_runs(dev):
     for k, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all().item(), k
     assert model.layer3[5].conv2.key_rel_h.grad.abs().sum().item() > 0
+
+
+def test_grad_cam_resnet_matches_reference_fixture(dev):
+    """Grad-CAM with the ResNet hook targets (layer4 / fc, chexpert.py:484) against the reference's own output."""
+    import numpy as np
+    from chexpert_amd.gradcam import grad_cam
+    from chexpert_amd.models import Bottleneck, ResNet
+    from oracle import nets
+    cam_ref = torch.from_numpy(np.load(os.path.join(G, "gradcam_more.npz"))["cam_resnet"])
+    layers = (1, 1, 1, 1)
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(nets.resnet_spec(5, layers=layers)), 22)
+    model = ResNet(Bottleneck, list(layers), num_classes=5)
+    model.load_state_dict(sd, strict=True)
+    cam = grad_cam(model.to(dev), synth.xray_batch(78, 3, 64).to(dev)).cpu()
+    assert cam.shape == cam_ref.shape
+    err = (cam - cam_ref).abs().max().item()
+    print("resnet grad-cam max abs err vs reference fixture: %.3e" % err)
+    assert err < 4e-2                      # maps are normalised to [0,1]; bf16 feature storage
