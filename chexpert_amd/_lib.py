@@ -92,7 +92,10 @@ SIGNATURES = {
     "cx_se_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_se_act_bwd": [_vp] * 11 + [_i, _i, _i, _vp],
     "cx_bn_lin_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
-    "cx_affine2_out": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_affine2_out": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp],
+    "cx_scale_rows": [_vp, _vp, _sz, _vp, _sz, _i, _vp],
+    "cx_dropout_mask": [_vp, _sz, _f, C.c_ulonglong, _vp],
+    "cx_mul_f32": [_vp, _vp, _vp, _sz, _vp],
     "cx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_gradcam_map": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_cam_norm_upsample": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -420,24 +420,59 @@ __global__ void se_act_bwd_kernel(const bf16* __restrict__ du, const bf16* __res
 }
 
 // out = a*pa + (b ? b : 0)*pb + pc   (BatchNorm output + optional skip, no activation)
+// ps (optional): per-sample scale of the a-branch = the DropConnect mask / keep probability (efficientnet.py:44-51)
 __global__ void affine2_out_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const float* __restrict__ pa,
-                                   const float* __restrict__ pb, const float* __restrict__ pc, bf16* __restrict__ out, size_t rows, int C) {
+                                   const float* __restrict__ pb, const float* __restrict__ pc, const float* __restrict__ ps,
+                                   size_t rows_per_sample, bf16* __restrict__ out, size_t rows, int C) {
   const int CP = C / 8;
   const size_t total = rows * CP;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int cq = idx % CP;
+    const float sb = ps ? ps[(idx / CP) / rows_per_sample] : 1.f;
     U128 u, v, o;
     u.u = *reinterpret_cast<const uint4*>(a + idx * 8);
     if (b) v.u = *reinterpret_cast<const uint4*>(b + idx * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = cq * 8 + j;
-      float r = fmaf(bf2f(u.e[j]), pa[c], pc[c]);
+      float r = sb * fmaf(bf2f(u.e[j]), pa[c], pc[c]);
       if (b) r = fmaf(bf2f(v.e[j]), pb[c], r);
       o.e[j] = f2bf(r);
     }
     *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
   }
+}
+
+// out[row][:] = ps[row / rows_per_sample] * g[row][:]   (gradient of the DropConnect-ed branch)
+__global__ void scale_rows_kernel(const bf16* __restrict__ g, const float* __restrict__ ps, size_t rows_per_sample, bf16* __restrict__ out,
+                                  size_t rows, int C) {
+  const int CP = C / 8;
+  const size_t total = rows * CP;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const float sb = ps[(idx / CP) / rows_per_sample];
+    U128 u, o;
+    u.u = *reinterpret_cast<const uint4*>(g + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(sb * bf2f(u.e[j]));
+    *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
+  }
+}
+
+// counter-based Bernoulli mask, already divided by the keep probability: out[i] in {0, 1/keep}
+__global__ void dropout_mask_kernel(float* __restrict__ out, size_t n, float keep, unsigned long long seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);          // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);               // 24 bits -> [0,1)
+  out[i] = u < keep ? 1.f / keep : 0.f;
+}
+
+__global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[i];
 }
 
 __global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -567,11 +602,30 @@ int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* s
   return launch_status();
 }
 
-int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows, int C,
-                   void* stream) {
-  if (!a || !pa || !pc || !out || (b && !pb) || C % 8) return CX_EINVAL;
+int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,
+                   size_t rows_per_sample, void* out, size_t rows, int C, void* stream) {
+  if (!a || !pa || !pc || !out || (b && !pb) || C % 8 || (sample_scale && rows_per_sample == 0)) return CX_EINVAL;
   hipLaunchKernelGGL(affine2_out_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)a,
-                     (const bf16*)b, pa, pb, pc, (bf16*)out, rows, C);
+                     (const bf16*)b, pa, pb, pc, sample_scale, sample_scale ? rows_per_sample : (size_t)1, (bf16*)out, rows, C);
+  return launch_status();
+}
+
+int cx_scale_rows(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream) {
+  if (!g || !sample_scale || !out || rows_per_sample == 0 || C % 8) return CX_EINVAL;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)g,
+                     sample_scale, rows_per_sample, (bf16*)out, rows, C);
+  return launch_status();
+}
+
+int cx_dropout_mask(float* out, size_t n, float keep_prob, unsigned long long seed, void* stream) {
+  if (!out || !(keep_prob > 0.f) || keep_prob > 1.f) return CX_EINVAL;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), out, n, keep_prob, seed);
+  return launch_status();
+}
+
+int cx_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream) {
+  if (!a || !b || !out) return CX_EINVAL;
+  hipLaunchKernelGGL(mul_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), a, b, out, n);
   return launch_status();
 }
 

@@ -112,6 +112,8 @@ class _Engine:
         self.pool = {}
         self.reducer = None
         self.mb = [b for rep in model.blocks for b in rep]
+        self.mb_names = ["blocks.%d.%d" % (si, bi) for si, rep in enumerate(model.blocks) for bi, _ in enumerate(rep)]
+        self.last_masks = {}         # name -> mask / keep of the most recent train-mode forward (tests, reproducibility)
         self.bns = [model.stem[1]] + [m for b in self.mb for m in b if isinstance(m, nn.BatchNorm2d)] + [model.head[1]]
         tmp = [_Region(0) for _ in range(3)]
         for bn in self.bns:
@@ -267,6 +269,9 @@ class _Engine:
         self.bind(x.device)
         self.pack()
         ws = self.acquire(B, H, W)
+        self.last_masks = {}
+        self.n_forward = getattr(self, "n_forward", 0) + 1
+        ws.step = self.n_forward
         z0, zn = self.fwd_zero
         ws.vec[z0:z0 + zn].zero_()
         st = (lambda s: v(ws, s)) if train else (lambda s: None)
@@ -303,8 +308,16 @@ class _Engine:
                   "cx_scale_act_bc")
             ops.conv_gemm(t["u"], self.w_fwd(conv_p), t["yp"], N=c["cout"], stat_sum=st(Sp.sum), stat_sq=st(Sp.sq))
             self._bn_coef(ws, bn_p, B * ho * wo, train)
+            # DropConnect (efficientnet.py:44-51, :100-101): train mode only, on blocks with a skip; the per-image mask / keep
+            # probability is drawn by cx_dropout_mask from the model's step counter (reproducible, independent of torch's RNG)
+            p_dc = list(b)[-1].p if (train and c["skip"] and isinstance(list(b)[-1], DropMarker)) else 0.0
+            t["dc"] = None
+            if p_dc > 0.0:
+                t["dc"] = torch.empty(B, dtype=torch.float32, device=self.device)
+                check(lb.cx_dropout_mask(ptr(t["dc"]), B, 1.0 - p_dc, self._seed(ws, bi), sp), "cx_dropout_mask")
+                self.last_masks[self.mb_names[bi]] = t["dc"]
             check(lb.cx_affine2_out(ptr(t["yp"]), ptr(xin) if c["skip"] else None, ptr(v(ws, Sp.sc)), ptr(v(ws, self.ones)),
-                                    ptr(v(ws, Sp.sh)), ptr(t["out"]), B * ho * wo, c["cout"], sp), "cx_affine2_out")
+                                    ptr(v(ws, Sp.sh)), ptr(t["dc"]), ho * wo, ptr(t["out"]), B * ho * wo, c["cout"], sp), "cx_affine2_out")
             xin = t["out"]
         Sh = self.bn[id(m.head[1])]
         hl, wl = ws.hw_last
@@ -312,11 +325,27 @@ class _Engine:
         self._bn_coef(ws, m.head[1], B * hl * wl, train)
         check(lb.cx_gap_affine_act(ptr(ws.yh), ptr(v(ws, Sh.sc)), ptr(v(ws, Sh.sh)), ptr(ws.pooled), B, hl * wl, 1280, 2, sp),
               "cx_gap_affine_act")
-        check(lb.cx_linear_fwd(ptr(ws.pooled), ptr(m.head[6].weight), ptr(m.head[6].bias), ptr(ws.logits), B, 1280, self.n_classes, sp),
+        # Dropout in front of the classifier (efficientnet.py:169-171), train mode only
+        p_do = m.head[5].p if train else 0.0
+        ws.drop = None
+        fc_in = ws.pooled
+        if p_do > 0.0:
+            ws.drop = torch.empty(B, 1280, dtype=torch.float32, device=self.device)
+            check(lb.cx_dropout_mask(ptr(ws.drop), B * 1280, 1.0 - p_do, self._seed(ws, len(self.mb)), sp), "cx_dropout_mask")
+            ws.pooled_d = torch.empty_like(ws.pooled)
+            check(lb.cx_mul_f32(ptr(ws.pooled), ptr(ws.drop), ptr(ws.pooled_d), B * 1280, sp), "cx_mul_f32")
+            fc_in = ws.pooled_d
+            self.last_masks["head"] = ws.drop
+        ws.fc_in = fc_in
+        check(lb.cx_linear_fwd(ptr(fc_in), ptr(m.head[6].weight), ptr(m.head[6].bias), ptr(ws.logits), B, 1280, self.n_classes, sp),
               "cx_linear_fwd")
         if train:
             m._nbt_pending += 1
         return ws
+
+    def _seed(self, ws, idx):
+        """64-bit seed of the mask of block `idx` in this forward: (model seed, forward counter, block)."""
+        return (int(self.model.drop_seed) * 0x9E3779B1 + ws.step * 1000003 + idx * 7919 + 12345) & 0xFFFFFFFFFFFFFFFF
 
     # ---- backward
     def _alloc_bwd(self, ws):
@@ -335,6 +364,7 @@ class _Engine:
         bw["dzd"] = torch.empty_like(bw["du"])
         bw["dze"] = torch.empty(max([t["ye"].numel() for t in ws.blk if t["ye"] is not None] + [ws.yh.numel(), ws.ys.numel()]),
                                 dtype=bf, device=dev)
+        bw["gdc"] = torch.empty(max(t["out"].numel() for t in ws.blk), dtype=bf, device=dev)     # DropConnect-masked gradient
         ws.bwd = bw
 
     def backward(self, ws, dlogits):
@@ -362,7 +392,9 @@ class _Engine:
         fc, Sh = m.head[6], self.bn[id(m.head[1])]
         hl, wl = ws.hw_last
         dpool = torch.empty(B, 1280, dtype=torch.float32, device=self.device)
-        ops.head_bwd(dlogits, ws.pooled, fc.weight, G(fc.weight), G(fc.bias), dpool)
+        ops.head_bwd(dlogits, ws.fc_in, fc.weight, G(fc.weight), G(fc.bias), dpool)
+        if ws.drop is not None:
+            check(lb.cx_mul_f32(ptr(dpool), ptr(ws.drop), ptr(dpool), B * 1280, sp), "cx_mul_f32")
         dzh = bw["dze"][:ws.yh.numel()].view(ws.yh.shape)
         check(lb.cx_se_act_bwd(None, ptr(ws.yh), ptr(v(ws, Sh.sc)), ptr(v(ws, Sh.sh)), ptr(v(ws, Sh.mean)), ptr(v(ws, Sh.rstd)), None,
                                ptr(dpool), ptr(dzh), ptr(v(ws, Sh.S1)), ptr(v(ws, Sh.S2)), B, hl * wl, 1280, sp), "cx_se_act_bwd")
@@ -383,8 +415,13 @@ class _Engine:
             Sd, Sp = self.bn[id(bn_d)], self.bn[id(bn_p)]
             xin = ws.blk[bi - 1]["out"] if bi > 0 else ws.x0
             g = bw["g"][bi]
-            gin = g if c["skip"] else (bw["g"][bi - 1] if bi > 0 else bw["g0"])
+            gin = g if c["skip"] else (bw["g"][bi - 1] if bi > 0 else bw["g0"])       # skip: dx accumulates into g itself
             ce, rows_o = c["ce"], B * ho * wo
+            gsk = g                                   # gradient of the block output: the skip path takes it as it is
+            if t.get("dc") is not None:               # the branch sees it through the DropConnect mask
+                gb = bw["gdc"][:g.numel()].view(g.shape)
+                check(lb.cx_scale_rows(ptr(g), ptr(t["dc"]), ho * wo, ptr(gb), rows_o, c["cout"], sp), "cx_scale_rows")
+                g = gb
             check(lb.cx_bn_lin_bwd_stats(ptr(g), ptr(t["yp"]), ptr(v(ws, Sp.mean)), ptr(v(ws, Sp.rstd)), ptr(v(ws, Sp.S1)), ptr(v(ws, Sp.S2)),
                                          rows_o, c["cout"], sp), "cx_bn_lin_bwd_stats")
             bn_bwd(Sp, bn_p, rows_o)
@@ -495,6 +532,7 @@ class EfficientNet(nn.Module):
                 nn.init.constant_(mod.bias, 0)
         self._nbt_pending = 0
         self._engine = None
+        self.drop_seed = 0           # seed of the Dropout / DropConnect masks (with the forward counter and the block index)
 
     def _eng(self):
         if self._engine is None:

@@ -259,9 +259,15 @@ int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* s
                   const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream);
 int cx_bn_lin_bwd_stats(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
                         void* stream);
-/* out = a*pa + b*pb + pc (b may be NULL): projection BatchNorm output + skip (:105-110)                         */
-int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows, int C,
-                   void* stream);
+/* out = s*(a*pa + pc) + b*pb (b may be NULL): projection BatchNorm output, DropConnect, skip (:105-110).  sample_scale
+ * (optional, one float per image, rows_per_sample rows each) is the DropConnect mask / keep probability (:44-51)     */
+int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,
+                   size_t rows_per_sample, void* out, size_t rows, int C, void* stream);
+/* out[row][:] = sample_scale[row / rows_per_sample] * g[row][:]: gradient entering a DropConnect-ed branch            */
+int cx_scale_rows(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream);
+/* out[i] in {0, 1/keep_prob}: counter-based (splitmix64 of seed and index) Bernoulli mask for Dropout (:170) and DropConnect */
+int cx_dropout_mask(float* out, size_t n, float keep_prob, unsigned long long seed, void* stream);
+int cx_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream);
 int cx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int N, void* stream);
 
 /* Grad-CAM as the reference code executes it (chexpert.py:260-303):

@@ -289,9 +289,10 @@ def _swish(x):
     return x * torch.sigmoid(x)
 
 
-def efficientnet_forward(sd, x, name, train=True, taps=None):
-    """Deterministic part only: DropConnect / Dropout act as identity (their masks depend on the
-    framework RNG)."""
+def efficientnet_forward(sd, x, name, train=True, taps=None, masks=None):
+    """DropConnect / Dropout act as identity unless `masks` hands in the (already 1/keep-scaled) masks that were drawn:
+    {"blocks.S.B": (B,) per-image scale of the residual branch (efficientnet.py:44-51, :100-101), "head": (B,1280) in front
+    of the classifier (:169-171)} -- the masks themselves depend on the framework RNG."""
     _, stages, _ = efficientnet_arch(name)
     bn = lambda p, t: _bn(sd, p, t, train, eps=1e-3, momentum=0.01)
     x = _swish(bn("stem.1", _same_pad_conv(x, sd["stem.0.weight"], 2, 1)))
@@ -309,9 +310,13 @@ def efficientnet_forward(sd, x, name, train=True, taps=None):
             se = torch.sigmoid(F.conv2d(se, sd["%s.%d.3.weight" % (p, j + 3)], sd["%s.%d.3.bias" % (p, j + 3)]))
             y = y * se
             y = bn("%s.%d" % (p, j + 5), F.conv2d(y, sd["%s.%d.weight" % (p, j + 4)]))
+            if masks is not None and p in masks and y.shape == x.shape:
+                y = y * masks[p].view(-1, 1, 1, 1)
             x = y + x if y.shape == x.shape else y
     f = bn("head.1", F.conv2d(x, sd["head.0.weight"]))
     if taps is not None:
         taps["head1"] = f
     pooled = _swish(f).mean((2, 3))
+    if masks is not None and "head" in masks:
+        pooled = pooled * masks["head"]
     return F.linear(pooled, sd["head.6.weight"], sd["head.6.bias"])

@@ -30,7 +30,7 @@ def _cos(a, b):
     return float((a * b).sum() / (a.norm() * b.norm() + 1e-30)), float(a.norm() / (b.norm() + 1e-30))
 
 
-def _build(name, n_cls, seed, dev):
+def _build(name, n_cls, seed, dev, stochastic=False):
     from chexpert_amd.models import construct_model
     from oracle import nets
     spec = nets.efficientnet_spec(name, n_cls)
@@ -38,6 +38,11 @@ def _build(name, n_cls, seed, dev):
     model = construct_model(name, n_cls)
     assert list(model.state_dict().keys()) == list(spec.keys())
     model.load_state_dict(sd, strict=True)
+    if not stochastic:                      # deterministic part, as the goldens were recorded (make_golden.py sets p = 0)
+        from chexpert_amd.models.efficientnet import DropMarker
+        for mod in model.modules():
+            if isinstance(mod, DropMarker):
+                mod.p = 0.0
     return model.to(dev), sd
 
 
@@ -118,3 +123,59 @@ def test_grad_cam_efficientnet_matches_reference_fixture(dev):
     err = (cam - cam_ref).abs().max().item()
     print("efficientnet grad-cam max abs err vs reference fixture: %.3e" % err)
     assert err < 5e-2
+
+
+def test_efficientnet_dropout_and_dropconnect_train_mode(dev):
+    """Train mode with the reference rates (Dropout 0.2 in front of the classifier, DropConnect 0.2*i/n on skip blocks,
+    efficientnet.py:44-51, :100-101, :169-171).  The masks depend on the RNG, so: (1) their statistics are checked; (2) the
+    oracle is fed the very masks the engine drew and must give the same logits and gradients; (3) the same seed / step
+    reproduces them, the next step does not; (4) eval mode ignores them."""
+    from oracle import nets, step
+    name, n_cls, B, S = "efficientnet-b0", 5, 16, 96
+    model, sd = _build(name, n_cls, 21, dev, stochastic=True)
+    x, t = synth.xray_batch(1234, B, S), synth.targets(99, B, n_cls)
+    model.train()
+    model.zero_grad()
+    loss, logits = model.forward_backward(x.to(dev), t.to(dev))
+    eng = model._eng()
+    masks = {k: v.detach().cpu().clone() for k, v in eng.last_masks.items()}
+    assert "head" in masks and masks["head"].shape == (B, 1280)
+    keep = 0.8
+    hm = masks["head"]
+    assert all(u == 0.0 or abs(u - 1 / keep) < 1e-6 for u in torch.unique(hm).tolist())
+    assert abs((hm > 0).float().mean().item() - keep) < 0.02
+    dc = {k: v for k, v in masks.items() if k != "head"}
+    assert len(dc) == 9                                   # b0: the 9 blocks with a skip (repeat index i >= 1: rate 0.2*i/n > 0)
+    for k, v in dc.items():
+        assert v.shape == (B,) and all(u == 0.0 or u > 1.0 for u in v.tolist()), k
+    # (2) oracle with the same masks
+    fwd = lambda s, xx: nets.efficientnet_forward(s, xx, name, train=True, masks=masks)
+    loss_o, logits_o, grads_o = step.train_step(fwd, {k: v.clone() for k, v in sd.items()}, x, t)
+    print("dropout train logits rel %.3e" % _rel(logits.cpu(), logits_o))
+    assert _rel(logits.cpu(), logits_o) < 8e-2            # 3x3 maps at 96x96: 144 samples per BatchNorm channel at the end
+    gmax = max(g.norm().item() for g in grads_o.values())
+    worst = []
+    for k, p in model.named_parameters():
+        if grads_o[k].norm().item() < 1e-4 * gmax:
+            continue
+        c, n = _cos(p.grad.cpu(), grads_o[k])
+        worst.append((c, n, k))
+    worst.sort()
+    print("dropout worst (cos, norm ratio): %s" % worst[:4])
+    named = dict(model.named_parameters())
+    # BatchNorm gains / biases are cancellation-heavy sums (stem.1.weight moves between 0.88 and 0.96 from run to run)
+    bad = [w for w in worst if w[0] < (0.80 if named[w[2]].dim() == 1 else 0.90)]     # (SE convs: 0.93-0.99)
+    assert not bad, bad[:6]
+    # identity masks would NOT explain the result: the masked oracle is closer than the unmasked one
+    _, logits_id, _ = step.train_step(lambda s, xx: nets.efficientnet_forward(s, xx, name, train=True), {k: v.clone() for k, v in sd.items()}, x, t)
+    print("dropout: masked oracle %.3e away, mask-free oracle %.3e away" % (_rel(logits.cpu(), logits_o), _rel(logits.cpu(), logits_id)))
+    assert _rel(logits.cpu(), logits_o) < 0.5 * _rel(logits.cpu(), logits_id)
+    # (3) the next step draws different masks
+    model.zero_grad()
+    model.forward_backward(x.to(dev), t.to(dev))
+    assert not torch.equal(eng.last_masks["head"].cpu(), hm)
+    # (4) eval mode is mask free
+    model.eval()
+    with torch.no_grad():
+        a, b = model(x.to(dev)), model(x.to(dev))
+    assert _rel(a.cpu(), b.cpu()) < 1e-2 and not eng.last_masks                  # (fp32 atomic pooling sums: not bitwise)
