@@ -97,6 +97,7 @@ __global__ __launch_bounds__(AQ) void aa_attn_fwd_kernel(const bf16* __restrict_
     __syncthreads();
     const int jn = min(TK, HW - j0);
     int ky = j0 / W, kx = j0 - ky * W;
+#pragma unroll 4
     for (int j = 0; j < jn; ++j) {
       float s = rh[tid * (H + 1) + ky] + rw[tid * (W + 1) + kx];
       const float4* kp = reinterpret_cast<const float4*>(Kt + j * DKH);
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(AQ) void aa_attn_weights_kernel(const bf16* __restr
     __syncthreads();
     const int jn = min(TK, HW - j0);
     int ky = j0 / W, kx = j0 - ky * W;
+#pragma unroll 4
     for (int j = 0; j < jn; ++j) {
       float sl = rh[tid * (H + 1) + ky] + rw[tid * (W + 1) + kx];
       const float4* kp = reinterpret_cast<const float4*>(Kt + j * DKH);
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restric
     __syncthreads();
     const int jn = min(TK, HW - j0);
     int ky = j0 / W, kx = j0 - ky * W;
+#pragma unroll 4
     for (int j = 0; j < jn; ++j) {
       float s = rh[tid * (H + 1) + ky] + rw[tid * (W + 1) + kx];
       const float4* kp = reinterpret_cast<const float4*>(Kt + j * DKH);
