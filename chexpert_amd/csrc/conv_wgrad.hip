@@ -432,7 +432,7 @@ int launch_stem(const CxWgrad& p, hipStream_t st) {
 }
 
 
-// ------------------------------------------------------------------------------------------------ bottleneck 1x1 (N = 128)
+// ------------------------------------------------------------------------------------------------ 1x1, N a multiple of 128
 // dW[128 n][K c] += sum_px dZ[px][n] * A[px][c].  The generic kernel above walks 32 pixels per barrier with 4 MFMAs per
 // wave and keeps ~20 KB per workgroup in flight; it measured 1.9-2.9 TB/s on these layers.  This variant: 512 threads, a
 // 128 x 128 tile (the dZ operand -- two tensors under AFFINE2 -- is re-read by half as many channel tiles), 64 pixels per
@@ -444,7 +444,7 @@ constexpr int PW_STAGE = 2 * PW_TILE;
 constexpr int PW_COEF = 5 * 128 * 4;                   // ga gb gc (dZ channels) | pa pb (this tile's input channels)
 
 template <int GPRO, int XPRO>
-__global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const int M, const int c_tiles, const int splits,
+__global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const int M, const int c_tiles, const int n_tiles,
                                                          const int steps_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* coef = reinterpret_cast<float*>(smem);
@@ -453,16 +453,18 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const
   const int wn = wave >> 2, wc = wave & 3;
   int id = xcd_remap(blockIdx.x, gridDim.x);
   const int ct = id % c_tiles;                         // channel tiles of one pixel range are neighbours: dZ shared in L2
-  const int split = id / c_tiles;
-  const int c0 = ct * 128;
+  id /= c_tiles;
+  const int nt = id % n_tiles;                         // N > 128 (ResNet 1x1 convolutions): 128-row tiles of dW
+  const int split = id / n_tiles;
+  const int c0 = ct * 128, n0 = nt * 128;
   const bf16* __restrict__ Gp = reinterpret_cast<const bf16*>(p.g);
   const bf16* __restrict__ G2 = reinterpret_cast<const bf16*>(p.g2);
   const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
 
   if (tid < 128) {
-    coef[tid] = GPRO == CX_PRO_AFFINE2 ? p.ga[tid] : 1.f;
-    coef[128 + tid] = GPRO == CX_PRO_AFFINE2 ? p.gb[tid] : 0.f;
-    coef[256 + tid] = GPRO == CX_PRO_AFFINE2 ? p.gc[tid] : 0.f;
+    coef[tid] = GPRO == CX_PRO_AFFINE2 ? p.ga[n0 + tid] : 1.f;
+    coef[128 + tid] = GPRO == CX_PRO_AFFINE2 ? p.gb[n0 + tid] : 0.f;
+    coef[256 + tid] = GPRO == CX_PRO_AFFINE2 ? p.gc[n0 + tid] : 0.f;
     const int c = c0 + tid;
     coef[384 + tid] = (XPRO == CX_PRO_AFFINE_RELU && c < p.K) ? p.pa[c] : 0.f;
     coef[512 + tid] = (XPRO == CX_PRO_AFFINE_RELU && c < p.K) ? p.pb[c] : 0.f;
@@ -486,8 +488,8 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const
       const int m = mbase + r0 + 32 * i;
       rv[i] = m < M;
       const int mc = rv[i] ? m : M - 1;                // unconditional loads on clamped addresses
-      rg[i] = *reinterpret_cast<const uint4*>(Gp + (size_t)mc * p.ldg + q * 8);
-      if (GPRO == CX_PRO_AFFINE2) rg2[i] = *reinterpret_cast<const uint4*>(G2 + (size_t)mc * p.ldg2 + q * 8);
+      rg[i] = *reinterpret_cast<const uint4*>(Gp + (size_t)mc * p.ldg + n0 + q * 8);
+      if (GPRO == CX_PRO_AFFINE2) rg2[i] = *reinterpret_cast<const uint4*>(G2 + (size_t)mc * p.ldg2 + n0 + q * 8);
       rx[i] = *reinterpret_cast<const uint4*>(X + (size_t)mc * p.ldx + xc);
     }
   };
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = (wn * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int n = n0 + (wn * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         atomicAdd(p.dw + (size_t)n * p.K + c, acc[i][r]);
       }
   }
@@ -569,9 +571,9 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const
 template <int GPRO, int XPRO>
 int launch_pw_wgrad(const CxWgrad& p, hipStream_t st) {
   const int M = p.B * p.Ho * p.Wo;
-  const int c_tiles = (p.K + 127) / 128;
+  const int c_tiles = (p.K + 127) / 128, n_tiles = p.N / 128;
   const int total_steps = (M + PW_PX - 1) / PW_PX;
-  int splits = p.splits > 0 ? p.splits : 1024 / c_tiles;
+  int splits = p.splits > 0 ? p.splits : 1024 / (c_tiles * n_tiles);
   if (splits < 1) splits = 1;
   if (splits > total_steps) splits = total_steps;
   const int sps = (total_steps + splits - 1) / splits;
@@ -583,7 +585,7 @@ int launch_pw_wgrad(const CxWgrad& p, hipStream_t st) {
                               (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL((pw_wgrad_kernel<GPRO, XPRO>), dim3(c_tiles * splits), dim3(512), smem, st, p, M, c_tiles, splits, sps);
+  hipLaunchKernelGGL((pw_wgrad_kernel<GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(512), smem, st, p, M, c_tiles, n_tiles, sps);
   return launch_status();
 }
 
@@ -626,7 +628,7 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
     }
     // the dense-layer bottleneck with enough work to fill the chip with 512-thread workgroups (measured crossover against
     // the generic kernel: 102 k pixels x 512 channels)
-    if (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && p.N == 128 && p.K >= 64 &&
+    if (p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && p.N % 128 == 0 && p.K >= 64 &&
         (long long)p.B * p.Ho * p.Wo * p.K >= (1ll << 25)) {
       if (p.x_prologue == CX_PRO_AFFINE_RELU)
         return g2 ? launch_pw_wgrad<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU>(p, st) : launch_pw_wgrad<CX_PRO_NONE, CX_PRO_AFFINE_RELU>(p, st);

@@ -439,12 +439,12 @@ def test_fused_optimisers_match_torch_optim(dev, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gpro,xpro,K", [(2, 1, 264), (0, 1, 320), (2, 0, 264)])
-def test_wgrad_1x1_bottleneck_large(dev, gpro, xpro, K):
+@pytest.mark.parametrize("gpro,xpro,K,N", [(2, 1, 264, 128), (0, 1, 320, 128), (2, 0, 264, 128), (2, 1, 264, 384)])
+def test_wgrad_1x1_bottleneck_large(dev, gpro, xpro, K, N):
     """The 512-thread bottleneck weight-gradient kernel (taken when pixels x channels >= 2^25): partial last channel tile,
     pixel count not a multiple of the 64-pixel step, with / without the two-tensor dY and the BN-ReLU input prologue."""
     from chexpert_amd import ops
-    B, H, W, N = 8, 127, 129, 128
+    B, H, W = 8, 127, 129
     gb_, g = nhwc_buf(100, B, H, W, N, dev)
     g2b, g2 = nhwc_buf(101, B, H, W, N, dev)
     xb, x = nhwc_buf(102, B, H, W, K + 8, dev)
