@@ -88,6 +88,8 @@ class KernelTimer:
             if not self.enabled:
                 return og(x, w, y, **kw)
             tag = self.gemm_kernel_name(x, kw)
+            if kw.get("fused_dw") is not None:
+                tag = "pw_bwd_kernel<%d, %s>" % (kw.get("prologue", 0), "true" if kw.get("accumulate") else "false")
             if self.only is not None and tag != self.only:
                 return og(x, w, y, **kw)
             mi, ci = self._dims(x)

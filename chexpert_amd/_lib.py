@@ -51,6 +51,7 @@ SIGNATURES = {
     "cx_error_string": [_i],
     "cx_conv_gemm": [C.POINTER(CxConv), _vp],
     "cx_conv_wgrad": [C.POINTER(CxWgrad), _vp],
+    "cx_conv1x1_dgrad_wgrad": [C.POINTER(CxConv), _vp, _vp],
     "cx_pack_weights": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "cx_pack_weights_table": [_vp, _vp, _vp, _i, _vp],
     "cx_nchw3_to_nhwc4": [_vp, _vp, _i, _i, _i, _vp],

@@ -1,0 +1,316 @@
+// Fused input gradient + weight gradient of the dense-layer bottleneck 1x1 convolution.
+//
+//   dX[m][c] (+)= e_scale[c] * mask(x[m][c]) * sum_n dZ[m][n] * W[c][n]          (conv1x1_dgrad.hip)
+//   dW[n][c]  += sum_m dZ[m][n] * relu(x[m][c]*e_sc[c] + e_sh[c])                 (conv_wgrad.hip, pw_wgrad_kernel)
+//
+// Run separately the two kernels each read dZ (two tensors under AFFINE2) and the activation slice x: 20 of the 60 GB they
+// move per DenseNet121 step are that second pass.  Here one workgroup owns a 64-channel tile of x / dX / dW and a range of
+// pixels and walks it in 128-pixel tiles:
+//   * W[64 c][128 n] sits in LDS for the whole workgroup; the dZ tile (128 px x 128 n) is normalised into LDS once per tile
+//     and serves both products -- as the B operand of the swapped input-gradient MFMA (rows of 272 B, ds_read_b128) and, read
+//     with the transposing ds_read_b64_tr_b16, as the A operand of the weight-gradient MFMA (contraction over pixels);
+//   * the mask epilogue runs on the accumulators as in conv1x1_dgrad.hip (lane = pixel, 8 consecutive channels after
+//     v_permlane32_swap, 16-B loads / stores) and hands relu(bn(x)) -- already in registers for the mask -- to LDS as two
+//     32-channel pixel-major images (64-B rows) for the second product;
+//   * dW (128 x 64 fp32) and the channel sums S1, S2 live in registers across all tiles of the workgroup: one burst of
+//     atomics at the end.  The channel tiles of one pixel range are neighbours in the grid and share dZ in L2.
+#include "common.h"
+
+namespace {
+
+constexpr int KD = 128;                 // dZ channels (n)
+constexpr int BM = 128;                 // pixels per tile
+constexpr int BC = 64;                  // buffer channels per workgroup (c)
+constexpr int PITCH = KD * 2 + 16;      // 272 B
+constexpr int A_BYTES = BM * PITCH;
+constexpr int W_BYTES = BC * PITCH;
+constexpr int XH_PITCH = 64;            // 32 channels per image row
+constexpr int XH_BYTES = BM * XH_PITCH; // one 32-channel image
+constexpr int COEF_BYTES = (5 * BC + 3 * KD) * 4;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  return v + __shfl_xor(v, 16);
+}
+
+// fragment of the 32x32x16 MFMA from a pixel-major image: this lane gets channel ch0 + (lane&31), pixels k0 + 8*(lane>>5) + 0..7
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int k0, int ch0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const char* base = tile + (k0 + 8 * (g >> 1) + q) * pitch + (ch0 + 16 * (g & 1) + 4 * pp) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  U64 lo, hi;
+  lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+  hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch));
+  bf16x8 r;
+  r[0] = lo.e[0]; r[1] = lo.e[1]; r[2] = lo.e[2]; r[3] = lo.e[3];
+  r[4] = hi.e[0]; r[5] = hi.e[1]; r[6] = hi.e[2]; r[7] = hi.e[3];
+  return r;
+}
+
+template <int PRO, bool ACC>
+__global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* __restrict__ dw, const int M, const int c_tiles,
+                                                       const int tiles_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ecoef = reinterpret_cast<float*>(smem);               // e_sc, e_sh, e_mu, e_r, e_scale [64] each, then pa, pb, pc [128]
+  char* Wt = smem + COEF_BYTES;                                 // [64 c][272 B]
+  char* At = Wt + W_BYTES;                                      // [128 px][272 B]
+  char* Xh = At + A_BYTES;                                      // [2][128 px][64 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = id % c_tiles, split = id / c_tiles;
+  const int c0 = ct * BC;
+  const int m_tiles = (M + BM - 1) / BM;
+  const int t0 = split * tiles_per_split;
+  const int t1 = (t0 + tiles_per_split < m_tiles) ? t0 + tiles_per_split : m_tiles;
+
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const bf16* __restrict__ X2 = reinterpret_cast<const bf16*>(p.x2);
+  const bf16* __restrict__ Wp = reinterpret_cast<const bf16*>(p.w);
+  const bf16* __restrict__ EX = reinterpret_cast<const bf16*>(p.ex);
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+
+  // ---- once per workgroup: epilogue vectors and the weight tile of this channel range
+  if (tid < BC) {
+    const int n = c0 + tid;
+    const bool ok = n < p.N;
+    ecoef[tid] = ok ? p.e_sc[n] : 0.f;
+    ecoef[BC + tid] = ok ? p.e_sh[n] : 0.f;
+    ecoef[2 * BC + tid] = ok ? p.e_mu[n] : 0.f;
+    ecoef[3 * BC + tid] = ok ? p.e_r[n] : 0.f;
+    ecoef[4 * BC + tid] = ok ? p.e_scale[n] : 0.f;
+  }
+  const int q = tid & 15, r0 = tid >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = c0 + r0 + 16 * i;
+    const uint4 v = *reinterpret_cast<const uint4*>(Wp + (size_t)(n < p.N ? n : 0) * KD + q * 8);
+    *reinterpret_cast<uint4*>(Wt + (r0 + 16 * i) * PITCH + q * 16) = n < p.N ? v : make_uint4(0, 0, 0, 0);
+  }
+  if (PRO == CX_PRO_AFFINE2 && tid < KD) {
+    ecoef[5 * BC + tid] = p.pa[tid];
+    ecoef[5 * BC + KD + tid] = p.pb[tid];
+    ecoef[5 * BC + 2 * KD + tid] = p.pc[tid];
+  }
+  const float* aco = ecoef + 5 * BC + q * 8;                    // AFFINE2 vectors of this thread's dZ channel chunk (LDS)
+  __syncthreads();                                              // the dZ staging of the first tile reads them
+
+  const int wn2 = wave >> 1, wc = wave & 1;                     // weight-gradient tiles of this wave: n sub-tiles 2*wn2, 2*wn2+1; c sub-tile wc
+  f32x16 accw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+  float s1[2][2][8], s2[2][2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[j][cc][e] = s2[j][cc][e] = 0.f;
+
+  for (int mt = t0; mt < t1; ++mt) {
+    const int m0 = mt * BM;
+    // ---- read-modify-write operands of this lane's pixel (requested first: the longest round trip)
+    const int m = m0 + wave * 32 + lrow;
+    const bool pok = m < M;
+    const int mc = pok ? m : M - 1;
+    U128 xv[2][2], old[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int n = c0 + j * 32 + 8 * (2 * cc + lh);
+        const int ncl = n < p.N ? n : 0;
+        xv[j][cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl);
+        if (ACC) old[j][cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl);
+        else old[j][cc].u = make_uint4(0, 0, 0, 0);
+      }
+    // ---- dZ tile -> LDS (two batches of four rows per thread)
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      uint4 ru[4], rv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mm = m0 + r0 + 16 * (hb * 4 + i);
+        const int mmc = mm < M ? mm : M - 1;
+        ru[i] = *reinterpret_cast<const uint4*>(X + (size_t)mmc * p.ldx + q * 8);
+        if (PRO == CX_PRO_AFFINE2) rv[i] = *reinterpret_cast<const uint4*>(X2 + (size_t)mmc * p.ldx2 + q * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 16 * (hb * 4 + i);
+        U128 o;
+        if (m0 + row >= M) {
+          o.u = make_uint4(0, 0, 0, 0);
+        } else if (PRO == CX_PRO_NONE) {
+          o.u = ru[i];
+        } else {
+          U128 u, v;
+          u.u = ru[i];
+          v.u = rv[i];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
+        }
+        *reinterpret_cast<uint4*>(At + row * PITCH + q * 16) = o.u;
+      }
+    }
+    __syncthreads();                              // dZ tile (first time: weights, coefficients) visible
+
+    // ---- input gradient of this wave's 32 pixels x 64 channels: D[row = channel][col = pixel]
+    f32x16 accd[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd[j][r] = 0.f;
+    {
+      const char* Ab = At + (wave * 32 + lrow) * PITCH + lh * 16;
+      const char* Wb = Wt + lrow * PITCH + lh * 16;
+#pragma unroll
+      for (int kk = 0; kk < KD / 16; ++kk) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + kk * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wb + j * 32 * PITCH + kk * 32);
+          accd[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, accd[j], 0, 0, 0);
+        }
+      }
+    }
+    // ---- mask epilogue on the accumulators; relu(bn(x)) goes to LDS for the second product
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int cl = j * 32 + 8 * (2 * cc + lh);
+        const int n = c0 + cl;
+        float v[8];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accd[j][8 * cc + r4]), __float_as_uint(accd[j][8 * cc + 4 + r4]),
+                                                           false, false);
+          v[r4] = __uint_as_float(sw[0]);
+          v[4 + r4] = __uint_as_float(sw[1]);
+        }
+        asm volatile("" ::: "memory");
+        const float4 a0 = *reinterpret_cast<const float4*>(ecoef + cl), a1 = *reinterpret_cast<const float4*>(ecoef + cl + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ecoef + BC + cl), b1 = *reinterpret_cast<const float4*>(ecoef + BC + cl + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl), e1 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl + 4);
+        const float esc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        U128 o, xh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xf = bf2f(xv[j][cc].e[e]);
+          const float pre = fmaf(xf, esc[e], esh[e]);
+          const bool on = pok && pre > 0.f;
+          const float dz = on ? v[e] : 0.f;
+          s1[j][cc][e] += dz;
+          s2[j][cc][e] = fmaf(dz, xf, s2[j][cc][e]);      // S2 = r * (sum dz*x - mu * S1), affine part at the end
+          o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[j][cc].e[e])));
+          xh.e[e] = f2bf(on ? pre : 0.f);
+        }
+        if (pok && n < p.N) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + n) = o.u;
+        *reinterpret_cast<uint4*>(Xh + j * XH_BYTES + (wave * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
+      }
+    __syncthreads();                              // relu(bn(x)) tile visible
+
+    // ---- weight gradient: dW[n][c] += sum over the 128 pixels of the tile (k = pixel, transposing LDS reads)
+#pragma unroll
+    for (int kk = 0; kk < BM / 16; ++kk) {
+      const bf16x8 bfr = tr_frag(Xh + wc * XH_BYTES, XH_PITCH, kk * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 af = tr_frag(At, PITCH, kk * 16, (wn2 * 2 + i) * 32, lane);
+        accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();                              // both LDS tiles free for the next pixel tile
+  }
+
+  // ---- one burst of atomics per workgroup: dW tile, then S1 / S2
+  {
+    const int c = c0 + wc * 32 + lrow;
+    if (c < p.N) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = (wn2 * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          atomicAdd(dw + (size_t)n * p.N + c, accw[i][r]);
+        }
+    }
+  }
+  {
+    const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float t1v = 0.f, t2v = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = half_sum(s1[j][cc][e]);
+          const float b = half_sum(s2[j][cc][e]);
+          if (lrow == 8 * cc + e) { t1v = a; t2v = b; }
+        }
+      if (lrow < 16) {
+        const int cl = j * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
+        const int n = c0 + cl;
+        if (n < p.N) {
+          atomicAdd(&p.stat_sum[rep + n], t1v);
+          atomicAdd(&p.stat_sq[rep + n], ecoef[3 * BC + cl] * (t2v - ecoef[2 * BC + cl] * t1v));
+        }
+      }
+    }
+  }
+}
+
+template <int PRO, bool ACC>
+int launch_bwd(const CxConv& p, float* dw, hipStream_t st) {
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + BM - 1) / BM);
+  const int c_tiles = (p.N + BC - 1) / BC;
+  int splits = 1024 / c_tiles;                       // ~4 workgroups per CU
+  if (splits < 1) splits = 1;
+  if (splits > m_tiles) splits = m_tiles;
+  const int tps = (m_tiles + splits - 1) / splits;
+  splits = (m_tiles + tps - 1) / tps;
+  const size_t smem = COEF_BYTES + W_BYTES + A_BYTES + 2 * XH_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_kernel<PRO, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL((pw_bwd_kernel<PRO, ACC>), dim3(c_tiles * splits), dim3(256), smem, st, p, dw, (int)M, c_tiles, tps);
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" int cx_conv1x1_dgrad_wgrad(const CxConv* pp, float* dw, void* stream) {
+  if (!pp || !dw) return CX_EINVAL;
+  const CxConv& p = *pp;
+  if (!p.x || !p.w || !p.y || !p.ex || !p.e_sc || !p.e_sh || !p.e_mu || !p.e_r || !p.e_scale || !p.stat_sum || !p.stat_sq) return CX_EINVAL;
+  if (p.mode != CX_MODE_CONV || p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0 || p.tstride > 1) return CX_EUNSUPPORTED;
+  if (p.epilogue != CX_EPI_MASK || p.K != KD || (p.N % 8) || p.N <= 0) return CX_EUNSUPPORTED;
+  if (p.prologue != CX_PRO_AFFINE2 && p.prologue != CX_PRO_NONE) return CX_EUNSUPPORTED;
+  if (p.prologue == CX_PRO_AFFINE2 && (!p.x2 || !p.pa || !p.pb || !p.pc || (p.ldx2 % 8) || !aligned16(p.x2))) return CX_EINVAL;
+  if (p.B <= 0 || p.Ho != p.H || p.Wo != p.W || (long long)p.B * p.H * p.W >= (1ll << 31)) return CX_ESHAPE;
+  if ((p.ldx % 8) || (p.ldy % 8) || (p.ldex % 8) || p.ldx < KD || !aligned16(p.x) || !aligned16(p.y) || !aligned16(p.ex) || !aligned16(p.w))
+    return CX_EALIGN;
+  if (p.stat_replicas < 0 || (p.stat_replicas > 1 && p.stat_rstride < p.N)) return CX_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (p.prologue == CX_PRO_AFFINE2)
+    return p.accumulate ? launch_bwd<CX_PRO_AFFINE2, true>(p, dw, st) : launch_bwd<CX_PRO_AFFINE2, false>(p, dw, st);
+  return p.accumulate ? launch_bwd<CX_PRO_NONE, true>(p, dw, st) : launch_bwd<CX_PRO_NONE, false>(p, dw, st);
+}

@@ -20,9 +20,21 @@ def _nhwc(t):
     return B, H, W, Cc, sw
 
 
-def conv_gemm(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
-              pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
-              e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1, stat_replicas=1, stat_rstride=0):
+def conv_gemm(x, w_packed, y, *, fused_dw=None, **kw):
+    """cx_conv_gemm; with `fused_dw` (fp32 OIHW gradient of the forward 1x1 weight) cx_conv1x1_dgrad_wgrad instead: the input
+    gradient with the mask epilogue AND the weight gradient of the same bottleneck convolution in one pass."""
+    p = _conv_params(x, w_packed, y, **kw)
+    if fused_dw is None:
+        check(lib().cx_conv_gemm(C.byref(p), stream_ptr()), "cx_conv_gemm")
+    else:
+        require_cuda(fused_dw)
+        assert fused_dw.dtype == torch.float32 and fused_dw.is_contiguous()
+        check(lib().cx_conv1x1_dgrad_wgrad(C.byref(p), ptr(fused_dw), stream_ptr()), "cx_conv1x1_dgrad_wgrad")
+
+
+def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
+                 pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
+                 e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1, stat_replicas=1, stat_rstride=0):
     require_cuda(x, w_packed, y)
     p = CxConv()
     B, H, W, Cx, ldx = _nhwc(x)
@@ -46,7 +58,8 @@ def conv_gemm(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV,
         assert ex.shape == y.shape
         p.ex, p.ldex = ptr(ex), _nhwc(ex)[4]
     p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale = ptr(e_sc), ptr(e_sh), ptr(e_mu), ptr(e_r), ptr(e_scale)
-    check(lib().cx_conv_gemm(C.byref(p), stream_ptr()), "cx_conv_gemm")
+    p._keep = (x, w_packed, y, pa, pb, pc, x2, stat_sum, stat_sq, ex, e_sc, e_sh, e_mu, e_r, e_scale)      # keep the views alive
+    return p
 
 
 def conv_wgrad(g, x, dw, *, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, g_prologue=PRO_NONE, g2=None, ga=None, gb=None,

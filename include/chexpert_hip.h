@@ -100,6 +100,12 @@ int cx_conv_gemm(const CxConv* p, void* stream);
 /* weight gradient (autograd of the same convs)                                                   */
 int cx_conv_wgrad(const CxWgrad* p, void* stream);
 
+/* Input gradient AND weight gradient of the dense-layer bottleneck 1x1 convolution in one pass over dZ and the activation
+ * slice (K = 128 gradient channels, CX_EPI_MASK): p as for cx_conv_gemm (p->ex = the activation slice x, p->e_sc / p->e_sh its
+ * BatchNorm scale / shift), and dW[n][c] += sum_m dZ[m][n] * relu(x[m][c]*e_sc[c] + e_sh[c]) into the fp32 OIHW gradient
+ * dw (128, N, 1, 1) -- the same result as cx_conv_gemm followed by cx_conv_wgrad with x_prologue = AFFINE_RELU(e_sc, e_sh). */
+int cx_conv1x1_dgrad_wgrad(const CxConv* p, float* dw, void* stream);
+
 /* OIHW fp32 -> packed bf16.  transpose=0: [tap][O][I] (forward);  transpose=1: [tap'][I][O] with
  * taps rotated by 180 degrees (input-gradient of a stride-1 conv).  stem=1: (64,3,7,7) -> [ky][O][8*4].  */
 int cx_pack_weights(const float* w_oihw, void* packed, int O, int I, int kh, int kw, int transpose, int stem,

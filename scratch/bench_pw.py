@@ -41,6 +41,13 @@ for hw, ct, cins in shapes:
                                               stat_rstride=1024))
             by = M * (512 + cin * 6)
             print("dgrad hw=%2d cin=%4d %8.1f us  %5.2f TB/s" % (hw, cin, us, by / us / 1e6), flush=True)
+        if 'fused' in kinds:
+            us = timeit(lambda: ops.conv_gemm(dz2, wf, gbuf[..., :cin], N=cin, prologue=ops.PRO_AFFINE2, x2=y1, pa=ones, pb=zeros, pc=zeros,
+                                              epilogue=ops.EPI_MASK, ex=buf[..., :cin], e_sc=ones, e_sh=zeros, e_mu=zeros, e_r=ones,
+                                              e_scale=ones, stat_sum=st[0], stat_sq=st[1], accumulate=True, stat_replicas=R,
+                                              stat_rstride=1024, fused_dw=dw))
+            by = M * (512 + cin * 6)
+            print("fused hw=%2d cin=%4d %8.1f us  %5.2f TB/s" % (hw, cin, us, by / us / 1e6), flush=True)
         if 'wgrad' in kinds:
             us = timeit(lambda: ops.conv_wgrad(dz2, buf[..., :cin], dw, g_prologue=ops.PRO_AFFINE2, g2=y1, ga=ones, gb=zeros, gc=zeros,
                                                x_prologue=ops.PRO_AFFINE_RELU, pa=ones, pb=zeros))

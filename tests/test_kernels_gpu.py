@@ -481,3 +481,42 @@ def test_wgrad_stem_affine2_odd_pixel_count(dev):
     ops.conv_wgrad(ub, ops.nchw3_to_nhwc4(xs.to(dev)), dw, mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=vb, ga=ga.to(dev),
                    gb=gb_.to(dev), gc=gc.to(dev), splits=5)
     close(dw.cpu(), want, rel=2e-3, what="dW stem affine2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pro,acc,B,H,W,N", [(2, True, 2, 9, 10, 96), (0, False, 1, 5, 5, 8), (2, True, 8, 127, 129, 264)])
+def test_fused_1x1_dgrad_wgrad_equals_separate_kernels(dev, pro, acc, B, H, W, N):
+    """cx_conv1x1_dgrad_wgrad = input gradient with the mask epilogue (cx_conv_gemm) + weight gradient with the BN-ReLU input
+    prologue (cx_conv_wgrad) of the bottleneck 1x1 convolution, against a torch reference of both."""
+    from chexpert_amd import ops
+    K = 128
+    ub, u = nhwc_buf(120, B, H, W, K, dev)
+    vb, v = nhwc_buf(121, B, H, W, K, dev)
+    exb, ex = nhwc_buf(122, B, H, W, N + 8, dev)
+    oldb, old = nhwc_buf(123, B, H, W, N + 8, dev)
+    w = bf(rnd(124, (K, N, 1, 1), -0.1, 0.1))                          # forward weight (O = K = 128, I = N)
+    pa, pb, pc = rnd(125, (K,), 0.5, 1.5), rnd(126, (K,), -0.3, 0.3), rnd(127, (K,), -0.2, 0.2)
+    e_sc, e_sh = rnd(128, (N,), -0.3, 1.5), rnd(129, (N,), -0.5, 0.5)
+    e_mu, e_r, e_scale = rnd(130, (N,), -0.5, 0.5), rnd(131, (N,), 0.5, 2.0), rnd(132, (N,), -0.3, 1.5)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    dy = bf(u * cv(pa) + v * cv(pb) + cv(pc)) if pro == 2 else u
+    acc_ref = F.conv_transpose2d(dy, w)
+    exs = ex[:, :N]
+    pre = exs * cv(e_sc) + cv(e_sh)
+    dz = torch.where(pre > 0, acc_ref, torch.zeros(()))
+    want_g = cv(e_scale) * dz + (old[:, :N] if acc else 0)
+    S1 = dz.double().sum((0, 2, 3)).float()
+    S2 = (dz * (exs - cv(e_mu)) * cv(e_r)).double().sum((0, 2, 3)).float()
+    want_dw = torch.nn.grad.conv2d_weight(bf(F.relu(pre)), (K, N, 1, 1), dy)
+    R = 4
+    st = torch.zeros(2, R, N, device=dev)
+    dw = torch.zeros(K, N, 1, 1, device=dev)
+    kw = dict(prologue=ops.PRO_AFFINE2, x2=vb, pa=pa.to(dev), pb=pb.to(dev), pc=pc.to(dev)) if pro == 2 else {}
+    ops.conv_gemm(ub, ops.pack_weights(w.to(dev), transpose=True), oldb[..., :N], N=N, epilogue=ops.EPI_MASK, ex=exb[..., :N],
+                  e_sc=e_sc.to(dev), e_sh=e_sh.to(dev), e_mu=e_mu.to(dev), e_r=e_r.to(dev), e_scale=e_scale.to(dev), stat_sum=st[0],
+                  stat_sq=st[1], accumulate=acc, stat_replicas=R, stat_rstride=N, fused_dw=dw, **kw)
+    close(to_nchw(oldb[..., :N]), want_g, rel=8e-3, what="g")
+    assert torch.equal(to_nchw(oldb[..., N:]), old[:, N:]), "wrote outside the slice"
+    close(st[0].sum(0).cpu(), S1, rel=2e-3, what="S1")
+    close(st[1].sum(0).cpu(), S2, rel=3e-3, what="S2")
+    close(dw.cpu(), want_dw, rel=3e-3, what="dW")
