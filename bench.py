@@ -88,13 +88,16 @@ class KernelTimer:
             if not self.enabled:
                 return og(x, w, y, **kw)
             tag = self.gemm_kernel_name(x, kw)
-            if kw.get("fused_dw") is not None:
-                tag = "pw_bwd_kernel<%d, %s>" % (kw.get("prologue", 0), "true" if kw.get("accumulate") else "false")
-            if self.only is not None and tag != self.only:
-                return og(x, w, y, **kw)
             mi, ci = self._dims(x)
             mo, co = self._dims(y)
             alg = 2.0 * (mi * ci + mo * co)          # |X| + |Y| elements, bf16 (SURVEY 8d rule, per kernel)
+            if kw.get("fused_dw") is not None:       # conv1x1_bwd.hip launch_bwd: 128-channel tiles for wide slices / big maps
+                wide = kw["N"] >= 128
+                tag = "pw_bwd_kernel<%d, %s, %d>" % (kw.get("prologue", 0), "true" if kw.get("accumulate") else "false",
+                                                     128 if wide else 64)
+                alg += 2.0 * mo * co                 # the weight-gradient half also needs the layer input (|dZ| counted once)
+            if self.only is not None and tag != self.only:
+                return og(x, w, y, **kw)
             return self._timed(tag, alg, og, x, w, y, **kw)
 
         def conv_wgrad(g, x, dw, **kw):

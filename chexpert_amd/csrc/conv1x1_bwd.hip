@@ -14,19 +14,17 @@
 //     32-channel pixel-major images (64-B rows) for the second product;
 //   * dW (128 x 64 fp32) and the channel sums S1, S2 live in registers across all tiles of the workgroup: one burst of
 //     atomics at the end.  The channel tiles of one pixel range are neighbours in the grid and share dZ in L2.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 constexpr int KD = 128;                 // dZ channels (n)
 constexpr int BM = 128;                 // pixels per tile
-constexpr int BC = 64;                  // buffer channels per workgroup (c)
 constexpr int PITCH = KD * 2 + 16;      // 272 B
 constexpr int A_BYTES = BM * PITCH;
-constexpr int W_BYTES = BC * PITCH;
 constexpr int XH_PITCH = 64;            // 32 channels per image row
 constexpr int XH_BYTES = BM * XH_PITCH; // one 32-channel image
-constexpr int COEF_BYTES = (5 * BC + 3 * KD) * 4;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -54,14 +52,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int k0, i
   return r;
 }
 
-template <int PRO, bool ACC>
-__global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* __restrict__ dw, const int M, const int c_tiles,
-                                                       const int tiles_per_split) {
+// BC = buffer channels per workgroup: 64 (256 threads, two workgroups per CU) or 128 (512 threads, one per CU: dZ is re-read by
+// half as many channel tiles, for the layers with many input channels)
+template <int PRO, bool ACC, int BC>
+__global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const CxConv p, float* __restrict__ dw, const int M,
+                                                                         const int c_tiles, const int tiles_per_split) {
+  constexpr int NT = BC * 4;
+  constexpr int W_BYTES = BC * PITCH;
+  constexpr int COEF_BYTES = (5 * BC + 3 * KD) * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ecoef = reinterpret_cast<float*>(smem);               // e_sc, e_sh, e_mu, e_r, e_scale [64] each, then pa, pb, pc [128]
   char* Wt = smem + COEF_BYTES;                                 // [64 c][272 B]
   char* At = Wt + W_BYTES;                                      // [128 px][272 B]
-  char* Xh = At + A_BYTES;                                      // [2][128 px][64 B]
+  char* Xh = At + A_BYTES;                                      // [BC/32][128 px][64 B]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5;
@@ -89,11 +92,12 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
     ecoef[4 * BC + tid] = ok ? p.e_scale[n] : 0.f;
   }
   const int q = tid & 15, r0 = tid >> 4;
+  constexpr int RS = NT / 16;                                   // rows covered by one pass of the workgroup
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = c0 + r0 + 16 * i;
+  for (int i = 0; i < BC / RS; ++i) {
+    const int n = c0 + r0 + RS * i;
     const uint4 v = *reinterpret_cast<const uint4*>(Wp + (size_t)(n < p.N ? n : 0) * KD + q * 8);
-    *reinterpret_cast<uint4*>(Wt + (r0 + 16 * i) * PITCH + q * 16) = n < p.N ? v : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(Wt + (r0 + RS * i) * PITCH + q * 16) = n < p.N ? v : make_uint4(0, 0, 0, 0);
   }
   if (PRO == CX_PRO_AFFINE2 && tid < KD) {
     ecoef[5 * BC + tid] = p.pa[tid];
@@ -103,7 +107,10 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
   const float* aco = ecoef + 5 * BC + q * 8;                    // AFFINE2 vectors of this thread's dZ channel chunk (LDS)
   __syncthreads();                                              // the dZ staging of the first tile reads them
 
-  const int wn2 = wave >> 1, wc = wave & 1;                     // weight-gradient tiles of this wave: n sub-tiles 2*wn2, 2*wn2+1; c sub-tile wc
+  // input gradient: wave = (pixel sub-tile pw, 64-channel half ch); weight gradient: two 32x32 tiles of dW per wave
+  const int pw = wave & 3, ch = wave >> 2;
+  const int wn_[2] = {BC == 64 ? (wave >> 1) * 2 : (wave & 3), BC == 64 ? (wave >> 1) * 2 + 1 : (wave & 3)};      // n sub-tiles
+  const int wc_[2] = {BC == 64 ? (wave & 1) : (wave >> 2) * 2, BC == 64 ? (wave & 1) : (wave >> 2) * 2 + 1};      // c sub-tiles
   f32x16 accw[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
   for (int mt = t0; mt < t1; ++mt) {
     const int m0 = mt * BM;
     // ---- read-modify-write operands of this lane's pixel (requested first: the longest round trip)
-    const int m = m0 + wave * 32 + lrow;
+    const int m = m0 + pw * 32 + lrow;
     const bool pok = m < M;
     const int mc = pok ? m : M - 1;
     U128 xv[2][2], old[2][2];
@@ -128,30 +135,29 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
-        const int n = c0 + j * 32 + 8 * (2 * cc + lh);
+        const int n = c0 + ch * 64 + j * 32 + 8 * (2 * cc + lh);
         const int ncl = n < p.N ? n : 0;
         xv[j][cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl);
         if (ACC) old[j][cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl);
         else old[j][cc].u = make_uint4(0, 0, 0, 0);
       }
-    // ---- dZ tile -> LDS (two batches of four rows per thread)
+    // ---- dZ tile -> LDS (batches of four rows per thread)
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
+    for (int hb = 0; hb < BM / (4 * RS); ++hb) {
       uint4 ru[4], rv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int mm = m0 + r0 + 16 * (hb * 4 + i);
+        const int mm = m0 + r0 + RS * (hb * 4 + i);
         const int mmc = mm < M ? mm : M - 1;
         ru[i] = *reinterpret_cast<const uint4*>(X + (size_t)mmc * p.ldx + q * 8);
         if (PRO == CX_PRO_AFFINE2) rv[i] = *reinterpret_cast<const uint4*>(X2 + (size_t)mmc * p.ldx2 + q * 8);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = r0 + 16 * (hb * 4 + i);
+        const int row = r0 + RS * (hb * 4 + i);
+        // branch-free: a branch on the row bound lets the compiler sink the loads under it, one vmcnt(0) each
         U128 o;
-        if (m0 + row >= M) {
-          o.u = make_uint4(0, 0, 0, 0);
-        } else if (PRO == CX_PRO_NONE) {
+        if (PRO == CX_PRO_NONE) {
           o.u = ru[i];
         } else {
           U128 u, v;
@@ -160,6 +166,8 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
 #pragma unroll
           for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
         }
+        const unsigned keep = m0 + row < M ? 0xffffffffu : 0u;
+        o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
         *reinterpret_cast<uint4*>(At + row * PITCH + q * 16) = o.u;
       }
     }
@@ -172,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) accd[j][r] = 0.f;
     {
-      const char* Ab = At + (wave * 32 + lrow) * PITCH + lh * 16;
-      const char* Wb = Wt + lrow * PITCH + lh * 16;
+      const char* Ab = At + (pw * 32 + lrow) * PITCH + lh * 16;
+      const char* Wb = Wt + (ch * 64 + lrow) * PITCH + lh * 16;
 #pragma unroll
       for (int kk = 0; kk < KD / 16; ++kk) {
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + kk * 32);
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
-        const int cl = j * 32 + 8 * (2 * cc + lh);
+        const int cl = ch * 64 + j * 32 + 8 * (2 * cc + lh);
         const int n = c0 + cl;
         float v[8];
 #pragma unroll
@@ -219,34 +227,42 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
           xh.e[e] = f2bf(on ? pre : 0.f);
         }
         if (pok && n < p.N) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + n) = o.u;
-        *reinterpret_cast<uint4*>(Xh + j * XH_BYTES + (wave * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
+        *reinterpret_cast<uint4*>(Xh + (ch * 2 + j) * XH_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
       }
     __syncthreads();                              // relu(bn(x)) tile visible
 
     // ---- weight gradient: dW[n][c] += sum over the 128 pixels of the tile (k = pixel, transposing LDS reads)
 #pragma unroll
     for (int kk = 0; kk < BM / 16; ++kk) {
-      const bf16x8 bfr = tr_frag(Xh + wc * XH_BYTES, XH_PITCH, kk * 16, 0, lane);
+      if (BC == 64) {                               // one c sub-tile, two n sub-tiles
+        const bf16x8 bfr = tr_frag(Xh + wc_[0] * XH_BYTES, XH_PITCH, kk * 16, 0, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bf16x8 af = tr_frag(At, PITCH, kk * 16, (wn2 * 2 + i) * 32, lane);
-        accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 af = tr_frag(At, PITCH, kk * 16, wn_[i] * 32, lane);
+          accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+        }
+      } else {                                      // one n sub-tile, two c sub-tiles
+        const bf16x8 af = tr_frag(At, PITCH, kk * 16, wn_[0] * 32, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 bfr = tr_frag(Xh + wc_[i] * XH_BYTES, XH_PITCH, kk * 16, 0, lane);
+          accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+        }
       }
     }
     __syncthreads();                              // both LDS tiles free for the next pixel tile
   }
 
   // ---- one burst of atomics per workgroup: dW tile, then S1 / S2
-  {
-    const int c = c0 + wc * 32 + lrow;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = c0 + wc_[i] * 32 + lrow;
     if (c < p.N) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = (wn2 * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          atomicAdd(dw + (size_t)n * p.N + c, accw[i][r]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int n = wn_[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        atomicAdd(dw + (size_t)n * p.N + c, accw[i][r]);
+      }
     }
   }
   {
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
           if (lrow == 8 * cc + e) { t1v = a; t2v = b; }
         }
       if (lrow < 16) {
-        const int cl = j * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
+        const int cl = ch * 64 + j * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
         const int n = c0 + cl;
         if (n < p.N) {
           atomicAdd(&p.stat_sum[rep + n], t1v);
@@ -274,25 +290,32 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_kernel(const CxConv p, float* _
   }
 }
 
-template <int PRO, bool ACC>
-int launch_bwd(const CxConv& p, float* dw, hipStream_t st) {
+template <int PRO, bool ACC, int BC>
+int launch_bwd_bc(const CxConv& p, float* dw, hipStream_t st) {
   const long long M = (long long)p.B * p.Ho * p.Wo;
   const int m_tiles = (int)((M + BM - 1) / BM);
   const int c_tiles = (p.N + BC - 1) / BC;
-  int splits = 1024 / c_tiles;                       // ~4 workgroups per CU
+  int splits = (BC == 64 ? 1024 : 512) / c_tiles;    // ~4 (2) workgroups per CU in the grid
   if (splits < 1) splits = 1;
   if (splits > m_tiles) splits = m_tiles;
   const int tps = (m_tiles + splits - 1) / splits;
   splits = (m_tiles + tps - 1) / tps;
-  const size_t smem = COEF_BYTES + W_BYTES + A_BYTES + 2 * XH_BYTES;
+  const size_t smem = (5 * BC + 3 * KD) * 4 + BC * PITCH + A_BYTES + (BC / 32) * XH_BYTES;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_kernel<PRO, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_kernel<PRO, ACC, BC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL((pw_bwd_kernel<PRO, ACC>), dim3(c_tiles * splits), dim3(256), smem, st, p, dw, (int)M, c_tiles, tps);
+  hipLaunchKernelGGL((pw_bwd_kernel<PRO, ACC, BC>), dim3(c_tiles * splits), dim3(BC * 4), smem, st, p, dw, (int)M, c_tiles, tps);
   return launch_status();
+}
+
+template <int PRO, bool ACC>
+int launch_bwd(const CxConv& p, float* dw, hipStream_t st) {
+  static const int force = []() { const char* e = getenv("CX_PW_BWD_BC"); return e ? atoi(e) : 0; }();
+  const bool wide = force ? force == 128 : p.N >= 128;  // measured crossover
+  return wide ? launch_bwd_bc<PRO, ACC, 128>(p, dw, st) : launch_bwd_bc<PRO, ACC, 64>(p, dw, st);
 }
 
 }  // namespace
