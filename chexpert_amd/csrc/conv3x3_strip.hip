@@ -1,3 +1,4 @@
+#include <cstdlib>
 // 3x3 stride-1 pad-1 convolutions of the dense layers as persistent "strip" kernels (gfx950).
 //
 // The generic implicit GEMM re-stages its A tile once per tap (9x L2 reads, two MFMAs per barrier at
@@ -440,14 +441,20 @@ __device__ __forceinline__ bf16x8 tr2(const char* a0, const char* a1) {
   return r;
 }
 
-constexpr int NCHW = 5;         // 16-B chunks per thread and step (192 threads), for the input rows and for the gradient rows
+constexpr int NCHW1 = 5;        // 16-B chunks per thread and step (192 threads), for the input rows and for the gradient rows
+constexpr int NCHW4 = 3;        // the same with four wave groups (768 threads, <= 168 VGPRs)
 constexpr int WP = 64;          // bytes per ring / strip pixel: 32 channels; rows of a half-wave hit disjoint bank quarters
 
 // Workgroup = (32-input-channel tile ct, pixel range), 3 waves: wave dy owns the three taps (dy, 0..2) of
 // dW[32 n][32 c] (48 accumulator registers), so nothing is reduced across waves and ~47 KB of LDS / ~170
 // VGPRs let 2-3 workgroups share a CU (their staging and MFMA phases overlap).  At the end the tile is
 // transposed through LDS and added to the OIHW gradient with atomics over 1152-B contiguous runs.
-__global__ __launch_bounds__(192) void conv3x3_strip_wgrad_kernel(
+//
+// NG > 1 (small maps, one workgroup per CU): NG groups of three waves share one staged strip and split its 16-pixel
+// k-steps round-robin, so a step can be NG times longer (up to a whole image: more bytes in flight per barrier) while its
+// MFMA and staging phases shrink by NG; the groups' tiles meet in LDS before the atomics.
+template <int NG, int NCHW>
+__global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
     const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const StripGeo g) {
@@ -458,12 +465,14 @@ __global__ __launch_bounds__(192) void conv3x3_strip_wgrad_kernel(
   char* ring = smem + 160 * 4;                                     // [(Q+2)][64 B]
   char* gst = ring + (size_t)(Q + 2) * WP;                         // [nk*16][64 B]
   float* red = reinterpret_cast<float*>(ring);                     // [32 n][32 c][9] aliased on ring+strip at the end
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave = kernel row dy
+  constexpr int NTHR = 192 * NG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) % 3, grp = (tid >> 6) / 3;           // wave = kernel row dy, grp = k-step residue
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int ct = wg & 3, split = wg >> 2;                          // the 4 channel tiles of a pixel range are neighbours
   const int c0 = ct * 32;
 
-  for (int i = tid; i < ((Q + 2) + nk * 16) * (WP / 16); i += 192) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < ((Q + 2) + nk * 16) * (WP / 16); i += NTHR) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
   if (tid < 32) {
     coef[tid] = pa[c0 + tid];
     coef[32 + tid] = pb[c0 + tid];
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(192) void conv3x3_strip_wgrad_kernel(
   int crow[NCHW], cpx[NCHW], cc8[NCHW];
 #pragma unroll
   for (int i = 0; i < NCHW; ++i) {
-    const int cid = tid + 192 * i;
+    const int cid = tid + NTHR * i;
     crow[i] = cid / cpr;
     const int rem = cid - crow[i] * cpr;
     cpx[i] = rem >> 2;
@@ -582,10 +591,10 @@ __global__ __launch_bounds__(192) void conv3x3_strip_wgrad_kernel(
     if (slot0 < 0) slot0 += R + 2;
     const int ws = slot0 * P;
     // running byte offsets of this lane's two pixel rows in kernel row dy = wave
-    int o0 = wrapq(wrapq(ws + lrow + wave * P, Q), Q) * WP;
-    int o1 = wrapq(wrapq(ws + lrow + 4 + wave * P, Q), Q) * WP;
+    int o0 = ((ws + lrow + wave * P + grp * 16) % Q) * WP;
+    int o1 = ((ws + lrow + 4 + wave * P + grp * 16) % Q) * WP;
 #pragma unroll 2
-    for (int kk = 0; kk < nk; ++kk) {
+    for (int kk = grp; kk < nk; kk += NG) {
       const char* gbase = gst + (size_t)(kk * 16 + lrow) * WP + gcol;
       const bf16x8 af = tr2(gbase, gbase + 4 * WP);
 #pragma unroll
@@ -593,10 +602,10 @@ __global__ __launch_bounds__(192) void conv3x3_strip_wgrad_kernel(
         const bf16x8 bfr = tr2(ring + o0 + gcol + dx * WP, ring + o1 + gcol + dx * WP);
         acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[dx], 0, 0, 0);
       }
-      o0 += 16 * WP;
-      if (o0 >= QB) o0 -= QB;
-      o1 += 16 * WP;
-      if (o1 >= QB) o1 -= QB;
+      o0 += 16 * NG * WP;
+      while (o0 >= QB) o0 -= QB;
+      o1 += 16 * NG * WP;
+      while (o1 >= QB) o1 -= QB;
     }
     __syncthreads();
     have_window = true;
@@ -605,15 +614,20 @@ __global__ __launch_bounds__(192) void conv3x3_strip_wgrad_kernel(
   }
 
   // ---- transpose through LDS into OIHW order, then atomics over contiguous runs (288 floats per output channel)
+  for (int round = 0; round < NG; ++round) {
+    if (grp == round) {
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx)
+      for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      red[(n * 32 + (lane & 31)) * 9 + wave * 3 + dx] = acc[dx][r];
+        for (int r = 0; r < 16; ++r) {
+          const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          float* slot = red + (n * 32 + (lane & 31)) * 9 + wave * 3 + dx;
+          *slot = round == 0 ? acc[dx][r] : *slot + acc[dx][r];
+        }
     }
-  __syncthreads();
-  for (int idx = tid; idx < 32 * 288; idx += 192) {
+    __syncthreads();
+  }
+  for (int idx = tid; idx < 32 * 288; idx += NTHR) {
     const int n = idx / 288, i = idx - n * 288;
     atomicAdd(dw + ((size_t)n * 128 + c0) * 9 + i, red[idx]);
   }
@@ -691,21 +705,46 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   if (p.K != 128 || p.N != 32 || p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
   if (p.g_prologue != CX_PRO_NONE && p.g_prologue != CX_PRO_AFFINE2) return 0;
   if (p.W + 2 > 128 || p.W < 4) return 0;
+  const long long px = (long long)p.B * p.H * p.W;
+  // small maps: four wave groups per workgroup on strips of up to 880 flat pixels, one workgroup per CU
+  {
+    int flat = NCHW4 * 768 / (p.W * 4) * (p.W + 2);          // rows the staging registers hold
+    if (flat > 880) flat = 880;
+    StripGeo g = make_geo(p.B, p.H, p.W, 64, 1, flat);
+    const int nk = (g.R * g.P + 15) / 16;
+    size_t smem = 160 * 4 + (size_t)(g.Q + 2) * WP + (size_t)nk * 16 * WP;
+    if (smem < 160 * 4 + 32 * 288 * 4) smem = 160 * 4 + 32 * 288 * 4;
+    static const bool off = getenv("CX_SW_NG1") != nullptr;
+    if (!off && g.R * p.W * 4 <= NCHW4 * 768 && 2 * p.W * 4 <= NCHW4 * 768 && g.Q >= 64 && smem <= 150 * 1024) {
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_wgrad_kernel<4, NCHW4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr = true;
+      }
+      const int total = g.B * g.spi;
+      const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+      hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<4, NCHW4>), dim3(splits * 4), dim3(768), smem, st, (const bf16*)p.g, p.ldg,
+                         (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx,
+                         p.pa, p.pb, p.dw, g);
+      *handled = true;
+      return launch_status();
+    }
+  }
   // pixel-range splits: >= 2 workgroups per CU over the 4 channel tiles, few enough that the final atomics
   // (147 KB per split) stay small next to the activations (384 B per pixel)
-  const long long px = (long long)p.B * p.H * p.W;
   int target = (int)(px / 3200);
   if (target < 64) target = 64;
   if (target > 192) target = 192;
   StripGeo g = make_geo(p.B, p.H, p.W, target, 1, 256);
-  if (g.R * p.W * 4 > NCHW * 192 || 2 * p.W * 4 > NCHW * 192 || g.Q < 16) return 0;
+  if (g.R * p.W * 4 > NCHW1 * 192 || 2 * p.W * 4 > NCHW1 * 192 || g.Q < 16) return 0;
   const int nk = (g.R * g.P + 15) / 16;
   size_t smem = 160 * 4 + (size_t)(g.Q + 2) * WP + (size_t)nk * 16 * WP;
   if (smem < 160 * 4 + 32 * 288 * 4) smem = 160 * 4 + 32 * 288 * 4;
   if (smem > 64 * 1024) return 0;
   const int total = g.B * g.spi;
   const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
-  hipLaunchKernelGGL(conv3x3_strip_wgrad_kernel, dim3(splits * 4), dim3(192), smem, st, (const bf16*)p.g, p.ldg, (const bf16*)p.g2,
+  hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<1, NCHW1>), dim3(splits * 4), dim3(192), smem, st, (const bf16*)p.g, p.ldg, (const bf16*)p.g2,
                      p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx, p.pa, p.pb, p.dw, g);
   *handled = true;
   return launch_status();
