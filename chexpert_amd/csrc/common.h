@@ -16,6 +16,7 @@ union U128 {
   bf16x8 h;
   bf16 e[8];
 };
+
 union U64 {
   uint2 u;
   bf16x4 h;

@@ -12,6 +12,7 @@
 //     pixel m + dy*(W+2) + dx, two mirror pixels past the end cover the wrap;
 //   * the R new rows of the next step are requested before the MFMAs of the current one (<= 7 x 16 B per thread) and are
 //     normalised (BN + ReLU) while they are written to the ring; two barriers per step.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -87,6 +88,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   float csc[8], csh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { csc[j] = sc[cc8 * 8 + j]; csh[j] = sh[cc8 * 8 + j]; }
+  // retire these loads here: a load still pending at the loop header makes every first use inside the loop a vmcnt(0), which
+  // drains the DEPTH row sets in flight each step
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(csc[j]), "v"(csh[j]));
   // rows [y0, y0+n) of image b -> registers; unconditional loads on clamped addresses, validity applied when staged
   auto issue_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int b, int y0, int n) __attribute__((always_inline)) {
 #pragma unroll
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
         U128 o, v;
         v.u = pre[i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(pv[i] ? fmaxf(fmaf(bf2f(v.e[j]), csc[j], csh[j]), 0.f) : 0.f);
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), csc[j], csh[j]), 0.f));
+        { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
         *reinterpret_cast<uint4*>(ring + (size_t)pos * XP + cc8 * 16) = o.u;
         if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * XP + cc8 * 16) = o.u;   // mirror of pixels 0,1
@@ -116,9 +122,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
     }
   };
   // new rows of step v (a continuation step of its image inside this workgroup's range), else a harmless clamped load
+  int ulim = u1;              // end of the pass being walked (below)
   auto issue_step = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int v) __attribute__((always_inline)) {
     const int bv = v / g.spi, sv = v - bv * g.spi;
-    const bool ok = v < u1 && sv != 0;
+    const bool ok = v < ulim && sv != 0;
     issue_rows(pre, pv, ok ? bv : 0, ok ? sv * R + 1 : 0, ok ? R : 0);
   };
 
@@ -135,17 +142,6 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
     uint4 (&cur)[NCH] = pre[k];
     bool (&cv)[NCH] = pv[k];
     const int b = u / g.spi, yc = (u - b * g.spi) * R;
-    if (u == u0 || yc == 0) {
-      // first step of an image (or of this workgroup): build the window rows yc-1, yc synchronously, refill the pipeline
-      base_row = yc - 1;
-      issue_rows(cur, cv, b, yc - 1, 1);
-      write_rows(cur, cv, yc - 1, 1);
-      issue_rows(cur, cv, b, yc, 1);
-      write_rows(cur, cv, yc, 1);
-      issue_rows(cur, cv, b, yc + 1, R);
-#pragma unroll
-      for (int d = 1; d < DEPTH; ++d) issue_step(pre[(k + d) % DEPTH], pv[(k + d) % DEPTH], u + d);
-    }
     write_rows(cur, cv, yc + 1, R);
     __syncthreads();                                   // the window of this step is complete
     issue_step(cur, cv, u + DEPTH);                    // in flight under the MFMAs of this and the next DEPTH-1 steps
@@ -159,27 +155,36 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const int m = s * 32 + lrow;
       const int pix = min(m, R * P - 1);
-      // one tap per iteration (16 fragment reads, 8 MFMAs): unrolling all 72 lets the scheduler hoist every read and spill
-#pragma unroll 1
-      for (int dy = 0; dy < 3; ++dy) {
-        const char* ap = ring + (size_t)wrapq(wrapq(ws + pix + dy * P, Q), Q) * XP + lh * 16;
-#pragma unroll 1
-        for (int dx = 0; dx < 3; ++dx) {
-          const char* wp = wbase + (dy * 3 + dx) * 32 * XP;
-          // all 16 fragments of the tap first, then its 8 MFMAs: read-then-multiply pairs expose the LDS latency once per
-          // MFMA (measured 130 cycles per MFMA with one computing wave per SIMD)
-          bf16x8 fa[8], fb[8];
+      // Software pipeline over the nine taps inside the wave: fragment reads run two groups ahead of the MFMAs (three
+      // register sets), so the LDS latency hides under the matrix pipe even when this is the only computing
+      // wave of its SIMD (W = 80: 3 sub-tiles per step for 8 waves).  Read-then-multiply per tap measured 130 cycles per
+      // MFMA; the sched_barriers keep the scheduler from hoisting every read of the unrolled loop (it spilled).
+      const char* ap0 = ring + (size_t)wrapq(wrapq(ws + pix, Q), Q) * XP + lh * 16;
+      const char* ap1 = ring + (size_t)wrapq(wrapq(ws + pix + P, Q), Q) * XP + lh * 16;
+      const char* ap2 = ring + (size_t)wrapq(wrapq(ws + pix + 2 * P, Q), Q) * XP + lh * 16;
+      // the 72 (tap, k-step) products in groups of 3, three register sets: the reads of group g+2 go out before the MFMAs of
+      // group g (6 MFMAs = 192 cycles ahead; 72 fragment registers)
+      constexpr int G = 3, NG = 72 / G;
+      bf16x8 fa[3][G], fb[3][G];
+      auto load_grp = [&](int gi, bf16x8 (&A)[G], bf16x8 (&B)[G]) __attribute__((always_inline)) {
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) {
-            fa[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 32);
-            fb[ks] = *reinterpret_cast<const bf16x8*>(ap + dx * XP + ks * 32);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ks = 0; ks < 8; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], acc, 0, 0, 0);     // D[row = out channel][col = pixel]
-          __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < G; ++j) {
+          const int f = gi * G + j, t = f >> 3, ks = f & 7;
+          const int dy = t / 3, dx = t - dy * 3;
+          A[j] = *reinterpret_cast<const bf16x8*>(wbase + t * 32 * XP + ks * 32);
+          B[j] = *reinterpret_cast<const bf16x8*>((dy == 0 ? ap0 : dy == 1 ? ap1 : ap2) + dx * XP + ks * 32);
         }
+      };
+      load_grp(0, fa[0], fb[0]);
+      load_grp(1, fa[1], fb[1]);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 2 < NG) load_grp(gi + 2, fa[(gi + 2) % 3], fb[(gi + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[gi % 3][j], fb[gi % 3][j], acc, 0, 0, 0);   // D[row = out channel][col = pixel]
+        __builtin_amdgcn_sched_barrier(0);
       }
       const int oy = m / P, ox = m - oy * P;
       const int yy = yc + oy;
@@ -209,10 +214,34 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
     __syncthreads();                                   // every wave is done with the oldest rows of the ring
   };
 
-  for (int u = u0; u < u1; u += DEPTH) {
-    step(u, std::integral_constant<int, 0>());
-    if (DEPTH > 1 && u + 1 < u1) step(u + 1, std::integral_constant<int, 1 % DEPTH>());
-    if (DEPTH > 2 && u + 2 < u1) step(u + 2, std::integral_constant<int, 2 % DEPTH>());
+  // One image (or the part of it in this workgroup's range) at a time: the window rows yc-1, yc of its first step are built
+  // synchronously and the pipeline is refilled outside the step loop.
+  // The range is walked from a per-workgroup offset and wraps (two passes): with every workgroup starting at row 0 of its
+  // own image, all 256 read addresses that differ by multiples of the image size at the same moment.
+  const int rot = u1 - u0 > 1 ? (int)((blockIdx.x * 37u) % (unsigned)(u1 - u0)) : 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+  ulim = pass == 0 ? u1 : u0 + rot;
+  for (int ui = pass == 0 ? u0 + rot : u0; ui < ulim;) {
+    const int b = ui / g.spi, yc = (ui - b * g.spi) * R;
+    const int ue = min(ulim, (b + 1) * g.spi);
+    base_row = yc - 1;
+    auto sync_rows = [&](int y0) __attribute__((always_inline)) {
+      issue_rows(pre[0], pv[0], b, y0, 1);
+      write_rows(pre[0], pv[0], y0, 1);
+    };
+    sync_rows(yc - 1);
+    sync_rows(yc);
+    issue_rows(pre[0], pv[0], b, yc + 1, R);
+#pragma unroll
+    for (int d = 1; d < DEPTH; ++d) issue_step(pre[d], pv[d], ui + d);
+    for (int u = ui; u < ue; u += DEPTH) {
+      step(u, std::integral_constant<int, 0>());
+      if (DEPTH > 1) { if (u + 1 >= ue) break; step(u + 1, std::integral_constant<int, 1 % DEPTH>()); }
+      if (DEPTH > 2) { if (u + 2 >= ue) break; step(u + 2, std::integral_constant<int, 2 % DEPTH>()); }
+    }
+    ui = ue;
+  }
   }
 
   if (stat_sum) {
@@ -335,7 +364,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
         v.u = pg2[i];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          o.e[j] = f2bf(gv[i] ? fmaf(bf2f(u.e[j]), kco[j], fmaf(bf2f(v.e[j]), kco[32 + j], kco[64 + j])) : 0.f);
+          o.e[j] = f2bf(fmaf(bf2f(u.e[j]), kco[j], fmaf(bf2f(v.e[j]), kco[32 + j], kco[64 + j])));
+        { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
         *reinterpret_cast<uint4*>(ring + (size_t)pos * GP + cc4 * 16) = o.u;
         if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * GP + cc4 * 16) = o.u;
@@ -394,27 +424,34 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         const int pix = min(s * 32 + lrow, R * P - 1);
-#pragma unroll 1
-        for (int dy = 0; dy < 3; ++dy) {
-          const char* ap = ring + (size_t)wrapq(wrapq(ws + pix + dy * P, Q), Q) * GP + lh * 16;
-          const char* wp = wbase + (size_t)(dy * 3) * 128 * GP;
-          // one tap per iteration: 2 pixel fragments + 4 weight fragments, 4 MFMAs (the second wave of the SIMD fills the gaps)
-#pragma unroll 1
-          for (int dx = 0; dx < 3; ++dx) {
-            bf16x8 fb[2], fa[2][2];
+        // software pipeline over the nine taps inside the wave (as in the forward kernel): the 6 fragment reads of tap t+1 go
+        // out before the 4 MFMAs of tap t (two register sets)
+        const char* ap0 = ring + (size_t)wrapq(wrapq(ws + pix, Q), Q) * GP + lh * 16;
+        const char* ap1 = ring + (size_t)wrapq(wrapq(ws + pix + P, Q), Q) * GP + lh * 16;
+        const char* ap2 = ring + (size_t)wrapq(wrapq(ws + pix + 2 * P, Q), Q) * GP + lh * 16;
+        bf16x8 fb[2][2], fa[2][2][2];
+        auto load_tap = [&](int t, bf16x8 (&B)[2], bf16x8 (&A)[2][2]) __attribute__((always_inline)) {
+          const int dy = t / 3, dx = t - dy * 3;
+          const char* ap = (dy == 0 ? ap0 : dy == 1 ? ap1 : ap2) + dx * GP;
+          const char* wp = wbase + (size_t)t * 128 * GP;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-              fb[ks] = *reinterpret_cast<const bf16x8*>(ap + dx * GP + ks * 32);
+          for (int ks = 0; ks < 2; ++ks) {
+            B[ks] = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
 #pragma unroll
-              for (int j = 0; j < 2; ++j)
-                fa[ks][j] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(dx * 128 + j * 32) * GP + ks * 32);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][j], fb[ks], acc[j], 0, 0, 0);   // D[channel][pixel]
+            for (int j = 0; j < 2; ++j) A[ks][j] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(j * 32) * GP + ks * 32);
           }
+        };
+        load_tap(0, fb[0], fa[0]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          if (t + 1 < 9) load_tap(t + 1, fb[(t + 1) & 1], fa[(t + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][ks][j], fb[t & 1][ks], acc[j], 0, 0, 0);   // D[channel][pixel]
+          __builtin_amdgcn_sched_barrier(0);
         }
         bf16* yrow = y + (size_t)poff * ldy;
 #pragma unroll
@@ -598,7 +635,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
         U128 o, v;
         v.u = pre[i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(pv[i] ? fmaxf(fmaf(bf2f(v.e[j]), xco[j], xco[128 + j]), 0.f) : 0.f);
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), xco[j], xco[128 + j]), 0.f));
+        { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + xpx[i] + 1;
         *reinterpret_cast<uint4*>(ring + (size_t)pos * WXP + cx8 * 16) = o.u;
         if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * WXP + cx8 * 16) = o.u;   // mirror of pixels 0,1
@@ -625,7 +663,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
         v.u = pg2[i];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          o.e[j] = f2bf(gv[i] ? fmaf(bf2f(u.e[j]), gco[j], fmaf(bf2f(v.e[j]), gco[32 + j], gco[64 + j])) : 0.f);
+          o.e[j] = f2bf(fmaf(bf2f(u.e[j]), gco[j], fmaf(bf2f(v.e[j]), gco[32 + j], gco[64 + j])));
+        { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         *reinterpret_cast<uint4*>(gst + (size_t)(grow[i] * P + gpx[i]) * WGP + cg4 * 16) = o.u;     // pad columns / tail stay zero
       }
     }

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(192, 2) void conv3x3_strip_fwd_kernel(const bf16* _
         v.u = pre[i];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          o.e[j] = f2bf(pv[i] ? fmaxf(fmaf(bf2f(v.e[j]), coef[cc8[i] * 8 + j], coef[128 + cc8[i] * 8 + j]), 0.f) : 0.f);
+          o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[cc8[i] * 8 + j], coef[128 + cc8[i] * 8 + j]), 0.f));
+        { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
         *reinterpret_cast<uint4*>(ring + (size_t)pos * XP_FWD + cc8[i] * 16) = o.u;
         if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * XP_FWD + cc8[i] * 16) = o.u;   // mirror of pixels 0,1
@@ -299,8 +300,9 @@ __global__ __launch_bounds__(192, 2) void conv3x3_strip_dgrad_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float t = fmaf(bf2f(u.e[j]), coef[cc8[i] * 8 + j], fmaf(bf2f(v.e[j]), coef[32 + cc8[i] * 8 + j], coef[64 + cc8[i] * 8 + j]));
-          o.e[j] = f2bf(gv[i] ? t : 0.f);
+          o.e[j] = f2bf(t);
         }
+        { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
         *reinterpret_cast<uint4*>(ring + (size_t)pos * GP + cc8[i] * 16) = o.u;
         if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * GP + cc8[i] * 16) = o.u;
@@ -519,7 +521,8 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
         v.u = pre[i];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          o.e[j] = f2bf(pv[i] ? fmaxf(fmaf(bf2f(v.e[j]), coef[cc8[i] * 8 + j], coef[32 + cc8[i] * 8 + j]), 0.f) : 0.f);
+          o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[cc8[i] * 8 + j], coef[32 + cc8[i] * 8 + j]), 0.f));
+        { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
         *reinterpret_cast<uint4*>(ring + (size_t)pos * WP + cc8[i] * 16) = o.u;
         if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * WP + cc8[i] * 16) = o.u;   // mirror of pixels 0,1
@@ -547,8 +550,9 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float t = fmaf(bf2f(u.e[j]), coef[64 + cc8[i] * 8 + j], fmaf(bf2f(v.e[j]), coef[96 + cc8[i] * 8 + j], coef[128 + cc8[i] * 8 + j]));
-          o.e[j] = f2bf(gv[i] ? t : 0.f);
+          o.e[j] = f2bf(t);
         }
+        { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         *reinterpret_cast<uint4*>(gst + (size_t)(crow[i] * P + cpx[i]) * WP + cc8[i] * 16) = o.u;   // pad columns / tail stay zero
       }
     }
