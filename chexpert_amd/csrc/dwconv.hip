@@ -1,0 +1,524 @@
+// Depthwise k x k convolution of the EfficientNet MBConv blocks (/root/reference/models/efficientnet.py:53-64, 93-95), tiled.
+//
+// The first generation (effnet.hip dwconv_*_kernel) gave a thread one output pixel: every tap re-read its input from global
+// memory behind a bounds branch, re-evaluated Swish on it (k*k exponentials per input element) and fetched eight weights with
+// scalar loads -- 45 of the 70 ms of an EfficientNet-B0 step.  Here a 256-thread workgroup owns a tile of TH x 16 pixels x CB
+// channels (CB = 32 or 64):
+//   * the source tile with its halo is read once, 16 B per lane along the channel axis, normalised / activated ONCE (or, for
+//     the gradients, passed through the deferred BatchNorm-backward affine) and parked in LDS as bf16 -- the same rounding a
+//     materialised activation would have had; pixels outside the image are zeros, so the stencil has no bounds tests;
+//   * a thread computes 4 consecutive pixels of one row for one 8-channel chunk: per kernel row it reads 3*S+K staged vectors
+//     and K weight vectors from LDS (80-/144-B pixel pitch keeps the ds_read_b128 groups on distinct banks) for 4*K*8 FMAs;
+//   * workgroups are persistent over tiles; channel statistics / weight gradients stay in registers and leave through LDS
+//     and one global atomic per channel (tap) and workgroup.
+// Same C ABI (cx_dwconv_fwd / _dgrad / _wgrad); shapes outside k in {3,5}, stride in {1,2}, pad = k/2 keep the old kernels.
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 16;
+
+__device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + __expf(-z)); }
+__device__ __forceinline__ float swish(float z) { return z * sigm(z); }
+__device__ __forceinline__ float dswish(float z) {
+  const float s = sigm(z);
+  return s * (1.f + z * (1.f - s));
+}
+
+struct DwGeo {
+  int B, H, W, C, Ho, Wo;
+  int tiles_x, tiles_y;        // tiles of the walked map (output map for forward / weight gradient, input map for the input gradient)
+};
+
+// ---------------------------------------------------------------------------------------------------------------- forward
+template <int K, int S, int TH, int NCQ>
+__global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ sc, const float* __restrict__ sh,
+                                                          bf16* __restrict__ y, float* g1, float* g2, const DwGeo g) {
+  constexpr int PAD = K / 2, IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, CB = NCQ * 8, PP = CB * 2 + 16, NI = 3 * S + K;
+  static_assert(TH * 4 * NCQ == 256, "one thread per (row, 4-pixel group, chunk)");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wl = reinterpret_cast<float*>(smem);       // [K*K][CB]
+  float* red = wl + K * K * CB;                     // [2][CB]
+  char* tile = reinterpret_cast<char*>(red + 2 * CB);   // [IH*IW][PP]
+  const int tid = threadIdx.x, cq = tid % NCQ, pg = tid / NCQ, row = pg >> 2, xg = pg & 3;
+  const int c0 = blockIdx.y * CB, cch = c0 + cq * 8;
+  const bool cok = cch < g.C;
+  const int ccl = cok ? cch : 0;
+  const int H = g.H, W = g.W, C = g.C;
+  for (int i = tid; i < K * K * CB; i += 256) {
+    const int t = i / CB, c = i - t * CB;
+    wl[i] = c0 + c < C ? w[(size_t)(c0 + c) * K * K + t] : 0.f;
+  }
+  for (int i = tid; i < 2 * CB; i += 256) red[i] = 0.f;
+  const bool act = sc != nullptr;
+  float fsc[8], fsh[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    fsc[j] = act ? sc[ccl + j] : 1.f;
+    fsh[j] = act ? sh[ccl + j] : 0.f;
+    s1[j] = s2[j] = 0.f;
+  }
+  const int ntiles = g.B * g.tiles_y * g.tiles_x;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int b = t / (g.tiles_y * g.tiles_x), r_ = t - b * g.tiles_y * g.tiles_x;
+    const int ty = r_ / g.tiles_x, tx = r_ - ty * g.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    __syncthreads();                                  // the previous tile has been read (first time: weights staged)
+    constexpr int NCHUNK = IH * IW * NCQ;
+    for (int base = 0; base < NCHUNK; base += 1024) {
+      U128 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = (base + u * 256 + tid) / NCQ;     // 256 % NCQ == 0: the chunk column of this thread is always cq
+        const int pr = p / IW, pc = p - pr * IW, iy = iy0 + pr, ix = ix0 + pc;
+        ok[u] = cok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+        v[u].u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + iyc) * W + ixc) * C + ccl);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid, p = i / NCQ;
+        U128 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = bf2f(v[u].e[j]);
+          o.e[j] = act ? f2bf(swish(fmaf(a, fsc[j], fsh[j]))) : v[u].e[j];       // the rounding of a materialised activation
+        }
+        const unsigned keep = ok[u] ? 0xffffffffu : 0u;
+        o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
+        if (i < NCHUNK) *reinterpret_cast<uint4*>(tile + (size_t)p * PP + cq * 16) = o.u;
+      }
+    }
+    __syncthreads();
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+#pragma unroll 1
+    for (int dy = 0; dy < K; ++dy) {                  // rolled: unrolled, the K*K*8 weights are hoisted and spill
+      float wv[K][8];
+#pragma unroll
+      for (int dx = 0; dx < K; ++dx) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (dy * K + dx) * CB + cq * 8);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(wl + (dy * K + dx) * CB + cq * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wv[dx][e] = a[e]; wv[dx][4 + e] = c[e]; }
+      }
+      const char* rp = tile + (size_t)((row * S + dy) * IW + xg * 4 * S) * PP + cq * 16;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        U128 v;
+        v.u = *reinterpret_cast<const uint4*>(rp + i * PP);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = bf2f(v.e[e]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int dx = i - j * S;
+          if (dx >= 0 && dx < K)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(f[e], wv[dx][e], acc[j][e]);
+        }
+      }
+    }
+    const int oy = oy0 + row;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ox = ox0 + xg * 4 + j;
+      if (cok && oy < g.Ho && ox < g.Wo) {
+        U128 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o.e[e] = f2bf(acc[j][e]);
+          const float rv = bf2f(o.e[e]);
+          s1[e] += rv;
+          s2[e] += rv * rv;
+        }
+        *reinterpret_cast<uint4*>(y + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * C + cch) = o.u;
+      }
+    }
+  }
+  if (g1) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&red[cq * 8 + e], s1[e]);
+      atomicAdd(&red[CB + cq * 8 + e], s2[e]);
+    }
+    __syncthreads();
+    for (int c = tid; c < CB; c += 256)
+      if (c0 + c < C) {
+        atomicAdd(&g1[c0 + c], red[c]);
+        atomicAdd(&g2[c0 + c], red[CB + c]);
+      }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------- input gradient
+// da[p][c] = sum_t dY[(p + pad - t)/S][c] * w[c][t] over the taps whose source lands on the output grid; the tile walks the
+// INPUT map, the staged region is the part of dY it touches (OH x OW pixels from (oyb, oxb)), dY = bf16(g*ga + g2*gb + gc).
+template <int K, int S, int TH, int NCQ>
+__global__ __launch_bounds__(256) void dw_dgrad_tile_kernel(const bf16* __restrict__ gq, const bf16* __restrict__ g2,
+                                                            const float* __restrict__ ga, const float* __restrict__ gb,
+                                                            const float* __restrict__ gc, const float* __restrict__ w,
+                                                            const bf16* __restrict__ x, const float* __restrict__ sc,
+                                                            const float* __restrict__ sh, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, bf16* __restrict__ dz, float* S1,
+                                                            float* S2, int accumulate, const DwGeo g) {
+  constexpr int PAD = K / 2, CB = NCQ * 8, PP = CB * 2 + 16;
+  constexpr int OH = S == 1 ? TH + K - 1 : TH / 2 + 2, OW = S == 1 ? TW + K - 1 : TW / 2 + 2, NI = S == 1 ? K + 3 : 4;
+  static_assert(TH * 4 * NCQ == 256, "one thread per (row, 4-pixel group, chunk)");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wl = reinterpret_cast<float*>(smem);       // [K*K][CB]
+  float* red = wl + K * K * CB;                     // [2][CB]
+  char* tile = reinterpret_cast<char*>(red + 2 * CB);   // [OH*OW][PP]
+  const int tid = threadIdx.x, cq = tid % NCQ, pg = tid / NCQ, row = pg >> 2, xg = pg & 3;
+  const int c0 = blockIdx.y * CB, cch = c0 + cq * 8;
+  const bool cok = cch < g.C;
+  const int ccl = cok ? cch : 0;
+  const int H = g.H, W = g.W, C = g.C, Ho = g.Ho, Wo = g.Wo;
+  for (int i = tid; i < K * K * CB; i += 256) {
+    const int t = i / CB, c = i - t * CB;
+    wl[i] = c0 + c < C ? w[(size_t)(c0 + c) * K * K + t] : 0.f;
+  }
+  for (int i = tid; i < 2 * CB; i += 256) red[i] = 0.f;
+  const bool act = sc != nullptr;
+  float fa[8], fb[8], fc[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    fa[j] = ga[ccl + j]; fb[j] = gb[ccl + j]; fc[j] = gc[ccl + j];
+    s1[j] = s2[j] = 0.f;
+  }
+  const int ntiles = g.B * g.tiles_y * g.tiles_x;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int b = t / (g.tiles_y * g.tiles_x), r_ = t - b * g.tiles_y * g.tiles_x;
+    const int ty = r_ / g.tiles_x, tx = r_ - ty * g.tiles_x;
+    const int iy0 = ty * TH, ix0 = tx * TW;
+    const int oyb = S == 1 ? iy0 - PAD : iy0 / 2 - 1, oxb = S == 1 ? ix0 - PAD : ix0 / 2 - 1;
+    __syncthreads();
+    constexpr int NCHUNK = OH * OW * NCQ;
+    for (int base = 0; base < NCHUNK; base += 1024) {
+      U128 u_[4], v_[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = (base + u * 256 + tid) / NCQ;
+        const int pr = p / OW, pc = p - pr * OW, oy = oyb + pr, ox = oxb + pc;
+        ok[u] = cok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+        const size_t off = ((size_t)(b * Ho + min(max(oy, 0), Ho - 1)) * Wo + min(max(ox, 0), Wo - 1)) * C + ccl;
+        u_[u].u = *reinterpret_cast<const uint4*>(gq + off);
+        v_[u].u = *reinterpret_cast<const uint4*>(g2 + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid, p = i / NCQ;
+        U128 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u_[u].e[j]), fa[j], fmaf(bf2f(v_[u].e[j]), fb[j], fc[j])));
+        const unsigned keep = ok[u] ? 0xffffffffu : 0u;
+        o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
+        if (i < NCHUNK) *reinterpret_cast<uint4*>(tile + (size_t)p * PP + cq * 16) = o.u;
+      }
+    }
+    // epilogue operands of this thread's 4 pixels, requested before the stencil
+    const int iy = iy0 + row;
+    U128 xv[4], old[4];
+    bool pok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ix = ix0 + xg * 4 + j;
+      pok[j] = cok && iy < H && ix < W;
+      const size_t off = ((size_t)(b * H + min(iy, H - 1)) * W + min(ix, W - 1)) * C + ccl;
+      xv[j].u = *reinterpret_cast<const uint4*>(x + off);
+      old[j].u = accumulate ? *reinterpret_cast<const uint4*>(dz + off) : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    // kernel rows whose source row lies on the output grid: dy = iy + PAD - oy*S
+#pragma unroll 1
+    for (int dy = S == 1 ? 0 : ((row + PAD) & 1); dy < K; dy += S) {
+      const int pr = (iy + PAD - dy) / S - oyb;                 // staged row, 0 <= pr < OH by construction
+      float wv[K][8];
+#pragma unroll
+      for (int dx = 0; dx < K; ++dx) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (dy * K + dx) * CB + cq * 8);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(wl + (dy * K + dx) * CB + cq * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wv[dx][e] = a[e]; wv[dx][4 + e] = c[e]; }
+      }
+      const char* rp = tile + (size_t)(pr * OW + (S == 1 ? xg * 4 : xg * 2)) * PP + cq * 16;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        U128 v;
+        v.u = *reinterpret_cast<const uint4*>(rp + i * PP);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = bf2f(v.e[e]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int dx = S == 1 ? j + K - 1 - i : j + PAD - 2 * (i - 1);      // staged column i feeds pixel j through tap dx
+          if (dx >= 0 && dx < K)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(f[e], wv[dx][e], acc[j][e]);
+        }
+      }
+    }
+    float fsc[8], fsh[8], fmu[8], fr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      fsc[e] = act ? sc[ccl + e] : 1.f; fsh[e] = act ? sh[ccl + e] : 0.f;
+      fmu[e] = act ? mean[ccl + e] : 0.f; fr[e] = act ? rstd[ccl + e] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (pok[j]) {
+        U128 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xf = bf2f(xv[j].e[e]);
+          float d = acc[j][e];
+          if (act) d *= dswish(fmaf(xf, fsc[e], fsh[e]));
+          s1[e] += d;
+          s2[e] += d * (xf - fmu[e]) * fr[e];
+          if (accumulate) d += bf2f(old[j].e[e]);
+          o.e[e] = f2bf(d);
+        }
+        *reinterpret_cast<uint4*>(dz + ((size_t)(b * H + iy) * W + ix0 + xg * 4 + j) * C + cch) = o.u;
+      }
+    }
+  }
+  if (S1) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&red[cq * 8 + e], s1[e]);
+      atomicAdd(&red[CB + cq * 8 + e], s2[e]);
+    }
+    __syncthreads();
+    for (int c = tid; c < CB; c += 256)
+      if (c0 + c < C) {
+        atomicAdd(&S1[c0 + c], red[c]);
+        if (S2) atomicAdd(&S2[c0 + c], red[CB + c]);
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------- weight gradient
+// dW[c][t] += sum_p dY[p][c] * act(x[p*S - pad + t][c]): both tiles staged as in the forward kernel; a thread owns one chunk,
+// one kernel row and every NSUB-th pixel of the tile, K x 8 accumulators for the whole workgroup lifetime.
+template <int K, int S, int TH, int NCQ>
+__global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const bf16* __restrict__ gq, const bf16* __restrict__ g2,
+                                                            const float* __restrict__ ga, const float* __restrict__ gb,
+                                                            const float* __restrict__ gc, const bf16* __restrict__ x,
+                                                            const float* __restrict__ sc, const float* __restrict__ sh,
+                                                            float* __restrict__ dw, const DwGeo g) {
+  constexpr int PAD = K / 2, IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, CB = NCQ * 8, PP = CB * 2 + 16;
+  constexpr int NCOMB = NCQ * K, NSUB = 256 / NCOMB, NPX = TH * TW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);              // [K*K][CB]
+  char* xt = reinterpret_cast<char*>(red + K * K * CB);      // [IH*IW][PP]
+  char* gt = xt + (size_t)IH * IW * PP;                      // [TH*TW][PP]
+  const int tid = threadIdx.x, cq = tid % NCQ;
+  const int c0 = blockIdx.y * CB, cch = c0 + cq * 8;
+  const bool cok = cch < g.C;
+  const int ccl = cok ? cch : 0;
+  const int H = g.H, W = g.W, C = g.C, Ho = g.Ho, Wo = g.Wo;
+  // compute role: combination (chunk, kernel row) and pixel subset
+  const int comb = tid % NCOMB, ccq = comb % NCQ, cdy = comb / NCQ, sub = tid / NCOMB;
+  for (int i = tid; i < K * K * CB; i += 256) red[i] = 0.f;
+  const bool act = sc != nullptr;
+  float fsc[8], fsh[8], fa[8], fb[8], fc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    fsc[j] = act ? sc[ccl + j] : 1.f; fsh[j] = act ? sh[ccl + j] : 0.f;
+    fa[j] = ga[ccl + j]; fb[j] = gb[ccl + j]; fc[j] = gc[ccl + j];
+  }
+  float acc[K][8];
+#pragma unroll
+  for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[dx][e] = 0.f;
+  const int ntiles = g.B * g.tiles_y * g.tiles_x;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int b = t / (g.tiles_y * g.tiles_x), r_ = t - b * g.tiles_y * g.tiles_x;
+    const int ty = r_ / g.tiles_x, tx = r_ - ty * g.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    __syncthreads();
+    constexpr int NCHUNK = IH * IW * NCQ;
+    for (int base = 0; base < NCHUNK; base += 1024) {
+      U128 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = (base + u * 256 + tid) / NCQ;
+        const int pr = p / IW, pc = p - pr * IW, iy = iy0 + pr, ix = ix0 + pc;
+        ok[u] = cok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        v[u].u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * C + ccl);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid, p = i / NCQ;
+        U128 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = act ? f2bf(swish(fmaf(bf2f(v[u].e[j]), fsc[j], fsh[j]))) : v[u].e[j];
+        const unsigned keep = ok[u] ? 0xffffffffu : 0u;
+        o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
+        if (i < NCHUNK) *reinterpret_cast<uint4*>(xt + (size_t)p * PP + cq * 16) = o.u;
+      }
+    }
+    constexpr int GCHUNK = NPX * NCQ;
+    for (int base = 0; base < GCHUNK; base += 1024) {
+      U128 u_[4], v_[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = (base + u * 256 + tid) / NCQ;
+        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        ok[u] = cok && oy < Ho && ox < Wo;
+        const size_t off = ((size_t)(b * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 1)) * C + ccl;
+        u_[u].u = *reinterpret_cast<const uint4*>(gq + off);
+        v_[u].u = *reinterpret_cast<const uint4*>(g2 + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + tid, p = i / NCQ;
+        U128 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u_[u].e[j]), fa[j], fmaf(bf2f(v_[u].e[j]), fb[j], fc[j])));
+        const unsigned keep = ok[u] ? 0xffffffffu : 0u;
+        o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
+        if (i < GCHUNK) *reinterpret_cast<uint4*>(gt + (size_t)p * PP + cq * 16) = o.u;
+      }
+    }
+    __syncthreads();
+    if (sub < NSUB) {
+      for (int p = sub; p < NPX; p += NSUB) {
+        const int pr = p / TW, pc = p % TW;
+        U128 gv;
+        gv.u = *reinterpret_cast<const uint4*>(gt + (size_t)p * PP + ccq * 16);
+        float gf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gf[e] = bf2f(gv.e[e]);
+        const char* rp = xt + (size_t)((pr * S + cdy) * IW + pc * S) * PP + ccq * 16;
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          U128 v;
+          v.u = *reinterpret_cast<const uint4*>(rp + dx * PP);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[dx][e] = fmaf(gf[e], bf2f(v.e[e]), acc[dx][e]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (sub < NSUB) {
+#pragma unroll
+    for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&red[(cdy * K + dx) * CB + ccq * 8 + e], acc[dx][e]);
+  }
+  __syncthreads();
+  for (int i = tid; i < K * K * CB; i += 256) {
+    const int t = i / CB, c = i - t * CB;
+    if (c0 + c < C) atomicAdd(&dw[(size_t)(c0 + c) * K * K + t], red[i]);
+  }
+}
+
+template <int K, int S, int TH, int NCQ>
+size_t fwd_smem() {
+  return (size_t)(K * K + 2) * NCQ * 8 * 4 + (size_t)((TH - 1) * S + K) * ((TW - 1) * S + K) * (NCQ * 16 + 16);
+}
+template <int K, int S, int TH, int NCQ>
+size_t dgrad_smem() {
+  constexpr int OH = S == 1 ? TH + K - 1 : TH / 2 + 2, OW = S == 1 ? TW + K - 1 : TW / 2 + 2;
+  return (size_t)(K * K + 2) * NCQ * 8 * 4 + (size_t)OH * OW * (NCQ * 16 + 16);
+}
+template <int K, int S, int TH, int NCQ>
+size_t wgrad_smem() {
+  return (size_t)K * K * NCQ * 8 * 4 + (size_t)(((TH - 1) * S + K) * ((TW - 1) * S + K) + TH * TW) * (NCQ * 16 + 16);
+}
+
+template <typename Kern>
+void allow_smem(Kern kern, size_t smem, bool* done) {
+  if (*done) return;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  *done = true;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct DwArgs {
+  const bf16 *x, *g, *g2;
+  const float *w, *sc, *sh, *mean, *rstd, *ga, *gb, *gc;
+  bf16 *y, *dz;
+  float *s1, *s2, *dw;
+  int accumulate;
+};
+
+template <int K, int S, int TH, int NCQ>
+int launch_cfg(int which, const DwArgs& a, DwGeo g, hipStream_t st) {
+  const int cblocks = cdiv(g.C, NCQ * 8);
+  const int mh = which == 1 ? g.H : g.Ho, mw = which == 1 ? g.W : g.Wo;      // the walked map
+  g.tiles_y = cdiv(mh, TH);
+  g.tiles_x = cdiv(mw, TW);
+  const int ntiles = g.B * g.tiles_y * g.tiles_x;
+  int gx = 2048 / cblocks;                       // workgroups stay persistent: one flush of statistics / dW each
+  if (gx < 64) gx = 64;
+  if (gx > ntiles) gx = ntiles;
+  const dim3 grid(gx, cblocks);
+  static bool attr[3] = {false, false, false};       // per instantiation
+  if (which == 0) {
+    const size_t smem = fwd_smem<K, S, TH, NCQ>();
+    allow_smem(&dw_fwd_tile_kernel<K, S, TH, NCQ>, smem, &attr[0]);
+    hipLaunchKernelGGL((dw_fwd_tile_kernel<K, S, TH, NCQ>), grid, dim3(256), smem, st, a.x, a.w, a.sc, a.sh, a.y, a.s1, a.s2, g);
+  } else if (which == 1) {
+    const size_t smem = dgrad_smem<K, S, TH, NCQ>();
+    allow_smem(&dw_dgrad_tile_kernel<K, S, TH, NCQ>, smem, &attr[1]);
+    hipLaunchKernelGGL((dw_dgrad_tile_kernel<K, S, TH, NCQ>), grid, dim3(256), smem, st, a.g, a.g2, a.ga, a.gb, a.gc, a.w, a.x, a.sc,
+                       a.sh, a.mean, a.rstd, a.dz, a.s1, a.s2, a.accumulate, g);
+  } else {
+    const size_t smem = wgrad_smem<K, S, TH, NCQ>();
+    allow_smem(&dw_wgrad_tile_kernel<K, S, TH, NCQ>, smem, &attr[2]);
+    hipLaunchKernelGGL((dw_wgrad_tile_kernel<K, S, TH, NCQ>), grid, dim3(256), smem, st, a.g, a.g2, a.ga, a.gb, a.gc, a.x, a.sc, a.sh,
+                       a.dw, g);
+  }
+  return launch_status();
+}
+
+template <int K, int S>
+int launch_ks(int which, const DwArgs& a, const DwGeo& g, hipStream_t st) {
+  const int mh = which == 1 ? g.H : g.Ho;
+  // small maps / wide layers: 8-row tiles of 64 channels; otherwise 16-row tiles of 32 channels
+  if (mh <= 12 && g.C >= 64) return launch_cfg<K, S, 8, 8>(which, a, g, st);
+  return launch_cfg<K, S, 16, 4>(which, a, g, st);
+}
+
+}  // namespace
+
+// which: 0 forward, 1 input gradient, 2 weight gradient.  *handled = false: shape not covered, the caller keeps its own kernel.
+int cx_try_dw_tile(int which, const void* x, const float* w, const float* sc, const float* sh, const float* mean, const float* rstd,
+                   const void* gq, const void* g2, const float* ga, const float* gb, const float* gc, void* y, void* dz, float* s1,
+                   float* s2, float* dw, int accumulate, int B, int H, int W, int C, int k, int stride, int pad, hipStream_t st,
+                   bool* handled) {
+  *handled = false;
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2) || pad != k / 2 || C % 8) return 0;
+  DwGeo g;
+  g.B = B; g.H = H; g.W = W; g.C = C;
+  g.Ho = (H + 2 * pad - k) / stride + 1;
+  g.Wo = (W + 2 * pad - k) / stride + 1;
+  g.tiles_x = g.tiles_y = 0;
+  DwArgs a;
+  a.x = (const bf16*)x; a.g = (const bf16*)gq; a.g2 = (const bf16*)g2;
+  a.w = w; a.sc = sc; a.sh = sh; a.mean = mean; a.rstd = rstd; a.ga = ga; a.gb = gb; a.gc = gc;
+  a.y = (bf16*)y; a.dz = (bf16*)dz; a.s1 = s1; a.s2 = s2; a.dw = dw; a.accumulate = accumulate;
+  *handled = true;
+  if (k == 3) return stride == 1 ? launch_ks<3, 1>(which, a, g, st) : launch_ks<3, 2>(which, a, g, st);
+  return stride == 1 ? launch_ks<5, 1>(which, a, g, st) : launch_ks<5, 2>(which, a, g, st);
+}

@@ -6,6 +6,12 @@
 // cx_conv_gemm / cx_conv_wgrad on materialised bf16 activations.
 #include "common.h"
 
+// dwconv.hip: tiled depthwise kernels for k in {3,5}, stride in {1,2}, pad = k/2 (which: 0 forward, 1 dgrad, 2 wgrad)
+int cx_try_dw_tile(int which, const void* x, const float* w, const float* sc, const float* sh, const float* mean, const float* rstd,
+                   const void* gq, const void* g2, const float* ga, const float* gb, const float* gc, void* y, void* dz, float* s1,
+                   float* s2, float* dw, int accumulate, int B, int H, int W, int C, int k, int stride, int pad, hipStream_t st,
+                   bool* handled);
+
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
@@ -504,6 +510,12 @@ int cx_dwconv_fwd(const void* x, const float* w, const float* sc, const float* s
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
   if (CP > 1024) return CX_ESHAPE;
+  {
+    bool handled = false;
+    const int rc = cx_try_dw_tile(0, x, w, sc, sh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, y, nullptr, stat_sum,
+                                  stat_sq, nullptr, 0, B, H, W, C, k, stride, pad, as_stream(stream), &handled);
+    if (handled) return rc;
+  }
   const size_t npix = (size_t)B * Ho * Wo;
   hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
                      (const bf16*)x, w, sc, sh, (bf16*)y, stat_sum, stat_sq, B, H, W, C, Ho, Wo, k, stride, pad);
@@ -517,6 +529,12 @@ int cx_dwconv_dgrad(const void* g, const void* g2, const float* ga, const float*
   if (sc && (!sh || !mean || !rstd || !S1 || !S2)) return CX_EINVAL;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
+  {
+    bool handled = false;
+    const int rc = cx_try_dw_tile(1, x, w, sc, sh, mean, rstd, g, g2, ga, gb, gc, nullptr, dz, S1, S2, nullptr, accumulate, B, H, W, C, k,
+                                  stride, pad, as_stream(stream), &handled);
+    if (handled) return rc;
+  }
   const size_t npix = (size_t)B * H * W;
   hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
                      (const bf16*)g, (const bf16*)g2, ga, gb, gc, w, (const bf16*)x, sc, sh, mean, rstd, (bf16*)dz, S1, S2, B, H, W, C, Ho,
@@ -529,6 +547,12 @@ int cx_dwconv_wgrad(const void* g, const void* g2, const float* ga, const float*
   if (!g || !g2 || !ga || !gb || !gc || !x || !dw || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
+  {
+    bool handled = false;
+    const int rc = cx_try_dw_tile(2, x, nullptr, sc, sh, nullptr, nullptr, g, g2, ga, gb, gc, nullptr, nullptr, nullptr, nullptr, dw, 0, B,
+                                  H, W, C, k, stride, pad, as_stream(stream), &handled);
+    if (handled) return rc;
+  }
   const size_t npix = (size_t)B * Ho * Wo;
   hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(grid_for(npix, th / CP, 256), k * k), dim3(th), C * sizeof(float), as_stream(stream),
                      (const bf16*)g, (const bf16*)g2, ga, gb, gc, (const bf16*)x, sc, sh, dw, B, H, W, C, Ho, Wo, k, stride, pad);
