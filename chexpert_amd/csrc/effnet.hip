@@ -21,6 +21,14 @@ __device__ __forceinline__ float dswishf_(float z) {
   return s * (1.f + z * (1.f - s));
 }
 
+// eight consecutive per-channel floats as two 16-B loads (C % 8 == 0 keeps them aligned)
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&o)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+}
+
 inline int grid_for(size_t n, int block, int cap) {
   size_t g = (n + block - 1) / block;
   if (g > (size_t)cap) g = cap;
@@ -283,11 +291,12 @@ __global__ void scale_act_bc_kernel(const bf16* __restrict__ x, const float* __r
     const int b = pix / HW;
     U128 v, o;
     v.u = *reinterpret_cast<const uint4*>(x + idx * 8);
+    float fsc[8], fsh[8], fs[8];
+    load8(sc + cq * 8, fsc);
+    load8(sh + cq * 8, fsh);
+    if (s) load8(s + (size_t)b * C + cq * 8, fs);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = cq * 8 + j;
-      o.e[j] = f2bf(swishf_(fmaf(bf2f(v.e[j]), sc[c], sh[c])) * (s ? s[(size_t)b * C + c] : 1.f));
-    }
+    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(swishf_(fmaf(bf2f(v.e[j]), fsc[j], fsh[j])) * (s ? fs[j] : 1.f));
     *reinterpret_cast<uint4*>(u + idx * 8) = o.u;
   }
 }
@@ -342,45 +351,74 @@ __global__ void se_bwd_reduce_kernel(const bf16* __restrict__ du, const bf16* __
 }
 
 // SE backward through the two FCs: one block per sample
-__global__ void se_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s, const float* __restrict__ h1,
-                              const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ w2,
-                              float* dw1, float* db1, float* dw2, float* db2, float* __restrict__ dpooled, int C, int R) {
-  extern __shared__ float lds[];          // [C] dlogit2, [R] a1 = swish(h1), [R] dh1
+// Workgroup = (group of G images, slice of CS channels).  The weight-gradient outer products are summed over the group before
+// they meet the global atomics (one workgroup per image sent B*C*R contended atomics per matrix: 224 us per call at B = 128);
+// every slice recomputes the group's dlogit2 / dh1 (a few hundred thousand FMAs) rather than exchanging them.
+__global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                      const float* __restrict__ h1, const float* __restrict__ pooled,
+                                                      const float* __restrict__ w1, const float* __restrict__ w2, float* dw1, float* db1,
+                                                      float* dw2, float* db2, float* __restrict__ dpooled, int B, int C, int R, int G,
+                                                      int CS) {
+  extern __shared__ float lds[];          // [G][C] dlogit2, [G][R] a1 = swish(h1), [G][R] dh1
   float* dl2 = lds;
-  float* a1 = lds + C;
-  float* dh1 = a1 + R;
-  const int b = blockIdx.x;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) a1[r] = swishf_(h1[(size_t)b * R + r]);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float sv = s[(size_t)b * C + c];
-    dl2[c] = ds[(size_t)b * C + c] * sv * (1.f - sv);
+  float* a1 = lds + (size_t)G * C;
+  float* dh1 = a1 + G * R;
+  const int b0 = blockIdx.x * G, ng = min(G, B - b0);
+  const int cs0 = blockIdx.y * CS, ncs = min(CS, C - cs0);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < ng * R; i += nt) a1[i] = swishf_(h1[(size_t)b0 * R + i]);
+  for (int i = tid; i < ng * C; i += nt) {
+    const float sv = s[(size_t)b0 * C + i];
+    dl2[i] = ds[(size_t)b0 * C + i] * sv * (1.f - sv);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    atomicAdd(&db2[c], dl2[c]);
-    for (int r = 0; r < R; ++r) atomicAdd(&dw2[(size_t)c * R + r], dl2[c] * a1[r]);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int r = wave; r < R; r += nw) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a = fmaf(w2[(size_t)c * R + r], dl2[c], a);
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  for (int r = wave; r < R; r += nw) {                // a wave per hidden unit: each W2 element is read once for the whole group
+    float a[16];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
-    if (lane == 0) {
-      const float d = a * dswishf_(h1[(size_t)b * R + r]);
-      dh1[r] = d;
-      atomicAdd(&db1[r], d);
+    for (int gi = 0; gi < 16; ++gi) a[gi] = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float wv = w2[(size_t)c * R + r];
+#pragma unroll
+      for (int gi = 0; gi < 16; ++gi)
+        if (gi < ng) a[gi] = fmaf(wv, dl2[gi * C + c], a[gi]);
+    }
+#pragma unroll
+    for (int gi = 0; gi < 16; ++gi) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) a[gi] += __shfl_xor(a[gi], d);
+      if (lane == 0 && gi < ng) dh1[gi * R + r] = a[gi] * dswishf_(h1[(size_t)(b0 + gi) * R + r]);
     }
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int i = tid; i < ncs * R; i += nt) {           // dW2[c][r] += sum_g dlogit2[g][c] * a1[g][r]
+    const int cl = i / R, r = i - cl * R, c = cs0 + cl;
     float a = 0.f;
-    const float pc = pooled[(size_t)b * C + c];
-    for (int r = 0; r < R; ++r) {
-      a = fmaf(w1[(size_t)r * C + c], dh1[r], a);
-      atomicAdd(&dw1[(size_t)r * C + c], dh1[r] * pc);
+    for (int gi = 0; gi < ng; ++gi) a = fmaf(dl2[gi * C + c], a1[gi * R + r], a);
+    atomicAdd(&dw2[(size_t)c * R + r], a);
+  }
+  for (int cl = tid; cl < ncs; cl += nt) {
+    float a = 0.f;
+    for (int gi = 0; gi < ng; ++gi) a += dl2[gi * C + cs0 + cl];
+    atomicAdd(&db2[cs0 + cl], a);
+  }
+  __syncthreads();
+  if (blockIdx.y == 0)
+    for (int r = tid; r < R; r += nt) {
+      float a = 0.f;
+      for (int gi = 0; gi < ng; ++gi) a += dh1[gi * R + r];
+      atomicAdd(&db1[r], a);
     }
-    dpooled[(size_t)b * C + c] = a;
+  for (int i = tid; i < R * ncs; i += nt) {           // dW1[r][c] += sum_g dh1[g][r] * pooled[g][c]
+    const int r = i / ncs, c = cs0 + i - r * ncs;
+    float a = 0.f;
+    for (int gi = 0; gi < ng; ++gi) a = fmaf(dh1[gi * R + r], pooled[(size_t)(b0 + gi) * C + c], a);
+    atomicAdd(&dw1[(size_t)r * C + c], a);
+  }
+  for (int i = tid; i < ng * ncs; i += nt) {
+    const int gi = i / ncs, c = cs0 + i - gi * ncs;
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a = fmaf(w1[(size_t)r * C + c], dh1[gi * R + r], a);
+    dpooled[(size_t)(b0 + gi) * C + c] = a;
   }
 }
 
@@ -408,12 +446,14 @@ __global__ void se_act_bwd_kernel(const bf16* __restrict__ du, const bf16* __res
     U128 v, d, o;
     v.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
     if (du) d.u = *reinterpret_cast<const uint4*>(du + pix * C + cq * 8);
+    float fdp[8], fs[8];
+    if (dpooled) load8(dpooled + (size_t)b * C + cq * 8, fdp);
+    if (du && s) load8(s + (size_t)b * C + cq * 8, fs);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = cq * 8 + j;
       const float xf = bf2f(v.e[j]);
-      float da = dpooled ? dpooled[(size_t)b * C + c] * inv : 0.f;
-      if (du) da = fmaf(bf2f(d.e[j]), s ? s[(size_t)b * C + c] : 1.f, da);
+      float da = dpooled ? fdp[j] * inv : 0.f;
+      if (du) da = fmaf(bf2f(d.e[j]), s ? fs[j] : 1.f, da);
       const float dzv = da * dswishf_(fmaf(xf, fsc[j], fsh[j]));
       st[0][j] += dzv;
       st[1][j] += dzv * (xf - fmu[j]) * fr[j];
@@ -438,11 +478,14 @@ __global__ void affine2_out_kernel(const bf16* __restrict__ a, const bf16* __res
     U128 u, v, o;
     u.u = *reinterpret_cast<const uint4*>(a + idx * 8);
     if (b) v.u = *reinterpret_cast<const uint4*>(b + idx * 8);
+    float fpa[8], fpb[8], fpc[8];
+    load8(pa + cq * 8, fpa);
+    load8(pc + cq * 8, fpc);
+    if (b) load8(pb + cq * 8, fpb);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = cq * 8 + j;
-      float r = sb * fmaf(bf2f(u.e[j]), pa[c], pc[c]);
-      if (b) r = fmaf(bf2f(v.e[j]), pb[c], r);
+      float r = sb * fmaf(bf2f(u.e[j]), fpa[j], fpc[j]);
+      if (b) r = fmaf(bf2f(v.e[j]), fpb[j], r);
       o.e[j] = f2bf(r);
     }
     *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
@@ -612,8 +655,18 @@ int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float
 int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
               float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, void* stream) {
   if (!ds || !s || !h1 || !pooled || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpooled || R <= 0) return CX_EINVAL;
-  hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (C + 2 * R) * sizeof(float), as_stream(stream), ds, s, h1, pooled, w1, w2, dw1, db1,
-                     dw2, db2, dpooled, C, R);
+  int G = (int)((120 * 1024) / ((size_t)(C + 2 * R) * sizeof(float)));      // images per workgroup: what 120 KB of LDS hold, at most 16
+  if (G > 16) G = 16;
+  if (G < 1) return CX_ESHAPE;
+  const size_t smem = (size_t)G * (C + 2 * R) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&se_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    attr = true;
+  }
+  const int CS = 64;
+  hipLaunchKernelGGL(se_bwd_kernel, dim3((B + G - 1) / G, (C + CS - 1) / CS), dim3(1024), smem, as_stream(stream), ds, s, h1, pooled, w1, w2,
+                     dw1, db1, dw2, db2, dpooled, B, C, R, G, CS);
   return launch_status();
 }
 

@@ -131,3 +131,25 @@ def test_dwconv_weight_gradient(dev, k, s, B, H, W, C, act):
     check(lib().cx_dwconv_wgrad(ptr(gq), ptr(g2q), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(xq), ptr(t[3]) if act else None,
                                 ptr(t[4]) if act else None, ptr(dw), B, H, W, C, k, s, pad, stream_ptr()), "cx_dwconv_wgrad")
     close(dw.cpu() - dw0, want, 2e-3, "dW")
+
+
+@pytest.mark.parametrize("B,C,R", [(5, 96, 4), (37, 240, 10), (128, 672, 28), (3, 2688, 112)])
+def test_se_backward(dev, B, C, R):
+    """cx_se_bwd (SELayer FCs, efficientnet.py:70-73) against torch autograd; gradients accumulate into the given buffers."""
+    from chexpert_amd._lib import lib, ptr, check, stream_ptr
+    pooled = rnd(51, (B, C), -1, 1).requires_grad_(True)
+    w1, b1 = rnd(52, (R, C), -0.2, 0.2).requires_grad_(True), rnd(53, (R,), -0.2, 0.2).requires_grad_(True)
+    w2, b2 = rnd(54, (C, R), -0.5, 0.5).requires_grad_(True), rnd(55, (C,), -0.2, 0.2).requires_grad_(True)
+    ds = rnd(56, (B, C), -1, 1)
+    h1 = pooled @ w1.t() + b1
+    s = torch.sigmoid(swish(h1) @ w2.t() + b2)
+    s.backward(ds)
+    init = [rnd(60 + i, t.shape) for i, t in enumerate((w1, b1, w2, b2))]
+    d = [t.clone().to(dev) for t in init]
+    dpooled = torch.full((B, C), 7.0, device=dev)
+    args = [t.detach().to(dev).contiguous() for t in (ds, s, h1, pooled, w1, w2)]
+    check(lib().cx_se_bwd(*[ptr(t) for t in args], ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(dpooled), B, C, R, stream_ptr()),
+          "cx_se_bwd")
+    for got, i0, ref, what in zip(d, init, (w1, b1, w2, b2), ("dW1", "db1", "dW2", "db2")):
+        close(got.cpu() - i0, ref.grad, 1e-4, what)
+    close(dpooled.cpu(), pooled.grad, 1e-4, "dpooled")
