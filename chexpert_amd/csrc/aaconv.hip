@@ -13,6 +13,10 @@
 // bounded by LDS broadcast reads.  The backward pass recomputes P from the saved log-sum-exp.
 #include "common.h"
 
+// aaconv_row.hip: row-streamed kernels for map widths 40 and 20 (which: 0 forward, 1 the whole backward)
+int cx_try_aa_row(int which, const void* qkv, const float* rel_h, const float* rel_w, float* o, const float* d_o, float* lse, float* dqkv,
+                  float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq, hipStream_t st, bool* handled);
+
 namespace {
 
 constexpr int AQ = 128;      // queries per workgroup (one per thread)
@@ -664,10 +668,15 @@ int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w,
   if (nh <= 0 || dk != nh * DKH || dv % nh || dv / nh > MAXDV || (ldq % 4)) return CX_ESHAPE;
   const int dvh = dv / nh;
   AAGeo g{B, H, W, nh, dk, dv, ldq};
+  hipStream_t st = as_stream(stream);
+  {
+    bool handled = false;
+    const int rc = cx_try_aa_row(0, qkv, rel_h, rel_w, o, nullptr, lse, nullptr, nullptr, nullptr, B, H, W, nh, dk, dv, ldq, st, &handled);
+    if (handled) return rc;
+  }
   const size_t smem = attn_lds_floats(H, W, dvh) * 4;
   if (smem > 64 * 1024) return CX_ESHAPE;
   dim3 grid((H * W + AQ - 1) / AQ, B * nh);
-  hipStream_t st = as_stream(stream);
 #define LAUNCH(D) hipLaunchKernelGGL(aa_attn_fwd_kernel<D>, grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, lse, g)
   switch (dvh) {
     case 1: LAUNCH(1); break;
@@ -714,9 +723,16 @@ int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
+  bool row_q = false;
+  {
+    const int rc = cx_try_aa_row(1, qkv, rel_h, rel_w, const_cast<float*>(o), d_o, const_cast<float*>(lse), dqkv, d_rel_h, d_rel_w, B, H, W,
+                                 nh, dk, dv, ldq, st, &row_q);
+    if (row_q) return rc;               // dq, dk, dv and the table gradients all done there
+  }
 #define LAUNCH(D)                                                                                                              \
-  hipLaunchKernelGGL(aa_attn_bwd_q_kernel<D>, grid, dim3(AQ), smem_q, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv,   \
-                     d_rel_h, d_rel_w, g);                                                                                    \
+  if (!row_q)                                                                                                                  \
+    hipLaunchKernelGGL(aa_attn_bwd_q_kernel<D>, grid, dim3(AQ), smem_q, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, \
+                       d_rel_h, d_rel_w, g);                                                                                  \
   hipLaunchKernelGGL(aa_attn_bwd_k_kernel<D>, grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g)
   switch (dvh) {
     case 1: LAUNCH(1); break;
