@@ -138,23 +138,15 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_row_kernel(const bf16* __res
   float* dRW = dRH + DKH * LH;
   float* Kt = dRW + DKH * LW;
   float* Vt = Kt + WW * DKH;
+  float* Qs = Vt + WW * DVH;             // [AQ][DKH + 1] scaled queries of the workgroup
+  float* dr = Qs + AQ * (DKH + 1);       // [AQ] d rh_i[ky] of the key row just finished
+  float* dwq = dr + AQ;                  // [AQ][WW + 1] d rw_i[kx], parked once at the end
   const int tid = threadIdx.x;
   const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
-  // Lane -> query along DIAGONALS of a square map: consecutive lanes differ in both qy and qx, so the table columns a wave's
-  // lanes add to (r = ky - qy + H - 1 at a row end, kx - qx + W - 1 at the end) are distinct up to 2-way.  In raster order the
-  // 20-40 lanes of one image row hit the same LDS word, and same-address ds_add_f32 serialises at ~45 cycles per lane: that
-  // was half of this kernel's time.
-  const int t_ = blockIdx.x * AQ + tid;
-  const bool qvalid = t_ < HW;
-  const int tc = qvalid ? t_ : HW - 1;
-  int qy = tc / WW, qx = tc - qy * WW;
-  if (H == WW) {
-    const int c = qy;                    // diagonal number, position along it
-    qy = qx;
-    qx = qx + c;
-    if (qx >= WW) qx -= WW;
-  }
-  const int ic = qy * WW + qx, i = ic;
+  const int i = blockIdx.x * AQ + tid;
+  const bool qvalid = i < HW;
+  const int ic = qvalid ? i : HW - 1;
+  const int qy = ic / WW, qx = ic - qy * WW;
   const bf16* base = qkv + (size_t)b * HW * g.ldq;
   for (int t = tid; t < DKH * LH; t += AQ) { RH[t] = rel_h[t]; dRH[t] = 0.f; }
   for (int t = tid; t < DKH * LW; t += AQ) { RW[t] = rel_w[t]; dRW[t] = 0.f; }
@@ -178,6 +170,10 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_row_kernel(const bf16* __res
     for (int d = 0; d < DVH; ++d) { dO[d] = qvalid ? dp[d] : 0.f; delta = fmaf(dO[d], op[d], delta); }
   }
   const float L = lse[(size_t)bn * HW + ic];
+#pragma unroll
+  for (int d = 0; d < DKH; ++d) Qs[tid * (DKH + 1) + d] = qvalid ? q[d] : 0.f;
+  const int i0 = blockIdx.x * AQ;                      // first query of the workgroup; its image rows qy_a .. qy_b
+  const int qy_a = i0 / WW, qy_b = min(i0 + AQ - 1, HW - 1) / WW;
   __syncthreads();
   float rw[WW], drw[WW], dq[DKH];
 #pragma unroll
@@ -225,24 +221,48 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_row_kernel(const bf16* __res
       drh += ds;
       drw[j] += ds;
     }
-    if (qvalid) {                        // key row complete: fold d rh_i[ky] into dq and the workgroup's d key_rel_h partial
+    // key row complete: fold d rh_i[ky] into dq and into the workgroup's d key_rel_h partial.  Queries of one image row share
+    // the table column r; LDS float atomics cost ~7 cycles per lane even on distinct words and ~45 on the same word (they were
+    // half of this kernel), so no atomics: each query parks its scalar, then thread (image row, d) sums its row's products
+    // and owns the word it adds to.
+    const float drh_v = qvalid ? drh : 0.f;
+    if (qvalid) {                          // its own basic block: merged into the unrolled pair loop's block it spilled 2 KB per lane
 #pragma unroll
-      for (int d = 0; d < DKH; ++d) {
-        dq[d] = fmaf(drh, RH[d * LH + r], dq[d]);
-        atomicAdd(&dRH[d * LH + r], drh * q[d]);
-      }
+      for (int d = 0; d < DKH; ++d) dq[d] = fmaf(drh, RH[d * LH + r], dq[d]);
+    }
+    dr[tid] = drh_v;
+    __syncthreads();
+    for (int oo = tid; oo < (qy_b - qy_a + 1) * DKH; oo += AQ) {
+      const int seg = oo / DKH, d = oo - seg * DKH, yy = qy_a + seg;
+      const int l0 = max(yy * WW - i0, 0), l1 = min((yy + 1) * WW - i0, AQ);
+      float t = 0.f;
+      for (int l = l0; l < l1; ++l) t = fmaf(dr[l], Qs[l * (DKH + 1) + d], t);
+      dRH[d * LH + ky - yy + H - 1] += t;
     }
   }
-  if (qvalid) {
+  // d rw_i[kx] -> dq and d key_rel_w.  Park the per-query column sums in LDS (plain stores), then one thread per table word
+  // sums every (query, key column) pair that lands on it: no atomics.
 #pragma unroll
-    for (int kx = 0; kx < WW; ++kx) {
-      const int r = kx - qx + WW - 1;
+  for (int kx = 0; kx < WW; ++kx) {
+    const float dv_ = qvalid ? drw[kx] : 0.f;
+    const int r = kx - qx + WW - 1;
 #pragma unroll
-      for (int d = 0; d < DKH; ++d) {
-        dq[d] = fmaf(drw[kx], RW[d * LW + r], dq[d]);
-        atomicAdd(&dRW[d * LW + r], drw[kx] * q[d]);
-      }
+    for (int d = 0; d < DKH; ++d) dq[d] = fmaf(dv_, RW[d * LW + r], dq[d]);
+    dwq[tid * (WW + 1) + kx] = dv_;
+  }
+  __syncthreads();
+  for (int oo = tid; oo < LW * DKH; oo += AQ) {        // thread owns table word (d, rr): every (query, kx) with kx - qx + W - 1 = rr
+    const int rr = oo / DKH, d = oo - rr * DKH;
+    int xq = i0 % WW;                                   // qx of query l
+    float t = 0.f;
+    for (int l = 0; l < AQ; ++l) {
+      const int kx = xq + rr - (WW - 1);
+      if (kx >= 0 && kx < WW) t = fmaf(dwq[l * (WW + 1) + kx], Qs[l * (DKH + 1) + d], t);
+      if (++xq == WW) xq = 0;
     }
+    dRW[d * LW + rr] += t;
+  }
+  if (qvalid) {
     float* dqp = dqkv + ((size_t)b * HW + i) * (2 * g.dk + g.dv) + n * DKH;
 #pragma unroll
     for (int d = 0; d < DKH; ++d) dqp[d] = dq[d] * scale;       // q~ = q * scale
@@ -377,7 +397,7 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
     const size_t smem = (tables + (size_t)WW * (DKH + DVH)) * 4;
     hipLaunchKernelGGL((aa_attn_fwd_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, lse, g);
   } else {
-    const size_t smem = (2 * tables + (size_t)WW * (DKH + DVH)) * 4;
+    const size_t smem = (2 * tables + (size_t)WW * (DKH + DVH) + (size_t)AQ * (DKH + 2 + WW + 1)) * 4;
     hipLaunchKernelGGL((aa_attn_bwd_q_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv,
                        d_rel_h, d_rel_w, g);
     const size_t smem_k = (tables + (size_t)WW * (DKH + DVH + 2 + WW + 1)) * 4;
