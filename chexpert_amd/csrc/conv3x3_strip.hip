@@ -459,7 +459,8 @@ template <int NG, int NCHW>
 __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
-    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const StripGeo g) {
+    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const int K, const int c_tiles,
+    const int n_tiles, const StripGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
   const int nk = (R * P + 15) / 16;
@@ -471,16 +472,22 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) % 3, grp = (tid >> 6) / 3;           // wave = kernel row dy, grp = k-step residue
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int ct = wg & 3, split = wg >> 2;                          // the 4 channel tiles of a pixel range are neighbours
-  const int c0 = ct * 32;
+  // (32 input channels, 32 output channels) tile pairs of one pixel range are neighbours, input tile fastest: the dense
+  // layers are 4 x 1 pairs (K = 128, N = 32), a ResNet 256 -> 256 conv is 8 x 8
+  const int pairs = c_tiles * n_tiles;
+  const int split = wg / pairs, pair = wg - split * pairs;
+  const int nt = pair / c_tiles, ct = pair - nt * c_tiles;
+  const int c0 = ct * 32, n0 = nt * 32;
+  gsl += n0;
+  g2 += n0;
 
   for (int i = tid; i < ((Q + 2) + nk * 16) * (WP / 16); i += NTHR) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
   if (tid < 32) {
     coef[tid] = pa[c0 + tid];
     coef[32 + tid] = pb[c0 + tid];
-    coef[64 + tid] = g_affine2 ? ga[tid] : 1.f;
-    coef[96 + tid] = g_affine2 ? gb[tid] : 0.f;
-    coef[128 + tid] = g_affine2 ? gc[tid] : 0.f;
+    coef[64 + tid] = g_affine2 ? ga[n0 + tid] : 1.f;
+    coef[96 + tid] = g_affine2 ? gb[n0 + tid] : 0.f;
+    coef[128 + tid] = g_affine2 ? gc[n0 + tid] : 0.f;
   }
   __syncthreads();
 
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
   }
   for (int idx = tid; idx < 32 * 288; idx += NTHR) {
     const int n = idx / 288, i = idx - n * 288;
-    atomicAdd(dw + ((size_t)n * 128 + c0) * 9 + i, red[idx]);
+    atomicAdd(dw + ((size_t)(n0 + n) * K + c0) * 9 + i, red[idx]);
   }
 }
 
@@ -706,15 +713,21 @@ int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
 int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   *handled = false;
   if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1) return 0;
-  if (p.K != 128 || p.N != 32 || p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
+  if (p.K % 32 || p.N % 32 || p.K > 2048 || p.N > 2048 || p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
   if (p.g_prologue != CX_PRO_NONE && p.g_prologue != CX_PRO_AFFINE2) return 0;
   if (p.W + 2 > 128 || p.W < 4) return 0;
   const long long px = (long long)p.B * p.H * p.W;
+  const int c_tiles = p.K / 32, n_tiles = p.N / 32, pairs = c_tiles * n_tiles;
+  // pixel-range splits: the dense layers (4 tile pairs) take 64; wider convolutions ~768 workgroups in all, at least 4 splits
+  int wide_splits = 768 / pairs;
+  if (wide_splits < 4) wide_splits = 4;
+  if (wide_splits > 64) wide_splits = 64;
+  const int split_target = pairs == 4 ? 64 : wide_splits;
   // small maps: four wave groups per workgroup on strips of up to 880 flat pixels, one workgroup per CU
   {
     int flat = NCHW4 * 768 / (p.W * 4) * (p.W + 2);          // rows the staging registers hold
     if (flat > 880) flat = 880;
-    StripGeo g = make_geo(p.B, p.H, p.W, 64, 1, flat);
+    StripGeo g = make_geo(p.B, p.H, p.W, split_target, 1, flat);
     const int nk = (g.R * g.P + 15) / 16;
     size_t smem = 160 * 4 + (size_t)(g.Q + 2) * WP + (size_t)nk * 16 * WP;
     if (smem < 160 * 4 + 32 * 288 * 4) smem = 160 * 4 + 32 * 288 * 4;
@@ -728,9 +741,9 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
       }
       const int total = g.B * g.spi;
       const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
-      hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<4, NCHW4>), dim3(splits * 4), dim3(768), smem, st, (const bf16*)p.g, p.ldg,
+      hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<4, NCHW4>), dim3(splits * pairs), dim3(768), smem, st, (const bf16*)p.g, p.ldg,
                          (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx,
-                         p.pa, p.pb, p.dw, g);
+                         p.pa, p.pb, p.dw, p.K, c_tiles, n_tiles, g);
       *handled = true;
       return launch_status();
     }
@@ -740,6 +753,7 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   int target = (int)(px / 3200);
   if (target < 64) target = 64;
   if (target > 192) target = 192;
+  if (pairs != 4) target = split_target;
   StripGeo g = make_geo(p.B, p.H, p.W, target, 1, 256);
   if (g.R * p.W * 4 > NCHW1 * 192 || 2 * p.W * 4 > NCHW1 * 192 || g.Q < 16) return 0;
   const int nk = (g.R * g.P + 15) / 16;
@@ -748,8 +762,9 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   if (smem > 64 * 1024) return 0;
   const int total = g.B * g.spi;
   const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
-  hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<1, NCHW1>), dim3(splits * 4), dim3(192), smem, st, (const bf16*)p.g, p.ldg, (const bf16*)p.g2,
-                     p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx, p.pa, p.pb, p.dw, g);
+  hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<1, NCHW1>), dim3(splits * pairs), dim3(192), smem, st, (const bf16*)p.g, p.ldg,
+                     (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx, p.pa, p.pb,
+                     p.dw, p.K, c_tiles, n_tiles, g);
   *handled = true;
   return launch_status();
 }
