@@ -257,7 +257,7 @@ __global__ void gap_affine_act_kernel(const bf16* __restrict__ x, const float* _
 }
 
 // SE excitation: h1 = W1 pooled + b1; s = sigmoid(W2 swish(h1) + b2)      one block per sample
-__global__ void se_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
+__global__ __launch_bounds__(1024) void se_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
                               const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h1, float* __restrict__ s,
                               int C, int R) {
   extern __shared__ float lds[];          // [R] swish(h1)
@@ -618,7 +618,7 @@ int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* po
 int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
               int R, void* stream) {
   if (!pooled || !w1 || !b1 || !w2 || !b2 || !h1 || !s || R <= 0 || R > 1024) return CX_EINVAL;
-  hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(256), R * sizeof(float), as_stream(stream), pooled, w1, b1, w2, b2, h1, s, C, R);
+  hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(1024), R * sizeof(float), as_stream(stream), pooled, w1, b1, w2, b2, h1, s, C, R);
   return launch_status();
 }
 
