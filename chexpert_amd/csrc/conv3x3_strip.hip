@@ -722,7 +722,7 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   int wide_splits = 768 / pairs;                 // 384 / 1536 / 3072 workgroups measured 1-3 % slower on ResNet152
   if (wide_splits < 4) wide_splits = 4;
   if (wide_splits > 64) wide_splits = 64;
-  const int split_target = pairs == 4 ? 64 : wide_splits;
+  const int split_target = pairs == 4 ? 64 : wide_splits;     // 96 / 128 / 192 splits measured slower on the dense layers
   // small maps: four wave groups per workgroup on strips of up to 880 flat pixels, one workgroup per CU
   {
     int flat = NCHW4 * 768 / (p.W * 4) * (p.W + 2);          // rows the staging registers hold
