@@ -114,6 +114,9 @@ __global__ void bn_coef_kernel(const float* sum, const float* sq, float count, c
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = gid >> 4, q = gid & 15;
   const int cc = c < C ? c : C - 1;
+  // requested up front (one dependent chain of memory round trips otherwise)
+  const float g = gamma ? gamma[cc] : 1.f, b = beta ? beta[cc] : 0.f;
+  const float rm0 = rmean ? rmean[cc] : 0.f, rv0 = rvar ? rvar[cc] : 0.f;
   double ts = 0.0, tq = 0.0;
   for (int r = q; r < replicas; r += 16) {
     ts += (double)sum[(size_t)r * rstride + cc];
@@ -129,14 +132,13 @@ __global__ void bn_coef_kernel(const float* sum, const float* sq, float count, c
   double v = tq / count - m * m;
   if (v < 0) v = 0;
   const float r = (float)(1.0 / sqrt(v + (double)eps));
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   const float sc = g * r;
   if (scale) scale[c] = sc;
   if (shift) shift[c] = b - (float)m * sc;
   if (mean) mean[c] = (float)m;
   if (rstd) rstd[c] = r;
-  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(count > 1.f ? v * count / (count - 1.0) : v);
+  if (rmean) rmean[c] = (1.f - momentum) * rm0 + momentum * (float)m;
+  if (rvar) rvar[c] = (1.f - momentum) * rv0 + momentum * (float)(count > 1.f ? v * count / (count - 1.0) : v);
 }
 
 __global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const float* gamma, const float* beta,
@@ -157,10 +159,13 @@ __global__ void bn_bwd_coef_kernel(const float* S1, const float* S2, float count
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = gid >> 4, q = gid & 15;              // 16 lanes per channel over the replicas, as in bn_coef_kernel
   const int cc = c < C ? c : C - 1;
+  // everything this launch reads is requested up front: the kernel is one dependent chain of memory round trips
+  const float g = gamma ? gamma[cc] : 1.f, r = rstd[cc], mu = mean[cc];
+  const float dg0 = dgamma ? dgamma[cc] : 0.f, db0 = dbeta ? dbeta[cc] : 0.f, a0 = A ? A[cc] : 0.f, b0 = Bc ? Bc[cc] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  for (int r = q; r < replicas; r += 16) {
-    s1 += S1[(size_t)r * rstride + cc];
-    s2 += S2[(size_t)r * rstride + cc];
+  for (int rr = q; rr < replicas; rr += 16) {
+    s1 += S1[(size_t)rr * rstride + cc];
+    s2 += S2[(size_t)rr * rstride + cc];
   }
 #pragma unroll
   for (int d = 1; d < 16; d <<= 1) {
@@ -168,12 +173,11 @@ __global__ void bn_bwd_coef_kernel(const float* S1, const float* S2, float count
     s2 += __shfl_xor(s2, d);
   }
   if (c >= C || q != 0) return;
-  const float g = gamma ? gamma[c] : 1.f, r = rstd[c], mu = mean[c];
-  if (dgamma) dgamma[c] += s2;
-  if (dbeta) dbeta[c] += s1;
+  if (dgamma) dgamma[c] = dg0 + s2;
+  if (dbeta) dbeta[c] = db0 + s1;
   const float inv = 1.f / count;
-  if (A) A[c] += r * g * s1 * inv;
-  if (Bc) Bc[c] += r * g * s2 * inv;
+  if (A) A[c] = a0 + r * g * s1 * inv;
+  if (Bc) Bc[c] = b0 + r * g * s2 * inv;
   if (pa) {
     pa[c] = g * r;
     pb[c] = -g * r * r * s2 * inv;
