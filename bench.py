@@ -225,10 +225,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # CHEXPERT_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks share a device); the
+    # driver's runs use RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("CHEXPERT_BENCH_BACKEND", "nccl")
+    local_dev = local if backend == "nccl" else local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(1234)
     if args.model == "densenet121":
