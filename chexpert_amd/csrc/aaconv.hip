@@ -554,38 +554,47 @@ __global__ void aa_outproj_fwd_kernel(const float* __restrict__ o, const float* 
 
 // backward of out_proj: dO[pix][d] = sum_c dY[pix][c] * W[c][d];  dW[c][d] += sum_pix dY[pix][c] * O[pix][d]
 // dY = g*ga + gx*gb + gc (deferred BN correction of the gradient-buffer slice)
-__global__ void aa_outproj_bwd_kernel(const bf16* __restrict__ g, int ldg, const bf16* __restrict__ gx, int ldgx,
-                                      const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc,
-                                      const float* __restrict__ o, const float* __restrict__ w, float* __restrict__ d_o,
-                                      float* __restrict__ dw, size_t npix, int dv) {
+__global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const bf16* __restrict__ g, int ldg, const bf16* __restrict__ gx, int ldgx,
+                                                             const float* __restrict__ ga, const float* __restrict__ gb,
+                                                             const float* __restrict__ gc, const float* __restrict__ o,
+                                                             const float* __restrict__ w, float* __restrict__ d_o,
+                                                             float* __restrict__ dw, size_t npix, int dv) {
+  // Two small GEMMs per 64-pixel chunk staged in LDS: dO = dY W (thread per (pixel, d)) and dW += dY^T O (thread per (c, d)
+  // pair, which it owns: plain LDS accumulation, no atomics -- a pixel-per-thread outer product sent 64 lanes to the same
+  // LDS word dv*dv times per pixel: 2.2 ms per call).
+  constexpr int CH = 64, PT = 49;                      // pixels per chunk, padded row pitch (dv <= 48)
   __shared__ float ws[48 * 48];
   __shared__ float dws[48 * 48];
-  for (int t = threadIdx.x; t < dv * dv; t += blockDim.x) { ws[t] = w[t]; dws[t] = 0.f; }
-  __syncthreads();
-  for (size_t p0 = (size_t)blockIdx.x * blockDim.x; p0 < npix; p0 += (size_t)gridDim.x * blockDim.x) {     // wave-uniform trip count
-    const bool ok = p0 + threadIdx.x < npix;
-    const size_t pix = ok ? p0 + threadIdx.x : npix - 1;
-    float dy[48];
-    for (int c = 0; c < dv; ++c)
-      dy[c] = ok ? fmaf(bf2f(g[pix * ldg + c]), ga[c], fmaf(bf2f(gx[pix * ldgx + c]), gb[c], gc[c])) : 0.f;
-    const float* op = o + pix * dv;
-    for (int d = 0; d < dv; ++d) {
+  __shared__ float dyS[CH * PT];
+  __shared__ float oS[CH * PT];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < dv * dv; t += 256) { ws[t] = w[t]; dws[t] = 0.f; }
+  for (size_t p0 = (size_t)blockIdx.x * CH; p0 < npix; p0 += (size_t)gridDim.x * CH) {
+    __syncthreads();                                   // previous chunk consumed (first time: ws / dws initialised)
+    for (int idx = tid; idx < CH * dv; idx += 256) {
+      const int px = idx / dv, c = idx - px * dv;
+      const size_t pix = p0 + px;
+      const bool ok = pix < npix;
+      dyS[px * PT + c] = ok ? fmaf(bf2f(g[pix * ldg + c]), ga[c], fmaf(bf2f(gx[pix * ldgx + c]), gb[c], gc[c])) : 0.f;
+      oS[px * PT + c] = ok ? o[pix * dv + c] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < CH * dv; idx += 256) {
+      const int px = idx / dv, d = idx - px * dv;
       float a = 0.f;
-      for (int c = 0; c < dv; ++c) a = fmaf(dy[c], ws[c * dv + d], a);
-      if (ok) d_o[pix * dv + d] = a;
-      const float od = op[d];
-      // every lane of the wave adds to the SAME word: reduce across the wave first (64-way same-address ds_add_f32 cost
-      // ~2900 cycles per add; this loop was 2.2 ms per call)
-      for (int c = 0; c < dv; ++c) {
-        float t = dy[c] * od;
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) t += __shfl_xor(t, sft);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&dws[c * dv + d], t);
-      }
+      for (int c = 0; c < dv; ++c) a = fmaf(dyS[px * PT + c], ws[c * dv + d], a);
+      if (p0 + px < npix) d_o[(p0 + px) * dv + d] = a;
+    }
+    for (int pair = tid; pair < dv * dv; pair += 256) {
+      const int c = pair / dv, d = pair - c * dv;
+      float a = 0.f;
+#pragma unroll 8
+      for (int px = 0; px < CH; ++px) a = fmaf(dyS[px * PT + c], oS[px * PT + d], a);
+      dws[pair] += a;
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < dv * dv; t += blockDim.x) atomicAdd(&dw[t], dws[t]);
+  for (int t = tid; t < dv * dv; t += 256) atomicAdd(&dw[t], dws[t]);
 }
 
 // fp32 (B,HW,C) -> bf16 same shape
@@ -786,7 +795,7 @@ int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* s
 int cx_aa_outproj_bwd(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
                       const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, void* stream) {
   if (!g || !gx || !ga || !gb || !gc || !o || !w || !d_o || !dw || dv <= 0 || dv > 48) return CX_EINVAL;
-  hipLaunchKernelGGL(aa_outproj_bwd_kernel, dim3(grid_for(npix, 128, 1024)), dim3(128), 0, as_stream(stream), (const bf16*)g, ldg,
+  hipLaunchKernelGGL(aa_outproj_bwd_kernel, dim3(grid_for(npix, 64, 1024)), dim3(256), 0, as_stream(stream), (const bf16*)g, ldg,
                      (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, npix, dv);
   return launch_status();
 }
