@@ -459,8 +459,8 @@ template <int NG, int NCHW>
 __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
-    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const int K, const int c_tiles,
-    const int n_tiles, const StripGeo g) {
+    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const int K, const int N,
+    const int c_tiles, const int n_tiles, const StripGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
   const int nk = (R * P + 15) / 16;
@@ -485,9 +485,10 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
   if (tid < 32) {
     coef[tid] = pa[c0 + tid];
     coef[32 + tid] = pb[c0 + tid];
-    coef[64 + tid] = g_affine2 ? ga[n0 + tid] : 1.f;
-    coef[96 + tid] = g_affine2 ? gb[n0 + tid] : 0.f;
-    coef[128 + tid] = g_affine2 ? gc[n0 + tid] : 0.f;
+    const int nn = n0 + tid < N ? n0 + tid : N - 1;   // the last output-channel tile may be partial (N % 8 == 0)
+    coef[64 + tid] = g_affine2 ? ga[nn] : 1.f;
+    coef[96 + tid] = g_affine2 ? gb[nn] : 0.f;
+    coef[128 + tid] = g_affine2 ? gc[nn] : 0.f;
   }
   __syncthreads();
 
@@ -540,11 +541,13 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
       const int yy = yc + crow[i];
-      gv[i] = crow[i] < R && yy < H;
+      const bool nok = n0 + cc8[i] * 8 < N;          // chunk of 8 output channels inside the tensor
+      gv[i] = crow[i] < R && yy < H && nok;
       const int yc_ = min(yy, H - 1);
       const size_t pixel = (size_t)(b * H + yc_) * W + cpx[i];
-      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + cc8[i] * 8);
-      if (g_affine2) pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + cc8[i] * 8);
+      const int co = nok ? cc8[i] * 8 : 0;
+      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + co);
+      if (g_affine2) pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + co);
     }
   };
   auto write_g = [&]() {
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
   }
   for (int idx = tid; idx < 32 * 288; idx += NTHR) {
     const int n = idx / 288, i = idx - n * 288;
-    atomicAdd(dw + ((size_t)(n0 + n) * K + c0) * 9 + i, red[idx]);
+    if (n0 + n < N) atomicAdd(dw + ((size_t)(n0 + n) * K + c0) * 9 + i, red[idx]);
   }
 }
 
@@ -713,11 +716,11 @@ int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
 int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   *handled = false;
   if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1) return 0;
-  if (p.K % 32 || p.N % 32 || p.K > 2048 || p.N > 2048 || p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
+  if (p.K % 32 || p.N % 8 || p.K > 2048 || p.N > 2048 || p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
   if (p.g_prologue != CX_PRO_NONE && p.g_prologue != CX_PRO_AFFINE2) return 0;
   if (p.W + 2 > 128 || p.W < 4) return 0;
   const long long px = (long long)p.B * p.H * p.W;
-  const int c_tiles = p.K / 32, n_tiles = p.N / 32, pairs = c_tiles * n_tiles;
+  const int c_tiles = p.K / 32, n_tiles = (p.N + 31) / 32, pairs = c_tiles * n_tiles;
   // pixel-range splits: the dense layers (4 tile pairs) take 64; wider convolutions ~768 workgroups in all, at least 4 splits
   int wide_splits = 768 / pairs;                 // 384 / 1536 / 3072 workgroups measured 1-3 % slower on ResNet152
   if (wide_splits < 4) wide_splits = 4;
@@ -743,7 +746,7 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
       const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
       hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<4, NCHW4>), dim3(splits * pairs), dim3(768), smem, st, (const bf16*)p.g, p.ldg,
                          (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx,
-                         p.pa, p.pb, p.dw, p.K, c_tiles, n_tiles, g);
+                         p.pa, p.pb, p.dw, p.K, p.N, c_tiles, n_tiles, g);
       *handled = true;
       return launch_status();
     }
@@ -764,7 +767,7 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<1, NCHW1>), dim3(splits * pairs), dim3(192), smem, st, (const bf16*)p.g, p.ldg,
                      (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx, p.pa, p.pb,
-                     p.dw, p.K, c_tiles, n_tiles, g);
+                     p.dw, p.K, p.N, c_tiles, n_tiles, g);
   *handled = true;
   return launch_status();
 }

@@ -226,6 +226,8 @@ def test_dgrad_1x1_many_tiles_replicated_stats(dev, pro, acc):
                                                       (3, 128, 32, 2, 1, 5, 20, 20), (3, 128, 32, 2, 1, 9, 10, 10), (3, 128, 32, 2, 1, 2, 33, 40),
                                                       # the same kernel on other channel counts (ResNet 3x3: K x N tile pairs)
                                                       (3, 256, 96, 2, 1, 2, 20, 20), (3, 64, 128, 2, 1, 2, 33, 40), (3, 96, 64, 0, 1, 1, 80, 80),
+                                                      # output channels not a multiple of 32 (AAConv conv branch: planes - dv)
+                                                      (3, 256, 232, 2, 1, 2, 20, 20), (3, 64, 40, 0, 1, 2, 9, 40),
                                                       # ring wgrad geometries (W >= 56): R = 3 at W = 80, partial last step, no g2
                                                       (3, 128, 32, 2, 1, 2, 80, 80), (3, 128, 32, 0, 1, 3, 57, 64)])
 def test_wgrad(dev, ksz, K, N, gpro, xpro, B, H, W):
