@@ -70,7 +70,7 @@ class KernelTimer:
         if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and (gp, xp, K, N) == (2, 1, 128, 32):
             return "conv3x3_ring_wgrad_kernel" if x.shape[2] >= 56 and x.shape[1] * x.shape[2] >= 3136 else "conv3x3_strip_wgrad_kernel"
         if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and N % 128 == 0 and K >= 64 and \
-                g.shape[0] * g.shape[1] * g.shape[2] * K >= (1 << 25):
+                g.shape[0] * g.shape[1] * g.shape[2] * K >= (1 << 23):
             return "pw_wgrad_kernel<%d, %d>" % (gp, xp)
         t = (64, 32) if mode == 2 else ((32, 128) if N == 32 else ((128, 64) if N % 128 == 0 else (64, 64)))
         return "wgrad_kernel<%d, %d, %d, %d, %d>" % (t[0], t[1], gp, xp, mode)
