@@ -93,8 +93,10 @@ class KernelTimer:
             alg = 2.0 * (mi * ci + mo * co)          # |X| + |Y| elements, bf16 (SURVEY 8d rule, per kernel)
             if kw.get("fused_dw") is not None:       # conv1x1_bwd.hip launch_bwd: 128-channel tiles for wide slices / big maps
                 wide = kw["N"] >= 128
-                tag = "pw_bwd_kernel<%d, %s, %d>" % (kw.get("prologue", 0), "true" if kw.get("accumulate") else "false",
-                                                     128 if wide else 64)
+                v1 = os.environ.get("CX_PW_BWD_V1", "0") not in ("", "0")
+                acc_s = "true" if kw.get("accumulate") else "false"
+                tag = ("pw_bwd2_kernel<%d, %s>" % (kw.get("prologue", 0), acc_s)) if wide and not v1 else \
+                    ("pw_bwd_kernel<%d, %s, %d>" % (kw.get("prologue", 0), acc_s, 128 if wide else 64))
                 alg += 2.0 * mo * co                 # the weight-gradient half also needs the layer input (|dZ| counted once)
             if self.only is not None and tag != self.only:
                 return og(x, w, y, **kw)
@@ -178,7 +180,8 @@ _T0 = time.perf_counter()
 
 
 def cpu_baseline(n_classes, steps=3, batch=4, size=320):
-    """The reference CPU path as restated by oracle/ (fp32, all host cores): forward + loss + backward."""
+    """The reference CPU path as restated by oracle/ (fp32, all host cores): the same step as the GPU line -- forward, loss,
+    backward and the Adam update (chexpert.py:159-164, :470)."""
     from chexpert_amd import synth
     from oracle import nets, step
     cores = host_cores()
@@ -187,17 +190,33 @@ def cpu_baseline(n_classes, steps=3, batch=4, size=320):
     sd = synth.fill_state_dict_(nets.zeros_state_dict(spec), 5)
     x, t = synth.xray_batch(11, batch, size), synth.targets(12, batch, n_classes)
     fwd = lambda s, xx: nets.densenet_forward(s, xx, train=True)
-    step.train_step(fwd, sd, x, t)          # warm-up
+    for k in step.trainable(sd):
+        sd[k].requires_grad_(True)
+    opt, _ = step.make_optimizer("adam", [sd[k] for k in step.trainable(sd)], 1e-4)
+    step.train_step(fwd, sd, x, t, opt)     # warm-up
     t0 = time.perf_counter()
     done = 0
     while done < steps or (time.perf_counter() - t0 < 12.0 and done < 400):      # a bounded sample: >= 3 steps and ~12 s of CPU work
-        step.train_step(fwd, sd, x, t)
+        step.train_step(fwd, sd, x, t, opt)
         done += 1
     steps = done
     dt = time.perf_counter() - t0
     return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "densenet121 fp32 CPU (oracle restatement of chexpert.py:159-163 fwd+loss+bwd), bs=%d, %d steps, %dx%d"
+            "sample": "densenet121 fp32 CPU (oracle restatement of chexpert.py:159-164 fwd+loss+bwd+Adam), bs=%d, %d steps, %dx%d"
                       % (batch, steps, size, size)}
+
+
+def committed_counter(kernel, args, key):
+    """Per-kernel figures from the committed counter passes (profiles/*_sq_counters.json: SQ_VALU_MFMA_BUSY_CYCLES /
+    SQ_BUSY_CU_CYCLES collected with rocprofv3 --pmc in their own run); null for other workloads."""
+    if (args.model, args.batch, args.size) != ("densenet121", 256, 320):
+        return None
+    d = os.path.join(ROOT, "profiles")
+    files = sorted(f for f in os.listdir(d) if f.endswith("_sq_counters.json")) if os.path.isdir(d) else []
+    if not files:
+        return None
+    k = json.load(open(os.path.join(d, files[-1])))["kernels"].get(kernel)
+    return None if k is None else k.get(key)
 
 
 def main():
@@ -211,6 +230,7 @@ def main():
     ap.add_argument("--model", default="densenet121", choices=["densenet121", "aadensenet121", "resnet152", "aaresnet152", "efficientnet-b4", "efficientnet-b0"],
                     help="densenet121 is the headline (BASELINE configs[1]); the others are reported for reference only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying the captured hipGraph")
     ap.add_argument("--roofline-kernel", default=None, help="kernel tag to time (default: the one with the largest share)")
     args = ap.parse_args()
 
@@ -296,7 +316,7 @@ def main():
             log("  %-34s %4d launches %7.2f ms  %6.0f GB/s" % (k, fam[k]["launches"], fam[k]["ms"],
                                                              fam[k]["alg_bytes"] / fam[k]["ms"] / 1e6))
         timer.records = {}
-    timer.enabled, timer.only = True, only
+    timer.enabled, timer.only = False, only
     log("warm-up done; roofline kernel = %s" % only)
 
     def barrier():
@@ -304,22 +324,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def eager_steps(n):
+        l = None
+        for _ in range(n):                      # a full training step: zero, forward, loss, backward (+ all-reduce), Adam update
+            model.zero_grad()
+            l, _ = step()
+            if opt is not None:
+                opt.step()
+        return l
+
+    # N = 1: the step is captured once as a hipGraph (chexpert_amd/graph.py) and the timed region replays it -- the ~900
+    # launches of a step cost ~18 ms of host time when enqueued one by one.  N > 1 enqueues eagerly (RCCL collectives are
+    # issued from Python between the kernels).  HIP events cannot be recorded inside a captured graph, so the dominant
+    # kernel's launch time is taken with events in an eager replica of the same K steps right after the timed region.
+    use_graph = (world == 1 and opt is not None and not args.no_graph and os.environ.get("CHEXPERT_BENCH_GRAPH", "1") != "0"
+                 and not args.model.startswith("efficientnet"))
+    gstep = None
+    if use_graph:
+        from chexpert_amd.graph import GraphedTrainStep
+        timer.enabled = False
+        try:
+            gstep = GraphedTrainStep(model, opt, x, t)
+            for _ in range(max(1, args.warmup)):
+                gstep.replay()
+            torch.cuda.synchronize()
+            log("hipGraph captured and warmed up")
+        except Exception as e:                   # capture is an optimisation of the host side only: fall back loudly
+            log("graph capture failed (%s: %s); timing the eager step" % (type(e).__name__, e))
+            gstep = None
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):                 # a full training step: zero, forward, loss, backward (+ all-reduce), Adam update
-        model.zero_grad()
-        loss, _ = step()
-        if opt is not None:
-            opt.step()
+    if gstep is not None:
+        for _ in range(args.steps):
+            loss, _ = gstep.replay()
+    else:
+        timer.enabled, timer.only = True, only
+        loss = eager_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    log("timed region done: %.1f ms/step (%s)" % (dt / args.steps * 1e3, "graph replay" if gstep is not None else "eager"))
+    if gstep is not None:
+        opt.sync_from_device()
+        timer.enabled, timer.only, timer.records = True, only, {}
+        e0 = time.perf_counter()
+        eager_steps(args.steps)
+        torch.cuda.synchronize()
+        log("eager replica for the kernel events: %.1f ms/step" % ((time.perf_counter() - e0) / args.steps * 1e3))
     timer.enabled = False
     ksum = timer.summary()[only]
-    log("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
 
     # optimiser step timed on its own as well (it IS inside the timed region above; reported for reference)
     torch.cuda.synchronize()
@@ -350,11 +406,15 @@ def main():
                        "images_per_sec_per_gpu": round(value / world, 2),
                        "model_hbm_roofline_frac": round(value / world * ALG_BYTES[args.model] / (HBM_PEAK_GBS * 1e9), 4),
                        "optimizer_step_ms": round(opt_ms, 3), "loss": round(float(loss.item()), 5),
-                       "measured_copy_GBs": round(copy_gbs, 1)},
+                       "measured_copy_GBs": round(copy_gbs, 1),
+                       "launch": "hipGraph replay" if gstep is not None else "eager enqueue"},
             "roofline": {"bound": "hbm", "kernel": only, "launches_per_step": ksum["launches"] // args.steps,
                          "avg_launch_ms": round(avg_ms, 4), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(only, args), "alg_bytes_per_launch": round(ksum["alg_bytes"] / ksum["launches"])},
+                         "traffic": pmc_traffic(only, args), "alg_bytes_per_launch": round(ksum["alg_bytes"] / ksum["launches"]),
+                         "mfma_util": committed_counter(only, args, "mfma_util"),
+                         "timing": "hip events around each launch, eager replica of the timed steps" if gstep is not None
+                         else "hip events around each launch inside the timed region"},
         }
         if not args.no_cpu_baseline and args.model == "densenet121" and world == 1:
             log("cpu baseline on %d cores ..." % host_cores())

@@ -73,6 +73,10 @@ SIGNATURES = {
     "cx_adam_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp],
     "cx_sgd_nesterov_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _f, _vp],
     "cx_rmsprop_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp],
+    "cx_adam_step_dev": [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _vp],
+    "cx_sgd_nesterov_step_dev": [_vp, _vp, _vp, _sz, _vp, _f, _f, _f, _vp],
+    "cx_rmsprop_step_dev": [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _vp],
+    "cx_optim_tick": [_vp, _vp],
     "cx_aa_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_aa_attention_weights": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_aa_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -120,7 +124,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cx_error_string" else C.c_int
-        if l.cx_abi_version() != 2:
+        if l.cx_abi_version() != 3:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l
     return _lib

@@ -290,6 +290,272 @@ __global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const 
   }
 }
 
+// ---- v2 (round 2): the 128-channel form with 64-pixel tiles and the NEXT tile's operands in flight under the current tile's
+// MFMA / epilogue phases.  v1 issued a tile's loads, waited, then ran two MFMA phases and a VALU epilogue with nothing in flight
+// (3.3 TB/s of real traffic).  Halving the tile halves every per-thread register block (accumulators, channel sums, staging), which
+// pays for one prefetched tile in registers: dZ / y1 of tile t+1 are requested right after tile t's staging barrier, x / old dX of
+// tile t+1 right after tile t's epilogue.  The dZ and relu(bn(x)) images are double buffered in LDS: two barriers per tile.
+constexpr int BM2 = 64;
+constexpr int A2_BYTES = BM2 * PITCH;
+constexpr int XH2_BYTES = BM2 * XH_PITCH;
+
+template <int PRO, bool ACC>
+__global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* __restrict__ dw, const int M, const int c_tiles,
+                                                         const int tiles_per_split) {
+  constexpr int BC = 128, NT = 512;
+  constexpr int W_BYTES = BC * PITCH;
+  constexpr int COEF_BYTES = (5 * BC + 3 * KD) * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ecoef = reinterpret_cast<float*>(smem);
+  char* Wt = smem + COEF_BYTES;                                 // [128 c][272 B]
+  char* At = Wt + W_BYTES;                                      // [2][64 px][272 B]
+  char* Xh = At + 2 * A2_BYTES;                                 // [2][4][64 px][64 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = id % c_tiles, split = id / c_tiles;
+  const int c0 = ct * BC;
+  const int m_tiles = (M + BM2 - 1) / BM2;
+  const int t0 = split * tiles_per_split;
+  const int t1 = (t0 + tiles_per_split < m_tiles) ? t0 + tiles_per_split : m_tiles;
+
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const bf16* __restrict__ X2 = reinterpret_cast<const bf16*>(p.x2);
+  const bf16* __restrict__ Wp = reinterpret_cast<const bf16*>(p.w);
+  const bf16* __restrict__ EX = reinterpret_cast<const bf16*>(p.ex);
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+
+  if (tid < BC) {
+    const int n = c0 + tid;
+    const bool ok = n < p.N;
+    ecoef[tid] = ok ? p.e_sc[n] : 0.f;
+    ecoef[BC + tid] = ok ? p.e_sh[n] : 0.f;
+    ecoef[2 * BC + tid] = ok ? p.e_mu[n] : 0.f;
+    ecoef[3 * BC + tid] = ok ? p.e_r[n] : 0.f;
+    ecoef[4 * BC + tid] = ok ? p.e_scale[n] : 0.f;
+  }
+  const int q = tid & 15, r0 = tid >> 4;                        // dZ staging: chunk q of rows r0 and r0 + 32
+#pragma unroll
+  for (int i = 0; i < BC / 32; ++i) {
+    const int n = c0 + r0 + 32 * i;
+    const uint4 v = *reinterpret_cast<const uint4*>(Wp + (size_t)(n < p.N ? n : 0) * KD + q * 8);
+    *reinterpret_cast<uint4*>(Wt + (r0 + 32 * i) * PITCH + q * 16) = n < p.N ? v : make_uint4(0, 0, 0, 0);
+  }
+  if (PRO == CX_PRO_AFFINE2 && tid < KD) {
+    ecoef[5 * BC + tid] = p.pa[tid];
+    ecoef[5 * BC + KD + tid] = p.pb[tid];
+    ecoef[5 * BC + 2 * KD + tid] = p.pc[tid];
+  }
+  const float* aco = ecoef + 5 * BC + q * 8;
+
+  // input gradient: wave = (pixel half pw, 32-channel quarter cq); weight gradient: n sub-tile wn, c sub-tiles wc0, wc0 + 1
+  const int pw = wave & 1, cq = wave >> 1;
+  const int wn = wave & 3, wc0 = (wave >> 2) * 2;
+  f32x16 accw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+  float s1[2][8], s2[2][8];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[cc][e] = s2[cc][e] = 0.f;
+
+  // channel offsets of this lane's two 8-channel groups (clamped for loads, exact for stores)
+  int ncl[2];
+  bool nok[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int n = c0 + cq * 32 + 8 * (2 * cc + lh);
+    nok[cc] = n < p.N;
+    ncl[cc] = nok[cc] ? n : 0;
+  }
+
+  uint4 ru[2], rv[2];
+  U128 xv[2], old[2];
+  // ---- first tile's operands
+  {
+    const int m0 = t0 * BM2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mm = m0 + r0 + 32 * i;
+      const int mmc = mm < M ? mm : M - 1;
+      ru[i] = *reinterpret_cast<const uint4*>(X + (size_t)mmc * p.ldx + q * 8);
+      if (PRO == CX_PRO_AFFINE2) rv[i] = *reinterpret_cast<const uint4*>(X2 + (size_t)mmc * p.ldx2 + q * 8);
+    }
+    const int m = m0 + pw * 32 + lrow;
+    const int mc = m < M ? m : M - 1;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      xv[cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl[cc]);
+      if (ACC) old[cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl[cc]);
+      else old[cc].u = make_uint4(0, 0, 0, 0);
+    }
+  }
+  __syncthreads();                                              // coefficients (read by the staging) and weights visible
+
+  for (int mt = t0; mt < t1; ++mt) {
+    const int m0 = mt * BM2;
+    const int bsel = (mt - t0) & 1;
+    char* Ab_ = At + bsel * A2_BYTES;
+    char* Xb_ = Xh + bsel * (4 * XH2_BYTES);
+    // ---- dZ tile (already in registers) -> LDS
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = r0 + 32 * i;
+      U128 o;
+      if (PRO == CX_PRO_NONE) {
+        o.u = ru[i];
+      } else {
+        U128 u, v;
+        u.u = ru[i];
+        v.u = rv[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
+      }
+      const unsigned keep = m0 + row < M ? 0xffffffffu : 0u;
+      o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
+      *reinterpret_cast<uint4*>(Ab_ + row * PITCH + q * 16) = o.u;
+    }
+    __syncthreads();                              // dZ tile visible; the other At / Xh buffers are free (their readers passed here)
+    // ---- next tile's dZ / y1 (clamped tile index: the last iteration re-requests its own tile instead of branching)
+    const int mtn = mt + 1 < t1 ? mt + 1 : mt;
+    {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int mm = mtn * BM2 + r0 + 32 * i;
+        const int mmc = mm < M ? mm : M - 1;
+        ru[i] = *reinterpret_cast<const uint4*>(X + (size_t)mmc * p.ldx + q * 8);
+        if (PRO == CX_PRO_AFFINE2) rv[i] = *reinterpret_cast<const uint4*>(X2 + (size_t)mmc * p.ldx2 + q * 8);
+      }
+    }
+    // ---- input gradient of this wave's 32 pixels x 32 channels: D[row = channel][col = pixel]
+    f32x16 accd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+    {
+      const char* Ab = Ab_ + (pw * 32 + lrow) * PITCH + lh * 16;
+      const char* Wb = Wt + (cq * 32 + lrow) * PITCH + lh * 16;
+#pragma unroll
+      for (int kk = 0; kk < KD / 16; ++kk) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + kk * 32);
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wb + kk * 32);
+        accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, accd, 0, 0, 0);
+      }
+    }
+    // ---- mask epilogue; relu(bn(x)) goes to LDS for the second product
+    const int m = m0 + pw * 32 + lrow;
+    const bool pok = m < M;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int cl = cq * 32 + 8 * (2 * cc + lh);
+      float v[8];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accd[8 * cc + r4]), __float_as_uint(accd[8 * cc + 4 + r4]), false, false);
+        v[r4] = __uint_as_float(sw[0]);
+        v[4 + r4] = __uint_as_float(sw[1]);
+      }
+      const float4 a0 = *reinterpret_cast<const float4*>(ecoef + cl), a1 = *reinterpret_cast<const float4*>(ecoef + cl + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(ecoef + BC + cl), b1 = *reinterpret_cast<const float4*>(ecoef + BC + cl + 4);
+      const float4 e0 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl), e1 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl + 4);
+      const float esc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+      U128 o, xh;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xf = bf2f(xv[cc].e[e]);
+        const float pre = fmaf(xf, esc[e], esh[e]);
+        const bool on = pok && pre > 0.f;
+        const float dz = on ? v[e] : 0.f;
+        s1[cc][e] += dz;
+        s2[cc][e] = fmaf(dz, xf, s2[cc][e]);
+        o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[cc].e[e])));
+        xh.e[e] = f2bf(on ? pre : 0.f);
+      }
+      if (pok && nok[cc]) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + ncl[cc]) = o.u;
+      *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
+    }
+    // ---- next tile's x / old dX
+    {
+      const int mn = mtn * BM2 + pw * 32 + lrow;
+      const int mc = mn < M ? mn : M - 1;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        xv[cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl[cc]);
+        if (ACC) old[cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl[cc]);
+      }
+    }
+    __syncthreads();                              // relu(bn(x)) tile visible
+    // ---- weight gradient: dW[n][c] += sum over the 64 pixels of the tile
+#pragma unroll
+    for (int kk = 0; kk < BM2 / 16; ++kk) {
+      const bf16x8 af = tr_frag(Ab_, PITCH, kk * 16, wn * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 bfr = tr_frag(Xb_ + (wc0 + i) * XH2_BYTES, XH_PITCH, kk * 16, 0, lane);
+        accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = c0 + (wc0 + i) * 32 + lrow;
+    if (c < p.N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        atomicAdd(dw + (size_t)n * p.N + c, accw[i][r]);
+      }
+    }
+  }
+  {
+    const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+    float t1v = 0.f, t2v = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = half_sum(s1[cc][e]);
+        const float b = half_sum(s2[cc][e]);
+        if (lrow == 8 * cc + e) { t1v = a; t2v = b; }
+      }
+    if (lrow < 16) {
+      const int cl = cq * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
+      const int n = c0 + cl;
+      if (n < p.N) {
+        atomicAdd(&p.stat_sum[rep + n], t1v);
+        atomicAdd(&p.stat_sq[rep + n], ecoef[3 * BC + cl] * (t2v - ecoef[2 * BC + cl] * t1v));
+      }
+    }
+  }
+}
+
+template <int PRO, bool ACC>
+int launch_bwd2(const CxConv& p, float* dw, hipStream_t st) {
+  constexpr int BC = 128;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + BM2 - 1) / BM2);
+  const int c_tiles = (p.N + BC - 1) / BC;
+  int splits = 512 / c_tiles;
+  if (splits < 1) splits = 1;
+  if (splits > m_tiles) splits = m_tiles;
+  const int tps = (m_tiles + splits - 1) / splits;
+  splits = (m_tiles + tps - 1) / tps;
+  const size_t smem = (5 * BC + 3 * KD) * 4 + BC * PITCH + 2 * A2_BYTES + 2 * 4 * XH2_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd2_kernel<PRO, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL((pw_bwd2_kernel<PRO, ACC>), dim3(c_tiles * splits), dim3(512), smem, st, p, dw, (int)M, c_tiles, tps);
+  return launch_status();
+}
+
 template <int PRO, bool ACC, int BC>
 int launch_bwd_bc(const CxConv& p, float* dw, hipStream_t st) {
   const long long M = (long long)p.B * p.Ho * p.Wo;
@@ -315,6 +581,8 @@ template <int PRO, bool ACC>
 int launch_bwd(const CxConv& p, float* dw, hipStream_t st) {
   static const int force = []() { const char* e = getenv("CX_PW_BWD_BC"); return e ? atoi(e) : 0; }();
   const bool wide = force ? force == 128 : p.N >= 128;  // measured crossover
+  static const int v1 = []() { const char* e = getenv("CX_PW_BWD_V1"); return e ? atoi(e) : 0; }();   // diagnostic: the round-1 kernel
+  if (wide && !v1) return launch_bwd2<PRO, ACC>(p, dw, st);
   return wide ? launch_bwd_bc<PRO, ACC, 128>(p, dw, st) : launch_bwd_bc<PRO, ACC, 64>(p, dw, st);
 }
 

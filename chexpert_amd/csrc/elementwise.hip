@@ -682,6 +682,71 @@ __global__ void cam_norm_upsample_kernel(const float* __restrict__ cam, float* _
   }
 }
 
+// ---- optimiser steps with the learning rate and the step count in device memory (`hyper`), so that a captured hipGraph can
+// be replayed while both change: hyper = {lr, steps_done, sched_kind, gamma, warmup_steps, milestone0, milestone1, base_lr}.
+// cx_optim_tick advances steps_done and applies the reference's schedulers (chexpert.py:165: stepped once per minibatch from
+// lr_warmup_steps on; :480 MultiStepLR, :500 ExponentialLR).
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                size_t n, const float* __restrict__ hyper, float b1, float b2, float eps, float wd, float gscale) {
+  const float lr = hyper[0], step = hyper[1] + 1.f;
+  const float bc1 = 1.f - powf(b1, step), bc2_sqrt = sqrtf(1.f - powf(b2, step));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+__global__ void sgd_nesterov_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n,
+                                        const float* __restrict__ hyper, float mom, float wd, float gscale) {
+  const float lr = hyper[0];
+  const bool first = hyper[1] == 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float bi = first ? gi : mom * buf[i] + gi;
+    buf[i] = bi;
+    p[i] = pi - lr * (gi + mom * bi);
+  }
+}
+__global__ void rmsprop_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ buf,
+                                   size_t n, const float* __restrict__ hyper, float alpha, float eps, float mom, float wd, float gscale) {
+  const float lr = hyper[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float si = alpha * sq[i] + (1.f - alpha) * gi * gi;
+    sq[i] = si;
+    const float avg = sqrtf(si) + eps;
+    if (mom > 0.f) {
+      const float bi = mom * buf[i] + gi / avg;
+      buf[i] = bi;
+      p[i] = pi - lr * bi;
+    } else {
+      p[i] = pi - lr * gi / avg;
+    }
+  }
+}
+__global__ void optim_tick_kernel(float* hyper) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float step = hyper[1] + 1.f;
+  hyper[1] = step;
+  const int kind = (int)hyper[2];
+  const float sched = step - hyper[4];                 // scheduler.step() calls so far minus one (one per minibatch once step >= warmup)
+  if (kind == 1 && sched >= 0.f) hyper[0] *= hyper[3];                                     // ExponentialLR
+  if (kind == 2 && sched >= 0.f) {                                                        // MultiStepLR, two milestones
+    const float k = (sched + 1.f >= hyper[5] ? 1.f : 0.f) + (sched + 1.f >= hyper[6] ? 1.f : 0.f);
+    hyper[0] = hyper[7] * powf(hyper[3], k);
+  }
+}
+
 inline int grid_for(size_t n, int block, int cap = 4096) {
   size_t g = (n + block - 1) / block;
   if (g > (size_t)cap) g = cap;
@@ -888,6 +953,36 @@ int cx_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, bc1, bc2s, grad_scale);
+  return launch_status();
+}
+
+int cx_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2, float eps,
+                     float weight_decay, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !hyper) return CX_EINVAL;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, hyper, beta1, beta2,
+                     eps, weight_decay, grad_scale);
+  return launch_status();
+}
+
+int cx_sgd_nesterov_step_dev(float* p, const float* g, float* buf, size_t n, const float* hyper, float momentum, float weight_decay,
+                             float grad_scale, void* stream) {
+  if (!p || !g || !buf || !hyper) return CX_EINVAL;
+  hipLaunchKernelGGL(sgd_nesterov_dev_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, g, buf, n, hyper,
+                     momentum, weight_decay, grad_scale);
+  return launch_status();
+}
+
+int cx_rmsprop_step_dev(float* p, const float* g, float* sq, float* buf, size_t n, const float* hyper, float alpha, float eps,
+                        float momentum, float weight_decay, float grad_scale, void* stream) {
+  if (!p || !g || !sq || !hyper || (momentum > 0.f && !buf)) return CX_EINVAL;
+  hipLaunchKernelGGL(rmsprop_dev_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, g, sq, buf, n, hyper, alpha,
+                     eps, momentum, weight_decay, grad_scale);
+  return launch_status();
+}
+
+int cx_optim_tick(float* hyper, void* stream) {
+  if (!hyper) return CX_EINVAL;
+  hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(64), 0, as_stream(stream), hyper);
   return launch_status();
 }
 

@@ -223,6 +223,25 @@ def rmsprop_step(p, g, sq, buf, lr, alpha, eps, momentum, weight_decay, grad_sca
                                 grad_scale, stream_ptr()), "cx_rmsprop_step")
 
 
+def adam_step_dev(p, g, m, v, hyper, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    check(lib().cx_adam_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(hyper), beta1, beta2, eps, weight_decay, grad_scale,
+                                 stream_ptr()), "cx_adam_step_dev")
+
+
+def sgd_nesterov_step_dev(p, g, buf, hyper, momentum, weight_decay, grad_scale=1.0):
+    check(lib().cx_sgd_nesterov_step_dev(ptr(p), ptr(g), ptr(buf), p.numel(), ptr(hyper), momentum, weight_decay, grad_scale,
+                                         stream_ptr()), "cx_sgd_nesterov_step_dev")
+
+
+def rmsprop_step_dev(p, g, sq, buf, hyper, alpha, eps, momentum, weight_decay, grad_scale=1.0):
+    check(lib().cx_rmsprop_step_dev(ptr(p), ptr(g), ptr(sq), ptr(buf), p.numel(), ptr(hyper), alpha, eps, momentum, weight_decay,
+                                    grad_scale, stream_ptr()), "cx_rmsprop_step_dev")
+
+
+def optim_tick(hyper):
+    check(lib().cx_optim_tick(ptr(hyper), stream_ptr()), "cx_optim_tick")
+
+
 def bf16_to_f32_nchw(x, out=None):
     B, H, W, Cc, ldx = _nhwc(x)
     if out is None:

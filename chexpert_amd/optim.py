@@ -30,6 +30,29 @@ class _Flat:
     def zero_grad(self, set_to_none=True):
         self.model.zero_grad(set_to_none=set_to_none)
 
+    # ---- device-resident hyper-parameters (graph replay: chexpert_amd/graph.py)
+    SCHED = (0, 1.0, (0, 0))        # (kind, gamma, milestones): 0 none, 1 ExponentialLR, 2 MultiStepLR
+
+    def hyper(self, warmup_steps=0):
+        """float[8] on the device: {lr, steps_done, sched_kind, gamma, lr_warmup_steps, milestone0, milestone1, base_lr}
+        (include/chexpert_hip.h, cx_optim_tick).  Created from the host-side state on first use; from then on the device
+        copy is the truth for `step_dev()` / `tick()` and `sync_from_device()` reads it back."""
+        if getattr(self, "_hyper", None) is None:
+            kind, gamma, ms = self.SCHED if not hasattr(self, "_sched") else self._sched
+            eng = self.model._eng()
+            self._hyper = torch.tensor([self.lr, float(self.step_count), float(kind), float(gamma), float(warmup_steps),
+                                        float(ms[0]), float(ms[1]), self.base_lr], dtype=torch.float32, device=eng.flat.device)
+        return self._hyper
+
+    def tick(self):
+        """steps_done += 1 and the scheduler step of chexpert.py:165, on the device."""
+        ops.optim_tick(self.hyper())
+
+    def sync_from_device(self):
+        if getattr(self, "_hyper", None) is not None:
+            h = self._hyper.cpu()
+            self.lr, self.step_count = float(h[0]), int(h[1])
+
 
 class FusedAdam(_Flat):
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
@@ -41,11 +64,21 @@ class FusedAdam(_Flat):
         self.step_count += 1
         ops.adam_step(p, g, m, v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, grad_scale)
 
+    def step_dev(self, grad_scale=1.0):
+        p, g, (m, v) = self._bufs(2)
+        ops.adam_step_dev(p, g, m, v, self.hyper(), self.betas[0], self.betas[1], self.eps, self.wd, grad_scale)
+
 
 class FusedSGDNesterov(_Flat):
     def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, milestones=(40000, 60000), gamma=0.1):
         super().__init__(model, lr)
         self.momentum, self.wd, self.milestones, self.gamma = momentum, weight_decay, tuple(milestones), gamma
+        ms = (tuple(milestones) + (1 << 30, 1 << 30))[:2]
+        self._sched = (2, gamma, ms)
+
+    def step_dev(self, grad_scale=1.0):
+        p, g, (buf,) = self._bufs(1)
+        ops.sgd_nesterov_step_dev(p, g, buf, self.hyper(), self.momentum, self.wd, grad_scale)
 
     def step(self, grad_scale=1.0):
         p, g, (buf,) = self._bufs(1)
@@ -61,6 +94,11 @@ class FusedRMSprop(_Flat):
     def __init__(self, model, lr, alpha=0.99, eps=1e-3, momentum=0.9, weight_decay=0.0, decay=0.97):
         super().__init__(model, lr)
         self.alpha, self.eps, self.momentum, self.wd, self.decay = alpha, eps, momentum, weight_decay, decay
+        self._sched = (1, decay, (0, 0))
+
+    def step_dev(self, grad_scale=1.0):
+        p, g, (sq, buf) = self._bufs(2)
+        ops.rmsprop_step_dev(p, g, sq, buf, self.hyper(), self.alpha, self.eps, self.momentum, self.wd, grad_scale)
 
     def step(self, grad_scale=1.0):
         p, g, (sq, buf) = self._bufs(2)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 2
+#define CX_ABI_VERSION 3
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4 };
 
@@ -210,6 +210,18 @@ int cx_sgd_nesterov_step(float* p, const float* g, float* buf, size_t n, float l
                          float weight_decay, int first_step, float grad_scale, void* stream);
 int cx_rmsprop_step(float* p, const float* g, float* sq, float* buf, size_t n, float lr, float alpha, float eps,
                     float momentum, float weight_decay, float grad_scale, void* stream);
+
+/* The same updates with the learning rate and the step count read from device memory, so a captured hipGraph of the training
+ * step (chexpert.py:159-165) can be replayed while both change: hyper = float[8] {lr, steps_done, sched_kind (0 none,
+ * 1 ExponentialLR chexpert.py:500, 2 MultiStepLR :480), gamma, lr_warmup_steps (:165), milestone0, milestone1, base_lr}.
+ * cx_optim_tick = "step += 1; if step >= lr_warmup_steps: scheduler.step()" (:165).                                            */
+int cx_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2,
+                     float eps, float weight_decay, float grad_scale, void* stream);
+int cx_sgd_nesterov_step_dev(float* p, const float* g, float* buf, size_t n, const float* hyper, float momentum,
+                             float weight_decay, float grad_scale, void* stream);
+int cx_rmsprop_step_dev(float* p, const float* g, float* sq, float* buf, size_t n, const float* hyper, float alpha, float eps,
+                        float momentum, float weight_decay, float grad_scale, void* stream);
+int cx_optim_tick(float* hyper, void* stream);
 
 /* ---- attention-augmented convolution (AAConv2d, models/attn_aug_conv.py:19-100) --------------------
  * qkv: bf16 (B, H*W, ldq) output of in_proj_qkv (channels [q dk | k dk | v dv], head-major), dk = 20*nh.

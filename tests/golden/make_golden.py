@@ -212,6 +212,9 @@ def gen_nets(out_dir, which):
         "resnet152_320_b2": lambda: (ResNet(Bottleneck, [3, 8, 36, 3], num_classes=n_cls),
                                      nets.resnet_spec(n_cls), 2, 320,
                                      lambda s, x, train: nets.resnet_forward(s, x, train=train)),
+        "aaresnet152_320_b1": lambda: (ResNet(Bottleneck, [3, 8, 36, 3], num_classes=n_cls, attn_params=ref_attn((320, 320))),
+                                       nets.resnet_spec(n_cls, attn=attn), 1, 320,
+                                       lambda s, x, train: nets.resnet_forward(s, x, train=train, nh=8)),
         "resnet_tiny_64_b2": lambda: (ResNet(Bottleneck, [1, 1, 1, 1], num_classes=n_cls),
                                       nets.resnet_spec(n_cls, layers=(1, 1, 1, 1)), 2, 64,
                                       lambda s, x, train: nets.resnet_forward(s, x, (1, 1, 1, 1), train=train)),

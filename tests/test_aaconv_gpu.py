@@ -223,3 +223,33 @@ def test_aadensenet121_reference_golden_eval(dev):
     e = _rel(le, torch.tensor(rec["logits_eval"]))
     print("aadensenet121 golden eval logits rel %.3e" % e)
     assert e < 1e-2
+
+
+def test_aadensenet121_reference_golden_train_step(dev):
+    """BASELINE configs[2] at full size: one training step of aadensenet121 @320 (B = 1) against the logits / loss / gradient
+    norms recorded from the REAL reference (tests/golden/nets.json: aadensenet121_320_b1)."""
+    import json
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nets.json")))["aadensenet121_320_b1"]
+    model, sd = _build_aa((6, 12, 24, 16), 320, rec["n_classes"], rec["sd_seed"], dev, smooth=False)
+    x = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"]).to(dev)
+    t = synth.targets(rec["t_seed"], rec["B"], rec["n_classes"]).to(dev)
+    model.train()
+    loss, logits = model.forward_backward(x, t)
+    want = torch.tensor(rec["logits_train"])
+    e = _rel(logits.cpu(), want)
+    print("aadensenet121 golden train logits rel %.3e loss %.5f (ref %.5f)" % (e, loss.item(), rec["loss"]))
+    # B = 1: every BatchNorm of block 4 normalises over 100 values per channel, which amplifies bf16 storage rounding
+    # (tests/test_model_gpu.py docstring); north_star's 1e-2 is stated for this dtype
+    assert e < 2e-2
+    assert abs(loss.item() - rec["loss"]) < 1e-2 * rec["loss"]
+    named = dict(model.named_parameters())
+    rows = []
+    for k in ("classifier.weight", "classifier.bias", "features.norm5.weight", "features.transition3.conv.conv.weight",
+              "features.transition3.conv.in_proj_qkv.weight", "features.transition1.conv.key_rel_h",
+              "features.transition1.conv.key_rel_w", "features.conv0.weight"):
+        l2, ref = named[k].grad.double().norm().item(), rec["grads"][k]["l2"]
+        rows.append((k, l2 / ref))
+    print("aadensenet121 golden grad l2 ratios: %s" % rows)
+    for k, r in rows:
+        lim = 0.05 if k.startswith("classifier") or "norm5" in k else 0.15
+        assert abs(r - 1) < lim, (k, r)

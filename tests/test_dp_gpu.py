@@ -9,21 +9,39 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir):
+def _make(kind):
+    """One small model per engine: each engine has its own `red.ready()` call sites in backward (densenet.py, resnet.py,
+    efficientnet.py); a `ready()` fired before the kernels that fill the range are enqueued would average stale gradients."""
+    from chexpert_amd.models import Bottleneck, DenseNet, ResNet, construct_model
+    if kind == "densenet":
+        model, head, S = DenseNet(32, (2, 2, 2, 2), 64, num_classes=5), "classifier", 64
+    elif kind == "resnet":
+        model, head, S = ResNet(Bottleneck, [1, 2, 2, 1], num_classes=5), "fc", 64
+    else:
+        from chexpert_amd.models.efficientnet import DropMarker
+        model, head, S = construct_model("efficientnet-b0", 5), "head", 96
+        for mod in model.modules():                      # the two backward passes must see the same network
+            if isinstance(mod, DropMarker):
+                mod.p = 0.0
+    if kind != "efficientnet":
+        for n_, p in model.named_parameters():           # well-conditioned regime (tests/test_model_gpu.py)
+            if n_.endswith(".bias") and head not in n_:
+                p.data.fill_(2.5 if kind == "densenet" else 1.0)
+    return model, S
+
+
+def _worker(rank, world, port, out_dir, kind):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from chexpert_amd import synth
-    from chexpert_amd.models import DenseNet
     from chexpert_amd.parallel import broadcast_module_state
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
-    model = DenseNet(32, (2, 2, 2, 2), 64, num_classes=5).to(dev).train()
-    for n_, p in model.named_parameters():               # well-conditioned regime (tests/test_model_gpu.py)
-        if n_.endswith(".bias") and "classifier" not in n_:
-            p.data.fill_(2.5)
+    model, S = _make(kind)
+    model = model.to(dev).train()
     broadcast_module_state(model)
-    x = synth.xray_batch(100 + rank, 4, 64).to(dev)
+    x = synth.xray_batch(100 + rank, 4, S).to(dev)
     t = synth.targets(200 + rank, 4, 5).to(dev)
     model.forward_backward(x, t)                          # binds the engine; local gradient, no reducer yet
     eng = model._eng()
@@ -43,12 +61,13 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_data_parallel_backward_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("kind", ["densenet", "resnet", "efficientnet"])
+def test_data_parallel_backward_two_ranks_one_gpu(tmp_path, kind):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 400)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 400) + {"densenet": 0, "resnet": 400, "efficientnet": 800}[kind]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), kind), nprocs=2, join=True)
     for r in range(2):
         rec = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
         assert rec["same"], "ranks ended with different gradients"

@@ -442,6 +442,46 @@ def test_fused_optimisers_match_torch_optim(dev, kind):
     close(p.cpu(), pc.detach(), rel=2e-6, what=kind)
 
 
+@pytest.mark.parametrize("kind", ["adam", "sgd_nesterov", "rmsprop"])
+def test_device_hyper_optimisers_and_schedulers_match_torch(dev, kind):
+    """cx_*_step_dev + cx_optim_tick (learning rate / step count in device memory, for hipGraph replay) against torch.optim with
+    the reference's scheduler wiring: `scheduler.step()` once per minibatch from `lr_warmup_steps` on (chexpert.py:165),
+    MultiStepLR (:480) for SGD, ExponentialLR (:500) for RMSprop, none for Adam."""
+    from chexpert_amd import ops
+    from oracle import step as ostep
+    n, warm, lr0 = 4099, 2, 1e-2
+    p0 = rnd(140, (n,))
+    pc = p0.clone().requires_grad_(True)
+    opt, _ = ostep.make_optimizer(kind, [pc], lr0)
+    sched = None
+    kindc, gamma, ms = 0, 1.0, (0, 0)
+    if kind == "sgd_nesterov":
+        sched, kindc, gamma, ms = torch.optim.lr_scheduler.MultiStepLR(opt, [2, 4], 0.1), 2, 0.1, (2, 4)
+    if kind == "rmsprop":
+        sched, kindc, gamma = torch.optim.lr_scheduler.ExponentialLR(opt, 0.97), 1, 0.97
+    hyper = torch.tensor([lr0, 0, kindc, gamma, warm, ms[0], ms[1], lr0], dtype=torch.float32, device=dev)
+    p = p0.clone().to(dev)
+    st = [torch.zeros(n, device=dev) for _ in range(2)]
+    for it in range(8):
+        g = rnd(141 + it, (n,))
+        pc.grad = g.clone()
+        opt.step()
+        if sched is not None and it >= warm:
+            sched.step()
+        gd = g.to(dev)
+        if kind == "adam":
+            ops.adam_step_dev(p, gd, st[0], st[1], hyper, 0.9, 0.999, 1e-8, 0.0)
+        elif kind == "sgd_nesterov":
+            ops.sgd_nesterov_step_dev(p, gd, st[0], hyper, 0.9, 0.0)
+        else:
+            ops.rmsprop_step_dev(p, gd, st[0], st[1], hyper, 0.99, 1e-3, 0.9, 0.0)
+        ops.optim_tick(hyper)
+        h = hyper.cpu()
+        assert int(h[1]) == it + 1
+        assert abs(float(h[0]) - opt.param_groups[0]["lr"]) <= 1e-6 * lr0, (it, float(h[0]), opt.param_groups[0]["lr"])
+    close(p.cpu(), pc.detach(), rel=5e-6, what=kind)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("gpro,xpro,K,N", [(2, 1, 264, 128), (0, 1, 320, 128), (2, 0, 264, 128), (2, 1, 264, 384)])
 def test_wgrad_1x1_bottleneck_large(dev, gpro, xpro, K, N):
@@ -488,7 +528,9 @@ def test_wgrad_stem_affine2_odd_pixel_count(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pro,acc,B,H,W,N", [(2, True, 2, 9, 10, 96), (0, False, 1, 5, 5, 8), (2, True, 8, 127, 129, 264)])
+@pytest.mark.parametrize("pro,acc,B,H,W,N", [(2, True, 2, 9, 10, 96), (0, False, 1, 5, 5, 8), (2, True, 8, 127, 129, 264),
+                                              (0, False, 2, 20, 20, 128), (2, False, 3, 13, 7, 136), (0, True, 4, 40, 40, 512),
+                                              (2, True, 1, 3, 3, 160)])
 def test_fused_1x1_dgrad_wgrad_equals_separate_kernels(dev, pro, acc, B, H, W, N):
     """cx_conv1x1_dgrad_wgrad = input gradient with the mask epilogue (cx_conv_gemm) + weight gradient with the BN-ReLU input
     prologue (cx_conv_wgrad) of the bottleneck 1x1 convolution, against a torch reference of both."""

@@ -180,6 +180,59 @@ def test_matches_reference_golden_fixture(dev):
         assert abs(l2 - rec["grads"][k]["l2"]) <= 0.03 * rec["grads"][k]["l2"], (k, l2, rec["grads"][k]["l2"])
 
 
+def test_graphed_train_step_equals_eager_steps(dev):
+    """chexpert_amd.graph.GraphedTrainStep: three replays of the captured step (forward, loss, backward with its side-stream
+    weight gradients, Adam with device-resident step count) end where three eager steps end."""
+    from chexpert_amd.graph import GraphedTrainStep
+    from chexpert_amd.models import DenseNet
+    from chexpert_amd.optim import FusedAdam
+    cfg, B, S, n_cls = (2, 2, 2, 2), 4, 64, 5
+    xs = [synth.xray_batch(300 + i, B, S).to(dev) for i in range(3)]
+    ts = [synth.targets(400 + i, B, n_cls).to(dev) for i in range(3)]
+
+    def fresh():
+        torch.manual_seed(5)
+        m = DenseNet(32, cfg, 64, num_classes=n_cls).to(dev).train()
+        for n_, p in m.named_parameters():
+            if n_.endswith(".bias") and "classifier" not in n_:
+                p.data.fill_(2.5)
+        return m
+    m_e = fresh()
+    opt_e = None
+    losses_e = []
+    for x, t in zip(xs, ts):
+        m_e.zero_grad()
+        loss, _ = m_e.forward_backward(x, t)
+        if opt_e is None:
+            opt_e = FusedAdam(m_e, lr=1e-3)
+        opt_e.step()
+        losses_e.append(loss.item())
+    m_g = fresh()
+    sd0 = {k: v.clone() for k, v in m_g.state_dict().items()}
+    opt_g = FusedAdam(m_g, lr=1e-3)
+    gs = GraphedTrainStep(m_g, opt_g, xs[0], ts[0])
+    # the warm-up iterations inside the constructor ran forward/backward only (no optimiser step) but did update BatchNorm
+    # running statistics: start both from the same state
+    m_g.load_state_dict(sd0)
+    losses_g = []
+    for x, t in zip(xs, ts):
+        loss, _ = gs.replay(x, t)
+        losses_g.append(loss.item())
+    opt_g.sync_from_device()
+    assert opt_g.step_count == 3
+    print("eager losses %s graph losses %s" % (losses_e, losses_g))
+    for a, b in zip(losses_e, losses_g):
+        assert abs(a - b) < 2e-3 * abs(a)
+    pe = torch.cat([p.detach().flatten() for p in m_e.parameters()]).cpu()
+    pg = torch.cat([p.detach().flatten() for p in m_g.parameters()]).cpu()
+    # Adam normalises the update to ~lr per element whatever the gradient scale: compare in units of lr
+    assert (pe - pg).abs().max().item() < 3 * 1e-3, (pe - pg).abs().max().item()
+    assert (pe - pg).abs().mean().item() < 2e-4
+    sd_e, sd_g = m_e.state_dict(), m_g.state_dict()
+    assert int(sd_g["features.norm0.num_batches_tracked"]) == int(sd_e["features.norm0.num_batches_tracked"]) == 3
+    assert (sd_e["features.norm5.running_mean"] - sd_g["features.norm5.running_mean"]).abs().max().item() < 1e-2
+
+
 def test_cpu_tensor_raises(dev):
     from chexpert_amd.models import DenseNet
     m = DenseNet(32, (2, 2, 2, 2), 64, num_classes=5)

@@ -196,6 +196,41 @@ def test_aaresnet152_full_size_step_runs(dev):
     assert model.layer3[5].conv2.key_rel_h.grad.abs().sum().item() > 0
 
 
+def test_aaresnet152_reference_golden_train_step(dev):
+    """The full aaresnet152 of chexpert.py:486-494 at 320x320, one training step against the REAL reference
+    (tests/golden/nets.json: aaresnet152_320_b1; eval-mode logits of this fixture are ~1e5 with hash-filled running statistics
+    and carry no information, the train-mode step does)."""
+    from chexpert_amd.models import Bottleneck, ResNet
+    from oracle import nets
+    rec = json.load(open(os.path.join(G, "nets.json")))["aaresnet152_320_b1"]
+    spec = nets.resnet_spec(rec["n_classes"], attn=dict(k=.2, v=.1, nh=8))
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(spec), rec["sd_seed"])
+    model = ResNet(Bottleneck, [3, 8, 36, 3], num_classes=rec["n_classes"],
+                   attn_params={"k": .2, "v": .1, "nh": 8, "relative": True, "input_dims": (320, 320)})
+    assert list(model.state_dict().keys()) == list(spec.keys())
+    model.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in model.parameters()) == rec["n_params"] == 59609421
+    model = model.to(dev).train()
+    x = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"]).to(dev)
+    t = synth.targets(rec["t_seed"], rec["B"], rec["n_classes"]).to(dev)
+    loss, logits = model.forward_backward(x, t)
+    want = torch.tensor(rec["logits_train"])
+    e = _rel(logits.cpu(), want)
+    print("aaresnet152 golden train logits rel %.3e loss %.5f (ref %.5f)" % (e, loss.item(), rec["loss"]))
+    # B = 1 and 100 values per channel in layer4: the fp32 oracle itself differs from the reference by 2.5 % on gradient norms
+    # here (make_golden.py prints it); limits are set at that conditioning, not at the kernel's precision
+    assert e < 3e-2
+    assert abs(loss.item() - rec["loss"]) < 2e-2 * rec["loss"]
+    named = dict(model.named_parameters())
+    rows = [(k, named[k].grad.double().norm().item() / rec["grads"][k]["l2"]) for k in
+            ("fc.weight", "fc.bias", "layer4.2.conv2.key_rel_h", "layer3.5.conv2.in_proj_qkv.weight", "layer2.0.conv2.conv.weight")]
+    print("aaresnet152 golden grad l2 ratios: %s" % rows)
+    for k, r in rows:
+        assert abs(r - 1) < (0.05 if k.startswith("fc") else 0.25), (k, r)
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all().item(), k
+
+
 def test_grad_cam_resnet_matches_reference_fixture(dev):
     """Grad-CAM with the ResNet hook targets (layer4 / fc, chexpert.py:484) against the reference's own output."""
     import numpy as np
