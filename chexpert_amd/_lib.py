@@ -26,7 +26,7 @@ class CxConv(C.Structure):
                 ("ldx", _i32), ("ldx2", _i32), ("ldy", _i32), ("ldex", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32), ("tstride", _i32),
-                ("stat_replicas", _i32), ("stat_rstride", _i32)]
+                ("stat_replicas", _i32), ("stat_rstride", _i32), ("stat_det", _i32)]
 
 
 class CxWgrad(C.Structure):
@@ -57,16 +57,18 @@ SIGNATURES = {
     "cx_nchw3_to_nhwc4": [_vp, _vp, _i, _i, _i, _vp],
     "cx_u8_to_nhwc4": [_vp, _vp, _sz, _f, _f, _vp],
     "cx_bn_coef": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cx_bn_coef_moments": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_last_stat_rows": [],
     "cx_bn_coef_eval": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],
     "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_bn_bwd_slice_coef": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "cx_bnrelu_maxpool_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "cx_bnrelu_maxpool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_bnrelu_maxpool_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_bnrelu_maxpool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_head_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_bce_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp],
     "cx_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "cx_gap_relu_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "cx_unpool2_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_gap_relu_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_unpool2_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_affine2_inplace": [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_affine2_relu": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_relu_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],

@@ -40,3 +40,51 @@ static inline int launch_status() {
   return e == hipSuccess ? 0 : (int)e;
 }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- workgroup statistics ---------------------------------------------------------------------------------------------
+// Per-channel partial sums leave a workgroup through LDS: each wave deposits the channels it owns in its own slot, the slots
+// are summed in wave order (a fixed order: fp32 addition is not associative) and the workgroup row is either plain-stored
+// (CxConv.stat_det: one writer per element, consumers sum the rows in row order) or added to a replica with ONE atomic per
+// channel (legacy mode).  `scratch` = NW * 2 * CW floats of LDS that nothing else uses any more.
+extern thread_local int cx_tl_stat_rows;
+
+template <int NW>
+__device__ __forceinline__ void wg_stat_begin(float* scratch, int CW, int tid, int nthreads) {
+  __syncthreads();
+  for (int i = tid; i < NW * 2 * CW; i += nthreads) scratch[i] = 0.f;
+  __syncthreads();
+}
+__device__ __forceinline__ void wg_stat_put(float* scratch, int CW, int wave, int ch, float a, float b) {
+  scratch[(wave * 2) * CW + ch] += a;
+  scratch[(wave * 2 + 1) * CW + ch] += b;
+}
+template <int NW>
+__device__ __forceinline__ void wg_stat_end(float* scratch, int CW, int tid, int nthreads, float* sum, float* sq, int det, int row,
+                                            int replicas, int rstride, int n_base, int N) {
+  __syncthreads();
+  for (int c = tid; c < CW; c += nthreads) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      a += scratch[(w * 2) * CW + c];
+      b += scratch[(w * 2 + 1) * CW + c];
+    }
+    const int n = n_base + c;
+    if (n < N) {
+      if (det) {
+        sum[(size_t)row * rstride + n] = a;
+        sq[(size_t)row * rstride + n] = b;
+      } else {
+        const size_t rep = replicas > 1 ? (size_t)(row % replicas) * rstride : 0;
+        atomicAdd(&sum[rep + n], a);
+        atomicAdd(&sq[rep + n], b);
+      }
+    }
+  }
+}
+static inline int stat_rows_check(const CxConv& p, int rows) {
+  if (!p.stat_det || !p.stat_sum) return 0;
+  if (rows > p.stat_replicas || p.stat_rstride < p.N) return CX_ESTATROWS;
+  cx_tl_stat_rows = rows;
+  return 0;
+}

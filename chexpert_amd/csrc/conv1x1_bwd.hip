@@ -266,7 +266,8 @@ __global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const 
     }
   }
   {
-    const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+    float* scratch = reinterpret_cast<float*>(At);               // both tiles are free now (ecoef stays)
+    wg_stat_begin<NT / 64>(scratch, BC, tid, NT);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float t1v = 0.f, t2v = 0.f;
@@ -280,13 +281,11 @@ __global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const 
         }
       if (lrow < 16) {
         const int cl = ch * 64 + j * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
-        const int n = c0 + cl;
-        if (n < p.N) {
-          atomicAdd(&p.stat_sum[rep + n], t1v);
-          atomicAdd(&p.stat_sq[rep + n], ecoef[3 * BC + cl] * (t2v - ecoef[2 * BC + cl] * t1v));
-        }
+        wg_stat_put(scratch, BC, wave, cl, t1v, ecoef[3 * BC + cl] * (t2v - ecoef[2 * BC + cl] * t1v));
       }
     }
+    wg_stat_end<NT / 64>(scratch, BC, tid, NT, p.stat_sum, p.stat_sq, p.stat_det, p.stat_det ? split : (int)blockIdx.x, p.stat_replicas,
+                         p.stat_rstride, c0, p.N);
   }
 }
 
@@ -299,7 +298,10 @@ constexpr int BM2 = 64;
 constexpr int A2_BYTES = BM2 * PITCH;
 constexpr int XH2_BYTES = BM2 * XH_PITCH;
 
-template <int PRO, bool ACC>
+// DBG != 0: timing-only ablations of the <AFFINE2, accumulate> instantiation (results are wrong), a bit set: 1 no stores, 2 no
+// x / old dX loads after the first tile, 4 no dZ / y1 loads after the first tile, 8 no mask epilogue arithmetic, 16 no weight-gradient
+// phase, 32 no input-gradient MFMAs, 64 no AFFINE2 arithmetic in the staging
+template <int PRO, bool ACC, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* __restrict__ dw, const int M, const int c_tiles,
                                                          const int tiles_per_split) {
   constexpr int BC = 128, NT = 512;
@@ -406,8 +408,9 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
     for (int i = 0; i < 2; ++i) {
       const int row = r0 + 32 * i;
       U128 o;
-      if (PRO == CX_PRO_NONE) {
+      if (PRO == CX_PRO_NONE || (DBG & 64)) {
         o.u = ru[i];
+        if (DBG & 64) { o.u.x ^= rv[i].x; o.u.y ^= rv[i].y; o.u.z ^= rv[i].z; o.u.w ^= rv[i].w; }
       } else {
         U128 u, v;
         u.u = ru[i];
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
     __syncthreads();                              // dZ tile visible; the other At / Xh buffers are free (their readers passed here)
     // ---- next tile's dZ / y1 (clamped tile index: the last iteration re-requests its own tile instead of branching)
     const int mtn = mt + 1 < t1 ? mt + 1 : mt;
-    {
+    if constexpr (!(DBG & 4)) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int mm = mtn * BM2 + r0 + 32 * i;
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
       const char* Wb = Wt + (cq * 32 + lrow) * PITCH + lh * 16;
 #pragma unroll
       for (int kk = 0; kk < KD / 16; ++kk) {
+        if constexpr (DBG & 32) { if (kk > 0) continue; }
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + kk * 32);
         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wb + kk * 32);
         accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, accd, 0, 0, 0);
@@ -450,6 +454,11 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
     const bool pok = m < M;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
+      if constexpr (DBG & 8) {                  // ablation: keep the operands alive, no arithmetic
+        asm volatile("" ::"v"(accd[8 * cc]), "v"(accd[8 * cc + 7]), "v"(xv[cc].u.x), "v"(old[cc].u.w));
+        *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xv[cc].u;
+        continue;
+      }
       const int cl = cq * 32 + 8 * (2 * cc + lh);
       float v[8];
 #pragma unroll
@@ -476,11 +485,15 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
         o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[cc].e[e])));
         xh.e[e] = f2bf(on ? pre : 0.f);
       }
-      if (pok && nok[cc]) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + ncl[cc]) = o.u;
+      if constexpr (!(DBG & 1)) {
+        if (pok && nok[cc]) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + ncl[cc]) = o.u;
+      } else {
+        asm volatile("" ::"v"(o.u.x), "v"(o.u.y), "v"(o.u.z), "v"(o.u.w));
+      }
       *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
     }
     // ---- next tile's x / old dX
-    {
+    if constexpr (!(DBG & 2)) {
       const int mn = mtn * BM2 + pw * 32 + lrow;
       const int mc = mn < M ? mn : M - 1;
 #pragma unroll
@@ -493,6 +506,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
     // ---- weight gradient: dW[n][c] += sum over the 64 pixels of the tile
 #pragma unroll
     for (int kk = 0; kk < BM2 / 16; ++kk) {
+      if constexpr (DBG & 16) { if (kk > 0) continue; }
       const bf16x8 af = tr_frag(Ab_, PITCH, kk * 16, wn * 32, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -514,7 +528,8 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
     }
   }
   {
-    const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+    float* scratch = reinterpret_cast<float*>(At);               // both tiles are free now (ecoef stays)
+    wg_stat_begin<8>(scratch, BC, tid, NT);
     float t1v = 0.f, t2v = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
@@ -526,12 +541,10 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
       }
     if (lrow < 16) {
       const int cl = cq * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
-      const int n = c0 + cl;
-      if (n < p.N) {
-        atomicAdd(&p.stat_sum[rep + n], t1v);
-        atomicAdd(&p.stat_sq[rep + n], ecoef[3 * BC + cl] * (t2v - ecoef[2 * BC + cl] * t1v));
-      }
+      wg_stat_put(scratch, BC, wave, cl, t1v, ecoef[3 * BC + cl] * (t2v - ecoef[2 * BC + cl] * t1v));
     }
+    wg_stat_end<8>(scratch, BC, tid, NT, p.stat_sum, p.stat_sq, p.stat_det, p.stat_det ? split : (int)blockIdx.x, p.stat_replicas,
+                   p.stat_rstride, c0, p.N);
   }
 }
 
@@ -547,10 +560,29 @@ int launch_bwd2(const CxConv& p, float* dw, hipStream_t st) {
   const int tps = (m_tiles + splits - 1) / splits;
   splits = (m_tiles + tps - 1) / tps;
   const size_t smem = (5 * BC + 3 * KD) * 4 + BC * PITCH + 2 * A2_BYTES + 2 * 4 * XH2_BYTES;
+  if (const int e = stat_rows_check(p, splits)) return e;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd2_kernel<PRO, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
+  }
+  if constexpr (PRO == CX_PRO_AFFINE2 && ACC) {
+    static const int dbg = []() { const char* e = getenv("CX_PW_BWD_DBG"); return e ? atoi(e) : 0; }();
+    if (dbg) {
+      const dim3 g(c_tiles * splits), b(512);
+#define CX_DBG_CASE(D)                                                                                                       \
+  case D:                                                                                                                    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd2_kernel<PRO, ACC, D>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)smem);                                                                                    \
+    hipLaunchKernelGGL((pw_bwd2_kernel<PRO, ACC, D>), g, b, smem, st, p, dw, (int)M, c_tiles, tps);                           \
+    return launch_status();
+      switch (dbg) {
+        CX_DBG_CASE(1) CX_DBG_CASE(2) CX_DBG_CASE(4) CX_DBG_CASE(7) CX_DBG_CASE(15) CX_DBG_CASE(23) CX_DBG_CASE(39) CX_DBG_CASE(71)
+        CX_DBG_CASE(127)
+        default: break;
+      }
+#undef CX_DBG_CASE
+    }
   }
   hipLaunchKernelGGL((pw_bwd2_kernel<PRO, ACC>), dim3(c_tiles * splits), dim3(512), smem, st, p, dw, (int)M, c_tiles, tps);
   return launch_status();
@@ -567,6 +599,7 @@ int launch_bwd_bc(const CxConv& p, float* dw, hipStream_t st) {
   const int tps = (m_tiles + splits - 1) / splits;
   splits = (m_tiles + tps - 1) / tps;
   const size_t smem = (5 * BC + 3 * KD) * 4 + BC * PITCH + A_BYTES + (BC / 32) * XH_BYTES;
+  if (const int e = stat_rows_check(p, splits)) return e;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_kernel<PRO, ACC, BC>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -280,6 +280,7 @@ int cx_try_pw_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
   if (p.mode != CX_MODE_CONV || p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0 || p.tstride > 1) return 0;
   if (p.epilogue != CX_EPI_MASK || p.K != KD) return 0;
   if (p.prologue != CX_PRO_AFFINE2 && p.prologue != CX_PRO_NONE) return 0;
+  if (p.stat_det) return 0;          // per-wave atomics here: the generic kernel writes deterministic statistic rows
   *handled = true;
   if (p.prologue == CX_PRO_AFFINE2)
     return p.accumulate ? launch_pw<CX_PRO_AFFINE2, true>(p, st) : launch_pw<CX_PRO_AFFINE2, false>(p, st);

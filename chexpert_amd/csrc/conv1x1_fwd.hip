@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(const CxConv p, const in
   }
 
   if (want_stats) {
-    const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+    float* scratch = reinterpret_cast<float*>(Wt);               // the weight tile is no longer read
+    wg_stat_begin<4>(scratch, NO, tid, 256);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float t1 = 0.f, t2 = 0.f;
@@ -227,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(const CxConv p, const in
         }
       if (lrow < 16) {
         const int n = (wn * 2 + j) * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
-        atomicAdd(&p.stat_sum[rep + n], t1);
-        atomicAdd(&p.stat_sq[rep + n], t2);
+        wg_stat_put(scratch, NO, wave, n, t1, t2);
       }
     }
+    wg_stat_end<4>(scratch, NO, tid, 256, p.stat_sum, p.stat_sq, p.stat_det, (int)blockIdx.x, p.stat_replicas, p.stat_rstride, 0, p.N);
   }
 }
 
@@ -250,6 +251,7 @@ int launch_fwd(const CxConv& p, hipStream_t st) {
     attr_set = true;
   }
   if (smem > 80 * 1024) return CX_ESHAPE;
+  if (const int e = stat_rows_check(p, grid)) return e;
   hipLaunchKernelGGL((pw_fwd_kernel<PRO>), dim3(grid), dim3(256), smem, st, p, (int)M, m_tiles, nkb, kc, wpitch);
   return launch_status();
 }

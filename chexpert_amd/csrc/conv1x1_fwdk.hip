@@ -24,7 +24,6 @@ __global__ __launch_bounds__(256, 2) void pw_fwdk_kernel(const CxConv p, const i
   float* coef = reinterpret_cast<float*>(smem);                       // [2][K]
   char* At = smem + 2 * p.K * 4;
   char* Bt = At + A_BYTES;
-  float* lstat = reinterpret_cast<float*>(Bt + A_BYTES);              // [2][BN]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int mt = xcd_remap(blockIdx.x, gridDim.x);
@@ -34,7 +33,6 @@ __global__ __launch_bounds__(256, 2) void pw_fwdk_kernel(const CxConv p, const i
 
   if (PRO == CX_PRO_AFFINE_RELU)
     for (int i = tid; i < p.K; i += 256) { coef[i] = p.pa[i]; coef[p.K + i] = p.pb[i]; }
-  if (tid < 2 * BN) lstat[tid] = 0.f;
 
   const int q = tid % CPR, r0 = tid / CPR;
   const int nsteps = (p.K + BK - 1) / BK;
@@ -157,19 +155,13 @@ __global__ __launch_bounds__(256, 2) void pw_fwdk_kernel(const CxConv p, const i
         s2[j] += __shfl_xor(s2[j], d);
       }
     }
+    float* scratch = reinterpret_cast<float*>(At);               // tile buffers are free now
+    wg_stat_begin<4>(scratch, BN, tid, 256);
     if (lane < ECPR) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        atomicAdd(&lstat[cq * 8 + j], s1[j]);
-        atomicAdd(&lstat[BN + cq * 8 + j], s2[j]);
-      }
+      for (int j = 0; j < 8; ++j) wg_stat_put(scratch, BN, wave, cq * 8 + j, s1[j], s2[j]);
     }
-    __syncthreads();
-    if (tid < BN) {
-      const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
-      atomicAdd(&p.stat_sum[rep + tid], lstat[tid]);
-      atomicAdd(&p.stat_sq[rep + tid], lstat[BN + tid]);
-    }
+    wg_stat_end<4>(scratch, BN, tid, 256, p.stat_sum, p.stat_sq, p.stat_det, (int)blockIdx.x, p.stat_replicas, p.stat_rstride, 0, p.N);
   }
 }
 
@@ -186,6 +178,7 @@ int launch_fwdk(const CxConv& p, hipStream_t st) {
     attr = true;
   }
   if (smem > 80 * 1024) return CX_ESHAPE;
+  if (const int e = stat_rows_check(p, m_tiles)) return e;
   hipLaunchKernelGGL((pw_fwdk_kernel<BK, PRO>), dim3(m_tiles), dim3(256), smem, st, p, (int)M);
   return launch_status();
 }

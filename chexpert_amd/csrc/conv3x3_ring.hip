@@ -48,7 +48,7 @@ template <int NCH, int DEPTH>
 __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __restrict__ x, int ldx, const float* __restrict__ sc,
                                                                 const float* __restrict__ sh, const bf16* __restrict__ wpk,
                                                                 bf16* __restrict__ y, int ldy, float* stat_sum, float* stat_sq,
-                                                                int stat_replicas, int stat_rstride, const RingGeo g) {
+                                                                int stat_replicas, int stat_rstride, int stat_det, const RingGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* coef = reinterpret_cast<float*>(smem);                // [2][128]
   char* wl = smem + 1024 + 256;                                // [9*32][272 B]
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   }
 
   if (stat_sum) {
-    const size_t rep = stat_replicas > 1 ? (size_t)(blockIdx.x % stat_replicas) * stat_rstride : 0;
+    float* scratch = reinterpret_cast<float*>(wl);               // the weight slices are no longer read
+    wg_stat_begin<NT / 64>(scratch, 32, tid, NT);
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
@@ -257,9 +258,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
       }
     if (lrow < 16) {
       const int n = 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
-      atomicAdd(&stat_sum[rep + n], t1);
-      atomicAdd(&stat_sq[rep + n], t2);
+      wg_stat_put(scratch, 32, wave, n, t1, t2);
     }
+    wg_stat_end<NT / 64>(scratch, 32, tid, NT, stat_sum, stat_sq, stat_det, (int)blockIdx.x, stat_replicas, stat_rstride, 0, 32);
   }
 }
 
@@ -274,8 +275,9 @@ int launch_ring(const CxConv& p, hipStream_t st, const RingGeo& g) {
   }
   const int total = g.B * g.spi;
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  if (const int e = stat_rows_check(p, grid)) return e;
   hipLaunchKernelGGL((conv3x3_ring_fwd_kernel<NCH, DEPTH>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, p.pa, p.pb,
-                     (const bf16*)p.w, (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, g);
+                     (const bf16*)p.w, (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
   return launch_status();
 }
 
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     const float* __restrict__ gb, const float* __restrict__ gc, const bf16* __restrict__ wpk, const bf16* __restrict__ ex, int ldex,
     const float* __restrict__ e_sc, const float* __restrict__ e_sh, const float* __restrict__ e_mu, const float* __restrict__ e_r,
     const float* __restrict__ e_scale, bf16* __restrict__ y, int ldy, float* S1, float* S2, int stat_replicas, int stat_rstride,
-    const RingGeo g) {
+    int stat_det, const RingGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ecoef = reinterpret_cast<float*>(smem);               // e_sc, e_sh, e_mu, e_r, e_scale [128] each
   char* wl = smem + EC_BYTES;                                  // [9*128][80 B]
@@ -502,7 +504,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
   }
 
   {
-    const size_t rep = stat_replicas > 1 ? (size_t)(blockIdx.x % stat_replicas) * stat_rstride : 0;
+    float* scratch = reinterpret_cast<float*>(wl);               // the weight slices are no longer read (ecoef stays)
+    wg_stat_begin<NT / 64>(scratch, 128, tid, NT);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float t1 = 0.f, t2 = 0.f;
@@ -516,10 +519,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
         }
       if (lrow < 16) {
         const int n = (2 * h2 + j) * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
-        atomicAdd(&S1[rep + n], t1);
-        atomicAdd(&S2[rep + n], ecoef[384 + n] * (t2 - ecoef[256 + n] * t1));
+        wg_stat_put(scratch, 128, wave, n, t1, ecoef[384 + n] * (t2 - ecoef[256 + n] * t1));
       }
     }
+    wg_stat_end<NT / 64>(scratch, 128, tid, NT, S1, S2, stat_det, (int)blockIdx.x, stat_replicas, stat_rstride, 0, 128);
   }
 }
 
@@ -534,9 +537,10 @@ int launch_ring_dgrad(const CxConv& p, hipStream_t st, const RingGeo& g) {
   }
   const int total = g.B * g.spi;
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  if (const int e = stat_rows_check(p, grid)) return e;
   hipLaunchKernelGGL((conv3x3_ring_dgrad_kernel<NCH>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2,
                      p.ldx2, p.pa, p.pb, p.pc, (const bf16*)p.w, (const bf16*)p.ex, p.ldex, p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale,
-                     (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, g);
+                     (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
   return launch_status();
 }
 

@@ -40,7 +40,8 @@ __device__ __forceinline__ int wrapq(int v, int q) { return v >= q ? v - q : v; 
 __global__ __launch_bounds__(192, 2) void conv3x3_strip_fwd_kernel(const bf16* __restrict__ x, int ldx,
                                                                  const float* __restrict__ sc, const float* __restrict__ sh,
                                                                  const bf16* __restrict__ wpk, bf16* __restrict__ y, int ldy,
-                                                                 float* stat_sum, float* stat_sq, const StripGeo g) {
+                                                                 float* stat_sum, float* stat_sq, int stat_replicas, int stat_rstride,
+                                                                 int stat_det, const StripGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* coef = reinterpret_cast<float*>(smem);                // [2][128]
   float* lstat = coef + 256;                                   // [2][32]
@@ -200,18 +201,12 @@ __global__ __launch_bounds__(192, 2) void conv3x3_strip_fwd_kernel(const bf16* _
         s2[j] += __shfl_xor(s2[j], d);
       }
     }
+    wg_stat_begin<3>(scratch, 32, tid, 192);
     if (lane < 4 && wave < 2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        atomicAdd(&lstat[lane * 8 + j], s1[j]);
-        atomicAdd(&lstat[32 + lane * 8 + j], s2[j]);
-      }
+      for (int j = 0; j < 8; ++j) wg_stat_put(scratch, 32, wave, lane * 8 + j, s1[j], s2[j]);
     }
-    __syncthreads();
-    if (tid < 32) {
-      atomicAdd(&stat_sum[tid], lstat[tid]);
-      atomicAdd(&stat_sq[tid], lstat[32 + tid]);
-    }
+    wg_stat_end<3>(scratch, 32, tid, 192, stat_sum, stat_sq, stat_det, (int)blockIdx.x, stat_replicas, stat_rstride, 0, 32);
   }
 }
 
@@ -228,7 +223,8 @@ __global__ __launch_bounds__(192, 2) void conv3x3_strip_dgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, const bf16* __restrict__ wpk, const bf16* __restrict__ ex, int ldex,
     const float* __restrict__ e_sc, const float* __restrict__ e_sh, const float* __restrict__ e_mu, const float* __restrict__ e_r,
-    const float* __restrict__ e_scale, bf16* __restrict__ y, int ldy, float* S1, float* S2, const StripGeo g) {
+    const float* __restrict__ e_scale, bf16* __restrict__ y, int ldy, float* S1, float* S2, int stat_replicas, int stat_rstride,
+    int stat_det, const StripGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* coef = reinterpret_cast<float*>(smem);                // ga gb gc [32] each (96) + pad
   float* lstat = coef + 128;                                   // [2][128]
@@ -417,18 +413,12 @@ __global__ __launch_bounds__(192, 2) void conv3x3_strip_dgrad_kernel(
     s2[j] += __shfl_xor(s2[j], 16);
     s2[j] += __shfl_xor(s2[j], 32);
   }
+  wg_stat_begin<3>(scratch, 128, tid, 192);
   if (lane < 16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(&lstat[ec + j], s1[j]);
-      atomicAdd(&lstat[128 + ec + j], s2[j]);
-    }
+    for (int j = 0; j < 8; ++j) wg_stat_put(scratch, 128, wave, ec + j, s1[j], s2[j]);
   }
-  __syncthreads();
-  if (tid < 128) {
-    atomicAdd(&S1[tid], lstat[tid]);
-    atomicAdd(&S2[tid], lstat[128 + tid]);
-  }
+  wg_stat_end<3>(scratch, 128, tid, 192, S1, S2, stat_det, (int)blockIdx.x, stat_replicas, stat_rstride, 0, 128);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -683,9 +673,10 @@ int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   }
   const int total = g.B * g.spi;
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
-  hipLaunchKernelGGL(conv3x3_strip_fwd_kernel, dim3(grid), dim3(192), smem, st, (const bf16*)p.x, p.ldx, p.pa, p.pb,
-                     (const bf16*)p.w, (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, g);
   *handled = true;
+  if (const int e = stat_rows_check(p, grid)) return e;
+  hipLaunchKernelGGL(conv3x3_strip_fwd_kernel, dim3(grid), dim3(192), smem, st, (const bf16*)p.x, p.ldx, p.pa, p.pb,
+                     (const bf16*)p.w, (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
   return launch_status();
 }
 
@@ -706,10 +697,11 @@ int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
   }
   const int total = g.B * g.spi;
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  *handled = true;
+  if (const int e = stat_rows_check(p, grid)) return e;
   hipLaunchKernelGGL(conv3x3_strip_dgrad_kernel, dim3(grid), dim3(192), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2, p.ldx2,
                      p.pa, p.pb, p.pc, (const bf16*)p.w, (const bf16*)p.ex, p.ldex, p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale,
-                     (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, g);
-  *handled = true;
+                     (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
   return launch_status();
 }
 

@@ -43,7 +43,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* coef = reinterpret_cast<float*>(smem);                       // [NCoef][K]
   char* tiles = smem + NCoef<PRO>::v * p.K * 4;
-  float* lstat = reinterpret_cast<float*>(tiles + G::MAIN_BYTES);     // [2][BN]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -61,7 +60,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
       if (PRO == CX_PRO_AFFINE2) coef[2 * p.K + i] = p.pc[i];
     }
   }
-  if (tid < 2 * BN) lstat[tid] = 0.f;
 
   // ---- per-thread A rows
   const int qa = tid & 3;                 // 8-channel chunk inside the 32-wide K step
@@ -350,19 +348,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
         s2[j] += __shfl_xor(s2[j], d);
       }
     }
+    float* scratch = reinterpret_cast<float*>(tiles);            // the tile buffers are free now
+    wg_stat_begin<4>(scratch, BN, tid, 256);
     if (lane < CPR) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        atomicAdd(&lstat[cq * 8 + j], s1[j]);
-        atomicAdd(&lstat[BN + cq * 8 + j], s2[j]);
-      }
+      for (int j = 0; j < 8; ++j) wg_stat_put(scratch, BN, wave, cq * 8 + j, s1[j], s2[j]);
     }
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.N) {
-      const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
-      atomicAdd(&p.stat_sum[rep + n0 + tid], lstat[tid]);
-      atomicAdd(&p.stat_sq[rep + n0 + tid], lstat[BN + tid]);
-    }
+    // row = pixel tile: the n tiles of one pixel tile write disjoint channels of the same row
+    wg_stat_end<4>(scratch, BN, tid, 256, p.stat_sum, p.stat_sq, p.stat_det, p.stat_det ? mt : (int)blockIdx.x, p.stat_replicas,
+                   p.stat_rstride, n0, p.N);
   }
 }
 
@@ -374,6 +368,7 @@ int launch(const CxConv& p, hipStream_t st) {
   const int n_tiles = (p.N + BN - 1) / BN;
   const size_t smem = (size_t)NCoef<PRO>::v * p.K * 4 + G::MAIN_BYTES + 2 * BN * 4;
   if (smem > 160 * 1024) return CX_ESHAPE;
+  if (const int e = stat_rows_check(p, m_tiles)) return e;
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BN, PRO, MODE, EPI>),
@@ -402,6 +397,9 @@ int cx_try_pw_dgrad(const CxConv& p, hipStream_t st, bool* handled);        // c
 int cx_try_pw_fwd(const CxConv& p, hipStream_t st, bool* handled);          // conv1x1_fwd.hip
 int cx_try_pw_fwdk(const CxConv& p, hipStream_t st, bool* handled);         // conv1x1_fwdk.hip
 int cx_try_stem_fwd(const CxConv& p, hipStream_t st, bool* handled);        // conv_stem.hip
+
+thread_local int cx_tl_stat_rows = 0;
+extern "C" int cx_last_stat_rows(void) { return cx_tl_stat_rows; }
 
 extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   if (!pp) return CX_EINVAL;

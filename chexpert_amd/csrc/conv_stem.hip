@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const CxConv p, const 
   }
 
   if (want_stats) {
-    const size_t rep = p.stat_replicas > 1 ? (size_t)(blockIdx.x % p.stat_replicas) * p.stat_rstride : 0;
+    float* scratch = reinterpret_cast<float*>(wl);               // the weight tile is no longer read
+    wg_stat_begin<4>(scratch, 64, tid, 256);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float t1 = 0.f, t2 = 0.f;
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const CxConv p, const 
         }
       if (lrow < 16) {
         const int n = j * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
-        atomicAdd(&p.stat_sum[rep + n], t1);
-        atomicAdd(&p.stat_sq[rep + n], t2);
+        wg_stat_put(scratch, 64, wave, n, t1, t2);
       }
     }
+    wg_stat_end<4>(scratch, 64, tid, 256, p.stat_sum, p.stat_sq, p.stat_det, (int)blockIdx.x, p.stat_replicas, p.stat_rstride, 0, p.N);
   }
 }
 
@@ -164,6 +165,8 @@ int cx_try_stem_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   const long long M = (long long)p.B * p.Ho * p.Wo;
   const int m_tiles = (int)((M + 127) / 128);
   const int grid = m_tiles < 512 ? m_tiles : 512;
+  *handled = true;
+  if (const int e = stat_rows_check(p, grid)) return e;
   hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), SW_ROWS * SP, st, p, (int)M, m_tiles);
   *handled = true;
   return launch_status();

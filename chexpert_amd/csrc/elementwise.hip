@@ -9,17 +9,32 @@ namespace {
 // per-channel statistic reduction shared by the elementwise kernels: each thread owns one 8-channel
 // chunk `cq` (constant over its grid-stride loop) and 2x8 partial sums.
 __device__ __forceinline__ void block_stats_flush(const float (&s1)[8], const float (&s2)[8], int cq, int C,
-                                                  float* lds, float* g1, float* g2) {
-  // lds: [2][C] zeroed by the caller before the main loop (followed by a barrier)
+                                                  float* lds, float* g1, float* g2, int det) {
+  // lds: blockDim.x * 16 floats.  Every thread parks its 2 x 8 partial sums; the threads that own chunk c / 8 (tid % CP == c / 8)
+  // are then summed in thread order -- a fixed order -- and the block row is plain-stored (det: row = blockIdx.x of a [grid][C]
+  // slab, no atomics) or added to the single copy with one atomic per channel.
+  const int CP = C >> 3;
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    atomicAdd(&lds[cq * 8 + j], s1[j]);
-    atomicAdd(&lds[C + cq * 8 + j], s2[j]);
+    lds[threadIdx.x * 16 + j] = s1[j];
+    lds[threadIdx.x * 16 + 8 + j] = s2[j];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    atomicAdd(&g1[c], lds[c]);
-    atomicAdd(&g2[c], lds[C + c]);
+    const int chunk = c >> 3, j = c & 7;
+    float a = 0.f, b = 0.f;
+    for (int t = chunk; t < (int)blockDim.x; t += CP) {
+      a += lds[t * 16 + j];
+      b += lds[t * 16 + 8 + j];
+    }
+    if (det) {
+      g1[(size_t)blockIdx.x * C + c] = a;
+      g2[(size_t)blockIdx.x * C + c] = b;
+    } else {
+      atomicAdd(&g1[c], a);
+      atomicAdd(&g2[c], b);
+    }
   }
 }
 
@@ -107,27 +122,32 @@ __global__ void u8_to_nhwc4_kernel(const uint8_t* __restrict__ x, bf16* __restri
   }
 }
 
-__global__ void bn_coef_kernel(const float* sum, const float* sq, float count, const float* gamma, const float* beta,
-                               float eps, float momentum, float* rmean, float* rvar, float* scale, float* shift,
-                               float* mean, float* rstd, int C, int replicas, int rstride) {
-  // 16 lanes per channel: lane q sums replicas q, q+16, ...; xor-shuffles fold the 16 partial sums (all lanes stay active)
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = gid >> 4, q = gid & 15;
+// Both coefficient kernels reduce `replicas` rows per channel (16 atomic replicas, or the per-workgroup rows of a
+// CxConv.stat_det launch: hundreds to thousands).  A 256-thread workgroup owns 16 channels: thread (q, j) sums rows q, q + 16, ...
+// of channel j (64-B row segments per 16 lanes), the 16 partial sums meet in LDS and are added in q order -- a fixed order, so
+// the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void bn_coef_kernel(const float* sum, const float* sq, float count, const float* gamma,
+                                                      const float* beta, float eps, float momentum, float* rmean, float* rvar,
+                                                      float* scale, float* shift, float* mean, float* rstd, int C, int replicas,
+                                                      int rstride) {
+  __shared__ double part[2][16][17];
+  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + j;
   const int cc = c < C ? c : C - 1;
-  // requested up front (one dependent chain of memory round trips otherwise)
-  const float g = gamma ? gamma[cc] : 1.f, b = beta ? beta[cc] : 0.f;
-  const float rm0 = rmean ? rmean[cc] : 0.f, rv0 = rvar ? rvar[cc] : 0.f;
   double ts = 0.0, tq = 0.0;
   for (int r = q; r < replicas; r += 16) {
     ts += (double)sum[(size_t)r * rstride + cc];
     tq += (double)sq[(size_t)r * rstride + cc];
   }
+  part[0][q][j] = ts;
+  part[1][q][j] = tq;
+  __syncthreads();
+  if (q != 0 || c >= C) return;
+  ts = 0.0; tq = 0.0;
 #pragma unroll
-  for (int d = 1; d < 16; d <<= 1) {
-    ts += __shfl_xor(ts, d);
-    tq += __shfl_xor(tq, d);
-  }
-  if (c >= C || q != 0) return;
+  for (int k = 0; k < 16; ++k) { ts += part[0][k][j]; tq += part[1][k][j]; }
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float rm0 = rmean ? rmean[c] : 0.f, rv0 = rvar ? rvar[c] : 0.f;
   const double m = ts / count;
   double v = tq / count - m * m;
   if (v < 0) v = 0;
@@ -139,6 +159,65 @@ __global__ void bn_coef_kernel(const float* sum, const float* sq, float count, c
   if (rstd) rstd[c] = r;
   if (rmean) rmean[c] = (1.f - momentum) * rm0 + momentum * (float)m;
   if (rvar) rvar[c] = (1.f - momentum) * rv0 + momentum * (float)(count > 1.f ? v * count / (count - 1.0) : v);
+}
+
+// BatchNorm coefficients of one layer from per-channel moments that already exist (dense blocks: a channel's batch mean / rstd
+// are computed once, when the channel is produced; every later norm1 over the concatenation re-uses them with its own gamma /
+// beta / running buffers).  Channels [c_lo, c_lo + c_n) are "fresh": their moments are first reduced from `rows` statistic rows
+// (sum / sq at row pitch rstride, element c - c_lo) and written to mean / rstd.
+__global__ __launch_bounds__(256) void bn_coef_moments_kernel(float* mean, float* rstd, float count, const float* gamma,
+                                                              const float* beta, float eps, float momentum, float* rmean, float* rvar,
+                                                              float* scale, float* shift, int C, const float* sum, const float* sq,
+                                                              int rows, int rstride, int c_lo, int c_n) {
+  __shared__ double part[2][16][17];
+  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + j;
+  const int cc = c < C ? c : C - 1;
+  // block-uniform: does this group of 16 channels touch the fresh range?
+  const int g0 = blockIdx.x * 16;
+  const bool any_fresh = c_n > 0 && g0 < c_lo + c_n && g0 + 16 > c_lo;
+  float m, r;
+  if (any_fresh) {
+    const bool fresh = cc >= c_lo && cc < c_lo + c_n;
+    const int fc = fresh ? cc - c_lo : 0;
+    double ts = 0.0, tq = 0.0;
+    for (int rr = q; rr < rows; rr += 16) {
+      ts += (double)sum[(size_t)rr * rstride + fc];
+      tq += (double)sq[(size_t)rr * rstride + fc];
+    }
+    part[0][q][j] = ts;
+    part[1][q][j] = tq;
+    __syncthreads();
+    if (q != 0 || c >= C) return;
+    if (fresh) {
+      ts = 0.0; tq = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { ts += part[0][k][j]; tq += part[1][k][j]; }
+      const double md = ts / count;
+      double v = tq / count - md * md;
+      if (v < 0) v = 0;
+      m = (float)md;
+      r = (float)(1.0 / sqrt(v + (double)eps));
+      mean[c] = m;
+      rstd[c] = r;
+    } else {
+      m = mean[c];
+      r = rstd[c];
+    }
+  } else {
+    if (q != 0 || c >= C) return;
+    m = mean[c];
+    r = rstd[c];
+  }
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * r;
+  if (scale) scale[c] = sc;
+  if (shift) shift[c] = b - m * sc;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+  if (rvar) {
+    const float v = fmaxf(1.f / (r * r) - eps, 0.f);                 // biased batch variance back from rstd
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (count > 1.f ? v * count / (count - 1.f) : v);
+  }
 }
 
 __global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const float* gamma, const float* beta,
@@ -153,31 +232,31 @@ __global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const
   if (rstd) rstd[c] = r;
 }
 
-__global__ void bn_bwd_coef_kernel(const float* S1, const float* S2, float count, const float* gamma, const float* mean,
-                                   const float* rstd, float* dgamma, float* dbeta, float* A, float* Bc, float* pa,
-                                   float* pb, float* pc, int C, int replicas, int rstride) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = gid >> 4, q = gid & 15;              // 16 lanes per channel over the replicas, as in bn_coef_kernel
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* S1, const float* S2, float count, const float* gamma,
+                                                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* A,
+                                                          float* Bc, float* pa, float* pb, float* pc, int C, int replicas, int rstride) {
+  __shared__ float part[2][16][17];
+  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;       // 16 channels x 16 row lanes, as in bn_coef_kernel
+  const int c = blockIdx.x * 16 + j;
   const int cc = c < C ? c : C - 1;
-  // everything this launch reads is requested up front: the kernel is one dependent chain of memory round trips
-  const float g = gamma ? gamma[cc] : 1.f, r = rstd[cc], mu = mean[cc];
-  const float dg0 = dgamma ? dgamma[cc] : 0.f, db0 = dbeta ? dbeta[cc] : 0.f, a0 = A ? A[cc] : 0.f, b0 = Bc ? Bc[cc] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   for (int rr = q; rr < replicas; rr += 16) {
     s1 += S1[(size_t)rr * rstride + cc];
     s2 += S2[(size_t)rr * rstride + cc];
   }
+  part[0][q][j] = s1;
+  part[1][q][j] = s2;
+  __syncthreads();
+  if (q != 0 || c >= C) return;
+  s1 = 0.f; s2 = 0.f;
 #pragma unroll
-  for (int d = 1; d < 16; d <<= 1) {
-    s1 += __shfl_xor(s1, d);
-    s2 += __shfl_xor(s2, d);
-  }
-  if (c >= C || q != 0) return;
-  if (dgamma) dgamma[c] = dg0 + s2;
-  if (dbeta) dbeta[c] = db0 + s1;
+  for (int k = 0; k < 16; ++k) { s1 += part[0][k][j]; s2 += part[1][k][j]; }
+  const float g = gamma ? gamma[c] : 1.f, r = rstd[c], mu = mean[c];
+  if (dgamma) dgamma[c] += s2;
+  if (dbeta) dbeta[c] += s1;
   const float inv = 1.f / count;
-  if (A) A[c] = a0 + r * g * s1 * inv;
-  if (Bc) Bc[c] = b0 + r * g * s2 * inv;
+  if (A) A[c] += r * g * s1 * inv;
+  if (Bc) Bc[c] += r * g * s2 * inv;
   if (pa) {
     pa[c] = g * r;
     pb[c] = -g * r * r * s2 * inv;
@@ -200,7 +279,7 @@ __global__ void bn_bwd_slice_coef_kernel(const float* A, const float* Bc, const 
 __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ sc,
                                                                  const float* __restrict__ sh, bf16* __restrict__ y,
                                                                  uint8_t* __restrict__ amax, float* g1, float* g2, int B,
-                                                                 int H, int W, int C, int ldy) {
+                                                                 int H, int W, int C, int ldy, int det) {
   extern __shared__ float lds[];
   const int CP = C / 8;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
@@ -245,14 +324,14 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const bf16* __r
     *reinterpret_cast<uint4*>(y + pix * ldy + cq * 8) = o.u;
     *reinterpret_cast<uint2*>(amax + pix * C + cq * 8) = *reinterpret_cast<const uint2*>(idx);
   }
-  if (g1) block_stats_flush(s1, s2, cq, C, lds, g1, g2);
+  if (g1) block_stats_flush(s1, s2, cq, C, lds, g1, g2, det);
 }
 
 __global__ __launch_bounds__(256) void bnrelu_maxpool_bwd_kernel(
     const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
     const float* __restrict__ rstd, const uint8_t* __restrict__ amax, const bf16* __restrict__ g, const bf16* __restrict__ gx,
     const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc, bf16* __restrict__ dz, float* S1,
-    float* S2, int B, int H, int W, int C, int ldg, int ldgx) {
+    float* S2, int B, int H, int W, int C, int ldg, int ldgx, int det) {
   extern __shared__ float lds[];
   const int CP = C / 8;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
@@ -314,7 +393,7 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_bwd_kernel(
     }
     *reinterpret_cast<uint4*>(dz + pix * C + cq * 8) = o.u;
   }
-  block_stats_flush(s1, s2, cq, C, lds, S1, S2);
+  block_stats_flush(s1, s2, cq, C, lds, S1, S2, det);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -400,7 +479,7 @@ __global__ void head_bwd_kernel(const float* __restrict__ dlogits, const float* 
 __global__ void gap_relu_bn_bwd_kernel(const float* __restrict__ dpooled, const bf16* __restrict__ x, const float* __restrict__ sc,
                                        const float* __restrict__ sh, const float* __restrict__ mean, const float* __restrict__ rstd,
                                        const float* __restrict__ escale, bf16* __restrict__ g, float* S1, float* S2, int B, int HW,
-                                       int C, int ldx, int ldg) {
+                                       int C, int ldx, int ldg, int det) {
   const int CP = C / 8;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * CP) return;
@@ -429,8 +508,13 @@ __global__ void gap_relu_bn_bwd_kernel(const float* __restrict__ dpooled, const 
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    atomicAdd(&S1[cq * 8 + j], s1[j]);
-    atomicAdd(&S2[cq * 8 + j], s2[j]);
+    if (det) {                                  // row = image: B rows of C sums, one writer per element
+      S1[(size_t)b * C + cq * 8 + j] = s1[j];
+      S2[(size_t)b * C + cq * 8 + j] = s2[j];
+    } else {
+      atomicAdd(&S1[cq * 8 + j], s1[j]);
+      atomicAdd(&S2[cq * 8 + j], s2[j]);
+    }
   }
 }
 
@@ -439,7 +523,7 @@ __global__ __launch_bounds__(256) void unpool2_mask_kernel(const bf16* __restric
                                                            const float* __restrict__ sc, const float* __restrict__ sh,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ escale, bf16* __restrict__ g, float* S1,
-                                                           float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg) {
+                                                           float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg, int det) {
   extern __shared__ float lds[];
   const int CP = C / 8;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
@@ -473,7 +557,7 @@ __global__ __launch_bounds__(256) void unpool2_mask_kernel(const bf16* __restric
     }
     *reinterpret_cast<uint4*>(g + pix * ldg + cq * 8) = o.u;
   }
-  block_stats_flush(s1, s2, cq, C, lds, S1, S2);
+  block_stats_flush(s1, s2, cq, C, lds, S1, S2, det);
 }
 
 __global__ void affine2_inplace_kernel(bf16* __restrict__ dz, const bf16* __restrict__ x, const float* __restrict__ pa,
@@ -767,6 +851,7 @@ const char* cx_error_string(int code) {
     case CX_EALIGN: return "pointer or pitch not 16-byte aligned";
     case CX_ESHAPE: return "unsupported shape";
     case CX_EUNSUPPORTED: return "unsupported prologue/epilogue/mode combination";
+    case CX_ESTATROWS: return "stat_det: the launch needs more statistic rows than stat_replicas (capacity) provides";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown";
   }
 }
@@ -809,8 +894,18 @@ int cx_bn_coef(const float* sum, const float* sq, float count, const float* gamm
   if (!sum || !sq || C <= 0 || count <= 0) return CX_EINVAL;
   if (replicas < 1) replicas = 1;
   if (replicas > 1 && rstride < C) return CX_EINVAL;
-  hipLaunchKernelGGL(bn_coef_kernel, dim3((C * 16 + 255) / 256), dim3(256), 0, as_stream(stream), sum, sq, count, gamma, beta, eps,
+  hipLaunchKernelGGL(bn_coef_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), sum, sq, count, gamma, beta, eps,
                      momentum, running_mean, running_var, scale, shift, mean, rstd, C, replicas, rstride);
+  return launch_status();
+}
+
+int cx_bn_coef_moments(float* mean, float* rstd, float count, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* scale, float* shift, int C, const float* sum, const float* sq,
+                       int rows, int rstride, int c_lo, int c_n, void* stream) {
+  if (!mean || !rstd || C <= 0 || count <= 0) return CX_EINVAL;
+  if (c_n > 0 && (!sum || !sq || rows < 1 || rstride < c_n || c_lo < 0 || c_lo + c_n > C)) return CX_EINVAL;
+  hipLaunchKernelGGL(bn_coef_moments_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), mean, rstd, count, gamma, beta, eps,
+                     momentum, running_mean, running_var, scale, shift, C, sum, sq, rows, rstride, c_lo, c_n);
   return launch_status();
 }
 
@@ -829,7 +924,7 @@ int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* g
   if (replicas < 1) replicas = 1;
   if (replicas > 1 && rstride < C) return CX_EINVAL;
   if (pa && (!pb || !pc)) return CX_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C * 16 + 255) / 256), dim3(256), 0, as_stream(stream), S1, S2, count, gamma, mean,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), S1, S2, count, gamma, mean,
                      rstd, dgamma, dbeta, A, Bc, pa, pb, pc, C, replicas, rstride);
   return launch_status();
 }
@@ -843,26 +938,30 @@ int cx_bn_bwd_slice_coef(const float* A, const float* Bc, const float* mean, con
 }
 
 int cx_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax, float* stat_sum,
-                          float* stat_sq, int B, int H, int W, int C, int ldy, void* stream) {
+                          float* stat_sq, int B, int H, int W, int C, int ldy, int stat_rows, void* stream) {
   if (!x || !scale || !shift || !y || !argmax) return CX_EINVAL;
   if (C % 8 || C > 256 || 256 % (C / 8) || (H & 1) || (W & 1) || (ldy % 8)) return CX_ESHAPE;
   const size_t npix = (size_t)B * (H / 2) * (W / 2);
   const int ppb = 256 / (C / 8);
-  hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel, dim3(grid_for(npix, ppb, 2048)), dim3(256), 2 * C * sizeof(float), as_stream(stream),
-                     (const bf16*)x, scale, shift, (bf16*)y, argmax, stat_sum, stat_sq, B, H, W, C, ldy);
+  int grid = grid_for(npix, ppb, 2048);
+  if (stat_rows > 0 && stat_sum) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel, dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
+                     (const bf16*)x, scale, shift, (bf16*)y, argmax, stat_sum, stat_sq, B, H, W, C, ldy, stat_rows > 0 ? 1 : 0);
   return launch_status();
 }
 
 int cx_bnrelu_maxpool_bwd(const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
                           const uint8_t* argmax, const void* g, const void* gx, const float* ga, const float* gb, const float* gc,
-                          void* dz, float* S1, float* S2, int B, int H, int W, int C, int ldg, int ldgx, void* stream) {
+                          void* dz, float* S1, float* S2, int B, int H, int W, int C, int ldg, int ldgx, int stat_rows, void* stream) {
   if (!x || !scale || !shift || !mean || !rstd || !argmax || !g || !gx || !ga || !gb || !gc || !dz || !S1 || !S2) return CX_EINVAL;
   if (C % 8 || C > 256 || 256 % (C / 8) || (H & 1) || (W & 1) || (ldg % 8) || (ldgx % 8)) return CX_ESHAPE;
   const size_t npix = (size_t)B * H * W;
   const int ppb = 256 / (C / 8);
-  hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel, dim3(grid_for(npix, ppb, 2048)), dim3(256), 2 * C * sizeof(float), as_stream(stream),
+  int grid = grid_for(npix, ppb, 2048);
+  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel, dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
                      (const bf16*)x, scale, shift, mean, rstd, argmax, (const bf16*)g, (const bf16*)gx, ga, gb, gc, (bf16*)dz, S1,
-                     S2, B, H, W, C, ldg, ldgx);
+                     S2, B, H, W, C, ldg, ldgx, stat_rows > 0 ? 1 : 0);
   return launch_status();
 }
 
@@ -896,25 +995,29 @@ int cx_head_bwd(const float* dlogits, const float* pooled, const float* w, float
 
 int cx_gap_relu_bn_bwd(const float* dpooled, const void* x, const float* scale, const float* shift, const float* mean,
                        const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int HW, int C, int ldx,
-                       int ldg, void* stream) {
+                       int ldg, int stat_rows, void* stream) {
   if (!dpooled || !x || !scale || !shift || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
   if (C % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
   const size_t n = (size_t)B * (C / 8);
+  if (stat_rows > 0) { if (stat_rows < B) return CX_ESTATROWS; cx_tl_stat_rows = B; }
   hipLaunchKernelGGL(gap_relu_bn_bwd_kernel, dim3((n + 127) / 128), dim3(128), 0, as_stream(stream), dpooled, (const bf16*)x, scale,
-                     shift, mean, rstd, e_scale, (bf16*)g, S1, S2, B, HW, C, ldx, ldg);
+                     shift, mean, rstd, e_scale, (bf16*)g, S1, S2, B, HW, C, ldx, ldg, stat_rows > 0 ? 1 : 0);
   return launch_status();
 }
 
 int cx_unpool2_mask(const void* d, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd,
                     const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg,
-                    void* stream) {
+                    int stat_rows, void* stream) {
   if (!d || !x || !sc || !sh || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
   if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || (H & 1) || (W & 1) || ldd % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
   if (C / 8 > 256) return CX_ESHAPE;
   const size_t npix = (size_t)B * H * W;
   const int ppb = 256 / (C / 8);
-  hipLaunchKernelGGL(unpool2_mask_kernel, dim3(grid_for(npix, ppb, 2048)), dim3(256), 2 * C * sizeof(float), as_stream(stream),
-                     (const bf16*)d, (const bf16*)x, sc, sh, mean, rstd, e_scale, (bf16*)g, S1, S2, B, H, W, C, ldd, ldx, ldg);
+  int grid = grid_for(npix, ppb, 2048);
+  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  hipLaunchKernelGGL(unpool2_mask_kernel, dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
+                     (const bf16*)d, (const bf16*)x, sc, sh, mean, rstd, e_scale, (bf16*)g, S1, S2, B, H, W, C, ldd, ldx, ldg,
+                     stat_rows > 0 ? 1 : 0);
   return launch_status();
 }
 

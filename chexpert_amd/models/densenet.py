@@ -196,6 +196,9 @@ class _Workspace:
         self.logits = torch.empty(B, eng.n_classes, dtype=torch.float32, device=dev)
         self.vec = torch.zeros(eng.vec_size, dtype=torch.float32, device=dev)
         self.ones = torch.ones(max(eng.mid, 64), dtype=torch.float32, device=dev)
+        # deterministic statistics (CxConv.stat_det): every producer writes per-workgroup rows into this scratch pair and the
+        # coefficient kernel that follows on the same stream sums them in row order
+        self.slab = torch.empty(2, eng.SLAB, dtype=torch.float32, device=dev) if eng.det else None
 
     def v(self, slot):
         off, n = slot
@@ -225,6 +228,22 @@ class _Workspace:
 class _Engine:
     """Host-side schedule: binds the module's parameters to flat buffers, packs weights, and issues the
     kernel sequence of forward and backward on the current stream."""
+    SLAB = 1 << 21               # floats per half of the statistic-row scratch (rows x channels of the largest producer)
+    EW_ROWS = 1024               # workgroups (= rows) of the element-wise statistic producers in deterministic mode
+
+    # statistics plumbing: producer kwargs / consumer (sum, sq, replicas, rstride) for the two modes
+    def _sp(self, ws, slots, C, sub=None):
+        if self.det:
+            return dict(stat_sum=ws.slab[0], stat_sq=ws.slab[1], stat_det=True, stat_replicas=self.SLAB // C, stat_rstride=C)
+        a, b = slots
+        if sub is not None:
+            a, b = (a[0] + sub[0], sub[1]), (b[0] + sub[0], sub[1])
+        return dict(stat_sum=ws.v(a), stat_sq=ws.v(b), stat_replicas=self.stat_replicas, stat_rstride=slots[0][1])
+
+    def _sc(self, ws, slots, C, rows):
+        if self.det:
+            return ws.slab[0], ws.slab[1], rows, C
+        return ws.v(slots[0]), ws.v(slots[1]), self.stat_replicas, slots[0][1]
 
     def __init__(self, model):
         self.model = model
@@ -247,7 +266,12 @@ class _Engine:
         self.pool = {}
         self.reducer = None          # chexpert_amd.parallel.GradReducer when data-parallel
         self.side = None             # side stream for the weight-gradient kernels of the dense layers
-        self.stat_replicas = 16      # copies of every conv-produced statistics vector (memory-side atomic contention)
+        self.stat_replicas = 16      # legacy (atomic) statistics: copies of every conv-produced vector (memory-side contention)
+        # Deterministic statistics: per-workgroup rows summed in a fixed order instead of fp32 atomics (bit-identical activations,
+        # losses and input gradients from run to run).  The AA transitions feed a block's first channels from two different
+        # kernels (conv branch + attention out-projection) and stay on the atomic path; CHEXPERT_DET=0 forces it everywhere.
+        has_aa = any(isinstance(getattr(f, "transition%d" % (i + 1)).conv, AAConv2d) for i in range(len(model.block_config) - 1))
+        self.det = (not has_aa) and os.environ.get("CHEXPERT_DET", "1") != "0"
         self._plan_vectors()
 
     # ---- coefficient-vector layout
@@ -372,23 +396,39 @@ class _Engine:
             lst.append(ws)
 
     # ---- forward
-    def _bn(self, ws, sum_slot, sq_slot, count, bn, out_slots, C_, train, mean_slot=None, rstd_slot=None, replicas=1):
-        """scale/shift (+mean/rstd) of one BatchNorm over channels [0,C_) of the given statistics."""
+    def _bn(self, ws, stats, count, bn, out_slots, C_, train, mean_slot=None, rstd_slot=None):
+        """scale/shift (+mean/rstd) of one BatchNorm over C_ channels; stats = (sum, sq, replicas, rstride) of its input."""
         sc, sh = ws.v(out_slots[0])[:C_], ws.v(out_slots[1])[:C_]
         mean = ws.v(mean_slot)[:C_] if mean_slot is not None else None
         rstd = ws.v(rstd_slot)[:C_] if rstd_slot is not None else None
         if train:
             mom = bn.momentum if bn.momentum is not None else 0.1
-            ops.bn_coef(ws.v(sum_slot)[:C_], ws.v(sq_slot)[:C_], count, bn.weight, bn.bias, bn.eps, mom,
+            ssum, ssq, reps, rstride = stats
+            ops.bn_coef(ssum, ssq, count, bn.weight, bn.bias, bn.eps, mom,
                         bn.running_mean if bn.track_running_stats else None,
-                        bn.running_var if bn.track_running_stats else None, sc, sh, mean, rstd, C_, replicas=replicas,
-                        rstride=sum_slot[1])
+                        bn.running_var if bn.track_running_stats else None, sc, sh, mean, rstd, C_, replicas=reps, rstride=rstride)
         else:
             ops.bn_coef_eval(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, sc, sh, mean, rstd, C_)
 
+    def _bn_block(self, ws, bi, cin, count, bn, out_slots, train, fresh):
+        """BatchNorm over channels [0, cin) of block buffer bi (norm1 of a dense layer, a transition norm, norm5).  Batch moments
+        of a buffer channel exist once (bmean / brstd): deterministic mode reduces only the `fresh` channels -- those the
+        previous launch produced -- from their statistic rows; the atomic mode re-reads the replicated block sums."""
+        s = self.slots
+        bmean, brstd = s["bmr"][bi]
+        if not train:
+            return self._bn(ws, None, count, bn, out_slots, cin, False, bmean, brstd)
+        if not self.det:
+            bsum, bsq = s["bst"][bi]
+            return self._bn(ws, (ws.v(bsum), ws.v(bsq), self.stat_replicas, bsum[1]), count, bn, out_slots, cin, True, bmean, brstd)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        ops.bn_coef_moments(ws.v(bmean)[:cin], ws.v(brstd)[:cin], count, bn.weight, bn.bias, bn.eps, mom,
+                            bn.running_mean if bn.track_running_stats else None, bn.running_var if bn.track_running_stats else None,
+                            ws.v(out_slots[0])[:cin], ws.v(out_slots[1])[:cin], cin, fresh)
+
     def forward(self, x, train):
         m, f, s = self.model, self.model.features, self.slots
-        R = self.stat_replicas
+        det = self.det and train
         u8 = x.dtype == torch.uint8             # decoded grey bytes (B,1,H,W): whitened + expanded on the GPU (cx_u8_to_nhwc4)
         if x.dim() != 4 or x.shape[1] != (1 if u8 else 3):
             raise RuntimeError("expected a (B,3,H,W) float input or a (B,1,H,W) uint8 image")
@@ -398,61 +438,74 @@ class _Engine:
         self.bind(x.device)
         self.pack(train)
         ws = self.acquire(B, H, W)
-        z0, zn = self.fwd_zero
-        ws.vec[z0:z0 + zn].zero_()
-        st = (lambda a: ws.v(a)) if train else (lambda a: None)
+        if train and not self.det:
+            z0, zn = self.fwd_zero
+            ws.vec[z0:z0 + zn].zero_()
+        sp = (lambda slots, C, sub=None: self._sp(ws, slots, C, sub)) if train else (lambda slots, C, sub=None: {})
         if u8:
             ops.u8_to_nhwc4(x.contiguous(), ws.x4)
         else:
             ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
-        ops.conv_gemm(ws.x4, self.w_fwd(f.conv0), ws.c0, N=self.c_init, mode=ops.MODE_STEM, stat_sum=st(s["st0"][0]),
-                      stat_sq=st(s["st0"][1]))
-        self._bn(ws, s["st0"][0], s["st0"][1], B * (H // 2) * (W // 2), f.norm0, s["n0"][:2], self.c_init, train,
-                 s["n0"][2], s["n0"][3])
-        ops.bnrelu_maxpool_fwd(ws.c0, ws.v(s["n0"][0]), ws.v(s["n0"][1]), ws.buf[0][..., :self.c_init], ws.amax,
-                               st(s["bst"][0][0]), st(s["bst"][0][1]))
+        # stem: conv0 -> norm0 -> relu0 -> pool0 (attn_aug_conv.py:460-465)
+        if det:
+            rows = ops.conv_gemm(ws.x4, self.w_fwd(f.conv0), ws.c0, N=self.c_init, mode=ops.MODE_STEM, **sp(None, self.c_init))
+            st0 = (ws.slab[0], ws.slab[1], rows, self.c_init)
+        else:
+            ops.conv_gemm(ws.x4, self.w_fwd(f.conv0), ws.c0, N=self.c_init, mode=ops.MODE_STEM,
+                          stat_sum=ws.v(s["st0"][0]) if train else None, stat_sq=ws.v(s["st0"][1]) if train else None)
+            st0 = (ws.v(s["st0"][0]), ws.v(s["st0"][1]), 1, 0)
+        self._bn(ws, st0, B * (H // 2) * (W // 2), f.norm0, s["n0"][:2], self.c_init, train, s["n0"][2], s["n0"][3])
+        fresh = None                             # (sum rows, sq rows, rows, rstride, first channel, channels) of the newest slice
+        if det:
+            rows = ops.bnrelu_maxpool_fwd(ws.c0, ws.v(s["n0"][0]), ws.v(s["n0"][1]), ws.buf[0][..., :self.c_init], ws.amax,
+                                          ws.slab[0], ws.slab[1], stat_rows=min(self.EW_ROWS, self.SLAB // self.c_init))
+            fresh = (ws.slab[0], ws.slab[1], rows, self.c_init, 0, self.c_init)
+        else:
+            ops.bnrelu_maxpool_fwd(ws.c0, ws.v(s["n0"][0]), ws.v(s["n0"][1]), ws.buf[0][..., :self.c_init], ws.amax,
+                                   ws.v(s["bst"][0][0]) if train else None, ws.v(s["bst"][0][1]) if train else None)
         nb = len(self.blocks)
+        g_ = self.growth
         for bi, (c0, n_layers) in enumerate(self.blocks):
             buf = ws.buf[bi]
             h, w = ws.hw[bi]
             cnt = B * h * w
-            bsum, bsq = s["bst"][bi]
-            bmean, brstd = s["bmr"][bi]
             block = getattr(f, "denseblock%d" % (bi + 1))
             for li in range(n_layers):
                 layer = getattr(block, "denselayer%d" % (li + 1))
-                cin = c0 + li * self.growth
+                cin = c0 + li * g_
                 n1, n2 = s["n1"][bi][li], s["n2"][bi][li]
-                self._bn(ws, bsum, bsq, cnt, layer.norm1, n1, cin, train, bmean, brstd, replicas=R)
-                ysum, ysq = s["yst"][bi][li]
+                self._bn_block(ws, bi, cin, cnt, layer.norm1, n1, train, fresh)
+                yst = s["yst"][bi][li]
                 y1 = ws.y1[bi][li]
-                ops.conv_gemm(buf[..., :cin], self.w_fwd(layer.conv1), y1, N=self.mid, prologue=ops.PRO_AFFINE_RELU,
-                              pa=ws.v(n1[0]), pb=ws.v(n1[1]), stat_sum=st(ysum), stat_sq=st(ysq), stat_replicas=R,
-                              stat_rstride=ysum[1])
-                self._bn(ws, ysum, ysq, cnt, layer.norm2, n2[:2], self.mid, train, n2[2], n2[3], replicas=R)
-                off, _ = bsum
-                ops.conv_gemm(y1, self.w_fwd(layer.conv2), buf[..., cin:cin + self.growth], N=self.growth, kh=3, kw=3, pad=1,
-                              prologue=ops.PRO_AFFINE_RELU, pa=ws.v(n2[0]), pb=ws.v(n2[1]),
-                              stat_sum=st((bsum[0] + cin, self.growth)), stat_sq=st((bsq[0] + cin, self.growth)),
-                              stat_replicas=R, stat_rstride=bsum[1])
-            ct = c0 + n_layers * self.growth
+                rows = ops.conv_gemm(buf[..., :cin], self.w_fwd(layer.conv1), y1, N=self.mid, prologue=ops.PRO_AFFINE_RELU,
+                                     pa=ws.v(n1[0]), pb=ws.v(n1[1]), **sp(yst, self.mid))
+                self._bn(ws, self._sc(ws, yst, self.mid, rows) if train else None, cnt, layer.norm2, n2[:2], self.mid, train, n2[2],
+                         n2[3])
+                rows = ops.conv_gemm(y1, self.w_fwd(layer.conv2), buf[..., cin:cin + g_], N=g_, kh=3, kw=3, pad=1,
+                                     prologue=ops.PRO_AFFINE_RELU, pa=ws.v(n2[0]), pb=ws.v(n2[1]), **sp(s["bst"][bi], g_, (cin, g_)))
+                if det:
+                    fresh = (ws.slab[0], ws.slab[1], rows, g_, cin, g_)
+            ct = c0 + n_layers * g_
             nt = s["nt"][bi]
             if bi != nb - 1 and isinstance(getattr(f, "transition%d" % (bi + 1)).conv, AAConv2d):
                 # block statistics are still needed by backward (mean / rstd of the buffer channels)
                 if train:
+                    bsum, bsq = s["bst"][bi]
+                    bmean, brstd = s["bmr"][bi]
                     ops.bn_coef(ws.v(bsum), ws.v(bsq), cnt, None, None, 1e-5, 0.0, None, None, None, None, ws.v(bmean), ws.v(brstd), ct,
-                                replicas=R, rstride=bsum[1])
+                                replicas=self.stat_replicas, rstride=bsum[1])
+                st = (lambda a: ws.v(a)) if train else (lambda a: None)
                 self._aa_forward(ws, bi, getattr(f, "transition%d" % (bi + 1)).conv, st)
             elif bi != nb - 1:
                 tr = getattr(f, "transition%d" % (bi + 1))
-                self._bn(ws, bsum, bsq, cnt, tr.norm, nt, ct, train, bmean, brstd, replicas=R)
-                nsum, nsq = s["bst"][bi + 1]
-                ops.conv_gemm(buf, self.w_fwd(tr.conv), ws.buf[bi + 1][..., :ct // 2], N=ct // 2, mode=ops.MODE_POOL2,
-                              prologue=ops.PRO_AFFINE_RELU, pa=ws.v(nt[0]), pb=ws.v(nt[1]),
-                              stat_sum=st((nsum[0], ct // 2)), stat_sq=st((nsq[0], ct // 2)), stat_replicas=R,
-                              stat_rstride=nsum[1])
+                self._bn_block(ws, bi, ct, cnt, tr.norm, nt, train, fresh)
+                rows = ops.conv_gemm(buf, self.w_fwd(tr.conv), ws.buf[bi + 1][..., :ct // 2], N=ct // 2, mode=ops.MODE_POOL2,
+                                     prologue=ops.PRO_AFFINE_RELU, pa=ws.v(nt[0]), pb=ws.v(nt[1]),
+                                     **sp(s["bst"][bi + 1], ct // 2, (0, ct // 2)))
+                if det:
+                    fresh = (ws.slab[0], ws.slab[1], rows, ct // 2, 0, ct // 2)
             else:
-                self._bn(ws, bsum, bsq, cnt, f.norm5, nt, ct, train, bmean, brstd, replicas=R)
+                self._bn_block(ws, bi, ct, cnt, f.norm5, nt, train, fresh)
                 ops.head_fwd(buf, ws.v(nt[0]), ws.v(nt[1]), m.classifier.weight, m.classifier.bias, ws.pooled, ws.logits)
         if train:
             m._nbt_pending += 1
@@ -528,11 +581,21 @@ class _Engine:
         ops.head_bwd(dlogits, ws.pooled, m.classifier.weight, G(m.classifier.weight), G(m.classifier.bias) if
                      m.classifier.bias is not None else None, dpooled)
         St = s["St"][bi]
-        ops.gap_relu_bn_bwd(dpooled, ws.buf[bi], v(nt[0]), v(nt[1]), v(bmean), v(brstd), v(nt[0]), ws.gbuf[bi], v(St[0]),
-                            v(St[1]))
+        det = self.det
+        ew_rows = lambda C: min(self.EW_ROWS, self.SLAB // C)
+        if det:
+            if B * ct > self.SLAB:
+                raise RuntimeError("batch too large for the statistic-row scratch (B*C = %d > %d)" % (B * ct, self.SLAB))
+            rows = ops.gap_relu_bn_bwd(dpooled, ws.buf[bi], v(nt[0]), v(nt[1]), v(bmean), v(brstd), v(nt[0]), ws.gbuf[bi], ws.slab[0],
+                                       ws.slab[1], stat_rows=self.SLAB // ct)
+            red = (ws.slab[0], ws.slab[1], rows, ct)
+        else:
+            ops.gap_relu_bn_bwd(dpooled, ws.buf[bi], v(nt[0]), v(nt[1]), v(bmean), v(brstd), v(nt[0]), ws.gbuf[bi], v(St[0]),
+                                v(St[1]))
+            red = (v(St[0]), v(St[1]), 1, 0)
         h, w = ws.hw[bi]
-        ops.bn_bwd_coef(v(St[0]), v(St[1]), B * h * w, f.norm5.weight, v(bmean), v(brstd), G(f.norm5.weight), G(f.norm5.bias),
-                        v(A), v(Bc), None, None, None, ct)
+        ops.bn_bwd_coef(red[0], red[1], B * h * w, f.norm5.weight, v(bmean), v(brstd), G(f.norm5.weight), G(f.norm5.bias),
+                        v(A), v(Bc), None, None, None, ct, replicas=red[2], rstride=red[3])
         q, pv = s["q"], s["p"]
         # weight-gradient kernels only feed the flat gradient buffer: they run on a side stream, concurrently
         # with the input-gradient chain of the following layers (two dz2 buffers, per-layer coefficient slots)
@@ -569,17 +632,17 @@ class _Engine:
                 dz2 = dz2s[k & 1]
                 if k - 2 in w1_done:
                     main.wait_event(w1_done.pop(k - 2))        # the side stream has finished reading this dz2 buffer
-                ops.conv_gemm(gs, self.w_bwd(layer.conv2), dz2, N=self.mid, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=xs,
-                              pa=qa, pb=qb, pc=qc, epilogue=ops.EPI_MASK, ex=y1, e_sc=v(n2[0]), e_sh=v(n2[1]), e_mu=v(n2[2]),
-                              e_r=v(n2[3]), e_scale=ws.ones[:self.mid], stat_sum=v(S2[0]), stat_sq=v(S2[1]),
-                              stat_replicas=R, stat_rstride=S2[0][1])
+                rows = ops.conv_gemm(gs, self.w_bwd(layer.conv2), dz2, N=self.mid, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=xs,
+                                     pa=qa, pb=qb, pc=qc, epilogue=ops.EPI_MASK, ex=y1, e_sc=v(n2[0]), e_sh=v(n2[1]), e_mu=v(n2[2]),
+                                     e_r=v(n2[3]), e_scale=ws.ones[:self.mid], **self._sp(ws, S2, self.mid))
+                red2 = self._sc(ws, S2, self.mid, rows)
                 side.wait_event(ev_q)
                 with torch.cuda.stream(side):
                     ops.conv_wgrad(gs, y1, G(layer.conv2.weight), kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa,
                                    gb=qb, gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
                 pa, pb, pc = (v(t) for t in s["pl"][bi][li])
-                ops.bn_bwd_coef(v(S2[0]), v(S2[1]), cnt, layer.norm2.weight, v(n2[2]), v(n2[3]), G(layer.norm2.weight),
-                                G(layer.norm2.bias), None, None, pa, pb, pc, self.mid, replicas=R, rstride=S2[0][1])
+                ops.bn_bwd_coef(red2[0], red2[1], cnt, layer.norm2.weight, v(n2[2]), v(n2[3]), G(layer.norm2.weight),
+                                G(layer.norm2.bias), None, None, pa, pb, pc, self.mid, replicas=red2[2], rstride=red2[3])
                 ev_p = torch.cuda.Event()
                 ev_p.record(main)
                 S1 = s["S1"][bi][li]
@@ -587,11 +650,11 @@ class _Engine:
                 # (6-37 % less kernel time than the two separate kernels; whole step 37.6 vs 39.0 ms);
                 # CHEXPERT_1X1_BWD=split keeps them, with the weight gradient on the side stream
                 fused = os.environ.get("CHEXPERT_1X1_BWD", "fused") != "split"
-                ops.conv_gemm(dz2, self.w_bwd(layer.conv1), gbuf[..., :cin], N=cin, prologue=ops.PRO_AFFINE2, x2=y1, pa=pa,
-                              pb=pb, pc=pc, epilogue=ops.EPI_MASK, ex=buf[..., :cin], e_sc=v(n1[0]), e_sh=v(n1[1]),
-                              e_mu=v(bmean)[:cin], e_r=v(brstd)[:cin], e_scale=v(n1[0]), stat_sum=v(S1[0]), stat_sq=v(S1[1]),
-                              accumulate=True, stat_replicas=R, stat_rstride=S1[0][1],
-                              fused_dw=G(layer.conv1.weight) if fused else None)
+                rows = ops.conv_gemm(dz2, self.w_bwd(layer.conv1), gbuf[..., :cin], N=cin, prologue=ops.PRO_AFFINE2, x2=y1, pa=pa,
+                                     pb=pb, pc=pc, epilogue=ops.EPI_MASK, ex=buf[..., :cin], e_sc=v(n1[0]), e_sh=v(n1[1]),
+                                     e_mu=v(bmean)[:cin], e_r=v(brstd)[:cin], e_scale=v(n1[0]), accumulate=True,
+                                     fused_dw=G(layer.conv1.weight) if fused else None, **self._sp(ws, S1, cin))
+                red1 = self._sc(ws, S1, cin, rows)
                 side.wait_event(ev_p)
                 with torch.cuda.stream(side):
                     if not fused:
@@ -599,8 +662,8 @@ class _Engine:
                                        gc=pc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n1[0]), pb=v(n1[1]))
                     w1_done[k] = torch.cuda.Event()
                     w1_done[k].record(side)
-                ops.bn_bwd_coef(v(S1[0]), v(S1[1]), cnt, layer.norm1.weight, v(bmean), v(brstd), G(layer.norm1.weight),
-                                G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin, replicas=R, rstride=S1[0][1])
+                ops.bn_bwd_coef(red1[0], red1[1], cnt, layer.norm1.weight, v(bmean), v(brstd), G(layer.norm1.weight),
+                                G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin, replicas=red1[2], rstride=red1[3])
                 if red is not None:
                     main.wait_event(w1_done[k])
                 k += 1
@@ -622,19 +685,32 @@ class _Engine:
                 nt, (pmean, prstd), (pA, pB), St = s["nt"][bi - 1], s["bmr"][bi - 1], s["AB"][bi - 1], s["St"][bi - 1]
                 dpool = ws.dpool[:B * h * w * cprev].view(B, h, w, cprev)
                 ops.conv_gemm(gs, self.w_bwd(tr.conv), dpool, N=cprev, prologue=ops.PRO_AFFINE2, x2=xs, pa=qa, pb=qb, pc=qc)
-                ops.unpool2_mask(dpool, pbuf, v(nt[0]), v(nt[1]), v(pmean), v(prstd), v(nt[0]), pg, v(St[0]), v(St[1]))
+                if det:
+                    rows = ops.unpool2_mask(dpool, pbuf, v(nt[0]), v(nt[1]), v(pmean), v(prstd), v(nt[0]), pg, ws.slab[0], ws.slab[1],
+                                            stat_rows=ew_rows(cprev))
+                    red = (ws.slab[0], ws.slab[1], rows, cprev)
+                else:
+                    ops.unpool2_mask(dpool, pbuf, v(nt[0]), v(nt[1]), v(pmean), v(prstd), v(nt[0]), pg, v(St[0]), v(St[1]))
+                    red = (v(St[0]), v(St[1]), 1, 0)
                 ops.conv_wgrad(gs, pbuf, G(tr.conv.weight), mode=ops.MODE_POOL2, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa, gb=qb,
                                gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(nt[0]), pb=v(nt[1]))
-                ops.bn_bwd_coef(v(St[0]), v(St[1]), B * ph * pw, tr.norm.weight, v(pmean), v(prstd), G(tr.norm.weight),
-                                G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev)
+                ops.bn_bwd_coef(red[0], red[1], B * ph * pw, tr.norm.weight, v(pmean), v(prstd), G(tr.norm.weight),
+                                G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev, replicas=red[2], rstride=red[3])
                 done(tr.norm.weight)
             else:
                 n0, S0 = s["n0"], s["S0"]
-                ops.bnrelu_maxpool_bwd(ws.c0, v(n0[0]), v(n0[1]), v(n0[2]), v(n0[3]), ws.amax, gs, xs, qa, qb, qc, ws.dz0,
-                                       v(S0[0]), v(S0[1]))
+                if det:
+                    rows = ops.bnrelu_maxpool_bwd(ws.c0, v(n0[0]), v(n0[1]), v(n0[2]), v(n0[3]), ws.amax, gs, xs, qa, qb, qc, ws.dz0,
+                                                  ws.slab[0], ws.slab[1], stat_rows=ew_rows(self.c_init))
+                    red = (ws.slab[0], ws.slab[1], rows, self.c_init)
+                else:
+                    ops.bnrelu_maxpool_bwd(ws.c0, v(n0[0]), v(n0[1]), v(n0[2]), v(n0[3]), ws.amax, gs, xs, qa, qb, qc, ws.dz0,
+                                           v(S0[0]), v(S0[1]))
+                    red = (v(S0[0]), v(S0[1]), 1, 0)
                 pa, pb, pc = (v(t)[:self.c_init] for t in pv)
-                ops.bn_bwd_coef(v(S0[0]), v(S0[1]), B * (ws.H // 2) * (ws.W // 2), f.norm0.weight, v(n0[2]), v(n0[3]),
-                                G(f.norm0.weight), G(f.norm0.bias), None, None, pa, pb, pc, self.c_init)
+                ops.bn_bwd_coef(red[0], red[1], B * (ws.H // 2) * (ws.W // 2), f.norm0.weight, v(n0[2]), v(n0[3]),
+                                G(f.norm0.weight), G(f.norm0.bias), None, None, pa, pb, pc, self.c_init, replicas=red[2],
+                                rstride=red[3])
                 ops.conv_wgrad(ws.dz0, ws.x4, G(f.conv0.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0,
                                ga=pa, gb=pb, gc=pc)
         main.wait_stream(side)

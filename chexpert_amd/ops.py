@@ -30,11 +30,17 @@ def conv_gemm(x, w_packed, y, *, fused_dw=None, **kw):
         require_cuda(fused_dw)
         assert fused_dw.dtype == torch.float32 and fused_dw.is_contiguous()
         check(lib().cx_conv1x1_dgrad_wgrad(C.byref(p), ptr(fused_dw), stream_ptr()), "cx_conv1x1_dgrad_wgrad")
+    return lib().cx_last_stat_rows() if p.stat_det else None      # stat_det: rows the consumer has to sum
+
+
+def last_stat_rows():
+    return lib().cx_last_stat_rows()
 
 
 def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
                  pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
-                 e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1, stat_replicas=1, stat_rstride=0):
+                 e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1, stat_replicas=1, stat_rstride=0,
+                 stat_det=False):
     require_cuda(x, w_packed, y)
     p = CxConv()
     B, H, W, Cx, ldx = _nhwc(x)
@@ -53,7 +59,7 @@ def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CO
         assert x2.shape == x.shape
         p.x2, p.ldx2 = ptr(x2), _nhwc(x2)[4]
     p.stat_sum, p.stat_sq = ptr(stat_sum), ptr(stat_sq)
-    p.stat_replicas, p.stat_rstride = stat_replicas, stat_rstride
+    p.stat_replicas, p.stat_rstride, p.stat_det = stat_replicas, stat_rstride, int(bool(stat_det))
     if ex is not None:
         assert ex.shape == y.shape
         p.ex, p.ldex = ptr(ex), _nhwc(ex)[4]
@@ -126,6 +132,14 @@ def bn_coef(s, q, count, gamma, beta, eps, momentum, rmean, rvar, scale, shift, 
                            ptr(scale), ptr(shift), ptr(mean), ptr(rstd), Cn, replicas, rstride, stream_ptr()), "cx_bn_coef")
 
 
+def bn_coef_moments(mean, rstd, count, gamma, beta, eps, momentum, rmean, rvar, scale, shift, Cn, fresh=None):
+    """cx_bn_coef_moments; fresh = (sum, sq, rows, rstride, c_lo, c_n) reduces those channels from deterministic statistic rows first."""
+    fs, fq, rows, rstride, c_lo, c_n = fresh if fresh is not None else (None, None, 0, 0, 0, 0)
+    check(lib().cx_bn_coef_moments(ptr(mean), ptr(rstd), float(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),
+                                   ptr(scale), ptr(shift), Cn, ptr(fs), ptr(fq), rows, rstride, c_lo, c_n, stream_ptr()),
+          "cx_bn_coef_moments")
+
+
 def bn_coef_eval(rmean, rvar, gamma, beta, eps, scale, shift, mean, rstd, Cn=None):
     Cn = Cn if Cn is not None else rmean.numel()
     check(lib().cx_bn_coef_eval(ptr(rmean), ptr(rvar), ptr(gamma), ptr(beta), eps, ptr(scale), ptr(shift), ptr(mean),
@@ -142,20 +156,22 @@ def bn_bwd_slice_coef(A, Bc, mean, rstd, pa, pb, pc, Cn):
           "cx_bn_bwd_slice_coef")
 
 
-def bnrelu_maxpool_fwd(x, scale, shift, y, argmax, stat_sum, stat_sq):
+def bnrelu_maxpool_fwd(x, scale, shift, y, argmax, stat_sum, stat_sq, stat_rows=0):
     B, H, W, Cc, ldx = _nhwc(x)
     assert ldx == Cc
     ldy = _nhwc(y)[4]
     check(lib().cx_bnrelu_maxpool_fwd(ptr(x), ptr(scale), ptr(shift), ptr(y), ptr(argmax), ptr(stat_sum), ptr(stat_sq),
-                                      B, H, W, Cc, ldy, stream_ptr()), "cx_bnrelu_maxpool_fwd")
+                                      B, H, W, Cc, ldy, stat_rows, stream_ptr()), "cx_bnrelu_maxpool_fwd")
+    return lib().cx_last_stat_rows() if stat_rows else None
 
 
-def bnrelu_maxpool_bwd(x, scale, shift, mean, rstd, argmax, g, gx, ga, gb, gc, dz, S1, S2):
+def bnrelu_maxpool_bwd(x, scale, shift, mean, rstd, argmax, g, gx, ga, gb, gc, dz, S1, S2, stat_rows=0):
     B, H, W, Cc, ldx = _nhwc(x)
     assert ldx == Cc and _nhwc(dz)[4] == Cc
     check(lib().cx_bnrelu_maxpool_bwd(ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(argmax), ptr(g), ptr(gx),
                                       ptr(ga), ptr(gb), ptr(gc), ptr(dz), ptr(S1), ptr(S2), B, H, W, Cc, _nhwc(g)[4],
-                                      _nhwc(gx)[4], stream_ptr()), "cx_bnrelu_maxpool_bwd")
+                                      _nhwc(gx)[4], stat_rows, stream_ptr()), "cx_bnrelu_maxpool_bwd")
+    return lib().cx_last_stat_rows() if stat_rows else None
 
 
 def head_fwd(x, scale, shift, w, bias, pooled, logits):
@@ -176,16 +192,18 @@ def head_bwd(dlogits, pooled, w, dw, db, dpooled):
                             stream_ptr()), "cx_head_bwd")
 
 
-def gap_relu_bn_bwd(dpooled, x, scale, shift, mean, rstd, e_scale, g, S1, S2):
+def gap_relu_bn_bwd(dpooled, x, scale, shift, mean, rstd, e_scale, g, S1, S2, stat_rows=0):
     B, H, W, Cc, ldx = _nhwc(x)
     check(lib().cx_gap_relu_bn_bwd(ptr(dpooled), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(e_scale), ptr(g),
-                                   ptr(S1), ptr(S2), B, H * W, Cc, ldx, _nhwc(g)[4], stream_ptr()), "cx_gap_relu_bn_bwd")
+                                   ptr(S1), ptr(S2), B, H * W, Cc, ldx, _nhwc(g)[4], stat_rows, stream_ptr()), "cx_gap_relu_bn_bwd")
+    return lib().cx_last_stat_rows() if stat_rows else None
 
 
-def unpool2_mask(d, x, sc, sh, mean, rstd, e_scale, g, S1, S2):
+def unpool2_mask(d, x, sc, sh, mean, rstd, e_scale, g, S1, S2, stat_rows=0):
     B, H, W, Cc, ldx = _nhwc(x)
     check(lib().cx_unpool2_mask(ptr(d), ptr(x), ptr(sc), ptr(sh), ptr(mean), ptr(rstd), ptr(e_scale), ptr(g), ptr(S1), ptr(S2),
-                                B, H, W, Cc, _nhwc(d)[4], ldx, _nhwc(g)[4], stream_ptr()), "cx_unpool2_mask")
+                                B, H, W, Cc, _nhwc(d)[4], ldx, _nhwc(g)[4], stat_rows, stream_ptr()), "cx_unpool2_mask")
+    return lib().cx_last_stat_rows() if stat_rows else None
 
 
 def affine2_inplace(dz, x, pa, pb, pc):

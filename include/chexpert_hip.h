@@ -29,7 +29,7 @@ extern "C" {
 
 #define CX_ABI_VERSION 3
 
-enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4 };
+enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4, CX_ESTATROWS = -5 };
 
 /* A-operand prologues of the implicit GEMM (fused normalisation, never stored) */
 enum {
@@ -71,6 +71,12 @@ typedef struct CxConv {
   int32_t stat_rstride;  /* n lives at stat_sum[r*stat_rstride + n].  Thousands of workgroups adding to   */
                          /* the same N floats serialise at the memory side; the consumer (cx_bn_coef /   */
                          /* cx_bn_bwd_coef) sums the replicas.  0 or 1: a single copy                     */
+  int32_t stat_det;      /* != 0: DETERMINISTIC statistics.  No atomics: the launch writes `rows` complete rows   */
+                         /* stat_sum[r*stat_rstride + n] (r < rows, every n < N; one writer per element, partial */
+                         /* sums combined in a fixed order inside the workgroup), rows <= stat_replicas (the     */
+                         /* caller's capacity) or CX_ESTATROWS; cx_last_stat_rows() then returns `rows` and the   */
+                         /* consumer sums exactly those rows in row order (cx_bn_coef / cx_bn_bwd_coef with      */
+                         /* replicas = rows): bit-identical results from run to run.  No zero-fill is needed      */
 } CxConv;
 
 /* Weight gradient of the same convolution:  dW[n][c][ky][kx] += sum_m G[m][n] * A[m@tap][c]
@@ -91,6 +97,8 @@ typedef struct CxWgrad {
 
 int cx_abi_version(void);
 const char* cx_error_string(int code);
+/* rows written by the most recent successful stat_det launch issued from the calling thread */
+int cx_last_stat_rows(void);
 
 /* conv forward / input-gradient as one implicit GEMM family.
  * Replaces F.conv2d + F.batch_norm + F.relu (+ torch.cat, avg_pool2d) forward and their autograd
@@ -135,6 +143,13 @@ int cx_u8_to_nhwc4(const uint8_t* x, void* y, size_t npix, float mean, float std
 int cx_bn_coef(const float* sum, const float* sq, float count, const float* gamma, const float* beta, float eps,
                float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
                float* rstd, int C, int replicas, int rstride, void* stream);   /* sum/sq: `replicas` copies, `rstride` floats apart */
+/* BatchNorm coefficients from per-channel moments that already exist (a dense-block channel's batch mean / rstd are computed once,
+ * by the kernel that produced the channel; every later norm1 over the concatenation -- torchvision _DenseLayer.norm1 -- re-uses
+ * them with its own gamma / beta / running buffers).  Channels [c_lo, c_lo + c_n) are reduced first, in row order, from `rows`
+ * deterministic statistic rows (CxConv.stat_det) into mean / rstd.                                                             */
+int cx_bn_coef_moments(float* mean, float* rstd, float count, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* scale, float* shift, int C, const float* sum, const float* sq,
+                       int rows, int rstride, int c_lo, int c_n, void* stream);
 /* eval mode: scale/shift from running statistics                                                 */
 int cx_bn_coef_eval(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                     float eps, float* scale, float* shift, float* mean, float* rstd, int C, void* stream);
@@ -158,13 +173,13 @@ int cx_bn_bwd_slice_coef(const float* A, const float* Bc, const float* mean, con
  * (features.norm0/relu0/pool0, attn_aug_conv.py:462-464).  argmax: (B,H/2,W/2,C) uint8 window
  * position (0..8) of the first maximum, kept for the backward pass.                               */
 int cx_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax,
-                          float* stat_sum, float* stat_sq, int B, int H, int W, int C, int ldy, void* stream);
+                          float* stat_sum, float* stat_sq, int B, int H, int W, int C, int ldy, int stat_rows, void* stream);
 /* backward of the same: routes (corrected) dY to the arg-max, applies the ReLU mask, writes dz (bf16,
  * (B,H,W,C)) and accumulates S1 = sum dz, S2 = sum dz*xhat                                       */
 int cx_bnrelu_maxpool_bwd(const void* x, const float* scale, const float* shift, const float* mean,
                           const float* rstd, const uint8_t* argmax, const void* g, const void* gx, const float* ga,
                           const float* gb, const float* gc, void* dz, float* S1, float* S2, int B, int H, int W, int C,
-                          int ldg, int ldgx, void* stream);
+                          int ldg, int ldgx, int stat_rows, void* stream);
 
 /* head: pooled[b][c] = mean_hw relu(x*scale+shift); logits = pooled @ Wt + bias
  * (attn_aug_conv.py:514-516)                                                                      */
@@ -181,12 +196,12 @@ int cx_head_bwd(const float* dlogits, const float* pooled, const float* w, float
                 float* dpooled, int B, int C, int n_classes, void* stream);
 int cx_gap_relu_bn_bwd(const float* dpooled, const void* x, const float* scale, const float* shift,
                        const float* mean, const float* rstd, const float* e_scale, void* g, float* S1, float* S2,
-                       int B, int HW, int C, int ldx, int ldg, void* stream);
+                       int B, int HW, int C, int ldx, int ldg, int stat_rows, void* stream);
 
 /* transition backward glue: un-pool (each of the 4 inputs gets d/4), ReLU mask + BN mask epilogue */
 int cx_unpool2_mask(const void* d, const void* x, const float* sc, const float* sh, const float* mean,
                     const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W,
-                    int C, int ldd, int ldx, int ldg, void* stream);
+                    int C, int ldd, int ldx, int ldg, int stat_rows, void* stream);
 
 /* residual join of a Bottleneck: out = relu(a*pa + b*pb + pc) (bn3(conv3) + identity | bn_d(downsample),
  * attn_aug_conv.py:202-209); pa/pb/pc fp32 [C]                                                    */
@@ -296,6 +311,10 @@ int cx_linear_fwd(const float* x, const float* w, const float* bias, float* y, i
 int cx_gradcam_map(const void* x, const float* scale, const float* shift, const float* w, float* cam, int B, int HW, int C,
                    int ldx, int inner_relu, void* stream);
 int cx_cam_norm_upsample(const float* cam, float* out, int B, int h, int w, int H, int W, void* stream);
+
+/* stat_rows (cx_bnrelu_maxpool_fwd / _bwd, cx_gap_relu_bn_bwd, cx_unpool2_mask): 0 = the statistics are added to the single
+ * copy S1 / S2 [C] with atomics; > 0 = deterministic rows: the launch uses at most stat_rows workgroups (cx_gap_relu_bn_bwd: one row
+ * per image, B <= stat_rows) and plain-stores row r at S[r*C + c]; cx_last_stat_rows() gives the row count for the consumer.   */
 
 /* utilities */
 int cx_fill_f32(float* p, float v, size_t n, void* stream);

@@ -46,6 +46,9 @@ def _worker(rank, world, port, out_dir, kind):
     model.forward_backward(x, t)                          # binds the engine; local gradient, no reducer yet
     eng = model._eng()
     g_local = eng.flat_grad.detach().cpu().clone()
+    model.zero_grad()
+    model.forward_backward(x, t)                          # the same local step again: run-to-run spread of the fp32 atomic sums
+    noise = float((eng.flat_grad.detach().cpu() - g_local).norm() / g_local.norm())
     gathered = [torch.empty_like(g_local) for _ in range(world)]
     dist.all_gather(gathered, g_local)
     want = sum(gathered) / world
@@ -56,7 +59,9 @@ def _worker(rank, world, port, out_dir, kind):
     got = eng.flat_grad.detach().cpu().clone()
     both = [torch.empty_like(got) for _ in range(world)]
     dist.all_gather(both, got)
-    torch.save({"got": got, "want": want, "same": bool(torch.equal(both[0], both[1])), "n_buckets": len(eng.reducer.ranges)},
+    spans = [(n_, eng.off_of[id(p)], p.numel()) for n_, p in model.named_parameters()]
+    torch.save({"got": got, "want": want, "same": bool(torch.equal(both[0], both[1])), "n_buckets": len(eng.reducer.ranges),
+                "noise": noise, "spans": spans},
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -75,5 +80,18 @@ def test_data_parallel_backward_two_ranks_one_gpu(tmp_path, kind):
         g, w = rec["got"].double(), rec["want"].double()
         cos = float((g * w).sum() / (g.norm() * w.norm()))
         rel = float((g - w).norm() / w.norm())
-        print("rank %d: cos %.6f rel %.3e buckets %d" % (r, cos, rel, rec["n_buckets"]))
-        assert cos > 0.999 and rel < 5e-2
+        print("rank %d: cos %.6f rel %.3e buckets %d; the same local step twice differs by %.3e" % (r, cos, rel, rec["n_buckets"],
+                                                                                               rec["noise"]))
+        assert cos > 0.995 and rel < max(5e-2, 4 * rec["noise"])
+        # a `ready()` fired before a range was final (or a range never reduced) is a gross error on whole tensors, not noise
+        gmax = max(float(w[o:o + n].norm()) for _, o, n in rec["spans"])
+        bad = []
+        for name, o, n in rec["spans"]:
+            a, b = g[o:o + n], w[o:o + n]
+            if float(b.norm()) < 1e-3 * gmax:
+                continue
+            c = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+            ratio = float(a.norm() / b.norm())
+            if c < 0.9 or abs(ratio - 1) > 0.25:
+                bad.append((name, c, ratio))
+        assert not bad, "per-tensor mismatch after the overlapped all-reduce: %s" % bad[:6]
