@@ -122,30 +122,52 @@ __global__ void u8_to_nhwc4_kernel(const uint8_t* __restrict__ x, bf16* __restri
   }
 }
 
+// Row reduction shared by the coefficient kernels: a 1024-thread workgroup owns 16 channels; thread (q, j) sums rows q, q + 64, ...
+// of channel j with four loads in flight (added in row order), the 64 partial sums meet in LDS and are added in q order.  The
+// order is fixed, so the result does not depend on scheduling.
+template <typename T>
+__device__ __forceinline__ void reduce_rows16(const float* __restrict__ a, const float* __restrict__ b, int rows, int rstride, int ch,
+                                              T (*part)[64][17], T& ta, T& tb) {
+  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+  T sa = 0, sb = 0;
+  int r = q;
+  for (; r + 192 < rows; r += 256) {
+    const float a0 = a[(size_t)r * rstride + ch], a1 = a[(size_t)(r + 64) * rstride + ch];
+    const float a2 = a[(size_t)(r + 128) * rstride + ch], a3 = a[(size_t)(r + 192) * rstride + ch];
+    const float b0 = b[(size_t)r * rstride + ch], b1 = b[(size_t)(r + 64) * rstride + ch];
+    const float b2 = b[(size_t)(r + 128) * rstride + ch], b3 = b[(size_t)(r + 192) * rstride + ch];
+    sa += (T)a0; sa += (T)a1; sa += (T)a2; sa += (T)a3;
+    sb += (T)b0; sb += (T)b1; sb += (T)b2; sb += (T)b3;
+  }
+  for (; r < rows; r += 64) {
+    sa += (T)a[(size_t)r * rstride + ch];
+    sb += (T)b[(size_t)r * rstride + ch];
+  }
+  part[0][q][j] = sa;
+  part[1][q][j] = sb;
+  __syncthreads();
+  ta = 0; tb = 0;
+  if (q == 0) {
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) { ta += part[0][k][j]; tb += part[1][k][j]; }
+  }
+}
+
 // Both coefficient kernels reduce `replicas` rows per channel (16 atomic replicas, or the per-workgroup rows of a
 // CxConv.stat_det launch: hundreds to thousands).  A 256-thread workgroup owns 16 channels: thread (q, j) sums rows q, q + 16, ...
 // of channel j (64-B row segments per 16 lanes), the 16 partial sums meet in LDS and are added in q order -- a fixed order, so
 // the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void bn_coef_kernel(const float* sum, const float* sq, float count, const float* gamma,
-                                                      const float* beta, float eps, float momentum, float* rmean, float* rvar,
-                                                      float* scale, float* shift, float* mean, float* rstd, int C, int replicas,
-                                                      int rstride) {
-  __shared__ double part[2][16][17];
+__global__ __launch_bounds__(1024) void bn_coef_kernel(const float* sum, const float* sq, float count, const float* gamma,
+                                                       const float* beta, float eps, float momentum, float* rmean, float* rvar,
+                                                       float* scale, float* shift, float* mean, float* rstd, int C, int replicas,
+                                                       int rstride) {
+  __shared__ double part[2][64][17];
   const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + j;
   const int cc = c < C ? c : C - 1;
-  double ts = 0.0, tq = 0.0;
-  for (int r = q; r < replicas; r += 16) {
-    ts += (double)sum[(size_t)r * rstride + cc];
-    tq += (double)sq[(size_t)r * rstride + cc];
-  }
-  part[0][q][j] = ts;
-  part[1][q][j] = tq;
-  __syncthreads();
+  double ts, tq;
+  reduce_rows16<double>(sum, sq, replicas, rstride, cc, part, ts, tq);
   if (q != 0 || c >= C) return;
-  ts = 0.0; tq = 0.0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { ts += part[0][k][j]; tq += part[1][k][j]; }
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   const float rm0 = rmean ? rmean[c] : 0.f, rv0 = rvar ? rvar[c] : 0.f;
   const double m = ts / count;
@@ -165,11 +187,11 @@ __global__ __launch_bounds__(256) void bn_coef_kernel(const float* sum, const fl
 // are computed once, when the channel is produced; every later norm1 over the concatenation re-uses them with its own gamma /
 // beta / running buffers).  Channels [c_lo, c_lo + c_n) are "fresh": their moments are first reduced from `rows` statistic rows
 // (sum / sq at row pitch rstride, element c - c_lo) and written to mean / rstd.
-__global__ __launch_bounds__(256) void bn_coef_moments_kernel(float* mean, float* rstd, float count, const float* gamma,
-                                                              const float* beta, float eps, float momentum, float* rmean, float* rvar,
-                                                              float* scale, float* shift, int C, const float* sum, const float* sq,
-                                                              int rows, int rstride, int c_lo, int c_n) {
-  __shared__ double part[2][16][17];
+__global__ __launch_bounds__(1024) void bn_coef_moments_kernel(float* mean, float* rstd, float count, const float* gamma,
+                                                               const float* beta, float eps, float momentum, float* rmean, float* rvar,
+                                                               float* scale, float* shift, int C, const float* sum, const float* sq,
+                                                               int rows, int rstride, int c_lo, int c_n) {
+  __shared__ double part[2][64][17];
   const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + j;
   const int cc = c < C ? c : C - 1;
@@ -179,20 +201,10 @@ __global__ __launch_bounds__(256) void bn_coef_moments_kernel(float* mean, float
   float m, r;
   if (any_fresh) {
     const bool fresh = cc >= c_lo && cc < c_lo + c_n;
-    const int fc = fresh ? cc - c_lo : 0;
-    double ts = 0.0, tq = 0.0;
-    for (int rr = q; rr < rows; rr += 16) {
-      ts += (double)sum[(size_t)rr * rstride + fc];
-      tq += (double)sq[(size_t)rr * rstride + fc];
-    }
-    part[0][q][j] = ts;
-    part[1][q][j] = tq;
-    __syncthreads();
+    double ts, tq;
+    reduce_rows16<double>(sum, sq, rows, rstride, fresh ? cc - c_lo : 0, part, ts, tq);
     if (q != 0 || c >= C) return;
     if (fresh) {
-      ts = 0.0; tq = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { ts += part[0][k][j]; tq += part[1][k][j]; }
       const double md = ts / count;
       double v = tq / count - md * md;
       if (v < 0) v = 0;
@@ -232,25 +244,16 @@ __global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const
   if (rstd) rstd[c] = r;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* S1, const float* S2, float count, const float* gamma,
-                                                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* A,
-                                                          float* Bc, float* pa, float* pb, float* pc, int C, int replicas, int rstride) {
-  __shared__ float part[2][16][17];
-  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;       // 16 channels x 16 row lanes, as in bn_coef_kernel
+__global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(const float* S1, const float* S2, float count, const float* gamma,
+                                                           const float* mean, const float* rstd, float* dgamma, float* dbeta, float* A,
+                                                           float* Bc, float* pa, float* pb, float* pc, int C, int replicas, int rstride) {
+  __shared__ float part[2][64][17];
+  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + j;
   const int cc = c < C ? c : C - 1;
-  float s1 = 0.f, s2 = 0.f;
-  for (int rr = q; rr < replicas; rr += 16) {
-    s1 += S1[(size_t)rr * rstride + cc];
-    s2 += S2[(size_t)rr * rstride + cc];
-  }
-  part[0][q][j] = s1;
-  part[1][q][j] = s2;
-  __syncthreads();
+  float s1, s2;
+  reduce_rows16<float>(S1, S2, replicas, rstride, cc, part, s1, s2);
   if (q != 0 || c >= C) return;
-  s1 = 0.f; s2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { s1 += part[0][k][j]; s2 += part[1][k][j]; }
   const float g = gamma ? gamma[c] : 1.f, r = rstd[c], mu = mean[c];
   if (dgamma) dgamma[c] += s2;
   if (dbeta) dbeta[c] += s1;
@@ -823,12 +826,13 @@ __global__ void optim_tick_kernel(float* hyper) {
   const float step = hyper[1] + 1.f;
   hyper[1] = step;
   const int kind = (int)hyper[2];
-  const float sched = step - hyper[4];                 // scheduler.step() calls so far minus one (one per minibatch once step >= warmup)
-  if (kind == 1 && sched >= 0.f) hyper[0] *= hyper[3];                                     // ExponentialLR
-  if (kind == 2 && sched >= 0.f) {                                                        // MultiStepLR, two milestones
-    const float k = (sched + 1.f >= hyper[5] ? 1.f : 0.f) + (sched + 1.f >= hyper[6] ? 1.f : 0.f);
-    hyper[0] = hyper[7] * powf(hyper[3], k);
-  }
+  // chexpert.py:157-165: `args.step += 1` opens the minibatch, `if scheduler and args.step >= args.lr_warmup_steps:
+  // scheduler.step()` closes it -> after minibatch number `step` the scheduler has been stepped k times
+  const float warm = hyper[4];
+  if (step < warm) return;
+  const float k = step - fmaxf(warm, 1.f) + 1.f;
+  if (kind == 1) hyper[0] *= hyper[3];                                                   // ExponentialLR
+  if (kind == 2) hyper[0] = hyper[7] * powf(hyper[3], (k >= hyper[5] ? 1.f : 0.f) + (k >= hyper[6] ? 1.f : 0.f));   // MultiStepLR
 }
 
 inline int grid_for(size_t n, int block, int cap = 4096) {
@@ -894,7 +898,7 @@ int cx_bn_coef(const float* sum, const float* sq, float count, const float* gamm
   if (!sum || !sq || C <= 0 || count <= 0) return CX_EINVAL;
   if (replicas < 1) replicas = 1;
   if (replicas > 1 && rstride < C) return CX_EINVAL;
-  hipLaunchKernelGGL(bn_coef_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), sum, sq, count, gamma, beta, eps,
+  hipLaunchKernelGGL(bn_coef_kernel, dim3((C + 15) / 16), dim3(1024), 0, as_stream(stream), sum, sq, count, gamma, beta, eps,
                      momentum, running_mean, running_var, scale, shift, mean, rstd, C, replicas, rstride);
   return launch_status();
 }
@@ -904,7 +908,7 @@ int cx_bn_coef_moments(float* mean, float* rstd, float count, const float* gamma
                        int rows, int rstride, int c_lo, int c_n, void* stream) {
   if (!mean || !rstd || C <= 0 || count <= 0) return CX_EINVAL;
   if (c_n > 0 && (!sum || !sq || rows < 1 || rstride < c_n || c_lo < 0 || c_lo + c_n > C)) return CX_EINVAL;
-  hipLaunchKernelGGL(bn_coef_moments_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), mean, rstd, count, gamma, beta, eps,
+  hipLaunchKernelGGL(bn_coef_moments_kernel, dim3((C + 15) / 16), dim3(1024), 0, as_stream(stream), mean, rstd, count, gamma, beta, eps,
                      momentum, running_mean, running_var, scale, shift, C, sum, sq, rows, rstride, c_lo, c_n);
   return launch_status();
 }
@@ -924,7 +928,7 @@ int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* g
   if (replicas < 1) replicas = 1;
   if (replicas > 1 && rstride < C) return CX_EINVAL;
   if (pa && (!pb || !pc)) return CX_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), S1, S2, count, gamma, mean,
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 15) / 16), dim3(1024), 0, as_stream(stream), S1, S2, count, gamma, mean,
                      rstd, dgamma, dbeta, A, Bc, pa, pb, pc, C, replicas, rstride);
   return launch_status();
 }

@@ -24,6 +24,10 @@ class GraphedTrainStep:
         if any(getattr(m_, "p", 0) for m_ in model.modules() if type(m_).__name__ == "DropMarker"):
             raise RuntimeError("graph capture would freeze the Dropout / DropConnect seeds (host-drawn per step); use the eager step")
         model.train()
+        # construction is free of side effects on the model: the warm-up steps below really run (they update BatchNorm running
+        # statistics), so the module buffers and the num_batches_tracked bookkeeping are put back afterwards
+        saved = [(b, b.detach().clone()) for b in model.buffers()]
+        nbt = getattr(model, "_nbt_pending", 0)
         # eager warm-up on a side stream: binds the engine, allocates the workspaces, sets kernel attributes, creates the
         # optimiser state -- none of which may happen during capture
         s = torch.cuda.Stream(device=x.device)
@@ -44,6 +48,11 @@ class GraphedTrainStep:
             if optimizer is not None:
                 optimizer.step_dev()
                 optimizer.tick()
+        with torch.no_grad():
+            for b, v in saved:
+                b.copy_(v)
+        if hasattr(model, "_nbt_pending"):
+            model._nbt_pending = nbt
         self.replays = 0
 
     def replay(self, x=None, target=None):

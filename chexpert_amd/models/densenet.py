@@ -229,7 +229,7 @@ class _Engine:
     """Host-side schedule: binds the module's parameters to flat buffers, packs weights, and issues the
     kernel sequence of forward and backward on the current stream."""
     SLAB = 1 << 21               # floats per half of the statistic-row scratch (rows x channels of the largest producer)
-    EW_ROWS = 1024               # workgroups (= rows) of the element-wise statistic producers in deterministic mode
+    EW_ROWS = 2048               # workgroups (= rows) of the element-wise statistic producers in deterministic mode
 
     # statistics plumbing: producer kwargs / consumer (sum, sq, replicas, rstride) for the two modes
     def _sp(self, ws, slots, C, sub=None):
@@ -588,14 +588,14 @@ class _Engine:
                 raise RuntimeError("batch too large for the statistic-row scratch (B*C = %d > %d)" % (B * ct, self.SLAB))
             rows = ops.gap_relu_bn_bwd(dpooled, ws.buf[bi], v(nt[0]), v(nt[1]), v(bmean), v(brstd), v(nt[0]), ws.gbuf[bi], ws.slab[0],
                                        ws.slab[1], stat_rows=self.SLAB // ct)
-            red = (ws.slab[0], ws.slab[1], rows, ct)
+            sred = (ws.slab[0], ws.slab[1], rows, ct)
         else:
             ops.gap_relu_bn_bwd(dpooled, ws.buf[bi], v(nt[0]), v(nt[1]), v(bmean), v(brstd), v(nt[0]), ws.gbuf[bi], v(St[0]),
                                 v(St[1]))
-            red = (v(St[0]), v(St[1]), 1, 0)
+            sred = (v(St[0]), v(St[1]), 1, 0)
         h, w = ws.hw[bi]
-        ops.bn_bwd_coef(red[0], red[1], B * h * w, f.norm5.weight, v(bmean), v(brstd), G(f.norm5.weight), G(f.norm5.bias),
-                        v(A), v(Bc), None, None, None, ct, replicas=red[2], rstride=red[3])
+        ops.bn_bwd_coef(sred[0], sred[1], B * h * w, f.norm5.weight, v(bmean), v(brstd), G(f.norm5.weight), G(f.norm5.bias),
+                        v(A), v(Bc), None, None, None, ct, replicas=sred[2], rstride=sred[3])
         q, pv = s["q"], s["p"]
         # weight-gradient kernels only feed the flat gradient buffer: they run on a side stream, concurrently
         # with the input-gradient chain of the following layers (two dz2 buffers, per-layer coefficient slots)
@@ -688,29 +688,29 @@ class _Engine:
                 if det:
                     rows = ops.unpool2_mask(dpool, pbuf, v(nt[0]), v(nt[1]), v(pmean), v(prstd), v(nt[0]), pg, ws.slab[0], ws.slab[1],
                                             stat_rows=ew_rows(cprev))
-                    red = (ws.slab[0], ws.slab[1], rows, cprev)
+                    sred = (ws.slab[0], ws.slab[1], rows, cprev)
                 else:
                     ops.unpool2_mask(dpool, pbuf, v(nt[0]), v(nt[1]), v(pmean), v(prstd), v(nt[0]), pg, v(St[0]), v(St[1]))
-                    red = (v(St[0]), v(St[1]), 1, 0)
+                    sred = (v(St[0]), v(St[1]), 1, 0)
                 ops.conv_wgrad(gs, pbuf, G(tr.conv.weight), mode=ops.MODE_POOL2, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa, gb=qb,
                                gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(nt[0]), pb=v(nt[1]))
-                ops.bn_bwd_coef(red[0], red[1], B * ph * pw, tr.norm.weight, v(pmean), v(prstd), G(tr.norm.weight),
-                                G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev, replicas=red[2], rstride=red[3])
+                ops.bn_bwd_coef(sred[0], sred[1], B * ph * pw, tr.norm.weight, v(pmean), v(prstd), G(tr.norm.weight),
+                                G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev, replicas=sred[2], rstride=sred[3])
                 done(tr.norm.weight)
             else:
                 n0, S0 = s["n0"], s["S0"]
                 if det:
                     rows = ops.bnrelu_maxpool_bwd(ws.c0, v(n0[0]), v(n0[1]), v(n0[2]), v(n0[3]), ws.amax, gs, xs, qa, qb, qc, ws.dz0,
                                                   ws.slab[0], ws.slab[1], stat_rows=ew_rows(self.c_init))
-                    red = (ws.slab[0], ws.slab[1], rows, self.c_init)
+                    sred = (ws.slab[0], ws.slab[1], rows, self.c_init)
                 else:
                     ops.bnrelu_maxpool_bwd(ws.c0, v(n0[0]), v(n0[1]), v(n0[2]), v(n0[3]), ws.amax, gs, xs, qa, qb, qc, ws.dz0,
                                            v(S0[0]), v(S0[1]))
-                    red = (v(S0[0]), v(S0[1]), 1, 0)
+                    sred = (v(S0[0]), v(S0[1]), 1, 0)
                 pa, pb, pc = (v(t)[:self.c_init] for t in pv)
-                ops.bn_bwd_coef(red[0], red[1], B * (ws.H // 2) * (ws.W // 2), f.norm0.weight, v(n0[2]), v(n0[3]),
-                                G(f.norm0.weight), G(f.norm0.bias), None, None, pa, pb, pc, self.c_init, replicas=red[2],
-                                rstride=red[3])
+                ops.bn_bwd_coef(sred[0], sred[1], B * (ws.H // 2) * (ws.W // 2), f.norm0.weight, v(n0[2]), v(n0[3]),
+                                G(f.norm0.weight), G(f.norm0.bias), None, None, pa, pb, pc, self.c_init, replicas=sred[2],
+                                rstride=sred[3])
                 ops.conv_wgrad(ws.dz0, ws.x4, G(f.conv0.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0,
                                ga=pa, gb=pb, gc=pc)
         main.wait_stream(side)

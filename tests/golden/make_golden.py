@@ -200,6 +200,9 @@ def gen_nets(out_dir, which):
         "densenet121_320_b2": lambda: (DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls),
                                        nets.densenet_spec(n_cls), 2, 320,
                                        lambda s, x, train: nets.densenet_forward(s, x, train=train)),
+        "densenet121_320_b8": lambda: (DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls),
+                                       nets.densenet_spec(n_cls), 8, 320,
+                                       lambda s, x, train: nets.densenet_forward(s, x, train=train)),
         "densenet_tiny_64_b3": lambda: (DenseNet(32, (2, 2, 2, 2), 64, num_classes=n_cls),
                                         nets.densenet_spec(n_cls, block_config=(2, 2, 2, 2)), 3, 64,
                                         lambda s, x, train: nets.densenet_forward(s, x, (2, 2, 2, 2), train=train)),

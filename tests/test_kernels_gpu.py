@@ -466,7 +466,7 @@ def test_device_hyper_optimisers_and_schedulers_match_torch(dev, kind):
         g = rnd(141 + it, (n,))
         pc.grad = g.clone()
         opt.step()
-        if sched is not None and it >= warm:
+        if sched is not None and it + 1 >= warm:          # chexpert.py:157, :165: the 1-based step count is compared
             sched.step()
         gd = g.to(dev)
         if kind == "adam":

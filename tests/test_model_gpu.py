@@ -172,8 +172,16 @@ def test_matches_reference_golden_fixture(dev):
     loss, logits = model.forward_backward(x, t)
     want = torch.tensor(rec["logits_train"])
     print("golden train logits rel %.3e" % _rel(logits.cpu(), want))
-    # B=2 batch-statistic BatchNorm: the storage-rounded fp32 oracle is itself 0.74e-2 away (see module docstring)
-    assert _rel(logits.cpu(), want) < 2e-2
+    # Hash-filled weights + batch-statistic BatchNorm: the fp32 oracle with NOTHING but bf16 rounding of the stored activations
+    # (oracle.nets.bf16_storage) is itself e_q away from the reference on this fixture (0.7e-2 here, 1.6e-2 at B=8): that is what
+    # the storage type allows.  The path also rounds the weights and the normalised MFMA operands; its result is deterministic
+    # (statistic rows, no atomics), so this is one number, not a spread.  The 1e-3 check of the schedule is the fp32 mode.
+    from oracle import nets as onets
+    with torch.no_grad():
+        lq = onets.densenet_forward({k: v.clone() for k, v in sd.items()}, x.cpu(), cfg, train=True, q=onets.bf16_storage)
+    e_q = _rel(lq, want)
+    print("golden train logits: storage-rounded oracle vs reference %.3e" % e_q)
+    assert _rel(logits.cpu(), want) < max(1e-2, 2.0 * e_q)
     assert abs(loss.item() - rec["loss"]) < 1e-2 * rec["loss"]
     for k in ("classifier.weight", "classifier.bias", "features.norm5.weight", "features.norm5.bias"):
         l2 = dict(model.named_parameters())[k].grad.double().norm().item()
@@ -211,9 +219,8 @@ def test_graphed_train_step_equals_eager_steps(dev):
     sd0 = {k: v.clone() for k, v in m_g.state_dict().items()}
     opt_g = FusedAdam(m_g, lr=1e-3)
     gs = GraphedTrainStep(m_g, opt_g, xs[0], ts[0])
-    # the warm-up iterations inside the constructor ran forward/backward only (no optimiser step) but did update BatchNorm
-    # running statistics: start both from the same state
-    m_g.load_state_dict(sd0)
+    for k, v in m_g.state_dict().items():                # capture (and its warm-up steps) leave the model as it was
+        assert torch.equal(v, sd0[k]), k
     losses_g = []
     for x, t in zip(xs, ts):
         loss, _ = gs.replay(x, t)

@@ -217,9 +217,14 @@ def test_aaresnet152_reference_golden_train_step(dev):
     want = torch.tensor(rec["logits_train"])
     e = _rel(logits.cpu(), want)
     print("aaresnet152 golden train logits rel %.3e loss %.5f (ref %.5f)" % (e, loss.item(), rec["loss"]))
-    # B = 1 and 100 values per channel in layer4: the fp32 oracle itself differs from the reference by 2.5 % on gradient norms
-    # here (make_golden.py prints it); limits are set at that conditioning, not at the kernel's precision
-    assert e < 3e-2
+    # B = 1 and 100 values per channel in layer4: the fp32 oracle with bf16 rounding of the stored activations alone
+    # (oracle.nets.bf16_storage) is e_q = 9.7e-2 away from the reference on this fixture, and the fp32 oracle itself differs from
+    # the reference by 2.5 % on gradient norms (make_golden.py prints it): limits are set by that conditioning
+    with torch.no_grad():
+        lq = nets.resnet_forward({k: v.clone() for k, v in sd.items()}, x.cpu(), train=True, nh=8, q=nets.bf16_storage)
+    e_q = _rel(lq, want)
+    print("aaresnet152 golden train logits: storage-rounded oracle vs reference %.3e" % e_q)
+    assert e < max(1e-2, 1.5 * e_q)
     assert abs(loss.item() - rec["loss"]) < 2e-2 * rec["loss"]
     named = dict(model.named_parameters())
     rows = [(k, named[k].grad.double().norm().item() / rec["grads"][k]["l2"]) for k in
