@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALG_BYTES_PER_IMG = 283.1e6    # densenet121@320 bf16, fwd+bwd
+ALG_BYTES_FP32 = {"densenet121": 566.2e6}     # SURVEY.md section 8d, fp32 column
 ALG_BYTES = {"densenet121": 283.1e6, "aadensenet121": 295.4e6, "resnet152": 555.0e6, "aaresnet152": 555.0e6, "efficientnet-b4": 594.5e6,
              "efficientnet-b0": 166.2e6}
 
@@ -90,7 +91,10 @@ class KernelTimer:
             tag = self.gemm_kernel_name(x, kw)
             mi, ci = self._dims(x)
             mo, co = self._dims(y)
-            alg = 2.0 * (mi * ci + mo * co)          # |X| + |Y| elements, bf16 (SURVEY 8d rule, per kernel)
+            alg = (4.0 if x.dtype == torch.float32 else 2.0) * (mi * ci + mo * co)      # |X| + |Y| elements (SURVEY 8d rule, per kernel)
+            if x.dtype == torch.float32:
+                tag = "conv_f32_kernel<%d, %d, %d>" % (kw.get("prologue", 0), 0 if kw.get("mode", 0) == 2 else kw.get("mode", 0),
+                                                       kw.get("epilogue", 0))
             if kw.get("fused_dw") is not None:       # conv1x1_bwd.hip launch_bwd: 128-channel tiles for wide slices / big maps
                 wide = kw["N"] >= 128
                 v1 = os.environ.get("CX_PW_BWD_V1", "0") not in ("", "0")
@@ -106,11 +110,14 @@ class KernelTimer:
             if not self.enabled:
                 return ow(g, x, dw, **kw)
             tag = self.wgrad_kernel_name(g, x, kw)
-            if self.only is not None and tag != self.only:
-                return ow(g, x, dw, **kw)
             mg, cg = self._dims(g)
             mx, cx = self._dims(x)
-            return self._timed(tag, 2.0 * (mg * cg + mx * cx), ow, g, x, dw, **kw)
+            if g.dtype == torch.float32:
+                tag = "wgrad_f32_kernel<%d, %d, %d>" % (kw.get("g_prologue", 0), kw.get("x_prologue", 0),
+                                                        0 if kw.get("mode", 0) == 2 else kw.get("mode", 0))
+            if self.only is not None and tag != self.only:
+                return ow(g, x, dw, **kw)
+            return self._timed(tag, (4.0 if g.dtype == torch.float32 else 2.0) * (mg * cg + mx * cx), ow, g, x, dw, **kw)
         ops.conv_gemm, ops.conv_wgrad = conv_gemm, conv_wgrad
 
     def _timed(self, tag, alg, fn, *a, **kw):
@@ -132,7 +139,7 @@ class KernelTimer:
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
     collected with rocprofv3 --pmc in their own runs); null when the workload differs from the one the counters were taken on."""
-    if (args.model, args.batch, args.size) != ("densenet121", 256, 320):
+    if (args.model, args.batch, args.size, args.dtype) != ("densenet121", 256, 320, "bf16"):
         return None
     files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")) \
         if os.path.isdir(os.path.join(ROOT, "profiles")) else []
@@ -209,7 +216,7 @@ def cpu_baseline(n_classes, steps=3, batch=4, size=320):
 def committed_counter(kernel, args, key):
     """Per-kernel figures from the committed counter passes (profiles/*_sq_counters.json: SQ_VALU_MFMA_BUSY_CYCLES /
     SQ_BUSY_CU_CYCLES collected with rocprofv3 --pmc in their own run); null for other workloads."""
-    if (args.model, args.batch, args.size) != ("densenet121", 256, 320):
+    if (args.model, args.batch, args.size, args.dtype) != ("densenet121", 256, 320, "bf16"):
         return None
     d = os.path.join(ROOT, "profiles")
     files = sorted(f for f in os.listdir(d) if f.endswith("_sq_counters.json")) if os.path.isdir(d) else []
@@ -229,6 +236,8 @@ def main():
     ap.add_argument("--classes", type=int, default=14)
     ap.add_argument("--model", default="densenet121", choices=["densenet121", "aadensenet121", "resnet152", "aaresnet152", "efficientnet-b4", "efficientnet-b0"],
                     help="densenet121 is the headline (BASELINE configs[1]); the others are reported for reference only")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="activation storage type: bf16 (the headline, BASELINE configs[1]) or the fp32 parity mode (densenet121 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying the captured hipGraph")
     ap.add_argument("--roofline-kernel", default=None, help="kernel tag to time (default: the one with the largest share)")
@@ -258,8 +267,10 @@ def main():
             dist.init_process_group(backend)
 
     torch.manual_seed(1234)
+    if args.dtype == "fp32" and args.model != "densenet121":
+        sys.exit("the fp32 storage mode covers densenet121")
     if args.model == "densenet121":
-        model = densenet121(num_classes=args.classes).to(dev)
+        model = densenet121(num_classes=args.classes).storage_dtype(args.dtype).to(dev)
     elif args.model == "aadensenet121":
         from chexpert_amd.models import DenseNet
         model = DenseNet(32, (6, 12, 24, 16), 64, num_classes=args.classes,
@@ -393,18 +404,20 @@ def main():
         avg_ms = ksum["ms"] / ksum["launches"]
         achieved = ksum["alg_bytes"] / (ksum["ms"] * 1e-3) / 1e9
         out = {
-            "metric": "images/sec fwd+bwd %s %dx%d bf16 (per-GPU rate in config.images_per_sec_per_gpu)" % (
-            "DenseNet121" if args.model == "densenet121" else args.model, args.size, args.size),
+            "metric": "images/sec fwd+bwd %s %dx%d %s (per-GPU rate in config.images_per_sec_per_gpu)" % (
+            "DenseNet121" if args.model == "densenet121" else args.model, args.size, args.size, args.dtype),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s bf16 1xMI355X %dx%d bs=%d U-Ones labels (%s); %d classes; "
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "%s %s 1xMI355X %dx%d bs=%d U-Ones labels (%s); %d classes; "
                                    "random-init weights, synthetic uint8 X-rays" % (
-                                       args.model, args.size, args.size, args.batch,
-                                       "BASELINE configs[1]" if args.model == "densenet121" else "not the headline config", args.classes),
+                                       args.model, args.dtype, args.size, args.size, args.batch,
+                                       "BASELINE configs[1]" if (args.model, args.dtype) == ("densenet121", "bf16") else
+                                       "not the headline config", args.classes),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "images_per_sec_per_gpu": round(value / world, 2),
-                       "model_hbm_roofline_frac": round(value / world * ALG_BYTES[args.model] / (HBM_PEAK_GBS * 1e9), 4),
+                       "model_hbm_roofline_frac": round(value / world * (ALG_BYTES_FP32 if args.dtype == "fp32" else ALG_BYTES)[
+                           args.model] / (HBM_PEAK_GBS * 1e9), 4),
                        "optimizer_step_ms": round(opt_ms, 3), "loss": round(float(loss.item()), 5),
                        "measured_copy_GBs": round(copy_gbs, 1),
                        "launch": "hipGraph replay" if gstep is not None else "eager enqueue"},
@@ -416,7 +429,7 @@ def main():
                          "timing": "hip events around each launch, eager replica of the timed steps" if gstep is not None
                          else "hip events around each launch inside the timed region"},
         }
-        if not args.no_cpu_baseline and args.model == "densenet121" and world == 1:
+        if not args.no_cpu_baseline and args.model == "densenet121" and args.dtype == "bf16" and world == 1:
             log("cpu baseline on %d cores ..." % host_cores())
             out["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(out))

@@ -26,7 +26,7 @@ class CxConv(C.Structure):
                 ("ldx", _i32), ("ldx2", _i32), ("ldy", _i32), ("ldex", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32), ("tstride", _i32),
-                ("stat_replicas", _i32), ("stat_rstride", _i32), ("stat_det", _i32)]
+                ("stat_replicas", _i32), ("stat_rstride", _i32), ("stat_det", _i32), ("dtype", _i32)]
 
 
 class CxWgrad(C.Structure):
@@ -35,7 +35,7 @@ class CxWgrad(C.Structure):
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ho", _i32), ("Wo", _i32), ("K", _i32), ("N", _i32),
                 ("ldg", _i32), ("ldg2", _i32), ("ldx", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
-                ("g_prologue", _i32), ("x_prologue", _i32), ("mode", _i32), ("splits", _i32)]
+                ("g_prologue", _i32), ("x_prologue", _i32), ("mode", _i32), ("splits", _i32), ("dtype", _i32)]
 
 
 class CxPackDesc(C.Structure):
@@ -59,6 +59,14 @@ SIGNATURES = {
     "cx_bn_coef": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_bn_coef_moments": [_vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_last_stat_rows": [],
+    "cx_bnrelu_maxpool_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_bnrelu_maxpool_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_head_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cx_gap_relu_bn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_unpool2_mask_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_pack_weights_table_f32": [_vp, _vp, _vp, _i, _vp],
+    "cx_nchw3_to_nhwc4_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "cx_u8_to_nhwc4_f32": [_vp, _vp, _sz, _f, _f, _vp],
     "cx_bn_coef_eval": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],
     "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_bn_bwd_slice_coef": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],

@@ -625,6 +625,7 @@ extern "C" int cx_conv1x1_dgrad_wgrad(const CxConv* pp, float* dw, void* stream)
   if (!pp || !dw) return CX_EINVAL;
   const CxConv& p = *pp;
   if (!p.x || !p.w || !p.y || !p.ex || !p.e_sc || !p.e_sh || !p.e_mu || !p.e_r || !p.e_scale || !p.stat_sum || !p.stat_sq) return CX_EINVAL;
+  if (p.dtype != CX_DT_BF16) return CX_EUNSUPPORTED;
   if (p.mode != CX_MODE_CONV || p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0 || p.tstride > 1) return CX_EUNSUPPORTED;
   if (p.epilogue != CX_EPI_MASK || p.K != KD || (p.N % 8) || p.N <= 0) return CX_EUNSUPPORTED;
   if (p.prologue != CX_PRO_AFFINE2 && p.prologue != CX_PRO_NONE) return CX_EUNSUPPORTED;

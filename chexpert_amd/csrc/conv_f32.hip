@@ -1,0 +1,437 @@
+// fp32 storage mode (north_star: "1e-3 fp32"): the same implicit-GEMM contract as conv_gemm.hip / conv_wgrad.hip with fp32
+// activations, fp32 packed weights and the exact f32-input MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, one rounding
+// per product).  This is the parity mode: it runs the SAME schedule (statistics once per channel, BN + ReLU in the consumer
+// prologue, pool o conv commute, deferred BN-backward correction) with nothing but fp32 rounding in between, so the schedule
+// itself can be checked against the fp32 reference at 1e-3.  One generic kernel per direction, no shape-specialised fast
+// paths: the matrix pipe runs at 1/16 of its bf16 rate here and the tiles are small (see DESIGN.md for the measured rate).
+//
+//   forward / input gradient:  Y[m][n] = sum_{tap,c} A(m, tap, c) * W[tap][n][c]          (CxConv, dtype = CX_DT_F32)
+//   weight gradient:           dW[n][c][tap] += sum_m G[m][n] * A(m, tap, c)               (CxWgrad, dtype = CX_DT_F32)
+//
+// Tile (forward): 128 pixels x 64 channels x 16 k per step, 4 waves as 2 x 2, each wave two 32 x 32 accumulators; operands are
+// staged through LDS rows of 17 floats (odd pitch: the ds_read_b32 fragment reads of 32 consecutive rows hit 32 banks).
+#include "common.h"
+
+namespace {
+
+constexpr int FBM = 128, FBN = 64, FBK = 16;
+constexpr int FP = FBK + 1;                      // LDS row pitch in floats
+constexpr int EPITCH = FBN + 4;                  // epilogue tile pitch
+
+template <int PRO>
+struct NCoefF {
+  static constexpr int v = (PRO == CX_PRO_NONE) ? 0 : (PRO == CX_PRO_AFFINE_RELU ? 2 : 3);
+};
+
+template <int PRO, int MODE, int EPI>
+__global__ __launch_bounds__(256) void conv_f32_kernel(const CxConv p, const int M, const int n_tiles) {
+  constexpr int NSRC = (MODE == CX_MODE_POOL2) ? 4 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);                       // [NCoef][K]
+  float* At = coef + NCoefF<PRO>::v * p.K;                            // [128][17]
+  float* Bt = At + FBM * FP;                                          // [64][17]
+  float* etile = Bt + FBN * FP;                                       // [64][68]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = wgid / n_tiles, nt = wgid % n_tiles;
+  const int n0 = nt * FBN;
+
+  if (PRO != CX_PRO_NONE) {
+    for (int i = tid; i < p.K; i += 256) {
+      coef[i] = p.pa[i];
+      coef[p.K + i] = p.pb[i];
+      if (PRO == CX_PRO_AFFINE2) coef[2 * p.K + i] = p.pc[i];
+    }
+  }
+  const int qa = tid & 3;                  // 4-float chunk inside the 16-wide k step
+  int rb[2], riy[2], rix[2];
+  bool rvalid[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = mt * FBM + (tid >> 2) + 64 * i;
+    rvalid[i] = m < M;
+    const int mm = rvalid[i] ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    rb[i] = mm / hw;
+    const int rem = mm - rb[i] * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    if (MODE == CX_MODE_CONV) {
+      riy[i] = oy * p.stride - p.pad;
+      rix[i] = ox * p.stride - p.pad;
+    } else {
+      riy[i] = 2 * oy;
+      rix[i] = 2 * ox;
+    }
+  }
+  const int kpt = (p.K + FBK - 1) / FBK;
+  const int taps = p.kh * p.kw;
+  const int nsteps = taps * kpt;
+  const float* __restrict__ X = reinterpret_cast<const float*>(p.x);
+  const float* __restrict__ X2 = reinterpret_cast<const float*>(p.x2);
+  const float* __restrict__ Wp = reinterpret_cast<const float*>(p.w);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  __syncthreads();                       // coefficient table visible
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int tap = s / kpt, kc = s - tap * kpt;
+    const int dy = tap / p.kw, dx = tap - dy * p.kw;
+    const int c0 = kc * FBK + qa * 4;
+    const bool kok = c0 < p.K;
+    const int ck = kok ? c0 : 0;
+    // ---- stage A (two rows per thread) and B (one row per thread); loads are unconditional on clamped addresses
+    float4 ra[2][NSRC], ra2[2];
+    bool av[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (MODE == CX_MODE_POOL2) {
+        av[i] = rvalid[i] && kok;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const size_t pix = (size_t)(rb[i] * p.H + riy[i] + (a >> 1)) * p.W + rix[i] + (a & 1);
+          ra[i][a] = *reinterpret_cast<const float4*>(X + pix * p.ldx + ck);
+        }
+      } else {
+        int iy = riy[i] + dy, ix = rix[i] + dx;
+        bool ok = rvalid[i] && iy >= 0 && ix >= 0;
+        if (p.tstride > 1) {
+          ok = ok && (iy % p.tstride == 0) && (ix % p.tstride == 0);
+          iy /= p.tstride;
+          ix /= p.tstride;
+        }
+        av[i] = ok && iy < p.H && ix < p.W && kok;
+        const int cy = av[i] ? iy : 0, cx = av[i] ? ix : 0;
+        const size_t pix = (size_t)(rb[i] * p.H + cy) * p.W + cx;
+        ra[i][0] = *reinterpret_cast<const float4*>(X + pix * p.ldx + ck);
+        if (PRO == CX_PRO_AFFINE2) ra2[i] = *reinterpret_cast<const float4*>(X2 + pix * p.ldx2 + ck);
+      }
+    }
+    float4 rw;
+    bool wv;
+    {
+      const int n = n0 + (tid >> 2);
+      wv = n < p.N && kok;
+      rw = *reinterpret_cast<const float4*>(Wp + ((size_t)tap * p.N + (wv ? n : 0)) * p.K + ck);
+    }
+    __syncthreads();                     // the previous step's fragments have been read
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      if (av[i]) {
+        if (PRO == CX_PRO_NONE) {
+          o[0] = ra[i][0].x; o[1] = ra[i][0].y; o[2] = ra[i][0].z; o[3] = ra[i][0].w;
+        } else if (PRO == CX_PRO_AFFINE_RELU) {
+#pragma unroll
+          for (int a = 0; a < NSRC; ++a) {
+            const float v[4] = {ra[i][a].x, ra[i][a].y, ra[i][a].z, ra[i][a].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += fmaxf(fmaf(v[j], coef[c0 + j], coef[p.K + c0 + j]), 0.f);
+          }
+          if (NSRC == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] *= 0.25f;
+          }
+        } else {
+          const float u[4] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w};
+          const float v[4] = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = fmaf(u[j], coef[c0 + j], fmaf(v[j], coef[p.K + c0 + j], coef[2 * p.K + c0 + j]));
+        }
+      }
+      float* dst = At + ((tid >> 2) + 64 * i) * FP + qa * 4;
+      dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+    }
+    {
+      float* dst = Bt + (tid >> 2) * FP + qa * 4;
+      dst[0] = wv ? rw.x : 0.f; dst[1] = wv ? rw.y : 0.f; dst[2] = wv ? rw.z : 0.f; dst[3] = wv ? rw.w : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < FBK / 2; ++kk) {
+      const float b = Bt[(wn * 32 + lrow) * FP + 2 * kk + lh];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float a = At[((wm * 2 + i) * 32 + lrow) * FP + 2 * kk + lh];
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue: two 64-row halves through LDS
+  constexpr int CPR = FBN / 4, RPP = 256 / CPR, NPASS = 64 / RPP;        // 16 chunks per row, 16 rows per pass, 4 passes
+  const int cq = tid % CPR, rr = tid / CPR;
+  const int nch = n0 + cq * 4;
+  const bool nvalid = nch < p.N;
+  float* __restrict__ Y = reinterpret_cast<float*>(p.y);
+  const float* __restrict__ EX = reinterpret_cast<const float*>(p.ex);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float esc[4], esh[4], emu[4], er[4], escale[4];
+  if (EPI == CX_EPI_MASK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nvalid ? nch + j : 0;
+      esc[j] = p.e_sc[n]; esh[j] = p.e_sh[n]; emu[j] = p.e_mu[n]; er[j] = p.e_r[n]; escale[j] = p.e_scale[n];
+    }
+  }
+  const bool want_stats = p.stat_sum != nullptr;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          etile[row * EPITCH + wn * 32 + lrow] = acc[i][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + rr;
+      const int m = mt * FBM + half * 64 + row;
+      if (m < M && nvalid) {
+        const float4 v4 = *reinterpret_cast<const float4*>(etile + row * EPITCH + cq * 4);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float old[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.accumulate) {
+          const float4 o4 = *reinterpret_cast<const float4*>(Y + (size_t)m * p.ldy + nch);
+          old[0] = o4.x; old[1] = o4.y; old[2] = o4.z; old[3] = o4.w;
+        }
+        float o[4];
+        if (EPI == CX_EPI_STORE) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = v[j] + old[j];
+            s1[j] += o[j];
+            s2[j] = fmaf(o[j], o[j], s2[j]);
+          }
+        } else {
+          const float4 x4 = *reinterpret_cast<const float4*>(EX + (size_t)m * p.ldex + nch);
+          const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float dz = (fmaf(xv[j], esc[j], esh[j]) > 0.f) ? v[j] : 0.f;
+            s1[j] += dz;
+            s2[j] += dz * (xv[j] - emu[j]) * er[j];
+            o[j] = fmaf(escale[j], dz, old[j]);
+          }
+        }
+        *reinterpret_cast<float4*>(Y + (size_t)m * p.ldy + nch) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  if (want_stats) {
+    // lanes l, l + 16, l + 32, l + 48 of a wave share a channel chunk (tid % 16)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[j] += __shfl_xor(s1[j], 16);
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 16);
+      s2[j] += __shfl_xor(s2[j], 32);
+    }
+    float* scratch = At;
+    wg_stat_begin<4>(scratch, FBN, tid, 256);
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wg_stat_put(scratch, FBN, wave, cq * 4 + j, s1[j], s2[j]);
+    }
+    wg_stat_end<4>(scratch, FBN, tid, 256, p.stat_sum, p.stat_sq, p.stat_det, p.stat_det ? mt : (int)blockIdx.x, p.stat_replicas,
+                   p.stat_rstride, n0, p.N);
+  }
+}
+
+template <int PRO, int MODE, int EPI>
+int launch_f32(const CxConv& p, hipStream_t st) {
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + FBM - 1) / FBM);
+  const int n_tiles = (p.N + FBN - 1) / FBN;
+  const size_t smem = ((size_t)NCoefF<PRO>::v * p.K + FBM * FP + FBN * FP + 64 * EPITCH) * 4;
+  if (smem > 64 * 1024) return CX_ESHAPE;
+  if (const int e = stat_rows_check(p, m_tiles)) return e;
+  hipLaunchKernelGGL((conv_f32_kernel<PRO, MODE, EPI>), dim3(m_tiles * n_tiles), dim3(256), smem, st, p, (int)M, n_tiles);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// Workgroup = (tap, 64 output channels n, 64 input channels c, pixel range); 16 pixels per step: G[16][64 n] and A[16][64 c] in
+// LDS (pitch 65), wave (wn, wc) owns one 32 x 32 tile of dW, 8 MFMAs per step; fp32 atomics into OIHW at the end.
+constexpr int WP = 65;
+
+template <int GPRO, int XPRO, int MODE>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const CxWgrad p, const int M, const int n_tiles, const int c_tiles,
+                                                        const int px_per_split, const int dw_k) {
+  constexpr int NSRC = (MODE == CX_MODE_POOL2) ? 4 : 1;
+  __shared__ float Gt[16 * WP], Xt[16 * WP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int wn = wave >> 1, wc = wave & 1;
+  int id = blockIdx.x;
+  const int ct = id % c_tiles; id /= c_tiles;
+  const int nt = id % n_tiles; id /= n_tiles;
+  const int taps = p.kh * p.kw;
+  const int tap = id % taps;
+  const int split = id / taps;
+  const int dy = tap / p.kw, dx = tap - dy * p.kw;
+  const int n0 = nt * 64, c0 = ct * 64;
+  const int m_lo = split * px_per_split;
+  const int m_hi = (m_lo + px_per_split < M) ? m_lo + px_per_split : M;
+  const float* __restrict__ G = reinterpret_cast<const float*>(p.g);
+  const float* __restrict__ G2 = reinterpret_cast<const float*>(p.g2);
+  const float* __restrict__ X = reinterpret_cast<const float*>(p.x);
+
+  const int pr = tid >> 4, ch = (tid & 15) * 4;            // staging: pixel pr of the step, 4-float chunk ch
+  float ga[4], gb[4], gc[4], xa[4], xb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + ch + j, c = c0 + ch + j;
+    ga[j] = (GPRO == CX_PRO_AFFINE2 && n < p.N) ? p.ga[n] : 1.f;
+    gb[j] = (GPRO == CX_PRO_AFFINE2 && n < p.N) ? p.gb[n] : 0.f;
+    gc[j] = (GPRO == CX_PRO_AFFINE2 && n < p.N) ? p.gc[n] : 0.f;
+    xa[j] = (XPRO == CX_PRO_AFFINE_RELU && c < p.K) ? p.pa[c] : 1.f;
+    xb[j] = (XPRO == CX_PRO_AFFINE_RELU && c < p.K) ? p.pb[c] : 0.f;
+  }
+  const bool nok = n0 + ch < p.N, cok = c0 + ch < p.K;
+  const int hw = p.Ho * p.Wo;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int mb = m_lo; mb < m_hi; mb += 16) {
+    const int m = mb + pr;
+    const bool mok = m < m_hi;
+    const int mm = mok ? m : m_lo;
+    const int b = mm / hw;
+    const int rem = mm - b * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    float g[4] = {0.f, 0.f, 0.f, 0.f}, x[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float4 u = *reinterpret_cast<const float4*>(G + (size_t)mm * p.ldg + (nok ? n0 + ch : 0));
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (GPRO == CX_PRO_AFFINE2) v = *reinterpret_cast<const float4*>(G2 + (size_t)mm * p.ldg2 + (nok ? n0 + ch : 0));
+      const float uu[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
+      if (mok && nok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = (GPRO == CX_PRO_AFFINE2) ? fmaf(uu[j], ga[j], fmaf(vv[j], gb[j], gc[j])) : uu[j];
+      }
+    }
+    if (MODE == CX_MODE_POOL2) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const size_t pix = (size_t)(b * p.H + 2 * oy + (a >> 1)) * p.W + 2 * ox + (a & 1);
+        const float4 v = *reinterpret_cast<const float4*>(X + pix * p.ldx + (cok ? c0 + ch : 0));
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += (XPRO == CX_PRO_AFFINE_RELU) ? fmaxf(fmaf(vv[j], xa[j], xb[j]), 0.f) : vv[j];
+      }
+      if (mok && cok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = 0.25f * s[j];
+      }
+    } else {
+      const int iy = oy * p.stride - p.pad + dy, ix = ox * p.stride - p.pad + dx;
+      const bool ok = mok && cok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const size_t pix = (size_t)(b * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0);
+      const float4 v = *reinterpret_cast<const float4*>(X + pix * p.ldx + (cok ? c0 + ch : 0));
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = (XPRO == CX_PRO_AFFINE_RELU) ? fmaxf(fmaf(vv[j], xa[j], xb[j]), 0.f) : vv[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Gt[pr * WP + ch + j] = g[j];
+      Xt[pr * WP + ch + j] = x[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float a = Gt[(2 * kk + lh) * WP + wn * 32 + lrow];      // A operand: [i = n][k = pixel]
+      const float bb = Xt[(2 * kk + lh) * WP + wc * 32 + lrow];     // B operand: [k = pixel][j = c]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+    }
+  }
+  const int c = c0 + wc * 32 + lrow;
+  if (c < dw_k) {                                   // dw_k < K only for the stem (3 real channels of the 4-channel image)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < p.N) atomicAdd(p.dw + ((size_t)n * dw_k + c) * taps + tap, acc[r]);
+    }
+  }
+}
+
+template <int GPRO, int XPRO, int MODE>
+int launch_wgrad_f32(const CxWgrad& p, hipStream_t st, int dw_k) {
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int n_tiles = (p.N + 63) / 64, c_tiles = (p.K + 63) / 64, taps = p.kh * p.kw;
+  const long long base = (long long)n_tiles * c_tiles * taps;
+  long long splits = p.splits > 0 ? p.splits : (2048 + base - 1) / base;
+  if (splits > (M + 15) / 16) splits = (M + 15) / 16;
+  if (splits < 1) splits = 1;
+  long long pps = (M + splits - 1) / splits;
+  pps = (pps + 15) / 16 * 16;
+  splits = (M + pps - 1) / pps;
+  hipLaunchKernelGGL((wgrad_f32_kernel<GPRO, XPRO, MODE>), dim3((unsigned)(base * splits)), dim3(256), 0, st, p, (int)M, n_tiles, c_tiles,
+                     (int)pps, dw_k);
+  return launch_status();
+}
+
+}  // namespace
+
+// Called from cx_conv_gemm / cx_conv_wgrad when the parameter block says dtype = CX_DT_F32 (after the common validation).
+int cx_conv_gemm_f32(const CxConv& pin, hipStream_t st) {
+  CxConv p = pin;
+  if (p.mode == CX_MODE_STEM) {            // features.conv0 in fp32: a plain 7x7 stride-2 convolution over the (B,H,W,4) image
+    if (p.ldx != 4 || p.Ho != (p.H + 6 - 7) / 2 + 1 || p.Wo != (p.W + 6 - 7) / 2 + 1) return CX_ESHAPE;
+    p.mode = CX_MODE_CONV; p.kh = p.kw = 7; p.stride = 2; p.pad = 3; p.K = 4; p.tstride = 1;
+  }
+  if ((p.K % 4) || (p.N % 4) || (p.ldx % 4) || (p.ldy % 4) || p.K > 4096) return CX_ESHAPE;
+  if (p.prologue == CX_PRO_AFFINE2 && (!p.x2 || (p.ldx2 % 4))) return CX_EINVAL;
+  if (p.epilogue == CX_EPI_MASK && (!p.ex || (p.ldex % 4))) return CX_EINVAL;
+#define CX_F32_CASE(PRO, MODE, EPI) \
+  if (p.prologue == PRO && p.mode == MODE && p.epilogue == EPI) return launch_f32<PRO, MODE, EPI>(p, st);
+  CX_F32_CASE(CX_PRO_NONE, CX_MODE_CONV, CX_EPI_STORE)
+  CX_F32_CASE(CX_PRO_AFFINE_RELU, CX_MODE_CONV, CX_EPI_STORE)
+  CX_F32_CASE(CX_PRO_AFFINE2, CX_MODE_CONV, CX_EPI_STORE)
+  CX_F32_CASE(CX_PRO_AFFINE_RELU, CX_MODE_POOL2, CX_EPI_STORE)
+  CX_F32_CASE(CX_PRO_NONE, CX_MODE_CONV, CX_EPI_MASK)
+  CX_F32_CASE(CX_PRO_AFFINE2, CX_MODE_CONV, CX_EPI_MASK)
+#undef CX_F32_CASE
+  return CX_EUNSUPPORTED;
+}
+
+int cx_conv_wgrad_f32(const CxWgrad& pin, hipStream_t st) {
+  CxWgrad p = pin;
+  int dw_k = -1;
+  if (p.mode == CX_MODE_STEM) {            // dW of features.conv0: (64, 3, 7, 7) from the 4-channel image
+    if (p.ldx != 4) return CX_ESHAPE;
+    p.mode = CX_MODE_CONV; p.kh = p.kw = 7; p.stride = 2; p.pad = 3; p.K = 4;
+    dw_k = 3;
+  }
+  if (dw_k < 0) dw_k = p.K;
+  if ((p.K % 4) || (p.N % 4) || (p.ldx % 4) || (p.ldg % 4)) return CX_ESHAPE;
+  if (p.g_prologue == CX_PRO_AFFINE2 && (!p.g2 || (p.ldg2 % 4) || !p.ga || !p.gb || !p.gc)) return CX_EINVAL;
+  if (p.x_prologue == CX_PRO_AFFINE_RELU && (!p.pa || !p.pb)) return CX_EINVAL;
+#define CX_F32_WCASE(GP, XP, MODE) \
+  if (p.g_prologue == GP && p.x_prologue == XP && p.mode == MODE) return launch_wgrad_f32<GP, XP, MODE>(p, st, dw_k);
+  CX_F32_WCASE(CX_PRO_NONE, CX_PRO_NONE, CX_MODE_CONV)
+  CX_F32_WCASE(CX_PRO_AFFINE2, CX_PRO_NONE, CX_MODE_CONV)
+  CX_F32_WCASE(CX_PRO_NONE, CX_PRO_AFFINE_RELU, CX_MODE_CONV)
+  CX_F32_WCASE(CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU, CX_MODE_CONV)
+  CX_F32_WCASE(CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU, CX_MODE_POOL2)
+  CX_F32_WCASE(CX_PRO_NONE, CX_PRO_AFFINE_RELU, CX_MODE_POOL2)
+#undef CX_F32_WCASE
+  return CX_EUNSUPPORTED;
+}

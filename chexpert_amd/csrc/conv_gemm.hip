@@ -397,6 +397,7 @@ int cx_try_pw_dgrad(const CxConv& p, hipStream_t st, bool* handled);        // c
 int cx_try_pw_fwd(const CxConv& p, hipStream_t st, bool* handled);          // conv1x1_fwd.hip
 int cx_try_pw_fwdk(const CxConv& p, hipStream_t st, bool* handled);         // conv1x1_fwdk.hip
 int cx_try_stem_fwd(const CxConv& p, hipStream_t st, bool* handled);        // conv_stem.hip
+int cx_conv_gemm_f32(const CxConv& p, hipStream_t st);                      // conv_f32.hip
 
 thread_local int cx_tl_stat_rows = 0;
 extern "C" int cx_last_stat_rows(void) { return cx_tl_stat_rows; }
@@ -406,6 +407,30 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   const CxConv& p = *pp;
   if (!p.x || !p.w || !p.y) return CX_EINVAL;
   if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
+  if (p.dtype == CX_DT_F32) {             // fp32 storage mode: one generic kernel family (conv_f32.hip)
+    if (p.K <= 0 || p.N <= 0) return CX_ESHAPE;
+    if (!aligned16(p.x) || !aligned16(p.y) || !aligned16(p.w)) return CX_EALIGN;
+    if ((long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;
+    if (p.prologue != CX_PRO_NONE && (!p.pa || !p.pb)) return CX_EINVAL;
+    if (p.prologue == CX_PRO_AFFINE2 && (!p.x2 || !p.pc)) return CX_EINVAL;
+    if (p.epilogue == CX_EPI_MASK && (!p.ex || !p.e_sc || !p.e_sh || !p.e_mu || !p.e_r || !p.e_scale || !p.stat_sum || !p.stat_sq))
+      return CX_EINVAL;
+    if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return CX_EINVAL;
+    if (p.mode == CX_MODE_CONV) {
+      if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0 || p.ldx < p.K) return CX_ESHAPE;
+      if (p.tstride > 1) {
+        const int fpad = p.kh - 1 - p.pad;
+        if (p.stride != 1 || fpad < 0) return CX_ESHAPE;
+        if (p.H != (p.Ho + 2 * fpad - p.kh) / p.tstride + 1 || p.W != (p.Wo + 2 * fpad - p.kw) / p.tstride + 1) return CX_ESHAPE;
+      } else if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) {
+        return CX_ESHAPE;
+      }
+    } else if (p.mode == CX_MODE_POOL2) {
+      if ((p.H & 1) || (p.W & 1) || p.Ho != p.H / 2 || p.Wo != p.W / 2 || p.ldx < p.K) return CX_ESHAPE;
+    }
+    return cx_conv_gemm_f32(p, as_stream(stream));
+  }
+  if (p.dtype != CX_DT_BF16) return CX_EINVAL;
   if (p.K <= 0 || p.N <= 0 || (p.K % 8) || (p.N % 8)) return CX_ESHAPE;
   if (p.mode == CX_MODE_POOL2 && (p.K % 32)) return CX_ESHAPE;
   if (p.mode == CX_MODE_STEM ? (p.ldx != 4) : (p.ldx % 8 != 0)) return CX_EALIGN;

@@ -603,11 +603,25 @@ int launch_tile(const CxWgrad& p, hipStream_t st) {
 int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);    // conv3x3_ring.hip
 int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);   // conv3x3_strip.hip
 
+int cx_conv_wgrad_f32(const CxWgrad& p, hipStream_t st);                    // conv_f32.hip
+
 extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
   if (!pp) return CX_EINVAL;
   const CxWgrad& p = *pp;
   if (!p.g || !p.x || !p.dw) return CX_EINVAL;
   if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
+  if (p.dtype == CX_DT_F32) {             // fp32 storage mode (conv_f32.hip)
+    if (p.K <= 0 || p.N <= 0 || (long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;
+    if (!aligned16(p.g) || !aligned16(p.x)) return CX_EALIGN;
+    if (p.mode == CX_MODE_CONV) {
+      if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return CX_ESHAPE;
+      if (p.Ho != (p.H + 2 * p.pad - p.kh) / p.stride + 1 || p.Wo != (p.W + 2 * p.pad - p.kw) / p.stride + 1) return CX_ESHAPE;
+    } else if (p.mode == CX_MODE_POOL2) {
+      if ((p.H & 1) || (p.W & 1) || p.Ho != p.H / 2 || p.Wo != p.W / 2 || p.kh != 1 || p.kw != 1) return CX_ESHAPE;
+    }
+    return cx_conv_wgrad_f32(p, as_stream(stream));
+  }
+  if (p.dtype != CX_DT_BF16) return CX_EINVAL;
   if (p.K <= 0 || p.N <= 0 || (p.K % 8) || (p.N % 8)) return CX_ESHAPE;
   if ((long long)p.B * p.Ho * p.Wo >= (1ll << 31)) return CX_ESHAPE;
   if (p.mode == CX_MODE_STEM ? (p.ldx != 4) : (p.ldx % 8 != 0)) return CX_EALIGN;

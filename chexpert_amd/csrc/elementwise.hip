@@ -39,6 +39,40 @@ __device__ __forceinline__ void block_stats_flush(const float (&s1)[8], const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8-channel vector I/O of the element-wise kernels for both storage types (bf16: one 16-B access; fp32: two)
+template <typename T> struct V8;
+template <> struct V8<bf16> {
+  typedef uint4 raw;
+  static __device__ __forceinline__ raw ld(const bf16* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ float get(const raw& r, int j) { U128 u; u.u = r; return bf2f(u.e[j]); }
+  static __device__ __forceinline__ void st(bf16* p, const float (&v)[8]) {
+    U128 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(v[j]);
+    *reinterpret_cast<uint4*>(p) = o.u;
+  }
+  static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }      // the value as stored
+};
+template <> struct V8<float> {
+  struct raw { float4 a, b; };
+  static __device__ __forceinline__ raw ld(const float* p) {
+    raw r;
+    r.a = *reinterpret_cast<const float4*>(p);
+    r.b = *reinterpret_cast<const float4*>(p + 4);
+    return r;
+  }
+  static __device__ __forceinline__ float get(const raw& r, int j) {
+    const float v[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+    return v[j];
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+
+// ------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, bf16* __restrict__ out, int O, int I, int kh, int kw,
                                     int transpose, int stem) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,6 +133,43 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, bf16* __restr
   o.e[2] = f2bf(src[2 * hw]);
   o.e[3] = f2bf(0.f);
   *reinterpret_cast<uint2*>(y + idx * 4) = o.u;
+}
+
+__global__ void nchw3_to_nhwc4_f32_kernel(const float* __restrict__ x, float* __restrict__ y, size_t hw, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t b = idx / hw, p = idx - b * hw;
+  const float* src = x + b * 3 * hw + p;
+  *reinterpret_cast<float4*>(y + idx * 4) = make_float4(src[0], src[hw], src[2 * hw], 0.f);
+}
+
+__global__ void u8_to_nhwc4_f32_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, float scale, float shift, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const float g = fmaf((float)x[idx], scale, shift);
+  *reinterpret_cast<float4*>(y + idx * 4) = make_float4(g, g, g, 0.f);
+}
+
+// fp32 storage mode: the same table, fp32 output; descriptors with stem = 1 produce [49 taps][O][4] (the stem is a plain 7x7
+// convolution over the zero-padded 4-channel image there)
+__global__ void pack_table_f32_kernel(const float* __restrict__ flat, float* __restrict__ packed, const CxPackDesc* __restrict__ table) {
+  const CxPackDesc d = table[blockIdx.y];
+  const float* w = flat + d.src_off;
+  float* out = packed + d.dst_off;
+  const int O = d.O, I = d.I, taps = d.kh * d.kw;
+  const int Ip = d.stem ? 4 : I;
+  const size_t total = (size_t)taps * O * Ip;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    float v;
+    if (!d.transpose) {
+      const int i = idx % Ip, o = (idx / Ip) % O, tap = idx / ((size_t)Ip * O);
+      v = i < I ? w[((size_t)o * I + i) * taps + tap] : 0.f;
+    } else {
+      const int o = idx % O, i = (idx / O) % I, tp = idx / ((size_t)I * O);
+      v = w[((size_t)o * I + i) * taps + (taps - 1 - tp)];
+    }
+    out[idx] = v;
+  }
 }
 
 // uint8 grey image -> the three identical whitened channels of the reference transform chain, NHWC4 bf16, 16 pixels per thread
@@ -279,8 +350,9 @@ __global__ void bn_bwd_slice_coef_kernel(const float* A, const float* Bc, const 
 
 // ------------------------------------------------------------------------------------------------
 // stem: BN0 + ReLU + maxpool 3x3 s2 p1, arg-max recorded (uint8, window position 0..8)
-__global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ sc,
-                                                                 const float* __restrict__ sh, bf16* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ sc,
+                                                                 const float* __restrict__ sh, T* __restrict__ y,
                                                                  uint8_t* __restrict__ amax, float* g1, float* g2, int B,
                                                                  int H, int W, int C, int ldy, int det) {
   extern __shared__ float lds[];
@@ -306,34 +378,32 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const bf16* __r
     for (int t = 0; t < 9; ++t) {
       const int iy = 2 * oy - 1 + t / 3, ix = 2 * ox - 1 + t % 3;
       if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      U128 v;
-      v.u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
+      const typename V8<T>::raw v = V8<T>::ld(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float a = fmaxf(fmaf(bf2f(v.e[j]), fsc[j], fsh[j]), 0.f);
+        const float a = fmaxf(fmaf(V8<T>::get(v, j), fsc[j], fsh[j]), 0.f);
         if (a > best[j]) { best[j] = a; bi[j] = t; }
       }
     }
-    U128 o;
     uint8_t idx[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      o.e[j] = f2bf(best[j]);
-      const float rv = bf2f(o.e[j]);
+      const float rv = V8<T>::rnd(best[j]);
       s1[j] += rv;
       s2[j] += rv * rv;
       idx[j] = (uint8_t)bi[j];
     }
-    *reinterpret_cast<uint4*>(y + pix * ldy + cq * 8) = o.u;
+    V8<T>::st(y + pix * ldy + cq * 8, best);
     *reinterpret_cast<uint2*>(amax + pix * C + cq * 8) = *reinterpret_cast<const uint2*>(idx);
   }
   if (g1) block_stats_flush(s1, s2, cq, C, lds, g1, g2, det);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void bnrelu_maxpool_bwd_kernel(
-    const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
-    const float* __restrict__ rstd, const uint8_t* __restrict__ amax, const bf16* __restrict__ g, const bf16* __restrict__ gx,
-    const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc, bf16* __restrict__ dz, float* S1,
+    const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const uint8_t* __restrict__ amax, const T* __restrict__ g, const T* __restrict__ gx,
+    const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc, T* __restrict__ dz, float* S1,
     float* S2, int B, int H, int W, int C, int ldg, int ldgx, int det) {
   extern __shared__ float lds[];
   const int CP = C / 8;
@@ -363,7 +433,7 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_bwd_kernel(
     // (even coordinates) and windows past the edge are masked out afterwards.
     const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
     uint2 wi[4];
-    U128 wg[4], wx[4];
+    typename V8<T>::raw wg[4], wx[4];
     int wt[4];
     bool wok[4];
 #pragma unroll
@@ -374,34 +444,35 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_bwd_kernel(
       wt[k] = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
       const size_t op = ((size_t)b * Ho + oyc) * Wo + oxc;
       wi[k] = *reinterpret_cast<const uint2*>(amax + op * C + cq * 8);
-      wg[k].u = *reinterpret_cast<const uint4*>(g + op * ldg + cq * 8);
-      wx[k].u = *reinterpret_cast<const uint4*>(gx + op * ldgx + cq * 8);
+      wg[k] = V8<T>::ld(g + op * ldg + cq * 8);
+      wx[k] = V8<T>::ld(gx + op * ldgx + cq * 8);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint8_t* idx = reinterpret_cast<const uint8_t*>(&wi[k]);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (wok[k] && idx[j] == wt[k]) acc[j] += fmaf(bf2f(wg[k].e[j]), fa[j], fmaf(bf2f(wx[k].e[j]), fb[j], fc[j]));
+        if (wok[k] && idx[j] == wt[k]) acc[j] += fmaf(V8<T>::get(wg[k], j), fa[j], fmaf(V8<T>::get(wx[k], j), fb[j], fc[j]));
     }
-    U128 xin, o;
-    xin.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
+    const typename V8<T>::raw xin = V8<T>::ld(x + pix * C + cq * 8);
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xf = bf2f(xin.e[j]);
+      const float xf = V8<T>::get(xin, j);
       const float d = (fmaf(xf, fsc[j], fsh[j]) > 0.f) ? acc[j] : 0.f;
       s1[j] += d;
       s2[j] += d * (xf - fmu[j]) * fr[j];
-      o.e[j] = f2bf(d);
+      o[j] = d;
     }
-    *reinterpret_cast<uint4*>(dz + pix * C + cq * 8) = o.u;
+    V8<T>::st(dz + pix * C + cq * 8, o);
   }
   block_stats_flush(s1, s2, cq, C, lds, S1, S2, det);
 }
 
 // ------------------------------------------------------------------------------------------------
 // head
-__global__ void gap_bnrelu_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+template <typename T>
+__global__ void gap_bnrelu_kernel(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                                   float* __restrict__ pooled, int B, int HW, int C, int ldx) {
   const int CP = C / 8;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,10 +482,9 @@ __global__ void gap_bnrelu_kernel(const bf16* __restrict__ x, const float* __res
 #pragma unroll
   for (int j = 0; j < 8; ++j) { fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; acc[j] = 0.f; }
   for (int p = 0; p < HW; ++p) {
-    U128 v;
-    v.u = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * ldx + cq * 8);
+    const typename V8<T>::raw v = V8<T>::ld(x + ((size_t)b * HW + p) * ldx + cq * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf(bf2f(v.e[j]), fsc[j], fsh[j]), 0.f);
+    for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf(V8<T>::get(v, j), fsc[j], fsh[j]), 0.f);
   }
   const float inv = 1.f / HW;
 #pragma unroll
@@ -479,9 +549,10 @@ __global__ void head_bwd_kernel(const float* __restrict__ dlogits, const float* 
   }
 }
 
-__global__ void gap_relu_bn_bwd_kernel(const float* __restrict__ dpooled, const bf16* __restrict__ x, const float* __restrict__ sc,
+template <typename T>
+__global__ void gap_relu_bn_bwd_kernel(const float* __restrict__ dpooled, const T* __restrict__ x, const float* __restrict__ sc,
                                        const float* __restrict__ sh, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                       const float* __restrict__ escale, bf16* __restrict__ g, float* S1, float* S2, int B, int HW,
+                                       const float* __restrict__ escale, T* __restrict__ g, float* S1, float* S2, int B, int HW,
                                        int C, int ldx, int ldg, int det) {
   const int CP = C / 8;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,17 +568,17 @@ __global__ void gap_relu_bn_bwd_kernel(const float* __restrict__ dpooled, const 
     s1[j] = s2[j] = 0.f;
   }
   for (int p = 0; p < HW; ++p) {
-    U128 v, o;
-    v.u = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * ldx + cq * 8);
+    const typename V8<T>::raw v = V8<T>::ld(x + ((size_t)b * HW + p) * ldx + cq * 8);
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xf = bf2f(v.e[j]);
+      const float xf = V8<T>::get(v, j);
       const float d = (fmaf(xf, fsc[j], fsh[j]) > 0.f) ? dp[j] : 0.f;
       s1[j] += d;
       s2[j] += d * (xf - fmu[j]) * fr[j];
-      o.e[j] = f2bf(fe[j] * d);
+      o[j] = fe[j] * d;
     }
-    *reinterpret_cast<uint4*>(g + ((size_t)b * HW + p) * ldg + cq * 8) = o.u;
+    V8<T>::st(g + ((size_t)b * HW + p) * ldg + cq * 8, o);
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -522,10 +593,11 @@ __global__ void gap_relu_bn_bwd_kernel(const float* __restrict__ dpooled, const 
 }
 
 // transition backward glue: un-pool + ReLU/BN mask
-__global__ __launch_bounds__(256) void unpool2_mask_kernel(const bf16* __restrict__ d, const bf16* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void unpool2_mask_kernel(const T* __restrict__ d, const T* __restrict__ x,
                                                            const float* __restrict__ sc, const float* __restrict__ sh,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ escale, bf16* __restrict__ g, float* S1,
+                                                           const float* __restrict__ escale, T* __restrict__ g, float* S1,
                                                            float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg, int det) {
   extern __shared__ float lds[];
   const int CP = C / 8;
@@ -547,18 +619,18 @@ __global__ __launch_bounds__(256) void unpool2_mask_kernel(const bf16* __restric
     const int rem = pix - (size_t)b * H * W;
     const int iy = rem / W, ix = rem - iy * W;
     const size_t op = ((size_t)b * Ho + (iy >> 1)) * Wo + (ix >> 1);
-    U128 dv, xv, o;
-    dv.u = *reinterpret_cast<const uint4*>(d + op * ldd + cq * 8);
-    xv.u = *reinterpret_cast<const uint4*>(x + pix * ldx + cq * 8);
+    const typename V8<T>::raw dv = V8<T>::ld(d + op * ldd + cq * 8);
+    const typename V8<T>::raw xv = V8<T>::ld(x + pix * ldx + cq * 8);
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xf = bf2f(xv.e[j]);
-      const float dzv = (fmaf(xf, fsc[j], fsh[j]) > 0.f) ? 0.25f * bf2f(dv.e[j]) : 0.f;
+      const float xf = V8<T>::get(xv, j);
+      const float dzv = (fmaf(xf, fsc[j], fsh[j]) > 0.f) ? 0.25f * V8<T>::get(dv, j) : 0.f;
       s1[j] += dzv;
       s2[j] += dzv * (xf - fmu[j]) * fr[j];
-      o.e[j] = f2bf(fe[j] * dzv);
+      o[j] = fe[j] * dzv;
     }
-    *reinterpret_cast<uint4*>(g + pix * ldg + cq * 8) = o.u;
+    V8<T>::st(g + pix * ldg + cq * 8, o);
   }
   block_stats_flush(s1, s2, cq, C, lds, S1, S2, det);
 }
@@ -842,6 +914,79 @@ inline int grid_for(size_t n, int block, int cap = 4096) {
   return (int)g;
 }
 
+template <typename T>
+int bnrelu_maxpool_fwd_t(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax, float* stat_sum,
+                          float* stat_sq, int B, int H, int W, int C, int ldy, int stat_rows, void* stream) {
+  if (!x || !scale || !shift || !y || !argmax) return CX_EINVAL;
+  if (C % 8 || C > 256 || 256 % (C / 8) || (H & 1) || (W & 1) || (ldy % 8)) return CX_ESHAPE;
+  const size_t npix = (size_t)B * (H / 2) * (W / 2);
+  const int ppb = 256 / (C / 8);
+  int grid = grid_for(npix, ppb, 2048);
+  if (stat_rows > 0 && stat_sum) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  hipLaunchKernelGGL((bnrelu_maxpool_fwd_kernel<T>), dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
+                     (const T*)x, scale, shift, (T*)y, argmax, stat_sum, stat_sq, B, H, W, C, ldy, stat_rows > 0 ? 1 : 0);
+  return launch_status();
+}
+
+template <typename T>
+int bnrelu_maxpool_bwd_t(const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                          const uint8_t* argmax, const void* g, const void* gx, const float* ga, const float* gb, const float* gc,
+                          void* dz, float* S1, float* S2, int B, int H, int W, int C, int ldg, int ldgx, int stat_rows, void* stream) {
+  if (!x || !scale || !shift || !mean || !rstd || !argmax || !g || !gx || !ga || !gb || !gc || !dz || !S1 || !S2) return CX_EINVAL;
+  if (C % 8 || C > 256 || 256 % (C / 8) || (H & 1) || (W & 1) || (ldg % 8) || (ldgx % 8)) return CX_ESHAPE;
+  const size_t npix = (size_t)B * H * W;
+  const int ppb = 256 / (C / 8);
+  int grid = grid_for(npix, ppb, 2048);
+  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  hipLaunchKernelGGL((bnrelu_maxpool_bwd_kernel<T>), dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
+                     (const T*)x, scale, shift, mean, rstd, argmax, (const T*)g, (const T*)gx, ga, gb, gc, (T*)dz, S1,
+                     S2, B, H, W, C, ldg, ldgx, stat_rows > 0 ? 1 : 0);
+  return launch_status();
+}
+
+template <typename T>
+int head_fwd_t(const void* x, const float* scale, const float* shift, const float* w, const float* bias, float* pooled,
+                float* logits, int B, int HW, int C, int ldx, int n_classes, void* stream) {
+  if (!x || !scale || !shift || !w || !pooled || !logits) return CX_EINVAL;
+  if (C % 8 || ldx % 8 || n_classes <= 0) return CX_ESHAPE;
+  const size_t n = (size_t)B * (C / 8);
+  hipLaunchKernelGGL((gap_bnrelu_kernel<T>), dim3((n + 127) / 128), dim3(128), 0, as_stream(stream), (const T*)x, scale, shift, pooled,
+                     B, HW, C, ldx);
+  hipLaunchKernelGGL(linear_kernel, dim3(B), dim3(256), 0, as_stream(stream), pooled, w, bias, logits, C, n_classes);
+  return launch_status();
+}
+
+template <typename T>
+int gap_relu_bn_bwd_t(const float* dpooled, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int HW, int C, int ldx,
+                       int ldg, int stat_rows, void* stream) {
+  if (!dpooled || !x || !scale || !shift || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
+  if (C % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
+  const size_t n = (size_t)B * (C / 8);
+  if (stat_rows > 0) { if (stat_rows < B) return CX_ESTATROWS; cx_tl_stat_rows = B; }
+  hipLaunchKernelGGL((gap_relu_bn_bwd_kernel<T>), dim3((n + 127) / 128), dim3(128), 0, as_stream(stream), dpooled, (const T*)x, scale,
+                     shift, mean, rstd, e_scale, (T*)g, S1, S2, B, HW, C, ldx, ldg, stat_rows > 0 ? 1 : 0);
+  return launch_status();
+}
+
+template <typename T>
+int unpool2_mask_t(const void* d, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd,
+                    const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg,
+                    int stat_rows, void* stream) {
+  if (!d || !x || !sc || !sh || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
+  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || (H & 1) || (W & 1) || ldd % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
+  if (C / 8 > 256) return CX_ESHAPE;
+  const size_t npix = (size_t)B * H * W;
+  const int ppb = 256 / (C / 8);
+  int grid = grid_for(npix, ppb, 2048);
+  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  hipLaunchKernelGGL((unpool2_mask_kernel<T>), dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
+                     (const T*)d, (const T*)x, sc, sh, mean, rstd, e_scale, (T*)g, S1, S2, B, H, W, C, ldd, ldx, ldg,
+                     stat_rows > 0 ? 1 : 0);
+  return launch_status();
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -879,6 +1024,26 @@ int cx_nchw3_to_nhwc4(const float* x, void* y, int B, int H, int W, void* stream
   if (!x || !y || B <= 0 || H <= 0 || W <= 0) return CX_EINVAL;
   const size_t hw = (size_t)H * W, total = hw * B;
   hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y, hw, total);
+  return launch_status();
+}
+
+int cx_pack_weights_table_f32(const float* flat, float* packed, const CxPackDesc* table_dev, int n_desc, void* stream) {
+  if (!flat || !packed || !table_dev || n_desc <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(pack_table_f32_kernel, dim3(16, n_desc), dim3(256), 0, as_stream(stream), flat, packed, table_dev);
+  return launch_status();
+}
+
+int cx_nchw3_to_nhwc4_f32(const float* x, float* y, int B, int H, int W, void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0) return CX_EINVAL;
+  const size_t hw = (size_t)H * W, total = hw * B;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), x, y, hw, total);
+  return launch_status();
+}
+
+int cx_u8_to_nhwc4_f32(const uint8_t* x, float* y, size_t npix, float mean, float std, void* stream) {
+  if (!x || !y || std <= 0.f) return CX_EINVAL;
+  hipLaunchKernelGGL(u8_to_nhwc4_f32_kernel, dim3((npix + 255) / 256), dim3(256), 0, as_stream(stream), x, y, 1.f / (255.f * std),
+                     -mean / std, npix);
   return launch_status();
 }
 
@@ -941,43 +1106,25 @@ int cx_bn_bwd_slice_coef(const float* A, const float* Bc, const float* mean, con
   return launch_status();
 }
 
-int cx_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax, float* stat_sum,
-                          float* stat_sq, int B, int H, int W, int C, int ldy, int stat_rows, void* stream) {
-  if (!x || !scale || !shift || !y || !argmax) return CX_EINVAL;
-  if (C % 8 || C > 256 || 256 % (C / 8) || (H & 1) || (W & 1) || (ldy % 8)) return CX_ESHAPE;
-  const size_t npix = (size_t)B * (H / 2) * (W / 2);
-  const int ppb = 256 / (C / 8);
-  int grid = grid_for(npix, ppb, 2048);
-  if (stat_rows > 0 && stat_sum) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
-  hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel, dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
-                     (const bf16*)x, scale, shift, (bf16*)y, argmax, stat_sum, stat_sq, B, H, W, C, ldy, stat_rows > 0 ? 1 : 0);
-  return launch_status();
+int cx_bnrelu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax, float* stat_sum, float* stat_sq, int B, int H, int W, int C, int ldy, int stat_rows, void* stream) {
+  return bnrelu_maxpool_fwd_t<bf16>(x, scale, shift, y, argmax, stat_sum, stat_sq, B, H, W, C, ldy, stat_rows, stream);
+}
+int cx_bnrelu_maxpool_fwd_f32(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax, float* stat_sum, float* stat_sq, int B, int H, int W, int C, int ldy, int stat_rows, void* stream) {
+  return bnrelu_maxpool_fwd_t<float>(x, scale, shift, y, argmax, stat_sum, stat_sq, B, H, W, C, ldy, stat_rows, stream);
 }
 
-int cx_bnrelu_maxpool_bwd(const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
-                          const uint8_t* argmax, const void* g, const void* gx, const float* ga, const float* gb, const float* gc,
-                          void* dz, float* S1, float* S2, int B, int H, int W, int C, int ldg, int ldgx, int stat_rows, void* stream) {
-  if (!x || !scale || !shift || !mean || !rstd || !argmax || !g || !gx || !ga || !gb || !gc || !dz || !S1 || !S2) return CX_EINVAL;
-  if (C % 8 || C > 256 || 256 % (C / 8) || (H & 1) || (W & 1) || (ldg % 8) || (ldgx % 8)) return CX_ESHAPE;
-  const size_t npix = (size_t)B * H * W;
-  const int ppb = 256 / (C / 8);
-  int grid = grid_for(npix, ppb, 2048);
-  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
-  hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel, dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
-                     (const bf16*)x, scale, shift, mean, rstd, argmax, (const bf16*)g, (const bf16*)gx, ga, gb, gc, (bf16*)dz, S1,
-                     S2, B, H, W, C, ldg, ldgx, stat_rows > 0 ? 1 : 0);
-  return launch_status();
+int cx_bnrelu_maxpool_bwd(const void* x, const float* scale, const float* shift, const float* mean, const float* rstd, const uint8_t* argmax, const void* g, const void* gx, const float* ga, const float* gb, const float* gc, void* dz, float* S1, float* S2, int B, int H, int W, int C, int ldg, int ldgx, int stat_rows, void* stream) {
+  return bnrelu_maxpool_bwd_t<bf16>(x, scale, shift, mean, rstd, argmax, g, gx, ga, gb, gc, dz, S1, S2, B, H, W, C, ldg, ldgx, stat_rows, stream);
+}
+int cx_bnrelu_maxpool_bwd_f32(const void* x, const float* scale, const float* shift, const float* mean, const float* rstd, const uint8_t* argmax, const void* g, const void* gx, const float* ga, const float* gb, const float* gc, void* dz, float* S1, float* S2, int B, int H, int W, int C, int ldg, int ldgx, int stat_rows, void* stream) {
+  return bnrelu_maxpool_bwd_t<float>(x, scale, shift, mean, rstd, argmax, g, gx, ga, gb, gc, dz, S1, S2, B, H, W, C, ldg, ldgx, stat_rows, stream);
 }
 
-int cx_head_fwd(const void* x, const float* scale, const float* shift, const float* w, const float* bias, float* pooled,
-                float* logits, int B, int HW, int C, int ldx, int n_classes, void* stream) {
-  if (!x || !scale || !shift || !w || !pooled || !logits) return CX_EINVAL;
-  if (C % 8 || ldx % 8 || n_classes <= 0) return CX_ESHAPE;
-  const size_t n = (size_t)B * (C / 8);
-  hipLaunchKernelGGL(gap_bnrelu_kernel, dim3((n + 127) / 128), dim3(128), 0, as_stream(stream), (const bf16*)x, scale, shift, pooled,
-                     B, HW, C, ldx);
-  hipLaunchKernelGGL(linear_kernel, dim3(B), dim3(256), 0, as_stream(stream), pooled, w, bias, logits, C, n_classes);
-  return launch_status();
+int cx_head_fwd(const void* x, const float* scale, const float* shift, const float* w, const float* bias, float* pooled, float* logits, int B, int HW, int C, int ldx, int n_classes, void* stream) {
+  return head_fwd_t<bf16>(x, scale, shift, w, bias, pooled, logits, B, HW, C, ldx, n_classes, stream);
+}
+int cx_head_fwd_f32(const void* x, const float* scale, const float* shift, const float* w, const float* bias, float* pooled, float* logits, int B, int HW, int C, int ldx, int n_classes, void* stream) {
+  return head_fwd_t<float>(x, scale, shift, w, bias, pooled, logits, B, HW, C, ldx, n_classes, stream);
 }
 
 int cx_bce_fwd_bwd(const float* logits, const float* target, float* loss, float* loss_elem, float* dlogits, float grad_scale,
@@ -997,32 +1144,18 @@ int cx_head_bwd(const float* dlogits, const float* pooled, const float* w, float
   return launch_status();
 }
 
-int cx_gap_relu_bn_bwd(const float* dpooled, const void* x, const float* scale, const float* shift, const float* mean,
-                       const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int HW, int C, int ldx,
-                       int ldg, int stat_rows, void* stream) {
-  if (!dpooled || !x || !scale || !shift || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
-  if (C % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
-  const size_t n = (size_t)B * (C / 8);
-  if (stat_rows > 0) { if (stat_rows < B) return CX_ESTATROWS; cx_tl_stat_rows = B; }
-  hipLaunchKernelGGL(gap_relu_bn_bwd_kernel, dim3((n + 127) / 128), dim3(128), 0, as_stream(stream), dpooled, (const bf16*)x, scale,
-                     shift, mean, rstd, e_scale, (bf16*)g, S1, S2, B, HW, C, ldx, ldg, stat_rows > 0 ? 1 : 0);
-  return launch_status();
+int cx_gap_relu_bn_bwd(const float* dpooled, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int HW, int C, int ldx, int ldg, int stat_rows, void* stream) {
+  return gap_relu_bn_bwd_t<bf16>(dpooled, x, scale, shift, mean, rstd, e_scale, g, S1, S2, B, HW, C, ldx, ldg, stat_rows, stream);
+}
+int cx_gap_relu_bn_bwd_f32(const float* dpooled, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int HW, int C, int ldx, int ldg, int stat_rows, void* stream) {
+  return gap_relu_bn_bwd_t<float>(dpooled, x, scale, shift, mean, rstd, e_scale, g, S1, S2, B, HW, C, ldx, ldg, stat_rows, stream);
 }
 
-int cx_unpool2_mask(const void* d, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd,
-                    const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg,
-                    int stat_rows, void* stream) {
-  if (!d || !x || !sc || !sh || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
-  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || (H & 1) || (W & 1) || ldd % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
-  if (C / 8 > 256) return CX_ESHAPE;
-  const size_t npix = (size_t)B * H * W;
-  const int ppb = 256 / (C / 8);
-  int grid = grid_for(npix, ppb, 2048);
-  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
-  hipLaunchKernelGGL(unpool2_mask_kernel, dim3(grid), dim3(256), 256 * 16 * sizeof(float), as_stream(stream),
-                     (const bf16*)d, (const bf16*)x, sc, sh, mean, rstd, e_scale, (bf16*)g, S1, S2, B, H, W, C, ldd, ldx, ldg,
-                     stat_rows > 0 ? 1 : 0);
-  return launch_status();
+int cx_unpool2_mask(const void* d, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg, int stat_rows, void* stream) {
+  return unpool2_mask_t<bf16>(d, x, sc, sh, mean, rstd, e_scale, g, S1, S2, B, H, W, C, ldd, ldx, ldg, stat_rows, stream);
+}
+int cx_unpool2_mask_f32(const void* d, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg, int stat_rows, void* stream) {
+  return unpool2_mask_t<float>(d, x, sc, sh, mean, rstd, e_scale, g, S1, S2, B, H, W, C, ldd, ldx, ldg, stat_rows, stream);
 }
 
 int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb, const float* pc, size_t rows, int C, void* stream) {

@@ -151,7 +151,7 @@ class _Workspace:
     """Activation buffers + coefficient vectors for one (B,H,W); owned by one in-flight forward."""
 
     def __init__(self, eng, B, H, W, dev):
-        bf, u8 = torch.bfloat16, torch.uint8
+        bf, u8 = eng.dtype, torch.uint8         # activation storage type: bf16, or fp32 in the parity mode
         self.key = (B, H, W)
         self.B, self.H, self.W = B, H, W
         g = eng.growth
@@ -207,7 +207,7 @@ class _Workspace:
     def alloc_backward(self, eng, dev):
         if self.dz0 is not None:
             return
-        bf = torch.bfloat16
+        bf = eng.dtype
         B = self.B
         self.dz0 = torch.empty_like(self.c0)
         self.gbuf = [torch.empty_like(b) for b in self.buf]
@@ -228,7 +228,7 @@ class _Workspace:
 class _Engine:
     """Host-side schedule: binds the module's parameters to flat buffers, packs weights, and issues the
     kernel sequence of forward and backward on the current stream."""
-    SLAB = 1 << 21               # floats per half of the statistic-row scratch (rows x channels of the largest producer)
+    SLAB = 1 << 22               # floats per half of the statistic-row scratch (rows x channels of the largest producer)
     EW_ROWS = 2048               # workgroups (= rows) of the element-wise statistic producers in deterministic mode
 
     # statistics plumbing: producer kwargs / consumer (sum, sq, replicas, rstride) for the two modes
@@ -266,12 +266,15 @@ class _Engine:
         self.pool = {}
         self.reducer = None          # chexpert_amd.parallel.GradReducer when data-parallel
         self.side = None             # side stream for the weight-gradient kernels of the dense layers
+        self.dtype = getattr(model, "_storage_dtype", torch.bfloat16)
         self.stat_replicas = 16      # legacy (atomic) statistics: copies of every conv-produced vector (memory-side contention)
         # Deterministic statistics: per-workgroup rows summed in a fixed order instead of fp32 atomics (bit-identical activations,
         # losses and input gradients from run to run).  The AA transitions feed a block's first channels from two different
         # kernels (conv branch + attention out-projection) and stay on the atomic path; CHEXPERT_DET=0 forces it everywhere.
         has_aa = any(isinstance(getattr(f, "transition%d" % (i + 1)).conv, AAConv2d) for i in range(len(model.block_config) - 1))
         self.det = (not has_aa) and os.environ.get("CHEXPERT_DET", "1") != "0"
+        if has_aa and self.dtype != torch.bfloat16:
+            raise NotImplementedError("the fp32 storage mode covers the plain DenseNet path (the attention kernels are bf16)")
         self._plan_vectors()
 
     # ---- coefficient-vector layout
@@ -344,7 +347,8 @@ class _Engine:
         def add(conv, transpose=False, stem=False):
             nonlocal cur
             O, I, kh, kw = conv.weight.shape
-            n = 7 * O * 32 if stem else O * I * kh * kw
+            f32 = self.dtype == torch.float32
+            n = (49 * O * 4 if f32 else 7 * O * 32) if stem else O * I * kh * kw
             d = CxPackDesc(self.off_of[id(conv.weight)], cur, O, I, kh, kw, int(transpose), int(stem))
             descs.append(d)
             off = cur
@@ -356,7 +360,7 @@ class _Engine:
             if isinstance(mod, nn.Conv2d) and mod is not f.conv0:
                 self.wf[id(mod)] = add(mod)
                 self.wb[id(mod)] = add(mod, transpose=True)
-        self.packed = torch.empty(cur, dtype=torch.bfloat16, device=dev)
+        self.packed = torch.empty(cur, dtype=self.dtype, device=dev)
         arr = (CxPackDesc * len(descs))(*descs)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.desc_dev = host.to(dev)
@@ -369,8 +373,7 @@ class _Engine:
         ver = None if train else sum(p._version for p in self.params)
         if ver is not None and ver == self.packed_version:
             return
-        check(lib().cx_pack_weights_table(ptr(self.flat), ptr(self.packed), ptr(self.desc_dev), self.n_desc, stream_ptr()),
-              "cx_pack_weights_table")
+        ops.pack_weights_table(self.flat, self.packed, self.desc_dev, self.n_desc)
         self.packed_version = ver
 
     def w_fwd(self, conv):
@@ -649,7 +652,7 @@ class _Engine:
                 # input gradient + weight gradient of conv1 in one pass over dz2 / y1 / the buffer slice (conv1x1_bwd.hip);
                 # (6-37 % less kernel time than the two separate kernels; whole step 37.6 vs 39.0 ms);
                 # CHEXPERT_1X1_BWD=split keeps them, with the weight gradient on the side stream
-                fused = os.environ.get("CHEXPERT_1X1_BWD", "fused") != "split"
+                fused = os.environ.get("CHEXPERT_1X1_BWD", "fused") != "split" and self.dtype == torch.bfloat16
                 rows = ops.conv_gemm(dz2, self.w_bwd(layer.conv1), gbuf[..., :cin], N=cin, prologue=ops.PRO_AFFINE2, x2=y1, pa=pa,
                                      pb=pb, pc=pc, epilogue=ops.EPI_MASK, ex=buf[..., :cin], e_sc=v(n1[0]), e_sh=v(n1[1]),
                                      e_mu=v(bmean)[:cin], e_r=v(brstd)[:cin], e_scale=v(n1[0]), accumulate=True,
@@ -798,9 +801,20 @@ class DenseNet(nn.Module):
 
     # the engine is rebuilt lazily (the classifier may be replaced after construction, chexpert.py:464)
     def _eng(self):
-        if self._engine is None or self._engine.c_final != self.classifier.in_features:
+        if self._engine is None or self._engine.c_final != self.classifier.in_features or \
+                self._engine.dtype != getattr(self, "_storage_dtype", torch.bfloat16):
             object.__setattr__(self, "_engine", _Engine(self))
         return self._engine
+
+    def storage_dtype(self, dtype):
+        """Storage type of the activations inside the fused schedule: torch.bfloat16 (default: bf16 tensors, fp32 accumulation
+        and statistics) or torch.float32 -- the parity mode of north_star ("1e-3 fp32"): the same schedule on fp32 tensors with
+        the exact f32 MFMA (csrc/conv_f32.hip).  Parameters are fp32 masters either way.  Returns self."""
+        dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(dtype, dtype)
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("storage dtype must be bf16 or fp32")
+        object.__setattr__(self, "_storage_dtype", dtype)
+        return self
 
     def _flush_nbt(self):
         if self._nbt_pending:

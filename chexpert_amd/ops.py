@@ -12,8 +12,8 @@ import ctypes as C
 
 
 def _nhwc(t):
-    """(B,H,W,C) view -> (B,H,W,C,pitch)."""
-    assert t.dtype == torch.bfloat16 and t.dim() == 4, "expected a bf16 NHWC tensor"
+    """(B,H,W,C) view -> (B,H,W,C,pitch).  bf16 is the fast path; fp32 tensors select the fp32 storage mode (CX_DT_F32)."""
+    assert t.dtype in (torch.bfloat16, torch.float32) and t.dim() == 4, "expected a bf16 (or fp32-mode) NHWC tensor"
     B, H, W, Cc = t.shape
     sb, sh, sw, sc = t.stride()
     assert sc == 1 and sh == W * sw and sb == H * sh, "NHWC slice must be dense in (B,H,W) with a channel pitch"
@@ -28,6 +28,7 @@ def conv_gemm(x, w_packed, y, *, fused_dw=None, **kw):
         check(lib().cx_conv_gemm(C.byref(p), stream_ptr()), "cx_conv_gemm")
     else:
         require_cuda(fused_dw)
+        assert x.dtype == torch.bfloat16, "the fused 1x1 input + weight gradient is a bf16 kernel"
         assert fused_dw.dtype == torch.float32 and fused_dw.is_contiguous()
         check(lib().cx_conv1x1_dgrad_wgrad(C.byref(p), ptr(fused_dw), stream_ptr()), "cx_conv1x1_dgrad_wgrad")
     return lib().cx_last_stat_rows() if p.stat_det else None      # stat_det: rows the consumer has to sum
@@ -60,6 +61,9 @@ def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CO
         p.x2, p.ldx2 = ptr(x2), _nhwc(x2)[4]
     p.stat_sum, p.stat_sq = ptr(stat_sum), ptr(stat_sq)
     p.stat_replicas, p.stat_rstride, p.stat_det = stat_replicas, stat_rstride, int(bool(stat_det))
+    p.dtype = 1 if x.dtype == torch.float32 else 0
+    for t_ in (w_packed, y, x2, ex):
+        assert t_ is None or t_.dtype == x.dtype, "all tensors of one convolution share the storage type"
     if ex is not None:
         assert ex.shape == y.shape
         p.ex, p.ldex = ptr(ex), _nhwc(ex)[4]
@@ -86,6 +90,8 @@ def conv_wgrad(g, x, dw, *, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, g_prolo
     p.ga, p.gb, p.gc, p.pa, p.pb = ptr(ga), ptr(gb), ptr(gc), ptr(pa), ptr(pb)
     p.kh, p.kw, p.stride, p.pad = kh, kw, stride, pad
     p.g_prologue, p.x_prologue, p.mode, p.splits = g_prologue, x_prologue, mode, splits
+    p.dtype = 1 if g.dtype == torch.float32 else 0
+    assert x.dtype == g.dtype and (g2 is None or g2.dtype == g.dtype)
     check(lib().cx_conv_wgrad(C.byref(p), stream_ptr()), "cx_conv_wgrad")
 
 
@@ -101,6 +107,18 @@ def pack_weights(w, transpose=False, stem=False, out=None):
     return out
 
 
+def _fn(name, t):
+    """C entry point for the storage type of tensor t (bf16 or the fp32 mode)."""
+    return getattr(lib(), name + "_f32" if t.dtype == torch.float32 else name)
+
+
+def pack_weights_table(flat, packed, desc_dev, n_desc):
+    if packed.dtype == torch.float32:
+        check(lib().cx_pack_weights_table_f32(ptr(flat), ptr(packed), ptr(desc_dev), n_desc, stream_ptr()), "cx_pack_weights_table_f32")
+    else:
+        check(lib().cx_pack_weights_table(ptr(flat), ptr(packed), ptr(desc_dev), n_desc, stream_ptr()), "cx_pack_weights_table")
+
+
 def u8_to_nhwc4(x, out=None, mean=0.5330, std=0.0349):
     """uint8 grey images (B,1,H,W) or (B,H,W) -> whitened, channel-expanded (B,H,W,4) bf16 (chexpert.py:70-72 on the GPU)."""
     require_cuda(x)
@@ -112,7 +130,7 @@ def u8_to_nhwc4(x, out=None, mean=0.5330, std=0.0349):
         B, H, W = x.shape
     if out is None:
         out = torch.empty(B, H, W, 4, dtype=torch.bfloat16, device=x.device)
-    check(lib().cx_u8_to_nhwc4(ptr(x), ptr(out), B * H * W, mean, std, stream_ptr()), "cx_u8_to_nhwc4")
+    check(_fn("cx_u8_to_nhwc4", out)(ptr(x), ptr(out), B * H * W, mean, std, stream_ptr()), "cx_u8_to_nhwc4")
     return out
 
 
@@ -122,7 +140,7 @@ def nchw3_to_nhwc4(x, out=None):
     assert Cc == 3 and x.dtype == torch.float32 and x.is_contiguous()
     if out is None:
         out = torch.empty(B, H, W, 4, dtype=torch.bfloat16, device=x.device)
-    check(lib().cx_nchw3_to_nhwc4(ptr(x), ptr(out), B, H, W, stream_ptr()), "cx_nchw3_to_nhwc4")
+    check(_fn("cx_nchw3_to_nhwc4", out)(ptr(x), ptr(out), B, H, W, stream_ptr()), "cx_nchw3_to_nhwc4")
     return out
 
 
@@ -160,7 +178,7 @@ def bnrelu_maxpool_fwd(x, scale, shift, y, argmax, stat_sum, stat_sq, stat_rows=
     B, H, W, Cc, ldx = _nhwc(x)
     assert ldx == Cc
     ldy = _nhwc(y)[4]
-    check(lib().cx_bnrelu_maxpool_fwd(ptr(x), ptr(scale), ptr(shift), ptr(y), ptr(argmax), ptr(stat_sum), ptr(stat_sq),
+    check(_fn("cx_bnrelu_maxpool_fwd", x)(ptr(x), ptr(scale), ptr(shift), ptr(y), ptr(argmax), ptr(stat_sum), ptr(stat_sq),
                                       B, H, W, Cc, ldy, stat_rows, stream_ptr()), "cx_bnrelu_maxpool_fwd")
     return lib().cx_last_stat_rows() if stat_rows else None
 
@@ -168,7 +186,7 @@ def bnrelu_maxpool_fwd(x, scale, shift, y, argmax, stat_sum, stat_sq, stat_rows=
 def bnrelu_maxpool_bwd(x, scale, shift, mean, rstd, argmax, g, gx, ga, gb, gc, dz, S1, S2, stat_rows=0):
     B, H, W, Cc, ldx = _nhwc(x)
     assert ldx == Cc and _nhwc(dz)[4] == Cc
-    check(lib().cx_bnrelu_maxpool_bwd(ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(argmax), ptr(g), ptr(gx),
+    check(_fn("cx_bnrelu_maxpool_bwd", x)(ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(argmax), ptr(g), ptr(gx),
                                       ptr(ga), ptr(gb), ptr(gc), ptr(dz), ptr(S1), ptr(S2), B, H, W, Cc, _nhwc(g)[4],
                                       _nhwc(gx)[4], stat_rows, stream_ptr()), "cx_bnrelu_maxpool_bwd")
     return lib().cx_last_stat_rows() if stat_rows else None
@@ -176,7 +194,7 @@ def bnrelu_maxpool_bwd(x, scale, shift, mean, rstd, argmax, g, gx, ga, gb, gc, d
 
 def head_fwd(x, scale, shift, w, bias, pooled, logits):
     B, H, W, Cc, ldx = _nhwc(x)
-    check(lib().cx_head_fwd(ptr(x), ptr(scale), ptr(shift), ptr(w), ptr(bias), ptr(pooled), ptr(logits), B, H * W, Cc, ldx,
+    check(_fn("cx_head_fwd", x)(ptr(x), ptr(scale), ptr(shift), ptr(w), ptr(bias), ptr(pooled), ptr(logits), B, H * W, Cc, ldx,
                             logits.shape[1], stream_ptr()), "cx_head_fwd")
 
 
@@ -194,14 +212,14 @@ def head_bwd(dlogits, pooled, w, dw, db, dpooled):
 
 def gap_relu_bn_bwd(dpooled, x, scale, shift, mean, rstd, e_scale, g, S1, S2, stat_rows=0):
     B, H, W, Cc, ldx = _nhwc(x)
-    check(lib().cx_gap_relu_bn_bwd(ptr(dpooled), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(e_scale), ptr(g),
+    check(_fn("cx_gap_relu_bn_bwd", x)(ptr(dpooled), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(e_scale), ptr(g),
                                    ptr(S1), ptr(S2), B, H * W, Cc, ldx, _nhwc(g)[4], stat_rows, stream_ptr()), "cx_gap_relu_bn_bwd")
     return lib().cx_last_stat_rows() if stat_rows else None
 
 
 def unpool2_mask(d, x, sc, sh, mean, rstd, e_scale, g, S1, S2, stat_rows=0):
     B, H, W, Cc, ldx = _nhwc(x)
-    check(lib().cx_unpool2_mask(ptr(d), ptr(x), ptr(sc), ptr(sh), ptr(mean), ptr(rstd), ptr(e_scale), ptr(g), ptr(S1), ptr(S2),
+    check(_fn("cx_unpool2_mask", x)(ptr(d), ptr(x), ptr(sc), ptr(sh), ptr(mean), ptr(rstd), ptr(e_scale), ptr(g), ptr(S1), ptr(S2),
                                 B, H, W, Cc, _nhwc(d)[4], ldx, _nhwc(g)[4], stat_rows, stream_ptr()), "cx_unpool2_mask")
     return lib().cx_last_stat_rows() if stat_rows else None
 

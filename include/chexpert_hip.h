@@ -31,6 +31,10 @@ extern "C" {
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4, CX_ESTATROWS = -5 };
 
+/* storage type of the activation tensors of a CxConv / CxWgrad: bf16 (the fast path: fp32 accumulation, fp32 statistics) or
+ * fp32 (the parity mode of north_star "1e-3 fp32": same schedule, exact f32 MFMA, fp32 packed weights [tap][N][K])        */
+enum { CX_DT_BF16 = 0, CX_DT_F32 = 1 };
+
 /* A-operand prologues of the implicit GEMM (fused normalisation, never stored) */
 enum {
   CX_PRO_NONE = 0,         /* a = x                                                              */
@@ -77,6 +81,7 @@ typedef struct CxConv {
                          /* caller's capacity) or CX_ESTATROWS; cx_last_stat_rows() then returns `rows` and the   */
                          /* consumer sums exactly those rows in row order (cx_bn_coef / cx_bn_bwd_coef with      */
                          /* replicas = rows): bit-identical results from run to run.  No zero-fill is needed      */
+  int32_t dtype;         /* CX_DT_BF16 (0) or CX_DT_F32: x, x2, y, ex are fp32, w is fp32 [tap][N][K]; K, N, ld* % 4 */
 } CxConv;
 
 /* Weight gradient of the same convolution:  dW[n][c][ky][kx] += sum_m G[m][n] * A[m@tap][c]
@@ -93,6 +98,7 @@ typedef struct CxWgrad {
   int32_t kh, kw, stride, pad;
   int32_t g_prologue, x_prologue, mode;
   int32_t splits;                          /* pixel-range splits (0 = library picks)                */
+  int32_t dtype;                           /* CX_DT_BF16 (0) or CX_DT_F32 (g, g2, x fp32)          */
 } CxWgrad;
 
 int cx_abi_version(void);
@@ -315,6 +321,27 @@ int cx_cam_norm_upsample(const float* cam, float* out, int B, int h, int w, int 
 /* stat_rows (cx_bnrelu_maxpool_fwd / _bwd, cx_gap_relu_bn_bwd, cx_unpool2_mask): 0 = the statistics are added to the single
  * copy S1 / S2 [C] with atomics; > 0 = deterministic rows: the launch uses at most stat_rows workgroups (cx_gap_relu_bn_bwd: one row
  * per image, B <= stat_rows) and plain-stores row r at S[r*C + c]; cx_last_stat_rows() gives the row count for the consumer.   */
+
+/* ---- fp32 storage mode (CX_DT_F32): the element-wise kernels of the DenseNet path with fp32 activation tensors (same arguments,
+ * `const void*` tensors are fp32, pitches in elements), the fp32 weight table ([tap][O][I] fp32; descriptors with stem = 1 give
+ * [49][O][4]) and the fp32 image layouts.  cx_conv_gemm / cx_conv_wgrad take CxConv.dtype / CxWgrad.dtype = CX_DT_F32.          */
+int cx_pack_weights_table_f32(const float* flat, float* packed, const CxPackDesc* table_dev, int n_desc, void* stream);
+int cx_nchw3_to_nhwc4_f32(const float* x, float* y, int B, int H, int W, void* stream);
+int cx_u8_to_nhwc4_f32(const uint8_t* x, float* y, size_t npix, float mean, float std, void* stream);
+int cx_bnrelu_maxpool_fwd_f32(const void* x, const float* scale, const float* shift, void* y, uint8_t* argmax,
+                          float* stat_sum, float* stat_sq, int B, int H, int W, int C, int ldy, int stat_rows, void* stream);
+int cx_bnrelu_maxpool_bwd_f32(const void* x, const float* scale, const float* shift, const float* mean,
+                          const float* rstd, const uint8_t* argmax, const void* g, const void* gx, const float* ga,
+                          const float* gb, const float* gc, void* dz, float* S1, float* S2, int B, int H, int W, int C,
+                          int ldg, int ldgx, int stat_rows, void* stream);
+int cx_head_fwd_f32(const void* x, const float* scale, const float* shift, const float* w, const float* bias,
+                float* pooled, float* logits, int B, int HW, int C, int ldx, int n_classes, void* stream);
+int cx_gap_relu_bn_bwd_f32(const float* dpooled, const void* x, const float* scale, const float* shift,
+                       const float* mean, const float* rstd, const float* e_scale, void* g, float* S1, float* S2,
+                       int B, int HW, int C, int ldx, int ldg, int stat_rows, void* stream);
+int cx_unpool2_mask_f32(const void* d, const void* x, const float* sc, const float* sh, const float* mean,
+                    const float* rstd, const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W,
+                    int C, int ldd, int ldx, int ldg, int stat_rows, void* stream);
 
 /* utilities */
 int cx_fill_f32(float* p, float v, size_t n, void* stream);
