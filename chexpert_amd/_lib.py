@@ -67,6 +67,7 @@ SIGNATURES = {
     "cx_pack_weights_table_f32": [_vp, _vp, _vp, _i, _vp],
     "cx_nchw3_to_nhwc4_f32": [_vp, _vp, _i, _i, _i, _vp],
     "cx_u8_to_nhwc4_f32": [_vp, _vp, _sz, _f, _f, _vp],
+    "cx_u8_jitter": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "cx_bn_coef_eval": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],
     "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_bn_bwd_slice_coef": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
@@ -97,6 +98,7 @@ SIGNATURES = {
     "cx_in_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_f32_to_bf16": [_vp, _vp, _sz, _vp],
     "cx_nchw3_to_nhwc8": [_vp, _vp, _i, _i, _i, _vp],
+    "cx_u8_to_nhwc8": [_vp, _vp, _sz, _f, _f, _vp],
     "cx_dwconv_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_dwconv_dgrad": [_vp] * 14 + [_i] * 8 + [_vp],
     "cx_dwconv_wgrad": [_vp] * 9 + [_i] * 7 + [_vp],

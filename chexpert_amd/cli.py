@@ -1,9 +1,21 @@
 """Command line of the MI355X path, keeping the flag names and defaults of /root/reference/chexpert.py:29-57
-(`--train`, `--evaluate_single_model`, `--evaluate_ensemble`, `--visualize`, `--model`, `--batch_size 16`, `--lr 1e-4`,
-`--n_epochs 1`, `--log_interval 50`, `--eval_interval 300`, `--lr_decay_factor 0.97`, `--resize`, `--mini_data`, `--cuda`,
-`--restore`, `--load_config`, `--seed`), plus `--evaluate` (alias of --evaluate_single_model), `--synthetic N` (the
-CheXpert images are not available offline: N hash-generated X-rays with U-Ones-like labels), `--n_classes` and
-`--fused_optimizer`.  Logging goes to stdout / JSON (tensorboardX is not used).
+(`--train`, `--evaluate_single_model`, `--evaluate_ensemble`, `--visualize`, `--plot_roc`, `--model`, `--batch_size 16`,
+`--lr 1e-4`, `--n_epochs 1`, `--log_interval 50`, `--eval_interval 300`, `--lr_decay_factor 0.97`, `--lr_warmup_steps`,
+`--resize`, `--mini_data`, `--cuda`, `--restore`, `--load_config`, `--seed`), plus
+
+  --evaluate            alias of --evaluate_single_model (BASELINE.json spells it that way)
+  --synthetic N         N hash-generated uint8 X-rays with U-Ones-like labels (the CheXpert images are not available offline)
+  --n_classes K         5 = the reference's competition labels (chexpert.py:460)
+  --dtype {bf16,fp32}   activation storage of the fused schedule (fp32 = the 1e-3 parity mode, densenet121)
+  --fused_optimizer     one-kernel optimiser on the flat parameter buffer; with --graph the whole step (forward, loss, backward,
+                        optimiser, scheduler) is captured once as a hipGraph and replayed per minibatch
+  --jitter              brightness / contrast jitter +-0.25 of the uint8 image on the GPU (the reference's `_data_aug` rows)
+
+Data parallel: launch with `python -m torch.distributed.run --nproc-per-node N chexpert.py --train ...`; every rank holds a
+replica and a shard of each minibatch stream (per-rank BatchNorm statistics, averaged gradients: DDP semantics), the
+validation set is sharded too and its logits are gathered to rank 0, which alone writes checkpoints and results.
+Images travel as decoded grey bytes (1 B per pixel); whitening `(u/255 - 0.5330)/0.0349` and the expansion to three identical
+channels (chexpert.py:70-72) happen on the GPU.  Logging goes to stdout / JSON (tensorboardX is not used).
 """
 import argparse
 import json
@@ -16,6 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import metrics as M
+from . import parallel as P
 from . import synth
 
 ATTR_NAMES = ["Atelectasis", "Cardiomegaly", "Consolidation", "Edema", "Pleural Effusion"]     # dataset.py:25
@@ -28,6 +41,7 @@ def build_parser():
     p.add_argument("--evaluate_single_model", "--evaluate", dest="evaluate_single_model", action="store_true")
     p.add_argument("--evaluate_ensemble", action="store_true")
     p.add_argument("--visualize", action="store_true")
+    p.add_argument("--plot_roc", action="store_true")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--cuda", type=int, default=0)
     p.add_argument("--data_path", default="")
@@ -47,12 +61,16 @@ def build_parser():
     p.add_argument("--eval_interval", type=int, default=300)
     p.add_argument("--synthetic", type=int, default=0, help="number of synthetic training images (no dataset offline)")
     p.add_argument("--n_classes", type=int, default=len(ATTR_NAMES))
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--fused_optimizer", action="store_true", help="one-kernel optimiser on the flat parameter buffer")
+    p.add_argument("--graph", action="store_true", help="capture the training step as a hipGraph (needs --fused_optimizer)")
+    p.add_argument("--jitter", action="store_true", help="brightness / contrast jitter +-0.25 on the uint8 image (GPU)")
     return p
 
 
 class SyntheticXrays(torch.utils.data.Dataset):
-    """uint8 U{0..255} images through the reference transform chain (chexpert.py:70-72); Bernoulli(0.3) labels."""
+    """Decoded grey bytes (1,S,S) uint8 U{0..255} -- what PIL hands the reference's transform chain (chexpert.py:67-72) after
+    resize / centre-crop -- with Bernoulli(0.3) U-Ones-like labels (dataset.py:139-142)."""
 
     def __init__(self, n, size, n_classes, seed):
         self.n, self.size, self.n_classes, self.seed = n, size, n_classes, seed
@@ -62,29 +80,41 @@ class SyntheticXrays(torch.utils.data.Dataset):
         return self.n
 
     def __getitem__(self, i):
-        return synth.xray_batch(self.seed * 1000003 + i, 1, self.size)[0], self.targets[i], i
+        return synth.xray_u8(self.seed * 1000003 + i, 1, self.size)[0], self.targets[i], i
+
+
+def batches(ds, indices, batch_size, drop_last):
+    for k in range(0, len(indices), batch_size):
+        idx = indices[k:k + batch_size]
+        if drop_last and len(idx) < batch_size:
+            return
+        items = [ds[i] for i in idx]
+        yield torch.stack([it[0] for it in items]), torch.stack([it[1] for it in items]), torch.tensor(idx)
 
 
 def make_model(args, device):
-    """Model zoo of chexpert.py:461-502 (the families built so far)."""
+    """Model zoo and optimiser wiring of chexpert.py:461-502."""
+    from . import optim as O
     from .models import densenet121
     name = args.model
+    fused = args.fused_optimizer
+    sched = None
     if name == "densenet121":
         model = densenet121(pretrained=args.pretrained)
         model.classifier = nn.Linear(model.classifier.in_features, args.n_classes)
         nn.init.constant_(model.classifier.bias, 0)
-        model = model.to(device)
-        if args.fused_optimizer:
-            from .optim import FusedAdam
-            opt = FusedAdam(model, lr=args.lr)
-        else:
-            opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+        model = model.storage_dtype(args.dtype).to(device)
+        opt = O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)
         return model, opt, None
+    if args.dtype != "bf16":
+        raise RuntimeError("--dtype fp32 covers densenet121")
     if name in ("aadensenet121", "densenet121_attn_aug"):      # chexpert.py:474-480 (README row name accepted too)
         from .models import DenseNet
         size = args.resize or 320
         model = DenseNet(32, (6, 12, 24, 16), 64, num_classes=args.n_classes,
                          attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (size, size)}).to(device)
+        if fused:
+            return model, O.FusedSGDNesterov(model, lr=args.lr), "fused"
         opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, nesterov=True)
         return model, opt, torch.optim.lr_scheduler.MultiStepLR(opt, [40000, 60000])
     if name == "resnet152":                                   # chexpert.py:481-486
@@ -92,10 +122,12 @@ def make_model(args, device):
         model = resnet152(pretrained=args.pretrained)
         model.fc = nn.Linear(model.fc.in_features, args.n_classes)
         model = model.to(device)
-        return model, torch.optim.Adam(model.parameters(), lr=args.lr), None
+        return model, (O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)), None
     if "efficientnet" in name:                                # chexpert.py:496-500
         from .models import construct_model
         model = construct_model(name, n_classes=args.n_classes).to(device)
+        if fused:
+            return model, O.FusedRMSprop(model, lr=args.lr, decay=args.lr_decay_factor), "fused"
         opt = torch.optim.RMSprop(model.parameters(), lr=args.lr, momentum=0.9, eps=0.001)
         return model, opt, torch.optim.lr_scheduler.ExponentialLR(opt, args.lr_decay_factor)
     if name == "aaresnet152":                                 # chexpert.py:486-494
@@ -103,21 +135,35 @@ def make_model(args, device):
         size = args.resize or 320
         model = ResNet(Bottleneck, [3, 8, 36, 3], num_classes=args.n_classes,
                        attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (size, size)}).to(device)
-        return model, torch.optim.Adam(model.parameters(), lr=args.lr), None
+        return model, (O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)), None
     raise RuntimeError("Model architecture not supported.")
 
 
 @torch.no_grad()
-def evaluate(model, loader, device):
+def evaluate(model, ds, indices, batch_size, device):
+    """chexpert.py:198-211 on this rank's slice of the validation set; returns logits, targets, per-element losses, indices."""
     model.eval()
-    outs, tgts, losses = [], [], []
+    outs, tgts, losses, ids = [], [], [], []
     loss_fn = nn.BCEWithLogitsLoss(reduction="none")
-    for x, t, _ in loader:
+    for x, t, idx in batches(ds, indices, batch_size, False):
         o = model(x.to(device))
-        losses.append(loss_fn(o, t.to(device)).cpu())
-        outs.append(o.cpu())
-        tgts.append(t)
-    return torch.cat(outs), torch.cat(tgts), torch.cat(losses)
+        losses.append(loss_fn(o, t.to(device)))
+        outs.append(o)
+        tgts.append(t.to(device))
+        ids.append(idx.to(device))
+    if not outs:
+        z = torch.zeros(0, ds.n_classes, device=device)
+        return z, z.clone(), z.clone(), torch.zeros(0, dtype=torch.int64, device=device)
+    return torch.cat(outs), torch.cat(tgts), torch.cat(losses), torch.cat(ids)
+
+
+def evaluate_sharded(model, ds, batch_size, device, rank, world):
+    """Every rank forwards indices rank::world; the (N,5) logits / targets / losses are gathered and put back in dataset order."""
+    idx = list(range(len(ds)))[rank::world]
+    o, t, l, i = evaluate(model, ds, idx, batch_size, device)
+    o, t, l, i = (P.gather_rows(v) for v in (o, t, l, i))
+    order = torch.argsort(i)
+    return o[order].cpu(), t[order].cpu(), l[order].cpu()
 
 
 def save_checkpoint(ckpt, optim_state, sched_state, args, max_records=10):
@@ -145,65 +191,143 @@ def save_checkpoint(ckpt, optim_state, sched_state, args, max_records=10):
         torch.save(ckpt, os.path.join(d, "best_checkpoints", "checkpoint_%d.pt" % file_id))
 
 
+def restore(args, model, optimizer, scheduler, device):
+    """chexpert.py:504-518: model weights + step from the file; when training also `optim_<name>` / `sched_<name>` beside it."""
+    ck = torch.load(args.restore, map_location=device)
+    model.load_state_dict(ck["state_dict"])
+    args.step = ck["global_step"]
+    if args.train:
+        d, b = os.path.dirname(args.restore), os.path.basename(args.restore)
+        optimizer.load_state_dict(torch.load(os.path.join(d, "optim_" + b), map_location=device))
+        if scheduler is not None and scheduler != "fused":
+            scheduler.load_state_dict(torch.load(os.path.join(d, "sched_" + b), map_location=device))
+
+
+def plot_roc(res, args, name):
+    """chexpert.py:399-427: ROC and precision-recall curves per class from an eval_results_*.json."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    n = len(res["aucs"])
+    fig, axs = plt.subplots(2, n, figsize=(4 * n, 8))
+    for i in range(n):
+        k = str(i) if str(i) in res["fpr"] else i
+        axs[0, i].plot(res["fpr"][k], res["tpr"][k], label="AUC = %.2f" % res["aucs"][k])
+        axs[0, i].plot([0, 1], [0, 1], "k--")
+        axs[0, i].set_xlabel("False positive rate")
+        axs[0, i].set_ylabel("True positive rate")
+        axs[0, i].set_title(ATTR_NAMES[i] if i < len(ATTR_NAMES) else "class %d" % i)
+        axs[0, i].legend(loc="lower right")
+        axs[1, i].step(res["recall"][k], res["precision"][k], where="post")
+        axs[1, i].set_xlabel("Recall")
+        axs[1, i].set_ylabel("Precision")
+    plt.tight_layout()
+    os.makedirs(os.path.join(args.output_dir, "plots"), exist_ok=True)
+    plt.savefig(os.path.join(args.output_dir, "plots", name + ".png"), bbox_inches="tight")
+    plt.close()
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.load_config:
         args.__dict__.update(json.load(open(args.load_config)))
+    rank, world, local = P.dist_info()
+    if world > 1:
+        # the process group comes first, before anything touches the GPU; one rank per GPU over RCCL ("nccl"), or ranks sharing
+        # a device over gloo when the box has fewer GPUs than ranks (tests)
+        import torch.distributed as dist
+        one_per_gpu = torch.cuda.device_count() >= world
+        dist.init_process_group("nccl" if one_per_gpu else "gloo")
+        args.cuda = local if one_per_gpu else 0
     if not args.output_dir:
         if args.restore:
             raise RuntimeError("Must specify `output_dir` argument")
         args.output_dir = os.path.join("results", time.strftime("%Y-%m-%d_%H-%M-%S", time.gmtime()))
-    os.makedirs(args.output_dir, exist_ok=True)
-    cfg_path = os.path.join(args.output_dir, "config.json")
-    if not os.path.exists(cfg_path):
-        json.dump(args.__dict__, open(cfg_path, "w"), indent=4)
+    if rank == 0:
+        os.makedirs(args.output_dir, exist_ok=True)
+        cfg_path = os.path.join(args.output_dir, "config.json")
+        if not os.path.exists(cfg_path):
+            json.dump(args.__dict__, open(cfg_path, "w"), indent=4)
     if not torch.cuda.is_available():
         raise RuntimeError("chexpert_amd needs an MI355X (no CPU fallback)")
     device = torch.device("cuda:%d" % (args.cuda or 0))
+    torch.cuda.set_device(device)
     if args.seed:
         torch.manual_seed(args.seed)
         np.random.seed(args.seed)
     model, optimizer, scheduler = make_model(args, device)
     if args.restore and os.path.isfile(args.restore):
-        ck = torch.load(args.restore, map_location=device)
-        model.load_state_dict(ck["state_dict"])
-        args.step = ck["global_step"]
+        restore(args, model, optimizer, scheduler, device)
     size = args.resize or 320
     if not args.synthetic:
         raise RuntimeError("the CheXpert-small dataset is not available offline; pass --synthetic N")
     n_valid = max(args.batch_size, args.synthetic // 5)
-    train = torch.utils.data.DataLoader(SyntheticXrays(args.mini_data or args.synthetic, size, args.n_classes, 7),
-                                        args.batch_size, shuffle=True, drop_last=True)
-    valid = torch.utils.data.DataLoader(SyntheticXrays(n_valid, size, args.n_classes, 11), args.batch_size)
+    train_ds = SyntheticXrays(args.mini_data or args.synthetic, size, args.n_classes, 7)
+    valid_ds = SyntheticXrays(n_valid, size, args.n_classes, 11)
     loss_fn = nn.BCEWithLogitsLoss(reduction="none")
-    print("Loaded %s (number of parameters: %s; weights trained to step %d)" % (
-        model._get_name(), format(sum(p.numel() for p in model.parameters()), ","), args.step))
+    if rank == 0:
+        print("Loaded %s (number of parameters: %s; weights trained to step %d)" % (
+            model._get_name(), format(sum(p.numel() for p in model.parameters()), ","), args.step))
 
     def run_eval(tag):
-        res = M.compute_metrics(*evaluate(model, valid, device))
-        print("Evaluate metrics @ step %d:\nAUC:\n%s\nLoss:\n%s" % (args.step, pprint.pformat(res["aucs"]), pprint.pformat(res["loss"])))
-        json.dump(res, open(os.path.join(args.output_dir, tag + ".json"), "w"), indent=4)
+        res = M.compute_metrics(*evaluate_sharded(model, valid_ds, args.batch_size, device, rank, world))
+        if rank == 0:
+            print("Evaluate metrics @ step %d:\nAUC:\n%s\nLoss:\n%s" % (args.step, pprint.pformat(res["aucs"]), pprint.pformat(res["loss"])))
+            json.dump(res, open(os.path.join(args.output_dir, tag + ".json"), "w"), indent=4)
         return res
 
+    def jitter(x_u8, step):
+        from . import ops
+        B = x_u8.shape[0]
+        u = synth.uniform(step * 7919 + 13 + rank, (3, B), 0.0, 1.0)
+        return ops.u8_jitter(x_u8, (0.75 + 0.5 * u[0]).to(device), (0.75 + 0.5 * u[1]).to(device),
+                             (u[2] > 0.5).to(torch.int32).to(device))
+
     if args.train:
+        fused = args.fused_optimizer
+        gstep, dp_on = None, world == 1
         for epoch in range(args.n_epochs):
             model.train()
-            for x, t, _ in train:
+            idx = P.shard_indices(len(train_ds), rank, world, seed=args.seed or 1, epoch=epoch)
+            for x, t, _ in batches(train_ds, idx, args.batch_size, True):
                 args.step += 1
-                out = model(x.to(device))
-                loss = loss_fn(out, t.to(device)).sum(1).mean(0)          # chexpert.py:160
-                optimizer.zero_grad()
-                loss.backward()
-                optimizer.step()
-                if scheduler and args.step >= args.lr_warmup_steps:
-                    scheduler.step()
-                if args.step % args.log_interval == 0:
+                x, t = x.to(device), t.to(device)
+                if args.jitter:
+                    x = jitter(x, args.step)
+                if args.graph and fused and world == 1:
+                    if gstep is None:                       # captured on the first minibatch's shapes
+                        from .graph import GraphedTrainStep
+                        gstep = GraphedTrainStep(model, optimizer, x, t, warmup_steps=int(args.lr_warmup_steps))
+                    loss, _ = gstep.replay(x, t)
+                elif fused:
+                    optimizer.zero_grad()
+                    loss, _ = model.forward_backward(x, t)  # chexpert.py:159-163 as one fused schedule
+                    optimizer.step()
+                    if scheduler == "fused" and args.step >= args.lr_warmup_steps:
+                        optimizer.scheduler_step()
+                else:
+                    out = model(x)
+                    loss = loss_fn(out, t).sum(1).mean(0)                     # chexpert.py:160
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+                    if scheduler and args.step >= args.lr_warmup_steps:
+                        scheduler.step()
+                if not dp_on:                               # replicas start identical; gradients are averaged from now on
+                    P.broadcast_module_state(model)
+                    model._eng().enable_data_parallel()
+                    dp_on = True
+                if args.step % args.log_interval == 0 and rank == 0:
                     print(json.dumps({"step": args.step, "train_loss": round(loss.item(), 5)}), flush=True)
                 if args.step % args.eval_interval == 0:
-                    res = M.compute_metrics(*evaluate(model, valid, device))
-                    save_checkpoint({"global_step": args.step, "eval_loss": float(np.sum(list(res["loss"].values()))),
-                                     "avg_auc": M.mean_auc(res), "state_dict": model.state_dict()},
-                                    optimizer.state_dict() if hasattr(optimizer, "state_dict") else {}, None, args)
+                    res = M.compute_metrics(*evaluate_sharded(model, valid_ds, args.batch_size, device, rank, world))
+                    if rank == 0:
+                        if gstep is not None:
+                            optimizer.sync_from_device()
+                        sched_state = scheduler.state_dict() if scheduler is not None and scheduler != "fused" else None
+                        save_checkpoint({"global_step": args.step, "eval_loss": float(np.sum(list(res["loss"].values()))),
+                                         "avg_auc": M.mean_auc(res), "state_dict": model.state_dict()},
+                                        optimizer.state_dict(), sched_state, args)
                     model.train()
             run_eval("eval_results_step_%d" % args.step)
     if args.evaluate_single_model:
@@ -213,19 +337,31 @@ def main(argv=None):
         outs, losses = [], []
         for c in sorted(f for f in os.listdir(args.restore) if f.startswith("checkpoint") and f.endswith(".pt")):
             model.load_state_dict(torch.load(os.path.join(args.restore, c), map_location=device)["state_dict"])
-            o, tg, l = evaluate(model, valid, device)
+            o, tg, l = evaluate_sharded(model, valid_ds, args.batch_size, device, rank, world)
             outs.append(o)
             losses.append(l)
         res = M.compute_metrics(torch.stack(outs, 2).mean(2), tg, torch.stack(losses, 2).mean(2))   # mean of logits, chexpert.py:233
-        json.dump(res, open(os.path.join(args.output_dir, "eval_results_ensemble.json"), "w"), indent=4)
-        print("AUC:\n", pprint.pformat(res["aucs"]))
-    if args.visualize:
+        if rank == 0:
+            json.dump(res, open(os.path.join(args.output_dir, "eval_results_ensemble.json"), "w"), indent=4)
+            print("AUC:\n", pprint.pformat(res["aucs"]))
+    if args.visualize and rank == 0:
         from .gradcam import grad_cam
-        x, _, _ = next(iter(valid))
+        x, _, _ = next(batches(valid_ds, list(range(min(len(valid_ds), args.batch_size))), args.batch_size, False))
         cam = grad_cam(model, x.to(device))
         os.makedirs(os.path.join(args.output_dir, "vis"), exist_ok=True)
         np.save(os.path.join(args.output_dir, "vis", "grad_cam.npy"), cam.cpu().numpy())
         print("grad-cam maps:", tuple(cam.shape))
+    if args.plot_roc and rank == 0:
+        files = [f for f in os.listdir(args.output_dir) if f.startswith("eval_results") and f.endswith(".json")]
+        if not files:
+            raise RuntimeError("No `eval_results` files found in `%s` to plot results from." % args.output_dir)
+        for f in files:
+            plot_roc(json.load(open(os.path.join(args.output_dir, f))), args, "roc_pr_" + f.split(".")[0])
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return model
 
 
 if __name__ == "__main__":

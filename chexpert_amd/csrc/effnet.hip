@@ -65,6 +65,18 @@ __global__ void nchw3_to_nhwc8_kernel(const float* __restrict__ x, bf16* __restr
   *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
 }
 
+// decoded grey bytes -> the three identical whitened channels (chexpert.py:70-72), NHWC8 bf16 (channels 3..7 zero)
+__global__ void u8_to_nhwc8_kernel(const uint8_t* __restrict__ x, bf16* __restrict__ y, float scale, float shift, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const bf16 g = f2bf(fmaf((float)x[idx], scale, shift));
+  U128 o;
+  o.e[0] = g; o.e[1] = g; o.e[2] = g;
+#pragma unroll
+  for (int j = 3; j < 8; ++j) o.e[j] = f2bf(0.f);
+  *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+}
+
 // ---------------------------------------------------------------------------------------------- depthwise conv
 // forward: y[p][c] = sum_t act(x[p@t][c]) * w[c][t],  act = swish(x*sc+sh) or identity (sc == nullptr)
 __global__ void dwconv_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sc,
@@ -544,6 +556,13 @@ int cx_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, void* stream
   if (!x || !y || B <= 0 || H <= 0 || W <= 0) return CX_EINVAL;
   const size_t hw = (size_t)H * W, total = hw * B;
   hipLaunchKernelGGL(nchw3_to_nhwc8_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y, hw, total);
+  return launch_status();
+}
+
+int cx_u8_to_nhwc8(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream) {
+  if (!x || !y || std <= 0.f) return CX_EINVAL;
+  hipLaunchKernelGGL(u8_to_nhwc8_kernel, dim3((npix + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y, 1.f / (255.f * std),
+                     -mean / std, npix);
   return launch_status();
 }
 

@@ -907,6 +907,72 @@ __global__ void optim_tick_kernel(float* hyper) {
   if (kind == 2) hyper[0] = hyper[7] * powf(hyper[3], (k >= hyper[5] ? 1.f : 0.f) + (k >= hyper[6] ? 1.f : 0.f));   // MultiStepLR
 }
 
+// ------------------------------------------------------------------------------------------------
+// Brightness / contrast jitter of the decoded grey image on the GPU (the `_data_aug` rows of the reference README are its
+// explore_data.ipynb cell 6: ColorJitter(brightness=0.25, contrast=0.25)).  torchvision tensor semantics on uint8:
+//   brightness b: y = trunc(clamp(b * x, 0, 255))
+//   contrast   c: y = trunc(clamp(c * x + (1 - c) * mean(x), 0, 255)), mean over the image (fp32)
+// applied in the order `order[b]` says (0: brightness first).  One workgroup per image; the image lives in LDS between the
+// passes (320 x 320 = 100 KB, 380 x 380 = 141 KB), so HBM sees one read and one write.
+__global__ __launch_bounds__(1024) void u8_jitter_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, int HW,
+                                                         const float* __restrict__ bfac, const float* __restrict__ cfac,
+                                                         const int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char img[];      // [HW] image, then 32 floats of reduction scratch
+  float* red = reinterpret_cast<float*>(img + HW);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint8_t* src = x + (size_t)b * HW;
+  const float bf_ = bfac[b], cf = cfac[b];
+  const bool bright_first = order[b] == 0;
+  float sum = 0.f;
+  for (int i = tid * 16; i < HW; i += 1024 * 16) {                // HW % 16 == 0
+    uint4 v = *reinterpret_cast<const uint4*>(src + i);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t o = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float p = (float)((w[q] >> (8 * e)) & 0xffu);
+        if (bright_first) p = truncf(fminf(fmaxf(bf_ * p, 0.f), 255.f));
+        sum += p;
+        o |= ((uint32_t)p) << (8 * e);
+      }
+      w[q] = o;
+    }
+    *reinterpret_cast<uint4*>(img + i) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // deterministic block sum: lanes by shuffles, waves in order
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    red[16] = t / (float)HW;
+  }
+  __syncthreads();
+  const float mean = red[16];
+  uint8_t* dst = y + (size_t)b * HW;
+  for (int i = tid * 16; i < HW; i += 1024 * 16) {
+    uint4 v = *reinterpret_cast<const uint4*>(img + i);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t o = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float p = (float)((w[q] >> (8 * e)) & 0xffu);
+        p = truncf(fminf(fmaxf(fmaf(cf, p, (1.f - cf) * mean), 0.f), 255.f));
+        if (!bright_first) p = truncf(fminf(fmaxf(bf_ * p, 0.f), 255.f));
+        o |= ((uint32_t)p) << (8 * e);
+      }
+      w[q] = o;
+    }
+    *reinterpret_cast<uint4*>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 inline int grid_for(size_t n, int block, int cap = 4096) {
   size_t g = (n + block - 1) / block;
   if (g > (size_t)cap) g = cap;
@@ -1044,6 +1110,20 @@ int cx_u8_to_nhwc4_f32(const uint8_t* x, float* y, size_t npix, float mean, floa
   if (!x || !y || std <= 0.f) return CX_EINVAL;
   hipLaunchKernelGGL(u8_to_nhwc4_f32_kernel, dim3((npix + 255) / 256), dim3(256), 0, as_stream(stream), x, y, 1.f / (255.f * std),
                      -mean / std, npix);
+  return launch_status();
+}
+
+int cx_u8_jitter(const uint8_t* x, uint8_t* y, int B, int HW, const float* brightness, const float* contrast, const int* order,
+                 void* stream) {
+  if (!x || !y || !brightness || !contrast || !order || B <= 0 || HW <= 0) return CX_EINVAL;
+  if ((HW % 16) || !aligned16(x) || !aligned16(y)) return CX_EALIGN;
+  if (HW > 150 * 1024) return CX_ESHAPE;                       // the image is parked in LDS between the two passes
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&u8_jitter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024 + 128);
+    attr = true;
+  }
+  hipLaunchKernelGGL(u8_jitter_kernel, dim3(B), dim3(1024), (size_t)HW + 128, as_stream(stream), x, y, HW, brightness, contrast, order);
   return launch_status();
 }
 

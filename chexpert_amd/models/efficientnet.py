@@ -263,8 +263,9 @@ class _Engine:
     # ---- forward
     def forward(self, x, train):
         m, v, lb = self.model, self._v, lib()
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise RuntimeError("expected a (B,3,H,W) input")
+        u8 = x.dtype == torch.uint8             # decoded grey bytes (B,1,H,W): whitened + expanded on the GPU (cx_u8_to_nhwc8)
+        if x.dim() != 4 or x.shape[1] != (1 if u8 else 3):
+            raise RuntimeError("expected a (B,3,H,W) float input or a (B,1,H,W) uint8 image")
         B, _, H, W = x.shape
         self.bind(x.device)
         self.pack()
@@ -277,7 +278,10 @@ class _Engine:
         st = (lambda s: v(ws, s)) if train else (lambda s: None)
         sp = stream_ptr()
         S0 = self.bn[id(m.stem[1])]
-        check(lb.cx_nchw3_to_nhwc8(ptr(x.contiguous().float()), ptr(ws.x8), B, H, W, sp), "cx_nchw3_to_nhwc8")
+        if u8:
+            check(lb.cx_u8_to_nhwc8(ptr(x.contiguous()), ptr(ws.x8), B * H * W, 0.5330, 0.0349, sp), "cx_u8_to_nhwc8")
+        else:
+            check(lb.cx_nchw3_to_nhwc8(ptr(x.contiguous().float()), ptr(ws.x8), B, H, W, sp), "cx_nchw3_to_nhwc8")
         c0 = m.stem[0].out_channels
         ops.conv_gemm(ws.x8, self.packed[self.stem_off:], ws.ys, N=c0, kh=3, kw=3, stride=2, pad=ws.stem_pad, stat_sum=st(S0.sum),
                       stat_sq=st(S0.sq))

@@ -134,6 +134,19 @@ def u8_to_nhwc4(x, out=None, mean=0.5330, std=0.0349):
     return out
 
 
+def u8_jitter(x, brightness, contrast, order, out=None):
+    """ColorJitter(brightness, contrast) of explore_data.ipynb cell 6 on decoded grey bytes (B,1,H,W) / (B,H,W) uint8, on the GPU;
+    brightness / contrast: fp32 (B,) factors, order: int32 (B,), 0 = brightness first."""
+    require_cuda(x, brightness, contrast, order)
+    assert x.dtype == torch.uint8 and x.is_contiguous() and order.dtype == torch.int32
+    B = x.shape[0]
+    HW = x.numel() // B
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().cx_u8_jitter(ptr(x), ptr(out), B, HW, ptr(brightness), ptr(contrast), ptr(order), stream_ptr()), "cx_u8_jitter")
+    return out
+
+
 def nchw3_to_nhwc4(x, out=None):
     require_cuda(x)
     B, Cc, H, W = x.shape

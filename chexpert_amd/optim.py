@@ -25,6 +25,11 @@ class _Flat:
             raise RuntimeError("run a forward pass first (parameters are bound to the flat buffer lazily)")
         if self._state is None or self._state[0].numel() != eng.flat.numel() or self._state[0].device != eng.flat.device:
             self._state = [torch.zeros_like(eng.flat) for _ in range(n)]
+            pend = getattr(self, "_pending_state", None)
+            if pend is not None:
+                for dst, src in zip(self._state, pend):
+                    dst.copy_(src)
+                self._pending_state = None
         return eng.flat, eng.flat_grad, self._state
 
     def zero_grad(self, set_to_none=True):
@@ -47,6 +52,19 @@ class _Flat:
     def tick(self):
         """steps_done += 1 and the scheduler step of chexpert.py:165, on the device."""
         ops.optim_tick(self.hyper())
+
+    def state_dict(self):
+        """What the reference saves as `optim_checkpoint_latest.pt` (chexpert.py:188-189), for the flat-buffer state."""
+        self.sync_from_device()
+        return {"kind": type(self).__name__, "lr": self.lr, "base_lr": self.base_lr, "step_count": self.step_count,
+                "sched_steps": self.sched_steps, "state": None if self._state is None else [t.detach().cpu().clone() for t in self._state]}
+
+    def load_state_dict(self, sd):
+        if sd.get("kind") != type(self).__name__:
+            raise RuntimeError("optimizer checkpoint was written by %s, this is %s" % (sd.get("kind"), type(self).__name__))
+        self.lr, self.base_lr, self.step_count, self.sched_steps = sd["lr"], sd["base_lr"], sd["step_count"], sd["sched_steps"]
+        self._pending_state = sd["state"]              # copied into the flat-buffer state once the engine is bound
+        self._hyper = None
 
     def sync_from_device(self):
         if getattr(self, "_hyper", None) is not None:

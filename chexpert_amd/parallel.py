@@ -70,3 +70,40 @@ def broadcast_module_state(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src, group=group)
+
+
+# ---- data-parallel training loop helpers (chexpert_amd/cli.py) ------------------------------------------------------------------
+def dist_info():
+    """(rank, world, local_rank) from the torch.distributed.run environment; (0, 1, 0) when launched directly."""
+    import os
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def shard_indices(n, rank, world, seed=0, epoch=0, shuffle=True, drop_last=True):
+    """This rank's sample indices for one epoch: one seeded permutation shared by all ranks, dealt round-robin (what
+    torch.utils.data.DistributedSampler does); drop_last trims to a multiple of `world` so every rank steps equally often."""
+    import numpy as np
+    order = np.random.RandomState(seed * 1000003 + epoch).permutation(n) if shuffle else np.arange(n)
+    if drop_last:
+        order = order[:(n // world) * world]
+    return order[rank::world].tolist()
+
+
+def gather_rows(t, group=None):
+    """Concatenate per-rank row blocks (N_r, ...) of possibly different N_r in rank order on every rank (sharded evaluation:
+    every rank forwards its slice of the validation set, rank 0 computes AUROC on the whole)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device if dist.get_backend(group) == "nccl" else "cpu")
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    ns = [int(v) for v in ns]
+    m = max(ns)
+    cpu = dist.get_backend(group) != "nccl"
+    src = t.cpu() if cpu else t
+    pad = torch.zeros((m,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[:src.shape[0]] = src
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:k] for o, k in zip(outs, ns)]).to(t.device)

@@ -275,6 +275,8 @@ int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream);
  * depthwise k x k conv on (B,H,W,C) bf16, weights fp32 (C,1,k,k); the preceding BatchNorm+Swish is applied on load
  * when sc/sh are given (sc == NULL: raw input).  Output / statistics as cx_conv_gemm.                          */
 int cx_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, void* stream);
+/* uint8 grey image (npix pixels) -> whitened, channel-expanded (.., 8) bf16 for the EfficientNet stem (chexpert.py:70-72 on the GPU) */
+int cx_u8_to_nhwc8(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream);
 int cx_dwconv_fwd(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
                   int W, int C, int k, int stride, int pad, void* stream);
 /* dY = g*ga + g2*gb + gc;  dz = (sum_t dY w) * swish'(x*sc+sh), S1 += dz, S2 += dz*(x-mean)*rstd (sc==NULL: dz = sum) */
@@ -321,6 +323,13 @@ int cx_cam_norm_upsample(const float* cam, float* out, int B, int h, int w, int 
 /* stat_rows (cx_bnrelu_maxpool_fwd / _bwd, cx_gap_relu_bn_bwd, cx_unpool2_mask): 0 = the statistics are added to the single
  * copy S1 / S2 [C] with atomics; > 0 = deterministic rows: the launch uses at most stat_rows workgroups (cx_gap_relu_bn_bwd: one row
  * per image, B <= stat_rows) and plain-stores row r at S[r*C + c]; cx_last_stat_rows() gives the row count for the consumer.   */
+
+/* Brightness / contrast jitter of the decoded grey images (B, HW) uint8 on the GPU: the "+ data aug" of the reference's
+ * `_data_aug` README rows = ColorJitter(brightness=0.25, contrast=0.25) of explore_data.ipynb cell 6, torchvision tensor
+ * semantics on uint8 (y = trunc(clamp(b*x)); y = trunc(clamp(c*x + (1-c)*mean(x)))), per-image factors and order (0 = brightness
+ * first) drawn by the caller.  HW % 16 == 0, HW <= 150 KiB (the image is parked in LDS between the two passes).               */
+int cx_u8_jitter(const uint8_t* x, uint8_t* y, int B, int HW, const float* brightness, const float* contrast, const int* order,
+                 void* stream);
 
 /* ---- fp32 storage mode (CX_DT_F32): the element-wise kernels of the DenseNet path with fp32 activation tensors (same arguments,
  * `const void*` tensors are fp32, pitches in elements), the fp32 weight table ([tap][O][I] fp32; descriptors with stem = 1 give

@@ -179,3 +179,13 @@ def test_efficientnet_dropout_and_dropconnect_train_mode(dev):
     with torch.no_grad():
         a, b = model(x.to(dev)), model(x.to(dev))
     assert _rel(a.cpu(), b.cpu()) < 1e-2 and not eng.last_masks                  # (fp32 atomic pooling sums: not bitwise)
+
+
+def test_efficientnet_uint8_input_path(dev):
+    """SURVEY.md section 8f rank 1 for EfficientNet: decoded grey bytes in, whitening + channel expansion on the GPU."""
+    model, sd = _build("efficientnet-b0", 5, 21, dev)
+    u8 = synth.xray_u8(31, 2, 96)
+    model.eval()
+    with torch.no_grad():
+        a, b = model(u8.to(dev)), model(synth.normalise(u8).to(dev))
+    assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()

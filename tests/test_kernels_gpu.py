@@ -566,3 +566,30 @@ def test_fused_1x1_dgrad_wgrad_equals_separate_kernels(dev, pro, acc, B, H, W, N
     close(st[0].sum(0).cpu(), S1, rel=2e-3, what="S1")
     close(st[1].sum(0).cpu(), S2, rel=3e-3, what="S2")
     close(dw.cpu(), want_dw, rel=3e-3, what="dW")
+
+
+def test_u8_brightness_contrast_jitter_matches_torch_restatement(dev):
+    """cx_u8_jitter against a CPU restatement of torchvision's tensor ColorJitter(brightness, contrast) on uint8 (the reference's
+    only augmentation code: explore_data.ipynb cell 6, ColorJitter(0.25, 0.25))."""
+    from chexpert_amd import ops
+    B, S = 5, 96
+    u8 = synth.xray_u8(55, B, S)
+    bfac = rnd(56, (B,), 0.75, 1.25)
+    cfac = rnd(57, (B,), 0.75, 1.25)
+    order = torch.tensor([0, 1, 0, 1, 1], dtype=torch.int32)
+    want = torch.empty_like(u8)
+    for i in range(B):
+        img = u8[i].float()
+
+        def bright(t):
+            return (t * bfac[i]).clamp(0, 255).to(torch.uint8).float()
+
+        def contrast(t):
+            return (cfac[i] * t + (1 - cfac[i]) * t.mean()).clamp(0, 255).to(torch.uint8).float()
+        img = contrast(bright(img)) if order[i] == 0 else bright(contrast(img))
+        want[i] = img.to(torch.uint8)
+    got = ops.u8_jitter(u8.to(dev), bfac.to(dev), cfac.to(dev), order.to(dev)).cpu()
+    diff = (got.int() - want.int()).abs()
+    # the image mean is an fp32 sum in a different order: a product within 1e-5 of an integer may truncate the other way
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 1e-3, (diff.max().item(), (diff > 0).float().mean().item())
+    assert got.float().std() > 10

@@ -272,6 +272,33 @@ def test_cli_train_eval_synthetic(dev, tmp_path):
     assert set(ck) == {"global_step", "eval_loss", "avg_auc", "state_dict"} and len(ck["state_dict"]) == 727
 
 
+def test_cli_restore_continues_with_optimizer_state_and_graph_fp32_smoke(dev, tmp_path):
+    """--restore <file> --train reloads weights, step and `optim_<name>` (chexpert.py:504-518); --fused_optimizer --graph replays
+    the captured step; --dtype fp32 runs the parity mode; --plot_roc draws from the eval_results files (:399-427)."""
+    from chexpert_amd import cli
+    base = ["--synthetic", "16", "--batch_size", "4", "--resize", "64", "--output_dir", str(tmp_path), "--eval_interval", "2",
+            "--log_interval", "1"]
+    cli.main(["--train"] + base)
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint_latest.pt"))
+    assert ck["global_step"] == 4
+    opt_sd = torch.load(os.path.join(str(tmp_path), "optim_checkpoint_latest.pt"))
+    assert opt_sd["state"][0]["step"] == 4 if not torch.is_tensor(opt_sd["state"][0]["step"]) else int(opt_sd["state"][0]["step"]) == 4
+    cli.main(["--train", "--restore", os.path.join(str(tmp_path), "checkpoint_latest.pt")] + base)
+    ck2 = torch.load(os.path.join(str(tmp_path), "checkpoint_latest.pt"))
+    assert ck2["global_step"] == 8
+    opt_sd = torch.load(os.path.join(str(tmp_path), "optim_checkpoint_latest.pt"))
+    assert int(opt_sd["state"][0]["step"]) == 8                          # Adam moments continued, not restarted
+    g = str(tmp_path / "graph")
+    cli.main(["--train", "--fused_optimizer", "--graph", "--jitter", "--synthetic", "16", "--batch_size", "4", "--resize", "64",
+              "--output_dir", g, "--eval_interval", "4", "--log_interval", "1"])
+    osd = torch.load(os.path.join(g, "optim_checkpoint_latest.pt"))
+    assert osd["kind"] == "FusedAdam" and osd["step_count"] == 4
+    f = str(tmp_path / "fp32")
+    cli.main(["--train", "--evaluate", "--plot_roc", "--dtype", "fp32", "--synthetic", "8", "--batch_size", "4", "--resize", "64",
+              "--output_dir", f, "--log_interval", "1"])
+    assert any(n.startswith("roc_pr_eval_results") for n in os.listdir(os.path.join(f, "plots")))
+
+
 def test_uint8_input_equals_reference_transform_chain(dev):
     """feeding the decoded grey bytes (B,1,H,W) uint8 gives the logits of the reference transform
     chain `float().div(255)`, `Normalize(0.5330, 0.0349)`, `expand(3,-1,-1)` (chexpert.py:70-72) fed as fp32 NCHW."""
