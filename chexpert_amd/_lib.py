@@ -117,6 +117,7 @@ SIGNATURES = {
     "cx_gradcam_map": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_cam_norm_upsample": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_fill_f32": [_vp, _f, _sz, _vp],
+    "cx_affine_to_f32_nchw": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_bf16_to_f32_nchw": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
 }
 

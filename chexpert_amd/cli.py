@@ -285,7 +285,11 @@ def main(argv=None):
 
     if args.train:
         fused = args.fused_optimizer
-        gstep, dp_on = None, world == 1
+        gstep = None
+        if world > 1:            # replicas start identical (parameters, buffers) and average their gradients inside backward from
+            model._eng().bind(device)                 # the first step on: bind the flat buffers now, before any optimiser state exists
+            P.broadcast_module_state(model)
+            model._eng().enable_data_parallel()
         for epoch in range(args.n_epochs):
             model.train()
             idx = P.shard_indices(len(train_ds), rank, world, seed=args.seed or 1, epoch=epoch)
@@ -313,10 +317,6 @@ def main(argv=None):
                     optimizer.step()
                     if scheduler and args.step >= args.lr_warmup_steps:
                         scheduler.step()
-                if not dp_on:                               # replicas start identical; gradients are averaged from now on
-                    P.broadcast_module_state(model)
-                    model._eng().enable_data_parallel()
-                    dp_on = True
                 if args.step % args.log_interval == 0 and rank == 0:
                     print(json.dumps({"step": args.step, "train_loss": round(loss.item(), 5)}), flush=True)
                 if args.step % args.eval_interval == 0:

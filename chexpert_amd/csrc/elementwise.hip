@@ -790,6 +790,19 @@ __global__ void bf16_to_f32_nchw_kernel(const bf16* __restrict__ x, float* __res
   y[idx] = bf2f(x[(b * HW + p) * ldx + c]);
 }
 
+// y[b][c][p] = act(x[b][p][c] * sc[c] + sh[c]) as fp32 NCHW: the feature map a forward hook on features.norm5 / layer4 / head[1] sees
+__global__ void affine_to_f32_nchw_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                          int relu, float* __restrict__ y, int HW, int C, int ldx, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int p = idx % HW;
+  const int c = (idx / HW) % C;
+  const size_t b = idx / ((size_t)HW * C);
+  float v = bf2f(x[(b * HW + p) * ldx + c]);
+  if (sc) v = fmaf(v, sc[c], sh[c]);
+  y[idx] = relu ? fmaxf(v, 0.f) : v;
+}
+
 // Grad-CAM: cam[b][p] = relu(sum_c w[c] * relu(x[b][p][c]*sc[c]+sh[c]))   (chexpert.py:283-285 as executed)
 __global__ void gradcam_map_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                                    const float* __restrict__ w, float* __restrict__ cam, size_t npix, int C, int ldx, int inner_relu) {
@@ -1340,6 +1353,15 @@ int cx_cam_norm_upsample(const float* cam, float* out, int B, int h, int w, int 
 int cx_fill_f32(float* p, float v, size_t n, void* stream) {
   if (!p) return CX_EINVAL;
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), p, v, n);
+  return launch_status();
+}
+
+int cx_affine_to_f32_nchw(const void* x, const float* scale, const float* shift, int relu, float* y, int B, int H, int W, int C, int ldx,
+                          void* stream) {
+  if (!x || !y || ((scale == nullptr) != (shift == nullptr))) return CX_EINVAL;
+  const size_t total = (size_t)B * H * W * C;
+  hipLaunchKernelGGL(affine_to_f32_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), (const bf16*)x, scale, shift,
+                     relu, y, H * W, C, ldx, total);
   return launch_status();
 }
 

@@ -557,6 +557,10 @@ class EfficientNet(nn.Module):
         eng = self._eng()
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _Fn.apply(x, self.head[6].weight, self)
+        if not self.training:
+            from ..gradcam import hooked_eval_forward, hooks_registered
+            if hooks_registered(self):                     # Grad-CAM hook protocol of the reference (chexpert.py:271-272)
+                return hooked_eval_forward(self, x)
         ws = eng.forward(x, self.training)
         out = ws.logits.clone()
         eng.release(ws)

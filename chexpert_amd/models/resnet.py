@@ -52,6 +52,38 @@ class Bottleneck(nn.Module):
         raise RuntimeError("chexpert_amd: call the parent ResNet (fused HIP schedule)")
 
 
+class BasicBlock(nn.Module):
+    """Signature and parameters of /root/reference/models/attn_aug_conv.py:107-156 (two 3x3 convolutions; AAConv2d replaces
+    conv1 in layers 2-4).  The reference uses it only in the CIFAR harness (models/test_model.py): constructible here
+    (parameter counts, state_dict keys), not part of the MI355X schedule."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None,
+                 input_dims=None, attn_params=None):
+        super().__init__()
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        if attn_params is None:
+            self.conv1 = Conv2dParams(inplanes, planes, 3, stride, 1, bias=False)
+        else:
+            nh = attn_params["nh"]
+            dk = max(20 * nh, int((attn_params["k"] * planes // nh) * nh))
+            dv = int((attn_params["v"] * planes // nh) * nh)
+            dims = (int(attn_params["input_dims"][0] * 16 / planes), int(attn_params["input_dims"][1] * 16 / planes))
+            self.conv1 = AAConv2d(inplanes, planes, 3, stride, dk, dv, nh, attn_params["relative"], dims)
+        self.bn1 = BatchNorm2dParams(planes)
+        self.relu = ReLUMarker(inplace=True)
+        self.conv2 = Conv2dParams(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = BatchNorm2dParams(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):  # pragma: no cover - guard
+        raise RuntimeError("chexpert_amd: BasicBlock only holds parameters (CIFAR harness variant, not on the HIP schedule)")
+
+
 class _BN:
     """Vector slots of one BatchNorm."""
 
@@ -485,8 +517,9 @@ class ResNet(nn.Module):
     def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
                  replace_stride_with_dilation=None, norm_layer=None, attn_params=None):
         super().__init__()
-        if block is not Bottleneck:
-            raise NotImplementedError("only Bottleneck ResNets are on the hot path (BasicBlock / WideResNet: CIFAR harness)")
+        if block not in (Bottleneck, BasicBlock):
+            raise NotImplementedError("block must be Bottleneck or BasicBlock")
+        self.block = block
         if groups != 1 or width_per_group != 64 or (replace_stride_with_dilation not in (None, [False] * 3, (False,) * 3)):
             raise NotImplementedError("groups / width / dilation variants are not on the hot path")
         self.inplanes = 64
@@ -499,7 +532,7 @@ class ResNet(nn.Module):
         self.layer3 = self._make_layer(256, layers[2], 2, attn_params)
         self.layer4 = self._make_layer(512, layers[3], 2, attn_params)
         self.avgpool = PoolMarker()
-        self.fc = nn.Linear(512 * 4, num_classes)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
         for mod in self.modules():                      # initialisers of attn_aug_conv.py:248-263
             if isinstance(mod, nn.Conv2d):
                 nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
@@ -510,20 +543,30 @@ class ResNet(nn.Module):
             for mod in self.modules():
                 if isinstance(mod, Bottleneck):
                     nn.init.constant_(mod.bn3.weight, 0)
+                elif isinstance(mod, BasicBlock):
+                    nn.init.constant_(mod.bn2.weight, 0)
         self._nbt_pending = 0
         self._engine = None
 
     def _make_layer(self, planes, blocks, stride, attn_params=None):
+        block, e = self.block, self.block.expansion
         down = None
-        if stride != 1 or self.inplanes != planes * 4:
-            down = nn.Sequential(Conv2dParams(self.inplanes, planes * 4, 1, stride, bias=False), BatchNorm2dParams(planes * 4))
-        layers = [Bottleneck(self.inplanes, planes, stride, down, attn_params=attn_params)]
-        self.inplanes = planes * 4
+        if stride != 1 or self.inplanes != planes * e:
+            down = nn.Sequential(Conv2dParams(self.inplanes, planes * e, 1, stride, bias=False), BatchNorm2dParams(planes * e))
+        layers = [block(self.inplanes, planes, stride, down, attn_params=attn_params)]
+        self.inplanes = planes * e
         for _ in range(1, blocks):
-            layers.append(Bottleneck(self.inplanes, planes, attn_params=attn_params))
+            layers.append(block(self.inplanes, planes, attn_params=attn_params))
         return nn.Sequential(*layers)
 
     def _eng(self):
+        if self.block is not Bottleneck:
+            raise NotImplementedError("BasicBlock ResNets (ResNet18/34 of models/test_model.py) are constructible but only the "
+                                      "Bottleneck networks chexpert.py trains run on the HIP schedule")
+        for mod in self.modules():
+            if isinstance(mod, AAConv2d) and not mod.kernel_support:
+                raise NotImplementedError("AAConv2d(dk=%d, dv=%d, nh=%d): the HIP attention kernels cover dk/nh = 20, dv/nh in "
+                                          "{1,2,3,4,6}, relative=True" % (mod.dk, mod.dv, mod.nh))
         if self._engine is None:
             object.__setattr__(self, "_engine", _Engine(self))
         return self._engine
@@ -539,11 +582,15 @@ class ResNet(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("chexpert_amd.ResNet runs on the GPU only (hand-written HIP kernels); there is no CPU fallback")
+        eng = self._eng()
         if self.fc.in_features != 2048:
             raise RuntimeError("fc.in_features must be 2048")
-        eng = self._eng()
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _Fn.apply(x, self.fc.weight, self)
+        if not self.training:
+            from ..gradcam import hooked_eval_forward, hooks_registered
+            if hooks_registered(self):                     # Grad-CAM hook protocol of the reference (chexpert.py:271-272)
+                return hooked_eval_forward(self, x)
         ws = eng.forward(x, self.training)
         out = ws.logits.clone()
         eng.release(ws)
@@ -560,6 +607,48 @@ class ResNet(nn.Module):
         logits = ws.logits.clone()
         eng.release(ws)
         return loss, logits
+
+
+class WideResNet(nn.Module):
+    """Signature and parameters of /root/reference/models/attn_aug_conv.py:311-404 (WRN-d-k on CIFAR: 3x3 stem, three stages of
+    BasicBlocks, AAConv2d in stages 2-3).  CIFAR harness only (models/test_model.py): constructible, not on the HIP schedule."""
+
+    def __init__(self, block, depth, width, num_classes=100, zero_init_residual=False, groups=1, width_per_group=64,
+                 replace_stride_with_dilation=None, norm_layer=None, attn_params=None):
+        super().__init__()
+        assert (depth - 4) % 6 == 0, "depth should be 6n+4"
+        n = (depth - 4) // 6
+        if attn_params:                          # the reference rescales (and mutates) the caller's dict, :322-324
+            attn_params = dict(attn_params)
+            attn_params["input_dims"] = (int(attn_params["input_dims"][0] * width), int(attn_params["input_dims"][1] * width))
+        if replace_stride_with_dilation not in (None, [False] * 3, (False,) * 3):
+            raise NotImplementedError("dilated variants are not built")
+        self.block = block
+        self.inplanes = 16
+        self.conv1 = Conv2dParams(3, 16, 3, 1, 1, bias=False)
+        self.bn1 = BatchNorm2dParams(16)
+        self.relu = ReLUMarker(inplace=True)
+        self.layer1 = self._make_layer(16 * width, n, 1)
+        self.layer2 = self._make_layer(32 * width, n, 2, attn_params)
+        self.layer3 = self._make_layer(64 * width, n, 2, attn_params)
+        self.avgpool = PoolMarker()
+        self.fc = nn.Linear(64 * width, num_classes)
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.constant_(mod.weight, 1)
+                nn.init.constant_(mod.bias, 0)
+        if zero_init_residual:
+            for mod in self.modules():
+                if isinstance(mod, BasicBlock):
+                    nn.init.constant_(mod.bn2.weight, 0)
+
+    _make_layer = ResNet._make_layer
+
+    def forward(self, x):  # pragma: no cover - guard
+        raise NotImplementedError("WideResNet is the CIFAR harness network of models/test_model.py: constructible (parameter "
+                                  "counts, state_dict), not part of the MI355X schedule")
 
 
 def resnet152(pretrained=False, **kwargs):

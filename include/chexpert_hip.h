@@ -354,6 +354,10 @@ int cx_unpool2_mask_f32(const void* d, const void* x, const float* sc, const flo
 
 /* utilities */
 int cx_fill_f32(float* p, float v, size_t n, void* stream);
+/* y (B,C,H,W) fp32 = act(x*scale + shift) of a bf16 NHWC tensor (scale/shift NULL: identity; relu != 0: ReLU): the tensor a
+ * forward hook on the reference's hook targets receives (features.norm5 / layer4 / head[1], chexpert.py:468, :484, :498)      */
+int cx_affine_to_f32_nchw(const void* x, const float* scale, const float* shift, int relu, float* y, int B, int H, int W, int C,
+                          int ldx, void* stream);
 int cx_bf16_to_f32_nchw(const void* x, float* y, int B, int H, int W, int C, int ldx, void* stream);
 
 #ifdef __cplusplus

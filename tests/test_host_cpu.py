@@ -215,3 +215,31 @@ def test_fused_optimiser_state_dict_round_trip():
     import pytest
     with pytest.raises(RuntimeError):
         FusedRMSprop(_M(), lr=1.0).load_state_dict(sd)
+
+
+def test_reference_parameter_counts_and_import_paths():
+    """The known answers of the reference's only self-test (attn_aug_conv.py:522-655: parameter counts of the papers) through the
+    reference's own import paths (`models.attn_aug_conv`, `models.efficientnet`; chexpert.py:25-26)."""
+    from models.attn_aug_conv import BasicBlock, Bottleneck, DenseNet, ResNet, WideResNet
+    from models.efficientnet import SCALING_PARAMS, construct_model
+    n = lambda m: round(sum(p.numel() for p in m.parameters()) * 1e-6, 1)
+    attn = lambda k, v, nh, d: {"k": k, "v": v, "nh": nh, "relative": True, "input_dims": d}
+    assert n(DenseNet(12, (16, 16, 16), 24, num_classes=10)) == 0.8                       # :530
+    assert n(DenseNet(24, (41, 41, 41), 48, num_classes=10)) == 15.3                      # :537
+    assert n(DenseNet(40, (31, 31, 31), 80, num_classes=10)) == 25.6                      # :545
+    assert sum(p.numel() for p in DenseNet(32, (6, 12, 24, 16), 64).parameters()) == 7978856
+    assert n(WideResNet(BasicBlock, 28, 10, num_classes=100, attn_params=attn(.2, .1, 8, (32, 32)))) == 36.2        # :602
+    assert n(ResNet(BasicBlock, [3, 4, 6, 3])) == 21.8                                    # :610
+    assert n(ResNet(Bottleneck, [3, 4, 6, 3])) == 25.6                                    # :616
+    assert n(ResNet(BasicBlock, [3, 4, 6, 3], attn_params=attn(.25, .25, 8, (224, 224)))) == 20.7                  # :623
+    assert n(ResNet(Bottleneck, [3, 4, 6, 3], attn_params=attn(.2, .1, 8, (224, 224)))) == 25.8                    # :629
+    for k, want in ((.25, 24.3), (.5, 22.3), (.75, 20.7), (1, 19.4)):                       # :635-653
+        assert n(ResNet(Bottleneck, [3, 4, 6, 3], attn_params=attn(k, k, 8, (224, 224)))) == want
+    assert set(SCALING_PARAMS) == {"efficientnet-b%d" % i for i in range(8)}
+    assert sum(p.numel() for p in construct_model("efficientnet-b0", 5).parameters()) == 4013953
+    import pytest
+    with pytest.raises(NotImplementedError):               # constructible, not on the MI355X schedule
+        ResNet(BasicBlock, [2, 2, 2, 2])._eng()
+    d = {"k": .2, "v": .1, "nh": 8, "relative": True, "input_dims": (320, 320)}
+    DenseNet(32, (6, 12, 24, 16), 64, attn_params=d)
+    assert d["input_dims"] == (320, 320)                   # the reference mutates the caller's dict; the drop-in works on a copy

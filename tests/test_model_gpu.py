@@ -261,6 +261,42 @@ def test_grad_cam_matches_reference_fixture_and_oracle(dev):
     assert float(cam.max()) <= 1.0 + 1e-5 and float(cam.min()) >= 0.0
 
 
+def test_reference_hook_protocol_fires_on_the_drop_in(dev):
+    """chexpert.py:266-285 as the reference executes it -- forward hook on `features.norm5`, legacy backward hook on `classifier`,
+    `one_hot.mul(outputs).sum().backward()`, `linear_grad[0][2].mean(1)` -- run against the drop-in module: the hooks fire with
+    the tensors the reference's modules would hand them, and the resulting map equals chexpert_amd.gradcam.grad_cam (itself
+    pinned by the reference's own grad_cam output, tests/golden/gradcam.npz)."""
+    import warnings
+    import numpy as np
+    import torch.nn.functional as F
+    from chexpert_amd.gradcam import grad_cam
+    model, sd = _build((2, 2, 2, 2), 5, 21, dev)
+    x = synth.xray_batch(77, 3, 64).to(dev)
+    feats, lgrad = [], []
+    model.eval()
+    model.zero_grad()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hf = model.features.norm5.register_forward_hook(lambda m, i, o: feats.append(o))
+        hb = model.classifier.register_backward_hook(lambda m, gi, go: lgrad.append(gi))
+    out = model(x)
+    one_hot = F.one_hot(out.argmax(1), out.shape[1]).float().requires_grad_(True)
+    one_hot.mul(out).sum().backward()
+    hf.remove()
+    hb.remove()
+    assert len(feats) == 1 and len(lgrad) == 1 and feats[0].shape == (3, model.classifier.in_features, 2, 2)
+    assert float(feats[0].min()) >= 0.0                                   # mutated by the model's in-place ReLU (:514)
+    w = lgrad[0][2].mean(1).view(1, -1, 1, 1)                             # legacy hook: grad wrt W^T, (in_features, n_classes)
+    cam = F.relu((w * feats[0]).sum(1, keepdim=True))
+    mn, mx = cam.flatten(1).min(1)[0].view(-1, 1, 1, 1), cam.flatten(1).max(1)[0].view(-1, 1, 1, 1)
+    cam = F.interpolate((cam - mn) / (mx - mn + 1e-5), x.shape[2:], mode="bilinear", align_corners=True)
+    ref = torch.from_numpy(np.load(os.path.join(G, "gradcam.npz"))["cam"])
+    assert (cam.cpu() - ref).abs().max().item() < 3e-2
+    assert (cam - grad_cam(model, x)).abs().max().item() < 1e-3
+    with torch.no_grad():
+        assert model(x).grad_fn is None                                   # no hooks left: plain fused eval forward
+
+
 def test_cli_train_eval_synthetic(dev, tmp_path):
     from chexpert_amd import cli
     cli.main(["--train", "--evaluate", "--visualize", "--synthetic", "16", "--batch_size", "4", "--resize", "64",
