@@ -136,16 +136,24 @@ class KernelTimer:
         return out
 
 
+def _committed(suffix, args):
+    """Latest profiles/*<suffix>*.json taken on this workload (key model:dtype:batch:size), else None."""
+    d = os.path.join(ROOT, "profiles")
+    key = "%s:%s:%d:%d" % (args.model, args.dtype, args.batch, args.size)
+    best = None
+    for f in sorted(os.listdir(d)) if os.path.isdir(d) else []:
+        if suffix in f and f.endswith(".json"):
+            j = json.load(open(os.path.join(d, f)))
+            if j.get("workload_key", "densenet121:bf16:256:320") == key:
+                best = j
+    return best
+
+
 def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
-    collected with rocprofv3 --pmc in their own runs); null when the workload differs from the one the counters were taken on."""
-    if (args.model, args.batch, args.size, args.dtype) != ("densenet121", 256, 320, "bf16"):
-        return None
-    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")) \
-        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-    if not files:
-        return None
-    k = json.load(open(os.path.join(ROOT, "profiles", files[-1])))["kernels"].get(kernel)
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic*.json: FETCH_SIZE x2 + WRITE_SIZE,
+    collected with rocprofv3 --pmc in their own runs); null when no pass was taken on this workload."""
+    j = _committed("_pmc_traffic", args)
+    k = None if j is None else j["kernels"].get(kernel)
     return None if k is None else k["hbm_bytes_per_launch"]
 
 
@@ -214,15 +222,10 @@ def cpu_baseline(n_classes, steps=3, batch=4, size=320):
 
 
 def committed_counter(kernel, args, key):
-    """Per-kernel figures from the committed counter passes (profiles/*_sq_counters.json: SQ_VALU_MFMA_BUSY_CYCLES /
-    SQ_BUSY_CU_CYCLES collected with rocprofv3 --pmc in their own run); null for other workloads."""
-    if (args.model, args.batch, args.size, args.dtype) != ("densenet121", 256, 320, "bf16"):
-        return None
-    d = os.path.join(ROOT, "profiles")
-    files = sorted(f for f in os.listdir(d) if f.endswith("_sq_counters.json")) if os.path.isdir(d) else []
-    if not files:
-        return None
-    k = json.load(open(os.path.join(d, files[-1])))["kernels"].get(kernel)
+    """Per-kernel figures from the committed SQ counter pass (profiles/*_sq_counters*.json: SQ_VALU_MFMA_BUSY_CYCLES over
+    GRBM_GUI_ACTIVE, collected with rocprofv3 --pmc in its own run); null when no pass was taken on this workload."""
+    j = _committed("_sq_counters", args)
+    k = None if j is None else j["kernels"].get(kernel)
     return None if k is None else k.get(key)
 
 

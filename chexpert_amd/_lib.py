@@ -69,7 +69,7 @@ SIGNATURES = {
     "cx_u8_to_nhwc4_f32": [_vp, _vp, _sz, _f, _f, _vp],
     "cx_u8_jitter": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "cx_bn_coef_eval": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],
-    "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cx_bn_bwd_coef": [_vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "cx_bn_bwd_slice_coef": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "cx_bnrelu_maxpool_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "cx_bnrelu_maxpool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

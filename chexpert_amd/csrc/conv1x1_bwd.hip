@@ -295,6 +295,15 @@ __global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const 
 // pays for one prefetched tile in registers: dZ / y1 of tile t+1 are requested right after tile t's staging barrier, x / old dX of
 // tile t+1 right after tile t's epilogue.  The dZ and relu(bn(x)) images are double buffered in LDS: two barriers per tile.
 constexpr int BM2 = 64;
+// diagnostic build (DBG & 256): s_memtime stamps at the phase boundaries of every tile, summed per workgroup (wave 0)
+__device__ unsigned long long pw_bwd2_stamps[1024 * 8];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
 constexpr int A2_BYTES = BM2 * PITCH;
 constexpr int XH2_BYTES = BM2 * XH_PITCH;
 
@@ -376,8 +385,8 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
   }
 
   uint4 ru[2], rv[2];
-  U128 xv[2], old[2];
-  // ---- first tile's operands
+  U128 xvA[2], oldA[2], xvB[2], oldB[2];
+  // ---- first tile's dZ / y1, first two tiles' x / old dX
   {
     const int m0 = t0 * BM2;
 #pragma unroll
@@ -389,131 +398,308 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
     }
     const int m = m0 + pw * 32 + lrow;
     const int mc = m < M ? m : M - 1;
+    const int mtb = t0 + 1 < t1 ? t0 + 1 : t0;
+    const int mb = mtb * BM2 + pw * 32 + lrow;
+    const int mcb = mb < M ? mb : M - 1;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
-      xv[cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl[cc]);
-      if (ACC) old[cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl[cc]);
-      else old[cc].u = make_uint4(0, 0, 0, 0);
+      xvA[cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl[cc]);
+      xvB[cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mcb * p.ldex + ncl[cc]);
+      if (ACC) {
+        oldA[cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl[cc]);
+        oldB[cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mcb * p.ldy + ncl[cc]);
+      } else {
+        oldA[cc].u = make_uint4(0, 0, 0, 0);
+        oldB[cc].u = make_uint4(0, 0, 0, 0);
+      }
     }
   }
   __syncthreads();                                              // coefficients (read by the staging) and weights visible
 
-  for (int mt = t0; mt < t1; ++mt) {
-    const int m0 = mt * BM2;
-    const int bsel = (mt - t0) & 1;
-    char* Ab_ = At + bsel * A2_BYTES;
-    char* Xb_ = Xh + bsel * (4 * XH2_BYTES);
-    // ---- dZ tile (already in registers) -> LDS
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = r0 + 32 * i;
-      U128 o;
-      if (PRO == CX_PRO_NONE || (DBG & 64)) {
-        o.u = ru[i];
-        if (DBG & 64) { o.u.x ^= rv[i].x; o.u.y ^= rv[i].y; o.u.z ^= rv[i].z; o.u.w ^= rv[i].w; }
-      } else {
-        U128 u, v;
-        u.u = ru[i];
-        v.u = rv[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
-      }
-      const unsigned keep = m0 + row < M ? 0xffffffffu : 0u;
-      o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
-      *reinterpret_cast<uint4*>(Ab_ + row * PITCH + q * 16) = o.u;
-    }
-    __syncthreads();                              // dZ tile visible; the other At / Xh buffers are free (their readers passed here)
-    // ---- next tile's dZ / y1 (clamped tile index: the last iteration re-requests its own tile instead of branching)
-    const int mtn = mt + 1 < t1 ? mt + 1 : mt;
-    if constexpr (!(DBG & 4)) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int mm = mtn * BM2 + r0 + 32 * i;
-        const int mmc = mm < M ? mm : M - 1;
-        ru[i] = *reinterpret_cast<const uint4*>(X + (size_t)mmc * p.ldx + q * 8);
-        if (PRO == CX_PRO_AFFINE2) rv[i] = *reinterpret_cast<const uint4*>(X2 + (size_t)mmc * p.ldx2 + q * 8);
-      }
-    }
-    // ---- input gradient of this wave's 32 pixels x 32 channels: D[row = channel][col = pixel]
-    f32x16 accd;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+  unsigned long long acc_t[7] = {0, 0, 0, 0, 0, 0, 0};
+  const int n_pairs = (t1 - t0 + 1) >> 1;
+  for (int pr_ = 0; pr_ < n_pairs; ++pr_) {
     {
-      const char* Ab = Ab_ + (pw * 32 + lrow) * PITCH + lh * 16;
-      const char* Wb = Wt + (cq * 32 + lrow) * PITCH + lh * 16;
-#pragma unroll
-      for (int kk = 0; kk < KD / 16; ++kk) {
-        if constexpr (DBG & 32) { if (kk > 0) continue; }
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + kk * 32);
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wb + kk * 32);
-        accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, accd, 0, 0, 0);
-      }
-    }
-    // ---- mask epilogue; relu(bn(x)) goes to LDS for the second product
-    const int m = m0 + pw * 32 + lrow;
-    const bool pok = m < M;
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      if constexpr (DBG & 8) {                  // ablation: keep the operands alive, no arithmetic
-        asm volatile("" ::"v"(accd[8 * cc]), "v"(accd[8 * cc + 7]), "v"(xv[cc].u.x), "v"(old[cc].u.w));
-        *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xv[cc].u;
-        continue;
-      }
-      const int cl = cq * 32 + 8 * (2 * cc + lh);
-      float v[8];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accd[8 * cc + r4]), __float_as_uint(accd[8 * cc + 4 + r4]), false, false);
-        v[r4] = __uint_as_float(sw[0]);
-        v[4 + r4] = __uint_as_float(sw[1]);
-      }
-      const float4 a0 = *reinterpret_cast<const float4*>(ecoef + cl), a1 = *reinterpret_cast<const float4*>(ecoef + cl + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(ecoef + BC + cl), b1 = *reinterpret_cast<const float4*>(ecoef + BC + cl + 4);
-      const float4 e0 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl), e1 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl + 4);
-      const float esc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-      U128 o, xh;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xf = bf2f(xv[cc].e[e]);
-        const float pre = fmaf(xf, esc[e], esh[e]);
-        const bool on = pok && pre > 0.f;
-        const float dz = on ? v[e] : 0.f;
-        s1[cc][e] += dz;
-        s2[cc][e] = fmaf(dz, xf, s2[cc][e]);
-        o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[cc].e[e])));
-        xh.e[e] = f2bf(on ? pre : 0.f);
-      }
-      if constexpr (!(DBG & 1)) {
-        if (pok && nok[cc]) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + ncl[cc]) = o.u;
-      } else {
-        asm volatile("" ::"v"(o.u.x), "v"(o.u.y), "v"(o.u.z), "v"(o.u.w));
-      }
-      *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
-    }
-    // ---- next tile's x / old dX
-    if constexpr (!(DBG & 2)) {
-      const int mn = mtn * BM2 + pw * 32 + lrow;
-      const int mc = mn < M ? mn : M - 1;
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        xv[cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl[cc]);
-        if (ACC) old[cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl[cc]);
-      }
-    }
-    __syncthreads();                              // relu(bn(x)) tile visible
-    // ---- weight gradient: dW[n][c] += sum over the 64 pixels of the tile
-#pragma unroll
-    for (int kk = 0; kk < BM2 / 16; ++kk) {
-      if constexpr (DBG & 16) { if (kk > 0) continue; }
-      const bf16x8 af = tr_frag(Ab_, PITCH, kk * 16, wn * 32, lane);
-#pragma unroll
+      const int mt = t0 + 2 * pr_;
+      constexpr int SEL = 0;
+      U128 (&xv)[2] = xvA;
+      U128 (&old)[2] = oldA;
+      unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+      if constexpr (DBG & 256) ts0 = stamp();
+      const int m0 = mt * BM2;
+      const int bsel = SEL;
+      const bool tvalid = mt < t1;              // odd tile counts: the second half of the last pair is a masked dummy
+      char* Ab_ = At + bsel * A2_BYTES;
+      char* Xb_ = Xh + bsel * (4 * XH2_BYTES);
+      // ---- dZ tile (already in registers) -> LDS
+  #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const bf16x8 bfr = tr_frag(Xb_ + (wc0 + i) * XH2_BYTES, XH_PITCH, kk * 16, 0, lane);
-        accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+        const int row = r0 + 32 * i;
+        U128 o;
+        if (PRO == CX_PRO_NONE || (DBG & 64)) {
+          o.u = ru[i];
+          if (DBG & 64) { o.u.x ^= rv[i].x; o.u.y ^= rv[i].y; o.u.z ^= rv[i].z; o.u.w ^= rv[i].w; }
+        } else {
+          U128 u, v;
+          u.u = ru[i];
+          v.u = rv[i];
+  #pragma unroll
+          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
+        }
+        const unsigned keep = (tvalid && m0 + row < M) ? 0xffffffffu : 0u;
+        o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
+        *reinterpret_cast<uint4*>(Ab_ + row * PITCH + q * 16) = o.u;
+      }
+      if constexpr (DBG & 256) ts1 = stamp();
+      __syncthreads();                              // dZ tile visible; the other At / Xh buffers are free (their readers passed here)
+      if constexpr (DBG & 256) ts2 = stamp();
+      // ---- next tile's dZ / y1 (clamped tile index: the last iteration re-requests its own tile instead of branching)
+      const int mtn = mt + 1 < t1 ? mt + 1 : t1 - 1;
+      if constexpr (!(DBG & 4)) {
+  #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int mm = mtn * BM2 + r0 + 32 * i;
+          const int mmc = mm < M ? mm : M - 1;
+          ru[i] = *reinterpret_cast<const uint4*>(X + (size_t)mmc * p.ldx + q * 8);
+          if (PRO == CX_PRO_AFFINE2) rv[i] = *reinterpret_cast<const uint4*>(X2 + (size_t)mmc * p.ldx2 + q * 8);
+        }
+      }
+      // ---- input gradient of this wave's 32 pixels x 32 channels: D[row = channel][col = pixel]
+      f32x16 accd;
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+      {
+        const char* Ab = Ab_ + (pw * 32 + lrow) * PITCH + lh * 16;
+        const char* Wb = Wt + (cq * 32 + lrow) * PITCH + lh * 16;
+  #pragma unroll
+        for (int kk = 0; kk < KD / 16; ++kk) {
+          if constexpr (DBG & 32) { if (kk > 0) continue; }
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + kk * 32);
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wb + kk * 32);
+          accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, accd, 0, 0, 0);
+        }
+      }
+      if constexpr (DBG & 256) { asm volatile("" ::"v"(accd[0]), "v"(accd[15])); ts3 = stamp(); }
+      // ---- mask epilogue; relu(bn(x)) goes to LDS for the second product
+      const int m = m0 + pw * 32 + lrow;
+      const bool pok = tvalid && m < M;
+  #pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if constexpr (DBG & 8) {                  // ablation: keep the operands alive, no arithmetic
+          asm volatile("" ::"v"(accd[8 * cc]), "v"(accd[8 * cc + 7]), "v"(xv[cc].u.x), "v"(old[cc].u.w));
+          *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xv[cc].u;
+          continue;
+        }
+        const int cl = cq * 32 + 8 * (2 * cc + lh);
+        float v[8];
+  #pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accd[8 * cc + r4]), __float_as_uint(accd[8 * cc + 4 + r4]), false, false);
+          v[r4] = __uint_as_float(sw[0]);
+          v[4 + r4] = __uint_as_float(sw[1]);
+        }
+        const float4 a0 = *reinterpret_cast<const float4*>(ecoef + cl), a1 = *reinterpret_cast<const float4*>(ecoef + cl + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ecoef + BC + cl), b1 = *reinterpret_cast<const float4*>(ecoef + BC + cl + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl), e1 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl + 4);
+        const float esc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        U128 o, xh;
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xf = bf2f(xv[cc].e[e]);
+          const float pre = fmaf(xf, esc[e], esh[e]);
+          const bool on = pok && pre > 0.f;
+          const float dz = on ? v[e] : 0.f;
+          s1[cc][e] += dz;
+          s2[cc][e] = fmaf(dz, xf, s2[cc][e]);
+          o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[cc].e[e])));
+          xh.e[e] = f2bf(on ? pre : 0.f);
+        }
+        if constexpr (!(DBG & 1)) {
+          if (pok && nok[cc]) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + ncl[cc]) = o.u;
+        } else {
+          asm volatile("" ::"v"(o.u.x), "v"(o.u.y), "v"(o.u.z), "v"(o.u.w));
+        }
+        *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
+      }
+      // ---- x / old dX of the tile after next, into the register set this tile has just consumed (two tiles of compute between
+      // request and use: the epilogue waited 2-4 k cycles per tile for operands requested only one tile ahead)
+      if constexpr (!(DBG & 2)) {
+        const int mt2 = mt + 2 < t1 ? mt + 2 : t1 - 1;
+        const int mn = mt2 * BM2 + pw * 32 + lrow;
+        const int mc = mn < M ? mn : M - 1;
+  #pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          xv[cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl[cc]);
+          if (ACC) old[cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl[cc]);
+        }
+      }
+      if constexpr (DBG & 256) ts4 = stamp();
+      __syncthreads();                              // relu(bn(x)) tile visible
+      if constexpr (DBG & 256) ts5 = stamp();
+      // ---- weight gradient: dW[n][c] += sum over the 64 pixels of the tile
+  #pragma unroll
+      for (int kk = 0; kk < BM2 / 16; ++kk) {
+        if constexpr (DBG & 16) { if (kk > 0) continue; }
+        const bf16x8 af = tr_frag(Ab_, PITCH, kk * 16, wn * 32, lane);
+  #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 bfr = tr_frag(Xb_ + (wc0 + i) * XH2_BYTES, XH_PITCH, kk * 16, 0, lane);
+          accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+        }
+      }
+      if constexpr (DBG & 256) {
+        asm volatile("" ::"v"(accw[0][0]), "v"(accw[1][15]));
+        ts6 = stamp();
+        acc_t[0] += ts1 - ts0; acc_t[1] += ts2 - ts1; acc_t[2] += ts3 - ts2; acc_t[3] += ts4 - ts3; acc_t[4] += ts5 - ts4;
+        acc_t[5] += ts6 - ts5; acc_t[6] += 1;
       }
     }
+    {
+      const int mt = t0 + 2 * pr_ + 1;
+      constexpr int SEL = 1;
+      U128 (&xv)[2] = xvB;
+      U128 (&old)[2] = oldB;
+      unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+      if constexpr (DBG & 256) ts0 = stamp();
+      const int m0 = mt * BM2;
+      const int bsel = SEL;
+      const bool tvalid = mt < t1;              // odd tile counts: the second half of the last pair is a masked dummy
+      char* Ab_ = At + bsel * A2_BYTES;
+      char* Xb_ = Xh + bsel * (4 * XH2_BYTES);
+      // ---- dZ tile (already in registers) -> LDS
+  #pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = r0 + 32 * i;
+        U128 o;
+        if (PRO == CX_PRO_NONE || (DBG & 64)) {
+          o.u = ru[i];
+          if (DBG & 64) { o.u.x ^= rv[i].x; o.u.y ^= rv[i].y; o.u.z ^= rv[i].z; o.u.w ^= rv[i].w; }
+        } else {
+          U128 u, v;
+          u.u = ru[i];
+          v.u = rv[i];
+  #pragma unroll
+          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
+        }
+        const unsigned keep = (tvalid && m0 + row < M) ? 0xffffffffu : 0u;
+        o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
+        *reinterpret_cast<uint4*>(Ab_ + row * PITCH + q * 16) = o.u;
+      }
+      if constexpr (DBG & 256) ts1 = stamp();
+      __syncthreads();                              // dZ tile visible; the other At / Xh buffers are free (their readers passed here)
+      if constexpr (DBG & 256) ts2 = stamp();
+      // ---- next tile's dZ / y1 (clamped tile index: the last iteration re-requests its own tile instead of branching)
+      const int mtn = mt + 1 < t1 ? mt + 1 : t1 - 1;
+      if constexpr (!(DBG & 4)) {
+  #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int mm = mtn * BM2 + r0 + 32 * i;
+          const int mmc = mm < M ? mm : M - 1;
+          ru[i] = *reinterpret_cast<const uint4*>(X + (size_t)mmc * p.ldx + q * 8);
+          if (PRO == CX_PRO_AFFINE2) rv[i] = *reinterpret_cast<const uint4*>(X2 + (size_t)mmc * p.ldx2 + q * 8);
+        }
+      }
+      // ---- input gradient of this wave's 32 pixels x 32 channels: D[row = channel][col = pixel]
+      f32x16 accd;
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+      {
+        const char* Ab = Ab_ + (pw * 32 + lrow) * PITCH + lh * 16;
+        const char* Wb = Wt + (cq * 32 + lrow) * PITCH + lh * 16;
+  #pragma unroll
+        for (int kk = 0; kk < KD / 16; ++kk) {
+          if constexpr (DBG & 32) { if (kk > 0) continue; }
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ab + kk * 32);
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wb + kk * 32);
+          accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, accd, 0, 0, 0);
+        }
+      }
+      if constexpr (DBG & 256) { asm volatile("" ::"v"(accd[0]), "v"(accd[15])); ts3 = stamp(); }
+      // ---- mask epilogue; relu(bn(x)) goes to LDS for the second product
+      const int m = m0 + pw * 32 + lrow;
+      const bool pok = tvalid && m < M;
+  #pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if constexpr (DBG & 8) {                  // ablation: keep the operands alive, no arithmetic
+          asm volatile("" ::"v"(accd[8 * cc]), "v"(accd[8 * cc + 7]), "v"(xv[cc].u.x), "v"(old[cc].u.w));
+          *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xv[cc].u;
+          continue;
+        }
+        const int cl = cq * 32 + 8 * (2 * cc + lh);
+        float v[8];
+  #pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accd[8 * cc + r4]), __float_as_uint(accd[8 * cc + 4 + r4]), false, false);
+          v[r4] = __uint_as_float(sw[0]);
+          v[4 + r4] = __uint_as_float(sw[1]);
+        }
+        const float4 a0 = *reinterpret_cast<const float4*>(ecoef + cl), a1 = *reinterpret_cast<const float4*>(ecoef + cl + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ecoef + BC + cl), b1 = *reinterpret_cast<const float4*>(ecoef + BC + cl + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl), e1 = *reinterpret_cast<const float4*>(ecoef + 4 * BC + cl + 4);
+        const float esc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        U128 o, xh;
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xf = bf2f(xv[cc].e[e]);
+          const float pre = fmaf(xf, esc[e], esh[e]);
+          const bool on = pok && pre > 0.f;
+          const float dz = on ? v[e] : 0.f;
+          s1[cc][e] += dz;
+          s2[cc][e] = fmaf(dz, xf, s2[cc][e]);
+          o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[cc].e[e])));
+          xh.e[e] = f2bf(on ? pre : 0.f);
+        }
+        if constexpr (!(DBG & 1)) {
+          if (pok && nok[cc]) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + ncl[cc]) = o.u;
+        } else {
+          asm volatile("" ::"v"(o.u.x), "v"(o.u.y), "v"(o.u.z), "v"(o.u.w));
+        }
+        *reinterpret_cast<uint4*>(Xb_ + cq * XH2_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
+      }
+      // ---- x / old dX of the tile after next, into the register set this tile has just consumed (two tiles of compute between
+      // request and use: the epilogue waited 2-4 k cycles per tile for operands requested only one tile ahead)
+      if constexpr (!(DBG & 2)) {
+        const int mt2 = mt + 2 < t1 ? mt + 2 : t1 - 1;
+        const int mn = mt2 * BM2 + pw * 32 + lrow;
+        const int mc = mn < M ? mn : M - 1;
+  #pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          xv[cc].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + ncl[cc]);
+          if (ACC) old[cc].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + ncl[cc]);
+        }
+      }
+      if constexpr (DBG & 256) ts4 = stamp();
+      __syncthreads();                              // relu(bn(x)) tile visible
+      if constexpr (DBG & 256) ts5 = stamp();
+      // ---- weight gradient: dW[n][c] += sum over the 64 pixels of the tile
+  #pragma unroll
+      for (int kk = 0; kk < BM2 / 16; ++kk) {
+        if constexpr (DBG & 16) { if (kk > 0) continue; }
+        const bf16x8 af = tr_frag(Ab_, PITCH, kk * 16, wn * 32, lane);
+  #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 bfr = tr_frag(Xb_ + (wc0 + i) * XH2_BYTES, XH_PITCH, kk * 16, 0, lane);
+          accw[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, accw[i], 0, 0, 0);
+        }
+      }
+      if constexpr (DBG & 256) {
+        asm volatile("" ::"v"(accw[0][0]), "v"(accw[1][15]));
+        ts6 = stamp();
+        acc_t[0] += ts1 - ts0; acc_t[1] += ts2 - ts1; acc_t[2] += ts3 - ts2; acc_t[3] += ts4 - ts3; acc_t[4] += ts5 - ts4;
+        acc_t[5] += ts6 - ts5; acc_t[6] += 1;
+      }
+    }
+  }
+  if constexpr (DBG & 256) {
+    if (tid == 0 && blockIdx.x < 1024) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) pw_bwd2_stamps[blockIdx.x * 8 + k] = acc_t[k];
+    }
+    if (tid == 256 && blockIdx.x < 1024) pw_bwd2_stamps[blockIdx.x * 8 + 7] = acc_t[2] + acc_t[3];   // a wave of the younger half
   }
 
 #pragma unroll
@@ -578,7 +764,7 @@ int launch_bwd2(const CxConv& p, float* dw, hipStream_t st) {
     return launch_status();
       switch (dbg) {
         CX_DBG_CASE(1) CX_DBG_CASE(2) CX_DBG_CASE(4) CX_DBG_CASE(7) CX_DBG_CASE(15) CX_DBG_CASE(23) CX_DBG_CASE(39) CX_DBG_CASE(71)
-        CX_DBG_CASE(127)
+        CX_DBG_CASE(127) CX_DBG_CASE(256)
         default: break;
       }
 #undef CX_DBG_CASE
@@ -620,6 +806,11 @@ int launch_bwd(const CxConv& p, float* dw, hipStream_t st) {
 }
 
 }  // namespace
+
+// diagnostic only (not part of the ABI): copies the s_memtime sums of the CX_PW_BWD_DBG=256 build to the host
+extern "C" int dbg_pw_bwd2_stamps(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pw_bwd2_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
 
 extern "C" int cx_conv1x1_dgrad_wgrad(const CxConv* pp, float* dw, void* stream) {
   if (!pp || !dw) return CX_EINVAL;

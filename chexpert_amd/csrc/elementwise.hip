@@ -317,7 +317,8 @@ __global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const
 
 __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(const float* S1, const float* S2, float count, const float* gamma,
                                                            const float* mean, const float* rstd, float* dgamma, float* dbeta, float* A,
-                                                           float* Bc, float* pa, float* pb, float* pc, int C, int replicas, int rstride) {
+                                                           float* Bc, float* pa, float* pb, float* pc, int C, int replicas, int rstride,
+                                                           float* qa, float* qb, float* qc, int q_lo, int q_n) {
   __shared__ float part[2][64][17];
   const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + j;
@@ -329,8 +330,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_kernel(const float* S1, cons
   if (dgamma) dgamma[c] += s2;
   if (dbeta) dbeta[c] += s1;
   const float inv = 1.f / count;
-  if (A) A[c] += r * g * s1 * inv;
-  if (Bc) Bc[c] += r * g * s2 * inv;
+  float a_new = 0.f, b_new = 0.f;
+  if (A) { a_new = A[c] + r * g * s1 * inv; A[c] = a_new; }
+  if (Bc) { b_new = Bc[c] + r * g * s2 * inv; Bc[c] = b_new; }
+  if (qa && c >= q_lo && c < q_lo + q_n) {      // cx_bn_bwd_slice_coef for the channels whose A / B are final after this consumer
+    const float rb = r * b_new;
+    qa[c - q_lo] = 1.f;
+    qb[c - q_lo] = -rb;
+    qc[c - q_lo] = mu * rb - a_new;
+  }
   if (pa) {
     pa[c] = g * r;
     pb[c] = -g * r * r * s2 * inv;
@@ -1181,13 +1189,14 @@ int cx_bn_coef_eval(const float* rm, const float* rv, const float* gamma, const 
 
 int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* gamma, const float* mean, const float* rstd,
                    float* dgamma, float* dbeta, float* A, float* Bc, float* pa, float* pb, float* pc, int C, int replicas,
-                   int rstride, void* stream) {
+                   int rstride, float* qa, float* qb, float* qc, int q_lo, int q_n, void* stream) {
   if (!S1 || !S2 || !mean || !rstd || C <= 0 || count <= 0) return CX_EINVAL;
+  if (qa && (!qb || !qc || !A || !Bc || q_lo < 0 || q_n <= 0 || q_lo + q_n > C)) return CX_EINVAL;
   if (replicas < 1) replicas = 1;
   if (replicas > 1 && rstride < C) return CX_EINVAL;
   if (pa && (!pb || !pc)) return CX_EINVAL;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 15) / 16), dim3(1024), 0, as_stream(stream), S1, S2, count, gamma, mean,
-                     rstd, dgamma, dbeta, A, Bc, pa, pb, pc, C, replicas, rstride);
+                     rstd, dgamma, dbeta, A, Bc, pa, pb, pc, C, replicas, rstride, qa, qb, qc, q_lo, q_n);
   return launch_status();
 }
 

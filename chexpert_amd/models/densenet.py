@@ -599,8 +599,17 @@ class _Engine:
                                 v(St[1]))
             sred = (v(St[0]), v(St[1]), 1, 0)
         h, w = ws.hw[bi]
+        g_ = self.growth
+
+        def slice_q(bi_, li_):
+            """(qa, qb, qc, first channel, channels) of the slice layer li_ of block bi_ produced (li_ = -1: the block's first
+            c0 channels): emitted by the coefficient kernel of the slice's LAST consumer, whose A / B update completes them."""
+            c0_, _ = self.blocks[bi_]
+            if li_ < 0:
+                return tuple(v(t)[:c0_] for t in s["q"]) + (0, c0_)
+            return tuple(v(t) for t in s["ql"][bi_][li_]) + (c0_ + li_ * g_, g_)
         ops.bn_bwd_coef(sred[0], sred[1], B * h * w, f.norm5.weight, v(bmean), v(brstd), G(f.norm5.weight), G(f.norm5.bias),
-                        v(A), v(Bc), None, None, None, ct, replicas=sred[2], rstride=sred[3])
+                        v(A), v(Bc), None, None, None, ct, replicas=sred[2], rstride=sred[3], q=slice_q(bi, n_layers - 1))
         q, pv = s["q"], s["p"]
         # weight-gradient kernels only feed the flat gradient buffer: they run on a side stream, concurrently
         # with the input-gradient chain of the following layers (two dz2 buffers, per-layer coefficient slots)
@@ -621,15 +630,19 @@ class _Engine:
             block = getattr(f, "denseblock%d" % (bi + 1))
             dz2s = [d.view(-1)[:B * h * w * self.mid].view(B, h, w, self.mid) for d in ws.dz2]
             sub = lambda slot, a, n: (slot[0] + a, n)
+            if bi != nb - 1 and isinstance(getattr(f, "transition%d" % (bi + 1)).conv, AAConv2d):
+                # an AA transition normalises per instance (its backward is complete in cx_in_relu_bwd): no BatchNorm consumer
+                # follows the block, so nobody has emitted the slice coefficients of its last layer -- A = B = 0 there
+                cl = c0 + (n_layers - 1) * self.growth
+                ops.bn_bwd_slice_coef(v(sub(A, cl, self.growth)), v(sub(Bc, cl, self.growth)), v(sub(bmean, cl, self.growth)),
+                                      v(sub(brstd, cl, self.growth)), *(v(t) for t in s["ql"][bi][n_layers - 1]), self.growth)
             for li in range(n_layers - 1, -1, -1):
                 layer = getattr(block, "denselayer%d" % (li + 1))
                 cin = c0 + li * self.growth
                 g_ = self.growth
                 n1, n2 = s["n1"][bi][li], s["n2"][bi][li]
                 y1 = ws.y1[bi][li]
-                qa, qb, qc = (v(t) for t in s["ql"][bi][li])
-                ops.bn_bwd_slice_coef(v(sub(A, cin, g_)), v(sub(Bc, cin, g_)), v(sub(bmean, cin, g_)), v(sub(brstd, cin, g_)),
-                                      qa, qb, qc, g_)
+                qa, qb, qc = (v(t) for t in s["ql"][bi][li])      # written by the previous coefficient launch (slice_q)
                 ev_q = torch.cuda.Event()
                 ev_q.record(main)
                 gs, xs = gbuf[..., cin:cin + g_], buf[..., cin:cin + g_]
@@ -668,14 +681,14 @@ class _Engine:
                     w1_done[k] = torch.cuda.Event()
                     w1_done[k].record(side)
                 ops.bn_bwd_coef(red1[0], red1[1], cnt, layer.norm1.weight, v(bmean), v(brstd), G(layer.norm1.weight),
-                                G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin, replicas=red1[2], rstride=red1[3])
+                                G(layer.norm1.bias), v(A), v(Bc), None, None, None, cin, replicas=red1[2], rstride=red1[3],
+                                q=slice_q(bi, li - 1))
                 if red is not None:
                     main.wait_event(w1_done[k])
                 k += 1
                 done(layer.norm1.weight)      # every gradient from this layer to the end of the buffer is final
             # the block's first c0 channels were produced by the previous transition (or the stem)
-            qa, qb, qc = (v(t)[:c0] for t in q)
-            ops.bn_bwd_slice_coef(v(A), v(Bc), v(bmean), v(brstd), qa, qb, qc, c0)
+            qa, qb, qc = (v(t)[:c0] for t in q)               # written by layer 0's norm1 coefficient launch
             gs, xs = gbuf[..., :c0], buf[..., :c0]
             if bi > 0 and isinstance(getattr(f, "transition%d" % bi).conv, AAConv2d):
                 aa = getattr(f, "transition%d" % bi).conv
@@ -700,7 +713,8 @@ class _Engine:
                 ops.conv_wgrad(gs, pbuf, G(tr.conv.weight), mode=ops.MODE_POOL2, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa, gb=qb,
                                gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(nt[0]), pb=v(nt[1]))
                 ops.bn_bwd_coef(sred[0], sred[1], B * ph * pw, tr.norm.weight, v(pmean), v(prstd), G(tr.norm.weight),
-                                G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev, replicas=sred[2], rstride=sred[3])
+                                G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev, replicas=sred[2], rstride=sred[3],
+                                q=slice_q(bi - 1, pn - 1))
                 done(tr.norm.weight)
             else:
                 n0, S0 = s["n0"], s["S0"]

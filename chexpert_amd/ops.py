@@ -177,9 +177,12 @@ def bn_coef_eval(rmean, rvar, gamma, beta, eps, scale, shift, mean, rstd, Cn=Non
                                 ptr(rstd), Cn, stream_ptr()), "cx_bn_coef_eval")
 
 
-def bn_bwd_coef(S1, S2, count, gamma, mean, rstd, dgamma, dbeta, A, Bc, pa, pb, pc, Cn, replicas=1, rstride=0):
+def bn_bwd_coef(S1, S2, count, gamma, mean, rstd, dgamma, dbeta, A, Bc, pa, pb, pc, Cn, replicas=1, rstride=0, q=None):
+    """q = (qa, qb, qc, q_lo, q_n): also emit the slice coefficients (cx_bn_bwd_slice_coef) of channels [q_lo, q_lo + q_n)."""
+    qa, qb, qc, q_lo, q_n = q if q is not None else (None, None, None, 0, 0)
     check(lib().cx_bn_bwd_coef(ptr(S1), ptr(S2), float(count), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta),
-                               ptr(A), ptr(Bc), ptr(pa), ptr(pb), ptr(pc), Cn, replicas, rstride, stream_ptr()), "cx_bn_bwd_coef")
+                               ptr(A), ptr(Bc), ptr(pa), ptr(pb), ptr(pc), Cn, replicas, rstride, ptr(qa), ptr(qb), ptr(qc), q_lo, q_n,
+                               stream_ptr()), "cx_bn_bwd_coef")
 
 
 def bn_bwd_slice_coef(A, Bc, mean, rstd, pa, pb, pc, Cn):

@@ -169,7 +169,10 @@ int cx_bn_coef_eval(const float* running_mean, const float* running_var, const f
  *   dY = dz*pa + y*pb + pc.                                                                       */
 int cx_bn_bwd_coef(const float* S1, const float* S2, float count, const float* gamma, const float* mean,
                    const float* rstd, float* dgamma, float* dbeta, float* A, float* Bc, float* pa, float* pb,
-                   float* pc, int C, int replicas, int rstride, void* stream);   /* S1/S2 replicated as above */
+                   float* pc, int C, int replicas, int rstride,
+                   /* optional: the cx_bn_bwd_slice_coef vectors of channels [q_lo, q_lo + q_n) from the A / B this call has just
+                      completed (their last consumer), qa/qb/qc of q_n floats, or NULL                                   */
+                   float* qa, float* qb, float* qc, int q_lo, int q_n, void* stream);   /* S1/S2 replicated as above */
 /* AFFINE2 vectors that apply the deferred correction to a gradient slice:
  *   dY_true = G*1 + x*(-r*Bc) + (mean*r*Bc - A)                                                   */
 int cx_bn_bwd_slice_coef(const float* A, const float* Bc, const float* mean, const float* rstd, float* pa,

@@ -1,4 +1,5 @@
-"""profiles/*_pmc_traffic.json from the two rocprofv3 --pmc passes: python scratch/pmc_summary.py <fetch.csv> <write.csv> <out.json> <steps>"""
+"""profiles/*_pmc_traffic*.json from the two rocprofv3 --pmc passes:
+python scratch/pmc_summary.py <fetch.csv> <write.csv> <out.json> <steps> [workload key model:dtype:batch:size]"""
 import csv, collections, json, sys
 def agg(path):
     d = collections.defaultdict(lambda: [0, 0.0])
@@ -11,6 +12,10 @@ f, w = agg(sys.argv[1]), agg(sys.argv[2])
 steps = int(sys.argv[4])
 out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py --no-cpu-baseline --steps 2 --warmup 1` (densenet121 bf16 bs=256 320x320, %d steps incl. warm-up and the instrumented step). Counter unit KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B); WRITE_SIZE as read. Bytes are per launch (mean over all launches of that kernel)." % steps,
        "workload": "densenet121 bf16 bs=256 320x320", "steps": steps, "kernels": {}}
+if len(sys.argv) > 5:
+    out["workload_key"] = sys.argv[5]
+    out["workload"] = sys.argv[5]
+    out["_note"] = out["_note"].replace("(densenet121 bf16 bs=256 320x320, ", "(" + sys.argv[5] + ", ")
 for k in f:
     n, fv = f[k]; wn, wv = w.get(k, [0, 0.0])
     if fv * 2 + wv < 1e3: continue

@@ -1,14 +1,27 @@
 #!/bin/bash
-# one gpurun call that refreshes every committed measurement: tests, bench line, kernel stats, PMC traffic
+# one gpurun call that refreshes every committed measurement of round 2: tests, bench lines, kernel stats, PMC traffic, SQ counters
+# usage: bash scratch/refresh.sh            (then copy gpurun_out/refresh/* into profiles/ as r02_*)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
-timeout -k 10 400 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1
+timeout -k 10 600 python -m pytest tests -m gpu -q > $O/tests.log 2>&1 || true
 timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline > $O/bench_prof.json 2>> $O/bench.err
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
-python scratch/pmc_summary.py $(ls $O/fetch/*/*counter_collection.csv) $(ls $O/write/*/*counter_collection.csv) $O/pmc_traffic.json 4 > $O/pmc.txt
-cp $(ls $O/stats/*/*_kernel_stats.csv) $O/kernel_stats.csv
-rm -rf $O/stats/*/*kernel_trace.csv $O/fetch $O/write
-tail -2 $O/tests.log; cat $O/bench.json
+timeout -k 10 300 python bench.py --dtype fp32 --steps 3 --warmup 1 > $O/bench_fp32.json 2>> $O/bench.err
+CHEXPERT_SERIAL_WGRAD=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-graph > $O/bench_prof.json 2>> $O/bench.err
+cp $(ls $O/stats/*/*_kernel_stats.csv) $O/kernel_stats.csv; rm -rf $O/stats
+pmc() {   # model dtype batch size
+  local M=$1 D=$2 B=$3 S=$4 T=$O/pmc_$1
+  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $T/fetch -- python bench.py --model $M --dtype $D --batch $B --size $S --no-cpu-baseline --no-graph --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
+  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $T/write -- python bench.py --model $M --dtype $D --batch $B --size $S --no-cpu-baseline --no-graph --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
+  python scratch/pmc_summary.py $(ls $T/fetch/*/*counter_collection.csv) $(ls $T/write/*/*counter_collection.csv) $O/pmc_traffic_$M.json 4 $M:$D:$B:$S > $O/pmc_$M.txt
+  timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --kernel-trace --output-format csv -d $T/sq -- python bench.py --model $M --dtype $D --batch $B --size $S --no-cpu-baseline --no-graph --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
+  python scratch/sq_summary.py $(ls $T/sq/*/*counter_collection.csv) $O/sq_counters_$M.json $M:$D:$B:$S 4 > $O/sq_$M.txt
+  rm -rf $T
+}
+pmc densenet121 bf16 256 320
+for spec in "aadensenet121 128 320" "resnet152 128 320" "efficientnet-b4 64 380"; do
+  set -- $spec
+  timeout -k 10 300 python bench.py --model $1 --batch $2 --size $3 --no-cpu-baseline > $O/bench_$1.json 2>> $O/bench.err || true
+  pmc $1 bf16 $2 $3 || true
+done
+tail -2 $O/tests.log; cat $O/bench.json; cat $O/sq_densenet121.txt

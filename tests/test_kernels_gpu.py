@@ -415,6 +415,14 @@ def test_bn_backward_coefficients(dev):
     G, x = rnd(112, (7, Cn)), rnd(113, (7, Cn))
     want = G - A.cpu() - (x - mu) * r * Bc.cpu()
     close(G * qa.cpu() + x * qb.cpu() + qc.cpu(), want, rel=1e-5)
+    # the same slice vectors emitted by cx_bn_bwd_coef itself for a sub-range (fused form: one launch per consumer)
+    A2, B2 = t(A0), t(B0)
+    dg2, db2 = t(dg0), t(db0)
+    q2 = [torch.full((24,), 9.0, device=dev) for _ in range(3)]
+    ops.bn_bwd_coef(t(S1), t(S2), cnt, t(gamma), t(mu), t(r), dg2, db2, A2, B2, None, None, None, Cn, q=(q2[0], q2[1], q2[2], 8, 24))
+    assert torch.equal(A2, A) and torch.equal(B2, Bc)
+    for a, b in zip(q2, (qa, qb, qc)):
+        assert torch.equal(a, b[8:32])
 
 
 @pytest.mark.parametrize("kind", ["adam", "sgd_nesterov", "rmsprop"])
