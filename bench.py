@@ -99,7 +99,7 @@ class KernelTimer:
                 wide = kw["N"] >= 128
                 v1 = os.environ.get("CX_PW_BWD_V1", "0") not in ("", "0")
                 acc_s = "true" if kw.get("accumulate") else "false"
-                tag = ("pw_bwd2_kernel<%d, %s>" % (kw.get("prologue", 0), acc_s)) if wide and not v1 else \
+                tag = ("pw_bwd2_kernel<%d, %s, 0>" % (kw.get("prologue", 0), acc_s)) if wide and not v1 else \
                     ("pw_bwd_kernel<%d, %s, %d>" % (kw.get("prologue", 0), acc_s, 128 if wide else 64))
                 alg += 2.0 * mo * co                 # the weight-gradient half also needs the layer input (|dZ| counted once)
             if self.only is not None and tag != self.only:
