@@ -686,10 +686,12 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
                                                              const float* __restrict__ r_a, const bf16* __restrict__ b,
                                                              const float* __restrict__ mu_b, const float* __restrict__ r_b,
                                                              bf16* __restrict__ dz, float* S1, float* S2a, float* S2b, size_t rows,
-                                                             int C) {
-  extern __shared__ float lds[];          // [3][C]
+                                                             int C, int det) {
+  extern __shared__ float lds[];          // [3][C] (atomic mode) / [256][24] (deterministic rows)
   const int CP = C / 8;
-  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) lds[i] = 0.f;
+  if (!det) {
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) lds[i] = 0.f;
+  }
   __syncthreads();
   // CP may exceed the block: thread handles chunk columns cq = tid % CP only when CP divides 256, else strided generic path
   float s1[8], s2[8], s3[8];
@@ -721,6 +723,28 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
       d.e[j] = f2bf(dzv);
     }
     *reinterpret_cast<uint4*>(dz + idx * 8) = d.u;
+  }
+  if (det) {               // one row per workgroup, partial sums of the threads sharing a chunk folded in thread order
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      lds[threadIdx.x * 24 + j] = s1[j];
+      lds[threadIdx.x * 24 + 8 + j] = s2[j];
+      lds[threadIdx.x * 24 + 16 + j] = s3[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const int chunk = c >> 3, j = c & 7;
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      for (int t = chunk; t < (int)blockDim.x; t += CP) {
+        t1 += lds[t * 24 + j];
+        t2 += lds[t * 24 + 8 + j];
+        t3 += lds[t * 24 + 16 + j];
+      }
+      S1[(size_t)blockIdx.x * C + c] = t1;
+      S2a[(size_t)blockIdx.x * C + c] = t2;
+      if (b) S2b[(size_t)blockIdx.x * C + c] = t3;
+    }
+    return;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -1277,14 +1301,17 @@ int cx_affine2_relu(const void* a, const void* b, const float* pa, const float* 
 
 int cx_relu_bwd_stats(const void* dout, const void* out, const void* a, const float* mu_a, const float* r_a, const void* b,
                       const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b, size_t rows, int C,
-                      void* stream) {
+                      int stat_rows, void* stream) {
   if (!dout || !out || !a || !mu_a || !r_a || !dz || !S1 || !S2a) return CX_EINVAL;
   if (b && (!mu_b || !r_b || !S2b)) return CX_EINVAL;
   if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8)) return CX_ESHAPE;
   if (C / 8 > 256) return CX_ESHAPE;
-  hipLaunchKernelGGL(relu_bwd_stats_kernel, dim3(grid_for(rows * (C / 8), 256, 2048)), dim3(256), 3 * C * sizeof(float),
+  int grid = grid_for(rows * (C / 8), 256, 2048);
+  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  const size_t lds_bytes = (stat_rows > 0 ? (size_t)256 * 24 : (size_t)3 * C) * sizeof(float);
+  hipLaunchKernelGGL(relu_bwd_stats_kernel, dim3(grid), dim3(256), lds_bytes,
                      as_stream(stream), (const bf16*)dout, (const bf16*)out, (const bf16*)a, mu_a, r_a, (const bf16*)b, mu_b, r_b,
-                     (bf16*)dz, S1, S2a, S2b, rows, C);
+                     (bf16*)dz, S1, S2a, S2b, rows, C, stat_rows > 0 ? 1 : 0);
   return launch_status();
 }
 

@@ -102,8 +102,15 @@ class _Region(_Vec):
 
 
 class _Engine:
+    SLAB = 1 << 22               # floats per statistic-row scratch (rows x channels of the largest producer)
+    EW_ROWS = 2048
+
     def __init__(self, model):
+        import os
         self.model = model
+        # deterministic statistics (per-workgroup rows summed in row order, as in the DenseNet engine); the attention-augmented
+        # bottlenecks feed bn2 from two kernels (conv branch + out-projection) and stay on the atomic path
+        self.det = not any(isinstance(m_, AAConv2d) for m_ in model.modules()) and os.environ.get("CHEXPERT_DET", "1") != "0"
         self.flat = None
         self.device = None
         self.pool = {}
@@ -249,6 +256,7 @@ class _Engine:
             ws.blk.append(t)
             h, w = ho, wo
         ws.pooled = torch.empty(B, 2048, dtype=torch.float32, device=dev)
+        ws.slab = torch.empty(3, self.SLAB, dtype=torch.float32, device=dev) if self.det else None
         ws.logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=dev)
         ws.vec = torch.zeros(self.vec_size, dtype=torch.float32, device=dev)
         o, n = self.ones
@@ -266,12 +274,21 @@ class _Engine:
         off, m = slot
         return ws.vec[off:off + (m if n is None else n)]
 
-    def _bn_coef(self, ws, bn, count, train):
+    def _sp(self, ws, S, train):
+        """Statistics arguments of a producer of BatchNorm S's input."""
+        if not train:
+            return {}
+        if self.det:
+            return dict(stat_sum=ws.slab[0], stat_sq=ws.slab[1], stat_det=True, stat_replicas=self.SLAB // S.C, stat_rstride=S.C)
+        return dict(stat_sum=self._v(ws, S.sum), stat_sq=self._v(ws, S.sq))
+
+    def _bn_coef(self, ws, bn, count, train, rows=None):
         S, v = self.bn[id(bn)], self._v
         if train:
             mom = bn.momentum if bn.momentum is not None else 0.1
-            ops.bn_coef(v(ws, S.sum), v(ws, S.sq), count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var,
-                        v(ws, S.sc), v(ws, S.sh), v(ws, S.mean), v(ws, S.rstd), S.C)
+            ssum, ssq, reps, rstride = (ws.slab[0], ws.slab[1], rows, S.C) if self.det else (v(ws, S.sum), v(ws, S.sq), 1, 0)
+            ops.bn_coef(ssum, ssq, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var,
+                        v(ws, S.sc), v(ws, S.sh), v(ws, S.mean), v(ws, S.rstd), S.C, replicas=reps, rstride=rstride)
         else:
             ops.bn_coef_eval(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, v(ws, S.sc), v(ws, S.sh), v(ws, S.mean),
                              v(ws, S.rstd), S.C)
@@ -288,16 +305,18 @@ class _Engine:
         self.bind(x.device)
         self.pack(train)
         ws = self.acquire(B, H, W)
-        z0, zn = self.fwd_zero
-        ws.vec[z0:z0 + zn].zero_()
+        if train and not self.det:
+            z0, zn = self.fwd_zero
+            ws.vec[z0:z0 + zn].zero_()
         st = (lambda s: v(ws, s)) if train else (lambda s: None)
+        sp = lambda S_: self._sp(ws, S_, train)
         S0 = self.bn[id(m.bn1)]
         if u8:
             ops.u8_to_nhwc4(x.contiguous(), ws.x4)
         else:
             ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
-        ops.conv_gemm(ws.x4, self.w_fwd(m.conv1), ws.c0, N=64, mode=ops.MODE_STEM, stat_sum=st(S0.sum), stat_sq=st(S0.sq))
-        self._bn_coef(ws, m.bn1, B * (H // 2) * (W // 2), train)
+        rows = ops.conv_gemm(ws.x4, self.w_fwd(m.conv1), ws.c0, N=64, mode=ops.MODE_STEM, **sp(S0))
+        self._bn_coef(ws, m.bn1, B * (H // 2) * (W // 2), train, rows)
         ops.bnrelu_maxpool_fwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), ws.pool0, ws.amax, None, None)
         xin = ws.pool0
         for bi, b in enumerate(self.blocks):
@@ -306,8 +325,8 @@ class _Engine:
             hi, wi = t["hin"]
             ho, wo = t["hout"]
             S1, S2, S3 = self.bn[id(b.bn1)], self.bn[id(b.bn2)], self.bn[id(b.bn3)]
-            ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, stat_sum=st(S1.sum), stat_sq=st(S1.sq))
-            self._bn_coef(ws, b.bn1, B * hi * wi, train)
+            rows = ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, **sp(S1))
+            self._bn_coef(ws, b.bn1, B * hi * wi, train, rows)
             if isinstance(b.conv2, AAConv2d):
                 # attn_aug_conv.py:65-97: 3x3 conv branch || multi-head attention over the stride-s grid, concatenated on channels
                 aa, sub = b.conv2, (lambda slot, lo, n: None if slot is None else slot[lo:lo + n])
@@ -320,18 +339,19 @@ class _Engine:
                 ops.aa_attention_fwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], t["LSE"], aa.nh, aa.dk, aa.dv)
                 object.__setattr__(aa, "_last", (t["QKV"], t["LSE"]))
                 ops.aa_outproj_fwd(t["O"], aa.out_proj.weight, t["y2"][..., cc:], sub(st(S2.sum), cc, aa.dv), sub(st(S2.sq), cc, aa.dv))
+                rows = None
             else:
-                ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=s_, pad=1, prologue=ops.PRO_AFFINE_RELU,
-                              pa=v(ws, S1.sc), pb=v(ws, S1.sh), stat_sum=st(S2.sum), stat_sq=st(S2.sq))
-            self._bn_coef(ws, b.bn2, B * ho * wo, train)
-            ops.conv_gemm(t["y2"], self.w_fwd(b.conv3), t["y3"], N=4 * p_, prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S2.sc),
-                          pb=v(ws, S2.sh), stat_sum=st(S3.sum), stat_sq=st(S3.sq))
-            self._bn_coef(ws, b.bn3, B * ho * wo, train)
+                rows = ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=s_, pad=1,
+                                     prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh), **sp(S2))
+            self._bn_coef(ws, b.bn2, B * ho * wo, train, rows)
+            rows = ops.conv_gemm(t["y2"], self.w_fwd(b.conv3), t["y3"], N=4 * p_, prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S2.sc),
+                                 pb=v(ws, S2.sh), **sp(S3))
+            self._bn_coef(ws, b.bn3, B * ho * wo, train, rows)
             ja, jb, jc = (v(ws, sl) for sl in self.join[bi])
             if b.downsample is not None:
                 Sd = self.bn[id(b.downsample[1])]
-                ops.conv_gemm(xin, self.w_fwd(b.downsample[0]), t["yd"], N=4 * p_, stride=s_, stat_sum=st(Sd.sum), stat_sq=st(Sd.sq))
-                self._bn_coef(ws, b.downsample[1], B * ho * wo, train)
+                rows = ops.conv_gemm(xin, self.w_fwd(b.downsample[0]), t["yd"], N=4 * p_, stride=s_, **sp(Sd))
+                self._bn_coef(ws, b.downsample[1], B * ho * wo, train, rows)
                 torch.add(v(ws, S3.sh), v(ws, Sd.sh), out=jc)
                 ops.affine2_relu(t["y3"], t["yd"], v(ws, S3.sc), v(ws, Sd.sc), jc, t["out"])
             else:
@@ -388,6 +408,18 @@ class _Engine:
         if red is not None:
             red.begin()
         done = (lambda p: red.ready(self.off_of[id(p)])) if red is not None else (lambda p: None)
+        det = self.det
+        ew = lambda C: min(self.EW_ROWS, self.SLAB // C)
+
+        def msp(S_):         # statistics arguments of a mask-epilogue producer of BatchNorm S_'s backward sums
+            if det:
+                return dict(stat_sum=ws.slab[0], stat_sq=ws.slab[1], stat_det=True, stat_replicas=self.SLAB // S_.C, stat_rstride=S_.C)
+            return dict(stat_sum=v(ws, S_.S1), stat_sq=v(ws, S_.S2))
+
+        def srows(S_, rows, second=None):      # (S1, S2, replicas, rstride) for cx_bn_bwd_coef
+            if det:
+                return ws.slab[0], (ws.slab[1] if second is None else second), rows, S_.C
+            return v(ws, S_.S1), v(ws, S_.S2), 1, 0
         ones = lambda n: v(ws, self.ones, n)
         zeros = lambda n: v(ws, self.zeros, n)
         last = ws.blk[-1]["out"]
@@ -408,22 +440,35 @@ class _Engine:
             Sd = self.bn[id(b.downsample[1])] if b.downsample is not None else None
             g = bw["g"][bi]
             # residual join backward: dz = dOut * [out > 0] (in place), statistics for bn3 (and the downsample BN)
-            ops.relu_bwd_stats(g, t["out"], t["y3"], v(ws, S3.mean), v(ws, S3.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
-                               v(ws, Sd.rstd) if Sd else None, g, v(ws, S3.S1), v(ws, S3.S2), v(ws, Sd.S2) if Sd else None)
             cnt_o, cnt_i = B * ho * wo, B * hi * wi
-            ops.bn_bwd_coef(v(ws, S3.S1), v(ws, S3.S2), cnt_o, b.bn3.weight, v(ws, S3.mean), v(ws, S3.rstd), G(b.bn3.weight),
-                            G(b.bn3.bias), None, None, v(ws, S3.pa), v(ws, S3.pb), v(ws, S3.pc), S3.C)
+            if det:
+                rows = ops.relu_bwd_stats(g, t["out"], t["y3"], v(ws, S3.mean), v(ws, S3.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
+                                          v(ws, Sd.rstd) if Sd else None, g, ws.slab[0], ws.slab[1], ws.slab[2] if Sd else None,
+                                          stat_rows=ew(S3.C))
+            else:
+                rows = None
+                ops.relu_bwd_stats(g, t["out"], t["y3"], v(ws, S3.mean), v(ws, S3.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
+                                   v(ws, Sd.rstd) if Sd else None, g, v(ws, S3.S1), v(ws, S3.S2), v(ws, Sd.S2) if Sd else None)
+            r3 = srows(S3, rows)
+            ops.bn_bwd_coef(r3[0], r3[1], cnt_o, b.bn3.weight, v(ws, S3.mean), v(ws, S3.rstd), G(b.bn3.weight),
+                            G(b.bn3.bias), None, None, v(ws, S3.pa), v(ws, S3.pb), v(ws, S3.pc), S3.C, replicas=r3[2], rstride=r3[3])
+            if Sd is not None and det:       # the downsample BatchNorm shares S1 with bn3: reduce it before the rows are re-used
+                bnd = b.downsample[1]
+                rd = srows(S3, rows, ws.slab[2])
+                ops.bn_bwd_coef(rd[0], rd[1], cnt_o, bnd.weight, v(ws, Sd.mean), v(ws, Sd.rstd), G(bnd.weight), G(bnd.bias), None, None,
+                                v(ws, Sd.pa), v(ws, Sd.pb), v(ws, Sd.pc), Sd.C, replicas=rd[2], rstride=rd[3])
             dz2 = bw["dz2"][:B * ho * wo * p_].view(B, ho, wo, p_)
-            ops.conv_gemm(g, self.w_bwd(b.conv3), dz2, N=p_, prologue=ops.PRO_AFFINE2, x2=t["y3"], pa=v(ws, S3.pa), pb=v(ws, S3.pb),
-                          pc=v(ws, S3.pc), epilogue=ops.EPI_MASK, ex=t["y2"], e_sc=v(ws, S2.sc), e_sh=v(ws, S2.sh), e_mu=v(ws, S2.mean),
-                          e_r=v(ws, S2.rstd), e_scale=ones(p_), stat_sum=v(ws, S2.S1), stat_sq=v(ws, S2.S2))
+            rows = ops.conv_gemm(g, self.w_bwd(b.conv3), dz2, N=p_, prologue=ops.PRO_AFFINE2, x2=t["y3"], pa=v(ws, S3.pa),
+                                 pb=v(ws, S3.pb), pc=v(ws, S3.pc), epilogue=ops.EPI_MASK, ex=t["y2"], e_sc=v(ws, S2.sc),
+                                 e_sh=v(ws, S2.sh), e_mu=v(ws, S2.mean), e_r=v(ws, S2.rstd), e_scale=ones(p_), **msp(S2))
+            r2 = srows(S2, rows)
             ops.conv_wgrad(g, t["y2"], G(b.conv3.weight), g_prologue=ops.PRO_AFFINE2, g2=t["y3"], ga=v(ws, S3.pa), gb=v(ws, S3.pb),
                            gc=v(ws, S3.pc), x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S2.sc), pb=v(ws, S2.sh))
-            ops.bn_bwd_coef(v(ws, S2.S1), v(ws, S2.S2), cnt_o, b.bn2.weight, v(ws, S2.mean), v(ws, S2.rstd), G(b.bn2.weight),
-                            G(b.bn2.bias), None, None, v(ws, S2.pa), v(ws, S2.pb), v(ws, S2.pc), S2.C)
+            ops.bn_bwd_coef(r2[0], r2[1], cnt_o, b.bn2.weight, v(ws, S2.mean), v(ws, S2.rstd), G(b.bn2.weight),
+                            G(b.bn2.bias), None, None, v(ws, S2.pa), v(ws, S2.pb), v(ws, S2.pc), S2.C, replicas=r2[2], rstride=r2[3])
             dz1 = bw["dz1"][:B * hi * wi * p_].view(B, hi, wi, p_)
             mask1 = dict(epilogue=ops.EPI_MASK, ex=t["y1"], e_sc=v(ws, S1.sc), e_sh=v(ws, S1.sh), e_mu=v(ws, S1.mean),
-                         e_r=v(ws, S1.rstd), e_scale=ones(p_), stat_sum=v(ws, S1.S1), stat_sq=v(ws, S1.S2))
+                         e_r=v(ws, S1.rstd), e_scale=ones(p_), **msp(S1))
             if isinstance(b.conv2, AAConv2d):
                 aa = b.conv2
                 cc = p_ - aa.dv
@@ -445,13 +490,14 @@ class _Engine:
                 ops.conv_wgrad(dQ, t["y1"], G(aa.in_proj_qkv.weight), stride=s_, x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc),
                                pb=v(ws, S1.sh))
             else:
-                ops.conv_gemm(dz2, self.w_bwd(b.conv2), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["y2"],
-                              pa=v(ws, S2.pa), pb=v(ws, S2.pb), pc=v(ws, S2.pc), **mask1)
+                rows = ops.conv_gemm(dz2, self.w_bwd(b.conv2), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2,
+                                     x2=t["y2"], pa=v(ws, S2.pa), pb=v(ws, S2.pb), pc=v(ws, S2.pc), **mask1)
                 ops.conv_wgrad(dz2, t["y1"], G(b.conv2.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=t["y2"],
                                ga=v(ws, S2.pa), gb=v(ws, S2.pb), gc=v(ws, S2.pc), x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc),
                                pb=v(ws, S1.sh))
-            ops.bn_bwd_coef(v(ws, S1.S1), v(ws, S1.S2), cnt_i, b.bn1.weight, v(ws, S1.mean), v(ws, S1.rstd), G(b.bn1.weight),
-                            G(b.bn1.bias), None, None, v(ws, S1.pa), v(ws, S1.pb), v(ws, S1.pc), S1.C)
+            r1 = srows(S1, rows)
+            ops.bn_bwd_coef(r1[0], r1[1], cnt_i, b.bn1.weight, v(ws, S1.mean), v(ws, S1.rstd), G(b.bn1.weight),
+                            G(b.bn1.bias), None, None, v(ws, S1.pa), v(ws, S1.pb), v(ws, S1.pc), S1.C, replicas=r1[2], rstride=r1[3])
             gx = (bw["g"][bi - 1] if bi > 0 else bw["g_in0"]) if Sd is not None or bi == 0 else g
             identity = Sd is None
             if identity and gx is not g:
@@ -462,8 +508,9 @@ class _Engine:
                            gc=v(ws, S1.pc))
             if Sd is not None:
                 bnd, convd = b.downsample[1], b.downsample[0]
-                ops.bn_bwd_coef(v(ws, S3.S1), v(ws, Sd.S2), cnt_o, bnd.weight, v(ws, Sd.mean), v(ws, Sd.rstd), G(bnd.weight),
-                                G(bnd.bias), None, None, v(ws, Sd.pa), v(ws, Sd.pb), v(ws, Sd.pc), Sd.C)
+                if not det:
+                    ops.bn_bwd_coef(v(ws, S3.S1), v(ws, Sd.S2), cnt_o, bnd.weight, v(ws, Sd.mean), v(ws, Sd.rstd), G(bnd.weight),
+                                    G(bnd.bias), None, None, v(ws, Sd.pa), v(ws, Sd.pb), v(ws, Sd.pc), Sd.C)
                 ops.conv_gemm(g, self.w_bwd(convd), gx, N=cin, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["yd"], pa=v(ws, Sd.pa),
                               pb=v(ws, Sd.pb), pc=v(ws, Sd.pc), accumulate=True)
                 ops.conv_wgrad(g, xin, G(convd.weight), stride=s_, g_prologue=ops.PRO_AFFINE2, g2=t["yd"], ga=v(ws, Sd.pa),
@@ -472,10 +519,17 @@ class _Engine:
         # stem
         S0 = self.bn[id(m.bn1)]
         gx = bw["g_in0"]
-        ops.bnrelu_maxpool_bwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), v(ws, S0.mean), v(ws, S0.rstd), ws.amax, gx, gx, ones(64), zeros(64),
-                               zeros(64), bw["dz0"], v(ws, S0.S1), v(ws, S0.S2))
-        ops.bn_bwd_coef(v(ws, S0.S1), v(ws, S0.S2), B * (ws.H // 2) * (ws.W // 2), m.bn1.weight, v(ws, S0.mean), v(ws, S0.rstd),
-                        G(m.bn1.weight), G(m.bn1.bias), None, None, v(ws, S0.pa), v(ws, S0.pb), v(ws, S0.pc), 64)
+        if det:
+            rows = ops.bnrelu_maxpool_bwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), v(ws, S0.mean), v(ws, S0.rstd), ws.amax, gx, gx, ones(64),
+                                          zeros(64), zeros(64), bw["dz0"], ws.slab[0], ws.slab[1], stat_rows=ew(64))
+        else:
+            rows = None
+            ops.bnrelu_maxpool_bwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), v(ws, S0.mean), v(ws, S0.rstd), ws.amax, gx, gx, ones(64),
+                                   zeros(64), zeros(64), bw["dz0"], v(ws, S0.S1), v(ws, S0.S2))
+        r0 = srows(S0, rows)
+        ops.bn_bwd_coef(r0[0], r0[1], B * (ws.H // 2) * (ws.W // 2), m.bn1.weight, v(ws, S0.mean), v(ws, S0.rstd),
+                        G(m.bn1.weight), G(m.bn1.bias), None, None, v(ws, S0.pa), v(ws, S0.pb), v(ws, S0.pc), 64, replicas=r0[2],
+                        rstride=r0[3])
         ops.conv_wgrad(bw["dz0"], ws.x4, G(m.conv1.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0, ga=v(ws, S0.pa),
                        gb=v(ws, S0.pb), gc=v(ws, S0.pc))
         if red is not None:

@@ -253,11 +253,12 @@ def affine2_relu(a, b, pa, pb, pc, out):
     check(lib().cx_affine2_relu(ptr(a), ptr(b), ptr(pa), ptr(pb), ptr(pc), ptr(out), B * H * W, Cc, stream_ptr()), "cx_affine2_relu")
 
 
-def relu_bwd_stats(dout, out, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b):
+def relu_bwd_stats(dout, out, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b, stat_rows=0):
     B, H, W, Cc, ld = _nhwc(dout)
     assert ld == Cc
     check(lib().cx_relu_bwd_stats(ptr(dout), ptr(out), ptr(a), ptr(mu_a), ptr(r_a), ptr(b), ptr(mu_b), ptr(r_b), ptr(dz), ptr(S1),
-                                  ptr(S2a), ptr(S2b), B * H * W, Cc, stream_ptr()), "cx_relu_bwd_stats")
+                                  ptr(S2a), ptr(S2b), B * H * W, Cc, stat_rows, stream_ptr()), "cx_relu_bwd_stats")
+    return lib().cx_last_stat_rows() if stat_rows else None
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

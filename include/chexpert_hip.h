@@ -220,7 +220,7 @@ int cx_affine2_relu(const void* a, const void* b, const float* pa, const float* 
  * (b / S2b optional).  dz may alias dout.                                                         */
 int cx_relu_bwd_stats(const void* dout, const void* out, const void* a, const float* mu_a, const float* r_a, const void* b,
                       const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b, size_t rows, int C,
-                      void* stream);
+                      int stat_rows, void* stream);
 
 /* dz (B,H,W,C) bf16 -> dY = dz*pa + x*pb + pc in place (BN0 backward ahead of the stem wgrad)      */
 int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb, const float* pc, size_t rows,
@@ -323,7 +323,7 @@ int cx_gradcam_map(const void* x, const float* scale, const float* shift, const 
                    int ldx, int inner_relu, void* stream);
 int cx_cam_norm_upsample(const float* cam, float* out, int B, int h, int w, int H, int W, void* stream);
 
-/* stat_rows (cx_bnrelu_maxpool_fwd / _bwd, cx_gap_relu_bn_bwd, cx_unpool2_mask): 0 = the statistics are added to the single
+/* stat_rows (cx_bnrelu_maxpool_fwd / _bwd, cx_gap_relu_bn_bwd, cx_unpool2_mask, cx_relu_bwd_stats): 0 = the statistics are added to the single
  * copy S1 / S2 [C] with atomics; > 0 = deterministic rows: the launch uses at most stat_rows workgroups (cx_gap_relu_bn_bwd: one row
  * per image, B <= stat_rows) and plain-stores row r at S[r*C + c]; cx_last_stat_rows() gives the row count for the consumer.   */
 

@@ -274,3 +274,30 @@ def test_training_step_is_reproducible_bit_for_bit(dev, cfg, B, S):
                 worst = max(worst, float((g0 - gi).abs().max() / (g0.abs().max() + 1e-20)))
         print("run 0 vs %d: norm-parameter gradients bit-identical; conv / linear weight gradients within %.2e" % (i, worst))
         assert worst < 1e-5
+
+
+def test_resnet_training_step_is_reproducible_bit_for_bit(dev):
+    """The plain Bottleneck ResNet engine on deterministic statistic rows (conv epilogues, the residual-join backward
+    cx_relu_bwd_stats with its three sums, the stem pool backward)."""
+    from chexpert_amd.models import Bottleneck, ResNet
+    torch.manual_seed(12)
+    model = ResNet(Bottleneck, [1, 2, 2, 1], num_classes=5).to(dev).train()
+    assert model._eng().det
+    x, t = synth.xray_batch(510, 4, 64).to(dev), synth.targets(511, 4, 5).to(dev)
+    runs = []
+    for _ in range(3):
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        model.zero_grad()
+        loss, logits = model.forward_backward(x, t)
+        runs.append((loss.clone(), logits.clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+        model.load_state_dict(sd)
+    for i in (1, 2):
+        assert torch.equal(runs[0][0], runs[i][0]) and torch.equal(runs[0][1], runs[i][1])
+        worst = 0.0
+        for k, g0 in runs[0][2].items():
+            gi = runs[i][2][k]
+            if g0.dim() == 1 and not k.startswith("fc"):
+                assert torch.equal(g0, gi), "%s differs between runs" % k
+            else:
+                worst = max(worst, float((g0 - gi).abs().max() / (g0.abs().max() + 1e-20)))
+        assert worst < 1e-5, worst
