@@ -300,7 +300,12 @@ def main():
         return model.forward_backward(x, t)
 
     log("model + data ready")
-    loss, _ = step()                           # binds the engine, allocates workspaces
+    if world > 1:                               # replicas start identical and average their gradients from the first step on
+        from chexpert_amd.parallel import broadcast_module_state
+        model._eng().bind(dev)
+        broadcast_module_state(model)
+        model._eng().enable_data_parallel()
+    loss, _ = step()                           # binds the engine (N = 1), allocates workspaces
     torch.cuda.synchronize()
     log("first step done, loss %.4f" % loss.item())
     try:
@@ -308,10 +313,6 @@ def main():
     except (AttributeError, RuntimeError) as e: # an engine without flat parameter buffers: forward+backward only
         log("no fused optimiser for this model (%s)" % e)
         opt = None
-    if world > 1:
-        from chexpert_amd.parallel import broadcast_module_state
-        broadcast_module_state(model)
-        model._eng().enable_data_parallel()
     for _ in range(max(0, args.warmup - 1)):
         model.zero_grad()
         step()
