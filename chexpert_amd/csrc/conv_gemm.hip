@@ -398,6 +398,7 @@ int cx_try_pw_fwd(const CxConv& p, hipStream_t st, bool* handled);          // c
 int cx_try_pw_fwdk(const CxConv& p, hipStream_t st, bool* handled);         // conv1x1_fwdk.hip
 int cx_try_stem_fwd(const CxConv& p, hipStream_t st, bool* handled);        // conv_stem.hip
 int cx_conv_gemm_f32(const CxConv& p, hipStream_t st);                      // conv_f32.hip
+int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled);         // conv_mm.hip
 
 thread_local int cx_tl_stat_rows = 0;
 extern "C" int cx_last_stat_rows(void) { return cx_tl_stat_rows; }
@@ -472,6 +473,8 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
       rc = cx_try_pw_fwd(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_pw_fwdk(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_conv_mm(p, st, &handled);
       if (handled) return rc;
     }
     if (p.epilogue == CX_EPI_STORE) {

@@ -1,0 +1,552 @@
+// Implicit-GEMM convolution for the MFMA-heavy shapes (ResNet bottlenecks, EfficientNet / AAConv 1x1 with wide channels):
+// K % 64 == 0 input channels per tap, N % 128 == 0 output channels, NHWC bf16, any kernel size / stride / transposed stride.
+//
+//   Y[m][n] = sum_{tap,c} A(m, tap, c) * W[tap][n][c]        m = (b, oy, ox) flattened
+//
+// What differs from conv_gemm.hip (which stays the path for narrow / ragged channel counts): these shapes are bound by the
+// vector-memory path of a CU (L2 -> L1 -> registers, ~56-64 B/clk/CU), not by HBM, and a k-step of the 128x128x32 kernel
+// is one L2 round trip long (loads requested at the top of a step are staged at its bottom: bytes in flight per CU ~ 48 KB).
+// Here: 64 input channels per step (half the barriers), 128 x 128, 256 x 128 or 128 x 256 output tiles, and the operands of step
+// s+2 are requested while step s multiplies - two register sets, so two steps are always in flight.  Measured with s_memtime
+// stamps, a step is bound by vector-instruction issue (two waves per SIMD: ~8 cycles per instruction per wave), not by MFMA or
+// bandwidth, so the instruction streams are kept short: per staged row one bit-field extract (tap validity, precomputed per
+// tile), one add of the step's scalar byte offset and one AND; 32-bit offsets against scalar bases; ReLU on packed bf16.
+// Prologues (BN + ReLU, two-tensor BN-backward form) are applied once per element on the way to LDS; epilogues (store /
+// accumulate / ReLU-mask + BN-backward sums, statistic rows) are those of conv_gemm.hip.
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: copies of it become memcpys that pin register sets to scratch)
+
+#ifndef CX_MM_INTERLEAVE
+#define CX_MM_INTERLEAVE 1
+#endif
+constexpr bool kInterleave = CX_MM_INTERLEAVE;
+constexpr int BK = 64;
+constexpr int PITCH = 144;             // bytes per LDS row: 64 bf16 + 16 B pad (36 dwords: ds_read_b128 fragment reads conflict-free)
+
+// A workgroup is WMW x WNW waves, each wave owns a 64 x 64 output block: (2,2) = 128 x 128 with 256 threads (two workgroups per
+// CU), (4,2) = 256 x 128 and (2,4) = 128 x 256 with 512 threads (one per CU).  The 128 x 256 form transforms each activation
+// once per 256 output channels: the prologue arithmetic per MFMA halves, which is what bounds these kernels (vector issue).
+template <int WMW, int WNW>
+struct MG {
+  static constexpr int BM = 64 * WMW;
+  static constexpr int BN = 64 * WNW;
+  static constexpr int NW = WMW * WNW;
+  static constexpr int NT = 64 * NW;
+  static constexpr int RSTEP = NT / 8;                  // rows covered by one staging pass (8 chunks of 16 B per row)
+  static constexpr int NA = BM / RSTEP;                 // activation rows per thread per step
+  static constexpr int NB = BN / RSTEP;                 // weight rows per thread per step
+  static constexpr int A_BYTES = BM * PITCH;
+  static constexpr int B_BYTES = BN * PITCH;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int EPITCH = BN + 4;
+  static constexpr int MAIN_BYTES = 2 * STAGE;          // > 64 * EPITCH * 4 (epilogue tile) and > NW * 2 * BN * 4 (statistics)
+};
+
+template <int PRO>
+struct NCoef {
+  static constexpr int v = (PRO == CX_PRO_NONE) ? 0 : (PRO == CX_PRO_AFFINE_RELU ? 2 : 3);
+};
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t packbf(float a, float b) {      // one v_cvt_pk_bf16_f32 (RNE)
+  union {
+    bf16x2 h;
+    uint32_t u;
+  } o;
+  o.h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+  return o.u;
+}
+// relu on a packed pair of bf16: as 16-bit integers the negative values (sign bit) are below zero
+__device__ __forceinline__ uint32_t relu_pk(uint32_t v) {
+  union {
+    uint32_t u;
+    s16x2 s;
+  } a, r;
+  a.u = v;
+  r.s = __builtin_elementwise_max(a.s, s16x2{0, 0});
+  return r.u;
+}
+// 16 B at base + 32-bit byte offset (the scalar-base form of global_load: no 64-bit vector arithmetic per load)
+__device__ __forceinline__ u32x4 ld16(const char* base, uint32_t off) { return *reinterpret_cast<const u32x4*>(base + (size_t)off); }
+
+// diagnostic build (DBG): s_memtime phase sums of the main loop per workgroup, waves 0 and NW-1: [issue, multiply, stage, barrier, steps]
+__device__ unsigned long long conv_mm_stamps[2048 * 2 * 8];
+
+template <int WMW, int WNW, int PRO, int EPI, bool DBG = false>
+__global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mm_kernel(const CxConv p, const int M,
+                                                                                                          const int n_tiles) {
+  using G = MG<WMW, WNW>;
+  constexpr int BN = G::BN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);                       // [NCoef][K]
+  char* tiles = smem + NCoef<PRO>::v * p.K * 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = wgid / n_tiles, nt = wgid - mt * n_tiles;
+  const int n0 = nt * BN;
+
+  if (PRO != CX_PRO_NONE) {
+    for (int i = tid; i < p.K; i += G::NT) {
+      coef[i] = p.pa[i];
+      coef[p.K + i] = p.pb[i];
+      if (PRO == CX_PRO_AFFINE2) coef[2 * p.K + i] = p.pc[i];
+    }
+  }
+
+  // ---- staging geometry: 16-byte chunk qa of rows r0 + RSTEP * i.  Per row: byte offset of its (tap 0, channel 0) element and
+  // one validity bit per tap; inside the loop a row costs a bit-field extract, an add of the step's scalar offset and an AND.
+  const int qa = tid & 7;
+  const int r0 = tid >> 3;
+  const int ntaps = p.kh * p.kw;
+  uint32_t roff[G::NA], roff2[G::NA], vbits[G::NA];
+#pragma unroll
+  for (int i = 0; i < G::NA; ++i) {
+    const int m = mt * G::BM + r0 + G::RSTEP * i;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int hw = p.Ho * p.Wo;
+    const int b = mm / hw;
+    const int rem = mm - b * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    const int pix = (b * p.H + iy0) * p.W + ix0;          // may be "negative": only used where the tap is valid
+    roff[i] = ((uint32_t)pix * (uint32_t)p.ldx + qa * 8) * 2u;
+    roff2[i] = ((uint32_t)pix * (uint32_t)p.ldx2 + qa * 8) * 2u;
+    // tap (dy, dx) is valid where row iy0 + dy and column ix0 + dx exist: separable, so kh + kw tests instead of kh * kw
+    uint32_t xb = 0, bits = 0;
+#pragma nounroll
+    for (int dx = 0; dx < p.kw; ++dx) xb |= ((uint32_t)(ix0 + dx) < (uint32_t)p.W) ? (1u << dx) : 0u;
+#pragma nounroll
+    for (int dy = 0; dy < p.kh; ++dy) bits |= (ok && (uint32_t)(iy0 + dy) < (uint32_t)p.H) ? (xb << (dy * p.kw)) : 0u;
+    vbits[i] = bits;
+  }
+  const int kpt = p.K / BK;
+  const int nsteps = ntaps * kpt;
+  const char* __restrict__ X = reinterpret_cast<const char*>(p.x);
+  const char* __restrict__ X2 = reinterpret_cast<const char*>(p.x2);
+  const char* __restrict__ Wb = reinterpret_cast<const char*>(p.w);
+  uint32_t woff[G::NB];
+#pragma unroll
+  for (int i = 0; i < G::NB; ++i) woff[i] = ((uint32_t)(n0 + r0 + G::RSTEP * i) * (uint32_t)p.K + qa * 8) * 2u;
+  const uint32_t wtap = (uint32_t)p.N * (uint32_t)p.K * 2u;      // weight bytes per tap
+
+  // Activations: two register sets (requests run two steps ahead of the multiplication).  Weights: one set, requested one step
+  // ahead - each row is requested again right after it has been stored to LDS (they come from L2, and a second set does not fit).
+  struct Regs {
+    u32x4 a[G::NA], a2[G::NA];
+    int tap, kc;
+  };
+  Regs set0, set1;
+  u32x4 wreg[G::NB];
+  // next step to request: tap (row, column), channel step; byte offsets of the step inside the activation / weight tensors
+  int q_tap = 0, q_dy = 0, q_dx = 0, q_kc = 0;
+  uint32_t q_x = 0, q_x2 = 0, q_w = 0;
+
+  // Every load is unconditional on an in-bounds address (a branch around a load serialises the prefetch): invalid taps read
+  // offset 0 and are zeroed when staged.
+  auto issue_a = [&](Regs& R, int i) __attribute__((always_inline)) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vbits[i], q_tap, 1);       // 0 or 0xffffffff
+    R.a[i] = ld16(X, (roff[i] + q_x) & m);
+    if (PRO == CX_PRO_AFFINE2) R.a2[i] = ld16(X2, (roff2[i] + q_x2) & m);
+  };
+  auto issue_w = [&](int i) __attribute__((always_inline)) { wreg[i] = ld16(Wb, woff[i] + q_w); };
+  auto advance = [&](Regs& R) __attribute__((always_inline)) {
+    R.tap = q_tap;
+    R.kc = q_kc;
+    q_x += BK * 2;
+    q_x2 += BK * 2;
+    q_w += BK * 2;
+    if (++q_kc == kpt) {
+      q_kc = 0;
+      ++q_tap;
+      if (++q_dx == p.kw) {
+        q_dx = 0;
+        ++q_dy;
+      }
+      q_x = (uint32_t)((q_dy * p.W + q_dx) * p.ldx) * 2u;
+      q_x2 = (uint32_t)((q_dy * p.W + q_dx) * p.ldx2) * 2u;
+      q_w = (uint32_t)q_tap * wtap;
+    }
+  };
+
+  float ca[8], cb[8], cc[8];
+  auto load_coef = [&](const Regs& R) __attribute__((always_inline)) {
+    if (PRO != CX_PRO_NONE) {
+      const int c0 = R.kc * BK + qa * 8;
+      *reinterpret_cast<float4*>(ca) = *reinterpret_cast<const float4*>(coef + c0);
+      *reinterpret_cast<float4*>(ca + 4) = *reinterpret_cast<const float4*>(coef + c0 + 4);
+      *reinterpret_cast<float4*>(cb) = *reinterpret_cast<const float4*>(coef + p.K + c0);
+      *reinterpret_cast<float4*>(cb + 4) = *reinterpret_cast<const float4*>(coef + p.K + c0 + 4);
+      if (PRO == CX_PRO_AFFINE2) {
+        *reinterpret_cast<float4*>(cc) = *reinterpret_cast<const float4*>(coef + 2 * p.K + c0);
+        *reinterpret_cast<float4*>(cc + 4) = *reinterpret_cast<const float4*>(coef + 2 * p.K + c0 + 4);
+      }
+    }
+  };
+  // dword j (two channels) of staged row i -> o[j]; after j == 3 the row is masked and written
+  auto stage_unit = [&](const Regs& R, int i, int j, u32x4& o, char* A) __attribute__((always_inline)) {
+    const uint32_t g = R.a[i][j];
+    if (PRO == CX_PRO_NONE) {
+      o[j] = g;
+    } else if (PRO == CX_PRO_AFFINE_RELU) {
+      o[j] = relu_pk(packbf(fmaf(bf_lo(g), ca[2 * j], cb[2 * j]), fmaf(bf_hi(g), ca[2 * j + 1], cb[2 * j + 1])));
+    } else {
+      const uint32_t y = R.a2[i][j];
+      o[j] = packbf(fmaf(bf_lo(g), ca[2 * j], fmaf(bf_lo(y), cb[2 * j], cc[2 * j])),
+                    fmaf(bf_hi(g), ca[2 * j + 1], fmaf(bf_hi(y), cb[2 * j + 1], cc[2 * j + 1])));
+    }
+    if (j == 3) {
+      o &= (uint32_t)__builtin_amdgcn_sbfe((int)vbits[i], R.tap, 1);
+      *reinterpret_cast<u32x4*>(A + (r0 + G::RSTEP * i) * PITCH + qa * 16) = o;
+    }
+  };
+  auto stage_w = [&](int i, char* Bt) __attribute__((always_inline)) {
+    *reinterpret_cast<u32x4*>(Bt + (r0 + G::RSTEP * i) * PITCH + qa * 16) = wreg[i];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31, lh = lane >> 5;
+  const char* fragA = tiles + (wm * 64 + lrow) * PITCH + lh * 16;
+  const char* fragB = tiles + G::A_BYTES + (wn * 64 + lrow) * PITCH + lh * 16;
+
+  // One step = 16 MFMAs of LDS image `bufc`, and between them, one packet each, the step's other work: the requests of step
+  // (this + 2) into Rn (ISSUE) and the prologue + LDS stores of step (this + 1) from Rc into image `bufn` (STAGE).  The packets
+  // are fenced (sched_barrier) so that vector, memory and LDS instructions issue while the matrix pipe runs: all waves of a
+  // workgroup move in lock step between barriers, and phases of their own would leave every pipe idle most of the time
+  // (measured with s_memtime: 2300 cycles per step in phases, of which the MFMAs need 512).
+  auto step = [&](Regs& Rn, const Regs& Rc, int bufc, int bufn, auto IssueC, auto StageC) __attribute__((always_inline)) {
+    constexpr bool ISSUE = decltype(IssueC)::value, STAGE = decltype(StageC)::value;
+    // (the 128 x 128 form has four staged rows AND four weight rows per thread: fenced, it runs out of registers)
+    constexpr bool FENCE = kInterleave && !(WMW == 2 && WNW == 2);
+    const char* A = fragA + bufc * G::STAGE;
+    const char* Bt = fragB + bufc * G::STAGE;
+    char* As = tiles + bufn * G::STAGE;
+    char* Bs = As + G::A_BYTES;
+    u32x4 o[G::NA];
+    // fragments of the next k group are read ahead of the current group's MFMAs, except in the two-tensor forms with four staged
+    // rows per thread, which have no registers left for a second fragment set
+    constexpr int FD = (PRO == CX_PRO_AFFINE2 && G::NA == 4) ? 1 : 2;
+    bf16x8 fa[FD][2], fb[FD][2];
+    auto read_frags = [&](int slot, int kk) __attribute__((always_inline)) {
+      fa[slot][0] = *reinterpret_cast<const bf16x8*>(A + kk * 32);
+      fa[slot][1] = *reinterpret_cast<const bf16x8*>(A + 32 * PITCH + kk * 32);
+      fb[slot][0] = *reinterpret_cast<const bf16x8*>(Bt + kk * 32);
+      fb[slot][1] = *reinterpret_cast<const bf16x8*>(Bt + 32 * PITCH + kk * 32);
+    };
+    read_frags(0, 0);
+    if (STAGE) load_coef(Rc);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int cur = FD == 2 ? (kk & 1) : 0;
+      if (FD == 2 && kk < 3) read_frags(cur ^ 1, kk + 1);
+      if (FD == 1 && kk > 0) read_frags(0, kk);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[q >> 1][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][q >> 1], fb[cur][q & 1], acc[q >> 1][q & 1], 0, 0, 0);
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
+        const int slot = kk * 4 + q;
+        if (ISSUE && q == 0 && kk < G::NA) issue_a(Rn, kk);
+        if (STAGE) {
+          // 4 * NA dword units spread over the 16 slots
+          if ((slot * G::NA) % 4 == 0) {
+            const int u = slot * G::NA / 4;
+            stage_unit(Rc, u >> 2, u & 3, o[u >> 2], As);
+          }
+          if (q == 2 && kk < G::NB) stage_w(kk, Bs);
+        }
+        if (ISSUE) {
+          if (q == 3 && kk < G::NB) issue_w(kk);         // the row stored one packet ago
+          if (slot == 15) advance(Rn);
+        }
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+  // prologue of the pipeline: step 0 requested and staged, step 1 requested
+  {
+#pragma unroll
+    for (int i = 0; i < G::NA; ++i) issue_a(set0, i);
+#pragma unroll
+    for (int i = 0; i < G::NB; ++i) issue_w(i);
+    advance(set0);
+    __syncthreads();                       // coefficient table visible
+    load_coef(set0);
+    u32x4 o[G::NA];
+#pragma unroll
+    for (int i = 0; i < G::NA; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) stage_unit(set0, i, j, o[i], tiles);
+#pragma unroll
+    for (int i = 0; i < G::NB; ++i) stage_w(i, tiles + G::A_BYTES);
+    if (nsteps > 1) {
+#pragma unroll
+      for (int i = 0; i < G::NA; ++i) issue_a(set1, i);
+#pragma unroll
+      for (int i = 0; i < G::NB; ++i) issue_w(i);
+      advance(set1);
+    }
+    __syncthreads();
+  }
+
+  // Steps in pairs while two more remain to be requested: the requests inside this loop are unconditional, so the compiler's
+  // s_waitcnt in the staging packets counts the younger set's loads (vmcnt(n) instead of a full drain).
+  int s = 0;
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (DBG) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tacc[k] += t - tprev;
+      tprev = t;
+    }
+  };
+  if (DBG) tprev = __builtin_amdgcn_s_memtime();
+  for (; s + 3 < nsteps; s += 2) {
+    step(set0, set1, 0, 1, T{}, T{});      // multiplies step s, requests s+2, stages s+1
+    stamp(0);
+    __syncthreads();
+    stamp(1);
+    step(set1, set0, 1, 0, T{}, T{});
+    stamp(0);
+    __syncthreads();
+    stamp(1);
+  }
+  if (DBG && (wave == 0 || wave == G::NW - 1) && lane == 0 && blockIdx.x < 2048) {
+    unsigned long long* o = conv_mm_stamps + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+    for (int k = 0; k < 4; ++k) o[k] = tacc[k];
+    o[4] = s;
+  }
+  // one to three steps left: LDS image 0 = step s, set1 = step s+1 (if any), nothing requested for step s+2 yet
+  const int left = nsteps - s;
+  if (left == 3) {
+    step(set0, set1, 0, 1, T{}, T{});
+    __syncthreads();
+    step(set1, set0, 1, 0, F{}, T{});
+    __syncthreads();
+    step(set0, set1, 0, 1, F{}, F{});
+  } else if (left == 2) {
+    step(set0, set1, 0, 1, F{}, T{});
+    __syncthreads();
+    step(set1, set0, 1, 0, F{}, F{});
+  } else {
+    step(set0, set1, 0, 1, F{}, F{});
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- epilogue: 64-row groups through LDS
+  constexpr int CPR = BN / 8;              // 16-byte chunks per row
+  constexpr int RPP = G::NT / CPR;         // rows per pass
+  constexpr int NPASS = 64 / RPP;
+  constexpr int NGRP = G::BM / 64;
+  const int cq = tid % CPR, rr = tid / CPR;
+  const int nch = n0 + cq * 8;
+  float* etile = reinterpret_cast<float*>(tiles);
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+  const bf16* __restrict__ EX = reinterpret_cast<const bf16*>(p.ex);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  float esc[8], esh[8], emu[8], er[8], escale[8];
+  if (EPI == CX_EPI_MASK) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      esc[j] = p.e_sc[nch + j];
+      esh[j] = p.e_sh[nch + j];
+      emu[j] = p.e_mu[nch + j];
+      er[j] = p.e_r[nch + j];
+      escale[j] = p.e_scale[nch + j];
+    }
+  }
+  const bool want_stats = p.stat_sum != nullptr;
+
+  U128 xv[NGRP][NPASS], old[NGRP][NPASS];
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int m = mt * G::BM + g * 64 + pass * RPP + rr;
+      const int mc = m < M ? m : M - 1;
+      if (EPI == CX_EPI_MASK) xv[g][pass].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + nch);
+      if (p.accumulate)
+        old[g][pass].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + nch);
+      else
+        old[g][pass].u = make_uint4(0, 0, 0, 0);
+    }
+
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g) {
+    if (wm == g) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int col = (wn * 2 + j) * 32 + lrow;
+            etile[row * G::EPITCH + col] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + rr;
+      const int m = mt * G::BM + g * 64 + row;
+      if (m < M) {
+        const float4 v0 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        U128 o;
+        if (EPI == CX_EPI_STORE) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            o.e[j] = f2bf(v[j] + bf2f(old[g][pass].e[j]));
+            const float rv = bf2f(o.e[j]);
+            s1[j] += rv;
+            s2[j] += rv * rv;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xf = bf2f(xv[g][pass].e[j]);
+            const float dz = (fmaf(xf, esc[j], esh[j]) > 0.f) ? v[j] : 0.f;
+            s1[j] += dz;
+            s2[j] += dz * (xf - emu[j]) * er[j];
+            o.e[j] = f2bf(fmaf(escale[j], dz, bf2f(old[g][pass].e[j])));
+          }
+        }
+        *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + nch) = o.u;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (want_stats) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int d = CPR; d < 64; d <<= 1) {
+        s1[j] += __shfl_xor(s1[j], d);
+        s2[j] += __shfl_xor(s2[j], d);
+      }
+    }
+    float* scratch = reinterpret_cast<float*>(tiles);
+    wg_stat_begin<G::NW>(scratch, BN, tid, G::NT);
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wg_stat_put(scratch, BN, wave, cq * 8 + j, s1[j], s2[j]);
+    }
+    wg_stat_end<G::NW>(scratch, BN, tid, G::NT, p.stat_sum, p.stat_sq, p.stat_det, p.stat_det ? mt : (int)blockIdx.x, p.stat_replicas,
+                       p.stat_rstride, n0, p.N);
+  }
+}
+
+static int g_mm_dbg = 0;
+extern "C" int dbg_conv_mm_stamps(unsigned long long* host, int n_words) {     // not part of the ABI
+  if (!host) {
+    g_mm_dbg = n_words;
+    return 0;
+  }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(conv_mm_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+
+template <int WMW, int WNW, int PRO, int EPI>
+int launch(const CxConv& p, hipStream_t st) {
+  using G = MG<WMW, WNW>;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + G::BM - 1) / G::BM);
+  const int n_tiles = p.N / G::BN;
+  const size_t smem = (size_t)NCoef<PRO>::v * p.K * 4 + G::MAIN_BYTES;
+  if (smem > 160 * 1024) return CX_ESHAPE;
+  if (const int e = stat_rows_check(p, m_tiles)) return e;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mm_kernel<WMW, WNW, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  if (g_mm_dbg && (PRO == CX_PRO_AFFINE_RELU || PRO == CX_PRO_NONE) && EPI == CX_EPI_STORE) {
+    constexpr int DP = PRO == CX_PRO_NONE ? CX_PRO_NONE : CX_PRO_AFFINE_RELU;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mm_kernel<WMW, WNW, DP, CX_EPI_STORE, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, DP, CX_EPI_STORE, true>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, (int)M, n_tiles);
+    return launch_status();
+  }
+  hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, PRO, EPI>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, (int)M, n_tiles);
+  return launch_status();
+}
+
+// tile form: 1 = 128 x 128 (256 threads), 3 = 128 x 256 (512 threads).  (2 = 256 x 128, MG<4, 2>, was measured and never won:
+// it stages twice the activations per weight row, the expensive operand; not instantiated.)
+template <int PRO, int EPI>
+int launch_form(const CxConv& p, hipStream_t st, int form) {
+  if (form == 3) return launch<2, 4, PRO, EPI>(p, st);
+  return launch<2, 2, PRO, EPI>(p, st);
+}
+
+}  // namespace
+
+static int g_mm_on = -1, g_mm_form = -1;       // diagnostic overrides (-1: environment CX_MM / CX_MM_FORM, else the default)
+// Not part of the ABI: lets the tests and micro-benchmarks pin the kernel choice (on = 0: conv_gemm.hip; form = 1 | 2 | 3: tile).
+extern "C" void dbg_conv_mm_select(int on, int form) {
+  g_mm_on = on;
+  g_mm_form = form;
+}
+
+// Called by cx_conv_gemm after validation, once the specialised DenseNet kernels have declined.
+int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  static const int env_on0 = [] { const char* e = getenv("CX_MM"); return e ? atoi(e) : 1; }();
+  static const int env_form0 = [] { const char* e = getenv("CX_MM_FORM"); return e ? atoi(e) : 0; }();
+  const int env_on = g_mm_on >= 0 ? g_mm_on : env_on0;
+  const int env_form = g_mm_form >= 0 ? g_mm_form : env_form0;
+  // the transposed-stride input gradients (three per ResNet152 step) stay on the generic kernel: their tap offsets are not linear
+  if (!env_on || p.mode != CX_MODE_CONV || p.tstride > 1 || (p.K % BK) || (p.N % 128) || p.kh * p.kw > 32 || p.dtype != CX_DT_BF16) return 0;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  // 32-bit byte offsets inside every tensor
+  if ((unsigned long long)p.B * p.H * p.W * (unsigned long long)(p.ldx > p.ldx2 ? p.ldx : p.ldx2) * 2 >= (1ull << 32)) return 0;
+  if ((unsigned long long)p.kh * p.kw * p.N * p.K * 2 >= (1ull << 32)) return 0;
+  // Measured on the ResNet152 shapes (scratch/bench_mm.py): 128 x 256 tiles wherever N allows and a tile has more than four
+  // k-steps (1.9-2.7x the generic kernel); with at most four steps a tile is prologue + epilogue, the smaller tile wins, and with
+  // one or two steps the generic kernel (32-channel steps, three workgroups per CU) is as fast.
+  const int nsteps = p.kh * p.kw * (p.K / BK);
+  if (!env_form && nsteps <= 2) return 0;
+  int form = (p.N % 256 == 0 && nsteps > 4) ? 3 : 1;
+  if (env_form) form = env_form == 3 ? 3 : 1;
+  if (form == 3 && (p.N % 256)) form = 1;
+  if (form == 3 && (size_t)NCoef<CX_PRO_AFFINE2>::v * p.K * 4 + MG<2, 4>::MAIN_BYTES > 160 * 1024) form = 1;
+  *handled = true;
+  if (p.epilogue == CX_EPI_STORE) {
+    if (p.prologue == CX_PRO_NONE) return launch_form<CX_PRO_NONE, CX_EPI_STORE>(p, st, form);
+    if (p.prologue == CX_PRO_AFFINE_RELU) return launch_form<CX_PRO_AFFINE_RELU, CX_EPI_STORE>(p, st, form);
+    if (p.prologue == CX_PRO_AFFINE2) return launch_form<CX_PRO_AFFINE2, CX_EPI_STORE>(p, st, form);
+  } else if (p.epilogue == CX_EPI_MASK) {
+    if (p.prologue == CX_PRO_AFFINE2) return launch_form<CX_PRO_AFFINE2, CX_EPI_MASK>(p, st, form);
+    if (p.prologue == CX_PRO_NONE) return launch_form<CX_PRO_NONE, CX_EPI_MASK>(p, st, form);
+  }
+  *handled = false;
+  return 0;
+}

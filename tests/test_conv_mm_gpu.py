@@ -1,0 +1,152 @@
+"""GPU: the wide-channel implicit-GEMM kernel (csrc/conv_mm.hip: K % 64 == 0, N % 128 == 0 -- the ResNet bottleneck shapes) through
+cx_conv_gemm against a PyTorch fp32 reference of the same op, for both tile forms, and against the generic kernel it replaces."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from chexpert_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from chexpert_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def select():
+    from chexpert_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    yield lambda on, wm: raw.dbg_conv_mm_select(on, wm)
+    raw.dbg_conv_mm_select(-1, -1)
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rnd(seed, shape, lo=-1.0, hi=1.0):
+    return synth.uniform(seed, shape, lo, hi)
+
+
+def nhwc(seed, B, H, W, C, dev, lo=-1.5, hi=1.5):
+    v = bf(rnd(seed, (B, H, W, C), lo, hi))
+    return v.to(torch.bfloat16).to(dev), v.permute(0, 3, 1, 2).contiguous()
+
+
+def to_nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, want, rel=6e-3, what=""):
+    scale = want.abs().max().item() + 1e-6
+    err = (got - want).abs().max().item()
+    assert err <= rel * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+
+
+cv = lambda t: t.view(1, -1, 1, 1)
+
+
+@pytest.mark.parametrize("form", [1, 3])
+@pytest.mark.parametrize("B,H,W,K,N,ksz,stride,pro", [
+    (2, 9, 11, 64, 256, 1, 1, 0),        # one k-step, ragged last pixel tile
+    (3, 10, 12, 128, 256, 1, 1, 1),      # two n tiles
+    (2, 12, 10, 64, 128, 3, 1, 1),       # 9 steps (odd)
+    (2, 11, 13, 128, 128, 3, 2, 1),      # strided 3x3, 18 steps
+    (5, 8, 8, 192, 128, 1, 2, 0),        # strided 1x1 (downsample), 3 steps
+    (1, 20, 20, 256, 384, 3, 1, 1),      # 36 steps, three n tiles, M = 400 (1.56 tiles of 256)
+])
+def test_forward_against_torch(dev, select, form, B, H, W, K, N, ksz, stride, pro):
+    from chexpert_amd import ops
+    select(1, form)          # 1 = 128 x 128, 3 = 128 x 256 (falls back to 1 where N % 256 != 0)
+    xb, x = nhwc(5, B, H, W, K + 64, dev)            # the operand is a channel slice of a wider buffer
+    xb, x = xb[..., 32:32 + K], x[:, 32:32 + K]
+    w = bf(rnd(6, (N, K, ksz, ksz), -0.1, 0.1))
+    pa, pb = rnd(7, (K,), -0.3, 1.5), rnd(8, (K,), -0.5, 0.5)
+    a = bf(F.relu(x * cv(pa) + cv(pb))) if pro else x
+    want = F.conv2d(a, w, stride=stride, padding=ksz // 2)
+    Ho, Wo = want.shape[2:]
+    buf = torch.full((B, Ho, Wo, 96 + N), -3.0, dtype=torch.bfloat16, device=dev)
+    rows_cap = 64
+    ssum, ssq = torch.zeros(rows_cap, N, device=dev), torch.zeros(rows_cap, N, device=dev)
+    rows = ops.conv_gemm(xb, ops.pack_weights(w.to(dev)), buf[..., 96:], N=N, kh=ksz, kw=ksz, stride=stride, pad=ksz // 2,
+                         prologue=ops.PRO_AFFINE_RELU if pro else ops.PRO_NONE, pa=pa.to(dev) if pro else None,
+                         pb=pb.to(dev) if pro else None, stat_sum=ssum, stat_sq=ssq, stat_det=True, stat_replicas=rows_cap,
+                         stat_rstride=N)
+    M = B * Ho * Wo
+    assert rows == (M + 127) // 128, "statistic rows = pixel tiles of the selected kernel"
+    got = to_nchw(buf[..., 96:])
+    close(got, want, what="y")
+    assert (buf[..., :96].float() == -3.0).all()
+    close(ssum[:rows].sum(0).cpu(), got.sum((0, 2, 3)), rel=1e-4, what="sum")
+    close(ssq[:rows].sum(0).cpu(), (got * got).sum((0, 2, 3)), rel=1e-4, what="sum of squares")
+    assert (ssum[rows:] == 0).all()
+
+
+@pytest.mark.parametrize("form", [1, 3])
+@pytest.mark.parametrize("B,H,W,K,N,ksz,ts,acc,pro", [
+    (2, 9, 10, 128, 128, 1, 1, False, 2),
+    (2, 9, 10, 256, 128, 1, 1, True, 2),
+    (3, 10, 12, 64, 256, 3, 1, False, 2),
+    (2, 6, 7, 128, 128, 3, 2, False, 2),        # input gradient of a stride-2 3x3 (declined: stays on the generic kernel)
+    (4, 10, 10, 128, 256, 3, 1, True, 2),       # 128 x 256 tiles with the two-tensor operand
+    (2, 8, 8, 192, 128, 1, 1, True, 0),         # plain operand, accumulate (AA projection gradient form)
+])
+def test_input_gradient_mask_epilogue_against_torch(dev, select, form, B, H, W, K, N, ksz, ts, acc, pro):
+    from chexpert_amd import ops
+    select(1, form)
+    Ho, Wo = (H * ts, W * ts) if ts > 1 else (H, W)              # forward input size (even sizes: stride-2 pad-1 3x3 halves them)
+    ub, u = nhwc(20, B, H, W, K, dev)
+    vb, v = nhwc(21, B, H, W, K, dev)
+    exb, ex = nhwc(22, B, Ho, Wo, N + 32, dev)
+    oldb, old = nhwc(23, B, Ho, Wo, N + 32, dev)
+    w = bf(rnd(24, (K, N, ksz, ksz), -0.1, 0.1))                  # forward weight (O=K, I=N): the gradient maps K -> N
+    pa, pb, pc = rnd(25, (K,), 0.5, 1.5), rnd(26, (K,), -0.3, 0.3), rnd(27, (K,), -0.2, 0.2)
+    e_sc, e_sh = rnd(28, (N,), -0.3, 1.5), rnd(29, (N,), -0.5, 0.5)
+    e_mu, e_r, e_scale = rnd(30, (N,), -0.5, 0.5), rnd(31, (N,), 0.5, 2.0), rnd(32, (N,), -0.3, 1.5)
+    dy = bf(u * cv(pa) + v * cv(pb) + cv(pc)) if pro == 2 else u
+    acc_ref = F.conv_transpose2d(dy, w, stride=ts, padding=ksz // 2, output_padding=ts - 1 if ksz == 3 else 0)
+    assert acc_ref.shape[2:] == (Ho, Wo)
+    exs = ex[:, :N]
+    dz = torch.where((exs * cv(e_sc) + cv(e_sh)) > 0, acc_ref, torch.zeros(()))
+    want = cv(e_scale) * dz + (old[:, :N] if acc else 0)
+    S1, S2 = dz.sum((0, 2, 3)), (dz * (exs - cv(e_mu)) * cv(e_r)).sum((0, 2, 3))
+    cap = 64
+    s1, s2 = torch.zeros(cap, N, device=dev), torch.zeros(cap, N, device=dev)
+    kw = dict(prologue=ops.PRO_AFFINE2, x2=vb, pa=pa.to(dev), pb=pb.to(dev), pc=pc.to(dev)) if pro == 2 else {}
+    rows = ops.conv_gemm(ub, ops.pack_weights(w.to(dev), transpose=True), oldb[..., :N], N=N, kh=ksz, kw=ksz, pad=ksz // 2 if ts == 1 else ksz - 1 - ksz // 2,
+                         tstride=ts, epilogue=ops.EPI_MASK, ex=exb[..., :N], e_sc=e_sc.to(dev), e_sh=e_sh.to(dev), e_mu=e_mu.to(dev),
+                         e_r=e_r.to(dev), e_scale=e_scale.to(dev), stat_sum=s1, stat_sq=s2, stat_det=True, stat_replicas=cap,
+                         stat_rstride=N, accumulate=acc, **kw)
+    close(to_nchw(oldb[..., :N]), want, rel=8e-3, what="g")
+    assert torch.equal(to_nchw(oldb[..., N:]), old[:, N:]), "wrote outside the slice"
+    close(s1[:rows].sum(0).cpu(), S1, rel=2e-3, what="S1")
+    close(s2[:rows].sum(0).cpu(), S2, rel=2e-3, what="S2")
+
+
+def test_same_result_as_the_generic_kernel(dev, select):
+    """AFFINE2 operand, plain store, no statistics: the wide-channel kernel and conv_gemm.hip's 128x128x32 kernel agree to bf16
+    rounding of identical fp32 sums (different accumulation order only)."""
+    from chexpert_amd import ops
+    B, H, W, K, N = 4, 20, 20, 256, 1024
+    ub, _ = nhwc(40, B, H, W, K, dev)
+    vb, _ = nhwc(41, B, H, W, K, dev)
+    wp = ops.pack_weights(bf(rnd(42, (N, K, 1, 1), -0.1, 0.1)).to(dev))
+    pa, pb, pc = (rnd(43 + i, (K,), -1.0, 1.0).to(dev) for i in range(3))
+    outs = []
+    for on, form in [(0, 0), (1, 1), (1, 3)]:
+        select(on, form)
+        y = torch.empty(B, H, W, N, dtype=torch.bfloat16, device=dev)
+        ops.conv_gemm(ub, wp, y, N=N, prologue=ops.PRO_AFFINE2, x2=vb, pa=pa, pb=pb, pc=pc)
+        outs.append(y.float())
+    scale = outs[0].abs().max().item()
+    for o in outs[1:]:
+        assert (o - outs[0]).abs().max().item() <= 8e-3 * scale
+    assert torch.equal(outs[1], outs[2]), "both tile forms add the k-steps in the same order"
