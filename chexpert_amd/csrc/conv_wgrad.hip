@@ -605,6 +605,8 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);   // co
 
 int cx_conv_wgrad_f32(const CxWgrad& p, hipStream_t st);                    // conv_f32.hip
 
+int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled);          // wgrad_mm.hip
+
 extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
   if (!pp) return CX_EINVAL;
   const CxWgrad& p = *pp;
@@ -639,6 +641,8 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
       int rc = cx_try_ring_wgrad(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_strip_wgrad(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_wgrad_mm(p, st, &handled);
       if (handled) return rc;
     }
     const long long pw_min = 1ll << 23;              // ResNet152 1x1 layers: 2^23 measured 1 % faster end to end than 2^25

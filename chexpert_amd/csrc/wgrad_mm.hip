@@ -1,0 +1,338 @@
+// Weight gradient of the wide 1x1 convolutions (ResNet bottlenecks): dW[n][c] += sum_px dZ[px][n] * A[px][c], stride 1,
+// N % 128 == 0 output channels, pixels a multiple of 64, NHWC bf16 operands, fp32 OIHW result.
+//
+// Same recipe as conv_mm.hip, which measured what bounds these kernels (vector-instruction issue with two waves per SIMD, not
+// MFMA or bandwidth): tiles of 128 x 256 (or 256 x 128, 128 x 128) outputs so that each operand element is transformed for 256
+// (128) outputs instead of 128 / 32, 64 pixels per step, the operands of step s+2 requested while step s multiplies (two register
+// sets), prologue coefficients of the thread's fixed channel chunk held in registers, and the step's loads / prologue arithmetic /
+// LDS stores issued in packets between the MFMAs.  Both operands have the reduction index (pixel) as their slow memory axis:
+// fragments come from the [pixel][channel] LDS images through ds_read_b64_tr_b16.
+// The pixel range is split over workgroups; partial tiles leave through fp32 atomics (CxWgrad has no scratch slab).
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PX = 64;                                 // pixels per step
+
+template <int WA, int WB>
+struct WG {
+  static constexpr int TN = 64 * WA;                   // dZ channels (rows of dW) per tile
+  static constexpr int TC = 64 * WB;                   // input channels (columns of dW) per tile
+  static constexpr int NW = WA * WB;
+  static constexpr int NT = 64 * NW;
+  static constexpr int GQ = TN / 8, XQ = TC / 8;       // 16-byte chunks per image row
+  static constexpr int RG = NT / GQ, RX = NT / XQ;     // rows covered by one staging pass
+  static constexpr int NG = PX / RG, NX = PX / RX;     // chunks per thread per step
+  static constexpr int GP = TN * 2 + 64;               // LDS pitches: == 64 B (mod 256 B) for the transposing reads
+  static constexpr int XP = TC * 2 + 64;
+  static constexpr int STAGE = PX * (GP + XP);
+  static constexpr int UNITS = (NG + NX) * 4;          // dword units of prologue work per step
+};
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t packbf(float a, float b) {
+  union {
+    bf16x2 h;
+    uint32_t u;
+  } o;
+  o.h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+  return o.u;
+}
+__device__ __forceinline__ uint32_t relu_pk(uint32_t v) {
+  union {
+    uint32_t u;
+    s16x2 s;
+  } a, r;
+  a.u = v;
+  r.s = __builtin_elementwise_max(a.s, s16x2{0, 0});
+  return r.u;
+}
+__device__ __forceinline__ u32x4 ld16(const char* base, uint32_t off) { return *reinterpret_cast<const u32x4*>(base + (size_t)off); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int k0, int ch0, int lane) {
+  // fragment of the 32x32x16 MFMA: this lane gets channel ch0 + (lane&31), pixels k0 + 8*(lane>>5) + 0..7
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const char* base = tile + (k0 + 8 * (g >> 1) + q) * pitch + (ch0 + 16 * (g & 1) + 4 * pp) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  U64 lo, hi;
+  lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+  hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch));
+  bf16x8 r;
+  r[0] = lo.e[0]; r[1] = lo.e[1]; r[2] = lo.e[2]; r[3] = lo.e[3];
+  r[4] = hi.e[0]; r[5] = hi.e[1]; r[6] = hi.e[2]; r[7] = hi.e[3];
+  return r;
+}
+
+template <int WA, int WB, int GPRO, int XPRO>
+__global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_mm_kernel(const CxWgrad p, const int c_tiles,
+                                                                                                        const int n_tiles,
+                                                                                                        const int total_steps,
+                                                                                                        const int steps_per_split) {
+  using G = WG<WA, WB>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave / WB, wb = wave % WB;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = id % c_tiles;                         // tiles of one pixel range are neighbours: operands shared in L2
+  id /= c_tiles;
+  const int nt = id % n_tiles;
+  const int split = id / n_tiles;
+  const int c0 = ct * G::TC, n0 = nt * G::TN;
+
+  // this thread's chunk columns and their prologue coefficients (fixed for the whole kernel)
+  const int qg = tid % G::GQ, rg0 = tid / G::GQ;
+  const int qx = tid % G::XQ, rx0 = tid / G::XQ;
+  const bool xact = c0 + qx * 8 < p.K;
+  const uint32_t xmask = xact ? 0xffffffffu : 0u;
+  const int xc = xact ? c0 + qx * 8 : 0;
+  float ga[8], gb[8], gc[8], pa[8], pb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ga[j] = GPRO == CX_PRO_AFFINE2 ? p.ga[n0 + qg * 8 + j] : 1.f;
+    gb[j] = GPRO == CX_PRO_AFFINE2 ? p.gb[n0 + qg * 8 + j] : 0.f;
+    gc[j] = GPRO == CX_PRO_AFFINE2 ? p.gc[n0 + qg * 8 + j] : 0.f;
+    pa[j] = XPRO == CX_PRO_AFFINE_RELU ? p.pa[xc + j] : 1.f;
+    pb[j] = XPRO == CX_PRO_AFFINE_RELU ? p.pb[xc + j] : 0.f;
+  }
+
+  const int step0 = split * steps_per_split;
+  int nsteps = total_steps - step0;
+  if (nsteps > steps_per_split) nsteps = steps_per_split;
+
+  // byte offsets of the thread's chunks inside a 64-pixel step; the step itself is a scalar byte offset
+  uint32_t goff[G::NG], goff2[G::NG], xoff[G::NX];
+#pragma unroll
+  for (int i = 0; i < G::NG; ++i) {
+    goff[i] = ((uint32_t)(rg0 + G::RG * i) * (uint32_t)p.ldg + n0 + qg * 8) * 2u;
+    goff2[i] = ((uint32_t)(rg0 + G::RG * i) * (uint32_t)p.ldg2 + n0 + qg * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < G::NX; ++i) xoff[i] = ((uint32_t)(rx0 + G::RX * i) * (uint32_t)p.ldx + xc) * 2u;
+  const char* __restrict__ Gb = reinterpret_cast<const char*>(p.g);
+  const char* __restrict__ G2b = reinterpret_cast<const char*>(p.g2);
+  const char* __restrict__ Xb = reinterpret_cast<const char*>(p.x);
+  uint32_t q_g = (uint32_t)step0 * PX * (uint32_t)p.ldg * 2u, q_g2 = (uint32_t)step0 * PX * (uint32_t)p.ldg2 * 2u,
+           q_x = (uint32_t)step0 * PX * (uint32_t)p.ldx * 2u;
+  const uint32_t sg = PX * (uint32_t)p.ldg * 2u, sg2 = PX * (uint32_t)p.ldg2 * 2u, sx = PX * (uint32_t)p.ldx * 2u;
+
+  // dZ (two tensors under AFFINE2): two register sets, requests two steps ahead.  Activations: one set, each chunk requested
+  // again right after it has been stored to LDS (one step ahead) - a second set does not fit beside the coefficients.
+  struct Regs {
+    u32x4 g[G::NG], g2[G::NG];
+  };
+  Regs set0, set1;
+  u32x4 xreg[G::NX];
+  auto issue_g = [&](Regs& R, int i) __attribute__((always_inline)) {
+    R.g[i] = ld16(Gb, goff[i] + q_g);
+    if (GPRO == CX_PRO_AFFINE2) R.g2[i] = ld16(G2b, goff2[i] + q_g2);
+  };
+  auto issue_x = [&](int i) __attribute__((always_inline)) { xreg[i] = ld16(Xb, xoff[i] + q_x); };
+  auto advance = [&]() __attribute__((always_inline)) {
+    q_g += sg;
+    q_g2 += sg2;
+    q_x += sx;
+  };
+  // dword j (two channels) of chunk i -> o[j]; after j == 3 the chunk is written
+  auto unit_g = [&](const Regs& R, int i, int j, u32x4& o, char* Gt) __attribute__((always_inline)) {
+    const uint32_t g = R.g[i][j];
+    if (GPRO == CX_PRO_NONE) {
+      o[j] = g;
+    } else {
+      const uint32_t y = R.g2[i][j];
+      o[j] = packbf(fmaf(bf_lo(g), ga[2 * j], fmaf(bf_lo(y), gb[2 * j], gc[2 * j])),
+                    fmaf(bf_hi(g), ga[2 * j + 1], fmaf(bf_hi(y), gb[2 * j + 1], gc[2 * j + 1])));
+    }
+    if (j == 3) *reinterpret_cast<u32x4*>(Gt + (rg0 + G::RG * i) * G::GP + qg * 16) = o;
+  };
+  auto unit_x = [&](int i, int j, u32x4& o, char* Xt, bool reissue) __attribute__((always_inline)) {
+    const uint32_t x = xreg[i][j];
+    if (XPRO == CX_PRO_NONE) {
+      o[j] = x;
+    } else {
+      o[j] = relu_pk(packbf(fmaf(bf_lo(x), pa[2 * j], pb[2 * j]), fmaf(bf_hi(x), pa[2 * j + 1], pb[2 * j + 1])));
+    }
+    if (j == 3) {
+      o &= xmask;
+      *reinterpret_cast<u32x4*>(Xt + (rx0 + G::RX * i) * G::XP + qx * 16) = o;
+      if (reissue) issue_x(i);
+    }
+  };
+  auto unit = [&](const Regs& R, int u, u32x4& o, char* St, bool reissue) __attribute__((always_inline)) {
+    if (u < G::NG * 4)
+      unit_g(R, u >> 2, u & 3, o, St);
+    else
+      unit_x((u - G::NG * 4) >> 2, u & 3, o, St + PX * G::GP, reissue);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // One step = 16 MFMAs of LDS image `bufc`; between them, in fenced packets: the requests of step (this + 2) into Rn and the
+  // prologue + LDS stores of step (this + 1) from Rc into image `bufn`.
+  auto step = [&](Regs& Rn, const Regs& Rc, int bufc, int bufn, auto IssueC, auto StageC) __attribute__((always_inline)) {
+    constexpr bool ISSUE = decltype(IssueC)::value, STAGE = decltype(StageC)::value;
+    constexpr bool FENCE = G::NG + G::NX <= 6;               // (the 128 x 128 form keeps 8 chunks per set: no registers to spare)
+    const char* Gt = smem + bufc * G::STAGE;
+    const char* Xt = Gt + PX * G::GP;
+    char* Sn = smem + bufn * G::STAGE;
+    u32x4 o;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[2], bfr[2];
+      af[0] = tr_frag(Gt, G::GP, kk * 16, (wa * 2) * 32, lane);
+      af[1] = tr_frag(Gt, G::GP, kk * 16, (wa * 2 + 1) * 32, lane);
+      bfr[0] = tr_frag(Xt, G::XP, kk * 16, (wb * 2) * 32, lane);
+      bfr[1] = tr_frag(Xt, G::XP, kk * 16, (wb * 2 + 1) * 32, lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[q >> 1][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q >> 1], bfr[q & 1], acc[q >> 1][q & 1], 0, 0, 0);
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
+        const int slot = kk * 4 + q;
+        if (ISSUE && q == 0 && kk < G::NG) issue_g(Rn, kk);
+        if (STAGE) {
+#pragma unroll
+          for (int u = slot * G::UNITS / 16; u < (slot + 1) * G::UNITS / 16; ++u) unit(Rc, u, o, Sn, ISSUE);
+        }
+        if (ISSUE && slot == 15) advance();
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+  if (nsteps > 0) {
+    // prologue of the pipeline: step 0 requested and staged, step 1 requested
+#pragma unroll
+    for (int i = 0; i < G::NG; ++i) issue_g(set0, i);
+#pragma unroll
+    for (int i = 0; i < G::NX; ++i) issue_x(i);
+    advance();
+    if (nsteps > 1) {
+#pragma unroll
+      for (int i = 0; i < G::NG; ++i) issue_g(set1, i);
+    }
+    {
+      u32x4 o;
+#pragma unroll
+      for (int u = 0; u < G::UNITS; ++u) unit(set0, u, o, smem, nsteps > 1);      // (re-requests the activations of step 1)
+    }
+    if (nsteps > 1) advance();
+    __syncthreads();
+
+    int s = 0;
+    for (; s + 3 < nsteps; s += 2) {
+      step(set0, set1, 0, 1, T{}, T{});      // multiplies step s, requests s+2, stages s+1
+      __syncthreads();
+      step(set1, set0, 1, 0, T{}, T{});
+      __syncthreads();
+    }
+    const int left = nsteps - s;
+    if (left == 3) {
+      step(set0, set1, 0, 1, T{}, T{});
+      __syncthreads();
+      step(set1, set0, 1, 0, F{}, T{});
+      __syncthreads();
+      step(set0, set1, 0, 1, F{}, F{});
+    } else if (left == 2) {
+      step(set0, set1, 0, 1, F{}, T{});
+      __syncthreads();
+      step(set1, set0, 1, 0, F{}, F{});
+    } else {
+      step(set0, set1, 0, 1, F{}, F{});
+    }
+  }
+
+  // ---- partial tile -> fp32 OIHW gradient
+  const int lrow = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + (wb * 2 + j) * 32 + lrow;
+      if (c < p.K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + (wa * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          atomicAdd(p.dw + (size_t)n * p.K + c, acc[i][j][r]);
+        }
+      }
+    }
+}
+
+template <int WA, int WB, int GPRO, int XPRO>
+int launch(const CxWgrad& p, hipStream_t st, int wgs_target) {
+  using G = WG<WA, WB>;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int c_tiles = (p.K + G::TC - 1) / G::TC, n_tiles = p.N / G::TN;
+  const int total_steps = (int)(M / PX);
+  int splits = p.splits > 0 ? p.splits : wgs_target / (c_tiles * n_tiles);
+  if (splits < 1) splits = 1;
+  if (splits > total_steps) splits = total_steps;
+  const int sps = (total_steps + splits - 1) / splits;
+  splits = (total_steps + sps - 1) / sps;
+  const size_t smem = 2 * G::STAGE;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mm_kernel<WA, WB, GPRO, XPRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL((wgrad_mm_kernel<WA, WB, GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(G::NT), smem, st, p, c_tiles, n_tiles,
+                     total_steps, sps);
+  return launch_status();
+}
+
+template <int GPRO, int XPRO>
+int launch_form(const CxWgrad& p, hipStream_t st, int form) {
+  if (form == 3) return launch<2, 4, GPRO, XPRO>(p, st, 256);      // 128 x 256, one 512-thread workgroup per CU
+  if (form == 2) return launch<4, 2, GPRO, XPRO>(p, st, 256);      // 256 x 128
+  return launch<2, 2, GPRO, XPRO>(p, st, 512);                     // 128 x 128, two 256-thread workgroups per CU
+}
+
+}  // namespace
+
+static int g_wm_on = -1, g_wm_form = -1;       // diagnostic overrides (-1: environment CX_WGRAD_MM / CX_WGRAD_MM_FORM, else default)
+// Not part of the ABI: pins the kernel choice for tests and micro-benchmarks (on = 0: conv_wgrad.hip's kernels; form 1 | 2 | 3).
+extern "C" void dbg_wgrad_mm_select(int on, int form) {
+  g_wm_on = on;
+  g_wm_form = form;
+}
+
+// Called by cx_conv_wgrad after validation (bf16, MODE_CONV).
+int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  static const int env_on0 = [] { const char* e = getenv("CX_WGRAD_MM"); return e ? atoi(e) : 1; }();
+  static const int env_form0 = [] { const char* e = getenv("CX_WGRAD_MM_FORM"); return e ? atoi(e) : 0; }();
+  const int on = g_wm_on >= 0 ? g_wm_on : env_on0;
+  const int env_form = g_wm_form >= 0 ? g_wm_form : env_form0;
+  if (!on || p.mode != CX_MODE_CONV || p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0) return 0;
+  if ((p.N % 128) || (p.K % 8) || p.K < 64) return 0;
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  if (M % PX) return 0;
+  const unsigned long long ldmax = (unsigned long long)(p.ldg > p.ldx ? p.ldg : p.ldx);
+  if ((unsigned long long)M * (ldmax > (unsigned long long)p.ldg2 ? ldmax : (unsigned long long)p.ldg2) * 2 >= (1ull << 32)) return 0;
+  const bool g2 = p.g_prologue == CX_PRO_AFFINE2;
+  if (p.g_prologue != CX_PRO_NONE && !g2) return 0;
+  if (p.x_prologue != CX_PRO_NONE && p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
+  int form = 3;                   // measured on the ResNet152 shapes (scratch/bench_wmm.py): 128 x 256 wins at every K >= 64
+  if (env_form) form = env_form;
+  if (form == 2 && (p.N % 256)) form = 1;
+  *handled = true;
+  if (p.x_prologue == CX_PRO_AFFINE_RELU)
+    return g2 ? launch_form<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU>(p, st, form) : launch_form<CX_PRO_NONE, CX_PRO_AFFINE_RELU>(p, st, form);
+  return g2 ? launch_form<CX_PRO_AFFINE2, CX_PRO_NONE>(p, st, form) : launch_form<CX_PRO_NONE, CX_PRO_NONE>(p, st, form);
+}

@@ -150,3 +150,38 @@ def test_same_result_as_the_generic_kernel(dev, select):
     for o in outs[1:]:
         assert (o - outs[0]).abs().max().item() <= 8e-3 * scale
     assert torch.equal(outs[1], outs[2]), "both tile forms add the k-steps in the same order"
+
+
+# ------------------------------------------------------------------------------------------------ weight gradient (wgrad_mm.hip)
+@pytest.fixture
+def select_w():
+    from chexpert_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    yield lambda on, form: raw.dbg_wgrad_mm_select(on, form)
+    raw.dbg_wgrad_mm_select(-1, -1)
+
+
+@pytest.mark.parametrize("form", [1, 2, 3])
+@pytest.mark.parametrize("K,N,gpro,xpro,B,H,W,splits", [
+    (256, 128, 2, 1, 2, 8, 16, 0),        # one 256-channel tile, four steps per image pair
+    (64, 256, 2, 1, 3, 8, 8, 2),          # partial channel tile (64 of 256 / 128), three steps split in two ranges
+    (320, 128, 0, 0, 1, 16, 20, 5),       # plain operands, two channel tiles with a partial second one, one step per range
+    (512, 256, 2, 0, 4, 12, 16, 3),       # 12 steps in three ranges (pairs + tails of the step pipeline)
+    (128, 384, 0, 1, 7, 8, 8, 1),         # 7 steps in one range (odd count)
+])
+def test_1x1_weight_gradient_against_torch(dev, select_w, form, K, N, gpro, xpro, B, H, W, splits):
+    from chexpert_amd import ops
+    select_w(1, form)           # 1 = 128 x 128, 2 = 256 x 128 (needs N % 256 == 0, else 1), 3 = 128 x 256
+    gb_, g = nhwc(40, B, H, W, N + 32, dev)
+    g2b, g2 = nhwc(41, B, H, W, N, dev)
+    xb, x = nhwc(42, B, H, W, K + 64, dev)
+    ga, gbv, gc = rnd(43, (N,), 0.5, 1.5), rnd(44, (N,), -0.3, 0.3), rnd(45, (N,), -0.2, 0.2)
+    pa, pb = rnd(46, (K,), -0.3, 1.5), rnd(47, (K,), -0.5, 0.5)
+    G = bf(g[:, :N] * cv(ga) + g2 * cv(gbv) + cv(gc)) if gpro else g[:, :N]
+    A = bf(F.relu(x[:, 32:32 + K] * cv(pa) + cv(pb))) if xpro else x[:, 32:32 + K]
+    want = torch.nn.grad.conv2d_weight(A, (N, K, 1, 1), G)
+    dw0 = rnd(48, (N, K, 1, 1), -1, 1)
+    dw = dw0.clone().to(dev)
+    ops.conv_wgrad(gb_[..., :N], xb[..., 32:32 + K], dw, g_prologue=gpro, g2=g2b if gpro else None, ga=ga.to(dev), gb=gbv.to(dev),
+                   gc=gc.to(dev), x_prologue=xpro, pa=pa.to(dev), pb=pb.to(dev), splits=splits)
+    close(dw.cpu() - dw0, want, rel=2e-3, what="dW")
