@@ -79,12 +79,26 @@ __device__ __forceinline__ uint32_t relu_pk(uint32_t v) {
 // 16 B at base + 32-bit byte offset (the scalar-base form of global_load: no 64-bit vector arithmetic per load)
 __device__ __forceinline__ u32x4 ld16(const char* base, uint32_t off) { return *reinterpret_cast<const u32x4*>(base + (size_t)off); }
 
+// Geometry of one launch.  A plain convolution is one launch over all output pixels.  The input gradient of a stride-2
+// convolution (CxConv.tstride == 2) is up to four launches, one per parity class (oy & 1, ox & 1) of the output pixels: inside a
+// class every pixel has the same valid taps (1, 2, 2 or 4 of a 3x3 instead of 9 with three quarters of the products zero), they
+// form a dense grid in the gradient image, and the rows of the implicit GEMM enumerate the class's pixels (b, oy', ox').
+struct Cls {
+  int nty, ntx;                   // taps walked: nty x ntx
+  int i_mul, iy_add, ix_add;      // first tap's source pixel of row (oy', ox'): (oy' * i_mul + iy_add, ox' * i_mul + ix_add)
+  int wy0, wx0, wstep;            // weight tap of walked tap (ty, tx): (wy0 + wstep * ty) * kw + wx0 + wstep * tx
+  int Hq, Wq, Mq;                 // class image size, rows (B * Hq * Wq)
+  int o_mul, oy_add, ox_add;      // output pixel of row (oy', ox'): (oy' * o_mul + oy_add, ox' * o_mul + ox_add)
+  int row0;                       // first statistic row of the launch
+};
+
 // diagnostic build (DBG): s_memtime phase sums of the main loop per workgroup, waves 0 and NW-1: [issue, multiply, stage, barrier, steps]
 __device__ unsigned long long conv_mm_stamps[2048 * 2 * 8];
 
 template <int WMW, int WNW, int PRO, int EPI, bool DBG = false>
-__global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mm_kernel(const CxConv p, const int M,
+__global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mm_kernel(const CxConv p, const Cls c,
                                                                                                           const int n_tiles) {
+  const int M = c.Mq;
   using G = MG<WMW, WNW>;
   constexpr int BN = G::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,27 +125,27 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   // one validity bit per tap; inside the loop a row costs a bit-field extract, an add of the step's scalar offset and an AND.
   const int qa = tid & 7;
   const int r0 = tid >> 3;
-  const int ntaps = p.kh * p.kw;
+  const int ntaps = c.nty * c.ntx;
   uint32_t roff[G::NA], roff2[G::NA], vbits[G::NA];
 #pragma unroll
   for (int i = 0; i < G::NA; ++i) {
     const int m = mt * G::BM + r0 + G::RSTEP * i;
     const bool ok = m < M;
     const int mm = ok ? m : 0;
-    const int hw = p.Ho * p.Wo;
+    const int hw = c.Hq * c.Wq;
     const int b = mm / hw;
     const int rem = mm - b * hw;
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    const int oy = rem / c.Wq, ox = rem - oy * c.Wq;
+    const int iy0 = oy * c.i_mul + c.iy_add, ix0 = ox * c.i_mul + c.ix_add;
     const int pix = (b * p.H + iy0) * p.W + ix0;          // may be "negative": only used where the tap is valid
     roff[i] = ((uint32_t)pix * (uint32_t)p.ldx + qa * 8) * 2u;
     roff2[i] = ((uint32_t)pix * (uint32_t)p.ldx2 + qa * 8) * 2u;
     // tap (dy, dx) is valid where row iy0 + dy and column ix0 + dx exist: separable, so kh + kw tests instead of kh * kw
     uint32_t xb = 0, bits = 0;
 #pragma nounroll
-    for (int dx = 0; dx < p.kw; ++dx) xb |= ((uint32_t)(ix0 + dx) < (uint32_t)p.W) ? (1u << dx) : 0u;
+    for (int dx = 0; dx < c.ntx; ++dx) xb |= ((uint32_t)(ix0 + dx) < (uint32_t)p.W) ? (1u << dx) : 0u;
 #pragma nounroll
-    for (int dy = 0; dy < p.kh; ++dy) bits |= (ok && (uint32_t)(iy0 + dy) < (uint32_t)p.H) ? (xb << (dy * p.kw)) : 0u;
+    for (int dy = 0; dy < c.nty; ++dy) bits |= (ok && (uint32_t)(iy0 + dy) < (uint32_t)p.H) ? (xb << (dy * c.ntx)) : 0u;
     vbits[i] = bits;
   }
   const int kpt = p.K / BK;
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   u32x4 wreg[G::NB];
   // next step to request: tap (row, column), channel step; byte offsets of the step inside the activation / weight tensors
   int q_tap = 0, q_dy = 0, q_dx = 0, q_kc = 0;
-  uint32_t q_x = 0, q_x2 = 0, q_w = 0;
+  uint32_t q_x = 0, q_x2 = 0, q_w = (uint32_t)(c.wy0 * p.kw + c.wx0) * wtap;
 
   // Every load is unconditional on an in-bounds address (a branch around a load serialises the prefetch): invalid taps read
   // offset 0 and are zeroed when staged.
@@ -173,13 +187,13 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
     if (++q_kc == kpt) {
       q_kc = 0;
       ++q_tap;
-      if (++q_dx == p.kw) {
+      if (++q_dx == c.ntx) {
         q_dx = 0;
         ++q_dy;
       }
       q_x = (uint32_t)((q_dy * p.W + q_dx) * p.ldx) * 2u;
       q_x2 = (uint32_t)((q_dy * p.W + q_dx) * p.ldx2) * 2u;
-      q_w = (uint32_t)q_tap * wtap;
+      q_w = (uint32_t)((c.wy0 + c.wstep * q_dy) * p.kw + c.wx0 + c.wstep * q_dx) * wtap;
     }
   };
 
@@ -383,12 +397,21 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   const bool want_stats = p.stat_sum != nullptr;
 
   U128 xv[NGRP][NPASS], old[NGRP][NPASS];
+  int mo[NGRP][NPASS];                     // output pixel of each epilogue row (a parity class strides the output image)
 #pragma unroll
   for (int g = 0; g < NGRP; ++g)
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       const int m = mt * G::BM + g * 64 + pass * RPP + rr;
-      const int mc = m < M ? m : M - 1;
+      int mc = m < M ? m : M - 1;
+      if (c.o_mul != 1) {
+        const int hw = c.Hq * c.Wq;
+        const int b = mc / hw;
+        const int rem = mc - b * hw;
+        const int oy = rem / c.Wq, ox = rem - oy * c.Wq;
+        mc = (b * p.Ho + oy * c.o_mul + c.oy_add) * p.Wo + ox * c.o_mul + c.ox_add;
+      }
+      mo[g][pass] = mc;
       if (EPI == CX_EPI_MASK) xv[g][pass].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + nch);
       if (p.accumulate)
         old[g][pass].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + nch);
@@ -438,7 +461,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
             o.e[j] = f2bf(fmaf(escale[j], dz, bf2f(old[g][pass].e[j])));
           }
         }
-        *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + nch) = o.u;
+        *reinterpret_cast<uint4*>(Y + (size_t)mo[g][pass] * p.ldy + nch) = o.u;
       }
     }
     __syncthreads();
@@ -459,7 +482,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
       for (int j = 0; j < 8; ++j) wg_stat_put(scratch, BN, wave, cq * 8 + j, s1[j], s2[j]);
     }
-    wg_stat_end<G::NW>(scratch, BN, tid, G::NT, p.stat_sum, p.stat_sq, p.stat_det, p.stat_det ? mt : (int)blockIdx.x, p.stat_replicas,
+    wg_stat_end<G::NW>(scratch, BN, tid, G::NT, p.stat_sum, p.stat_sq, p.stat_det, p.stat_det ? c.row0 + mt : (int)blockIdx.x, p.stat_replicas,
                        p.stat_rstride, n0, p.N);
   }
 }
@@ -474,14 +497,12 @@ extern "C" int dbg_conv_mm_stamps(unsigned long long* host, int n_words) {     /
 }
 
 template <int WMW, int WNW, int PRO, int EPI>
-int launch(const CxConv& p, hipStream_t st) {
+int launch(const CxConv& p, const Cls& c, hipStream_t st) {
   using G = MG<WMW, WNW>;
-  const long long M = (long long)p.B * p.Ho * p.Wo;
-  const int m_tiles = (int)((M + G::BM - 1) / G::BM);
+  const int m_tiles = (c.Mq + G::BM - 1) / G::BM;
   const int n_tiles = p.N / G::BN;
   const size_t smem = (size_t)NCoef<PRO>::v * p.K * 4 + G::MAIN_BYTES;
   if (smem > 160 * 1024) return CX_ESHAPE;
-  if (const int e = stat_rows_check(p, m_tiles)) return e;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mm_kernel<WMW, WNW, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -492,19 +513,29 @@ int launch(const CxConv& p, hipStream_t st) {
     constexpr int DP = PRO == CX_PRO_NONE ? CX_PRO_NONE : CX_PRO_AFFINE_RELU;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mm_kernel<WMW, WNW, DP, CX_EPI_STORE, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, DP, CX_EPI_STORE, true>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, (int)M, n_tiles);
+    hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, DP, CX_EPI_STORE, true>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, c, n_tiles);
     return launch_status();
   }
-  hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, PRO, EPI>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, (int)M, n_tiles);
+  hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, PRO, EPI>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, c, n_tiles);
   return launch_status();
 }
 
 // tile form: 1 = 128 x 128 (256 threads), 3 = 128 x 256 (512 threads).  (2 = 256 x 128, MG<4, 2>, was measured and never won:
 // it stages twice the activations per weight row, the expensive operand; not instantiated.)
 template <int PRO, int EPI>
-int launch_form(const CxConv& p, hipStream_t st, int form) {
-  if (form == 3) return launch<2, 4, PRO, EPI>(p, st);
-  return launch<2, 2, PRO, EPI>(p, st);
+int launch_form(const CxConv& p, const Cls& c, hipStream_t st, int form) {
+  if (form == 3) return launch<2, 4, PRO, EPI>(p, c, st);
+  return launch<2, 2, PRO, EPI>(p, c, st);
+}
+
+int launch_any(const CxConv& p, const Cls& c, hipStream_t st, int form) {
+  if (p.epilogue == CX_EPI_STORE) {
+    if (p.prologue == CX_PRO_NONE) return launch_form<CX_PRO_NONE, CX_EPI_STORE>(p, c, st, form);
+    if (p.prologue == CX_PRO_AFFINE_RELU) return launch_form<CX_PRO_AFFINE_RELU, CX_EPI_STORE>(p, c, st, form);
+    return launch_form<CX_PRO_AFFINE2, CX_EPI_STORE>(p, c, st, form);
+  }
+  if (p.prologue == CX_PRO_AFFINE2) return launch_form<CX_PRO_AFFINE2, CX_EPI_MASK>(p, c, st, form);
+  return launch_form<CX_PRO_NONE, CX_EPI_MASK>(p, c, st, form);
 }
 
 }  // namespace
@@ -523,30 +554,70 @@ int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   static const int env_form0 = [] { const char* e = getenv("CX_MM_FORM"); return e ? atoi(e) : 0; }();
   const int env_on = g_mm_on >= 0 ? g_mm_on : env_on0;
   const int env_form = g_mm_form >= 0 ? g_mm_form : env_form0;
-  // the transposed-stride input gradients (three per ResNet152 step) stay on the generic kernel: their tap offsets are not linear
-  if (!env_on || p.mode != CX_MODE_CONV || p.tstride > 1 || (p.K % BK) || (p.N % 128) || p.kh * p.kw > 32 || p.dtype != CX_DT_BF16) return 0;
-  const long long M = (long long)p.B * p.Ho * p.Wo;
+  if (!env_on || p.mode != CX_MODE_CONV || p.tstride > 2 || (p.K % BK) || (p.N % 128) || p.kh * p.kw > 32 || p.dtype != CX_DT_BF16) return 0;
+  const bool ok_combo = (p.epilogue == CX_EPI_STORE && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE_RELU || p.prologue == CX_PRO_AFFINE2)) ||
+                        (p.epilogue == CX_EPI_MASK && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE2));
+  if (!ok_combo) return 0;
   // 32-bit byte offsets inside every tensor
   if ((unsigned long long)p.B * p.H * p.W * (unsigned long long)(p.ldx > p.ldx2 ? p.ldx : p.ldx2) * 2 >= (1ull << 32)) return 0;
   if ((unsigned long long)p.kh * p.kw * p.N * p.K * 2 >= (1ull << 32)) return 0;
+  const int ts = p.tstride > 1 ? 2 : 1;
   // Measured on the ResNet152 shapes (scratch/bench_mm.py): 128 x 256 tiles wherever N allows and a tile has more than four
   // k-steps (1.9-2.7x the generic kernel); with at most four steps a tile is prologue + epilogue, the smaller tile wins, and with
   // one or two steps the generic kernel (32-channel steps, three workgroups per CU) is as fast.
-  const int nsteps = p.kh * p.kw * (p.K / BK);
-  if (!env_form && nsteps <= 2) return 0;
+  const int nsteps = (ts == 2 ? (p.kh * p.kw + 3) / 4 : p.kh * p.kw) * (p.K / BK);
+  if (!env_form && ts == 1 && nsteps <= 2) return 0;
   int form = (p.N % 256 == 0 && nsteps > 4) ? 3 : 1;
   if (env_form) form = env_form == 3 ? 3 : 1;
   if (form == 3 && (p.N % 256)) form = 1;
   if (form == 3 && (size_t)NCoef<CX_PRO_AFFINE2>::v * p.K * 4 + MG<2, 4>::MAIN_BYTES > 160 * 1024) form = 1;
-  *handled = true;
-  if (p.epilogue == CX_EPI_STORE) {
-    if (p.prologue == CX_PRO_NONE) return launch_form<CX_PRO_NONE, CX_EPI_STORE>(p, st, form);
-    if (p.prologue == CX_PRO_AFFINE_RELU) return launch_form<CX_PRO_AFFINE_RELU, CX_EPI_STORE>(p, st, form);
-    if (p.prologue == CX_PRO_AFFINE2) return launch_form<CX_PRO_AFFINE2, CX_EPI_STORE>(p, st, form);
-  } else if (p.epilogue == CX_EPI_MASK) {
-    if (p.prologue == CX_PRO_AFFINE2) return launch_form<CX_PRO_AFFINE2, CX_EPI_MASK>(p, st, form);
-    if (p.prologue == CX_PRO_NONE) return launch_form<CX_PRO_NONE, CX_EPI_MASK>(p, st, form);
+  const int bm = 128;
+
+  if (ts == 1) {
+    Cls c;
+    c.nty = p.kh, c.ntx = p.kw;
+    c.i_mul = p.stride, c.iy_add = -p.pad, c.ix_add = -p.pad;
+    c.wy0 = c.wx0 = 0, c.wstep = 1;
+    c.Hq = p.Ho, c.Wq = p.Wo, c.Mq = p.B * p.Ho * p.Wo;
+    c.o_mul = 1, c.oy_add = c.ox_add = 0, c.row0 = 0;
+    if (const int e = stat_rows_check(p, (c.Mq + bm - 1) / bm)) {
+      *handled = true;
+      return e;
+    }
+    *handled = true;
+    return launch_any(p, c, st, form);
   }
-  *handled = false;
+
+  // input gradient of a stride-2 convolution: one launch per parity class of the output pixels
+  Cls cls[4];
+  int n = 0, rows = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int d0y = (p.pad + py) & 1, d0x = (p.pad + px) & 1;
+      Cls c;
+      c.nty = d0y < p.kh ? (p.kh - d0y + 1) / 2 : 0;
+      c.ntx = d0x < p.kw ? (p.kw - d0x + 1) / 2 : 0;
+      c.Hq = (p.Ho - py + 1) / 2, c.Wq = (p.Wo - px + 1) / 2;
+      c.Mq = p.B * c.Hq * c.Wq;
+      if (c.Mq <= 0) continue;
+      if (c.nty * c.ntx == 0) {
+        // no tap reaches these pixels: their gradient is zero.  Accumulating, that is nothing to do (the statistic sums gain
+        // zeros); storing, the generic kernel writes the zeros.
+        if (!p.accumulate) return 0;
+        continue;
+      }
+      c.i_mul = 1;
+      c.iy_add = (py + d0y - p.pad) >> 1, c.ix_add = (px + d0x - p.pad) >> 1;      // (arithmetic shift: exact, may be negative)
+      c.wy0 = d0y, c.wx0 = d0x, c.wstep = 2;
+      c.o_mul = 2, c.oy_add = py, c.ox_add = px;
+      c.row0 = rows;
+      rows += (c.Mq + bm - 1) / bm;
+      cls[n++] = c;
+    }
+  if (n == 0) return 0;
+  *handled = true;
+  if (const int e = stat_rows_check(p, rows)) return e;
+  for (int i = 0; i < n; ++i)
+    if (const int e = launch_any(p, cls[i], st, form)) return e;
   return 0;
 }

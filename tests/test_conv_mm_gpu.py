@@ -95,14 +95,18 @@ def test_forward_against_torch(dev, select, form, B, H, W, K, N, ksz, stride, pr
     (2, 9, 10, 128, 128, 1, 1, False, 2),
     (2, 9, 10, 256, 128, 1, 1, True, 2),
     (3, 10, 12, 64, 256, 3, 1, False, 2),
-    (2, 6, 7, 128, 128, 3, 2, False, 2),        # input gradient of a stride-2 3x3 (declined: stays on the generic kernel)
+    (2, 6, 7, 128, 128, 3, 2, False, 2),        # input gradient of a stride-2 3x3: four parity-class launches (1, 2, 2, 4 taps)
+    (3, 7, 5, 64, 256, 3, -2, True, 2),         # the same with odd input sizes (13 x 9): classes of unequal size
+    (2, 6, 7, 128, 256, 1, 2, True, 2),         # stride-2 1x1 (downsample), accumulating: only the even-even class has a tap
+    (2, 6, 7, 128, 128, 1, 2, False, 0),        # storing: the untouched classes need zeros (declined, generic kernel)
     (4, 10, 10, 128, 256, 3, 1, True, 2),       # 128 x 256 tiles with the two-tensor operand
     (2, 8, 8, 192, 128, 1, 1, True, 0),         # plain operand, accumulate (AA projection gradient form)
 ])
 def test_input_gradient_mask_epilogue_against_torch(dev, select, form, B, H, W, K, N, ksz, ts, acc, pro):
     from chexpert_amd import ops
     select(1, form)
-    Ho, Wo = (H * ts, W * ts) if ts > 1 else (H, W)              # forward input size (even sizes: stride-2 pad-1 3x3 halves them)
+    odd, ts = (1, -ts) if ts < 0 else (0, ts)                    # negative ts: odd forward input size (2H-1, 2W-1)
+    Ho, Wo = (H * ts - odd, W * ts - odd) if ts > 1 else (H, W)  # forward input size
     ub, u = nhwc(20, B, H, W, K, dev)
     vb, v = nhwc(21, B, H, W, K, dev)
     exb, ex = nhwc(22, B, Ho, Wo, N + 32, dev)
@@ -112,7 +116,7 @@ def test_input_gradient_mask_epilogue_against_torch(dev, select, form, B, H, W, 
     e_sc, e_sh = rnd(28, (N,), -0.3, 1.5), rnd(29, (N,), -0.5, 0.5)
     e_mu, e_r, e_scale = rnd(30, (N,), -0.5, 0.5), rnd(31, (N,), 0.5, 2.0), rnd(32, (N,), -0.3, 1.5)
     dy = bf(u * cv(pa) + v * cv(pb) + cv(pc)) if pro == 2 else u
-    acc_ref = F.conv_transpose2d(dy, w, stride=ts, padding=ksz // 2, output_padding=ts - 1 if ksz == 3 else 0)
+    acc_ref = F.conv_transpose2d(dy, w, stride=ts, padding=ksz // 2, output_padding=(ts - 1 - odd) if (ksz == 3 or ts > 1) else 0)
     assert acc_ref.shape[2:] == (Ho, Wo)
     exs = ex[:, :N]
     dz = torch.where((exs * cv(e_sc) + cv(e_sh)) > 0, acc_ref, torch.zeros(()))
