@@ -61,6 +61,16 @@ class KernelTimer:
             return "pw_fwdk_kernel<128, %d>" % pro
         if mode == 2:
             return "stem_fwd_kernel"
+        # conv_mm.hip (cx_try_conv_mm): wide channel counts; 128 x 256 tiles where N allows and a tile has more than four k-steps
+        ts, taps = kw.get("tstride", 1), kh * kw.get("kw", 1)
+        if mode == 0 and K % 64 == 0 and N % 128 == 0 and ts <= 2 and taps <= 32 and \
+                ((epi == 0 and pro in (0, 1, 2)) or (epi == 1 and pro in (0, 2))):
+            nsteps = ((taps + 3) // 4 if ts == 2 else taps) * (K // 64)
+            zero_tap_classes = ts == 2 and (kh < 2 or kw.get("kw", 1) < 2)
+            if not (ts == 1 and nsteps <= 2) and not (zero_tap_classes and not kw.get("accumulate")):
+                wide = N % 256 == 0 and nsteps > 4 and (3 * K * 4 + 2 * (128 + 256) * 144 <= 160 * 1024)
+                # (a stride-2 input gradient is up to four launches of the kernel, one per parity class: timed as one unit)
+                return "conv_mm_kernel<2, %d, %d, %d, false>%s" % (4 if wide else 2, pro, epi, " x parity classes" if ts == 2 else "")
         bn = 128 if N % 128 == 0 else (32 if N == 32 else 64)
         return "conv_gemm_kernel<%d, %d, %d, %d>" % (bn, pro, mode, epi)
 
@@ -70,8 +80,14 @@ class KernelTimer:
         K = kw.get("K") or x.shape[3]
         if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and (gp, xp, K, N) == (2, 1, 128, 32):
             return "conv3x3_ring_wgrad_kernel" if x.shape[2] >= 56 and x.shape[1] * x.shape[2] >= 3136 else "conv3x3_strip_wgrad_kernel"
-        if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and N % 128 == 0 and K >= 64 and \
-                g.shape[0] * g.shape[1] * g.shape[2] * K >= (1 << 23):
+        if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and K % 32 == 0 and N % 8 == 0 and \
+                K <= 2048 and N <= 2048 and xp == 1 and gp in (0, 2) and 4 <= x.shape[2] <= 126:
+            return "conv3x3_strip_wgrad_kernel"               # (cx_try_strip_wgrad: any tile pairs of 32 x 32 channels)
+        M = g.shape[0] * g.shape[1] * g.shape[2]
+        if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0 and N % 128 == 0 and K % 8 == 0 and K >= 64 and \
+                M % 64 == 0 and gp in (0, 2) and xp in (0, 1):
+            return "wgrad_mm_kernel<2, 4, %d, %d>" % (gp, xp)  # wgrad_mm.hip (cx_try_wgrad_mm)
+        if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and N % 128 == 0 and K >= 64 and M * K >= (1 << 23):
             return "pw_wgrad_kernel<%d, %d>" % (gp, xp)
         t = (64, 32) if mode == 2 else ((32, 128) if N == 32 else ((128, 64) if N % 128 == 0 else (64, 64)))
         return "wgrad_kernel<%d, %d, %d, %d, %d>" % (t[0], t[1], gp, xp, mode)

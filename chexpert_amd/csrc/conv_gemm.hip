@@ -98,15 +98,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
   // NOTE: every global load below is UNCONDITIONAL (invalid rows read a clamped, in-bounds address and are
   // zeroed when staged).  A branch around a load makes hipcc wait vmcnt(0) per load (cdna_hip_programming.md,
   // "Three .s-level traps" (c)), which serialises the whole prefetch.
+  // Steps are requested in order: the tap / channel-step position advances incrementally (no per-step integer divisions), and a
+  // transposed stride is 1 or 2 (shift and mask).
+  const int ts_sh = p.tstride > 1 ? 1 : 0;
+  int q_tap = 0, q_kc = 0, q_dy = 0, q_dx = 0, w_kc = 0;
   auto issue_loads = [&](int s) {
-    const int tap = s / kpt, kc = s - tap * kpt;
-    const int dy = (MODE == CX_MODE_CONV) ? tap / p.kw : tap;
-    const int dx = (MODE == CX_MODE_CONV) ? tap - dy * p.kw : 0;
+    (void)s;
+    const int tap = q_tap, kc = q_kc;
+    const int dy = (MODE == CX_MODE_CONV) ? q_dy : tap;
+    const int dx = (MODE == CX_MODE_CONV) ? q_dx : 0;
+    w_kc = kc;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (MODE == CX_MODE_STEM) {
         const int iy = riy[i] + dy, ix = rix[i];
-        av[i] = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        av[i] = rvalid[i] & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
         const int cy = av[i] ? iy : 0, cx = av[i] ? ix : 0;
         ra[i][0] = *reinterpret_cast<const uint4*>(X + ((size_t)(rb[i] * p.H + cy) * p.W + cx) * 4);
       } else if (MODE == CX_MODE_POOL2) {
@@ -118,14 +124,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
         }
       } else {
         int iy = riy[i] + dy, ix = rix[i] + dx;
-        bool ok = rvalid[i] && iy >= 0 && ix >= 0;
-        if (p.tstride > 1) {          // input gradient of a strided conv: only source positions on the stride grid exist
-          ok = ok && (iy % p.tstride == 0) && (ix % p.tstride == 0);
-          iy /= p.tstride;
-          ix /= p.tstride;
-        }
+        // input gradient of a stride-2 conv: only source positions on the stride grid exist
+        bool ok = rvalid[i] & (iy >= 0) & (ix >= 0) & (((iy | ix) & ts_sh) == 0);
+        iy >>= ts_sh;
+        ix >>= ts_sh;
         const bool kok = kc * BK + qa * 8 < p.K;                  // partial last K step
-        av[i] = ok && iy < p.H && ix < p.W && kok;
+        av[i] = ok & (iy < p.H) & (ix < p.W) & kok;
         const int cy = av[i] ? iy : 0, cx = av[i] ? ix : 0;
         const int ck = kok ? kc * BK + qa * 8 : 0;
         const size_t pix = (size_t)(rb[i] * p.H + cy) * p.W + cx;
@@ -146,10 +150,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
         rbw[i] = *reinterpret_cast<const uint4*>(Wp + off);
       }
     }
+    if (++q_kc == kpt) {
+      q_kc = 0;
+      ++q_tap;
+      if (++q_dx == p.kw) {
+        q_dx = 0;
+        ++q_dy;
+      }
+    }
   };
 
   auto write_stage = [&](int s, int buf) {
-    const int tap = s / kpt, kc = s - tap * kpt;
+    (void)s;
+    const int tap = 0, kc = w_kc;             // the step requested last
     char* A = tiles + buf * G::STAGE;
     char* Bt = A + A_BYTES;
     const int c0 = kc * BK + qa * 8;
@@ -448,6 +461,7 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   hipStream_t st = as_stream(stream);
   if (p.mode == CX_MODE_CONV) {
     if (p.kh <= 0 || p.kw <= 0 || p.stride <= 0 || p.pad < 0) return CX_ESHAPE;
+    if (p.tstride > 2) return CX_EUNSUPPORTED;        // the reference's strides are 1 and 2
     if (p.tstride > 1) {
       // (B,H,W) is the strided conv's OUTPUT gradient, (Ho,Wo) its input: H = (Ho + 2*fwd_pad - kh)/tstride + 1 with
       // pad = kh-1-fwd_pad; stride of the implicit GEMM itself is 1

@@ -69,7 +69,7 @@ typedef struct CxConv {
   int32_t ldx, ldx2, ldy, ldex;
   int32_t kh, kw, stride, pad;
   int32_t prologue, mode, epilogue, accumulate;   /* accumulate: y += result (both epilogues)             */
-  int32_t tstride;      /* > 1: input gradient of a conv with that stride (x is its output gradient,    */
+  int32_t tstride;      /* 2: input gradient of a stride-2 conv (x is its output gradient,              */
                         /* stride must be 1, pad = kh-1-forward_pad, weights packed with transpose=1)    */
   int32_t stat_replicas; /* R > 1: workgroup b adds its statistics to replica b % R, replica r of channel */
   int32_t stat_rstride;  /* n lives at stat_sum[r*stat_rstride + n].  Thousands of workgroups adding to   */
