@@ -257,6 +257,7 @@ __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2,
   }
 
   // ---- partial tile -> fp32 OIHW gradient
+  if (p.splits == -7) return;           // (timing-only diagnostic, CX_WGRAD_MM_NOSTORE: results are wrong)
   const int lrow = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -291,7 +292,10 @@ int launch(const CxWgrad& p, hipStream_t st, int wgs_target) {
                               (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL((wgrad_mm_kernel<WA, WB, GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(G::NT), smem, st, p, c_tiles, n_tiles,
+  static const bool nostore = getenv("CX_WGRAD_MM_NOSTORE") != nullptr;
+  CxWgrad q = p;
+  if (nostore) q.splits = -7;
+  hipLaunchKernelGGL((wgrad_mm_kernel<WA, WB, GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(G::NT), smem, st, q, c_tiles, n_tiles,
                      total_steps, sps);
   return launch_status();
 }
