@@ -165,11 +165,20 @@ def _committed(suffix, args):
     return best
 
 
+def _lookup(kernels, tag):
+    """Entry of a committed per-kernel table for a bench tag: the exact instantiation name, else the only instantiation of the
+    same kernel template (tags that do not spell the template arguments, e.g. conv3x3_strip_wgrad_kernel)."""
+    if tag in kernels:
+        return kernels[tag]
+    same = [k for k in kernels if k.split("<")[0] == tag.split("<")[0]]
+    return kernels[same[0]] if len(same) == 1 and "<" not in tag else None
+
+
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic*.json: FETCH_SIZE x2 + WRITE_SIZE,
     collected with rocprofv3 --pmc in their own runs); null when no pass was taken on this workload."""
     j = _committed("_pmc_traffic", args)
-    k = None if j is None else j["kernels"].get(kernel)
+    k = None if j is None else _lookup(j["kernels"], kernel)
     return None if k is None else k["hbm_bytes_per_launch"]
 
 
@@ -241,7 +250,7 @@ def committed_counter(kernel, args, key):
     """Per-kernel figures from the committed SQ counter pass (profiles/*_sq_counters*.json: SQ_VALU_MFMA_BUSY_CYCLES over
     GRBM_GUI_ACTIVE, collected with rocprofv3 --pmc in its own run); null when no pass was taken on this workload."""
     j = _committed("_sq_counters", args)
-    k = None if j is None else j["kernels"].get(kernel)
+    k = None if j is None else _lookup(j["kernels"], kernel)
     return None if k is None else k.get(key)
 
 

@@ -1,7 +1,12 @@
 import csv, sys, glob
 f = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_stats.csv'))[-1]
-steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = list(csv.DictReader(open(f)))
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1
+# training steps actually profiled (warm-up, instrumented and timed): the loss kernel runs once per step
+for r in rows:
+    if 'bce_' in r['Name']:
+        steps = float(r['Calls'])
+        break
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 16]:
     n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:70]
