@@ -35,7 +35,8 @@ class CxWgrad(C.Structure):
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ho", _i32), ("Wo", _i32), ("K", _i32), ("N", _i32),
                 ("ldg", _i32), ("ldg2", _i32), ("ldx", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
-                ("g_prologue", _i32), ("x_prologue", _i32), ("mode", _i32), ("splits", _i32), ("dtype", _i32)]
+                ("g_prologue", _i32), ("x_prologue", _i32), ("mode", _i32), ("splits", _i32), ("dtype", _i32),
+                ("scratch", _fp), ("scratch_floats", C.c_int64)]
 
 
 class CxPackDesc(C.Structure):
@@ -52,6 +53,7 @@ SIGNATURES = {
     "cx_conv_gemm": [C.POINTER(CxConv), _vp],
     "cx_conv_wgrad": [C.POINTER(CxWgrad), _vp],
     "cx_conv1x1_dgrad_wgrad": [C.POINTER(CxConv), _vp, _vp],
+    "cx_conv1x1_dgrad_wgrad_ws": [C.POINTER(CxConv), _vp, _vp, C.c_int64, _vp],
     "cx_pack_weights": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "cx_pack_weights_table": [_vp, _vp, _vp, _i, _vp],
     "cx_nchw3_to_nhwc4": [_vp, _vp, _i, _i, _i, _vp],
@@ -137,7 +139,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cx_error_string" else C.c_int
-        if l.cx_abi_version() != 3:
+        if l.cx_abi_version() != 4:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l
     return _lib

@@ -82,6 +82,22 @@ __device__ __forceinline__ void wg_stat_end(float* scratch, int CW, int tid, int
     }
   }
 }
+// ---- weight-gradient partial tiles --------------------------------------------------------------------------------------
+// A weight-gradient kernel splits the pixel range over workgroups.  Its partial sums either go to dw through fp32 atomics (order,
+// and with it the last bits, change from run to run) or, with a slab workspace, each (split, element) is plain-stored exactly once
+// and cx_dw_reduce adds the slabs to dw in split order.
+__device__ __forceinline__ void dw_out(float* dw, float* slab, size_t total, int split, size_t idx, float v) {
+  if (slab)
+    slab[(size_t)split * total + idx] = v;
+  else
+    atomicAdd(dw + idx, v);
+}
+// the slab to hand to a kernel: p's workspace if it holds splits * total floats, else null (atomics)
+static inline float* dw_slab(float* scratch, long long scratch_floats, long long splits, long long total) {
+  return (scratch && splits * total <= scratch_floats) ? scratch : nullptr;
+}
+int cx_dw_reduce(float* dw, const float* slab, size_t total, int splits, hipStream_t st);      // elementwise.hip
+
 static inline int stat_rows_check(const CxConv& p, int rows) {
   if (!p.stat_det || !p.stat_sum) return 0;
   if (rows > p.stat_replicas || p.stat_rstride < p.N) return CX_ESTATROWS;

@@ -56,7 +56,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int k0, i
 // half as many channel tiles, for the layers with many input channels)
 template <int PRO, bool ACC, int BC>
 __global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const CxConv p, float* __restrict__ dw, const int M,
-                                                                         const int c_tiles, const int tiles_per_split) {
+                                                                         const int c_tiles, const int tiles_per_split,
+                                                                         float* __restrict__ slab) {
   constexpr int NT = BC * 4;
   constexpr int W_BYTES = BC * PITCH;
   constexpr int COEF_BYTES = (5 * BC + 3 * KD) * 4;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = wn_[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(dw + (size_t)n * p.N + c, accw[i][r]);
+        dw_out(dw, slab, (size_t)KD * p.N, split, (size_t)n * p.N + c, accw[i][r]);
       }
     }
   }
@@ -312,7 +313,7 @@ constexpr int XH2_BYTES = BM2 * XH_PITCH;
 // phase, 32 no input-gradient MFMAs, 64 no AFFINE2 arithmetic in the staging
 template <int PRO, bool ACC, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* __restrict__ dw, const int M, const int c_tiles,
-                                                         const int tiles_per_split) {
+                                                         const int tiles_per_split, float* __restrict__ slab) {
   constexpr int BC = 128, NT = 512;
   constexpr int W_BYTES = BC * PITCH;
   constexpr int COEF_BYTES = (5 * BC + 3 * KD) * 4;
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(dw + (size_t)n * p.N + c, accw[i][r]);
+        dw_out(dw, slab, (size_t)KD * p.N, split, (size_t)n * p.N + c, accw[i][r]);
       }
     }
   }
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
 }
 
 template <int PRO, bool ACC>
-int launch_bwd2(const CxConv& p, float* dw, hipStream_t st) {
+int launch_bwd2(const CxConv& p, float* dw, float* scratch, long long scratch_floats, hipStream_t st) {
   constexpr int BC = 128;
   const long long M = (long long)p.B * p.Ho * p.Wo;
   const int m_tiles = (int)((M + BM2 - 1) / BM2);
@@ -765,7 +766,7 @@ int launch_bwd2(const CxConv& p, float* dw, hipStream_t st) {
   case D:                                                                                                                    \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd2_kernel<PRO, ACC, D>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)smem);                                                                                    \
-    hipLaunchKernelGGL((pw_bwd2_kernel<PRO, ACC, D>), g, b, smem, st, p, dw, (int)M, c_tiles, tps);                           \
+    hipLaunchKernelGGL((pw_bwd2_kernel<PRO, ACC, D>), g, b, smem, st, p, dw, (int)M, c_tiles, tps, (float*)nullptr);          \
     return launch_status();
       switch (dbg) {
         CX_DBG_CASE(1) CX_DBG_CASE(2) CX_DBG_CASE(4) CX_DBG_CASE(7) CX_DBG_CASE(15) CX_DBG_CASE(23) CX_DBG_CASE(39) CX_DBG_CASE(71)
@@ -775,12 +776,15 @@ int launch_bwd2(const CxConv& p, float* dw, hipStream_t st) {
 #undef CX_DBG_CASE
     }
   }
-  hipLaunchKernelGGL((pw_bwd2_kernel<PRO, ACC>), dim3(c_tiles * splits), dim3(512), smem, st, p, dw, (int)M, c_tiles, tps);
-  return launch_status();
+  const size_t total = (size_t)KD * p.N;
+  float* slab = dw_slab(scratch, scratch_floats, splits, (long long)total);
+  hipLaunchKernelGGL((pw_bwd2_kernel<PRO, ACC>), dim3(c_tiles * splits), dim3(512), smem, st, p, dw, (int)M, c_tiles, tps, slab);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(dw, slab, total, splits, st) : 0;
 }
 
 template <int PRO, bool ACC, int BC>
-int launch_bwd_bc(const CxConv& p, float* dw, hipStream_t st) {
+int launch_bwd_bc(const CxConv& p, float* dw, float* scratch, long long scratch_floats, hipStream_t st) {
   const long long M = (long long)p.B * p.Ho * p.Wo;
   const int m_tiles = (int)((M + BM - 1) / BM);
   const int c_tiles = (p.N + BC - 1) / BC;
@@ -797,17 +801,21 @@ int launch_bwd_bc(const CxConv& p, float* dw, hipStream_t st) {
                               (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL((pw_bwd_kernel<PRO, ACC, BC>), dim3(c_tiles * splits), dim3(BC * 4), smem, st, p, dw, (int)M, c_tiles, tps);
-  return launch_status();
+  const size_t total = (size_t)KD * p.N;
+  float* slab = dw_slab(scratch, scratch_floats, splits, (long long)total);
+  hipLaunchKernelGGL((pw_bwd_kernel<PRO, ACC, BC>), dim3(c_tiles * splits), dim3(BC * 4), smem, st, p, dw, (int)M, c_tiles, tps, slab);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(dw, slab, total, splits, st) : 0;
 }
 
 template <int PRO, bool ACC>
-int launch_bwd(const CxConv& p, float* dw, hipStream_t st) {
+int launch_bwd(const CxConv& p, float* dw, float* scratch, long long scratch_floats, hipStream_t st) {
   static const int force = []() { const char* e = getenv("CX_PW_BWD_BC"); return e ? atoi(e) : 0; }();
   const bool wide = force ? force == 128 : p.N >= 128;  // measured crossover
   static const int v1 = []() { const char* e = getenv("CX_PW_BWD_V1"); return e ? atoi(e) : 0; }();   // diagnostic: the round-1 kernel
-  if (wide && !v1) return launch_bwd2<PRO, ACC>(p, dw, st);
-  return wide ? launch_bwd_bc<PRO, ACC, 128>(p, dw, st) : launch_bwd_bc<PRO, ACC, 64>(p, dw, st);
+  if (wide && !v1) return launch_bwd2<PRO, ACC>(p, dw, scratch, scratch_floats, st);
+  return wide ? launch_bwd_bc<PRO, ACC, 128>(p, dw, scratch, scratch_floats, st)
+              : launch_bwd_bc<PRO, ACC, 64>(p, dw, scratch, scratch_floats, st);
 }
 
 }  // namespace
@@ -817,7 +825,7 @@ extern "C" int dbg_pw_bwd2_stamps(unsigned long long* host, int n_words) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pw_bwd2_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
 }
 
-extern "C" int cx_conv1x1_dgrad_wgrad(const CxConv* pp, float* dw, void* stream) {
+extern "C" int cx_conv1x1_dgrad_wgrad_ws(const CxConv* pp, float* dw, float* scratch, int64_t scratch_floats, void* stream) {
   if (!pp || !dw) return CX_EINVAL;
   const CxConv& p = *pp;
   if (!p.x || !p.w || !p.y || !p.ex || !p.e_sc || !p.e_sh || !p.e_mu || !p.e_r || !p.e_scale || !p.stat_sum || !p.stat_sq) return CX_EINVAL;
@@ -832,6 +840,12 @@ extern "C" int cx_conv1x1_dgrad_wgrad(const CxConv* pp, float* dw, void* stream)
   if (p.stat_replicas < 0 || (p.stat_replicas > 1 && p.stat_rstride < p.N)) return CX_EINVAL;
   hipStream_t st = as_stream(stream);
   if (p.prologue == CX_PRO_AFFINE2)
-    return p.accumulate ? launch_bwd<CX_PRO_AFFINE2, true>(p, dw, st) : launch_bwd<CX_PRO_AFFINE2, false>(p, dw, st);
-  return p.accumulate ? launch_bwd<CX_PRO_NONE, true>(p, dw, st) : launch_bwd<CX_PRO_NONE, false>(p, dw, st);
+    return p.accumulate ? launch_bwd<CX_PRO_AFFINE2, true>(p, dw, scratch, scratch_floats, st)
+                        : launch_bwd<CX_PRO_AFFINE2, false>(p, dw, scratch, scratch_floats, st);
+  return p.accumulate ? launch_bwd<CX_PRO_NONE, true>(p, dw, scratch, scratch_floats, st)
+                      : launch_bwd<CX_PRO_NONE, false>(p, dw, scratch, scratch_floats, st);
+}
+
+extern "C" int cx_conv1x1_dgrad_wgrad(const CxConv* pp, float* dw, void* stream) {
+  return cx_conv1x1_dgrad_wgrad_ws(pp, dw, nullptr, 0, stream);
 }

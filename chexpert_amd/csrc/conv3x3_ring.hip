@@ -572,7 +572,8 @@ template <int NX, int NG>
 __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
-    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const RingGeo g) {
+    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const RingGeo g,
+    float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
   const int nk = (R * P + 15) / 16;
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
     __syncthreads();
     for (int idx = tid; idx < 32 * 288; idx += WNT) {
       const int n = idx / 288, i = idx - n * 288;
-      atomicAdd(dw + ((size_t)n * 128 + round * 32) * 9 + i, red[idx]);
+      dw_out(dw, slab, (size_t)32 * 128 * 9, (int)blockIdx.x, ((size_t)n * 128 + round * 32) * 9 + i, red[idx]);
     }
     __syncthreads();
   }
@@ -759,10 +760,13 @@ int launch_ring_wgrad(const CxWgrad& p, hipStream_t st, const RingGeo& g, size_t
   const int total = g.B * g.spi;
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   const bool a2 = p.g_prologue == CX_PRO_AFFINE2;
+  const size_t wtotal = (size_t)32 * 128 * 9;
+  float* slab = dw_slab(p.scratch, p.scratch_floats, grid, (long long)wtotal);
   hipLaunchKernelGGL((conv3x3_ring_wgrad_kernel<NX, NG>), dim3(grid), dim3(WNT), smem, st, (const bf16*)p.g, p.ldg,
                      (const bf16*)(a2 ? p.g2 : p.g), a2 ? p.ldg2 : p.ldg, p.ga, p.gb, p.gc, (int)a2, (const bf16*)p.x, p.ldx, p.pa, p.pb,
-                     p.dw, g);
-  return launch_status();
+                     p.dw, g, slab);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(p.dw, slab, wtotal, grid, st) : 0;
 }
 
 }  // namespace

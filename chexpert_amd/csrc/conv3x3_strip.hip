@@ -450,7 +450,7 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
     const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const int K, const int N,
-    const int c_tiles, const int n_tiles, const StripGeo g) {
+    const int c_tiles, const int n_tiles, const StripGeo g, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
   const int nk = (R * P + 15) / 16;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
   }
   for (int idx = tid; idx < 32 * 288; idx += NTHR) {
     const int n = idx / 288, i = idx - n * 288;
-    if (n0 + n < N) atomicAdd(dw + ((size_t)(n0 + n) * K + c0) * 9 + i, red[idx]);
+    if (n0 + n < N) dw_out(dw, slab, (size_t)N * K * 9, split, ((size_t)(n0 + n) * K + c0) * 9 + i, red[idx]);
   }
 }
 
@@ -736,11 +736,14 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
       }
       const int total = g.B * g.spi;
       const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+      const size_t wtotal = (size_t)p.N * p.K * 9;
+      float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
       hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<4, NCHW4>), dim3(splits * pairs), dim3(768), smem, st, (const bf16*)p.g, p.ldg,
                          (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx,
-                         p.pa, p.pb, p.dw, p.K, p.N, c_tiles, n_tiles, g);
+                         p.pa, p.pb, p.dw, p.K, p.N, c_tiles, n_tiles, g, slab);
       *handled = true;
-      return launch_status();
+      if (const int e = launch_status()) return e;
+      return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;
     }
   }
   // pixel-range splits: >= 2 workgroups per CU over the 4 channel tiles, few enough that the final atomics
@@ -757,9 +760,12 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   if (smem > 64 * 1024) return 0;
   const int total = g.B * g.spi;
   const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  const size_t wtotal = (size_t)p.N * p.K * 9;
+  float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
   hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<1, NCHW1>), dim3(splits * pairs), dim3(192), smem, st, (const bf16*)p.g, p.ldg,
                      (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx, p.pa, p.pb,
-                     p.dw, p.K, p.N, c_tiles, n_tiles, g);
+                     p.dw, p.K, p.N, c_tiles, n_tiles, g, slab);
   *handled = true;
-  return launch_status();
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;
 }

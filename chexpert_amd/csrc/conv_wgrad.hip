@@ -52,7 +52,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int k0, i
 
 template <int BNW, int BCW, int GPRO, int XPRO, int MODE>
 __global__ __launch_bounds__(256) void wgrad_kernel(const CxWgrad p, const int M, const int n_tiles, const int c_tiles,
-                                                    const int taps, const int splits, const int steps_per_split) {
+                                                    const int taps, const int splits, const int steps_per_split,
+                                                    float* __restrict__ slab) {
   using G = WGeo<BNW, BCW>;
   constexpr int NSRC = (MODE == CX_MODE_POOL2) ? 4 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -250,9 +251,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const CxWgrad p, const int M
         if (n >= p.N) continue;
         if (MODE == CX_MODE_STEM) {
           const int kx = (c >> 2) - 1, ch = c & 3;
-          if (c < 32 && kx >= 0 && ch < 3) atomicAdd(p.dw + ((size_t)(n * 3 + ch) * 7 + tap) * 7 + kx, acc[i][j][r]);
+          if (c < 32 && kx >= 0 && ch < 3)
+            dw_out(p.dw, slab, (size_t)p.N * 147, split * G::WAVES_K + wk, ((size_t)(n * 3 + ch) * 7 + tap) * 7 + kx, acc[i][j][r]);
         } else if (c < p.K) {
-          atomicAdd(p.dw + ((size_t)n * p.K + c) * taps + tap, acc[i][j][r]);
+          dw_out(p.dw, slab, (size_t)p.N * p.K * taps, split * G::WAVES_K + wk, ((size_t)n * p.K + c) * taps + tap, acc[i][j][r]);
         }
       }
     }
@@ -275,9 +277,14 @@ int launch(const CxWgrad& p, hipStream_t st) {
   const int sps = (total_steps + splits - 1) / splits;
   splits = (total_steps + sps - 1) / sps;
   const size_t smem = 2 * G::STAGE;
+  // (each k-group of waves holds its own partial sums: a slab per (split, group))
+  const size_t wtotal = (MODE == CX_MODE_STEM) ? (size_t)p.N * 147 : (size_t)p.N * p.K * taps;
+  const int slabs = splits * G::WAVES_K;
+  float* slab = dw_slab(p.scratch, p.scratch_floats, slabs, (long long)wtotal);
   hipLaunchKernelGGL((wgrad_kernel<BNW, BCW, GPRO, XPRO, MODE>), dim3(n_tiles * c_tiles * taps * splits), dim3(256), smem,
-                     st, p, M, n_tiles, c_tiles, taps, splits, sps);
-  return launch_status();
+                     st, p, M, n_tiles, c_tiles, taps, splits, sps, slab);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(p.dw, slab, wtotal, slabs, st) : 0;
 }
 
 
@@ -292,7 +299,8 @@ constexpr int ST_X_BYTES = PX * ST_XP;
 constexpr int ST_STAGE = ST_G_BYTES + 7 * ST_X_BYTES;
 
 template <int GPRO>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const int M, const int steps_per_split) {
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const int M, const int steps_per_split,
+                                                         float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16* __restrict__ Gp = reinterpret_cast<const bf16*>(p.g);
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          atomicAdd(p.dw + ((size_t)(n * 3 + ch) * 7 + tap) * 7 + kx, acc[t][i][r]);
+          dw_out(p.dw, slab, (size_t)64 * 147, (int)blockIdx.x, ((size_t)(n * 3 + ch) * 7 + tap) * 7 + kx, acc[t][i][r]);
         }
     }
   }
@@ -428,8 +436,11 @@ int launch_stem(const CxWgrad& p, hipStream_t st) {
   if (splits > total_steps) splits = total_steps;
   const int sps = (total_steps + splits - 1) / splits;
   splits = (total_steps + sps - 1) / sps;
-  hipLaunchKernelGGL((stem_wgrad_kernel<GPRO>), dim3(splits), dim3(256), 2 * ST_STAGE, st, p, M, sps);
-  return launch_status();
+  const size_t wtotal = (size_t)64 * 147;
+  float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
+  hipLaunchKernelGGL((stem_wgrad_kernel<GPRO>), dim3(splits), dim3(256), 2 * ST_STAGE, st, p, M, sps, slab);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;
 }
 
 
@@ -446,7 +457,7 @@ constexpr int PW_COEF = 5 * 128 * 4;                   // ga gb gc (dZ channels)
 
 template <int GPRO, int XPRO>
 __global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const int M, const int c_tiles, const int n_tiles,
-                                                         const int steps_per_split) {
+                                                         const int steps_per_split, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* coef = reinterpret_cast<float*>(smem);
   char* tiles = smem + PW_COEF;
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void pw_wgrad_kernel(const CxWgrad p, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + (wn * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(p.dw + (size_t)n * p.K + c, acc[i][r]);
+        dw_out(p.dw, slab, (size_t)p.N * p.K, split, (size_t)n * p.K + c, acc[i][r]);
       }
   }
 }
@@ -586,8 +597,11 @@ int launch_pw_wgrad(const CxWgrad& p, hipStream_t st) {
                               (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL((pw_wgrad_kernel<GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(512), smem, st, p, M, c_tiles, n_tiles, sps);
-  return launch_status();
+  const size_t wtotal = (size_t)p.N * p.K;
+  float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
+  hipLaunchKernelGGL((pw_wgrad_kernel<GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(512), smem, st, p, M, c_tiles, n_tiles, sps, slab);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;
 }
 
 template <int GPRO, int XPRO, int MODE>

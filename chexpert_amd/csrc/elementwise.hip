@@ -98,6 +98,46 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16* __restric
   }
 }
 
+// dw[i] += sum over the slabs, in a fixed association (bit-reproducible): eight threads per group of four elements each add a
+// contiguous range of slabs in order (four loads in flight), then lane 0 of the eight adds the eight partial sums in order.
+template <bool VEC>
+__global__ __launch_bounds__(256) void dw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slab, size_t total, int splits) {
+  constexpr int E = VEC ? 4 : 1;
+  __shared__ float part[32][8][4];
+  const int oi = threadIdx.x >> 3, j = threadIdx.x & 7;
+  const size_t i = ((size_t)blockIdx.x * 32 + oi) * E;
+  const int per = (splits + 7) >> 3;
+  const int s0 = j * per, s1 = (s0 + per < splits) ? s0 + per : splits;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < total) {
+    for (int s = s0; s < s1; ++s) {
+      if (VEC) {
+        const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)s * total + i);
+        a[0] += b.x; a[1] += b.y; a[2] += b.z; a[3] += b.w;
+      } else {
+        a[0] += slab[(size_t)s * total + i];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[oi][j][e] = a[e];
+  __syncthreads();
+  if (j == 0 && i < total) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += part[oi][k][e];
+    if (VEC) {
+      float4 d = *reinterpret_cast<float4*>(dw + i);
+      d.x += t[0]; d.y += t[1]; d.z += t[2]; d.w += t[3];
+      *reinterpret_cast<float4*>(dw + i) = d;
+    } else {
+      dw[i] += t[0];
+    }
+  }
+}
+
 // one launch for every conv weight of a model: blockIdx.y = descriptor, blockIdx.x strides over its (output, input) channel pairs.
 // A thread owns one pair: it reads the pair's kh*kw taps (contiguous fp32 in OIHW) and writes one bf16 into each tap plane; the
 // pairs run in the destination's order (input channel fastest, or output channel fastest in the transposed layout), so a wave
@@ -1103,6 +1143,17 @@ int unpool2_mask_t(const void* d, const void* x, const float* sc, const float* s
 
 
 }  // namespace
+
+int cx_dw_reduce(float* dw, const float* slab, size_t total, int splits, hipStream_t st) {
+  if (!dw || !slab || total == 0 || splits <= 0) return CX_EINVAL;
+  if ((total & 3) == 0 && aligned16(dw) && aligned16(slab)) {
+    const size_t n4 = total / 4;
+    hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, dw, slab, total, splits);
+  } else {
+    hipLaunchKernelGGL(dw_reduce_kernel<false>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, dw, slab, total, splits);
+  }
+  return launch_status();
+}
 
 extern "C" {
 

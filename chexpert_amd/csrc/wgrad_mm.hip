@@ -7,7 +7,8 @@
 // sets), prologue coefficients of the thread's fixed channel chunk held in registers, and the step's loads / prologue arithmetic /
 // LDS stores issued in packets between the MFMAs.  Both operands have the reduction index (pixel) as their slow memory axis:
 // fragments come from the [pixel][channel] LDS images through ds_read_b64_tr_b16.
-// The pixel range is split over workgroups; partial tiles leave through fp32 atomics (CxWgrad has no scratch slab).
+// The pixel range is split over workgroups; partial tiles leave through fp32 atomics, or, with CxWgrad.scratch, through slabs
+// that a second launch adds in split order (bit-reproducible).
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -75,7 +76,8 @@ template <int WA, int WB, int GPRO, int XPRO>
 __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_mm_kernel(const CxWgrad p, const int c_tiles,
                                                                                                         const int n_tiles,
                                                                                                         const int total_steps,
-                                                                                                        const int steps_per_split) {
+                                                                                                        const int steps_per_split,
+                                                                                                        float* __restrict__ slab) {
   using G = WG<WA, WB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = n0 + (wa * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          atomicAdd(p.dw + (size_t)n * p.K + c, acc[i][j][r]);
+          dw_out(p.dw, slab, (size_t)p.N * p.K, split, (size_t)n * p.K + c, acc[i][j][r]);
         }
       }
     }
@@ -295,9 +297,12 @@ int launch(const CxWgrad& p, hipStream_t st, int wgs_target) {
   static const bool nostore = getenv("CX_WGRAD_MM_NOSTORE") != nullptr;
   CxWgrad q = p;
   if (nostore) q.splits = -7;
+  const size_t total = (size_t)p.N * p.K;
+  float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)total);
   hipLaunchKernelGGL((wgrad_mm_kernel<WA, WB, GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(G::NT), smem, st, q, c_tiles, n_tiles,
-                     total_steps, sps);
-  return launch_status();
+                     total_steps, sps, slab);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(p.dw, slab, total, splits, st) : 0;
 }
 
 template <int GPRO, int XPRO>

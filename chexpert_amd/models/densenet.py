@@ -558,6 +558,7 @@ class _Engine:
 
     # ---- backward
     def backward(self, ws, dlogits):
+        ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
         m, f, s = self.model, self.model.features, self.slots
         R = self.stat_replicas
         B = ws.B

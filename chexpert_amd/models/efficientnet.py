@@ -372,6 +372,7 @@ class _Engine:
         ws.bwd = bw
 
     def backward(self, ws, dlogits):
+        ops.set_det_wgrad(False)               # (this engine's statistics still use atomics: no point in slab sums)
         m, v, G, lb = self.model, self._v, self.G, lib()
         B = ws.B
         sp = stream_ptr()

@@ -393,6 +393,7 @@ class _Engine:
         ws.bwd = bw
 
     def backward(self, ws, dlogits):
+        ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
         m, v, G = self.model, self._v, self.G
         B = ws.B
         self._alloc_bwd(ws)

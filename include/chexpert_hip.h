@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 3
+#define CX_ABI_VERSION 4
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4, CX_ESTATROWS = -5 };
 
@@ -99,6 +99,13 @@ typedef struct CxWgrad {
   int32_t g_prologue, x_prologue, mode;
   int32_t splits;                          /* pixel-range splits (0 = library picks)                */
   int32_t dtype;                           /* CX_DT_BF16 (0) or CX_DT_F32 (g, g2, x fp32)          */
+  /* Optional workspace for a reproducible sum (ABI 4).  The pixel range of a weight gradient is split over workgroups; */
+  /* with scratch == NULL (or too small for this launch) the partial tiles are added to dw with fp32 atomics, whose order */
+  /* changes from run to run.  With scratch_floats >= splits * |dW| every workgroup plain-stores its partial tile into   */
+  /* slab `split` and a second launch on the same stream adds the slabs to dw in split order: bit-identical results.      */
+  /* The library picks `splits`; 12 M floats cover every layer of the reference's networks at their benchmark batches.    */
+  float* scratch;
+  int64_t scratch_floats;
 } CxWgrad;
 
 int cx_abi_version(void);
@@ -119,6 +126,8 @@ int cx_conv_wgrad(const CxWgrad* p, void* stream);
  * BatchNorm scale / shift), and dW[n][c] += sum_m dZ[m][n] * relu(x[m][c]*e_sc[c] + e_sh[c]) into the fp32 OIHW gradient
  * dw (128, N, 1, 1) -- the same result as cx_conv_gemm followed by cx_conv_wgrad with x_prologue = AFFINE_RELU(e_sc, e_sh). */
 int cx_conv1x1_dgrad_wgrad(const CxConv* p, float* dw, void* stream);
+/* the same with a workspace for the reproducible weight-gradient sum (see CxWgrad.scratch; NULL / 0 = atomics) */
+int cx_conv1x1_dgrad_wgrad_ws(const CxConv* p, float* dw, float* scratch, int64_t scratch_floats, void* stream);
 
 /* OIHW fp32 -> packed bf16.  transpose=0: [tap][O][I] (forward);  transpose=1: [tap'][I][O] with
  * taps rotated by 180 degrees (input-gradient of a stride-1 conv).  stem=1: (64,3,7,7) -> [ky][O][8*4].  */
