@@ -80,6 +80,15 @@ class KernelTimer:
         K = kw.get("K") or x.shape[3]
         if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and (gp, xp, K, N) == (2, 1, 128, 32):
             return "conv3x3_ring_wgrad_kernel" if x.shape[2] >= 56 and x.shape[1] * x.shape[2] >= 3136 else "conv3x3_strip_wgrad_kernel"
+        if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and K % 128 == 0 and N % 128 == 0 and \
+                gp in (0, 2) and xp in (0, 1):
+            # wgrad_mm.hip wgrad3_kernel: needs the slab workspace (ops.wgrad_scratch) for its splits x 9 x N x K partial sums
+            from chexpert_amd import ops as _ops
+            steps = (g.shape[0] * g.shape[1] * (g.shape[2] + 2) + 63) // 64
+            splits = min(max(1, 256 // ((K // 128) * (N // 128) * 3)), steps)
+            sps = -(-steps // splits)
+            if -(-steps // sps) * 9 * N * K <= _ops.WGRAD_SCRATCH_FLOATS:
+                return "wgrad3_kernel<%d, %d>" % (gp, xp)
         if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and K % 32 == 0 and N % 8 == 0 and \
                 K <= 2048 and N <= 2048 and xp == 1 and gp in (0, 2) and 4 <= x.shape[2] <= 126:
             return "conv3x3_strip_wgrad_kernel"               # (cx_try_strip_wgrad: any tile pairs of 32 x 32 channels)

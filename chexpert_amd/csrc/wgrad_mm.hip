@@ -276,6 +276,295 @@ __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3, stride 1, pad 1
+// dW[n][c][dy][dx] += sum_px dZ[px][n] * A[px + (dy-1, dx-1)][c] for N % 128 == 0, K % 128 == 0 (the ResNet bottleneck 3x3 layers).
+// A workgroup owns 128 n x 128 c x the THREE taps of one kernel row dy, so one staged dZ tile (the expensive operand: two tensors
+// and nine prologue operations per element pair) and one staged activation strip serve three products: the pixels are walked in
+// a zero-padded index space (each image row is W + 2 positions, columns 0 and W + 1 are zeros), where the dx = 0, 1, 2 neighbours of
+// position p are positions p - 1, p, p + 1 of the strip and never wrap into another image row; the rows above / below the image
+// (dy = 0 / 2 at y = 0 / H - 1) are zero rows of the strip.  What a padded position is (real pixel or zero, and which pixel) comes
+// from a small LDS table that 136 threads fill three steps ahead (two exact divisions by multiplication per entry), so a staged
+// chunk costs one table read, one multiply-add and one AND.  Per step: 24 MFMAs per wave against 16 staged chunks per thread pair.
+struct W3Geo {
+  int B, H, W, P, TP;              // P = W + 2 positions per padded row, TP = B * H * P positions
+  uint32_t mP, mH;                 // ceil(2^32 / P), ceil(2^32 / H): q / P == umulhi(q, mP) for q * P < 2^32
+};
+
+constexpr int W3_GP = 128 * 2 + 64, W3_XP = 128 * 2 + 64;
+constexpr int W3_XROWS = 68;       // 66 strip rows used (64 + the two dx neighbours), padded
+constexpr int W3_STAGE = PX * W3_GP + W3_XROWS * W3_XP;
+constexpr int W3_TAB = 64 + W3_XROWS;
+
+template <int GPRO, int XPRO>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3_kernel(const CxWgrad p, const W3Geo g, const int c_tiles,
+                                                                                              const int n_tiles, const int total_steps,
+                                                                                              const int steps_per_split,
+                                                                                              float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* tab = reinterpret_cast<uint32_t*>(smem + 2 * W3_STAGE);          // [3][W3_TAB]: bit 31 = real pixel, low bits = its index
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave >> 2, wb = wave & 3;             // 64 n x 32 c x 3 taps per wave
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = id % c_tiles;
+  id /= c_tiles;
+  const int nt = id % n_tiles;
+  id /= n_tiles;
+  const int dy = id % 3;
+  const int split = id / 3;
+  const int c0 = ct * 128, n0 = nt * 128;
+  const int xshift = (dy - 1) * g.P - 1;               // strip row j of a step = position (first position of the step) + xshift + j
+  const int ylo = dy == 2 ? 1 : 0, yhi = dy == 0 ? g.H - 2 : g.H - 1;      // image rows of the strip that are this dy's neighbours
+
+  const int q16 = tid & 15, r32 = tid >> 4;             // chunk column, row (+ 32 i) of both images
+  float ga[8], gb[8], gc[8], pa[8], pb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ga[j] = GPRO == CX_PRO_AFFINE2 ? p.ga[n0 + q16 * 8 + j] : 1.f;
+    gb[j] = GPRO == CX_PRO_AFFINE2 ? p.gb[n0 + q16 * 8 + j] : 0.f;
+    gc[j] = GPRO == CX_PRO_AFFINE2 ? p.gc[n0 + q16 * 8 + j] : 0.f;
+    pa[j] = XPRO == CX_PRO_AFFINE_RELU ? p.pa[c0 + q16 * 8 + j] : 1.f;
+    pb[j] = XPRO == CX_PRO_AFFINE_RELU ? p.pb[c0 + q16 * 8 + j] : 0.f;
+  }
+  const int step0 = split * steps_per_split;
+  int nsteps = total_steps - step0;
+  if (nsteps > steps_per_split) nsteps = steps_per_split;
+
+  const char* __restrict__ Gb = reinterpret_cast<const char*>(p.g);
+  const char* __restrict__ G2b = reinterpret_cast<const char*>(p.g2);
+  const char* __restrict__ Xb = reinterpret_cast<const char*>(p.x);
+  const uint32_t ldg2b = p.ldg * 2, ldg22b = p.ldg2 * 2, ldx2b = p.ldx * 2;
+  const uint32_t gcol = (n0 + q16 * 8) * 2, xcol = (c0 + q16 * 8) * 2;
+
+  // table of step t (absolute): entries 0..63 = the dZ positions, 64.. = the strip positions
+  auto fill_table = [&](int t) __attribute__((always_inline)) {
+    if (tid < W3_TAB) {
+      const int q = tid < 64 ? t * PX + tid : t * PX + (tid - 64) + xshift;
+      bool ok = q >= 0 && q < g.TP;
+      const uint32_t qc = ok ? (uint32_t)q : 0u;
+      const uint32_t R = __umulhi(qc, g.mP);             // padded row = b * H + y
+      const uint32_t xp = qc - R * g.P;
+      const uint32_t y = R - __umulhi(R, g.mH) * g.H;
+      ok = ok && (xp - 1u) < (uint32_t)g.W;
+      if (tid >= 64) ok = ok && (int)y >= ylo && (int)y <= yhi;
+      tab[(t % 3) * W3_TAB + tid] = ok ? (0x80000000u | (R * g.W + xp - 1u)) : 0u;
+    }
+  };
+
+  struct Regs {
+    u32x4 g[2], g2[2];
+  };
+  Regs set0, set1;
+  u32x4 xreg[3];                       // [2]: strip rows 64, 65 (threads 0..31)
+  auto issue_g = [&](Regs& R, int i, int t) __attribute__((always_inline)) {
+    const uint32_t e = tab[(t % 3) * W3_TAB + r32 + 32 * i];
+    const uint32_t m = (uint32_t)((int)e >> 31), pix = e & 0x7fffffffu;
+    R.g[i] = ld16(Gb, (__umul24(pix, ldg2b) + gcol) & m);
+    if (GPRO == CX_PRO_AFFINE2) R.g2[i] = ld16(G2b, (__umul24(pix, ldg22b) + gcol) & m);
+  };
+  auto issue_x = [&](int i, int t) __attribute__((always_inline)) {
+    const uint32_t e = tab[(t % 3) * W3_TAB + 64 + r32 + 32 * i];
+    const uint32_t m = (uint32_t)((int)e >> 31), pix = e & 0x7fffffffu;
+    xreg[i] = ld16(Xb, (__umul24(pix, ldx2b) + xcol) & m);
+  };
+  // dword j of dZ chunk i of step t -> o[j]; after j == 3 the chunk is masked and written
+  auto unit_g = [&](const Regs& R, int i, int j, u32x4& o, char* Gt, int t) __attribute__((always_inline)) {
+    const uint32_t gw = R.g[i][j];
+    if (GPRO == CX_PRO_NONE) {
+      o[j] = gw;
+    } else {
+      const uint32_t y = R.g2[i][j];
+      o[j] = packbf(fmaf(bf_lo(gw), ga[2 * j], fmaf(bf_lo(y), gb[2 * j], gc[2 * j])),
+                    fmaf(bf_hi(gw), ga[2 * j + 1], fmaf(bf_hi(y), gb[2 * j + 1], gc[2 * j + 1])));
+    }
+    if (j == 3) {
+      o &= (uint32_t)((int)tab[(t % 3) * W3_TAB + r32 + 32 * i] >> 31);
+      *reinterpret_cast<u32x4*>(Gt + (r32 + 32 * i) * W3_GP + q16 * 16) = o;
+    }
+  };
+  auto unit_x = [&](int i, int j, u32x4& o, char* Xt, int t, bool reissue) __attribute__((always_inline)) {
+    const uint32_t x = xreg[i][j];
+    if (XPRO == CX_PRO_NONE) {
+      o[j] = x;
+    } else {
+      o[j] = relu_pk(packbf(fmaf(bf_lo(x), pa[2 * j], pb[2 * j]), fmaf(bf_hi(x), pa[2 * j + 1], pb[2 * j + 1])));
+    }
+    if (j == 3) {
+      o &= (uint32_t)((int)tab[(t % 3) * W3_TAB + 64 + r32 + 32 * i] >> 31);
+      *reinterpret_cast<u32x4*>(Xt + (r32 + 32 * i) * W3_XP + q16 * 16) = o;
+      if (reissue) issue_x(i, t + 1);
+    }
+  };
+  // the whole third strip chunk (rows 64, 65) of threads 0..31
+  auto extra_x = [&](char* Xt, int t, bool reissue) __attribute__((always_inline)) {
+    if (tid < 32) {
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) unit_x(2, j, o, Xt, t, reissue);
+    }
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+  // One step = 24 MFMAs of LDS image `bufc` (step t); in fenced packets between them: the table of step t + 3, the dZ requests of
+  // step t + 2 into Rn, the prologue + LDS stores of step t + 1 from Rc / the strip registers into image `bufn`, each strip chunk
+  // requested again for step t + 2 as soon as it is stored.
+  auto step = [&](Regs& Rn, const Regs& Rc, int bufc, int bufn, int t, auto IssueC, auto StageC) __attribute__((always_inline)) {
+    constexpr bool ISSUE = decltype(IssueC)::value, STAGE = decltype(StageC)::value;
+    const char* Gt = smem + bufc * W3_STAGE;
+    const char* Xt = Gt + PX * W3_GP;
+    char* Gn = smem + bufn * W3_STAGE;
+    char* Xn = Gn + PX * W3_GP;
+    u32x4 o;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[2], bfr[3];
+      af[0] = tr_frag(Gt, W3_GP, kk * 16, wa * 64, lane);
+      af[1] = tr_frag(Gt, W3_GP, kk * 16, wa * 64 + 32, lane);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) bfr[dx] = tr_frag(Xt, W3_XP, kk * 16 + dx, wb * 32, lane);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        acc[q & 1][q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q & 1], bfr[q >> 1], acc[q & 1][q >> 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int slot = kk * 6 + q;                       // 24 slots
+        if (slot == 0) fill_table(t + 3);
+        if (ISSUE && (slot == 1 || slot == 2)) issue_g(Rn, slot - 1, t + 2);
+        if (STAGE) {
+          // 16 dword units (8 dZ, 8 strip) on slots 3..18, the extra strip chunk on slot 20
+          if (slot >= 3 && slot < 11) unit_g(Rc, (slot - 3) >> 2, (slot - 3) & 3, o, Gn, t + 1);
+          if (slot >= 11 && slot < 19) unit_x((slot - 11) >> 2, (slot - 11) & 3, o, Xn, t + 1, ISSUE);
+          if (slot == 20) extra_x(Xn, t + 1, ISSUE);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+  if (nsteps > 0) {
+    fill_table(step0);
+    fill_table(step0 + 1);
+    fill_table(step0 + 2);
+    __syncthreads();
+    issue_g(set0, 0, step0);
+    issue_g(set0, 1, step0);
+    issue_x(0, step0);
+    issue_x(1, step0);
+    if (tid < 32) issue_x(2, step0);
+    if (nsteps > 1) {
+      issue_g(set1, 0, step0 + 1);
+      issue_g(set1, 1, step0 + 1);
+    }
+    {
+      u32x4 o;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) unit_g(set0, u >> 2, u & 3, o, smem, step0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) unit_x(u >> 2, u & 3, o, smem + PX * W3_GP, step0, nsteps > 1);
+      extra_x(smem + PX * W3_GP, step0, nsteps > 1);
+    }
+    __syncthreads();
+
+    int s = 0;
+    for (; s + 3 < nsteps; s += 2) {
+      step(set0, set1, 0, 1, step0 + s, T{}, T{});      // multiplies step s, requests s+2, stages s+1
+      __syncthreads();
+      step(set1, set0, 1, 0, step0 + s + 1, T{}, T{});
+      __syncthreads();
+    }
+    const int left = nsteps - s;
+    if (left == 3) {
+      step(set0, set1, 0, 1, step0 + s, T{}, T{});
+      __syncthreads();
+      step(set1, set0, 1, 0, step0 + s + 1, F{}, T{});
+      __syncthreads();
+      step(set0, set1, 0, 1, step0 + s + 2, F{}, F{});
+    } else if (left == 2) {
+      step(set0, set1, 0, 1, step0 + s, F{}, T{});
+      __syncthreads();
+      step(set1, set0, 1, 0, step0 + s + 1, F{}, F{});
+    } else {
+      step(set0, set1, 0, 1, step0 + s, F{}, F{});
+    }
+  }
+
+  // ---- partial tile -> slab [split][tap][n][c] (c contiguous: the OIHW positions of one tap are 36 bytes apart, which as
+  // atomics costs nine memory-side requests per useful one - measured 400 us per launch); dw3_reduce_kernel adds the slabs in split
+  // order and transposes to OIHW
+  const int lrow = lane & 31, lh = lane >> 5;
+  const size_t nk = (size_t)p.N * p.K;
+  const int c = c0 + wb * 32 + lrow;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wa * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        slab[((size_t)split * 9 + dy * 3 + dx) * nk + (size_t)n * p.K + c] = acc[i][dx][r];
+      }
+}
+
+// dw[(n*K + c)*9 + tap] += sum over the splits (in split order) of slab[split][tap][n][c]: one thread per (n, c)
+__global__ __launch_bounds__(256) void dw3_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slab, size_t nk, int splits) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nk) return;
+  float a[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) a[t] = 0.f;
+  for (int s = 0; s < splits; ++s) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) a[t] += slab[((size_t)s * 9 + t) * nk + i];
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dw[i * 9 + t] += a[t];
+}
+
+static inline int w3_splits(const CxWgrad& p);
+
+template <int GPRO, int XPRO>
+int launch3(const CxWgrad& p, hipStream_t st) {
+  W3Geo g;
+  g.B = p.B, g.H = p.H, g.W = p.W, g.P = p.W + 2;
+  g.TP = p.B * p.H * g.P;
+  g.mP = 0xffffffffu / (uint32_t)g.P + 1u;
+  g.mH = 0xffffffffu / (uint32_t)p.H + 1u;
+  const int c_tiles = p.K / 128, n_tiles = p.N / 128;
+  const int total_steps = (g.TP + PX - 1) / PX;
+  const int splits = w3_splits(p);
+  const int sps = (total_steps + splits - 1) / splits;
+  const size_t smem = 2 * W3_STAGE + 3 * W3_TAB * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<GPRO, XPRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  const size_t nk = (size_t)p.N * p.K;
+  float* slab = p.scratch;                               // (the dispatcher checked its size)
+  hipLaunchKernelGGL((wgrad3_kernel<GPRO, XPRO>), dim3(c_tiles * n_tiles * 3 * splits), dim3(512), smem, st, p, g, c_tiles, n_tiles, total_steps,
+                     sps, slab);
+  if (const int e = launch_status()) return e;
+  hipLaunchKernelGGL(dw3_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, p.dw, slab, nk, splits);
+  return launch_status();
+}
+
+// pixel-range splits of the 3x3 kernel (shared by the dispatcher's workspace check and the launcher)
+static inline int w3_splits(const CxWgrad& p) {
+  const int total_steps = (p.B * p.H * (p.W + 2) + PX - 1) / PX;
+  int splits = p.splits > 0 ? p.splits : 256 / ((p.K / 128) * (p.N / 128) * 3);
+  if (splits < 1) splits = 1;
+  if (splits > total_steps) splits = total_steps;
+  const int sps = (total_steps + splits - 1) / splits;
+  return (total_steps + sps - 1) / sps;
+}
+
 template <int WA, int WB, int GPRO, int XPRO>
 int launch(const CxWgrad& p, hipStream_t st, int wgs_target) {
   using G = WG<WA, WB>;
@@ -328,7 +617,27 @@ int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
   static const int env_form0 = [] { const char* e = getenv("CX_WGRAD_MM_FORM"); return e ? atoi(e) : 0; }();
   const int on = g_wm_on >= 0 ? g_wm_on : env_on0;
   const int env_form = g_wm_form >= 0 ? g_wm_form : env_form0;
-  if (!on || p.mode != CX_MODE_CONV || p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0) return 0;
+  if (!on || p.mode != CX_MODE_CONV) return 0;
+  if (p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad == 1) {
+    // the bottleneck 3x3 layers (wgrad3_kernel); padded positions, pixel indices and byte offsets must fit their fields
+    static const int env3 = [] { const char* e = getenv("CX_WGRAD3"); return e ? atoi(e) : 1; }();
+    const int on3 = g_wm_form == 0 ? 0 : env3;          // dbg_wgrad_mm_select(1, 0): the strip kernel
+    if (!on3 || (p.N % 128) || (p.K % 128) || p.W < 2 || p.H < 2) return 0;
+    // its partial tiles leave through the slab workspace only (see the kernel's epilogue): without one the strip kernel runs
+    if (!p.scratch || (long long)w3_splits(p) * 9 * p.N * p.K > p.scratch_floats) return 0;
+    const unsigned long long tp = (unsigned long long)p.B * p.H * (p.W + 2);
+    if (tp * (p.W + 2) >= (1ull << 32) || (unsigned long long)p.B * p.H * p.H >= (1ull << 32) || tp >= (1ull << 24)) return 0;
+    int ldm = p.ldg > p.ldx ? p.ldg : p.ldx;
+    if (p.g_prologue == CX_PRO_AFFINE2 && p.ldg2 > ldm) ldm = p.ldg2;
+    if (ldm >= (1 << 23) || (unsigned long long)p.B * p.H * p.W * ldm * 2 >= (1ull << 32)) return 0;
+    const bool g2_ = p.g_prologue == CX_PRO_AFFINE2;
+    if (p.g_prologue != CX_PRO_NONE && !g2_) return 0;
+    if (p.x_prologue != CX_PRO_NONE && p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
+    *handled = true;
+    if (p.x_prologue == CX_PRO_AFFINE_RELU) return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU>(p, st) : launch3<CX_PRO_NONE, CX_PRO_AFFINE_RELU>(p, st);
+    return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_NONE>(p, st) : launch3<CX_PRO_NONE, CX_PRO_NONE>(p, st);
+  }
+  if (p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0) return 0;
   if ((p.N % 128) || (p.K % 8) || p.K < 64) return 0;
   const long long M = (long long)p.B * p.Ho * p.Wo;
   if (M % PX) return 0;

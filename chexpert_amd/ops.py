@@ -27,7 +27,7 @@ def _nhwc(t):
 # are deterministic (plain DenseNet / ResNet) switch it on for their backward pass (set_det_wgrad), which makes the whole training
 # step bit-reproducible; measured cost +1.3 % on DenseNet121 bs=256 (1.3 GB of slab traffic per step), none on ResNet152.
 # CHEXPERT_DET_WGRAD=0 keeps the fp32 atomics everywhere.  A launch whose splits x |dW| exceed the buffer falls back to atomics.
-WGRAD_SCRATCH_DEFAULT = 0 if os.environ.get("CHEXPERT_DET_WGRAD", "1") == "0" else 12 << 20
+WGRAD_SCRATCH_DEFAULT = 0 if os.environ.get("CHEXPERT_DET_WGRAD", "1") == "0" else 16 << 20
 WGRAD_SCRATCH_FLOATS = 0
 
 

@@ -103,7 +103,7 @@ typedef struct CxWgrad {
   /* with scratch == NULL (or too small for this launch) the partial tiles are added to dw with fp32 atomics, whose order */
   /* changes from run to run.  With scratch_floats >= splits * |dW| every workgroup plain-stores its partial tile into   */
   /* slab `split` and a second launch on the same stream adds the slabs to dw in split order: bit-identical results.      */
-  /* The library picks `splits`; 12 M floats cover every layer of the reference's networks at their benchmark batches.    */
+  /* The library picks `splits`; 16 M floats cover every layer of the reference's networks at their benchmark batches.    */
   float* scratch;
   int64_t scratch_floats;
 } CxWgrad;

@@ -7,6 +7,7 @@ dev = torch.device('cuda:0')
 raw = ctypes.CDLL(_lib.LIB_PATH)
 layers = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [1, 2, 3, 4]
 B, bf = 128, torch.bfloat16
+ops.WGRAD_SCRATCH_FLOATS = 16 << 20          # the slab workspace (as in the engines' backward)
 
 def timeit(fn, reps=10):
     fn(); fn(); torch.cuda.synchronize()
@@ -33,13 +34,16 @@ for L in layers:
         'w3': (lambda: ops.conv_wgrad(x4, y1, dw3, g_prologue=ops.PRO_AFFINE2, g2=x4b, ga=one, gb=zero, gc=zero, x_prologue=ops.PRO_AFFINE_RELU,
                                       pa=one[:C], pb=zero[:C]), C, 4 * C),
     }
+    dw2 = torch.zeros(C, C, 3, 3, device=dev)
+    cases['w2'] = (lambda: ops.conv_wgrad(y1, y1b, dw2, kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=y1b, ga=one[:C], gb=zero[:C], gc=zero[:C],
+                                          x_prologue=ops.PRO_AFFINE_RELU, pa=one[:C], pb=zero[:C]), 9 * C, C)
     for k, (fn, K, N) in cases.items():
         fl = 2.0 * M * K * N
         res = []
-        for on, form in [(0, 0), (1, 1), (1, 2), (1, 3), (-1, -1)]:
+        for on, form in [(0, 0), (1, 0) if k == 'w2' else (1, 1), (1, 2), (1, 3), (-1, -1)]:
             raw.dbg_wgrad_mm_select(on, form)
             us = timeit(fn)
             res.append("%6.1f us %5.0f TF" % (us, fl / us / 1e6))
-        print("L%d %s K=%4d N=%4d | old %s | 128x128 %s | 256x128 %s | 128x256 %s | default %s" % (L, k, K, N, *res), flush=True)
+        print("L%d %s K=%4d N=%4d | old %s | 128x128 (w2: strip) %s | 256x128 %s | 128x256 %s | default %s" % (L, k, K, N, *res), flush=True)
     raw.dbg_wgrad_mm_select(-1, -1)
     del x4, x4b, y1, y1b

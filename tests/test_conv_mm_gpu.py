@@ -189,3 +189,36 @@ def test_1x1_weight_gradient_against_torch(dev, select_w, form, K, N, gpro, xpro
     ops.conv_wgrad(gb_[..., :N], xb[..., 32:32 + K], dw, g_prologue=gpro, g2=g2b if gpro else None, ga=ga.to(dev), gb=gbv.to(dev),
                    gc=gc.to(dev), x_prologue=xpro, pa=pa.to(dev), pb=pb.to(dev), splits=splits)
     close(dw.cpu() - dw0, want, rel=2e-3, what="dW")
+
+
+@pytest.mark.parametrize("K,N,gpro,xpro,B,H,W,splits", [
+    (128, 128, 2, 1, 2, 10, 10, 0),        # 240 padded positions: four steps, the last one ragged
+    (256, 128, 2, 1, 3, 7, 20, 2),         # two channel tiles, 462 positions in two ranges
+    (128, 256, 0, 1, 1, 40, 40, 5),        # plain gradient operand, 1680 positions in five ranges (tails of the step pipeline)
+    (128, 128, 2, 0, 5, 4, 6, 1),          # plain activation operand, tiny map (every row touches the zero rows)
+    (128, 128, 2, 1, 2, 80, 80, 3),        # one padded row (82 positions) longer than a step
+])
+def test_3x3_weight_gradient_against_torch(dev, select_w, K, N, gpro, xpro, B, H, W, splits):
+    """wgrad3_kernel: the three taps of a kernel row per workgroup, pixels walked in the zero-padded index space.  (It leaves its
+    partial tiles through the slab workspace only; without one the strip kernel runs.)"""
+    from chexpert_amd import ops
+    keep, ops.WGRAD_SCRATCH_FLOATS = ops.WGRAD_SCRATCH_FLOATS, 16 << 20
+    gb_, g = nhwc(50, B, H, W, N + 32, dev)
+    g2b, g2 = nhwc(51, B, H, W, N, dev)
+    xb, x = nhwc(52, B, H, W, K + 64, dev)
+    ga, gbv, gc = rnd(53, (N,), 0.5, 1.5), rnd(54, (N,), -0.3, 0.3), rnd(55, (N,), -0.2, 0.2)
+    pa, pb = rnd(56, (K,), -0.3, 1.5), rnd(57, (K,), -0.5, 0.5)
+    G = bf(g[:, :N] * cv(ga) + g2 * cv(gbv) + cv(gc)) if gpro else g[:, :N]
+    A = bf(F.relu(x[:, 32:32 + K] * cv(pa) + cv(pb))) if xpro else x[:, 32:32 + K]
+    want = torch.nn.grad.conv2d_weight(A, (N, K, 3, 3), G, padding=1)
+    outs = []
+    for form in (3, 0):                     # wgrad3_kernel, then the strip kernel it replaces on these shapes
+        select_w(1, form)
+        dw0 = rnd(58, (N, K, 3, 3), -1, 1)
+        dw = dw0.clone().to(dev)
+        ops.conv_wgrad(gb_[..., :N], xb[..., 32:32 + K], dw, kh=3, kw=3, pad=1, g_prologue=gpro, g2=g2b if gpro else None, ga=ga.to(dev),
+                       gb=gbv.to(dev), gc=gc.to(dev), x_prologue=xpro, pa=pa.to(dev), pb=pb.to(dev), splits=splits if form else 0)
+        outs.append(dw.cpu() - dw0)
+        if form == 3 or xpro:               # (the strip kernel takes the BN + ReLU activation operand only)
+            close(outs[-1], want, rel=2e-3, what="dW (form %d)" % form)
+    ops.WGRAD_SCRATCH_FLOATS = keep

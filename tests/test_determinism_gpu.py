@@ -32,7 +32,7 @@ def det_wgrad():
     """The reproducible weight-gradient sums at kernel level: slab workspace on for the test (the DenseNet / ResNet engines switch
     it on themselves, ops.set_det_wgrad)."""
     from chexpert_amd import ops
-    keep, ops.WGRAD_SCRATCH_FLOATS = ops.WGRAD_SCRATCH_FLOATS, 12 << 20
+    keep, ops.WGRAD_SCRATCH_FLOATS = ops.WGRAD_SCRATCH_FLOATS, 16 << 20
     yield
     ops.WGRAD_SCRATCH_FLOATS = keep
 
