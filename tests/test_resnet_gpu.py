@@ -231,7 +231,10 @@ def test_aaresnet152_reference_golden_train_step(dev):
     # (the AA engine's statistics and attention gradients still leave their kernels through fp32 atomics: on this fixture two runs
     # of the same step gave 5.6e-2 and 1.2e-1 on the logits, and 1.01 .. 1.34 on the norm of the 39 x 40 relative-position gradient)
     assert e < max(1e-2, 2.5 * e_q)
-    assert abs(loss.item() - rec["loss"]) < 2e-2 * rec["loss"]
+    # the loss follows the logits: |d loss| <= sum_c |sigmoid(z_c) - t_c| * |d z| (BCE, summed over classes), so with logits
+    # e * scale away the loss may be that far away (2 % of slack on top; on this fixture runs gave 0.3 % .. 2.4 %)
+    sens = (torch.sigmoid(want) - t.cpu()).abs().sum(1).mean(0).item()
+    assert abs(loss.item() - rec["loss"]) < 2e-2 * rec["loss"] + sens * e * want.abs().max().item()
     named = dict(model.named_parameters())
     rows = [(k, named[k].grad.double().norm().item() / rec["grads"][k]["l2"], sdq[k].grad.double().norm().item() / rec["grads"][k]["l2"])
             for k in checked]
