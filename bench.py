@@ -63,12 +63,12 @@ class KernelTimer:
             return "stem_fwd_kernel"
         # conv_mm.hip (cx_try_conv_mm): wide channel counts; 128 x 256 tiles where N allows and a tile has more than four k-steps
         ts, taps = kw.get("tstride", 1), kh * kw.get("kw", 1)
-        if mode == 0 and K % 64 == 0 and N % 128 == 0 and ts <= 2 and taps <= 32 and \
+        if mode == 0 and K % 8 == 0 and K >= 64 and N % 128 == 0 and ts <= 2 and taps <= 32 and \
                 ((epi == 0 and pro in (0, 1, 2)) or (epi == 1 and pro in (0, 2))):
-            nsteps = ((taps + 3) // 4 if ts == 2 else taps) * (K // 64)
+            nsteps = ((taps + 3) // 4 if ts == 2 else taps) * ((K + 63) // 64)
             zero_tap_classes = ts == 2 and (kh < 2 or kw.get("kw", 1) < 2)
             if not (ts == 1 and nsteps <= 2) and not (zero_tap_classes and not kw.get("accumulate")):
-                wide = N % 256 == 0 and nsteps > 4 and (3 * K * 4 + 2 * (128 + 256) * 144 <= 160 * 1024)
+                wide = N % 256 == 0 and nsteps > 4 and (3 * ((K + 63) // 64 * 64) * 4 + 2 * (128 + 256) * 144 <= 160 * 1024)
                 # (a stride-2 input gradient is up to four launches of the kernel, one per parity class: timed as one unit)
                 return "conv_mm_kernel<2, %d, %d, %d, false>%s" % (4 if wide else 2, pro, epi, " x parity classes" if ts == 2 else "")
         bn = 128 if N % 128 == 0 else (32 if N == 32 else 64)

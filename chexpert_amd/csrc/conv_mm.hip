@@ -1,5 +1,6 @@
 // Implicit-GEMM convolution for the MFMA-heavy shapes (ResNet bottlenecks, EfficientNet / AAConv 1x1 with wide channels):
-// K % 64 == 0 input channels per tap, N % 128 == 0 output channels, NHWC bf16, any kernel size / stride / transposed stride.
+// K >= 64 input channels per tap (a multiple of 8; the last 64-channel step may be partial), N % 128 == 0 output channels, NHWC bf16,
+// any kernel size / stride, transposed stride 1 or 2.
 //
 //   Y[m][n] = sum_{tap,c} A(m, tap, c) * W[tap][n][c]        m = (b, oy, ox) flattened
 //
@@ -102,8 +103,9 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   using G = MG<WMW, WNW>;
   constexpr int BN = G::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* coef = reinterpret_cast<float*>(smem);                       // [NCoef][K]
-  char* tiles = smem + NCoef<PRO>::v * p.K * 4;
+  const int Kp = (p.K + BK - 1) / BK * BK;                            // K rounded up to whole steps (K % 8 == 0)
+  float* coef = reinterpret_cast<float*>(smem);                       // [NCoef][Kp]
+  char* tiles = smem + NCoef<PRO>::v * Kp * 4;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,10 +116,11 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   const int n0 = nt * BN;
 
   if (PRO != CX_PRO_NONE) {
-    for (int i = tid; i < p.K; i += G::NT) {
-      coef[i] = p.pa[i];
-      coef[p.K + i] = p.pb[i];
-      if (PRO == CX_PRO_AFFINE2) coef[2 * p.K + i] = p.pc[i];
+    for (int i = tid; i < Kp; i += G::NT) {
+      const bool in = i < p.K;
+      coef[i] = in ? p.pa[i] : 0.f;
+      coef[Kp + i] = in ? p.pb[i] : 0.f;
+      if (PRO == CX_PRO_AFFINE2) coef[2 * Kp + i] = in ? p.pc[i] : 0.f;
     }
   }
 
@@ -148,8 +151,11 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
     for (int dy = 0; dy < c.nty; ++dy) bits |= (ok && (uint32_t)(iy0 + dy) < (uint32_t)p.H) ? (xb << (dy * c.ntx)) : 0u;
     vbits[i] = bits;
   }
-  const int kpt = p.K / BK;
+  const int kpt = Kp / BK;
   const int nsteps = ntaps * kpt;
+  // the last channel step of a tap may be partial: this thread's 16-byte chunk exists there iff kl_mask (it reads offset 0 and is
+  // zeroed when staged otherwise)
+  const uint32_t kl_mask = ((kpt - 1) * BK + qa * 8 < p.K) ? 0xffffffffu : 0u;
   const char* __restrict__ X = reinterpret_cast<const char*>(p.x);
   const char* __restrict__ X2 = reinterpret_cast<const char*>(p.x2);
   const char* __restrict__ Wb = reinterpret_cast<const char*>(p.w);
@@ -173,11 +179,15 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   // Every load is unconditional on an in-bounds address (a branch around a load serialises the prefetch): invalid taps read
   // offset 0 and are zeroed when staged.
   auto issue_a = [&](Regs& R, int i) __attribute__((always_inline)) {
-    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vbits[i], q_tap, 1);       // 0 or 0xffffffff
+    const uint32_t km = q_kc == kpt - 1 ? kl_mask : 0xffffffffu;                      // partial last channel step
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vbits[i], q_tap, 1) & km; // 0 or 0xffffffff
     R.a[i] = ld16(X, (roff[i] + q_x) & m);
     if (PRO == CX_PRO_AFFINE2) R.a2[i] = ld16(X2, (roff2[i] + q_x2) & m);
   };
-  auto issue_w = [&](int i) __attribute__((always_inline)) { wreg[i] = ld16(Wb, woff[i] + q_w); };
+  // (a weight chunk past K is never zeroed: the activation chunk it meets is, and the weights read instead - offset 0 - are finite)
+  auto issue_w = [&](int i) __attribute__((always_inline)) {
+    wreg[i] = ld16(Wb, (woff[i] + q_w) & (q_kc == kpt - 1 ? kl_mask : 0xffffffffu));
+  };
   auto advance = [&](Regs& R) __attribute__((always_inline)) {
     R.tap = q_tap;
     R.kc = q_kc;
@@ -203,11 +213,11 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
       const int c0 = R.kc * BK + qa * 8;
       *reinterpret_cast<float4*>(ca) = *reinterpret_cast<const float4*>(coef + c0);
       *reinterpret_cast<float4*>(ca + 4) = *reinterpret_cast<const float4*>(coef + c0 + 4);
-      *reinterpret_cast<float4*>(cb) = *reinterpret_cast<const float4*>(coef + p.K + c0);
-      *reinterpret_cast<float4*>(cb + 4) = *reinterpret_cast<const float4*>(coef + p.K + c0 + 4);
+      *reinterpret_cast<float4*>(cb) = *reinterpret_cast<const float4*>(coef + Kp + c0);
+      *reinterpret_cast<float4*>(cb + 4) = *reinterpret_cast<const float4*>(coef + Kp + c0 + 4);
       if (PRO == CX_PRO_AFFINE2) {
-        *reinterpret_cast<float4*>(cc) = *reinterpret_cast<const float4*>(coef + 2 * p.K + c0);
-        *reinterpret_cast<float4*>(cc + 4) = *reinterpret_cast<const float4*>(coef + 2 * p.K + c0 + 4);
+        *reinterpret_cast<float4*>(cc) = *reinterpret_cast<const float4*>(coef + 2 * Kp + c0);
+        *reinterpret_cast<float4*>(cc + 4) = *reinterpret_cast<const float4*>(coef + 2 * Kp + c0 + 4);
       }
     }
   };
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
                     fmaf(bf_hi(g), ca[2 * j + 1], fmaf(bf_hi(y), cb[2 * j + 1], cc[2 * j + 1])));
     }
     if (j == 3) {
-      o &= (uint32_t)__builtin_amdgcn_sbfe((int)vbits[i], R.tap, 1);
+      o &= (uint32_t)__builtin_amdgcn_sbfe((int)vbits[i], R.tap, 1) & (R.kc == kpt - 1 ? kl_mask : 0xffffffffu);
       *reinterpret_cast<u32x4*>(A + (r0 + G::RSTEP * i) * PITCH + qa * 16) = o;
     }
   };
@@ -501,7 +511,7 @@ int launch(const CxConv& p, const Cls& c, hipStream_t st) {
   using G = MG<WMW, WNW>;
   const int m_tiles = (c.Mq + G::BM - 1) / G::BM;
   const int n_tiles = p.N / G::BN;
-  const size_t smem = (size_t)NCoef<PRO>::v * p.K * 4 + G::MAIN_BYTES;
+  const size_t smem = (size_t)NCoef<PRO>::v * ((p.K + BK - 1) / BK * BK) * 4 + G::MAIN_BYTES;
   if (smem > 160 * 1024) return CX_ESHAPE;
   static bool attr_set = false;
   if (!attr_set) {
@@ -554,7 +564,7 @@ int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   static const int env_form0 = [] { const char* e = getenv("CX_MM_FORM"); return e ? atoi(e) : 0; }();
   const int env_on = g_mm_on >= 0 ? g_mm_on : env_on0;
   const int env_form = g_mm_form >= 0 ? g_mm_form : env_form0;
-  if (!env_on || p.mode != CX_MODE_CONV || p.tstride > 2 || (p.K % BK) || (p.N % 128) || p.kh * p.kw > 32 || p.dtype != CX_DT_BF16) return 0;
+  if (!env_on || p.mode != CX_MODE_CONV || p.tstride > 2 || (p.K % 8) || p.K < BK || (p.N % 128) || p.kh * p.kw > 32 || p.dtype != CX_DT_BF16) return 0;
   const bool ok_combo = (p.epilogue == CX_EPI_STORE && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE_RELU || p.prologue == CX_PRO_AFFINE2)) ||
                         (p.epilogue == CX_EPI_MASK && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE2));
   if (!ok_combo) return 0;
@@ -565,12 +575,12 @@ int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   // Measured on the ResNet152 shapes (scratch/bench_mm.py): 128 x 256 tiles wherever N allows and a tile has more than four
   // k-steps (1.9-2.7x the generic kernel); with at most four steps a tile is prologue + epilogue, the smaller tile wins, and with
   // one or two steps the generic kernel (32-channel steps, three workgroups per CU) is as fast.
-  const int nsteps = (ts == 2 ? (p.kh * p.kw + 3) / 4 : p.kh * p.kw) * (p.K / BK);
+  const int nsteps = (ts == 2 ? (p.kh * p.kw + 3) / 4 : p.kh * p.kw) * ((p.K + BK - 1) / BK);
   if (!env_form && ts == 1 && nsteps <= 2) return 0;
   int form = (p.N % 256 == 0 && nsteps > 4) ? 3 : 1;
   if (env_form) form = env_form == 3 ? 3 : 1;
   if (form == 3 && (p.N % 256)) form = 1;
-  if (form == 3 && (size_t)NCoef<CX_PRO_AFFINE2>::v * p.K * 4 + MG<2, 4>::MAIN_BYTES > 160 * 1024) form = 1;
+  if (form == 3 && (size_t)NCoef<CX_PRO_AFFINE2>::v * ((p.K + BK - 1) / BK * BK) * 4 + MG<2, 4>::MAIN_BYTES > 160 * 1024) form = 1;
   const int bm = 128;
 
   if (ts == 1) {

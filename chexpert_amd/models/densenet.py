@@ -547,9 +547,11 @@ class _Engine:
         ops.aa_attention_bwd(T.QKV, aa.key_rel_h, aa.key_rel_w, T.O, T.dO, T.LSE, T.dQKV32, G(aa.key_rel_h), G(aa.key_rel_w), aa.nh,
                              aa.dk, aa.dv)
         ops.f32_to_bf16(T.dQKV32, T.dQKV)
-        ops.conv_gemm(T.dQKV, self.w_bwd(aa.in_proj_qkv), T.dA, N=Cp, tstride=2)
+        # (the 3x3 branch reaches every pixel and stores; the 1x1 branch only reaches the even-even ones: accumulating, its
+        # other parity classes are nothing to do)
         ops.conv_gemm(gs_c, self.w_bwd(aa.conv), T.dA, N=Cp, kh=3, kw=3, pad=1, tstride=2, prologue=ops.PRO_AFFINE2, x2=xs_c,
-                      pa=qa[:cc], pb=qb[:cc], pc=qc[:cc], accumulate=True)
+                      pa=qa[:cc], pb=qb[:cc], pc=qc[:cc])
+        ops.conv_gemm(T.dQKV, self.w_bwd(aa.in_proj_qkv), T.dA, N=Cp, tstride=2, accumulate=True)
         ops.conv_wgrad(T.dQKV, T.A, G(aa.in_proj_qkv.weight), stride=2)
         ops.conv_wgrad(gs_c, T.A, G(aa.conv.weight), kh=3, kw=3, stride=2, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs_c, ga=qa[:cc],
                        gb=qb[:cc], gc=qc[:cc])

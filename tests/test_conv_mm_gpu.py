@@ -62,6 +62,9 @@ cv = lambda t: t.view(1, -1, 1, 1)
     (2, 11, 13, 128, 128, 3, 2, 1),      # strided 3x3, 18 steps
     (5, 8, 8, 192, 128, 1, 2, 0),        # strided 1x1 (downsample), 3 steps
     (1, 20, 20, 256, 384, 3, 1, 1),      # 36 steps, three n tiles, M = 400 (1.56 tiles of 256)
+    (2, 10, 12, 120, 128, 3, 1, 1),      # K not a multiple of 64: the second channel step of every tap is partial (56 of 64)
+    (3, 9, 9, 200, 256, 1, 1, 0),        # 3 full steps + 8 channels
+    (2, 12, 12, 72, 256, 3, 2, 1),       # one chunk past the first step, strided
 ])
 def test_forward_against_torch(dev, select, form, B, H, W, K, N, ksz, stride, pro):
     from chexpert_amd import ops
@@ -99,6 +102,8 @@ def test_forward_against_torch(dev, select, form, B, H, W, K, N, ksz, stride, pr
     (3, 7, 5, 64, 256, 3, -2, True, 2),         # the same with odd input sizes (13 x 9): classes of unequal size
     (2, 6, 7, 128, 256, 1, 2, True, 2),         # stride-2 1x1 (downsample), accumulating: only the even-even class has a tap
     (2, 6, 7, 128, 128, 1, 2, False, 0),        # storing: the untouched classes need zeros (declined, generic kernel)
+    (2, 6, 7, 328, 256, 1, 2, True, 0),         # AAConv query/key/value projection gradient: K = 2 dk + dv, accumulating
+    (2, 5, 6, 120, 128, 3, 2, False, 2),        # AAConv 3x3 branch gradient: K = planes - dv
     (4, 10, 10, 128, 256, 3, 1, True, 2),       # 128 x 256 tiles with the two-tensor operand
     (2, 8, 8, 192, 128, 1, 1, True, 0),         # plain operand, accumulate (AA projection gradient form)
 ])
