@@ -8,6 +8,7 @@
 // logit rh_i[ky] is one 20-term dot product per key row: LDS holds only the relative tables and the current key row
 // (~20-30 KB per workgroup), the pair loop reads LDS only as broadcasts.  Same arithmetic and the same order of the
 // per-query sums as aaconv.hip; other widths keep those kernels.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -388,6 +389,262 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_k_row_kernel(const bf16* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------ query side on MFMA (W = 40)
+// The per-pair dot products of aa_attn_bwd_q_row_kernel (20 FMAs for the logit, 20 for dq += ds * k: 40 of its ~50 vector
+// instructions per (query, key) pair) move to the matrix pipe.  A wave owns 32 queries; a key row (40 keys, padded to 2 x 32) is
+// one tile:  S^T = K Q^T  (keys in accumulator rows, queries in lanes: lane (q, half) sees 16 + 4 of the row's 40 keys, always the
+// same columns kx, so its relative-column logits rw_q[kx] and their gradients are 20 registers indexed at compile time),
+// then per element  p = exp(S + rh + rw - lse),  ds = p (dO . v - delta),  and  dQ += dS K  with dS moved from accumulator to
+// operand layout by v_permlane32_swap and split into two bf16 terms (hi + lo: 2^-17 relative, dq is checked to 1e-3).
+// The relative-table gradients keep the owner-computes LDS sums of the row kernel.
+constexpr int AQM = 128;               // queries per workgroup (4 waves x 32)
+constexpr int KB_PITCH = 80;           // bf16 key image: 32 d (20 used) + 16 B pad
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  union { bf16x2v h; uint32_t u; } o;
+  o.h = __builtin_convertvector(f32x2v{a, b}, bf16x2v);
+  return o.u;
+}
+__device__ __forceinline__ bf16x8 tr_frag_k(const char* tile, int pitch, int k0, int lane) {
+  // B operand of D[q][d] += dS[q][k] K[k][d]: this lane gets column d = lane & 31, keys k0 + 8 * (lane >> 5) + 0..7
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const char* base = tile + (k0 + 8 * (g >> 1) + q) * pitch + (16 * (g & 1) + 4 * pp) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  U64 lo, hi;
+  lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+  hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch));
+  bf16x8 r;
+  r[0] = lo.e[0]; r[1] = lo.e[1]; r[2] = lo.e[2]; r[3] = lo.e[3];
+  r[4] = hi.e[0]; r[5] = hi.e[1]; r[6] = hi.e[2]; r[7] = hi.e[3];
+  return r;
+}
+
+template <int DVH>
+__global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                                const float* __restrict__ rel_w, const float* __restrict__ o,
+                                                                const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                                float* __restrict__ dqkv, float* __restrict__ d_rel_h,
+                                                                float* __restrict__ d_rel_w, const AAGeo g) {
+  constexpr int WW = 40, LW = 2 * WW - 1, NT = 256;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = g.H, HW = H * WW;
+  const int LH = 2 * H - 1;
+  float* RH = lds;
+  float* RW = RH + DKH * LH;
+  float* dRH = RW + DKH * LW;            // workgroup partials
+  float* dRW = dRH + DKH * LH;
+  float* Vt = dRW + DKH * LW;            // [64][DVH] fp32 (keys 40..63 zero)
+  float* Qs = Vt + 64 * DVH;             // [AQM][DKH + 1] scaled queries of the workgroup
+  float* dr = Qs + AQM * (DKH + 1);      // [AQM] d rh_q[ky] of the key row just finished
+  float* dwq = dr + AQM;                 // [AQM][WW + 1] d rw_q[kx]; at the very end [AQM][DKH + 1] relative-term part of dq
+  char* Kb = reinterpret_cast<char*>(dwq + AQM * (WW + 1));     // bf16 [64 keys][KB_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int ql = wave * 32 + lrow;                              // query of this lane inside the workgroup
+  const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
+  const int i0 = blockIdx.x * AQM;
+  const int i = i0 + ql;
+  const bool qvalid = i < HW;
+  const int ic = qvalid ? i : HW - 1;
+  const int qy = ic / WW, qx = ic - qy * WW;
+  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  for (int t = tid; t < DKH * LH; t += NT) { RH[t] = rel_h[t]; dRH[t] = 0.f; }
+  for (int t = tid; t < DKH * LW; t += NT) { RW[t] = rel_w[t]; dRW[t] = 0.f; }
+  for (int t = tid; t < 64 * KB_PITCH / 4; t += NT) reinterpret_cast<uint32_t*>(Kb)[t] = 0u;
+  for (int t = tid; t < 64 * DVH; t += NT) Vt[t] = 0.f;
+
+  // the query: bf16 operand fragments (B operand of S^T = K Q^T: d = kk * 16 + lh * 8 + 0..7) and fp32 scaled copy
+  float q[DKH];
+  const float scale = rsqrtf((float)DKH);
+  bf16x8 qf[2];
+  {
+    const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
+    bf16 qb[DKH];
+#pragma unroll
+    for (int d = 0; d < DKH; d += 4) {
+      U64 v;
+      v.u = *reinterpret_cast<const uint2*>(qp + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { qb[d + e] = v.e[e]; q[d + e] = bf2f(v.e[e]) * scale; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qf[0][e] = lh ? qb[8 + e] : qb[e];
+      qf[1][e] = (lh == 0 && e < 4) ? qb[16 + e] : f2bf(0.f);
+    }
+  }
+  float dO[DVH], delta = 0.f;
+  {
+    const float* op = o + ((size_t)b * HW + ic) * g.dv + n * DVH;
+    const float* dp = d_o + ((size_t)b * HW + ic) * g.dv + n * DVH;
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) { dO[d] = qvalid ? dp[d] : 0.f; delta = fmaf(dO[d], op[d], delta); }
+  }
+  const float Ll = lse[(size_t)bn * HW + ic] * LOG2E;
+  if (lh == 0) {
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) Qs[ql * (DKH + 1) + d] = qvalid ? q[d] : 0.f;
+  }
+  const int qy_a = i0 / WW, qy_b = min(i0 + AQM - 1, HW - 1) / WW;
+  __syncthreads();
+
+  // this lane's 20 key columns: kx = (e & 3) + 8 * (e >> 2) + 4 * lh for e < 16 (keys 0..31), 32 + (e - 16) + 4 * lh after
+  float rwl[20], drwl[20];
+#pragma unroll
+  for (int e = 0; e < 20; ++e) {
+    const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RW[d * LW + kx - qx + WW - 1], a);
+    rwl[e] = a * LOG2E;
+    drwl[e] = 0.f;
+  }
+  f32x16 dqa;                            // D[q][d]: rows = the wave's queries, columns = d (lane & 31)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dqa[r] = 0.f;
+  float dqr[10];                         // relative-term part of dq for d = 10 * lh + 0..9 (lane = query layout)
+#pragma unroll
+  for (int d = 0; d < 10; ++d) dqr[d] = 0.f;
+  const float sl = scale * LOG2E;
+  const int kofs = g.dk + n * DKH, vofs = 2 * g.dk + n * DVH;
+
+  // key row ky -> image (ky & 1): bf16 keys (5 chunks of 4 channels per key), fp32 values.  Requested at the top of the previous
+  // row into registers (unconditional loads on clamped indices), stored to LDS at its bottom: the latency hides under the row
+  const int sj = min(tid / 5, WW - 1), sc = tid - (tid / 5) * 5;
+  const int vj = min(tid / DVH, WW - 1), vd = tid - (tid / DVH) * DVH;
+  uint2 kreg;
+  bf16 vreg;
+  auto load_keys = [&](int ky) __attribute__((always_inline)) {
+    const size_t j0 = (size_t)ky * WW;
+    kreg = *reinterpret_cast<const uint2*>(base + (j0 + sj) * g.ldq + kofs + sc * 4);
+    vreg = base[(j0 + vj) * g.ldq + vofs + vd];
+  };
+  auto store_keys = [&]() __attribute__((always_inline)) {
+    if (tid < WW * 5) *reinterpret_cast<uint2*>(Kb + sj * KB_PITCH + sc * 8) = kreg;
+    if (tid < WW * DVH) Vt[vj * DVH + vd] = bf2f(vreg);
+  };
+  load_keys(0);
+  for (int ky = 0; ky < H; ++ky) {
+    __syncthreads();                      // the previous row's readers are done (first row: zero fill done)
+    store_keys();
+    __syncthreads();
+    load_keys(ky + 1 < H ? ky + 1 : ky);  // in flight under this row's arithmetic
+    const char* Kc = Kb;
+    const float* Vc = Vt;
+    const int r = ky - qy + H - 1;
+    float rhv = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) rhv = fmaf(q[d], RH[d * LH + r], rhv);
+    const float rhl = qvalid ? fmaf(rhv, LOG2E, -Ll) : -1.0e30f;         // (rows past the map: p = 0)
+
+    // S^T tiles: keys 0..31 and 32..63
+    f32x16 st0, st1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st0[e] = st1[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kc + lrow * KB_PITCH + kk * 32 + lh * 16);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kc + (32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+      st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], st0, 0, 0, 0);
+      st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], st1, 0, 0, 0);
+    }
+    float ds[20], drh = 0.f;
+#pragma unroll
+    for (int e = 0; e < 20; ++e) {
+      const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+      const float sv = e < 16 ? st0[e] : st1[e - 16];
+      const float p = __builtin_amdgcn_exp2f(fmaf(sv, sl, rhl + rwl[e]));
+      float dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < DVH; ++d) dp = fmaf(dO[d], Vc[kx * DVH + d], dp);
+      ds[e] = p * (dp - delta);
+      drh += ds[e];
+      drwl[e] += ds[e];
+    }
+    // dQ += dS K over the key groups [0,16), [16,32), [32,48): accumulator rows -> 8 consecutive keys per lane, hi + lo bf16
+#pragma unroll
+    for (int g16 = 0; g16 < 3; ++g16) {
+      float v[8];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float a = g16 < 2 ? ds[8 * g16 + r4] : ds[16 + r4];
+        const float c = g16 < 2 ? ds[8 * g16 + 4 + r4] : 0.f;             // keys 40..47 do not exist
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(c), false, false);
+        v[r4] = __uint_as_float(sw[0]);
+        v[4 + r4] = __uint_as_float(sw[1]);
+      }
+      union { bf16x8 h; uint32_t u[4]; } hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi.u[j] = pk_bf16(v[2 * j], v[2 * j + 1]);
+        lo.u[j] = pk_bf16(v[2 * j] - __uint_as_float(hi.u[j] << 16), v[2 * j + 1] - __uint_as_float(hi.u[j] & 0xffff0000u));
+      }
+      const bf16x8 kt = tr_frag_k(Kc, KB_PITCH, g16 * 16, lane);
+      dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi.h, kt, dqa, 0, 0, 0);
+      dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo.h, kt, dqa, 0, 0, 0);
+    }
+    // key row complete: d rh_q[ky] of the query (both lane halves) folds into dq now and is parked for the d key_rel_h sums
+    drh += __shfl_xor(drh, 32);
+#pragma unroll
+    for (int d = 0; d < 10; ++d) dqr[d] = fmaf(drh, RH[(10 * lh + d) * LH + r], dqr[d]);
+    if (lh == 0) dr[ql] = qvalid ? drh : 0.f;
+    __syncthreads();
+    for (int oo = tid; oo < (qy_b - qy_a + 1) * DKH; oo += NT) {
+      const int seg = oo / DKH, d = oo - seg * DKH, yy = qy_a + seg;
+      const int l0 = max(yy * WW - i0, 0), l1 = min((yy + 1) * WW - i0, AQM);
+      float t = 0.f;
+      for (int l = l0; l < l1; ++l) t = fmaf(dr[l], Qs[l * (DKH + 1) + d], t);
+      dRH[d * LH + ky - yy + H - 1] += t;
+    }
+  }
+  // d rw_q[kx] -> dq and d key_rel_w (owner-computes sums over the parked per-query columns)
+#pragma unroll
+  for (int e = 0; e < 20; ++e) {
+    const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+    dwq[ql * (WW + 1) + kx] = drwl[e];
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int kx = 0; kx < WW; ++kx) {
+    const float dv_ = dwq[ql * (WW + 1) + kx];
+    const int rr = kx - qx + WW - 1;
+#pragma unroll
+    for (int d = 0; d < 10; ++d) dqr[d] = fmaf(dv_, RW[(10 * lh + d) * LW + rr], dqr[d]);
+  }
+  for (int oo = tid; oo < LW * DKH; oo += NT) {        // thread owns table word (d, rr): every (query, kx) with kx - qx + W - 1 = rr
+    const int rr = oo / DKH, d = oo - rr * DKH;
+    int xq = i0 % WW;
+    float t = 0.f;
+    for (int l = 0; l < AQM; ++l) {
+      const int kx = xq + rr - (WW - 1);
+      if (kx >= 0 && kx < WW) t = fmaf(dwq[l * (WW + 1) + kx], Qs[l * (DKH + 1) + d], t);
+      if (++xq == WW) xq = 0;
+    }
+    dRW[d * LW + rr] += t;
+  }
+  __syncthreads();
+  // dq = (matrix part [query rows][d columns] + relative part [query lanes][d]) * scale, through LDS
+  float* dqx = dwq;                                     // [AQM][DKH + 1]
+#pragma unroll
+  for (int d = 0; d < 10; ++d) dqx[ql * (DKH + 1) + 10 * lh + d] = dqr[d];
+  __syncthreads();
+  if (lrow < DKH) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (i0 + qq < HW) {
+        float* dqp = dqkv + ((size_t)b * HW + i0 + qq) * (2 * g.dk + g.dv) + n * DKH;
+        dqp[lrow] = (dqa[r] + dqx[qq * (DKH + 1) + lrow]) * scale;
+      }
+    }
+  }
+  for (int t = tid; t < DKH * LH; t += NT) atomicAdd(&d_rel_h[t], dRH[t]);
+  for (int t = tid; t < DKH * LW; t += NT) atomicAdd(&d_rel_w[t], dRW[t]);
+}
+
 template <int DVH, int WW>
 int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_w, float* o, const float* d_o, float* lse, float* dqkv,
                float* d_rel_h, float* d_rel_w, const AAGeo& g, hipStream_t st) {
@@ -397,9 +654,22 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
     const size_t smem = (tables + (size_t)WW * (DKH + DVH)) * 4;
     hipLaunchKernelGGL((aa_attn_fwd_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, lse, g);
   } else {
-    const size_t smem = (2 * tables + (size_t)WW * (DKH + DVH) + (size_t)AQ * (DKH + 2 + WW + 1)) * 4;
-    hipLaunchKernelGGL((aa_attn_bwd_q_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv,
-                       d_rel_h, d_rel_w, g);
+    static const bool q_row = getenv("CX_AA_Q_ROW") != nullptr;          // diagnostic: the per-query VALU kernel
+    if (WW == 40 && !q_row) {
+      const size_t smem_m = (2 * tables + 64 * DVH + (size_t)AQM * (DKH + 2 + WW + 1)) * 4 + 64 * KB_PITCH;
+      static bool attr_m = false;
+      if (!attr_m) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_mfma_kernel<DVH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  96 * 1024);
+        attr_m = true;
+      }
+      hipLaunchKernelGGL((aa_attn_bwd_q_mfma_kernel<DVH>), dim3((g.H * WW + AQM - 1) / AQM, g.B * g.nh), dim3(256), smem_m, st,
+                         (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g);
+    } else {
+      const size_t smem = (2 * tables + (size_t)WW * (DKH + DVH) + (size_t)AQ * (DKH + 2 + WW + 1)) * 4;
+      hipLaunchKernelGGL((aa_attn_bwd_q_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv,
+                         d_rel_h, d_rel_w, g);
+    }
     const size_t smem_k = (tables + (size_t)WW * (DKH + DVH + 2 + WW + 1)) * 4;
     hipLaunchKernelGGL((aa_attn_bwd_k_row_kernel<DVH, WW>), grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g);
   }
