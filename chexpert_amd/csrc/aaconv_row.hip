@@ -438,9 +438,10 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
   float* dRW = dRH + DKH * LH;
   float* Vt = dRW + DKH * LW;            // [64][DVH] fp32 (keys 40..63 zero)
   float* Qs = Vt + 64 * DVH;             // [AQM][DKH + 1] scaled queries of the workgroup
-  float* dr = Qs + AQM * (DKH + 1);      // [AQM] d rh_q[ky] of the key row just finished
-  float* dwq = dr + AQM;                 // [AQM][WW + 1] d rw_q[kx]; at the very end [AQM][DKH + 1] relative-term part of dq
-  char* Kb = reinterpret_cast<char*>(dwq + AQM * (WW + 1));     // bf16 [64 keys][KB_PITCH]
+  float* dwq = Qs + AQM * (DKH + 1);     // during the key loop dr2[ky][AQM] = d rh_q[ky]; then [AQM][WW + 1] d rw_q[kx]; at the very end
+                                         // [AQM][DKH + 1] relative-term part of dq: AQM * max(H, WW + 1) floats
+  float* dr2 = dwq;
+  char* Kb = reinterpret_cast<char*>(dwq + AQM * (H > WW + 1 ? H : WW + 1));     // bf16 [64 keys][KB_PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5;
   const int ql = wave * 32 + lrow;                              // query of this lane inside the workgroup
@@ -590,16 +591,22 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
     drh += __shfl_xor(drh, 32);
 #pragma unroll
     for (int d = 0; d < 10; ++d) dqr[d] = fmaf(drh, RH[(10 * lh + d) * LH + r], dqr[d]);
-    if (lh == 0) dr[ql] = qvalid ? drh : 0.f;
-    __syncthreads();
-    for (int oo = tid; oo < (qy_b - qy_a + 1) * DKH; oo += NT) {
-      const int seg = oo / DKH, d = oo - seg * DKH, yy = qy_a + seg;
-      const int l0 = max(yy * WW - i0, 0), l1 = min((yy + 1) * WW - i0, AQM);
-      float t = 0.f;
-      for (int l = l0; l < l1; ++l) t = fmaf(dr[l], Qs[l * (DKH + 1) + d], t);
-      dRH[d * LH + ky - yy + H - 1] += t;
-    }
+    if (lh == 0) dr2[ky * AQM + ql] = qvalid ? drh : 0.f;       // parked for the d key_rel_h sums after the loop
   }
+  __syncthreads();
+  // d key_rel_h: thread owns table word (d, rr): every (query image row yy, key row ky) with ky - yy + H - 1 = rr
+  for (int oo = tid; oo < LH * DKH; oo += NT) {
+    const int rr = oo / DKH, d = oo - rr * DKH;
+    float t = 0.f;
+    for (int yy = qy_a; yy <= qy_b; ++yy) {
+      const int ky = rr + yy - (H - 1);
+      if (ky < 0 || ky >= H) continue;
+      const int l0 = max(yy * WW - i0, 0), l1 = min((yy + 1) * WW - i0, AQM);
+      for (int l = l0; l < l1; ++l) t = fmaf(dr2[ky * AQM + l], Qs[l * (DKH + 1) + d], t);
+    }
+    dRH[d * LH + rr] += t;
+  }
+  __syncthreads();                        // dr2 consumed: its space becomes dwq
   // d rw_q[kx] -> dq and d key_rel_w (owner-computes sums over the parked per-query columns)
 #pragma unroll
   for (int e = 0; e < 20; ++e) {
@@ -656,7 +663,7 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
   } else {
     static const bool q_row = getenv("CX_AA_Q_ROW") != nullptr;          // diagnostic: the per-query VALU kernel
     if (WW == 40 && !q_row) {
-      const size_t smem_m = (2 * tables + 64 * DVH + (size_t)AQM * (DKH + 2 + WW + 1)) * 4 + 64 * KB_PITCH;
+      const size_t smem_m = (2 * tables + 64 * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1))) * 4 + 64 * KB_PITCH;
       static bool attr_m = false;
       if (!attr_m) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_mfma_kernel<DVH>), hipFuncAttributeMaxDynamicSharedMemorySize,
