@@ -421,13 +421,18 @@ __device__ __forceinline__ bf16x8 tr_frag_k(const char* tile, int pitch, int k0,
   return r;
 }
 
-template <int DVH>
+template <int DVH, int WW>
 __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                 const float* __restrict__ rel_w, const float* __restrict__ o,
                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                 float* __restrict__ dqkv, float* __restrict__ d_rel_h,
                                                                 float* __restrict__ d_rel_w, const AAGeo g) {
-  constexpr int WW = 40, LW = 2 * WW - 1, NT = 256;
+  // WW = 40: 16 + 4 keys per lane (two 32-key tiles, the second one a quarter full); WW = 20: 12 slots per lane in one tile, the
+  // last four of the upper lane half (kx 20..23) past the row: their logit offset is -inf, so p = ds = 0
+  static_assert(WW == 40 || WW == 20, "key rows of 40 or 20");
+  constexpr int LW = 2 * WW - 1, NT = 256;
+  constexpr int NE = WW == 40 ? 20 : 12;               // accumulator slots of a key row seen by one lane
+  constexpr int NG16 = WW == 40 ? 3 : 2;               // 16-key groups of dQ += dS K
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int H = g.H, HW = H * WW;
@@ -492,15 +497,16 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
   const int qy_a = i0 / WW, qy_b = min(i0 + AQM - 1, HW - 1) / WW;
   __syncthreads();
 
-  // this lane's 20 key columns: kx = (e & 3) + 8 * (e >> 2) + 4 * lh for e < 16 (keys 0..31), 32 + (e - 16) + 4 * lh after
-  float rwl[20], drwl[20];
+  // this lane's key columns: kx = (e & 3) + 8 * (e >> 2) + 4 * lh for e < 16 (keys 0..31), 32 + (e - 16) + 4 * lh after
+  float rwl[NE], drwl[NE];
 #pragma unroll
-  for (int e = 0; e < 20; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+    const int kc = kx < WW ? kx : WW - 1;
     float a = 0.f;
 #pragma unroll
-    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RW[d * LW + kx - qx + WW - 1], a);
-    rwl[e] = a * LOG2E;
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RW[d * LW + kc - qx + WW - 1], a);
+    rwl[e] = kx < WW ? a * LOG2E : -1.0e30f;
     drwl[e] = 0.f;
   }
   f32x16 dqa;                            // D[q][d]: rows = the wave's queries, columns = d (lane & 31)
@@ -548,14 +554,16 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kc + lrow * KB_PITCH + kk * 32 + lh * 16);
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kc + (32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
       st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], st0, 0, 0, 0);
-      st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], st1, 0, 0, 0);
+      if (WW == 40) {
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kc + (32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+        st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], st1, 0, 0, 0);
+      }
     }
-    float ds[20], drh = 0.f;
+    float ds[NE], drh = 0.f;
 #pragma unroll
-    for (int e = 0; e < 20; ++e) {
-      const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+    for (int e = 0; e < NE; ++e) {
+      const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;      // (slots past the row read zero rows of Vc)
       const float sv = e < 16 ? st0[e] : st1[e - 16];
       const float p = __builtin_amdgcn_exp2f(fmaf(sv, sl, rhl + rwl[e]));
       float dp = 0.f;
@@ -567,12 +575,13 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
     }
     // dQ += dS K over the key groups [0,16), [16,32), [32,48): accumulator rows -> 8 consecutive keys per lane, hi + lo bf16
 #pragma unroll
-    for (int g16 = 0; g16 < 3; ++g16) {
+    for (int g16 = 0; g16 < NG16; ++g16) {
       float v[8];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const float a = g16 < 2 ? ds[8 * g16 + r4] : ds[16 + r4];
-        const float c = g16 < 2 ? ds[8 * g16 + 4 + r4] : 0.f;             // keys 40..47 do not exist
+        // (accumulator slots that do not exist - keys 40..47, or 24..31 of a 20-wide row - are zeros)
+        const float a = 8 * g16 + r4 < NE ? ds[8 * g16 + r4] : 0.f;
+        const float c = 8 * g16 + 4 + r4 < (WW == 40 ? 16 : NE) ? ds[8 * g16 + 4 + r4] : 0.f;
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(c), false, false);
         v[r4] = __uint_as_float(sw[0]);
         v[4 + r4] = __uint_as_float(sw[1]);
@@ -609,9 +618,9 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
   __syncthreads();                        // dr2 consumed: its space becomes dwq
   // d rw_q[kx] -> dq and d key_rel_w (owner-computes sums over the parked per-query columns)
 #pragma unroll
-  for (int e = 0; e < 20; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
-    dwq[ql * (WW + 1) + kx] = drwl[e];
+    if (kx < WW) dwq[ql * (WW + 1) + kx] = drwl[e];
   }
   __syncthreads();
 #pragma unroll 4
@@ -662,15 +671,15 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
     hipLaunchKernelGGL((aa_attn_fwd_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, lse, g);
   } else {
     static const bool q_row = getenv("CX_AA_Q_ROW") != nullptr;          // diagnostic: the per-query VALU kernel
-    if (WW == 40 && !q_row) {
+    if ((WW == 40 || WW == 20) && !q_row) {
       const size_t smem_m = (2 * tables + 64 * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1))) * 4 + 64 * KB_PITCH;
       static bool attr_m = false;
       if (!attr_m) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_mfma_kernel<DVH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_mfma_kernel<DVH, WW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   96 * 1024);
         attr_m = true;
       }
-      hipLaunchKernelGGL((aa_attn_bwd_q_mfma_kernel<DVH>), dim3((g.H * WW + AQM - 1) / AQM, g.B * g.nh), dim3(256), smem_m, st,
+      hipLaunchKernelGGL((aa_attn_bwd_q_mfma_kernel<DVH, WW>), dim3((g.H * WW + AQM - 1) / AQM, g.B * g.nh), dim3(256), smem_m, st,
                          (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g);
     } else {
       const size_t smem = (2 * tables + (size_t)WW * (DKH + DVH) + (size_t)AQ * (DKH + 2 + WW + 1)) * 4;
