@@ -227,3 +227,56 @@ def test_3x3_weight_gradient_against_torch(dev, select_w, K, N, gpro, xpro, B, H
         if form == 3 or xpro:               # (the strip kernel takes the BN + ReLU activation operand only)
             close(outs[-1], want, rel=2e-3, what="dW (form %d)" % form)
     ops.WGRAD_SCRATCH_FLOATS = keep
+
+
+# ------------------------------------------------------------------------------------------------ differential checks on random shapes
+def test_random_shapes_agree_with_the_kernels_they_replace(dev, select, select_w):
+    """conv_mm against the generic implicit GEMM, wgrad_mm / wgrad3 against conv_wgrad.hip's kernels, on shapes drawn at random
+    (ragged pixel tiles, partial channel steps, several n tiles, strides, both prologues): same inputs, results to bf16 / fp32 rounding."""
+    import random
+    from chexpert_amd import ops
+    rng = random.Random(1234)
+    keep, ops.WGRAD_SCRATCH_FLOATS = ops.WGRAD_SCRATCH_FLOATS, 16 << 20
+    try:
+        for it in range(24):
+            ksz = rng.choice([1, 1, 3])
+            K = 8 * rng.randint(8, 40)
+            N = 128 * rng.randint(1, 3)
+            B, H, W = rng.randint(1, 4), rng.randint(3, 14), rng.randint(3, 14)
+            stride = rng.choice([1, 1, 2]) if min(H, W) >= 4 else 1
+            pro = rng.choice([ops.PRO_NONE, ops.PRO_AFFINE_RELU, ops.PRO_AFFINE2])
+            xb, _ = nhwc(100 + it, B, H, W, K, dev)
+            x2b, _ = nhwc(200 + it, B, H, W, K, dev)
+            wp = ops.pack_weights(bf(rnd(300 + it, (N, K, ksz, ksz), -0.1, 0.1)).to(dev))
+            pa, pb, pc = (rnd(400 + 3 * it + i, (K,), -1.0, 1.0).to(dev) for i in range(3))
+            Ho, Wo = (H + 2 * (ksz // 2) - ksz) // stride + 1, (W + 2 * (ksz // 2) - ksz) // stride + 1
+            kw = dict(N=N, kh=ksz, kw=ksz, stride=stride, pad=ksz // 2)
+            if pro == ops.PRO_AFFINE_RELU:
+                kw.update(prologue=pro, pa=pa, pb=pb)
+            elif pro == ops.PRO_AFFINE2:
+                kw.update(prologue=pro, x2=x2b, pa=pa, pb=pb, pc=pc)
+            outs = []
+            for on in (0, 1):
+                select(on, 0)
+                y = torch.empty(B, Ho, Wo, N, dtype=torch.bfloat16, device=dev)
+                ops.conv_gemm(xb, wp, y, **kw)
+                outs.append(y.float())
+            scale = outs[0].abs().max().item() + 1e-6
+            err = (outs[0] - outs[1]).abs().max().item()
+            assert err <= 8e-3 * scale, ("conv", it, ksz, K, N, B, H, W, stride, pro, err / scale)
+            if stride == 1 and (B * H * W) % 64 == 0 or (ksz == 3 and stride == 1 and K % 128 == 0):
+                gb, _ = nhwc(500 + it, B, H, W, N, dev)
+                g2b, _ = nhwc(600 + it, B, H, W, N, dev)
+                ga, gbv, gc = (rnd(700 + 3 * it + i, (N,), -1.0, 1.0).to(dev) for i in range(3))
+                dws = []
+                for form in (0, 3):                 # conv_wgrad.hip's kernels (strip / pw / generic), then wgrad3 / wgrad_mm
+                    select_w(1 if form else 0, form)
+                    dw = torch.zeros(N, K, ksz, ksz, device=dev)
+                    ops.conv_wgrad(gb, xb, dw, kh=ksz, kw=ksz, pad=ksz // 2, g_prologue=ops.PRO_AFFINE2, g2=g2b, ga=ga, gb=gbv, gc=gc,
+                                   x_prologue=ops.PRO_AFFINE_RELU, pa=pa, pb=pb)
+                    dws.append(dw)
+                scale = dws[0].abs().max().item() + 1e-6
+                err = (dws[0] - dws[1]).abs().max().item()
+                assert err <= 2e-3 * scale, ("wgrad", it, ksz, K, N, B, H, W, err / scale)
+    finally:
+        ops.WGRAD_SCRATCH_FLOATS = keep
