@@ -345,12 +345,35 @@ def main(argv=None):
             json.dump(res, open(os.path.join(args.output_dir, "eval_results_ensemble.json"), "w"), indent=4)
             print("AUC:\n", pprint.pformat(res["aucs"]))
     if args.visualize and rank == 0:
+        # chexpert.py:556-563: Grad-CAM grids over the 'vis' subset (three examples per finding category), and for the
+        # attention-augmented models the attention-map grids of the stored softmax weights
+        from . import vis
         from .gradcam import grad_cam
-        x, _, _ = next(batches(valid_ds, list(range(min(len(valid_ds), args.batch_size))), args.batch_size, False))
-        cam = grad_cam(model, x.to(device))
-        os.makedirs(os.path.join(args.output_dir, "vis"), exist_ok=True)
-        np.save(os.path.join(args.output_dir, "vis", "grad_cam.npy"), cam.cpu().numpy())
-        print("grad-cam maps:", tuple(cam.shape))
+        names = ATTR_NAMES[:args.n_classes] if args.n_classes <= len(ATTR_NAMES) else ["class %d" % i for i in range(args.n_classes)]
+        groups = vis.select_vis_subset(valid_ds.targets, names)
+        flat = sorted({i for g in groups[1] for i in g})
+        pos = {i: k for k, i in enumerate(flat)}
+        imgs, labels, scores, masks = [], [], [], []
+        model.eval()
+        attn_layers = [m for m in model.modules() if type(m).__name__ == "AAConv2d"]
+        for x, tg, idx in batches(valid_ds, flat, args.batch_size, False):
+            xd = x.to(device)
+            with torch.no_grad():
+                scores.append(model(xd).float().cpu())
+            masks.append(grad_cam(model, xd).float().cpu())
+            imgs.append(x.float().div(255.0)[:, 0] if x.dtype == torch.uint8 else (x.float()[:, 0] * vis.STD + vis.MEAN))
+            labels.append(tg)
+            if attn_layers:
+                xn = (x.float().div(255.0) - vis.MEAN) / vis.STD if x.dtype == torch.uint8 else x.float()
+                for k in range(len(x)):
+                    vis.vis_attn(xn, ["synthetic/%d" % int(i) for i in idx], idx, attn_layers, args.output_dir, k)
+        imgs, labels, scores, masks = torch.cat(imgs), torch.cat(labels), torch.cat(scores), torch.cat(masks)
+        cam = masks
+        groups = (groups[0], [[pos[i] for i in g] for g in groups[1]])
+        files = vis.visualize(imgs.numpy(), labels.numpy(), scores.numpy(), masks[:, 0].numpy(), ["synthetic/%d" % i for i in flat], names,
+                              groups, args.output_dir, getattr(args, "step", 0))
+        np.save(os.path.join(args.output_dir, "vis", "grad_cam.npy"), cam.numpy())
+        print("grad-cam maps:", tuple(cam.shape), "figures:", len(files))
     if args.plot_roc and rank == 0:
         files = [f for f in os.listdir(args.output_dir) if f.startswith("eval_results") and f.endswith(".json")]
         if not files:

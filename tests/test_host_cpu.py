@@ -243,3 +243,24 @@ def test_reference_parameter_counts_and_import_paths():
     d = {"k": .2, "v": .1, "nh": 8, "relative": True, "input_dims": (320, 320)}
     DenseNet(32, (6, 12, 24, 16), 64, attn_params=d)
     assert d["input_dims"] == (320, 320)                   # the reference mutates the caller's dict; the drop-in works on a copy
+
+
+def test_visualisation_figures_from_maps(tmp_path):
+    """chexpert_amd/vis.py (chexpert.py:305-397, dataset.py:50-68): the 'vis' subset selection and the two figure kinds, from given maps."""
+    import numpy as np
+    from chexpert_amd import synth, vis
+    t = torch.tensor([[1, 0, 0], [0, 1, 0], [0, 0, 0], [1, 1, 0], [1, 1, 1], [1, 0, 0], [1, 0, 0], [1, 0, 0]], dtype=torch.float32)
+    names, groups = vis.select_vis_subset(t, ["A", "B", "C"])
+    assert names == ["A", "B", "C", "No findings", "2 conditions", "Multiple conditions"]
+    assert groups == [[0, 5, 6], [1], [], [2], [3], [4]]            # three per category at most, in data order
+    n = len(t)
+    files = vis.visualize(np.random.rand(n, 48, 48), t.numpy(), np.random.randn(n, 3), np.random.rand(n, 48, 48), ["p%d" % i for i in range(n)],
+                          ["A", "B", "C"], (names, groups), str(tmp_path), 7)
+    assert len(files) == 6 and all(os.path.getsize(f) > 200 for f in files) and os.path.getsize(files[0]) > 5000
+    assert os.path.basename(files[3]) == "vis_No_findings_step_7.png"
+
+    class Layer:
+        nh = 2
+        weights = torch.softmax(torch.randn(1, 2, 16, 16), -1)
+    out = vis.vis_attn(torch.randn(1, 3, 64, 64), ["p0"], [5], [Layer()], str(tmp_path))
+    assert [os.path.basename(f) for f in out] == ["attn_image_idx_5_0_layer_0.png"]

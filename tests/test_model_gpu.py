@@ -306,6 +306,20 @@ def test_cli_train_eval_synthetic(dev, tmp_path):
     assert any(f.startswith("eval_results_step_") for f in files)
     ck = torch.load(os.path.join(str(tmp_path), "checkpoint_latest.pt"))
     assert set(ck) == {"global_step", "eval_loss", "avg_auc", "state_dict"} and len(ck["state_dict"]) == 727
+    # --visualize (chexpert.py:305-337): one Grad-CAM grid per finding category of the 'vis' subset + the raw maps
+    vis = os.listdir(os.path.join(str(tmp_path), "vis"))
+    assert "grad_cam.npy" in vis and sum(f.startswith("vis_") and f.endswith(".png") for f in vis) == 5 + 3
+
+
+def test_cli_visualize_attention_maps(dev, tmp_path):
+    """chexpert.py:363-397 (`vis_attn`) on the attention-augmented DenseNet: an attention-map grid per image and AAConv2d layer from the
+    softmax weights rebuilt by the HIP path (AAConv2d.weights), beside the Grad-CAM grids."""
+    from chexpert_amd import cli
+    cli.main(["--visualize", "--model", "aadensenet121", "--synthetic", "12", "--batch_size", "4", "--resize", "64", "--n_classes", "3",
+              "--output_dir", str(tmp_path)])
+    vis = os.listdir(os.path.join(str(tmp_path), "vis"))
+    assert any(f.startswith("attn_image_idx_") and f.endswith("_layer_2.png") for f in vis), vis
+    assert sum(f.startswith("vis_") for f in vis) == 3 + 3
 
 
 def test_cli_restore_continues_with_optimizer_state_and_graph_fp32_smoke(dev, tmp_path):
