@@ -259,11 +259,16 @@ def main(argv=None):
     if args.restore and os.path.isfile(args.restore):
         restore(args, model, optimizer, scheduler, device)
     size = args.resize or 320
-    if not args.synthetic:
-        raise RuntimeError("the CheXpert-small dataset is not available offline; pass --synthetic N")
-    n_valid = max(args.batch_size, args.synthetic // 5)
-    train_ds = SyntheticXrays(args.mini_data or args.synthetic, size, args.n_classes, 7)
-    valid_ds = SyntheticXrays(n_valid, size, args.n_classes, 11)
+    if args.synthetic:
+        n_valid = max(args.batch_size, args.synthetic // 5)
+        train_ds = SyntheticXrays(args.mini_data or args.synthetic, size, args.n_classes, 7)
+        valid_ds = SyntheticXrays(n_valid, size, args.n_classes, 11)
+    else:                                  # chexpert.py:64-79 over the extracted CheXpert-v1.0-small folder (uint8 to the GPU)
+        from .data import ChexpertCSV
+        if not args.data_path:
+            raise RuntimeError("pass --data_path <folder holding CheXpert-v1.0-small> or --synthetic N (no download here)")
+        train_ds = ChexpertCSV(args.data_path, "train", args.resize, mini_data=args.mini_data)
+        valid_ds = ChexpertCSV(args.data_path, "valid", args.resize, mini_data=args.mini_data)
     loss_fn = nn.BCEWithLogitsLoss(reduction="none")
     if rank == 0:
         print("Loaded %s (number of parameters: %s; weights trained to step %d)" % (

@@ -1,0 +1,90 @@
+"""The CheXpert-small input pipeline of the reference, host side: what `ChexpertSmall` (dataset.py:17-153) and the transform chain of
+`fetch_dataloader` (chexpert.py:64-79) do up to the decoded, resized and centre-cropped grey image.  The image leaves as uint8
+(1, S, S): the rest of the chain -- `float().div(255)`, `Normalize(0.5330, 0.0349)`, `expand(3,-1,-1)` -- runs on the GPU inside
+the models' input kernels (cx_u8_to_nhwc4 / cx_u8_to_nhwc8), so a batch crosses PCIe at one byte per pixel.
+
+Labels follow dataset.py:134-153 (U-Ones): training rows get blanks -> 0 and uncertain (-1) -> 1 on the five competition findings;
+the validation file is used as it is; `test` mode reads a bare csv of paths with zero labels (dataset.py:33-37).  Nothing is
+downloaded here (no network): a missing data folder raises.
+"""
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+ATTR_NAMES = ["Atelectasis", "Cardiomegaly", "Consolidation", "Edema", "Pleural Effusion"]      # dataset.py:26
+DIR_NAME = "CheXpert-v1.0-small"                                                                  # dataset.py:18-19
+
+
+def resize_center_crop(img, resize, crop):
+    """T.Resize(resize) (shorter side to `resize`, bilinear, aspect kept; skipped when `resize` is falsy) then T.CenterCrop(crop)
+    (chexpert.py:67-69), on a PIL image; returns the grey bytes (crop, crop) uint8."""
+    img = img.convert("L")
+    if resize:
+        w, h = img.size
+        if w <= h:
+            nw, nh = resize, int(resize * h / w)
+        else:
+            nw, nh = int(resize * w / h), resize
+        if (nw, nh) != (w, h):
+            img = img.resize((nw, nh), Image.BILINEAR)
+    w, h = img.size
+    if w < crop or h < crop:                      # CenterCrop pads with zeros when the image is smaller than the crop
+        canvas = Image.new("L", (max(w, crop), max(h, crop)), 0)
+        canvas.paste(img, ((canvas.size[0] - w) // 2, (canvas.size[1] - h) // 2))
+        img, (w, h) = canvas, canvas.size
+    left, top = int(round((w - crop) / 2.0)), int(round((h - crop) / 2.0))
+    return np.asarray(img.crop((left, top, left + crop, top + crop)), dtype=np.uint8)
+
+
+class ChexpertCSV(torch.utils.data.Dataset):
+    """mode 'train' / 'valid' / 'vis': `root` holds the extracted CheXpert-v1.0-small folder; 'test': `root` is a csv of image paths.
+    Items are (uint8 (1,S,S), float32 labels (5,), row index in the source table) like the reference's (img, attr, idx)."""
+    attr_names = ATTR_NAMES
+
+    def __init__(self, root, mode="train", resize=None, data_filter=None, mini_data=None):
+        import pandas as pd
+        assert mode in ("train", "valid", "test", "vis")
+        self.mode, self.resize, self.crop = mode, resize, (resize or 320)
+        root = os.path.expanduser(root)
+        if mode == "test":
+            df = pd.read_csv(root, keep_default_na=True)
+            self.root = "."
+            for a in self.attr_names:
+                df[a] = 0.0
+        else:
+            folder = os.path.join(root, DIR_NAME)
+            if not os.path.isdir(folder):
+                raise FileNotFoundError("%s not found (the dataset is not downloaded here; pass --synthetic N)" % folder)
+            self.root = root
+            df = pd.read_csv(os.path.join(folder, "train.csv" if mode == "train" else "valid.csv"), keep_default_na=True)
+            if mode == "train":
+                df[self.attr_names] = df[self.attr_names].fillna(0).replace(-1, 1)            # U-Ones
+                for k, v in (data_filter or {}).items():
+                    df = df[df[k] == v]
+        if mini_data is not None:
+            df = df[:mini_data]
+        self.vis_attrs = self.vis_idxs = None
+        if mode == "vis":                          # dataset.py:50-68
+            from .vis import select_vis_subset
+            lab = torch.tensor(df[self.attr_names].fillna(0).values.astype(np.float32))
+            self.vis_attrs, groups = select_vis_subset(lab, self.attr_names)
+            self.vis_idxs = [[int(df.index[i]) for i in g] for g in groups]
+            df = df.iloc[[i for g in groups for i in g]]
+        self.data = df
+        self.targets = torch.tensor(df[self.attr_names].fillna(0).values.astype(np.float32))
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, i):
+        path = self.data.iloc[i, 0]                                     # 'Path' is the first column
+        with Image.open(os.path.join(self.root, path)) as img:
+            px = resize_center_crop(img, self.resize, self.crop)
+        return torch.from_numpy(px.copy()).unsqueeze(0), self.targets[i], int(self.data.index[i])
+
+
+def extract_patient_ids(dataset, idxs):
+    """dataset.py:156-160: '<...>/patient64541/study1' for each source row index."""
+    return dataset.data["Path"].loc[list(idxs)].str.rsplit("/", expand=True, n=1)[0].values

@@ -264,3 +264,49 @@ def test_visualisation_figures_from_maps(tmp_path):
         weights = torch.softmax(torch.randn(1, 2, 16, 16), -1)
     out = vis.vis_attn(torch.randn(1, 3, 64, 64), ["p0"], [5], [Layer()], str(tmp_path))
     assert [os.path.basename(f) for f in out] == ["attn_image_idx_5_0_layer_0.png"]
+
+
+def test_csv_dataset_u_ones_resize_center_crop(tmp_path):
+    """chexpert_amd/data.py against dataset.py:73-153 and chexpert.py:67-69: U-Ones label processing on the training file only, the
+    shorter side resized to --resize, centre crop, grey uint8 out, source-row indices, patient ids, the test-csv mode."""
+    import numpy as np
+    import pandas as pd
+    from PIL import Image
+    from chexpert_amd import data
+    root = tmp_path / data.DIR_NAME
+    rows = []
+    for split, n in (("train", 5), ("valid", 3)):
+        for i in range(n):
+            d = root / split / ("patient%05d" % i) / "study1"
+            d.mkdir(parents=True)
+            w, h = (390 + 7 * i, 320 + 5 * i) if i % 2 == 0 else (330, 412)
+            ramp = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)     # value = (row + col) mod 256
+            Image.fromarray(ramp, "L").save(str(d / "view1_frontal.png"))
+            rows.append((split, "%s/%s/patient%05d/study1/view1_frontal.png" % (data.DIR_NAME, split, i)))
+    nan = float("nan")
+    lab = {"train": [[1, nan, -1, 0, 0], [nan, nan, nan, nan, nan], [-1, -1, 1, 0, 1], [0, 1, 0, 0, 0], [1, 1, 1, 1, 1]],
+           "valid": [[1, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 1, 1, 0, 0]]}
+    for split in ("train", "valid"):
+        paths = [p for s_, p in rows if s_ == split]
+        df = pd.DataFrame({"Path": paths, "Sex": "F", "Frontal/Lateral": ["Frontal"] * (len(paths) - 1) + ["Lateral"]})
+        for j, a in enumerate(data.ATTR_NAMES):
+            df[a] = [r[j] for r in lab[split]]
+        df.to_csv(str(root / (split + ".csv")), index=False)
+    tr = data.ChexpertCSV(str(tmp_path), "train", resize=None)
+    assert len(tr) == 5 and tr.targets.tolist() == [[1, 0, 1, 0, 0], [0, 0, 0, 0, 0], [1, 1, 1, 0, 1], [0, 1, 0, 0, 0], [1, 1, 1, 1, 1]]
+    x, t, idx = tr[0]
+    assert x.dtype == torch.uint8 and tuple(x.shape) == (1, 320, 320) and idx == 0
+    # no resize: the centre 320 x 320 of the 390 x 320 ramp starts at column 35, row 0
+    assert x[0, 0, 0].item() == 35 and x[0, 10, 5].item() == (10 + 40) % 256
+    fr = data.ChexpertCSV(str(tmp_path), "train", resize=None, data_filter={"Frontal/Lateral": "Frontal"})
+    assert len(fr) == 4
+    va = data.ChexpertCSV(str(tmp_path), "valid", resize=224, mini_data=2)
+    x, t, idx = va[1]                                   # 330 x 412 -> shorter side 224, then the centre 224 x 224
+    assert tuple(x.shape) == (1, 224, 224) and len(va) == 2 and t.tolist() == [0, 0, 0, 0, 0]
+    assert list(data.extract_patient_ids(va, [0, 1])) == ["%s/valid/patient%05d/study1" % (data.DIR_NAME, i) for i in (0, 1)]
+    vi = data.ChexpertCSV(str(tmp_path), "vis")
+    assert vi.vis_attrs[-3:] == ["No findings", "2 conditions", "Multiple conditions"] and vi.vis_idxs[0] == [0] and vi.vis_idxs[5] == [1]
+    csv = tmp_path / "test.csv"
+    pd.DataFrame({"Path": [str(tmp_path / p) for _, p in rows[:2]]}).to_csv(str(csv), index=False)
+    te = data.ChexpertCSV(str(csv), "test", resize=64)
+    assert len(te) == 2 and te[0][1].tolist() == [0, 0, 0, 0, 0] and tuple(te[0][0].shape) == (1, 64, 64)

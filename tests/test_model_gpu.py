@@ -311,6 +311,34 @@ def test_cli_train_eval_synthetic(dev, tmp_path):
     assert "grad_cam.npy" in vis and sum(f.startswith("vis_") and f.endswith(".png") for f in vis) == 5 + 3
 
 
+def test_cli_trains_from_a_chexpert_folder(dev, tmp_path):
+    """--data_path: the csv / image pipeline of dataset.py + chexpert.py:64-79 (chexpert_amd/data.py: U-Ones labels, resize, centre crop,
+    uint8 to the GPU) feeding the training and evaluation loops."""
+    import numpy as np
+    import pandas as pd
+    from PIL import Image
+    from chexpert_amd import cli, data
+    root = tmp_path / "d" / data.DIR_NAME
+    rng = np.random.RandomState(0)
+    for split, n in (("train", 8), ("valid", 4)):
+        paths = []
+        for i in range(n):
+            d = root / split / ("patient%05d" % i) / "study1"
+            d.mkdir(parents=True)
+            Image.fromarray(rng.randint(0, 256, (72 + i, 80), dtype=np.uint8), "L").save(str(d / "view1_frontal.jpg"))
+            paths.append("%s/%s/patient%05d/study1/view1_frontal.jpg" % (data.DIR_NAME, split, i))
+        df = pd.DataFrame({"Path": paths})
+        for j, a in enumerate(data.ATTR_NAMES):
+            df[a] = rng.choice([0.0, 1.0, -1.0, np.nan], n) if split == "train" else rng.choice([0.0, 1.0], n)
+        df.loc[0, data.ATTR_NAMES[0]], df.loc[1, data.ATTR_NAMES[0]] = 1.0, 0.0          # both classes present
+        df.to_csv(str(root / (split + ".csv")), index=False)
+    out = str(tmp_path / "o")
+    cli.main(["--train", "--evaluate", "--data_path", str(tmp_path / "d"), "--batch_size", "4", "--resize", "64", "--n_classes", "5",
+              "--output_dir", out, "--eval_interval", "2", "--log_interval", "1"])
+    ck = torch.load(os.path.join(out, "checkpoint_latest.pt"))
+    assert ck["global_step"] == 2 and np.isfinite(ck["eval_loss"])
+
+
 def test_cli_visualize_attention_maps(dev, tmp_path):
     """chexpert.py:363-397 (`vis_attn`) on the attention-augmented DenseNet: an attention-map grid per image and AAConv2d layer from the
     softmax weights rebuilt by the HIP path (AAConv2d.weights), beside the Grad-CAM grids."""
