@@ -337,6 +337,22 @@ def test_cli_trains_from_a_chexpert_folder(dev, tmp_path):
               "--output_dir", out, "--eval_interval", "2", "--log_interval", "1"])
     ck = torch.load(os.path.join(out, "checkpoint_latest.pt"))
     assert ck["global_step"] == 2 and np.isfinite(ck["eval_loss"])
+    # predict.py of the reference: per-study probabilities (max over views) from one checkpoint / the mean over a folder
+    from chexpert_amd import predict
+    csv = tmp_path / "test.csv"
+    paths = [str(tmp_path / "d" / data.DIR_NAME / "valid" / ("patient%05d" % i) / "study1" / "view1_frontal.jpg") for i in range(4)]
+    pd.DataFrame({"Path": paths + paths[:1]}).to_csv(str(csv), index=False)                 # one study twice (two "views")
+    one = predict.main([str(csv), str(tmp_path / "p1.csv"), "--restore_path", os.path.join(out, "checkpoint_latest.pt"), "--resize", "64",
+                        "--batch_size", "3"])
+    assert list(one.columns) == data.ATTR_NAMES and len(one) == 4 and ((one.values > 0) & (one.values < 1)).all()
+    ens = predict.main([str(csv), str(tmp_path / "p2.csv"), "--restore_path", out, "--resize", "64"])
+    assert ens.shape == one.shape and os.path.getsize(str(tmp_path / "p2.csv")) > 100
+    model = cli.main(["--evaluate_single_model", "--restore", os.path.join(out, "checkpoint_latest.pt"), "--data_path", str(tmp_path / "d"),
+                      "--batch_size", "4", "--resize", "64", "--n_classes", "5", "--output_dir", out])
+    with torch.no_grad():
+        x = torch.stack([data.ChexpertCSV(str(csv), "test", 64)[i][0] for i in range(4)]).to(dev)
+        want = torch.sigmoid(model.eval()(x).float()).cpu().numpy()
+    assert np.abs(one.values - want).max() < 1e-5
 
 
 def test_cli_visualize_attention_maps(dev, tmp_path):
