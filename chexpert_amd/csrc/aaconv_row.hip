@@ -661,14 +661,152 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
   for (int t = tid; t < DKH * LW; t += NT) atomicAdd(&d_rel_w[t], dRW[t]);
 }
 
+// Forward on the same tiles: S^T = K Q^T per key row by MFMA, online softmax per query over the lane's 20 (12) accumulator slots
+// and its partner half (the two halves of a query share the running maximum), p V on the vector pipe (DVH <= 6).
+template <int DVH, int WW>
+__global__ __launch_bounds__(256) void aa_attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                              const float* __restrict__ rel_w, float* __restrict__ o,
+                                                              float* __restrict__ lse, const AAGeo g) {
+  static_assert(WW == 40 || WW == 20, "key rows of 40 or 20");
+  constexpr int LW = 2 * WW - 1, NT = 256;
+  constexpr int NE = WW == 40 ? 20 : 12;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = g.H, HW = H * WW;
+  const int LH = 2 * H - 1;
+  float* RH = lds;
+  float* RW = RH + DKH * LH;
+  float* Vt = RW + DKH * LW;             // [64][DVH] fp32 (rows past the key row zero)
+  char* Kb = reinterpret_cast<char*>(Vt + 64 * DVH);            // bf16 [64 keys][KB_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int ql = wave * 32 + lrow;
+  const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
+  const int i = blockIdx.x * AQM + ql;
+  const bool qvalid = i < HW;
+  const int ic = qvalid ? i : HW - 1;
+  const int qy = ic / WW, qx = ic - qy * WW;
+  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  for (int t = tid; t < DKH * LH; t += NT) RH[t] = rel_h[t];
+  for (int t = tid; t < DKH * LW; t += NT) RW[t] = rel_w[t];
+  for (int t = tid; t < 64 * KB_PITCH / 4; t += NT) reinterpret_cast<uint32_t*>(Kb)[t] = 0u;
+  for (int t = tid; t < 64 * DVH; t += NT) Vt[t] = 0.f;
+  float q[DKH];
+  const float scale = rsqrtf((float)DKH);
+  bf16x8 qf[2];
+  {
+    const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
+    bf16 qb[DKH];
+#pragma unroll
+    for (int d = 0; d < DKH; d += 4) {
+      U64 v;
+      v.u = *reinterpret_cast<const uint2*>(qp + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { qb[d + e] = v.e[e]; q[d + e] = bf2f(v.e[e]) * scale; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qf[0][e] = lh ? qb[8 + e] : qb[e];
+      qf[1][e] = (lh == 0 && e < 4) ? qb[16 + e] : f2bf(0.f);
+    }
+  }
+  __syncthreads();
+  float rwl[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+    const int kc = kx < WW ? kx : WW - 1;
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RW[d * LW + kc - qx + WW - 1], a);
+    rwl[e] = kx < WW ? a * LOG2E : -1.0e30f;
+  }
+  float m = -3.0e38f, l = 0.f, acc[DVH];
+#pragma unroll
+  for (int d = 0; d < DVH; ++d) acc[d] = 0.f;
+  const float sl = scale * LOG2E;
+  const int kofs = g.dk + n * DKH, vofs = 2 * g.dk + n * DVH;
+  const int sj = min(tid / 5, WW - 1), sc = tid - (tid / 5) * 5;
+  const int vj = min(tid / DVH, WW - 1), vd = tid - (tid / DVH) * DVH;
+  uint2 kreg;
+  bf16 vreg;
+  auto load_keys = [&](int ky) __attribute__((always_inline)) {
+    const size_t j0 = (size_t)ky * WW;
+    kreg = *reinterpret_cast<const uint2*>(base + (j0 + sj) * g.ldq + kofs + sc * 4);
+    vreg = base[(j0 + vj) * g.ldq + vofs + vd];
+  };
+  load_keys(0);
+  for (int ky = 0; ky < H; ++ky) {
+    __syncthreads();
+    if (tid < WW * 5) *reinterpret_cast<uint2*>(Kb + sj * KB_PITCH + sc * 8) = kreg;
+    if (tid < WW * DVH) Vt[vj * DVH + vd] = bf2f(vreg);
+    __syncthreads();
+    load_keys(ky + 1 < H ? ky + 1 : ky);
+    float rhv = 0.f;
+#pragma unroll
+    for (int d = 0; d < DKH; ++d) rhv = fmaf(q[d], RH[d * LH + ky - qy + H - 1], rhv);
+    const float rhl = rhv * LOG2E;
+    f32x16 st0, st1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st0[e] = st1[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kb + lrow * KB_PITCH + kk * 32 + lh * 16);
+      st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], st0, 0, 0, 0);
+      if (WW == 40) {
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kb + (32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+        st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], st1, 0, 0, 0);
+      }
+    }
+    float s2[NE], mx = -3.0e38f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      s2[e] = fmaf(e < 16 ? st0[e] : st1[e - 16], sl, rhl + rwl[e]);
+      mx = fmaxf(mx, s2[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    l *= alpha;
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) acc[d] *= alpha;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+      const float p = __builtin_amdgcn_exp2f(s2[e] - mn);
+      l += p;
+#pragma unroll
+      for (int d = 0; d < DVH; ++d) acc[d] = fmaf(p, Vt[kx * DVH + d], acc[d]);
+    }
+  }
+  l += __shfl_xor(l, 32);
+#pragma unroll
+  for (int d = 0; d < DVH; ++d) acc[d] += __shfl_xor(acc[d], 32);
+  if (qvalid && lh == 0) {
+    const float inv = 1.f / l;
+    float* op = o + ((size_t)b * HW + i) * g.dv + n * DVH;
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) op[d] = acc[d] * inv;
+    lse[(size_t)bn * HW + i] = m * LN2 + __logf(l);
+  }
+}
+
 template <int DVH, int WW>
 int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_w, float* o, const float* d_o, float* lse, float* dqkv,
                float* d_rel_h, float* d_rel_w, const AAGeo& g, hipStream_t st) {
   const dim3 grid((g.H * WW + AQ - 1) / AQ, g.B * g.nh);
   const size_t tables = (size_t)DKH * (2 * g.H - 1 + 2 * WW - 1);
   if (which == 0) {
-    const size_t smem = (tables + (size_t)WW * (DKH + DVH)) * 4;
-    hipLaunchKernelGGL((aa_attn_fwd_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, lse, g);
+    static const bool f_row = getenv("CX_AA_F_ROW") != nullptr;          // diagnostic: the per-query VALU kernel
+    if ((WW == 40 || WW == 20) && !f_row) {
+      const size_t smem_m = (tables + 64 * DVH) * 4 + 64 * KB_PITCH;
+      hipLaunchKernelGGL((aa_attn_fwd_mfma_kernel<DVH, WW>), dim3((g.H * WW + AQM - 1) / AQM, g.B * g.nh), dim3(256), smem_m, st,
+                         (const bf16*)qkv, rel_h, rel_w, o, lse, g);
+    } else {
+      const size_t smem = (tables + (size_t)WW * (DKH + DVH)) * 4;
+      hipLaunchKernelGGL((aa_attn_fwd_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, lse, g);
+    }
   } else {
     static const bool q_row = getenv("CX_AA_Q_ROW") != nullptr;          // diagnostic: the per-query VALU kernel
     if ((WW == 40 || WW == 20) && !q_row) {
