@@ -13,12 +13,14 @@
 //     and one global atomic per channel (tap) and workgroup.
 // Same C ABI (cx_dwconv_fwd / _dgrad / _wgrad); shapes outside k in {3,5}, stride in {1,2}, pad = k/2 keep the old kernels.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int TW = 16;
 
-__device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + __expf(-z)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp): the IEEE division sequence behind `1.f / x` was half of the staging instructions
+__device__ __forceinline__ float sigm(float z) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z)); }
 __device__ __forceinline__ float swish(float z) { return z * sigm(z); }
 __device__ __forceinline__ float dswish(float z) {
   const float s = sigm(z);
@@ -31,7 +33,7 @@ struct DwGeo {
 };
 
 // ---------------------------------------------------------------------------------------------------------------- forward
-template <int K, int S, int TH, int NCQ>
+template <int K, int S, int TH, int NCQ, bool PIPE_>
 __global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ sc, const float* __restrict__ sh,
                                                           bf16* __restrict__ y, float* g1, float* g2, const DwGeo g) {
@@ -60,12 +62,54 @@ __global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict
     s1[j] = s2[j] = 0.f;
   }
   const int ntiles = g.B * g.tiles_y * g.tiles_x;
+  constexpr int NCHUNK = IH * IW * NCQ;
+  // PIPE_ (experiment, CX_DW_PIPE=1): the NEXT tile's source vectors are requested right after the current tile has been staged, so
+  // they travel under its stencil (one tile in registers, at most 8 vectors per thread).  Measured on the B4 shapes: no gain -- the
+  // counters show the kernel waiting on LDS issue (SQ_WAIT_INST_LDS = 70 % of the issue stalls), not on memory.
+  constexpr int NLD = (NCHUNK + 255) / 256;
+  constexpr bool PIPE = PIPE_ && S == 1 && NLD <= 8;
+  U128 pre[PIPE ? NLD : 1];
+  unsigned pre_ok = 0;
+  auto issue = [&](int t) {
+    const int b = t / (g.tiles_y * g.tiles_x), r_ = t - b * g.tiles_y * g.tiles_x;
+    const int ty = r_ / g.tiles_x, tx = r_ - ty * g.tiles_x;
+    const int iy0 = ty * TH * S - PAD, ix0 = tx * TW * S - PAD;
+    pre_ok = 0;
+#pragma unroll
+    for (int u = 0; u < (PIPE ? NLD : 0); ++u) {
+      const int i = u * 256 + tid, p = (i < NCHUNK ? i : tid) / NCQ;
+      const int pr = p / IW, pc = p - pr * IW, iy = iy0 + pr, ix = ix0 + pc;
+      pre_ok |= (cok && iy >= 0 && iy < H && ix >= 0 && ix < W ? 1u : 0u) << u;
+      const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+      pre[u].u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + iyc) * W + ixc) * C + ccl);
+    }
+  };
+  if constexpr (PIPE) {
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+  }
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int b = t / (g.tiles_y * g.tiles_x), r_ = t - b * g.tiles_y * g.tiles_x;
     const int ty = r_ / g.tiles_x, tx = r_ - ty * g.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     __syncthreads();                                  // the previous tile has been read (first time: weights staged)
-    constexpr int NCHUNK = IH * IW * NCQ;
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int i = u * 256 + tid, p = i / NCQ;
+        U128 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = bf2f(pre[u].e[j]);
+          o.e[j] = act ? f2bf(swish(fmaf(a, fsc[j], fsh[j]))) : pre[u].e[j];
+        }
+        const unsigned keep = (pre_ok >> u) & 1u ? 0xffffffffu : 0u;
+        o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
+        if (i < NCHUNK) *reinterpret_cast<uint4*>(tile + (size_t)p * PP + cq * 16) = o.u;
+      }
+      __syncthreads();
+      const int tn = t + (int)gridDim.x;
+      issue(tn < ntiles ? tn : t);                    // unconditional request (the last tile re-requests itself)
+    } else {
     for (int base = 0; base < NCHUNK; base += 1024) {
       U128 v[4];
       bool ok[4];
@@ -92,6 +136,7 @@ __global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict
       }
     }
     __syncthreads();
+    }
     float acc[4][8];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -476,8 +521,15 @@ int launch_cfg(int which, const DwArgs& a, DwGeo g, hipStream_t st) {
   static bool attr[3] = {false, false, false};       // per instantiation
   if (which == 0) {
     const size_t smem = fwd_smem<K, S, TH, NCQ>();
-    allow_smem(&dw_fwd_tile_kernel<K, S, TH, NCQ>, smem, &attr[0]);
-    hipLaunchKernelGGL((dw_fwd_tile_kernel<K, S, TH, NCQ>), grid, dim3(256), smem, st, a.x, a.w, a.sc, a.sh, a.y, a.s1, a.s2, g);
+    static const bool pipe = getenv("CX_DW_PIPE") && atoi(getenv("CX_DW_PIPE")) == 1;    // measured: no gain (LDS-issue bound, not latency bound)
+    static bool attr_np = false;
+    if (pipe) {
+      allow_smem(&dw_fwd_tile_kernel<K, S, TH, NCQ, true>, smem, &attr[0]);
+      hipLaunchKernelGGL((dw_fwd_tile_kernel<K, S, TH, NCQ, true>), grid, dim3(256), smem, st, a.x, a.w, a.sc, a.sh, a.y, a.s1, a.s2, g);
+    } else {
+      allow_smem(&dw_fwd_tile_kernel<K, S, TH, NCQ, false>, smem, &attr_np);
+      hipLaunchKernelGGL((dw_fwd_tile_kernel<K, S, TH, NCQ, false>), grid, dim3(256), smem, st, a.x, a.w, a.sc, a.sh, a.y, a.s1, a.s2, g);
+    }
   } else if (which == 1) {
     const size_t smem = dgrad_smem<K, S, TH, NCQ>();
     allow_smem(&dw_dgrad_tile_kernel<K, S, TH, NCQ>, smem, &attr[1]);
@@ -495,8 +547,10 @@ int launch_cfg(int which, const DwArgs& a, DwGeo g, hipStream_t st) {
 template <int K, int S>
 int launch_ks(int which, const DwArgs& a, const DwGeo& g, hipStream_t st) {
   const int mh = which == 1 ? g.H : g.Ho;
-  // small maps / wide layers: 8-row tiles of 64 channels; otherwise 16-row tiles of 32 channels
-  if (mh <= 12 && g.C >= 64) return launch_cfg<K, S, 8, 8>(which, a, g, st);
+  // small maps / wide layers: 8-row tiles of 64 channels; otherwise 16-row tiles of 32 channels.  The input gradient also takes
+  // the 8-row tiles where they cover the height with less waste (24 rows: 3 x 8 instead of 2 x 16; measured -25..-35 % there,
+  // while the forward does not care and the weight gradient loses 40 %)
+  if (g.C >= 64 && (mh <= 12 || (which == 1 && cdiv(mh, 8) * 8 < cdiv(mh, 16) * 16))) return launch_cfg<K, S, 8, 8>(which, a, g, st);
   return launch_cfg<K, S, 16, 4>(which, a, g, st);
 }
 

@@ -14,7 +14,7 @@ int cx_try_dw_tile(int which, const void* x, const float* w, const float* sc, co
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+__device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z)); }
 __device__ __forceinline__ float swishf_(float z) { return z * sigmoidf_(z); }
 __device__ __forceinline__ float dswishf_(float z) {
   const float s = sigmoidf_(z);
@@ -247,25 +247,43 @@ __global__ void dwconv_wgrad_kernel(const bf16* __restrict__ g, const bf16* __re
 // pooled[b][c] = mean_hw act(x*sc+sh), act: 0 none, 1 relu, 2 swish
 __global__ void gap_affine_act_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                                       float* __restrict__ pooled, int HW, int C, int act, int splits) {
+  // four pixel rows of a thread are requested before the first is consumed (one 16-B load in flight per lane left this kernel
+  // at 0.8 TB/s); the rows of a workgroup meet in LDS, one global atomic per channel and workgroup
+  extern __shared__ float lds[];
+  constexpr int U = 4;
   const int CP = C / 8;
   const int b = blockIdx.y, sp = blockIdx.x;
   const int cq = threadIdx.x % CP, rr = threadIdx.x / CP, rpp = blockDim.x / CP;
   const int len = (HW + splits - 1) / splits, p0 = sp * len, p1 = min(HW, p0 + len);
+  for (int i = threadIdx.x; i < C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
   float a[8], fsc[8], fsh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a[j] = 0.f; fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; }
-  for (int p = p0 + rr; p < p1; p += rpp) {
-    U128 v;
-    v.u = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * C + cq * 8);
+  const bf16* __restrict__ xb = x + (size_t)b * HW * C + cq * 8;
+  for (int p = p0 + rr; p < p1; p += U * rpp) {
+    U128 v[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float z = fmaf(bf2f(v.e[j]), fsc[j], fsh[j]);
-      a[j] += act == 2 ? swishf_(z) : (act == 1 ? fmaxf(z, 0.f) : z);
+    for (int u = 0; u < U; ++u) {
+      const int pp = p + u * rpp;
+      v[u].u = *reinterpret_cast<const uint4*>(xb + (size_t)(pp < p1 ? pp : p1 - 1) * C);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = p + u * rpp < p1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = fmaf(bf2f(v[u].e[j]), fsc[j], fsh[j]);
+        const float t = act == 2 ? swishf_(z) : (act == 1 ? fmaxf(z, 0.f) : z);
+        a[j] += ok ? t : 0.f;
+      }
     }
   }
-  const float inv = 1.f / HW;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) atomicAdd(&pooled[(size_t)b * C + cq * 8 + j], a[j] * inv);
+  for (int j = 0; j < 8; ++j) atomicAdd(&lds[cq * 8 + j], a[j]);
+  __syncthreads();
+  const float inv = 1.f / HW;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&pooled[(size_t)b * C + c], lds[c] * inv);
 }
 
 // SE excitation: h1 = W1 pooled + b1; s = sigmoid(W2 swish(h1) + b2)      one block per sample
@@ -324,16 +342,25 @@ __global__ void bn_lin_bwd_stats_kernel(const bf16* __restrict__ g, const bf16* 
   float s[2][8], fmu[8], fr[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[0][j] = s[1][j] = 0.f; fmu[j] = mean[cq * 8 + j]; fr[j] = rstd[cq * 8 + j]; }
-  const size_t ppb = blockDim.x / CP;
-  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < rows; pix += (size_t)gridDim.x * ppb) {
-    U128 u, v;
-    u.u = *reinterpret_cast<const uint4*>(g + pix * C + cq * 8);
-    v.u = *reinterpret_cast<const uint4*>(y + pix * C + cq * 8);
+  const size_t ppb = blockDim.x / CP, stride = (size_t)gridDim.x * ppb;
+  constexpr int U = 4;                       // pixel rows in flight per thread
+  for (size_t pix0 = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix0 < rows; pix0 += U * stride) {
+    U128 u[U], v[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float gf = bf2f(u.e[j]);
-      s[0][j] += gf;
-      s[1][j] += gf * (bf2f(v.e[j]) - fmu[j]) * fr[j];
+    for (int i = 0; i < U; ++i) {
+      const size_t pix = pix0 + i * stride < rows ? pix0 + i * stride : pix0;
+      u[i].u = *reinterpret_cast<const uint4*>(g + pix * C + cq * 8);
+      v[i].u = *reinterpret_cast<const uint4*>(y + pix * C + cq * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const bool ok = pix0 + i * stride < rows;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gf = ok ? bf2f(u[i].e[j]) : 0.f;
+        s[0][j] += gf;
+        s[1][j] += gf * (bf2f(v[i].e[j]) - fmu[j]) * fr[j];
+      }
     }
   }
   float* const dst[2] = {S1, S2};
@@ -343,23 +370,41 @@ __global__ void bn_lin_bwd_stats_kernel(const bf16* __restrict__ g, const bf16* 
 // ds[b][c] = sum_hw du * swish(x*sc+sh)
 __global__ void se_bwd_reduce_kernel(const bf16* __restrict__ du, const bf16* __restrict__ x, const float* __restrict__ sc,
                                      const float* __restrict__ sh, float* __restrict__ ds, int HW, int C, int splits) {
+  extern __shared__ float lds[];
+  constexpr int U = 4;                       // pixel rows in flight per thread (see gap_affine_act_kernel)
   const int CP = C / 8;
   const int b = blockIdx.y, sp = blockIdx.x;
   const int cq = threadIdx.x % CP, rr = threadIdx.x / CP, rpp = blockDim.x / CP;
   const int len = (HW + splits - 1) / splits, p0 = sp * len, p1 = min(HW, p0 + len);
+  for (int i = threadIdx.x; i < C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
   float a[8], fsc[8], fsh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a[j] = 0.f; fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; }
-  for (int p = p0 + rr; p < p1; p += rpp) {
-    U128 v, d;
-    const size_t pix = (size_t)b * HW + p;
-    v.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
-    d.u = *reinterpret_cast<const uint4*>(du + pix * C + cq * 8);
+  const size_t base = (size_t)b * HW * C + cq * 8;
+  for (int p = p0 + rr; p < p1; p += U * rpp) {
+    U128 v[U], d[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = fmaf(bf2f(d.e[j]), swishf_(fmaf(bf2f(v.e[j]), fsc[j], fsh[j])), a[j]);
+    for (int u = 0; u < U; ++u) {
+      const int pp = p + u * rpp;
+      const size_t off = base + (size_t)(pp < p1 ? pp : p1 - 1) * C;
+      v[u].u = *reinterpret_cast<const uint4*>(x + off);
+      d[u].u = *reinterpret_cast<const uint4*>(du + off);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = p + u * rpp < p1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = bf2f(d[u].e[j]) * swishf_(fmaf(bf2f(v[u].e[j]), fsc[j], fsh[j]));
+        a[j] += ok ? t : 0.f;
+      }
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) atomicAdd(&ds[(size_t)b * C + cq * 8 + j], a[j]);
+  for (int j = 0; j < 8; ++j) atomicAdd(&lds[cq * 8 + j], a[j]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&ds[(size_t)b * C + c], lds[c]);
 }
 
 // SE backward through the two FCs: one block per sample
@@ -435,7 +480,8 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ 
 }
 
 // dz = (du * s[b][c] + dpooled[b][c]/HW) * swish'(x*sc+sh);  S1 += dz, S2 += dz * (x-mean)*rstd.   du / s may be null
-__global__ void se_act_bwd_kernel(const bf16* __restrict__ du, const bf16* __restrict__ x, const float* __restrict__ sc,
+template <int U, int MAXT>
+__global__ __launch_bounds__(MAXT) void se_act_bwd_kernel(const bf16* __restrict__ du, const bf16* __restrict__ x, const float* __restrict__ sc,
                                   const float* __restrict__ sh, const float* __restrict__ mean, const float* __restrict__ rstd,
                                   const float* __restrict__ s, const float* __restrict__ dpooled, bf16* __restrict__ dz, float* S1,
                                   float* S2, int B, int HW, int C) {
@@ -452,26 +498,39 @@ __global__ void se_act_bwd_kernel(const bf16* __restrict__ du, const bf16* __res
     fsc[j] = sc[c]; fsh[j] = sh[c]; fmu[j] = mean[c]; fr[j] = rstd[c];
   }
   const float inv = 1.f / HW;
-  const size_t npix = (size_t)B * HW, ppb = blockDim.x / CP;
-  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
-    const int b = pix / HW;
-    U128 v, d, o;
-    v.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
-    if (du) d.u = *reinterpret_cast<const uint4*>(du + pix * C + cq * 8);
-    float fdp[8], fs[8];
-    if (dpooled) load8(dpooled + (size_t)b * C + cq * 8, fdp);
-    if (du && s) load8(s + (size_t)b * C + cq * 8, fs);
+  const size_t npix = (size_t)B * HW, ppb = blockDim.x / CP, stride = (size_t)gridDim.x * ppb;
+  // U pixel rows in flight per thread: every load of the rows (activations, gradient, per-sample vectors) is requested before the
+  // first is consumed
+  const unsigned np = (unsigned)npix, str = (unsigned)stride;
+  for (unsigned pix0 = blockIdx.x * (unsigned)ppb + threadIdx.x / CP; pix0 < np; pix0 += U * str) {
+    U128 v[U], d[U];
+    float fdp[U][8], fs[U][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xf = bf2f(v.e[j]);
-      float da = dpooled ? fdp[j] * inv : 0.f;
-      if (du) da = fmaf(bf2f(d.e[j]), s ? fs[j] : 1.f, da);
-      const float dzv = da * dswishf_(fmaf(xf, fsc[j], fsh[j]));
-      st[0][j] += dzv;
-      st[1][j] += dzv * (xf - fmu[j]) * fr[j];
-      o.e[j] = f2bf(dzv);
+    for (int u = 0; u < U; ++u) {
+      const unsigned pix = pix0 + u * str < np ? pix0 + u * str : pix0;
+      const unsigned b = pix / (unsigned)HW;
+      v[u].u = *reinterpret_cast<const uint4*>(x + (size_t)pix * C + cq * 8);
+      if (du) d[u].u = *reinterpret_cast<const uint4*>(du + (size_t)pix * C + cq * 8);
+      if (dpooled) load8(dpooled + (size_t)b * C + cq * 8, fdp[u]);
+      if (du && s) load8(s + (size_t)b * C + cq * 8, fs[u]);
     }
-    *reinterpret_cast<uint4*>(dz + pix * C + cq * 8) = o.u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned pix = pix0 + u * str;
+      const bool ok = pix < np;
+      U128 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xf = bf2f(v[u].e[j]);
+        float da = dpooled ? fdp[u][j] * inv : 0.f;
+        if (du) da = fmaf(bf2f(d[u].e[j]), s ? fs[u][j] : 1.f, da);
+        const float dzv = ok ? da * dswishf_(fmaf(xf, fsc[j], fsh[j])) : 0.f;
+        st[0][j] += dzv;
+        st[1][j] += dzv * (xf - fmu[j]) * fr[j];
+        o.e[j] = f2bf(dzv);
+      }
+      if (ok) *reinterpret_cast<uint4*>(dz + (size_t)pix * C + cq * 8) = o.u;
+    }
   }
   float* const dst[2] = {S1, S2};
   flush_partials<2>(st, cq, C, lds, dst);
@@ -629,7 +688,7 @@ int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* po
   if (splits > HW / 16 + 1) splits = HW / 16 + 1;
   hipError_t e = hipMemsetAsync(pooled, 0, (size_t)B * C * sizeof(float), as_stream(stream));
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gap_affine_act_kernel, dim3(splits, B), dim3(th), 0, as_stream(stream), (const bf16*)x, sc, sh, pooled, HW, C, act,
+  hipLaunchKernelGGL(gap_affine_act_kernel, dim3(splits, B), dim3(th), C * sizeof(float), as_stream(stream), (const bf16*)x, sc, sh, pooled, HW, C, act,
                      splits);
   return launch_status();
 }
@@ -653,7 +712,7 @@ int cx_bn_lin_bwd_stats(const void* g, const void* y, const float* mean, const f
                         void* stream) {
   if (!g || !y || !mean || !rstd || !S1 || !S2 || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int CP = C / 8, th = threads_for(CP);
-  hipLaunchKernelGGL(bn_lin_bwd_stats_kernel, dim3(grid_for(rows, th / CP, 2048)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+  hipLaunchKernelGGL(bn_lin_bwd_stats_kernel, dim3(grid_for(rows, 8 * (th / CP), 1024)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
                      (const bf16*)g, (const bf16*)y, mean, rstd, S1, S2, rows, C);
   return launch_status();
 }
@@ -666,7 +725,7 @@ int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float
   if (splits > HW / 16 + 1) splits = HW / 16 + 1;
   hipError_t e = hipMemsetAsync(ds, 0, (size_t)B * C * sizeof(float), as_stream(stream));
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(splits, B), dim3(th), 0, as_stream(stream), (const bf16*)du, (const bf16*)x, sc, sh, ds, HW,
+  hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(splits, B), dim3(th), C * sizeof(float), as_stream(stream), (const bf16*)du, (const bf16*)x, sc, sh, ds, HW,
                      C, splits);
   return launch_status();
 }
@@ -693,8 +752,13 @@ int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* s
                   const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream) {
   if (!x || !sc || !sh || !mean || !rstd || !dz || !S1 || !S2 || (!du && !dpooled) || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int CP = C / 8, th = threads_for(CP);
-  hipLaunchKernelGGL(se_act_bwd_kernel, dim3(grid_for((size_t)B * HW, th / CP, 2048)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
-                     (const bf16*)du, (const bf16*)x, sc, sh, mean, rstd, s, dpooled, (bf16*)dz, S1, S2, B, HW, C);
+  if ((size_t)B * HW >= (1u << 31)) return CX_ESHAPE;
+  if (th <= 512)
+    hipLaunchKernelGGL((se_act_bwd_kernel<4, 512>), dim3(grid_for((size_t)B * HW, 8 * (th / CP), 1024)), dim3(th), 2 * C * sizeof(float),
+                       as_stream(stream), (const bf16*)du, (const bf16*)x, sc, sh, mean, rstd, s, dpooled, (bf16*)dz, S1, S2, B, HW, C);
+  else
+    hipLaunchKernelGGL((se_act_bwd_kernel<1, 1024>), dim3(grid_for((size_t)B * HW, th / CP, 2048)), dim3(th), 2 * C * sizeof(float),
+                       as_stream(stream), (const bf16*)du, (const bf16*)x, sc, sh, mean, rstd, s, dpooled, (bf16*)dz, S1, S2, B, HW, C);
   return launch_status();
 }
 
