@@ -17,8 +17,8 @@ def _targets(model, eng, ws, dev):
     if hasattr(model, "features"):                               # DenseNet: norm5 output, ReLU'd in place by the model (:514)
         nt = eng.slots["nt"][len(eng.blocks) - 1]
         return model.features.norm5, model.classifier, ws.buf[-1], ws.v(nt[0]), ws.v(nt[1]), True
-    if hasattr(model, "layer4"):                                 # ResNet: output of layer4 (already post-ReLU)
-        return model.layer4, model.fc, ws.blk[-1]["out"], None, None, False
+    if hasattr(model, "_stages"):                                # ResNet / WideResNet: output of the last stage (already post-ReLU)
+        return model._stages()[-1], model.fc, ws.blk[-1]["out"], None, None, False
     if hasattr(model, "head"):                                   # EfficientNet: head[1] BatchNorm output, before Swish
         S = eng.bn[id(model.head[1])]
         return model.head[1], model.head[-1], ws.yh, eng._v(ws, S.sc), eng._v(ws, S.sh), False
@@ -31,7 +31,7 @@ def hooks_registered(model):
     except NotImplementedError:
         return False
     mods = [model.features.norm5, model.classifier] if hasattr(model, "features") else \
-        ([model.layer4, model.fc] if hasattr(model, "layer4") else [model.head[1], model.head[-1]])
+        ([model._stages()[-1], model.fc] if hasattr(model, "_stages") else [model.head[1], model.head[-1]])
     return any(len(m._forward_hooks) or len(m._backward_hooks) for m in mods)
 
 
@@ -106,7 +106,7 @@ def grad_cam(model, x, hooks=None, cls_idx=None):
             buf = ws.buf[-1]
             nt = eng.slots["nt"][len(eng.blocks) - 1]
             sc, sh, inner = ws.v(nt[0]), ws.v(nt[1]), 1
-        elif hasattr(model, "layer4"):                               # ResNet: output of layer4 (post-ReLU, no BN in between)
+        elif hasattr(model, "_stages"):                              # ResNet: output of the last stage (post-ReLU, no BN in between)
             buf = ws.blk[-1]["out"]
             C_ = buf.shape[3]
             sc, sh, inner = torch.ones(C_, device=dev), torch.zeros(C_, device=dev), 0

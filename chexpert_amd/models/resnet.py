@@ -1,4 +1,5 @@
-"""Bottleneck ResNet (torchvision-shaped; resnet152 = layers [3, 8, 36, 3]) on the gfx950 kernels.
+"""Bottleneck / BasicBlock ResNet (torchvision-shaped; resnet152 = layers [3, 8, 36, 3]) and the WideResNet of the CIFAR
+harness on the gfx950 kernels.
 
 Drop-in surface: constructor signature of /root/reference/models/attn_aug_conv.py:218-220, `Bottleneck` with
 stride on conv2 (:159-211), torchvision `state_dict` keys (`conv1`, `bn1`, `layerL.i.{conv1,bn1,conv2,bn2,
@@ -54,8 +55,9 @@ class Bottleneck(nn.Module):
 
 class BasicBlock(nn.Module):
     """Signature and parameters of /root/reference/models/attn_aug_conv.py:107-156 (two 3x3 convolutions; AAConv2d replaces
-    conv1 in layers 2-4).  The reference uses it only in the CIFAR harness (models/test_model.py): constructible here
-    (parameter counts, state_dict keys), not part of the MI355X schedule."""
+    conv1 in layers 2-4).  The reference uses it in the CIFAR harness (models/test_model.py).  Plain BasicBlocks run on the
+    HIP schedule (conv3x3 raw + stats -> conv3x3 with bn1+ReLU in the prologue -> residual-join kernel); the
+    attention-augmented form is constructible (parameter counts, state_dict keys) only."""
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None,
@@ -81,7 +83,7 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):  # pragma: no cover - guard
-        raise RuntimeError("chexpert_amd: BasicBlock only holds parameters (CIFAR harness variant, not on the HIP schedule)")
+        raise RuntimeError("chexpert_amd: call the parent ResNet / WideResNet (fused HIP schedule)")
 
 
 class _BN:
@@ -117,9 +119,14 @@ class _Engine:
         self.reducer = None
         # geometry: list of (module, inplanes, planes, stride, has_downsample)
         self.blocks = []
-        for L in (model.layer1, model.layer2, model.layer3, model.layer4):
+        for L in model._stages():
             for blk in L:
                 self.blocks.append(blk)
+        self.basic = model.block is BasicBlock                 # two 3x3 convolutions per block (attn_aug_conv.py:107-156)
+        self.cifar = isinstance(model, WideResNet)              # 3x3 stride-1 stem, no max-pool, three stages (:311-404)
+        if any(isinstance(b.conv1, AAConv2d) for b in self.blocks):
+            raise NotImplementedError("attention-augmented BasicBlocks (AAConv2d as conv1) are constructible but not on the HIP "
+                                      "schedule; the attention-augmented Bottleneck networks are")
         # vector plan: [fwd-zero region | bwd-zero region | rest]
         nfz = sum(2 * bn.num_features for bn in self._all_bns()) + 64
         nbz = nfz
@@ -136,10 +143,14 @@ class _Engine:
             self.bn[id(bn)] = _BN(self.rest, bn.num_features, self.fz, self.bz)
         self.fwd_zero, self.bwd_zero = (0, nf), (nf, nb)
         cmax = 2048
-        self.join = [[self.rest.take(b.bn3.num_features) for _ in range(3)] for b in self.blocks]
+        self.join = [[self.rest.take(self._last_bn(b).num_features) for _ in range(3)] for b in self.blocks]
         self.ones, self.zeros = self.rest.take(cmax), self.rest.take(cmax)
         self.scratch = [self.rest.take(cmax) for _ in range(2)]
         self.vec_size = self.rest.n
+
+    @staticmethod
+    def _last_bn(b):
+        return b.bn3 if hasattr(b, "bn3") else b.bn2
 
     def _all_bns(self):
         m = self.model
@@ -147,7 +158,8 @@ class _Engine:
         for b in self.blocks:
             yield b.bn1
             yield b.bn2
-            yield b.bn3
+            if hasattr(b, "bn3"):
+                yield b.bn3
             if b.downsample is not None:
                 yield b.downsample[1]
 
@@ -190,7 +202,11 @@ class _Engine:
             off = cur
             cur += (n + 7) // 8 * 8
             return (off, n)
-        self.wf[id(m.conv1)] = add(m.conv1, stem=True)
+        if self.cifar:                          # 3 input channels padded to 8 for the implicit GEMM (packed in pack())
+            self.stem_off = cur
+            cur += 9 * m.conv1.out_channels * 8
+        else:
+            self.wf[id(m.conv1)] = add(m.conv1, stem=True)
         for mod in m.modules():
             if isinstance(mod, nn.Conv2d) and mod is not m.conv1:
                 self.wf[id(mod)] = add(mod)
@@ -207,6 +223,9 @@ class _Engine:
             return
         check(lib().cx_pack_weights_table(ptr(self.flat), ptr(self.packed), ptr(self.desc_dev), self.n_desc, stream_ptr()),
               "cx_pack_weights_table")
+        if self.cifar:
+            w8 = torch.nn.functional.pad(self.model.conv1.weight.detach(), (0, 0, 0, 0, 0, 5)).contiguous()   # (O,3,3,3) -> (O,8,3,3)
+            ops.pack_weights(w8, out=self.packed[self.stem_off:])
         self.packed_version = ver
 
     def w_fwd(self, conv):
@@ -233,18 +252,29 @@ class _Engine:
         e = lambda *s, dtype=bf: torch.empty(*s, dtype=dtype, device=dev)
         ws = _Engine.WS()
         ws.key, ws.B, ws.H, ws.W = (B, H, W), B, H, W
-        ws.x4 = e(B, H, W, 4)
-        h, w = H // 2, W // 2
-        ws.c0 = e(B, h, w, 64)
-        h, w = h // 2, w // 2
-        ws.amax = e(B, h, w, 64, dtype=torch.uint8)
-        ws.pool0 = e(B, h, w, 64)
+        if self.cifar:
+            c0 = self.model.conv1.out_channels
+            ws.x8 = e(B, H, W, 8)
+            h, w = H, W
+            ws.c0 = e(B, h, w, c0)
+            ws.pool0 = e(B, h, w, c0)                  # relu(bn1(c0)): the first stage's input (no max-pool in this stem)
+        else:
+            ws.x4 = e(B, H, W, 4)
+            h, w = H // 2, W // 2
+            ws.c0 = e(B, h, w, 64)
+            h, w = h // 2, w // 2
+            ws.amax = e(B, h, w, 64, dtype=torch.uint8)
+            ws.pool0 = e(B, h, w, 64)
         ws.blk = []
         for b in self.blocks:
             p_, s_ = b.conv1.out_channels, b.stride
             ho, wo = h // s_, w // s_
-            t = dict(hin=(h, w), hout=(ho, wo), y1=e(B, h, w, p_), y2=e(B, ho, wo, p_), y3=e(B, ho, wo, 4 * p_),
-                     yd=e(B, ho, wo, 4 * p_) if b.downsample is not None else None, out=e(B, ho, wo, 4 * p_))
+            if self.basic:                          # y1 = conv1 output (3x3, stride s), y2 = conv2 output, both on the block's output grid
+                t = dict(hin=(h, w), hout=(ho, wo), y1=e(B, ho, wo, p_), y2=e(B, ho, wo, p_),
+                         yd=e(B, ho, wo, p_) if b.downsample is not None else None, out=e(B, ho, wo, p_))
+            else:
+                t = dict(hin=(h, w), hout=(ho, wo), y1=e(B, h, w, p_), y2=e(B, ho, wo, p_), y3=e(B, ho, wo, 4 * p_),
+                         yd=e(B, ho, wo, 4 * p_) if b.downsample is not None else None, out=e(B, ho, wo, 4 * p_))
             if isinstance(b.conv2, AAConv2d):
                 aa = b.conv2
                 if (ho, wo) != tuple(aa.input_dims):
@@ -255,7 +285,7 @@ class _Engine:
                 t["LSE"] = e(B * aa.nh, ho * wo, dtype=torch.float32)
             ws.blk.append(t)
             h, w = ho, wo
-        ws.pooled = torch.empty(B, 2048, dtype=torch.float32, device=dev)
+        ws.pooled = torch.empty(B, self.model.fc.in_features, dtype=torch.float32, device=dev)
         ws.slab = torch.empty(3, self.SLAB, dtype=torch.float32, device=dev) if self.det else None
         ws.logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=dev)
         ws.vec = torch.zeros(self.vec_size, dtype=torch.float32, device=dev)
@@ -300,8 +330,9 @@ class _Engine:
         if x.dim() != 4 or x.shape[1] != (1 if u8 else 3):
             raise RuntimeError("expected a (B,3,H,W) float input or a (B,1,H,W) uint8 image")
         B, _, H, W = x.shape
-        if H % 32 or W % 32:
-            raise RuntimeError("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
+        mult = 4 if self.cifar else 32
+        if H % mult or W % mult:
+            raise RuntimeError("input height/width must be multiples of %d (got %dx%d)" % (mult, H, W))
         self.bind(x.device)
         self.pack(train)
         ws = self.acquire(B, H, W)
@@ -311,19 +342,48 @@ class _Engine:
         st = (lambda s: v(ws, s)) if train else (lambda s: None)
         sp = lambda S_: self._sp(ws, S_, train)
         S0 = self.bn[id(m.bn1)]
-        if u8:
-            ops.u8_to_nhwc4(x.contiguous(), ws.x4)
+        if self.cifar:
+            # attn_aug_conv.py:341-343, :391-393: 3x3 stride-1 stem, BatchNorm, ReLU -- no max-pool
+            if u8:
+                raise RuntimeError("the CIFAR stem takes (B,3,H,W) float images")
+            c0 = m.conv1.out_channels
+            check(lib().cx_nchw3_to_nhwc8(ptr(x.contiguous().float()), ptr(ws.x8), B, H, W, stream_ptr()), "cx_nchw3_to_nhwc8")
+            rows = ops.conv_gemm(ws.x8, self.packed[self.stem_off:], ws.c0, N=c0, kh=3, kw=3, stride=1, pad=1, **sp(S0))
+            self._bn_coef(ws, m.bn1, B * H * W, train, rows)
+            ops.affine2_relu(ws.c0, ws.c0, v(ws, S0.sc), v(ws, self.zeros, c0), v(ws, S0.sh), ws.pool0)
         else:
-            ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
-        rows = ops.conv_gemm(ws.x4, self.w_fwd(m.conv1), ws.c0, N=64, mode=ops.MODE_STEM, **sp(S0))
-        self._bn_coef(ws, m.bn1, B * (H // 2) * (W // 2), train, rows)
-        ops.bnrelu_maxpool_fwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), ws.pool0, ws.amax, None, None)
+            if u8:
+                ops.u8_to_nhwc4(x.contiguous(), ws.x4)
+            else:
+                ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
+            rows = ops.conv_gemm(ws.x4, self.w_fwd(m.conv1), ws.c0, N=64, mode=ops.MODE_STEM, **sp(S0))
+            self._bn_coef(ws, m.bn1, B * (H // 2) * (W // 2), train, rows)
+            ops.bnrelu_maxpool_fwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), ws.pool0, ws.amax, None, None)
         xin = ws.pool0
         for bi, b in enumerate(self.blocks):
             t = ws.blk[bi]
             s_, p_ = b.stride, b.conv1.out_channels
             hi, wi = t["hin"]
             ho, wo = t["hout"]
+            if self.basic:
+                # attn_aug_conv.py:135-156: conv3x3(stride) - bn1 - relu - conv3x3 - bn2, + identity | downsample(x), relu
+                S1, S2 = self.bn[id(b.bn1)], self.bn[id(b.bn2)]
+                rows = ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, kh=3, kw=3, stride=s_, pad=1, **sp(S1))
+                self._bn_coef(ws, b.bn1, B * ho * wo, train, rows)
+                rows = ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=1, pad=1,
+                                     prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh), **sp(S2))
+                self._bn_coef(ws, b.bn2, B * ho * wo, train, rows)
+                ja, jb, jc = (v(ws, sl) for sl in self.join[bi])
+                if b.downsample is not None:
+                    Sd = self.bn[id(b.downsample[1])]
+                    rows = ops.conv_gemm(xin, self.w_fwd(b.downsample[0]), t["yd"], N=p_, stride=s_, **sp(Sd))
+                    self._bn_coef(ws, b.downsample[1], B * ho * wo, train, rows)
+                    torch.add(v(ws, S2.sh), v(ws, Sd.sh), out=jc)
+                    ops.affine2_relu(t["y2"], t["yd"], v(ws, S2.sc), v(ws, Sd.sc), jc, t["out"])
+                else:
+                    ops.affine2_relu(t["y2"], xin, v(ws, S2.sc), v(ws, self.ones, p_), v(ws, S2.sh), t["out"])
+                xin = t["out"]
+                continue
             S1, S2, S3 = self.bn[id(b.bn1)], self.bn[id(b.bn2)], self.bn[id(b.bn3)]
             rows = ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, **sp(S1))
             self._bn_coef(ws, b.bn1, B * hi * wi, train, rows)
@@ -437,6 +497,9 @@ class _Engine:
             ho, wo = t["hout"]
             cin = b.conv1.in_channels
             xin = ws.blk[bi - 1]["out"] if bi > 0 else ws.pool0
+            if self.basic:
+                self._basic_backward(ws, bi, b, t, xin, msp, srows, ew, done)
+                continue
             S1, S2, S3 = self.bn[id(b.bn1)], self.bn[id(b.bn2)], self.bn[id(b.bn3)]
             Sd = self.bn[id(b.downsample[1])] if b.downsample is not None else None
             g = bw["g"][bi]
@@ -520,24 +583,93 @@ class _Engine:
         # stem
         S0 = self.bn[id(m.bn1)]
         gx = bw["g_in0"]
-        if det:
-            rows = ops.bnrelu_maxpool_bwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), v(ws, S0.mean), v(ws, S0.rstd), ws.amax, gx, gx, ones(64),
-                                          zeros(64), zeros(64), bw["dz0"], ws.slab[0], ws.slab[1], stat_rows=ew(64))
+        if self.cifar:
+            c0, cnt0 = m.conv1.out_channels, B * ws.H * ws.W
+            if det:
+                rows = ops.relu_bwd_stats(gx, ws.pool0, ws.c0, v(ws, S0.mean), v(ws, S0.rstd), None, None, None, bw["dz0"], ws.slab[0],
+                                          ws.slab[1], None, stat_rows=ew(c0))
+            else:
+                rows = None
+                ops.relu_bwd_stats(gx, ws.pool0, ws.c0, v(ws, S0.mean), v(ws, S0.rstd), None, None, None, bw["dz0"], v(ws, S0.S1),
+                                   v(ws, S0.S2), None)
+            r0 = srows(S0, rows)
+            ops.bn_bwd_coef(r0[0], r0[1], cnt0, m.bn1.weight, v(ws, S0.mean), v(ws, S0.rstd), G(m.bn1.weight), G(m.bn1.bias), None, None,
+                            v(ws, S0.pa), v(ws, S0.pb), v(ws, S0.pc), c0, replicas=r0[2], rstride=r0[3])
+            dw8 = torch.zeros(c0, 8, 3, 3, dtype=torch.float32, device=self.device)       # 3 input channels padded to 8
+            ops.conv_wgrad(bw["dz0"], ws.x8, dw8, kh=3, kw=3, stride=1, pad=1, g_prologue=ops.PRO_AFFINE2, g2=ws.c0, ga=v(ws, S0.pa),
+                           gb=v(ws, S0.pb), gc=v(ws, S0.pc))
+            G(m.conv1.weight).view(c0, 3, 3, 3).add_(dw8[:, :3])
         else:
-            rows = None
-            ops.bnrelu_maxpool_bwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), v(ws, S0.mean), v(ws, S0.rstd), ws.amax, gx, gx, ones(64),
-                                   zeros(64), zeros(64), bw["dz0"], v(ws, S0.S1), v(ws, S0.S2))
-        r0 = srows(S0, rows)
-        ops.bn_bwd_coef(r0[0], r0[1], B * (ws.H // 2) * (ws.W // 2), m.bn1.weight, v(ws, S0.mean), v(ws, S0.rstd),
-                        G(m.bn1.weight), G(m.bn1.bias), None, None, v(ws, S0.pa), v(ws, S0.pb), v(ws, S0.pc), 64, replicas=r0[2],
-                        rstride=r0[3])
-        ops.conv_wgrad(bw["dz0"], ws.x4, G(m.conv1.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0, ga=v(ws, S0.pa),
-                       gb=v(ws, S0.pb), gc=v(ws, S0.pc))
+            if det:
+                rows = ops.bnrelu_maxpool_bwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), v(ws, S0.mean), v(ws, S0.rstd), ws.amax, gx, gx, ones(64),
+                                              zeros(64), zeros(64), bw["dz0"], ws.slab[0], ws.slab[1], stat_rows=ew(64))
+            else:
+                rows = None
+                ops.bnrelu_maxpool_bwd(ws.c0, v(ws, S0.sc), v(ws, S0.sh), v(ws, S0.mean), v(ws, S0.rstd), ws.amax, gx, gx, ones(64),
+                                       zeros(64), zeros(64), bw["dz0"], v(ws, S0.S1), v(ws, S0.S2))
+            r0 = srows(S0, rows)
+            ops.bn_bwd_coef(r0[0], r0[1], B * (ws.H // 2) * (ws.W // 2), m.bn1.weight, v(ws, S0.mean), v(ws, S0.rstd),
+                            G(m.bn1.weight), G(m.bn1.bias), None, None, v(ws, S0.pa), v(ws, S0.pb), v(ws, S0.pc), 64, replicas=r0[2],
+                            rstride=r0[3])
+            ops.conv_wgrad(bw["dz0"], ws.x4, G(m.conv1.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0,
+                           ga=v(ws, S0.pa), gb=v(ws, S0.pb), gc=v(ws, S0.pc))
         if red is not None:
             red.finish()
         if fresh:
             for p, gv in zip(self.params, self.grad_views):
                 p.grad = gv
+
+    def _basic_backward(self, ws, bi, b, t, xin, msp, srows, ew, done):
+        """Backward of one BasicBlock (attn_aug_conv.py:135-156), same conventions as the bottleneck path: the block's output
+        gradient is masked in place by the join ReLU, BatchNorm backward rides in the two-tensor prologues of the consumers."""
+        v, G, bw, B, det = self._v, self.G, ws.bwd, ws.B, self.det
+        s_, p_, cin = b.stride, b.conv1.out_channels, b.conv1.in_channels
+        ho, wo = t["hout"]
+        S1, S2 = self.bn[id(b.bn1)], self.bn[id(b.bn2)]
+        Sd = self.bn[id(b.downsample[1])] if b.downsample is not None else None
+        g = bw["g"][bi]
+        cnt = B * ho * wo
+        ones = v(ws, self.ones, p_)
+        if det:
+            rows = ops.relu_bwd_stats(g, t["out"], t["y2"], v(ws, S2.mean), v(ws, S2.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
+                                      v(ws, Sd.rstd) if Sd else None, g, ws.slab[0], ws.slab[1], ws.slab[2] if Sd else None,
+                                      stat_rows=ew(S2.C))
+        else:
+            rows = None
+            ops.relu_bwd_stats(g, t["out"], t["y2"], v(ws, S2.mean), v(ws, S2.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
+                               v(ws, Sd.rstd) if Sd else None, g, v(ws, S2.S1), v(ws, S2.S2), v(ws, Sd.S2) if Sd else None)
+        r2 = srows(S2, rows)
+        ops.bn_bwd_coef(r2[0], r2[1], cnt, b.bn2.weight, v(ws, S2.mean), v(ws, S2.rstd), G(b.bn2.weight), G(b.bn2.bias), None, None,
+                        v(ws, S2.pa), v(ws, S2.pb), v(ws, S2.pc), S2.C, replicas=r2[2], rstride=r2[3])
+        if Sd is not None:                   # the downsample BatchNorm shares S1 (sum of the masked gradient) with bn2
+            bnd = b.downsample[1]
+            rd = srows(S2, rows, ws.slab[2]) if det else (v(ws, S2.S1), v(ws, Sd.S2), 1, 0)
+            ops.bn_bwd_coef(rd[0], rd[1], cnt, bnd.weight, v(ws, Sd.mean), v(ws, Sd.rstd), G(bnd.weight), G(bnd.bias), None, None,
+                            v(ws, Sd.pa), v(ws, Sd.pb), v(ws, Sd.pc), Sd.C, replicas=rd[2], rstride=rd[3])
+        dz1 = bw["dz1"][:cnt * p_].view(B, ho, wo, p_)
+        rows = ops.conv_gemm(g, self.w_bwd(b.conv2), dz1, N=p_, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=t["y2"], pa=v(ws, S2.pa),
+                             pb=v(ws, S2.pb), pc=v(ws, S2.pc), epilogue=ops.EPI_MASK, ex=t["y1"], e_sc=v(ws, S1.sc), e_sh=v(ws, S1.sh),
+                             e_mu=v(ws, S1.mean), e_r=v(ws, S1.rstd), e_scale=ones, **msp(S1))
+        r1 = srows(S1, rows)
+        ops.conv_wgrad(g, t["y1"], G(b.conv2.weight), kh=3, kw=3, stride=1, pad=1, g_prologue=ops.PRO_AFFINE2, g2=t["y2"],
+                       ga=v(ws, S2.pa), gb=v(ws, S2.pb), gc=v(ws, S2.pc), x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh))
+        ops.bn_bwd_coef(r1[0], r1[1], cnt, b.bn1.weight, v(ws, S1.mean), v(ws, S1.rstd), G(b.bn1.weight), G(b.bn1.bias), None, None,
+                        v(ws, S1.pa), v(ws, S1.pb), v(ws, S1.pc), S1.C, replicas=r1[2], rstride=r1[3])
+        gx = (bw["g"][bi - 1] if bi > 0 else bw["g_in0"]) if Sd is not None or bi == 0 else g
+        identity = Sd is None
+        if identity and gx is not g:
+            gx.copy_(g)
+        ops.conv_gemm(dz1, self.w_bwd(b.conv1), gx, N=cin, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["y1"],
+                      pa=v(ws, S1.pa), pb=v(ws, S1.pb), pc=v(ws, S1.pc), accumulate=identity)
+        ops.conv_wgrad(dz1, xin, G(b.conv1.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=t["y1"],
+                       ga=v(ws, S1.pa), gb=v(ws, S1.pb), gc=v(ws, S1.pc))
+        if Sd is not None:
+            convd = b.downsample[0]
+            ops.conv_gemm(g, self.w_bwd(convd), gx, N=cin, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["yd"], pa=v(ws, Sd.pa),
+                          pb=v(ws, Sd.pb), pc=v(ws, Sd.pc), accumulate=True)
+            ops.conv_wgrad(g, xin, G(convd.weight), stride=s_, g_prologue=ops.PRO_AFFINE2, g2=t["yd"], ga=v(ws, Sd.pa), gb=v(ws, Sd.pb),
+                           gc=v(ws, Sd.pc))
+        done(b.conv1.weight)
 
     def enable_data_parallel(self, bucket_bytes=16 << 20, group=None):
         from ..parallel import GradReducer
@@ -566,7 +698,58 @@ class _Fn(torch.autograd.Function):
         return None, None, None
 
 
-class ResNet(nn.Module):
+class _EngineNet(nn.Module):
+    """What the BasicBlock / Bottleneck ResNet and the WideResNet share: the fused engine behind forward / autograd."""
+
+    def _eng(self):
+        for mod in self.modules():
+            if isinstance(mod, AAConv2d) and not mod.kernel_support:
+                raise NotImplementedError("AAConv2d(dk=%d, dv=%d, nh=%d): the HIP attention kernels cover dk/nh = 20, dv/nh in "
+                                          "{1,2,3,4,6}, relative=True" % (mod.dk, mod.dv, mod.nh))
+        if self._engine is None:
+            object.__setattr__(self, "_engine", _Engine(self))
+        return self._engine
+
+    def state_dict(self, *args, **kwargs):
+        if self._nbt_pending:
+            for mod in self.modules():
+                if isinstance(mod, nn.BatchNorm2d):
+                    mod.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+        return super().state_dict(*args, **kwargs)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("chexpert_amd.ResNet runs on the GPU only (hand-written HIP kernels); there is no CPU fallback")
+        eng = self._eng()
+        if self.fc.in_features != self._stages()[-1][-1].bn1.num_features * self.block.expansion:
+            raise RuntimeError("fc.in_features must match the last stage (%d channels)"
+                               % (self._stages()[-1][-1].bn1.num_features * self.block.expansion))
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _Fn.apply(x, self.fc.weight, self)
+        if not self.training:
+            from ..gradcam import hooked_eval_forward, hooks_registered
+            if hooks_registered(self):                     # Grad-CAM hook protocol of the reference (chexpert.py:271-272)
+                return hooked_eval_forward(self, x)
+        ws = eng.forward(x, self.training)
+        out = ws.logits.clone()
+        eng.release(ws)
+        return out
+
+    def forward_backward(self, x, target):
+        eng = self._eng()
+        ws = eng.forward(x, self.training)
+        B, n = ws.logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dl = torch.empty(B, n, dtype=torch.float32, device=x.device)
+        ops.bce_fwd_bwd(ws.logits, target, loss, None, dl)
+        eng.backward(ws, dl)
+        logits = ws.logits.clone()
+        eng.release(ws)
+        return loss, logits
+
+
+class ResNet(_EngineNet):
     """Signature of /root/reference/models/attn_aug_conv.py:218-220."""
 
     def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
@@ -614,59 +797,14 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes, attn_params=attn_params))
         return nn.Sequential(*layers)
 
-    def _eng(self):
-        if self.block is not Bottleneck:
-            raise NotImplementedError("BasicBlock ResNets (ResNet18/34 of models/test_model.py) are constructible but only the "
-                                      "Bottleneck networks chexpert.py trains run on the HIP schedule")
-        for mod in self.modules():
-            if isinstance(mod, AAConv2d) and not mod.kernel_support:
-                raise NotImplementedError("AAConv2d(dk=%d, dv=%d, nh=%d): the HIP attention kernels cover dk/nh = 20, dv/nh in "
-                                          "{1,2,3,4,6}, relative=True" % (mod.dk, mod.dv, mod.nh))
-        if self._engine is None:
-            object.__setattr__(self, "_engine", _Engine(self))
-        return self._engine
-
-    def state_dict(self, *args, **kwargs):
-        if self._nbt_pending:
-            for mod in self.modules():
-                if isinstance(mod, nn.BatchNorm2d):
-                    mod.num_batches_tracked += self._nbt_pending
-            self._nbt_pending = 0
-        return super().state_dict(*args, **kwargs)
-
-    def forward(self, x):
-        if not x.is_cuda:
-            raise RuntimeError("chexpert_amd.ResNet runs on the GPU only (hand-written HIP kernels); there is no CPU fallback")
-        eng = self._eng()
-        if self.fc.in_features != 2048:
-            raise RuntimeError("fc.in_features must be 2048")
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _Fn.apply(x, self.fc.weight, self)
-        if not self.training:
-            from ..gradcam import hooked_eval_forward, hooks_registered
-            if hooks_registered(self):                     # Grad-CAM hook protocol of the reference (chexpert.py:271-272)
-                return hooked_eval_forward(self, x)
-        ws = eng.forward(x, self.training)
-        out = ws.logits.clone()
-        eng.release(ws)
-        return out
-
-    def forward_backward(self, x, target):
-        eng = self._eng()
-        ws = eng.forward(x, self.training)
-        B, n = ws.logits.shape
-        loss = torch.empty(1, dtype=torch.float32, device=x.device)
-        dl = torch.empty(B, n, dtype=torch.float32, device=x.device)
-        ops.bce_fwd_bwd(ws.logits, target, loss, None, dl)
-        eng.backward(ws, dl)
-        logits = ws.logits.clone()
-        eng.release(ws)
-        return loss, logits
+    def _stages(self):
+        return (self.layer1, self.layer2, self.layer3, self.layer4)
 
 
-class WideResNet(nn.Module):
+class WideResNet(_EngineNet):
     """Signature and parameters of /root/reference/models/attn_aug_conv.py:311-404 (WRN-d-k on CIFAR: 3x3 stem, three stages of
-    BasicBlocks, AAConv2d in stages 2-3).  CIFAR harness only (models/test_model.py): constructible, not on the HIP schedule."""
+    BasicBlocks, AAConv2d in stages 2-3).  The network of the CIFAR harness (models/test_model.py); the plain form runs on the
+    same HIP schedule as the BasicBlock ResNets (3x3 stem without max-pool), the attention-augmented form is constructible only."""
 
     def __init__(self, block, depth, width, num_classes=100, zero_init_residual=False, groups=1, width_per_group=64,
                  replace_stride_with_dilation=None, norm_layer=None, attn_params=None):
@@ -699,11 +837,13 @@ class WideResNet(nn.Module):
                 if isinstance(mod, BasicBlock):
                     nn.init.constant_(mod.bn2.weight, 0)
 
+        self._nbt_pending = 0
+        self._engine = None
+
     _make_layer = ResNet._make_layer
 
-    def forward(self, x):  # pragma: no cover - guard
-        raise NotImplementedError("WideResNet is the CIFAR harness network of models/test_model.py: constructible (parameter "
-                                  "counts, state_dict), not part of the MI355X schedule")
+    def _stages(self):
+        return (self.layer1, self.layer2, self.layer3)
 
 
 def resnet152(pretrained=False, **kwargs):

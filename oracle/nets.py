@@ -102,6 +102,39 @@ def resnet_spec(num_classes, layers=(3, 8, 36, 3), attn=None, input_hw=(320, 320
     return spec
 
 
+def basic_resnet_spec(num_classes, layers=(2, 2, 2, 2), wide=None):
+    """BasicBlock networks (attn_aug_conv.py:107-156).  wide=None: the ImageNet-shaped ResNet (:218-304, ResNet18 = (2,2,2,2));
+    wide=(depth, width): WideResNet-depth-width of the CIFAR harness (:311-404): 3x3 stem of 16 channels, three stages of
+    (depth-4)/6 blocks with 16w / 32w / 64w channels."""
+    spec = OrderedDict()
+    if wide is None:
+        spec["conv1.weight"] = (64, 3, 7, 7)
+        _bn_spec(spec, "bn1", 64)
+        inplanes, widths = 64, (64, 128, 256, 512)
+    else:
+        depth, width = wide
+        assert (depth - 4) % 6 == 0
+        layers = ((depth - 4) // 6,) * 3
+        spec["conv1.weight"] = (16, 3, 3, 3)
+        _bn_spec(spec, "bn1", 16)
+        inplanes, widths = 16, (16 * width, 32 * width, 64 * width)
+    for L, (planes, n) in enumerate(zip(widths, layers), 1):
+        for i in range(n):
+            p = "layer%d.%d" % (L, i)
+            s = 2 if (L > 1 and i == 0) else 1
+            spec[p + ".conv1.weight"] = (planes, inplanes, 3, 3)
+            _bn_spec(spec, p + ".bn1", planes)
+            spec[p + ".conv2.weight"] = (planes, planes, 3, 3)
+            _bn_spec(spec, p + ".bn2", planes)
+            if i == 0 and (s != 1 or inplanes != planes):
+                spec[p + ".downsample.0.weight"] = (planes, inplanes, 1, 1)
+                _bn_spec(spec, p + ".downsample.1", planes)
+            inplanes = planes
+    spec["fc.weight"] = (num_classes, inplanes)
+    spec["fc.bias"] = (num_classes,)
+    return spec
+
+
 EFFNET_SCALING = {  # width, depth, resolution, dropout  (efficientnet.py:13-21)
     "efficientnet-b0": (1.0, 1.0, 224, 0.2), "efficientnet-b1": (1.0, 1.1, 240, 0.2),
     "efficientnet-b2": (1.1, 1.2, 260, 0.3), "efficientnet-b3": (1.2, 1.4, 300, 0.3),
@@ -268,6 +301,30 @@ def resnet_forward(sd, x, layers=(3, 8, 36, 3), train=True, nh=None, taps=None, 
             x = q(F.relu(y + x))
     if taps is not None:
         taps["layer4"] = x
+    return F.linear(x.mean((2, 3)), sd["fc.weight"], sd["fc.bias"])
+
+
+def basic_resnet_forward(sd, x, layers=(2, 2, 2, 2), wide=None, train=True, q=None):
+    """BasicBlock ResNet / WideResNet forward (attn_aug_conv.py:135-156 block; :285-301 and :391-403 network)."""
+    q = q or (lambda t: t)
+    w = lambda k: q(sd[k])
+    if wide is None:
+        x = q(F.conv2d(q(x), w("conv1.weight"), stride=2, padding=3))
+        x = q(F.max_pool2d(F.relu(_bn(sd, "bn1", x, train)), 3, 2, 1))
+    else:
+        layers = ((wide[0] - 4) // 6,) * 3
+        x = q(F.conv2d(q(x), w("conv1.weight"), stride=1, padding=1))
+        x = q(F.relu(_bn(sd, "bn1", x, train)))
+    for L, n in enumerate(layers, 1):
+        for i in range(n):
+            p = "layer%d.%d" % (L, i)
+            s = 2 if (L > 1 and i == 0) else 1
+            y = q(F.conv2d(x, w(p + ".conv1.weight"), stride=s, padding=1))
+            y = q(F.relu(_bn(sd, p + ".bn1", y, train)))
+            y = _bn(sd, p + ".bn2", q(F.conv2d(y, w(p + ".conv2.weight"), padding=1)), train)
+            if p + ".downsample.0.weight" in sd:
+                x = _bn(sd, p + ".downsample.1", q(F.conv2d(x, w(p + ".downsample.0.weight"), stride=s)), train)
+            x = q(F.relu(y + x))
     return F.linear(x.mean((2, 3)), sd["fc.weight"], sd["fc.bias"])
 
 

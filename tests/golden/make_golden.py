@@ -183,7 +183,7 @@ def gen_aaconv(out_dir):
 
 
 def gen_nets(out_dir, which):
-    from models.attn_aug_conv import DenseNet, ResNet, Bottleneck
+    from models.attn_aug_conv import DenseNet, ResNet, Bottleneck, BasicBlock, WideResNet
     from models.efficientnet import construct_model
     from oracle import nets
     out = {}
@@ -221,6 +221,13 @@ def gen_nets(out_dir, which):
         "resnet_tiny_64_b2": lambda: (ResNet(Bottleneck, [1, 1, 1, 1], num_classes=n_cls),
                                       nets.resnet_spec(n_cls, layers=(1, 1, 1, 1)), 2, 64,
                                       lambda s, x, train: nets.resnet_forward(s, x, (1, 1, 1, 1), train=train)),
+        # BasicBlock networks of the CIFAR harness (models/test_model.py; attn_aug_conv.py:107-156, :311-404)
+        "resnet18_128_b4": lambda: (ResNet(BasicBlock, [2, 2, 2, 2], num_classes=n_cls),
+                                    nets.basic_resnet_spec(n_cls), 4, 128,
+                                    lambda s, x, train: nets.basic_resnet_forward(s, x, train=train)),
+        "wrn16_4_32_b8": lambda: (WideResNet(BasicBlock, 16, 4, num_classes=n_cls),
+                                  nets.basic_resnet_spec(n_cls, wide=(16, 4)), 8, 32,
+                                  lambda s, x, train: nets.basic_resnet_forward(s, x, wide=(16, 4), train=train)),
         "efficientnet-b0_224_b2": lambda: (construct_model("efficientnet-b0", n_cls),
                                            nets.efficientnet_spec("efficientnet-b0", n_cls), 2, 224,
                                            lambda s, x, train: nets.efficientnet_forward(s, x, "efficientnet-b0", train=train)),

@@ -35,6 +35,9 @@ NETS = {
     "resnet_tiny_64_b2": (lambda n: nets.resnet_spec(n, layers=(1, 1, 1, 1)),
                           lambda s, x, train: nets.resnet_forward(s, x, (1, 1, 1, 1), train=train)),
     "resnet152_320_b2": (lambda n: nets.resnet_spec(n), lambda s, x, train: nets.resnet_forward(s, x, train=train)),
+    "resnet18_128_b4": (lambda n: nets.basic_resnet_spec(n), lambda s, x, train: nets.basic_resnet_forward(s, x, train=train)),
+    "wrn16_4_32_b8": (lambda n: nets.basic_resnet_spec(n, wide=(16, 4)),
+                      lambda s, x, train: nets.basic_resnet_forward(s, x, wide=(16, 4), train=train)),
     "efficientnet-b0_224_b2": (lambda n: nets.efficientnet_spec("efficientnet-b0", n),
                                lambda s, x, train: nets.efficientnet_forward(s, x, "efficientnet-b0", train=train)),
     "efficientnet-b4_380_b2": (lambda n: nets.efficientnet_spec("efficientnet-b4", n),

@@ -265,3 +265,100 @@ def test_grad_cam_resnet_matches_reference_fixture(dev):
     err = (cam - cam_ref).abs().max().item()
     print("resnet grad-cam max abs err vs reference fixture: %.3e" % err)
     assert err < 4e-2                      # maps are normalised to [0,1]; bf16 feature storage
+
+
+def _basic_net(tag, n_cls, seed, dev, smooth):
+    from chexpert_amd.models import BasicBlock, ResNet, WideResNet
+    from oracle import nets
+    wide = (16, 4) if tag.startswith("wrn") else None
+    spec = nets.basic_resnet_spec(n_cls, wide=wide)
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(spec), seed)
+    if smooth:                                     # the well-conditioned regime of the tests above
+        for k in sd:
+            if k.endswith(".bias") and not k.startswith("fc"):
+                sd[k] = torch.full_like(sd[k], 1.0)
+            if k.endswith(".weight") and sd[k].dim() == 1:
+                sd[k] = synth.uniform(7, sd[k].shape, 0.8, 1.2)
+    model = WideResNet(BasicBlock, 16, 4, num_classes=n_cls) if wide else ResNet(BasicBlock, [2, 2, 2, 2], num_classes=n_cls)
+    assert list(model.state_dict().keys()) == list(spec.keys())
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev), sd, wide
+
+
+@pytest.mark.parametrize("tag", ["resnet18_128_b4", "wrn16_4_32_b8"])
+def test_basic_block_networks_match_reference_golden_fixture(dev, tag):
+    """The BasicBlock networks of the CIFAR harness (models/test_model.py; attn_aug_conv.py:107-156 block, :218-304 ResNet18,
+    :311-404 WideResNet-16-4) on the HIP schedule: eval / train logits and the loss against the fixture recorded from the real
+    reference (hash-filled weights: the storage-rounded fp32 oracle is the yardstick in train mode, as for resnet152 above)."""
+    from oracle import nets, step
+    rec = json.load(open(os.path.join(G, "nets.json")))[tag]
+    n_cls = rec["n_classes"]
+    model, sd, wide = _basic_net(tag, n_cls, rec["sd_seed"], dev, smooth=False)
+    assert sum(p.numel() for p in model.parameters()) == rec["n_params"]
+    x, t = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"]), synth.targets(rec["t_seed"], rec["B"], n_cls)
+    model.eval()
+    with torch.no_grad():
+        le = model(x.to(dev)).cpu()
+    e_eval = _rel(le, torch.tensor(rec["logits_eval"]))
+    model.train()
+    out = model(x.to(dev))
+    loss = torch.nn.BCEWithLogitsLoss(reduction="none")(out, t.to(dev)).sum(1).mean(0)
+    model.zero_grad()
+    loss.backward()
+    e_train = _rel(out.detach().cpu(), torch.tensor(rec["logits_train"]))
+    fwd_q = lambda s, xx: nets.basic_resnet_forward(s, xx, wide=wide, train=True, q=nets.bf16_storage)
+    loss_q, lq, _ = step.train_step(fwd_q, {k: v.clone() for k, v in sd.items()}, x, t)
+    e_q = _rel(lq, torch.tensor(rec["logits_train"]))
+    print("%s: eval logits rel %.3e, train logits rel %.3e (storage-rounded oracle %.3e), loss %.5f (reference %.5f, oracle_q %.5f)"
+          % (tag, e_eval, e_train, e_q, loss.item(), rec["loss"], float(loss_q)))
+    assert e_eval < 1e-2
+    assert e_train < max(2e-2, 2.0 * e_q)
+    assert abs(loss.item() - rec["loss"]) < max(1e-2, 2.0 * abs(float(loss_q) - rec["loss"]) / abs(rec["loss"])) * abs(rec["loss"])
+    gmax = max(r["l2"] for r in rec["grads"].values())
+    for k, p in model.named_parameters():          # every parameter receives a gradient of the reference's magnitude
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        if rec["grads"][k]["l2"] > 1e-3 * gmax:
+            assert 0.5 < p.grad.norm().item() / rec["grads"][k]["l2"] < 2.0, k
+
+
+@pytest.mark.parametrize("tag,B,S", [("resnet18", 8, 128), ("wrn16_4", 16, 32)])
+def test_basic_block_networks_smooth_regime_match_fp32_oracle(dev, tag, B, S):
+    """Same networks in the well-conditioned regime of test_resnet_smooth_regime_matches_fp32_oracle: every gradient and the
+    running statistics against the fp32 oracle, and a repeated step bit for bit (statistic rows + weight-gradient slabs)."""
+    from oracle import nets, step
+    n_cls = 5
+    model, sd, wide = _basic_net(tag, n_cls, 21, dev, smooth=True)
+    x, t = synth.xray_batch(1234, B, S), synth.targets(99, B, n_cls)
+    sd_o = {k: v.clone() for k, v in sd.items()}
+    fwd = lambda s, xx: nets.basic_resnet_forward(s, xx, wide=wide, train=True)
+    loss_o, logits_o, grads_o = step.train_step(fwd, sd_o, x, t)
+    model.train()
+    out = model(x.to(dev))
+    loss = torch.nn.BCEWithLogitsLoss(reduction="none")(out, t.to(dev)).sum(1).mean(0)
+    model.zero_grad()
+    loss.backward()
+    e = _rel(out.detach().cpu(), logits_o)
+    print("%s smooth: train logits rel %.3e" % (tag, e))
+    assert e < 2e-2
+    assert abs(loss.item() - loss_o.item()) < 1e-2 * abs(loss_o.item())
+    gmax = max(g.norm().item() for g in grads_o.values())
+    worst = []
+    for k, p in model.named_parameters():
+        if grads_o[k].norm().item() < 1e-4 * gmax:
+            continue
+        c, n = _cos(p.grad.cpu(), grads_o[k])
+        worst.append((c, n, k))
+    worst.sort()
+    print("%s worst (cos, norm ratio): %s" % (tag, worst[:4]))
+    is_norm = lambda k: ".bn" in k or "downsample.1" in k or k.startswith("bn1")
+    lim = lambda k: (0.93, 0.10) if is_norm(k) else (0.97, 0.05)
+    bad = [w for w in worst if w[0] < lim(w[2])[0] or abs(w[1] - 1) > lim(w[2])[1]]
+    assert not bad, "gradient mismatch (cos, norm-ratio, name): %s" % bad[:8]
+    sd_new = model.state_dict()
+    for k in ("bn1.running_mean", "layer2.0.downsample.1.running_var", "layer3.0.bn2.running_mean"):
+        assert _rel(sd_new[k].cpu(), sd_o[k]) < 1e-2, k
+    g1 = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    model.zero_grad()
+    out2 = model(x.to(dev))
+    torch.nn.BCEWithLogitsLoss(reduction="none")(out2, t.to(dev)).sum(1).mean(0).backward()
+    assert torch.equal(g1, torch.cat([p.grad.flatten() for p in model.parameters()]))
