@@ -1,0 +1,300 @@
+"""CIFAR harness of the reference (/root/reference/models/test_model.py) on the HIP-backed networks.
+
+Same command line (sub-command per architecture, :27-78), the same training loop (:107-131: forward, CrossEntropyLoss on the
+logits, zero_grad / backward / step / scheduler step per minibatch), evaluation with top-1 / top-5 accuracy (:97-101, :133-152),
+warm-up + cosine / staircase-exponential / multi-step learning-rate schedules (:176-199) and the two checkpoint files (:163-167).
+What runs on the GPU is the fused network (forward + backward through chexpert_amd.models) and the fused optimiser step; the loss
+on the (B, n_classes) logits, the schedule arithmetic and the data pipeline are host / torch plumbing, as in the reference.
+
+Data: the python-pickle CIFAR batches under --data_dir (`cifar-10-batches-py/` or `cifar-100-python/`) when they exist (there is
+no torchvision here), `--synthetic N` otherwise: N random normalised images with random labels -- enough to exercise the loop.
+
+Not on the HIP schedule (raise with the reason): `densenet` with the three-block CIFAR configuration (the DenseNet engine is the
+four-block ImageNet-shaped one) and the attention-augmented WideResNet (`--attn`); `--vis_attn` therefore has no runnable target.
+"""
+import argparse
+import json
+import math
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+MEAN = torch.tensor([125.3, 123.0, 113.9]) / 255            # test_model.py:225
+STD = torch.tensor([63.0, 62.1, 66.7]) / 255
+RESNET_LAYERS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+def _options(q, sub):
+    d = (lambda v: argparse.SUPPRESS) if sub else (lambda v: v)
+    q.add_argument("--attn", action="store_true", default=d(False))
+    q.add_argument("--attn_k", type=float, default=d(0.2))
+    q.add_argument("--attn_v", type=float, default=d(0.1))
+    q.add_argument("--attn_nh", type=int, default=d(8))
+    q.add_argument("--attn_relative", type=eval, default=d(True))
+    q.add_argument("--input_dims", default=d((32, 32)), type=int, nargs="+")
+    q.add_argument("--load_config", type=str, default=d(None))
+    q.add_argument("--train", action="store_true", default=d(False))
+    q.add_argument("--evaluate", action="store_true", default=d(False))
+    q.add_argument("--vis_attn", action="store_true", default=d(False))
+    q.add_argument("--seed", type=int, default=d(0))
+    q.add_argument("--cuda", type=int, default=d(0))
+    q.add_argument("--mini_data", action="store_true", default=d(False))
+    q.add_argument("--dataset", default=d("cifar100"), choices=["cifar10", "cifar100"])
+    q.add_argument("--data_dir", default=d("~/data/cifar100/"))
+    q.add_argument("--synthetic", type=int, default=d(0), help="use N random images instead of the CIFAR files")
+    q.add_argument("--output_dir", default=d(None))
+    q.add_argument("--restore", type=str, default=d(None))
+    q.add_argument("--batch_size", type=int, default=d(256))
+    q.add_argument("--n_epochs", type=int, default=d(1))
+    q.add_argument("--step", type=int, default=d(0))
+    q.add_argument("--log_interval", type=int, default=d(1))
+    q.add_argument("--eval_interval", type=int, default=d(10))
+    q.add_argument("--weight_decay", type=float, default=d(1e-5))
+    q.add_argument("--lr", type=float, default=d(0.016))
+    q.add_argument("--lr_warmup_epochs", type=int, default=d(5))
+    q.add_argument("--lr_cos_max_epochs", type=int, default=d(25))
+    q.add_argument("--lr_decay_factor", type=float, default=d(0.97))
+    q.add_argument("--lr_decay_epochs", type=float, default=d(2.4))
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    sub = p.add_subparsers(dest="model", help="Select model architecture.", required=True)
+    a = sub.add_parser("efficientnet")
+    a.add_argument("architecture", default="b0", choices=["b%d" % i for i in range(8)])
+    b = sub.add_parser("resnet")
+    b.add_argument("architecture", type=int, default=50, choices=[50, 101, 152])
+    c = sub.add_parser("wideresnet")
+    c.add_argument("architecture", type=int, default=[28, 10], nargs=2)
+    d = sub.add_parser("densenet")
+    d.add_argument("architecture", type=int, default=[12, 100], nargs=2)
+    _options(p, False)                           # where the reference defines them (:40-78): before the sub-command
+    for q in (a, b, c, d):                       # ... and accepted after it as well (set only when given)
+        _options(q, True)
+    return p
+
+
+# ------------------------------------------------------------------------------------------------------------------- data
+def load_cifar(dataset, data_dir, train):
+    """(N,3,32,32) uint8, (N,) int64 from the python-pickle batches (what torchvision.datasets.CIFAR10/100 unpack)."""
+    root = os.path.expanduser(data_dir)
+    if dataset == "cifar10":
+        files = ["data_batch_%d" % i for i in range(1, 6)] if train else ["test_batch"]
+        base, key = os.path.join(root, "cifar-10-batches-py"), "labels"
+    else:
+        files, base, key = (["train"] if train else ["test"]), os.path.join(root, "cifar-100-python"), "fine_labels"
+    xs, ys = [], []
+    for f in files:
+        with open(os.path.join(base, f), "rb") as fh:
+            d = pickle.load(fh, encoding="latin1")
+        xs.append(np.asarray(d["data"], dtype=np.uint8).reshape(-1, 3, 32, 32))
+        ys.extend(d[key])
+    return torch.from_numpy(np.concatenate(xs)), torch.tensor(ys, dtype=torch.int64)
+
+
+def synthetic_cifar(n, n_classes, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, (n, 3, 32, 32), generator=g, dtype=torch.uint8), torch.randint(0, n_classes, (n,), generator=g)
+
+
+def normalise(x_u8):
+    return (x_u8.float() / 255 - MEAN.view(1, 3, 1, 1)) / STD.view(1, 3, 1, 1)
+
+
+def augment(x_u8, gen):
+    """Pad(4, reflect) + RandomHorizontalFlip + RandomCrop(32) of test_model.py:226, per image, on uint8."""
+    B = x_u8.shape[0]
+    xp = torch.nn.functional.pad(x_u8.float(), (4, 4, 4, 4), mode="reflect")
+    flip = torch.rand(B, generator=gen) < 0.5
+    oy, ox = torch.randint(0, 9, (B,), generator=gen), torch.randint(0, 9, (B,), generator=gen)
+    out = torch.empty_like(x_u8, dtype=torch.float32)
+    for i in range(B):
+        img = xp[i, :, oy[i]:oy[i] + 32, ox[i]:ox[i] + 32]
+        out[i] = img.flip(2) if flip[i] else img
+    return out.to(torch.uint8)
+
+
+class Batches:
+    """DataLoader stand-in over in-memory tensors (shuffle / augmentation per epoch as test_model.py:233-236)."""
+
+    def __init__(self, x_u8, y, batch_size, shuffle, aug, seed):
+        self.x, self.y, self.bs, self.shuffle, self.aug = x_u8, y, batch_size, shuffle, aug
+        self.gen = torch.Generator().manual_seed(seed)
+        self.dataset = self.x
+
+    def __len__(self):
+        return (len(self.x) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        idx = torch.randperm(len(self.x), generator=self.gen) if self.shuffle else torch.arange(len(self.x))
+        for i in range(0, len(idx), self.bs):
+            j = idx[i:i + self.bs]
+            x = self.x[j]
+            yield normalise(augment(x, self.gen) if self.aug else x), self.y[j]
+
+
+# -------------------------------------------------------------------------------------------------------------- schedules
+def lr_at(args, step, n_batches):
+    """Learning rate after `step` scheduler steps: linear warm-up (test_model.py:188-199) into the model's schedule -- cosine
+    annealing (resnet / wideresnet, :263-264), staircase exponential decay (efficientnet, :256-257, :176-186) or
+    MultiStepLR[100, 150 epochs] (densenet, :281-282)."""
+    warm = args.lr_warmup_epochs * n_batches
+    if step < warm:
+        return args.lr * step / warm
+    if args.model in ("resnet", "wideresnet"):
+        # torch's CosineAnnealingLR is recursive (lr_t = lr_{t-1} * (1 + cos(pi t / T)) / (1 + cos(pi (t-1) / T))): wrapped behind
+        # the warm-up it continues from the LAST WARM-UP value lr * (warm - 1) / warm, not from the base rate
+        T = args.lr_cos_max_epochs * n_batches
+        cosf = lambda t: 0.5 * (1 + math.cos(math.pi * t / T))
+        scale = ((warm - 1) / warm) / cosf(warm - 1) if warm > 0 else 1.0
+        return args.lr * scale * cosf(step)
+    if args.model == "efficientnet":
+        # the reference's staircase multiplies the CURRENT lr by gamma**(t // decay_steps) at every step (:183-186), starting from
+        # the last warm-up value
+        ds = max(1.0, args.lr_decay_epochs * n_batches)
+        lr = args.lr * (warm - 1) / warm if warm > 0 else args.lr
+        for t in range(max(warm, 1), step + 1):
+            lr *= args.lr_decay_factor ** (t // ds)
+        return lr
+    return args.lr * 0.1 ** sum(step >= m * n_batches for m in (100, 150))
+
+
+@torch.no_grad()
+def accuracy(output, target, topk=(1, 5)):
+    """test_model.py:97-101."""
+    _, pred = output.topk(max(topk), dim=1, largest=True, sorted=True)
+    correct = pred.eq(target.view(-1, 1).expand(-1, pred.shape[1]))
+    return [correct[:, :k].float().sum(1).mean(0).item() for k in topk]
+
+
+# ------------------------------------------------------------------------------------------------------------------ model
+def build_model(args, n_classes):
+    from . import models, optim
+    attn = None if not args.attn else {"k": args.attn_k, "v": args.attn_v, "nh": args.attn_nh, "relative": args.attn_relative,
+                                       "input_dims": tuple(args.input_dims)}
+    if args.model == "efficientnet":
+        model = models.construct_model("efficientnet-" + args.architecture, n_classes=n_classes)
+        opt = optim.FusedRMSprop(model, lr=args.lr, momentum=0.9, eps=0.001)
+    elif args.model == "resnet":
+        model = models.ResNet(models.Bottleneck, RESNET_LAYERS[args.architecture], num_classes=n_classes, attn_params=attn)
+        opt = optim.FusedSGDNesterov(model, lr=args.lr, weight_decay=args.weight_decay, momentum=0.9, milestones=())
+    elif args.model == "wideresnet":
+        if attn is not None:
+            raise NotImplementedError("the attention-augmented WideResNet (AAConv2d as conv1 of a BasicBlock) is constructible "
+                                      "(chexpert_amd.models.WideResNet) but not on the HIP schedule")
+        model = models.WideResNet(models.BasicBlock, *args.architecture, num_classes=n_classes)
+        opt = optim.FusedSGDNesterov(model, lr=args.lr, weight_decay=args.weight_decay, momentum=0.9, milestones=())
+    else:
+        raise NotImplementedError("the three-block CIFAR DenseNet-BC of test_model.py:272-282 is not on the HIP schedule "
+                                  "(the DenseNet engine is the four-block network chexpert.py trains)")
+    return model, opt
+
+
+def train_epoch(model, loader, loss_fn, opt, epoch, args, log):
+    model.train()
+    n_batches = len(loader)
+    for x, y in loader:
+        args.step += 1
+        x, y = x.to(args.device), y.to(args.device)
+        outputs = model(x)
+        loss = loss_fn(outputs, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        opt.lr = lr_at(args, args.step, n_batches)           # scheduler.step() of test_model.py:123
+        if args.step % args.log_interval == 0:
+            log({"step": args.step, "epoch": epoch, "train_loss": loss.item(), "lr": opt.lr})
+
+
+@torch.no_grad()
+def evaluate(model, loader, loss_fn, args):
+    model.eval()
+    losses = top1s = top5s = 0.0
+    for x, y in loader:
+        x, y = x.to(args.device), y.to(args.device)
+        outputs = model(x)
+        top1, top5 = accuracy(outputs, y, topk=(1, 5))
+        losses += loss_fn(outputs, y).item() * x.shape[0]
+        top1s += top1 * x.shape[0]
+        top5s += top5 * x.shape[0]
+    n = len(loader.dataset)
+    return losses / n, top1s / n, top5s / n
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.load_config:
+        cfg = json.load(open(args.load_config))
+        cfg.pop("output_dir", None)
+        args.__dict__.update(cfg)
+        args.output_dir = os.path.dirname(args.load_config)
+    if not args.output_dir:
+        args.output_dir = os.path.dirname(args.restore) if args.restore else \
+            os.path.join("results", args.model, time.strftime("%Y-%m-%d_%H-%M-%S", time.gmtime()))
+    os.makedirs(args.output_dir, exist_ok=True)
+    if not os.path.exists(os.path.join(args.output_dir, "config.json")):
+        json.dump({k: v for k, v in args.__dict__.items()}, open(os.path.join(args.output_dir, "config.json"), "w"), indent=4)
+    if not torch.cuda.is_available():
+        raise RuntimeError("chexpert_amd runs on the GPU only (hand-written HIP kernels); there is no CPU fallback")
+    args.device = torch.device("cuda:%d" % args.cuda)
+    torch.manual_seed(args.seed)
+    n_classes = 10 if args.dataset == "cifar10" else 100
+
+    if args.synthetic:
+        xtr, ytr = synthetic_cifar(args.synthetic, n_classes, args.seed)
+        xva, yva = xtr, ytr
+    else:
+        xtr, ytr = load_cifar(args.dataset, args.data_dir, True)
+        xva, yva = load_cifar(args.dataset, args.data_dir, False)
+    if args.mini_data:                             # test_model.py:227-232: one batch, no augmentation, also the validation set
+        xtr, ytr = xtr[:args.batch_size], ytr[:args.batch_size]
+        xva, yva = xtr, ytr
+    aug = not (args.mini_data or args.synthetic)
+    train_loader = Batches(xtr, ytr, args.batch_size, shuffle=aug, aug=aug, seed=args.seed)
+    valid_loader = Batches(xva, yva, args.batch_size, shuffle=False, aug=False, seed=args.seed)
+
+    model, opt = build_model(args, n_classes)
+    model = model.to(args.device)
+    print("Loaded %s (number of parameters: %s)" % (args.model + "-" + str(args.architecture),
+                                                     "{:,}".format(sum(p.numel() for p in model.parameters()))))
+    if args.restore:
+        ck = torch.load(args.restore, map_location=args.device)
+        model.load_state_dict(ck["state_dict"])
+        args.step = ck["global_step"]
+        op = os.path.join(os.path.dirname(args.restore), "optim_" + os.path.basename(args.restore))
+        opt.load_state_dict(torch.load(op, map_location="cpu")["optimizer"])
+    opt.lr = lr_at(args, args.step, len(train_loader))
+    loss_fn = nn.CrossEntropyLoss().to(args.device)
+    logf = open(os.path.join(args.output_dir, "log.jsonl"), "a")
+
+    def log(rec):
+        logf.write(json.dumps(rec) + "\n")
+        logf.flush()
+
+    if args.train:
+        for epoch in range(args.n_epochs):
+            train_epoch(model, train_loader, loss_fn, opt, epoch, args, log)
+            if (epoch + 1) % args.eval_interval == 0:
+                loss, top1, top5 = evaluate(model, valid_loader, loss_fn, args)
+                print("Evaluate @ step %d: loss %.4f; acc@1 %.4f; acc@5 %.4f" % (args.step, loss, top1, top5))
+                log({"step": args.step, "eval_loss": loss, "acc@top1": top1, "acc@top5": top5})
+                torch.save({"global_step": args.step, "state_dict": model.state_dict()}, os.path.join(args.output_dir, "checkpoint.pt"))
+                torch.save({"optimizer": opt.state_dict(), "scheduler": {"last_epoch": args.step}},
+                           os.path.join(args.output_dir, "optim_checkpoint.pt"))
+    if args.evaluate:
+        loss, top1, top5 = evaluate(model, valid_loader, loss_fn, args)
+        print("Evaluate @ step %d: loss %.4f; acc@1 %.4f; acc@5 %.4f" % (args.step, loss, top1, top5))
+        log({"step": args.step, "eval_loss": loss, "acc@top1": top1, "acc@top5": top5})
+    if args.vis_attn:
+        raise NotImplementedError("--vis_attn needs an attention-augmented CIFAR network, none of which is on the HIP schedule; "
+                                  "chexpert_amd.vis.vis_attn draws the maps of the attention-augmented DenseNet121 / ResNet152")
+    logf.close()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

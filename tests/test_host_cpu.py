@@ -238,8 +238,9 @@ def test_reference_parameter_counts_and_import_paths():
     assert set(SCALING_PARAMS) == {"efficientnet-b%d" % i for i in range(8)}
     assert sum(p.numel() for p in construct_model("efficientnet-b0", 5).parameters()) == 4013953
     import pytest
-    with pytest.raises(NotImplementedError):               # constructible, not on the MI355X schedule
-        ResNet(BasicBlock, [2, 2, 2, 2])._eng()
+    ResNet(BasicBlock, [2, 2, 2, 2])._eng()                # plain BasicBlocks are on the MI355X schedule ...
+    with pytest.raises(NotImplementedError):               # ... the attention-augmented ones constructible only
+        ResNet(BasicBlock, [2, 2, 2, 2], attn_params=attn(.25, .25, 8, (224, 224)))._eng()
     d = {"k": .2, "v": .1, "nh": 8, "relative": True, "input_dims": (320, 320)}
     DenseNet(32, (6, 12, 24, 16), 64, attn_params=d)
     assert d["input_dims"] == (320, 320)                   # the reference mutates the caller's dict; the drop-in works on a copy
@@ -310,3 +311,74 @@ def test_csv_dataset_u_ones_resize_center_crop(tmp_path):
     pd.DataFrame({"Path": [str(tmp_path / p) for _, p in rows[:2]]}).to_csv(str(csv), index=False)
     te = data.ChexpertCSV(str(csv), "test", resize=64)
     assert len(te) == 2 and te[0][1].tolist() == [0, 0, 0, 0, 0] and tuple(te[0][0].shape) == (1, 64, 64)
+
+
+def test_cifar_harness_host_logic(tmp_path):
+    """chexpert_amd.cifar (the reference's models/test_model.py): command line, learning-rate schedules against the torch
+    schedulers the reference wraps (:176-199), top-k accuracy (:97-101), augmentation shapes and the pickle reader."""
+    import math
+    import pickle
+    import numpy as np
+    from chexpert_amd import cifar
+    a = cifar.build_parser().parse_args(["--train", "--lr", "0.1", "wideresnet", "16", "4", "--batch_size", "32"])
+    assert (a.model, a.architecture, a.train, a.lr, a.batch_size, a.dataset) == ("wideresnet", [16, 4], True, 0.1, 32, "cifar100")
+    # warm-up + cosine against torch's CosineAnnealingLR wrapped the way test_model.py:188-199 wraps it
+    nb = 4
+    a.lr_warmup_epochs, a.lr_cos_max_epochs = 2, 5
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=a.lr)
+
+    class Sched(torch.optim.lr_scheduler.CosineAnnealingLR):
+        def __init__(self, warm, *args, **kw):
+            self.warm = warm
+            super().__init__(*args, **kw)
+
+        def get_lr(self):
+            if self.last_epoch < self.warm:
+                return [b * self.last_epoch / self.warm for b in self.base_lrs]
+            return super().get_lr()
+    sched = Sched(a.lr_warmup_epochs * nb, opt, T_max=a.lr_cos_max_epochs * nb)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(1, 19):                     # warm-up, then torch's recursive cosine continuing from the last warm-up value
+            opt.step()
+            sched.step()
+            assert abs(opt.param_groups[0]["lr"] - cifar.lr_at(a, step, nb)) < 1e-9, step
+    a.model, a.lr_decay_epochs, a.lr_decay_factor = "efficientnet", 1.0, 0.5
+
+    class Stair(torch.optim.lr_scheduler.ExponentialLR):          # the staircase subclass of test_model.py:176-186 behind the warm-up
+        def __init__(self, warm, optimizer, gamma, decay_steps):
+            self.warm, self.decay_steps = warm, decay_steps
+            super().__init__(optimizer, gamma)
+
+        def get_lr(self):
+            if self.last_epoch < self.warm:
+                return [b * self.last_epoch / self.warm for b in self.base_lrs]
+            if self.last_epoch == 0:
+                return self.base_lrs
+            return [g["lr"] * self.gamma ** (self.last_epoch // self.decay_steps) for g in self.optimizer.param_groups]
+    opt = torch.optim.SGD([p], lr=a.lr)
+    sched = Stair(a.lr_warmup_epochs * nb, opt, a.lr_decay_factor, a.lr_decay_epochs * nb)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(1, 13):
+            opt.step()
+            sched.step()
+            assert abs(opt.param_groups[0]["lr"] - cifar.lr_at(a, step, nb)) < 1e-12 * a.lr + 1e-15, step
+    out = torch.tensor([[0.1, 0.5, 0.2, 0.05, 0.05, 0.1, 0.0], [0.9, 0.0, 0.02, 0.03, 0.01, 0.04, 0.0]])
+    assert cifar.accuracy(out, torch.tensor([1, 6]), topk=(1, 5)) == [0.5, 0.5]
+    x, y = cifar.synthetic_cifar(6, 10, 3)
+    g = torch.Generator().manual_seed(1)
+    xa = cifar.augment(x, g)
+    assert xa.shape == x.shape and xa.dtype == torch.uint8
+    n = cifar.normalise(x)
+    assert n.shape == (6, 3, 32, 32) and abs(float(n[0, 0, 0, 0]) - (float(x[0, 0, 0, 0]) / 255 - 125.3 / 255) / (63.0 / 255)) < 1e-5
+    d = tmp_path / "cifar-10-batches-py"
+    d.mkdir()
+    for i in range(1, 6):
+        pickle.dump({"data": np.full((2, 3072), i, dtype=np.uint8), "labels": [i, 9 - i]}, open(d / ("data_batch_%d" % i), "wb"))
+    xs, ys = cifar.load_cifar("cifar10", str(tmp_path), True)
+    assert xs.shape == (10, 3, 32, 32) and ys.tolist() == [1, 8, 2, 7, 3, 6, 4, 5, 5, 4] and int(xs[4, 0, 0, 0]) == 3
+    lb = cifar.Batches(xs, ys, 4, shuffle=False, aug=False, seed=0)
+    assert len(lb) == 3 and [b[1].tolist() for b in lb][2] == [5, 4]
