@@ -83,6 +83,8 @@ SIGNATURES = {
     "cx_affine2_inplace": [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_affine2_relu": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_relu_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
+    "cx_affine2_relu_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_relu_bwd_stats_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
     "cx_adam_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp],
     "cx_sgd_nesterov_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _f, _vp],
     "cx_rmsprop_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp],
@@ -139,7 +141,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cx_error_string" else C.c_int
-        if l.cx_abi_version() != 4:
+        if l.cx_abi_version() != 5:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l
     return _lib

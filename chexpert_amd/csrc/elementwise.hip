@@ -706,9 +706,11 @@ __global__ void affine2_inplace_kernel(bf16* __restrict__ dz, const bf16* __rest
 }
 
 // residual join: out = relu(a*pa + b*pb + pc)
+// mask (optional): one bit per element, byte idx = chunk of 8 channels, bit j = out[8 idx + j] > 0 -- what the backward of the join
+// needs of `out` (relu_bwd_stats_kernel), at 1/16 of its bytes
 __global__ void affine2_relu_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const float* __restrict__ pa,
-                                    const float* __restrict__ pb, const float* __restrict__ pc, bf16* __restrict__ out, size_t rows,
-                                    int C) {
+                                    const float* __restrict__ pb, const float* __restrict__ pc, bf16* __restrict__ out,
+                                    uint8_t* __restrict__ mask, size_t rows, int C) {
   const int CP = C / 8;
   const size_t total = rows * CP;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -722,6 +724,12 @@ __global__ void affine2_relu_kernel(const bf16* __restrict__ a, const bf16* __re
       o.e[j] = f2bf(fmaxf(fmaf(bf2f(u.e[j]), pa[c], fmaf(bf2f(v.e[j]), pb[c], pc[c])), 0.f));
     }
     *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
+    if (mask) {
+      unsigned m = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m |= (bf2f(o.e[j]) > 0.f ? 1u : 0u) << j;
+      mask[idx] = (uint8_t)m;
+    }
   }
 }
 
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
                                                              const float* __restrict__ r_a, const bf16* __restrict__ b,
                                                              const float* __restrict__ mu_b, const float* __restrict__ r_b,
                                                              bf16* __restrict__ dz, float* S1, float* S2a, float* S2b, size_t rows,
-                                                             int C, int det) {
+                                                             int C, int det, const uint8_t* __restrict__ mask) {
   extern __shared__ float lds[];          // [3][C] (atomic mode) / [256][24] (deterministic rows)
   const int CP = C / 8;
   if (!det) {
@@ -755,12 +763,15 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
   for (; idx < total; idx += stride) {
     U128 g, o, av, bv, d;
     g.u = *reinterpret_cast<const uint4*>(dout + idx * 8);
-    o.u = *reinterpret_cast<const uint4*>(out + idx * 8);
+    unsigned mk = 0;
+    if (mask) mk = mask[idx];                 // the forward's sign bits instead of the 16-B read of `out`
+    else o.u = *reinterpret_cast<const uint4*>(out + idx * 8);
     av.u = *reinterpret_cast<const uint4*>(a + idx * 8);
     if (b) bv.u = *reinterpret_cast<const uint4*>(b + idx * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float dzv = bf2f(o.e[j]) > 0.f ? bf2f(g.e[j]) : 0.f;
+      const bool on = mask ? ((mk >> j) & 1u) != 0 : bf2f(o.e[j]) > 0.f;
+      const float dzv = on ? bf2f(g.e[j]) : 0.f;
       s1[j] += dzv;
       s2[j] += dzv * (bf2f(av.e[j]) - ma[j]) * ra_[j];
       if (b) s3[j] += dzv * (bf2f(bv.e[j]) - mb[j]) * rb_[j];
@@ -1346,18 +1357,29 @@ int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb
   return launch_status();
 }
 
-int cx_affine2_relu(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows, int C,
-                    void* stream) {
+int cx_affine2_relu_mask(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, uint8_t* mask,
+                         size_t rows, int C, void* stream) {
   if (!a || !b || !pa || !pb || !pc || !out || C % 8) return CX_EINVAL;
   hipLaunchKernelGGL(affine2_relu_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)a,
-                     (const bf16*)b, pa, pb, pc, (bf16*)out, rows, C);
+                     (const bf16*)b, pa, pb, pc, (bf16*)out, mask, rows, C);
   return launch_status();
+}
+
+int cx_affine2_relu(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows, int C,
+                    void* stream) {
+  return cx_affine2_relu_mask(a, b, pa, pb, pc, out, nullptr, rows, C, stream);
 }
 
 int cx_relu_bwd_stats(const void* dout, const void* out, const void* a, const float* mu_a, const float* r_a, const void* b,
                       const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b, size_t rows, int C,
                       int stat_rows, void* stream) {
-  if (!dout || !out || !a || !mu_a || !r_a || !dz || !S1 || !S2a) return CX_EINVAL;
+  return cx_relu_bwd_stats_mask(dout, out, nullptr, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b, rows, C, stat_rows, stream);
+}
+
+int cx_relu_bwd_stats_mask(const void* dout, const void* out, const uint8_t* mask, const void* a, const float* mu_a, const float* r_a,
+                           const void* b, const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b, size_t rows,
+                           int C, int stat_rows, void* stream) {
+  if (!dout || (!out && !mask) || !a || !mu_a || !r_a || !dz || !S1 || !S2a) return CX_EINVAL;
   if (b && (!mu_b || !r_b || !S2b)) return CX_EINVAL;
   if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8)) return CX_ESHAPE;
   if (C / 8 > 256) return CX_ESHAPE;
@@ -1366,7 +1388,7 @@ int cx_relu_bwd_stats(const void* dout, const void* out, const void* a, const fl
   const size_t lds_bytes = (stat_rows > 0 ? (size_t)256 * 24 : (size_t)3 * C) * sizeof(float);
   hipLaunchKernelGGL(relu_bwd_stats_kernel, dim3(grid), dim3(256), lds_bytes,
                      as_stream(stream), (const bf16*)dout, (const bf16*)out, (const bf16*)a, mu_a, r_a, (const bf16*)b, mu_b, r_b,
-                     (bf16*)dz, S1, S2a, S2b, rows, C, stat_rows > 0 ? 1 : 0);
+                     (bf16*)dz, S1, S2a, S2b, rows, C, stat_rows > 0 ? 1 : 0, mask);
   return launch_status();
 }
 

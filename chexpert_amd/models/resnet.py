@@ -275,6 +275,7 @@ class _Engine:
             else:
                 t = dict(hin=(h, w), hout=(ho, wo), y1=e(B, h, w, p_), y2=e(B, ho, wo, p_), y3=e(B, ho, wo, 4 * p_),
                          yd=e(B, ho, wo, 4 * p_) if b.downsample is not None else None, out=e(B, ho, wo, 4 * p_))
+            t["mask"] = e(t["out"].numel() // 8, dtype=torch.uint8)          # sign bits of the join output for its backward
             if isinstance(b.conv2, AAConv2d):
                 aa = b.conv2
                 if (ho, wo) != tuple(aa.input_dims):
@@ -365,6 +366,7 @@ class _Engine:
             s_, p_ = b.stride, b.conv1.out_channels
             hi, wi = t["hin"]
             ho, wo = t["hout"]
+            mk = t["mask"] if train else None
             if self.basic:
                 # attn_aug_conv.py:135-156: conv3x3(stride) - bn1 - relu - conv3x3 - bn2, + identity | downsample(x), relu
                 S1, S2 = self.bn[id(b.bn1)], self.bn[id(b.bn2)]
@@ -379,9 +381,9 @@ class _Engine:
                     rows = ops.conv_gemm(xin, self.w_fwd(b.downsample[0]), t["yd"], N=p_, stride=s_, **sp(Sd))
                     self._bn_coef(ws, b.downsample[1], B * ho * wo, train, rows)
                     torch.add(v(ws, S2.sh), v(ws, Sd.sh), out=jc)
-                    ops.affine2_relu(t["y2"], t["yd"], v(ws, S2.sc), v(ws, Sd.sc), jc, t["out"])
+                    ops.affine2_relu(t["y2"], t["yd"], v(ws, S2.sc), v(ws, Sd.sc), jc, t["out"], mk)
                 else:
-                    ops.affine2_relu(t["y2"], xin, v(ws, S2.sc), v(ws, self.ones, p_), v(ws, S2.sh), t["out"])
+                    ops.affine2_relu(t["y2"], xin, v(ws, S2.sc), v(ws, self.ones, p_), v(ws, S2.sh), t["out"], mk)
                 xin = t["out"]
                 continue
             S1, S2, S3 = self.bn[id(b.bn1)], self.bn[id(b.bn2)], self.bn[id(b.bn3)]
@@ -413,9 +415,9 @@ class _Engine:
                 rows = ops.conv_gemm(xin, self.w_fwd(b.downsample[0]), t["yd"], N=4 * p_, stride=s_, **sp(Sd))
                 self._bn_coef(ws, b.downsample[1], B * ho * wo, train, rows)
                 torch.add(v(ws, S3.sh), v(ws, Sd.sh), out=jc)
-                ops.affine2_relu(t["y3"], t["yd"], v(ws, S3.sc), v(ws, Sd.sc), jc, t["out"])
+                ops.affine2_relu(t["y3"], t["yd"], v(ws, S3.sc), v(ws, Sd.sc), jc, t["out"], mk)
             else:
-                ops.affine2_relu(t["y3"], xin, v(ws, S3.sc), v(ws, self.ones, 4 * p_), v(ws, S3.sh), t["out"])
+                ops.affine2_relu(t["y3"], xin, v(ws, S3.sc), v(ws, self.ones, 4 * p_), v(ws, S3.sh), t["out"], mk)
             xin = t["out"]
         ops.head_fwd(xin, v(ws, self.ones), v(ws, self.zeros), m.fc.weight, m.fc.bias, ws.pooled, ws.logits)
         if train:
@@ -508,11 +510,12 @@ class _Engine:
             if det:
                 rows = ops.relu_bwd_stats(g, t["out"], t["y3"], v(ws, S3.mean), v(ws, S3.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
                                           v(ws, Sd.rstd) if Sd else None, g, ws.slab[0], ws.slab[1], ws.slab[2] if Sd else None,
-                                          stat_rows=ew(S3.C))
+                                          stat_rows=ew(S3.C), mask=t["mask"])
             else:
                 rows = None
                 ops.relu_bwd_stats(g, t["out"], t["y3"], v(ws, S3.mean), v(ws, S3.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
-                                   v(ws, Sd.rstd) if Sd else None, g, v(ws, S3.S1), v(ws, S3.S2), v(ws, Sd.S2) if Sd else None)
+                                   v(ws, Sd.rstd) if Sd else None, g, v(ws, S3.S1), v(ws, S3.S2), v(ws, Sd.S2) if Sd else None,
+                                   mask=t["mask"])
             r3 = srows(S3, rows)
             ops.bn_bwd_coef(r3[0], r3[1], cnt_o, b.bn3.weight, v(ws, S3.mean), v(ws, S3.rstd), G(b.bn3.weight),
                             G(b.bn3.bias), None, None, v(ws, S3.pa), v(ws, S3.pb), v(ws, S3.pc), S3.C, replicas=r3[2], rstride=r3[3])
@@ -633,11 +636,12 @@ class _Engine:
         if det:
             rows = ops.relu_bwd_stats(g, t["out"], t["y2"], v(ws, S2.mean), v(ws, S2.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
                                       v(ws, Sd.rstd) if Sd else None, g, ws.slab[0], ws.slab[1], ws.slab[2] if Sd else None,
-                                      stat_rows=ew(S2.C))
+                                      stat_rows=ew(S2.C), mask=t["mask"])
         else:
             rows = None
             ops.relu_bwd_stats(g, t["out"], t["y2"], v(ws, S2.mean), v(ws, S2.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
-                               v(ws, Sd.rstd) if Sd else None, g, v(ws, S2.S1), v(ws, S2.S2), v(ws, Sd.S2) if Sd else None)
+                               v(ws, Sd.rstd) if Sd else None, g, v(ws, S2.S1), v(ws, S2.S2), v(ws, Sd.S2) if Sd else None,
+                               mask=t["mask"])
         r2 = srows(S2, rows)
         ops.bn_bwd_coef(r2[0], r2[1], cnt, b.bn2.weight, v(ws, S2.mean), v(ws, S2.rstd), G(b.bn2.weight), G(b.bn2.bias), None, None,
                         v(ws, S2.pa), v(ws, S2.pb), v(ws, S2.pc), S2.C, replicas=r2[2], rstride=r2[3])

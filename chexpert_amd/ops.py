@@ -281,17 +281,21 @@ def affine2_inplace(dz, x, pa, pb, pc):
           "cx_affine2_inplace")
 
 
-def affine2_relu(a, b, pa, pb, pc, out):
+def affine2_relu(a, b, pa, pb, pc, out, mask=None):
+    """mask (optional, uint8 [rows * C / 8]): the sign bits of `out` for relu_bwd_stats (cx_affine2_relu_mask)."""
     B, H, W, Cc, ld = _nhwc(a)
     assert ld == Cc and _nhwc(b)[4] == Cc and _nhwc(out)[4] == Cc
-    check(lib().cx_affine2_relu(ptr(a), ptr(b), ptr(pa), ptr(pb), ptr(pc), ptr(out), B * H * W, Cc, stream_ptr()), "cx_affine2_relu")
+    assert mask is None or (mask.dtype == torch.uint8 and mask.numel() == B * H * W * Cc // 8)
+    check(lib().cx_affine2_relu_mask(ptr(a), ptr(b), ptr(pa), ptr(pb), ptr(pc), ptr(out), ptr(mask), B * H * W, Cc, stream_ptr()),
+          "cx_affine2_relu_mask")
 
 
-def relu_bwd_stats(dout, out, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b, stat_rows=0):
+def relu_bwd_stats(dout, out, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b, stat_rows=0, mask=None):
+    """mask (optional): sign bits written by affine2_relu, read instead of `out`."""
     B, H, W, Cc, ld = _nhwc(dout)
     assert ld == Cc
-    check(lib().cx_relu_bwd_stats(ptr(dout), ptr(out), ptr(a), ptr(mu_a), ptr(r_a), ptr(b), ptr(mu_b), ptr(r_b), ptr(dz), ptr(S1),
-                                  ptr(S2a), ptr(S2b), B * H * W, Cc, stat_rows, stream_ptr()), "cx_relu_bwd_stats")
+    check(lib().cx_relu_bwd_stats_mask(ptr(dout), ptr(out), ptr(mask), ptr(a), ptr(mu_a), ptr(r_a), ptr(b), ptr(mu_b), ptr(r_b), ptr(dz),
+                                       ptr(S1), ptr(S2a), ptr(S2b), B * H * W, Cc, stat_rows, stream_ptr()), "cx_relu_bwd_stats_mask")
     return lib().cx_last_stat_rows() if stat_rows else None
 
 

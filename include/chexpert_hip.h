@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 4
+#define CX_ABI_VERSION 5
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4, CX_ESTATROWS = -5 };
 
@@ -230,6 +230,14 @@ int cx_affine2_relu(const void* a, const void* b, const float* pa, const float* 
 int cx_relu_bwd_stats(const void* dout, const void* out, const void* a, const float* mu_a, const float* r_a, const void* b,
                       const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b, size_t rows, int C,
                       int stat_rows, void* stream);
+/* ABI 5: the same pair with the sign of `out` kept as one bit per element (mask: uint8 [rows * C / 8], byte i = the 8 channels
+ * of chunk i, bit j = out[8 i + j] > 0), written by the forward and read by the backward INSTEAD of `out` (a quarter of the
+ * backward's read bytes).  mask == NULL: the forms above.  `out` may be NULL in the backward when mask is given.            */
+int cx_affine2_relu_mask(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, uint8_t* mask,
+                         size_t rows, int C, void* stream);
+int cx_relu_bwd_stats_mask(const void* dout, const void* out, const uint8_t* mask, const void* a, const float* mu_a,
+                           const float* r_a, const void* b, const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a,
+                           float* S2b, size_t rows, int C, int stat_rows, void* stream);
 
 /* dz (B,H,W,C) bf16 -> dY = dz*pa + x*pb + pc in place (BN0 backward ahead of the stem wgrad)      */
 int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb, const float* pc, size_t rows,
