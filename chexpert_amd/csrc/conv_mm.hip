@@ -161,7 +161,10 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   const char* __restrict__ Wb = reinterpret_cast<const char*>(p.w);
   uint32_t woff[G::NB];
 #pragma unroll
-  for (int i = 0; i < G::NB; ++i) woff[i] = ((uint32_t)(n0 + r0 + G::RSTEP * i) * (uint32_t)p.K + qa * 8) * 2u;
+  for (int i = 0; i < G::NB; ++i) {          // N % 8 tiles: rows past N re-read row N - 1, their accumulator columns are never stored
+    const int nrow = n0 + r0 + G::RSTEP * i;
+    woff[i] = ((uint32_t)(nrow < p.N ? nrow : p.N - 1) * (uint32_t)p.K + qa * 8) * 2u;
+  }
   const uint32_t wtap = (uint32_t)p.N * (uint32_t)p.K * 2u;      // weight bytes per tap
 
   // Activations: two register sets (requests run two steps ahead of the multiplication).  Weights: one set, requested one step
@@ -386,7 +389,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   constexpr int NPASS = 64 / RPP;
   constexpr int NGRP = G::BM / 64;
   const int cq = tid % CPR, rr = tid / CPR;
-  const int nch = n0 + cq * 8;
+  const bool nok = n0 + cq * 8 < p.N;     // a partial last tile (N % 8 == 0): whole 8-channel vectors are in or out
+  const int nch = nok ? n0 + cq * 8 : 0;
   float* etile = reinterpret_cast<float*>(tiles);
   bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
   const bf16* __restrict__ EX = reinterpret_cast<const bf16*>(p.ex);
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + rr;
       const int m = mt * G::BM + g * 64 + row;
-      if (m < M) {
+      if (m < M && nok) {
         const float4 v0 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8 + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -510,7 +514,7 @@ template <int WMW, int WNW, int PRO, int EPI>
 int launch(const CxConv& p, const Cls& c, hipStream_t st) {
   using G = MG<WMW, WNW>;
   const int m_tiles = (c.Mq + G::BM - 1) / G::BM;
-  const int n_tiles = p.N / G::BN;
+  const int n_tiles = (p.N + G::BN - 1) / G::BN;
   const size_t smem = (size_t)NCoef<PRO>::v * ((p.K + BK - 1) / BK * BK) * 4 + G::MAIN_BYTES;
   if (smem > 160 * 1024) return CX_ESHAPE;
   static bool attr_set = false;
@@ -557,6 +561,12 @@ extern "C" void dbg_conv_mm_select(int on, int form) {
   g_mm_form = form;
 }
 
+// fewest k-steps per tile for which a shape with a partial last N tile is taken (CX_MM_MIN_STEPS)
+static int mm_min_steps() {
+  static const int v = [] { const char* e = getenv("CX_MM_MIN_STEPS"); return e ? atoi(e) : 14; }();
+  return v;
+}
+
 // Called by cx_conv_gemm after validation, once the specialised DenseNet kernels have declined.
 int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   *handled = false;
@@ -564,7 +574,7 @@ int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   static const int env_form0 = [] { const char* e = getenv("CX_MM_FORM"); return e ? atoi(e) : 0; }();
   const int env_on = g_mm_on >= 0 ? g_mm_on : env_on0;
   const int env_form = g_mm_form >= 0 ? g_mm_form : env_form0;
-  if (!env_on || p.mode != CX_MODE_CONV || p.tstride > 2 || (p.K % 8) || p.K < BK || (p.N % 128) || p.kh * p.kw > 32 || p.dtype != CX_DT_BF16) return 0;
+  if (!env_on || p.mode != CX_MODE_CONV || p.tstride > 2 || (p.K % 8) || p.K < BK || (p.N % 8) || p.kh * p.kw > 32 || p.dtype != CX_DT_BF16) return 0;
   const bool ok_combo = (p.epilogue == CX_EPI_STORE && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE_RELU || p.prologue == CX_PRO_AFFINE2)) ||
                         (p.epilogue == CX_EPI_MASK && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE2));
   if (!ok_combo) return 0;
@@ -577,9 +587,14 @@ int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   // one or two steps the generic kernel (32-channel steps, three workgroups per CU) is as fast.
   const int nsteps = (ts == 2 ? (p.kh * p.kw + 3) / 4 : p.kh * p.kw) * ((p.K + BK - 1) / BK);
   if (!env_form && ts == 1 && nsteps <= 2) return 0;
-  int form = (p.N % 256 == 0 && nsteps > 4) ? 3 : 1;
+  // Partial last tiles (N a multiple of 8, not of 128: EfficientNet widths, AAConv branches).  Measured on the EfficientNet-B4
+  // shapes (scratch/bench_mm_eff.py): with at least 14 k-steps per tile this kernel is 1.3-2x the generic one (K = 960 .. 2688
+  // projections and their gradients), with fewer the padded part of the tile costs more than the pipeline gains.
+  if (!env_form && (p.N % 128) && (nsteps < mm_min_steps() || p.N < 96)) return 0;
+  // partial last tiles (N % 8 == 0): the wider tile only where it does not add padding
+  const int pad1 = (p.N + 127) / 128 * 128, pad3 = (p.N + 255) / 256 * 256;
+  int form = (pad3 == pad1 && nsteps > 4) ? 3 : 1;
   if (env_form) form = env_form == 3 ? 3 : 1;
-  if (form == 3 && (p.N % 256)) form = 1;
   if (form == 3 && (size_t)NCoef<CX_PRO_AFFINE2>::v * ((p.K + BK - 1) / BK * BK) * 4 + MG<2, 4>::MAIN_BYTES > 160 * 1024) form = 1;
   const int bm = 128;
 

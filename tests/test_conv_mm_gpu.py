@@ -65,6 +65,11 @@ cv = lambda t: t.view(1, -1, 1, 1)
     (2, 10, 12, 120, 128, 3, 1, 1),      # K not a multiple of 64: the second channel step of every tap is partial (56 of 64)
     (3, 9, 9, 200, 256, 1, 1, 0),        # 3 full steps + 8 channels
     (2, 12, 12, 72, 256, 3, 2, 1),       # one chunk past the first step, strided
+    (2, 10, 12, 192, 24, 1, 1, 0),       # N % 8 tiles (EfficientNet projections): 24 of a 128-wide tile
+    (3, 9, 9, 144, 56, 1, 1, 1),
+    (2, 10, 10, 128, 328, 3, 1, 1),      # 2.56 tiles of 128 (AAConv query/key/value width)
+    (2, 8, 8, 256, 160, 1, 2, 0),        # one full tile + 32 channels, strided
+    (1, 12, 12, 384, 200, 1, 1, 1),
 ])
 def test_forward_against_torch(dev, select, form, B, H, W, K, N, ksz, stride, pro):
     from chexpert_amd import ops
@@ -106,6 +111,9 @@ def test_forward_against_torch(dev, select, form, B, H, W, K, N, ksz, stride, pr
     (2, 5, 6, 120, 128, 3, 2, False, 2),        # AAConv 3x3 branch gradient: K = planes - dv
     (4, 10, 10, 128, 256, 3, 1, True, 2),       # 128 x 256 tiles with the two-tensor operand
     (2, 8, 8, 192, 128, 1, 1, True, 0),         # plain operand, accumulate (AA projection gradient form)
+    (2, 9, 10, 192, 120, 1, 1, False, 2),       # N % 8 tiles: 120 of 128
+    (2, 6, 7, 128, 40, 3, 2, False, 2),         # ... through the parity classes
+    (2, 8, 8, 256, 328, 1, 1, True, 0),         # ... 2.56 tiles, accumulating
 ])
 def test_input_gradient_mask_epilogue_against_torch(dev, select, form, B, H, W, K, N, ksz, ts, acc, pro):
     from chexpert_amd import ops
