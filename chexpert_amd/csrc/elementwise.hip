@@ -1155,8 +1155,24 @@ int unpool2_mask_t(const void* d, const void* x, const float* sc, const float* s
 
 }  // namespace
 
+// Measurement hook (not part of the ABI): an event handed over by dbg_pre_reduce_event is recorded once, on the stream of the next
+// slab reduce, BEFORE that reduce is launched -- so a caller bracketing a weight-gradient entry point with events can time the
+// producing kernel alone (bench.py's roofline figure is per kernel, as rocprofv3 reports it).
+static thread_local hipEvent_t g_pre_reduce_event = nullptr;
+static thread_local int g_pre_reduce_taken = 0;
+extern "C" void dbg_pre_reduce_event(void* ev) {
+  g_pre_reduce_event = (hipEvent_t)ev;
+  g_pre_reduce_taken = 0;
+}
+extern "C" int dbg_pre_reduce_event_taken(void) { return g_pre_reduce_taken; }
+
 int cx_dw_reduce(float* dw, const float* slab, size_t total, int splits, hipStream_t st) {
   if (!dw || !slab || total == 0 || splits <= 0) return CX_EINVAL;
+  if (g_pre_reduce_event) {
+    (void)hipEventRecord(g_pre_reduce_event, st);
+    g_pre_reduce_event = nullptr;
+    g_pre_reduce_taken = 1;
+  }
   if ((total & 3) == 0 && aligned16(dw) && aligned16(slab)) {
     const size_t n4 = total / 4;
     hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, dw, slab, total, splits);
