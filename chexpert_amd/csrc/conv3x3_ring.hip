@@ -26,6 +26,7 @@ constexpr int RING_PX_MAX = (160 * 1024 - W_BYTES - 1024 - 256) / XP;     // 309
 
 struct RingGeo {
   int B, H, W, P, R, Q;         // P = W+2, Q = (R+2)*P ring pixels
+  int Wt, ntx;                  // forward: column tiles of Wt pixels (P = Wt+2, ntx per row; B counts tiles = images * ntx)
   int spi;                      // steps per image = ceil(H/R)
   int steps_per_wg;
 };
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   char* ring = wl + W_BYTES;                                   // [(Q+2)][272 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5;
-  const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
+  const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H, Wt = g.Wt, ntx = g.ntx;       // W: image width, Wt = P - 2: column-tile width
 
   // ---- one-time setup: weights [tap][n][k] -> LDS rows of 272 B, ring zeroed (pad columns stay zero), coefficients
   for (int i = tid; i < W_ROWS * 16; i += NT) {
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   const int total_steps = g.B * g.spi;
   const int u0 = blockIdx.x * g.steps_per_wg;
   const int u1 = min(total_steps, u0 + g.steps_per_wg);
-  const int chunks_per_row = W * 16;
+  const int chunks_per_row = P * 16;          // the two halo columns of a column tile are loaded (zeros outside the image)
 
   // DEPTH register sets of new rows: the rows of steps u+1 .. u+DEPTH are in flight while step u is multiplied (at W = 80 a
   // step is one image row and shorter than an HBM round trip under load)
@@ -92,14 +93,16 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   // drains the DEPTH row sets in flight each step
 #pragma unroll
   for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(csc[j]), "v"(csh[j]));
-  // rows [y0, y0+n) of image b -> registers; unconditional loads on clamped addresses, validity applied when staged
-  auto issue_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int b, int y0, int n) __attribute__((always_inline)) {
+  // rows [y0, y0+n) of column tile bv = image * ntx + tile -> registers (ring position p of a row is image column x0 - 1 + p);
+  // unconditional loads on clamped addresses, validity applied when staged
+  auto issue_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int bv, int y0, int n) __attribute__((always_inline)) {
+    const int b = bv / ntx, x0 = (bv - b * ntx) * Wt - 1;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int yy = y0 + crow[i];
-      pv[i] = crow[i] < n && yy >= 0 && yy < H;
-      const int yc_ = min(max(yy, 0), H - 1);
-      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + cpx[i]) * ldx + cc8 * 8);
+      const int yy = y0 + crow[i], xx = x0 + cpx[i];
+      pv[i] = crow[i] < n && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const int yc_ = min(max(yy, 0), H - 1), xc_ = min(max(xx, 0), W - 1);
+      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + xc_) * ldx + cc8 * 8);
     }
   };
   auto write_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int y0, int n) __attribute__((always_inline)) {
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), csc[j], csh[j]), 0.f));
         { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
-        const int pos = slot * P + cpx[i] + 1;
+        const int pos = slot * P + cpx[i];
         *reinterpret_cast<uint4*>(ring + (size_t)pos * XP + cc8 * 16) = o.u;
         if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * XP + cc8 * 16) = o.u;   // mirror of pixels 0,1
       }
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
     constexpr int k = decltype(KI)::value;
     uint4 (&cur)[NCH] = pre[k];
     bool (&cv)[NCH] = pv[k];
-    const int b = u / g.spi, yc = (u - b * g.spi) * R;
+    const int bv = u / g.spi, yc = (u - bv * g.spi) * R;
+    const int b = bv / ntx, x0 = (bv - b * ntx) * Wt;
     write_rows(cur, cv, yc + 1, R);
     __syncthreads();                                   // the window of this step is complete
     issue_step(cur, cv, u + DEPTH);                    // in flight under the MFMAs of this and the next DEPTH-1 steps
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
       }
       const int oy = m / P, ox = m - oy * P;
       const int yy = yc + oy;
-      const bool valid = m < R * P && ox < W && yy < H;
-      bf16* yrow = y + ((size_t)(b * H + (valid ? yy : 0)) * W + (valid ? ox : 0)) * ldy;
+      const bool valid = m < R * P && ox < Wt && x0 + ox < W && yy < H;
+      bf16* yrow = y + ((size_t)(b * H + (valid ? yy : 0)) * W + (valid ? x0 + ox : 0)) * ldy;
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         // registers 8cc..8cc+3 / 8cc+4..8cc+7: channels 16cc + 4*lh + e / 16cc + 8 + 4*lh + e; the swap of the upper half of
@@ -778,15 +782,21 @@ int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   if (p.K != 128 || p.N != 32 || p.prologue != CX_PRO_AFFINE_RELU || p.epilogue != CX_EPI_STORE || p.accumulate) return 0;
   if (p.W < 4) return 0;
   RingGeo g;
-  g.B = p.B; g.H = p.H; g.W = p.W; g.P = p.W + 2;
+  // Wide maps as two column tiles: an 80-pixel row is 2.5 sub-tiles for 8 waves and one row is all the ring holds, so a step was
+  // 3 busy waves and ~3.6 us of fixed latency (290 us per launch at bs = 256); halves of 40 columns take 5 rows per step (7
+  // sub-tiles) for one extra halo column per row.
+  static const int tile_on = [] { const char* e = getenv("CX_RING_TILE"); return e ? atoi(e) : 1; }();
+  g.ntx = (tile_on && p.W >= 64 && p.W % 2 == 0) ? 2 : 1;
+  g.Wt = p.W / g.ntx;
+  g.B = p.B * g.ntx; g.H = p.H; g.W = p.W; g.P = g.Wt + 2;
   int rmax = (RING_PX_MAX - 2) / g.P - 2;
   if (rmax < 1) return 0;
   if (rmax > p.H) rmax = p.H;
   g.spi = (p.H + rmax - 1) / rmax;
   g.R = (p.H + g.spi - 1) / g.spi;                   // balanced steps
   // at most 7 chunks of new rows per thread
-  while (g.R > 1 && g.R * p.W * 16 > 7 * NT) --g.R;
-  if (g.R * p.W * 16 > 7 * NT) return 0;
+  while (g.R > 1 && g.R * g.P * 16 > 7 * NT) --g.R;
+  if (g.R * g.P * 16 > 7 * NT) return 0;
   g.spi = (p.H + g.R - 1) / g.R;
   g.Q = (g.R + 2) * g.P;
   const int total = g.B * g.spi;
@@ -795,7 +805,7 @@ int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   if (g.B >= 256) spw = ((g.B + 255) / 256) * g.spi;
   if (spw < 1) spw = 1;
   g.steps_per_wg = spw;
-  const int need = (g.R * p.W * 16 + NT - 1) / NT;
+  const int need = (g.R * g.P * 16 + NT - 1) / NT;
   *handled = true;
   if (need <= 3) return launch_ring<3, 3>(p, st, g);      // short steps (one 80-pixel row): three row groups in flight
   if (need <= 5) return launch_ring<5, 2>(p, st, g);
