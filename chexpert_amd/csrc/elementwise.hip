@@ -426,15 +426,23 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const T* __rest
     int bi[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { best[j] = -1.f; bi[j] = 0; }
+    // all nine window loads go out first on clamped addresses (a branch around a load serialises them); taps outside the image
+    // are masked when compared
+    typename V8<T>::raw wv[9];
+    bool wok[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int iy = 2 * oy - 1 + t / 3, ix = 2 * ox - 1 + t % 3;
-      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const typename V8<T>::raw v = V8<T>::ld(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
+      wok[t] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+      wv[t] = V8<T>::ld(x + ((size_t)(b * H + iyc) * W + ixc) * C + cq * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float a = fmaxf(fmaf(V8<T>::get(v, j), fsc[j], fsh[j]), 0.f);
-        if (a > best[j]) { best[j] = a; bi[j] = t; }
+        const float a = fmaxf(fmaf(V8<T>::get(wv[t], j), fsc[j], fsh[j]), 0.f);
+        if (wok[t] && a > best[j]) { best[j] = a; bi[j] = t; }
       }
     }
     uint8_t idx[8];
