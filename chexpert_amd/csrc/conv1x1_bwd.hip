@@ -811,7 +811,7 @@ int launch_bwd_bc(const CxConv& p, float* dw, float* scratch, long long scratch_
 template <int PRO, bool ACC>
 int launch_bwd(const CxConv& p, float* dw, float* scratch, long long scratch_floats, hipStream_t st) {
   static const int force = []() { const char* e = getenv("CX_PW_BWD_BC"); return e ? atoi(e) : 0; }();
-  const bool wide = force ? force == 128 : p.N >= 128;  // measured crossover
+  const bool wide = force ? force == 128 : p.N >= 64;   // measured crossover (round 2: the v2 kernel also wins on the 64- and 96-channel layers)
   static const int v1 = []() { const char* e = getenv("CX_PW_BWD_V1"); return e ? atoi(e) : 0; }();   // diagnostic: the round-1 kernel
   if (wide && !v1) return launch_bwd2<PRO, ACC>(p, dw, scratch, scratch_floats, st);
   return wide ? launch_bwd_bc<PRO, ACC, 128>(p, dw, scratch, scratch_floats, st)

@@ -538,7 +538,8 @@ def test_wgrad_stem_affine2_odd_pixel_count(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("pro,acc,B,H,W,N", [(2, True, 2, 9, 10, 96), (0, False, 1, 5, 5, 8), (2, True, 8, 127, 129, 264),
                                               (0, False, 2, 20, 20, 128), (2, False, 3, 13, 7, 136), (0, True, 4, 40, 40, 512),
-                                              (2, True, 1, 3, 3, 160)])
+                                              (2, True, 1, 3, 3, 160), (2, True, 3, 11, 12, 64), (2, False, 2, 10, 10, 72),
+                                              (0, True, 2, 8, 9, 56)])
 def test_fused_1x1_dgrad_wgrad_equals_separate_kernels(dev, pro, acc, B, H, W, N):
     """cx_conv1x1_dgrad_wgrad = input gradient with the mask epilogue (cx_conv_gemm) + weight gradient with the BN-ReLU input
     prologue (cx_conv_wgrad) of the bottleneck 1x1 convolution, against a torch reference of both."""
