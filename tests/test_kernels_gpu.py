@@ -96,7 +96,9 @@ def test_conv1x1_persistent_many_tiles(dev, pro, K):
                                                     # strip kernel geometries: W=80 (R=1, ranges crossing images), W=40 (R=2, odd H),
                                                     # W=20 (R=4), W=10 (R=8 > H remainder)
                                                     (3, 10, 80, 128, 32, 1, 1), (2, 9, 40, 128, 32, 1, 1), (5, 20, 20, 128, 32, 1, 1),
-                                                    (7, 10, 10, 128, 32, 1, 1)])
+                                                    (7, 10, 10, 128, 32, 1, 1),
+                                                    # wide maps as two column tiles (W >= 64, even): halo columns between the tiles
+                                                    (2, 13, 64, 128, 32, 1, 1), (1, 6, 96, 128, 32, 1, 1), (300, 2, 66, 128, 32, 1, 1)])
 def test_conv3x3_slice_output(dev, B, H, W, K, N, stride, pro):
     from chexpert_amd import ops
     xb, x = nhwc_buf(5, B, H, W, K, dev)
