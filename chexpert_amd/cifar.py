@@ -9,8 +9,10 @@ on the (B, n_classes) logits, the schedule arithmetic and the data pipeline are 
 Data: the python-pickle CIFAR batches under --data_dir (`cifar-10-batches-py/` or `cifar-100-python/`) when they exist (there is
 no torchvision here), `--synthetic N` otherwise: N random normalised images with random labels -- enough to exercise the loop.
 
-Not on the HIP schedule (raise with the reason): `densenet` with the three-block CIFAR configuration (the DenseNet engine is the
-four-block ImageNet-shaped one) and the attention-augmented WideResNet (`--attn`); `--vis_attn` therefore has no runnable target.
+The attention-augmented WideResNet (`--attn`: AAConv2d as conv1 of the BasicBlocks of stages 2-3, test_model.py:265-269) runs on the
+HIP attention kernels where they cover the head sizes (dk/nh = 20, dv/nh in {1,2,3,4,6}: e.g. WRN-16-4, WRN-28-4 at 8 heads), and
+`--vis_attn` draws its attention maps (:201-234).  Not on the HIP schedule (raises with the reason): `densenet` with the three-block
+CIFAR configuration (the DenseNet engine is the four-block ImageNet-shaped one).
 """
 import argparse
 import json
@@ -171,6 +173,33 @@ def accuracy(output, target, topk=(1, 5)):
     return [correct[:, :k].float().sum(1).mean(0).item() for k in topk]
 
 
+def vis_attn(x, layers, args, batch_element=0):
+    """test_model.py:201-234: per attention layer a grid -- the image with the probed pixel marked (the corners of the centre third),
+    below it one row per head with that pixel's attention map (AAConv2d.weights, rebuilt from the stored q/k and log-sum-exp)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    pix = lambda h, w: [(h // 3, w // 3), (h // 3, int(2 * w / 3)), (int(2 * h / 3), w // 3), (int(2 * h / 3), int(2 * w / 3))]
+    for j, layer in enumerate(layers):
+        nh = layer.nh
+        fig, axs = plt.subplots(nh + 1, 4, figsize=(3, 3 / 4 * (1 + nh)), frameon=False)
+        for ax, (ph, pw) in zip(axs[0], pix(*x.shape[2:])):
+            image = x.clone()
+            image[:, :, ph, pw] = torch.tensor([1.0, 215 / 255, 0.0])
+            ax.imshow(image[batch_element].permute(1, 2, 0).numpy())
+            ax.axis("off")
+        attn = layer.weights.detach()[batch_element].float().cpu()
+        side = int(np.sqrt(attn.shape[-1]))
+        attn = attn.reshape(nh, side, side, side, side)
+        for i, (ph, pw) in enumerate(pix(side, side)):
+            for h in range(nh):
+                axs[h + 1, i].imshow(attn[h, ph, pw].numpy())
+                axs[h + 1, i].axis("off")
+        fig.subplots_adjust(0, 0, 1, 1, 0.05, 0.05)
+        plt.savefig(os.path.join(args.output_dir, "vis_attn_image_%d_layer_%d.png" % (batch_element, j)))
+        plt.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------ model
 def build_model(args, n_classes):
     from . import models, optim
@@ -183,10 +212,7 @@ def build_model(args, n_classes):
         model = models.ResNet(models.Bottleneck, RESNET_LAYERS[args.architecture], num_classes=n_classes, attn_params=attn)
         opt = optim.FusedSGDNesterov(model, lr=args.lr, weight_decay=args.weight_decay, momentum=0.9, milestones=())
     elif args.model == "wideresnet":
-        if attn is not None:
-            raise NotImplementedError("the attention-augmented WideResNet (AAConv2d as conv1 of a BasicBlock) is constructible "
-                                      "(chexpert_amd.models.WideResNet) but not on the HIP schedule")
-        model = models.WideResNet(models.BasicBlock, *args.architecture, num_classes=n_classes)
+        model = models.WideResNet(models.BasicBlock, *args.architecture, num_classes=n_classes, attn_params=attn)
         opt = optim.FusedSGDNesterov(model, lr=args.lr, weight_decay=args.weight_decay, momentum=0.9, milestones=())
     else:
         raise NotImplementedError("the three-block CIFAR DenseNet-BC of test_model.py:272-282 is not on the HIP schedule "
@@ -290,8 +316,17 @@ def main(argv=None):
         print("Evaluate @ step %d: loss %.4f; acc@1 %.4f; acc@5 %.4f" % (args.step, loss, top1, top5))
         log({"step": args.step, "eval_loss": loss, "acc@top1": top1, "acc@top5": top5})
     if args.vis_attn:
-        raise NotImplementedError("--vis_attn needs an attention-augmented CIFAR network, none of which is on the HIP schedule; "
-                                  "chexpert_amd.vis.vis_attn draws the maps of the attention-augmented DenseNet121 / ResNet152")
+        assert args.attn, "Enable --attn flag to visualize attention."
+        if args.model != "wideresnet":
+            raise RuntimeError("Model not supported.")                  # test_model.py:347-352 (the CIFAR DenseNet is not runnable here)
+        x = next(iter(valid_loader))[0][:8]
+        model.eval()
+        with torch.no_grad():
+            model(x.to(args.device))                                     # stores the attention operands of every AAConv2d
+        layers = [blk.conv1 for blk in model.layer2] + [blk.conv1 for blk in model.layer3]
+        images = (x * STD.view(1, 3, 1, 1) + MEAN.view(1, 3, 1, 1)).clamp(0, 1)
+        for i in range(len(x)):
+            vis_attn(images, layers, args, i)
     logf.close()
     return 0
 

@@ -124,9 +124,6 @@ class _Engine:
                 self.blocks.append(blk)
         self.basic = model.block is BasicBlock                 # two 3x3 convolutions per block (attn_aug_conv.py:107-156)
         self.cifar = isinstance(model, WideResNet)              # 3x3 stride-1 stem, no max-pool, three stages (:311-404)
-        if any(isinstance(b.conv1, AAConv2d) for b in self.blocks):
-            raise NotImplementedError("attention-augmented BasicBlocks (AAConv2d as conv1) are constructible but not on the HIP "
-                                      "schedule; the attention-augmented Bottleneck networks are")
         # vector plan: [fwd-zero region | bwd-zero region | rest]
         nfz = sum(2 * bn.num_features for bn in self._all_bns()) + 64
         nbz = nfz
@@ -147,6 +144,11 @@ class _Engine:
         self.ones, self.zeros = self.rest.take(cmax), self.rest.take(cmax)
         self.scratch = [self.rest.take(cmax) for _ in range(2)]
         self.vec_size = self.rest.n
+
+    @staticmethod
+    def _cin(b):
+        c1 = b.conv1
+        return c1.in_proj_qkv.in_channels if isinstance(c1, AAConv2d) else c1.in_channels
 
     @staticmethod
     def _last_bn(b):
@@ -267,7 +269,7 @@ class _Engine:
             ws.pool0 = e(B, h, w, 64)
         ws.blk = []
         for b in self.blocks:
-            p_, s_ = b.conv1.out_channels, b.stride
+            p_, s_ = b.bn1.num_features, b.stride
             ho, wo = h // s_, w // s_
             if self.basic:                          # y1 = conv1 output (3x3, stride s), y2 = conv2 output, both on the block's output grid
                 t = dict(hin=(h, w), hout=(ho, wo), y1=e(B, ho, wo, p_), y2=e(B, ho, wo, p_),
@@ -276,8 +278,8 @@ class _Engine:
                 t = dict(hin=(h, w), hout=(ho, wo), y1=e(B, h, w, p_), y2=e(B, ho, wo, p_), y3=e(B, ho, wo, 4 * p_),
                          yd=e(B, ho, wo, 4 * p_) if b.downsample is not None else None, out=e(B, ho, wo, 4 * p_))
             t["mask"] = e(t["out"].numel() // 8, dtype=torch.uint8)          # sign bits of the join output for its backward
-            if isinstance(b.conv2, AAConv2d):
-                aa = b.conv2
+            aa = b.conv1 if self.basic else b.conv2         # the AAConv2d position: conv1 of a BasicBlock, conv2 of a Bottleneck
+            if isinstance(aa, AAConv2d):
                 if (ho, wo) != tuple(aa.input_dims):
                     raise RuntimeError("AAConv2d was built for %s feature maps, the input gives %s (relative tables are "
                                        "size-bound, attn_aug_conv.py:38-41)" % (tuple(aa.input_dims), (ho, wo)))
@@ -363,14 +365,26 @@ class _Engine:
         xin = ws.pool0
         for bi, b in enumerate(self.blocks):
             t = ws.blk[bi]
-            s_, p_ = b.stride, b.conv1.out_channels
+            s_, p_ = b.stride, b.bn1.num_features
             hi, wi = t["hin"]
             ho, wo = t["hout"]
             mk = t["mask"] if train else None
             if self.basic:
                 # attn_aug_conv.py:135-156: conv3x3(stride) - bn1 - relu - conv3x3 - bn2, + identity | downsample(x), relu
                 S1, S2 = self.bn[id(b.bn1)], self.bn[id(b.bn2)]
-                rows = ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, kh=3, kw=3, stride=s_, pad=1, **sp(S1))
+                if isinstance(b.conv1, AAConv2d):
+                    # attn_aug_conv.py:124-131, :65-97: the first 3x3 is attention-augmented (conv branch || attention, on the raw input)
+                    aa, sub = b.conv1, (lambda slot, lo, n: None if slot is None else slot[lo:lo + n])
+                    cc = p_ - aa.dv
+                    ops.conv_gemm(xin, self.w_fwd(aa.conv), t["y1"][..., :cc], N=cc, kh=3, kw=3, stride=s_, pad=1,
+                                  stat_sum=sub(st(S1.sum), 0, cc), stat_sq=sub(st(S1.sq), 0, cc))
+                    ops.conv_gemm(xin, self.w_fwd(aa.in_proj_qkv), t["QKV"], N=2 * aa.dk + aa.dv, stride=s_)
+                    ops.aa_attention_fwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], t["LSE"], aa.nh, aa.dk, aa.dv)
+                    object.__setattr__(aa, "_last", (t["QKV"], t["LSE"]))
+                    ops.aa_outproj_fwd(t["O"], aa.out_proj.weight, t["y1"][..., cc:], sub(st(S1.sum), cc, aa.dv), sub(st(S1.sq), cc, aa.dv))
+                    rows = None
+                else:
+                    rows = ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, kh=3, kw=3, stride=s_, pad=1, **sp(S1))
                 self._bn_coef(ws, b.bn1, B * ho * wo, train, rows)
                 rows = ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=1, pad=1,
                                      prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh), **sp(S2))
@@ -494,10 +508,10 @@ class _Engine:
                             v(ws, self.scratch[1], Cl))
         for bi in range(len(self.blocks) - 1, -1, -1):
             b, t = self.blocks[bi], ws.blk[bi]
-            s_, p_ = b.stride, b.conv1.out_channels
+            s_, p_ = b.stride, b.bn1.num_features
             hi, wi = t["hin"]
             ho, wo = t["hout"]
-            cin = b.conv1.in_channels
+            cin = self._cin(b)
             xin = ws.blk[bi - 1]["out"] if bi > 0 else ws.pool0
             if self.basic:
                 self._basic_backward(ws, bi, b, t, xin, msp, srows, ew, done)
@@ -626,7 +640,7 @@ class _Engine:
         """Backward of one BasicBlock (attn_aug_conv.py:135-156), same conventions as the bottleneck path: the block's output
         gradient is masked in place by the join ReLU, BatchNorm backward rides in the two-tensor prologues of the consumers."""
         v, G, bw, B, det = self._v, self.G, ws.bwd, ws.B, self.det
-        s_, p_, cin = b.stride, b.conv1.out_channels, b.conv1.in_channels
+        s_, p_, cin = b.stride, b.bn1.num_features, self._cin(b)
         ho, wo = t["hout"]
         S1, S2 = self.bn[id(b.bn1)], self.bn[id(b.bn2)]
         Sd = self.bn[id(b.downsample[1])] if b.downsample is not None else None
@@ -663,17 +677,36 @@ class _Engine:
         identity = Sd is None
         if identity and gx is not g:
             gx.copy_(g)
-        ops.conv_gemm(dz1, self.w_bwd(b.conv1), gx, N=cin, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["y1"],
-                      pa=v(ws, S1.pa), pb=v(ws, S1.pb), pc=v(ws, S1.pc), accumulate=identity)
-        ops.conv_wgrad(dz1, xin, G(b.conv1.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=t["y1"],
-                       ga=v(ws, S1.pa), gb=v(ws, S1.pb), gc=v(ws, S1.pc))
+        if isinstance(b.conv1, AAConv2d):
+            aa = b.conv1
+            cc = p_ - aa.dv
+            qa, qb, qc = v(ws, S1.pa), v(ws, S1.pb), v(ws, S1.pc)              # BN1 backward as dY1 = dz1*pa + y1*pb + pc
+            gs_c, ys_c, gs_a, ys_a = dz1[..., :cc], t["y1"][..., :cc], dz1[..., cc:], t["y1"][..., cc:]
+            dO = bw["dO"][:t["O"].numel()].view(t["O"].shape)
+            dQ32 = bw["dQKV32"][:t["QKV"].numel()].view(t["QKV"].shape)
+            dQ = bw["dQKV"][:t["QKV"].numel()].view(t["QKV"].shape)
+            ops.aa_outproj_bwd(gs_a, ys_a, qa[cc:], qb[cc:], qc[cc:], t["O"], aa.out_proj.weight, dO, G(aa.out_proj.weight))
+            ops.aa_attention_bwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], dO, t["LSE"], dQ32, G(aa.key_rel_h), G(aa.key_rel_w),
+                                 aa.nh, aa.dk, aa.dv)
+            ops.f32_to_bf16(dQ32, dQ)
+            ops.conv_gemm(gs_c, self.w_bwd(aa.conv), gx, N=cin, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=ys_c,
+                          pa=qa[:cc], pb=qb[:cc], pc=qc[:cc], accumulate=identity)
+            ops.conv_gemm(dQ, self.w_bwd(aa.in_proj_qkv), gx, N=cin, tstride=s_, accumulate=True)
+            ops.conv_wgrad(gs_c, xin, G(aa.conv.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=ys_c, ga=qa[:cc],
+                           gb=qb[:cc], gc=qc[:cc])
+            ops.conv_wgrad(dQ, xin, G(aa.in_proj_qkv.weight), stride=s_)
+        else:
+            ops.conv_gemm(dz1, self.w_bwd(b.conv1), gx, N=cin, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["y1"],
+                          pa=v(ws, S1.pa), pb=v(ws, S1.pb), pc=v(ws, S1.pc), accumulate=identity)
+            ops.conv_wgrad(dz1, xin, G(b.conv1.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=t["y1"],
+                           ga=v(ws, S1.pa), gb=v(ws, S1.pb), gc=v(ws, S1.pc))
         if Sd is not None:
             convd = b.downsample[0]
             ops.conv_gemm(g, self.w_bwd(convd), gx, N=cin, tstride=s_, prologue=ops.PRO_AFFINE2, x2=t["yd"], pa=v(ws, Sd.pa),
                           pb=v(ws, Sd.pb), pc=v(ws, Sd.pc), accumulate=True)
             ops.conv_wgrad(g, xin, G(convd.weight), stride=s_, g_prologue=ops.PRO_AFFINE2, g2=t["yd"], ga=v(ws, Sd.pa), gb=v(ws, Sd.pb),
                            gc=v(ws, Sd.pc))
-        done(b.conv1.weight)
+        done(b.conv1.weight if not isinstance(b.conv1, AAConv2d) else b.conv1.key_rel_h)
 
     def enable_data_parallel(self, bucket_bytes=16 << 20, group=None):
         from ..parallel import GradReducer

@@ -102,10 +102,11 @@ def resnet_spec(num_classes, layers=(3, 8, 36, 3), attn=None, input_hw=(320, 320
     return spec
 
 
-def basic_resnet_spec(num_classes, layers=(2, 2, 2, 2), wide=None):
+def basic_resnet_spec(num_classes, layers=(2, 2, 2, 2), wide=None, attn=None, input_hw=(320, 320)):
     """BasicBlock networks (attn_aug_conv.py:107-156).  wide=None: the ImageNet-shaped ResNet (:218-304, ResNet18 = (2,2,2,2));
     wide=(depth, width): WideResNet-depth-width of the CIFAR harness (:311-404): 3x3 stem of 16 channels, three stages of
-    (depth-4)/6 blocks with 16w / 32w / 64w channels."""
+    (depth-4)/6 blocks with 16w / 32w / 64w channels.  `attn` puts AAConv2d in conv1 of the blocks from stage 2 on (:124-131; the
+    WideResNet scales input_dims by its width first, :322-324)."""
     spec = OrderedDict()
     if wide is None:
         spec["conv1.weight"] = (64, 3, 7, 7)
@@ -122,7 +123,13 @@ def basic_resnet_spec(num_classes, layers=(2, 2, 2, 2), wide=None):
         for i in range(n):
             p = "layer%d.%d" % (L, i)
             s = 2 if (L > 1 and i == 0) else 1
-            spec[p + ".conv1.weight"] = (planes, inplanes, 3, 3)
+            if attn is not None and L >= 2:
+                dk, dv = aa_dims(planes, attn["k"], attn["v"], attn["nh"])
+                hw = input_hw if wide is None else (input_hw[0] * wide[1], input_hw[1] * wide[1])
+                dims = (int(hw[0] * 16 / planes), int(hw[1] * 16 / planes))
+                _aa_spec(spec, p + ".conv1", inplanes, planes, 3, dk, dv, attn["nh"], dims)
+            else:
+                spec[p + ".conv1.weight"] = (planes, inplanes, 3, 3)
             _bn_spec(spec, p + ".bn1", planes)
             spec[p + ".conv2.weight"] = (planes, planes, 3, 3)
             _bn_spec(spec, p + ".bn2", planes)
@@ -304,7 +311,7 @@ def resnet_forward(sd, x, layers=(3, 8, 36, 3), train=True, nh=None, taps=None, 
     return F.linear(x.mean((2, 3)), sd["fc.weight"], sd["fc.bias"])
 
 
-def basic_resnet_forward(sd, x, layers=(2, 2, 2, 2), wide=None, train=True, q=None):
+def basic_resnet_forward(sd, x, layers=(2, 2, 2, 2), wide=None, train=True, q=None, nh=None):
     """BasicBlock ResNet / WideResNet forward (attn_aug_conv.py:135-156 block; :285-301 and :391-403 network)."""
     q = q or (lambda t: t)
     w = lambda k: q(sd[k])
@@ -319,7 +326,10 @@ def basic_resnet_forward(sd, x, layers=(2, 2, 2, 2), wide=None, train=True, q=No
         for i in range(n):
             p = "layer%d.%d" % (L, i)
             s = 2 if (L > 1 and i == 0) else 1
-            y = q(F.conv2d(x, w(p + ".conv1.weight"), stride=s, padding=1))
+            if p + ".conv1.weight" in sd:
+                y = q(F.conv2d(x, w(p + ".conv1.weight"), stride=s, padding=1))
+            else:
+                y = _aa(sd, p + ".conv1", x, s, nh)
             y = q(F.relu(_bn(sd, p + ".bn1", y, train)))
             y = _bn(sd, p + ".bn2", q(F.conv2d(y, w(p + ".conv2.weight"), padding=1)), train)
             if p + ".downsample.0.weight" in sd:

@@ -228,6 +228,13 @@ def gen_nets(out_dir, which):
         "wrn16_4_32_b8": lambda: (WideResNet(BasicBlock, 16, 4, num_classes=n_cls),
                                   nets.basic_resnet_spec(n_cls, wide=(16, 4)), 8, 32,
                                   lambda s, x, train: nets.basic_resnet_forward(s, x, wide=(16, 4), train=train)),
+        # ... and their attention-augmented forms (AAConv2d as conv1 of the BasicBlocks from stage 2 on; the harness's --attn)
+        "aawrn16_4_32_b8": lambda: (WideResNet(BasicBlock, 16, 4, num_classes=n_cls, attn_params=ref_attn((32, 32))),
+                                    nets.basic_resnet_spec(n_cls, wide=(16, 4), attn=attn, input_hw=(32, 32)), 8, 32,
+                                    lambda s, x, train: nets.basic_resnet_forward(s, x, wide=(16, 4), train=train, nh=8)),
+        "aaresnet18_128_b4": lambda: (ResNet(BasicBlock, [2, 2, 2, 2], num_classes=n_cls, attn_params=ref_attn((128, 128))),
+                                      nets.basic_resnet_spec(n_cls, attn=attn, input_hw=(128, 128)), 4, 128,
+                                      lambda s, x, train: nets.basic_resnet_forward(s, x, train=train, nh=8)),
         "efficientnet-b0_224_b2": lambda: (construct_model("efficientnet-b0", n_cls),
                                            nets.efficientnet_spec("efficientnet-b0", n_cls), 2, 224,
                                            lambda s, x, train: nets.efficientnet_forward(s, x, "efficientnet-b0", train=train)),

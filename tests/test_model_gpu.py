@@ -442,3 +442,10 @@ def test_cifar_harness_trains_evaluates_and_restores(dev, tmp_path):
         assert np.isfinite(r["train_loss"])
     with pytest.raises(NotImplementedError):
         cifar.main(["--train", "--synthetic", "16", "--output_dir", str(tmp_path / "d"), "densenet", "12", "100"])
+    # the harness's attention-augmented WideResNet: one step, then the attention maps of its four AAConv2d layers (--vis_attn)
+    o3 = str(tmp_path / "aawrn")
+    assert cifar.main(["--train", "--vis_attn", "--attn", "--dataset", "cifar10", "--synthetic", "16", "--mini_data", "--batch_size", "16",
+                       "--output_dir", o3, "wideresnet", "16", "4"]) == 0
+    assert np.isfinite(js.loads(open(os.path.join(o3, "log.jsonl")).readline())["train_loss"])
+    pngs = [f for f in os.listdir(o3) if f.startswith("vis_attn_image_")]
+    assert len(pngs) == 8 * 4 and os.path.getsize(os.path.join(o3, "vis_attn_image_0_layer_0.png")) > 2000

@@ -38,6 +38,10 @@ NETS = {
     "resnet18_128_b4": (lambda n: nets.basic_resnet_spec(n), lambda s, x, train: nets.basic_resnet_forward(s, x, train=train)),
     "wrn16_4_32_b8": (lambda n: nets.basic_resnet_spec(n, wide=(16, 4)),
                       lambda s, x, train: nets.basic_resnet_forward(s, x, wide=(16, 4), train=train)),
+    "aawrn16_4_32_b8": (lambda n: nets.basic_resnet_spec(n, wide=(16, 4), attn=dict(k=.2, v=.1, nh=8), input_hw=(32, 32)),
+                        lambda s, x, train: nets.basic_resnet_forward(s, x, wide=(16, 4), train=train, nh=8)),
+    "aaresnet18_128_b4": (lambda n: nets.basic_resnet_spec(n, attn=dict(k=.2, v=.1, nh=8), input_hw=(128, 128)),
+                          lambda s, x, train: nets.basic_resnet_forward(s, x, train=train, nh=8)),
     "efficientnet-b0_224_b2": (lambda n: nets.efficientnet_spec("efficientnet-b0", n),
                                lambda s, x, train: nets.efficientnet_forward(s, x, "efficientnet-b0", train=train)),
     "efficientnet-b4_380_b2": (lambda n: nets.efficientnet_spec("efficientnet-b4", n),
@@ -63,7 +67,10 @@ def test_network_against_reference_fixture(tag, nets_golden):
     torch.set_num_threads(8)
     with torch.no_grad():
         le = fwd({k: v.clone() for k, v in sd.items()}, x, train=False)
-    np.testing.assert_allclose(le.numpy(), np.array(rec["logits_eval"]), rtol=0, atol=2e-5)
+    # eval mode with hash-filled running statistics: the attention-augmented BasicBlock fixtures reach logits of 40-90 and the
+    # closed-form relative logits of the oracle round differently from the reference's rel_to_abs: tolerance relative to the abs-max
+    want_e = np.array(rec["logits_eval"])
+    np.testing.assert_allclose(le.numpy(), want_e, rtol=0, atol=2e-5 if not tag.startswith(("aawrn", "aaresnet18")) else 1e-4 * np.abs(want_e).max())
     loss, lt, grads = step.train_step(lambda s, xx: fwd(s, xx, train=True), sd, x, t)
     np.testing.assert_allclose(lt.numpy(), np.array(rec["logits_train"]), rtol=0, atol=2e-5)
     assert abs(float(loss) - rec["loss"]) < 2e-5
