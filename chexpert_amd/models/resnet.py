@@ -55,9 +55,8 @@ class Bottleneck(nn.Module):
 
 class BasicBlock(nn.Module):
     """Signature and parameters of /root/reference/models/attn_aug_conv.py:107-156 (two 3x3 convolutions; AAConv2d replaces
-    conv1 in layers 2-4).  The reference uses it in the CIFAR harness (models/test_model.py).  Plain BasicBlocks run on the
-    HIP schedule (conv3x3 raw + stats -> conv3x3 with bn1+ReLU in the prologue -> residual-join kernel); the
-    attention-augmented form is constructible (parameter counts, state_dict keys) only."""
+    conv1 in layers 2-4).  The reference uses it in the CIFAR harness (models/test_model.py).  On the HIP schedule: conv3x3 (or the
+    AAConv2d conv branch || attention) raw + stats -> conv3x3 with bn1+ReLU in the prologue -> residual-join kernel."""
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None,
@@ -840,8 +839,8 @@ class ResNet(_EngineNet):
 
 class WideResNet(_EngineNet):
     """Signature and parameters of /root/reference/models/attn_aug_conv.py:311-404 (WRN-d-k on CIFAR: 3x3 stem, three stages of
-    BasicBlocks, AAConv2d in stages 2-3).  The network of the CIFAR harness (models/test_model.py); the plain form runs on the
-    same HIP schedule as the BasicBlock ResNets (3x3 stem without max-pool), the attention-augmented form is constructible only."""
+    BasicBlocks, AAConv2d in stages 2-3).  The network of the CIFAR harness (models/test_model.py), on the same HIP schedule as the
+    BasicBlock ResNets (3x3 stem without max-pool); attention head sizes outside the kernels' set raise when the model is run."""
 
     def __init__(self, block, depth, width, num_classes=100, zero_init_residual=False, groups=1, width_per_group=64,
                  replace_stride_with_dilation=None, norm_layer=None, attn_params=None):
