@@ -11,8 +11,9 @@ Schedule per MBConv block (NHWC bf16):
   expand 1x1 (implicit GEMM, raw + stats) -> depthwise k x k with bn+Swish applied on load (raw + stats)
   -> SE: global pool of swish(bn(.)), two tiny FCs -> u = swish(bn(y_d)) * s[b][c] (one pass)
   -> project 1x1 (implicit GEMM) -> x_out = bn(y_p) (+ x_in).
-DropConnect / Dropout are stochastic regularisers tied to the framework RNG; they act as identity here
-(rate 0): the deterministic arithmetic is what the parity tests pin.
+DropConnect (efficientnet.py:44-51, :100-101) and the classifier Dropout (:169-171) are applied in train mode: per-image /
+per-element keep masks drawn on the GPU by `cx_dropout_mask` from (model.drop_seed, forward counter, block) -- reproducible and
+independent of torch's RNG; the parity tests feed the drawn masks (`engine.last_masks`) to the oracle.
 """
 import math
 from collections import OrderedDict
