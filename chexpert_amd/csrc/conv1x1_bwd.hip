@@ -741,11 +741,12 @@ int launch_bwd2(const CxConv& p, float* dw, float* scratch, long long scratch_fl
   const long long M = (long long)p.B * p.Ho * p.Wo;
   const int m_tiles = (int)((M + BM2 - 1) / BM2);
   const int c_tiles = (p.N + BC - 1) / BC;
-  // grid target: two workgroups per CU on the big maps (the second round's prologue hides under the first round's tail); one per
-  // CU up to 2^19 pixels, where a workgroup's fixed cost (34 KB weight tile, 64 KB of weight-gradient atomics) weighs against
-  // 6-25 tiles of work: 8-24 % less time on the 40x40 / 20x20 / 10x10 maps at bs = 256 (scratch/bench_pw.py)
+  // grid target: one workgroup per CU.  A workgroup's fixed cost (34 KB weight tile, 64 KB weight-gradient slab) weighs against
+  // 6-25 tiles of work on the 40x40 / 20x20 / 10x10 maps: 8-24 % less time than two per CU there (scratch/bench_pw.py); since the
+  // weight gradients leave as slabs (one per workgroup, summed by a second launch) it is also ahead on the 80x80 maps (+0.6 % of the
+  // DenseNet121 step; three per CU: -5 %)
   static const int wgs_env = []() { const char* e = getenv("CX_PW_BWD_WGS"); return e ? atoi(e) : 0; }();
-  const int wgs = wgs_env ? wgs_env : (M <= (1ll << 19) ? 256 : 512);
+  const int wgs = wgs_env ? wgs_env : 256;
   int splits = wgs / c_tiles;
   if (splits < 1) splits = 1;
   if (splits > m_tiles) splits = m_tiles;
