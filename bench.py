@@ -121,8 +121,8 @@ class KernelTimer:
             if x.dtype == torch.float32:
                 tag = "conv_f32_kernel<%d, %d, %d>" % (kw.get("prologue", 0), 0 if kw.get("mode", 0) == 2 else kw.get("mode", 0),
                                                        kw.get("epilogue", 0))
-            if kw.get("fused_dw") is not None:       # conv1x1_bwd.hip launch_bwd: 128-channel tiles for wide slices / big maps
-                wide = kw["N"] >= 128
+            if kw.get("fused_dw") is not None:       # conv1x1_bwd.hip launch_bwd: the v2 kernel (128-channel tiles) from 64 channels on
+                wide = kw["N"] >= 64
                 v1 = os.environ.get("CX_PW_BWD_V1", "0") not in ("", "0")
                 acc_s = "true" if kw.get("accumulate") else "false"
                 tag = ("pw_bwd2_kernel<%d, %s, 0>" % (kw.get("prologue", 0), acc_s)) if wide and not v1 else \
