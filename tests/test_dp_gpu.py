@@ -17,6 +17,13 @@ def _make(kind):
         model, head, S = DenseNet(32, (2, 2, 2, 2), 64, num_classes=5), "classifier", 64
     elif kind == "resnet":
         model, head, S = ResNet(Bottleneck, [1, 2, 2, 1], num_classes=5), "fc", 64
+    elif kind == "basic":                                # BasicBlock path of the same engine (_basic_backward)
+        from chexpert_amd.models import BasicBlock
+        model, head, S = ResNet(BasicBlock, [2, 1, 1, 1], num_classes=5), "fc", 64
+    elif kind == "aawrn":                                # attention-augmented WideResNet: 3x3 stem without max-pool, AAConv2d as conv1
+        from chexpert_amd.models import BasicBlock, WideResNet
+        model, head, S = WideResNet(BasicBlock, 10, 4, num_classes=5, attn_params={"k": .2, "v": .1, "nh": 8, "relative": True,
+                                                                                  "input_dims": (32, 32)}), "fc", 32
     else:
         from chexpert_amd.models.efficientnet import DropMarker
         model, head, S = construct_model("efficientnet-b0", 5), "head", 96
@@ -66,12 +73,12 @@ def _worker(rank, world, port, out_dir, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["densenet", "resnet", "efficientnet"])
+@pytest.mark.parametrize("kind", ["densenet", "resnet", "efficientnet", "basic", "aawrn"])
 def test_data_parallel_backward_two_ranks_one_gpu(tmp_path, kind):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 400) + {"densenet": 0, "resnet": 400, "efficientnet": 800}[kind]
+    port = 29500 + (os.getpid() % 400) + {"densenet": 0, "resnet": 400, "efficientnet": 800, "basic": 1200, "aawrn": 1600}[kind]
     mp.spawn(_worker, args=(2, port, str(tmp_path), kind), nprocs=2, join=True)
     for r in range(2):
         rec = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
