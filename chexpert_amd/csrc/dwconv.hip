@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict
 // da[p][c] = sum_t dY[(p + pad - t)/S][c] * w[c][t] over the taps whose source lands on the output grid; the tile walks the
 // INPUT map, the staged region is the part of dY it touches (OH x OW pixels from (oyb, oxb)), dY = bf16(g*ga + g2*gb + gc).
 template <int K, int S, int TH, int NCQ>
-__global__ __launch_bounds__(256) void dw_dgrad_tile_kernel(const bf16* __restrict__ gq, const bf16* __restrict__ g2,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dw_dgrad_tile_kernel(const bf16* __restrict__ gq, const bf16* __restrict__ g2,
                                                             const float* __restrict__ ga, const float* __restrict__ gb,
                                                             const float* __restrict__ gc, const float* __restrict__ w,
                                                             const bf16* __restrict__ x, const float* __restrict__ sc,
