@@ -1,5 +1,5 @@
 // Weight gradient of the wide 1x1 convolutions (ResNet bottlenecks): dW[n][c] += sum_px dZ[px][n] * A[px][c], stride 1,
-// N % 128 == 0 output channels, pixels a multiple of 64, NHWC bf16 operands, fp32 OIHW result.
+// N a multiple of 8 (partial last 128-channel tile) output channels, pixels a multiple of 64, NHWC bf16 operands, fp32 OIHW result.
 //
 // Same recipe as conv_mm.hip, which measured what bounds these kernels (vector-instruction issue with two waves per SIMD, not
 // MFMA or bandwidth): tiles of 128 x 256 (or 256 x 128, 128 x 128) outputs so that each operand element is transformed for 256
@@ -95,12 +95,15 @@ __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2,
   const bool xact = c0 + qx * 8 < p.K;
   const uint32_t xmask = xact ? 0xffffffffu : 0u;
   const int xc = xact ? c0 + qx * 8 : 0;
+  const bool gact = n0 + qg * 8 < p.N;            // partial last N tile (N % 8 == 0): chunks past N are staged as zeros
+  const uint32_t gmask = gact ? 0xffffffffu : 0u;
+  const int gn = gact ? n0 + qg * 8 : 0;
   float ga[8], gb[8], gc[8], pa[8], pb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    ga[j] = GPRO == CX_PRO_AFFINE2 ? p.ga[n0 + qg * 8 + j] : 1.f;
-    gb[j] = GPRO == CX_PRO_AFFINE2 ? p.gb[n0 + qg * 8 + j] : 0.f;
-    gc[j] = GPRO == CX_PRO_AFFINE2 ? p.gc[n0 + qg * 8 + j] : 0.f;
+    ga[j] = GPRO == CX_PRO_AFFINE2 ? p.ga[gn + j] : 1.f;
+    gb[j] = GPRO == CX_PRO_AFFINE2 ? p.gb[gn + j] : 0.f;
+    gc[j] = GPRO == CX_PRO_AFFINE2 ? p.gc[gn + j] : 0.f;
     pa[j] = XPRO == CX_PRO_AFFINE_RELU ? p.pa[xc + j] : 1.f;
     pb[j] = XPRO == CX_PRO_AFFINE_RELU ? p.pb[xc + j] : 0.f;
   }
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2,
   uint32_t goff[G::NG], goff2[G::NG], xoff[G::NX];
 #pragma unroll
   for (int i = 0; i < G::NG; ++i) {
-    goff[i] = ((uint32_t)(rg0 + G::RG * i) * (uint32_t)p.ldg + n0 + qg * 8) * 2u;
-    goff2[i] = ((uint32_t)(rg0 + G::RG * i) * (uint32_t)p.ldg2 + n0 + qg * 8) * 2u;
+    goff[i] = ((uint32_t)(rg0 + G::RG * i) * (uint32_t)p.ldg + gn) * 2u;
+    goff2[i] = ((uint32_t)(rg0 + G::RG * i) * (uint32_t)p.ldg2 + gn) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < G::NX; ++i) xoff[i] = ((uint32_t)(rx0 + G::RX * i) * (uint32_t)p.ldx + xc) * 2u;
@@ -152,7 +155,10 @@ __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2,
       o[j] = packbf(fmaf(bf_lo(g), ga[2 * j], fmaf(bf_lo(y), gb[2 * j], gc[2 * j])),
                     fmaf(bf_hi(g), ga[2 * j + 1], fmaf(bf_hi(y), gb[2 * j + 1], gc[2 * j + 1])));
     }
-    if (j == 3) *reinterpret_cast<u32x4*>(Gt + (rg0 + G::RG * i) * G::GP + qg * 16) = o;
+    if (j == 3) {
+      o &= gmask;
+      *reinterpret_cast<u32x4*>(Gt + (rg0 + G::RG * i) * G::GP + qg * 16) = o;
+    }
   };
   auto unit_x = [&](int i, int j, u32x4& o, char* Xt, bool reissue) __attribute__((always_inline)) {
     const uint32_t x = xreg[i][j];
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = n0 + (wa * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          dw_out(p.dw, slab, (size_t)p.N * p.K, split, (size_t)n * p.K + c, acc[i][j][r]);
+          if (n < p.N) dw_out(p.dw, slab, (size_t)p.N * p.K, split, (size_t)n * p.K + c, acc[i][j][r]);
         }
       }
     }
@@ -569,7 +575,7 @@ template <int WA, int WB, int GPRO, int XPRO>
 int launch(const CxWgrad& p, hipStream_t st, int wgs_target) {
   using G = WG<WA, WB>;
   const long long M = (long long)p.B * p.Ho * p.Wo;
-  const int c_tiles = (p.K + G::TC - 1) / G::TC, n_tiles = p.N / G::TN;
+  const int c_tiles = (p.K + G::TC - 1) / G::TC, n_tiles = (p.N + G::TN - 1) / G::TN;
   const int total_steps = (int)(M / PX);
   int splits = p.splits > 0 ? p.splits : wgs_target / (c_tiles * n_tiles);
   if (splits < 1) splits = 1;
@@ -638,7 +644,11 @@ int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
     return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_NONE>(p, st) : launch3<CX_PRO_NONE, CX_PRO_NONE>(p, st);
   }
   if (p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0) return 0;
-  if ((p.N % 128) || (p.K % 8) || p.K < 64) return 0;
+  if ((p.N % 8) || (p.K % 8) || p.K < 64) return 0;
+  // partial last N tile (dZ chunks past N staged as zeros): EfficientNet-B4 +1.4 % with every width taken (CX_WGRAD_MM_MIN_N = 24,
+  // 96, 256: +1.4 / +1.2 / +0.9 %; 0 = multiples of 128 only)
+  static const int min_n = [] { const char* e = getenv("CX_WGRAD_MM_MIN_N"); return e ? atoi(e) : 24; }();
+  if ((p.N % 128) && (min_n <= 0 || p.N < min_n)) return 0;
   const long long M = (long long)p.B * p.Ho * p.Wo;
   if (M % PX) return 0;
   const unsigned long long ldmax = (unsigned long long)(p.ldg > p.ldx ? p.ldg : p.ldx);
@@ -649,6 +659,7 @@ int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
   int form = 3;                   // measured on the ResNet152 shapes (scratch/bench_wmm.py): 128 x 256 wins at every K >= 64
   if (env_form) form = env_form;
   if (form == 2 && (p.N % 256)) form = 1;
+  if (form == 2 && (p.N % 128)) form = 3;
   *handled = true;
   if (p.x_prologue == CX_PRO_AFFINE_RELU)
     return g2 ? launch_form<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU>(p, st, form) : launch_form<CX_PRO_NONE, CX_PRO_AFFINE_RELU>(p, st, form);

@@ -185,6 +185,9 @@ def select_w():
     (320, 128, 0, 0, 1, 16, 20, 5),       # plain operands, two channel tiles with a partial second one, one step per range
     (512, 256, 2, 0, 4, 12, 16, 3),       # 12 steps in three ranges (pairs + tails of the step pipeline)
     (128, 384, 0, 1, 7, 8, 8, 1),         # 7 steps in one range (odd count)
+    (192, 24, 2, 1, 2, 8, 8, 0),          # partial last N tile (EfficientNet projections): 24 of 128
+    (144, 120, 0, 0, 3, 8, 8, 2),         # 120 of 128, partial channel tile as well
+    (64, 328, 2, 0, 1, 8, 16, 1),         # 2.56 tiles
 ])
 def test_1x1_weight_gradient_against_torch(dev, select_w, form, K, N, gpro, xpro, B, H, W, splits):
     from chexpert_amd import ops
