@@ -64,12 +64,14 @@ class KernelTimer:
             return "stem_fwd_kernel"
         # conv_mm.hip (cx_try_conv_mm): wide channel counts; 128 x 256 tiles where N allows and a tile has more than four k-steps
         ts, taps = kw.get("tstride", 1), kh * kw.get("kw", 1)
-        if mode == 0 and K % 8 == 0 and K >= 64 and N % 128 == 0 and ts <= 2 and taps <= 32 and \
+        if mode == 0 and K % 8 == 0 and K >= 64 and N % 8 == 0 and ts <= 2 and taps <= 32 and \
                 ((epi == 0 and pro in (0, 1, 2)) or (epi == 1 and pro in (0, 2))):
             nsteps = ((taps + 3) // 4 if ts == 2 else taps) * ((K + 63) // 64)
             zero_tap_classes = ts == 2 and (kh < 2 or kw.get("kw", 1) < 2)
-            if not (ts == 1 and nsteps <= 2) and not (zero_tap_classes and not kw.get("accumulate")):
-                wide = N % 256 == 0 and nsteps > 4 and (3 * ((K + 63) // 64 * 64) * 4 + 2 * (128 + 256) * 144 <= 160 * 1024)
+            partial_ok = N % 128 == 0 or (nsteps >= 14 and N >= 96)          # partial last N tile: only with >= 14 k-steps per tile
+            if partial_ok and not (ts == 1 and nsteps <= 2) and not (zero_tap_classes and not kw.get("accumulate")):
+                wide = (N + 255) // 256 * 256 == (N + 127) // 128 * 128 and nsteps > 4 and \
+                    (3 * ((K + 63) // 64 * 64) * 4 + 2 * (128 + 256) * 144 <= 160 * 1024)
                 # (a stride-2 input gradient is up to four launches of the kernel, one per parity class: timed as one unit)
                 return "conv_mm_kernel<2, %d, %d, %d, false>%s" % (4 if wide else 2, pro, epi, " x parity classes" if ts == 2 else "")
         bn = 128 if N % 128 == 0 else (32 if N == 32 else 64)
@@ -94,8 +96,8 @@ class KernelTimer:
                 K <= 2048 and N <= 2048 and xp == 1 and gp in (0, 2) and 4 <= x.shape[2] <= 126:
             return "conv3x3_strip_wgrad_kernel"               # (cx_try_strip_wgrad: any tile pairs of 32 x 32 channels)
         M = g.shape[0] * g.shape[1] * g.shape[2]
-        if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0 and N % 128 == 0 and K % 8 == 0 and K >= 64 and \
-                M % 64 == 0 and gp in (0, 2) and xp in (0, 1):
+        if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0 and N % 8 == 0 and N >= 24 and K % 8 == 0 and \
+                K >= 64 and M % 64 == 0 and gp in (0, 2) and xp in (0, 1):
             return "wgrad_mm_kernel<2, 4, %d, %d>" % (gp, xp)  # wgrad_mm.hip (cx_try_wgrad_mm)
         if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and N % 128 == 0 and K >= 64 and M * K >= (1 << 23):
             return "pw_wgrad_kernel<%d, %d>" % (gp, xp)
