@@ -294,8 +294,8 @@ def committed_counter(kernel, args, key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU minibatch (BASELINE config: 256)")
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--classes", type=int, default=14)
@@ -435,7 +435,9 @@ def main():
         for _ in range(args.steps):
             loss, _ = gstep.replay()
     else:
-        timer.enabled, timer.only = True, only
+        # N = 1 eager (--no-graph): the dominant kernel's events are taken inside the timed region.  N > 1: nothing but the step
+        # runs between the barriers; the events come from an eager replica afterwards, as for the graph
+        timer.enabled, timer.only = world == 1, only
         loss = eager_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
@@ -444,8 +446,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     log("timed region done: %.1f ms/step (%s)" % (dt / args.steps * 1e3, "graph replay" if gstep is not None else "eager"))
-    if gstep is not None:
-        opt.sync_from_device()
+    if gstep is not None or world > 1:
+        if gstep is not None:
+            opt.sync_from_device()
         timer.enabled, timer.only, timer.records = True, only, {}
         e0 = time.perf_counter()
         eager_steps(args.steps)
@@ -492,7 +495,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(only, args), "alg_bytes_per_launch": round(ksum["alg_bytes"] / ksum["launches"]),
                          "mfma_util": committed_counter(only, args, "mfma_util"),
-                         "timing": "hip events around each kernel launch (a slab reduce behind it excluded), eager replica of the timed steps" if gstep is not None
+                         "timing": "hip events around each kernel launch (a slab reduce behind it excluded), eager replica of the timed steps" if (gstep is not None or world > 1)
                          else "hip events around each kernel launch (a slab reduce behind it excluded) inside the timed region"},
         }
         if not args.no_cpu_baseline and args.model == "densenet121" and args.dtype == "bf16" and world == 1:

@@ -44,11 +44,19 @@ class CxPackDesc(C.Structure):
                 ("transpose", _i32), ("stem", _i32)]
 
 
+class CxReduceDesc(C.Structure):
+    _fields_ = [("dw", _fp), ("slab", _fp), ("total", C.c_int64), ("splits", _i32), ("vec", _i32), ("first_block", _i32), ("pad_", _i32)]
+
+
 # name -> argtypes (return type is int unless noted); kept in one table so the symbol-export test can
 # check it against include/chexpert_hip.h
 _f, _sz, _i = C.c_float, C.c_size_t, C.c_int
 SIGNATURES = {
     "cx_abi_version": [],
+    "cx_wgrad_defer": [C.c_int],
+    "cx_wgrad_defer_take": [C.POINTER(CxReduceDesc), C.c_int, C.POINTER(C.c_int64)],
+    "cx_last_slab_floats": [],
+    "cx_dw_reduce_table": [_vp, C.c_int, C.c_int64, _vp],
     "cx_error_string": [_i],
     "cx_conv_gemm": [C.POINTER(CxConv), _vp],
     "cx_conv_wgrad": [C.POINTER(CxWgrad), _vp],
@@ -141,7 +149,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cx_error_string" else C.c_int
-        if l.cx_abi_version() != 5:
+        if l.cx_abi_version() != 6:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l
     return _lib

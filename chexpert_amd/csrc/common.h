@@ -93,8 +93,11 @@ __device__ __forceinline__ void dw_out(float* dw, float* slab, size_t total, int
     atomicAdd(dw + idx, v);
 }
 // the slab to hand to a kernel: p's workspace if it holds splits * total floats, else null (atomics)
+extern thread_local int cx_tl_slab_floats_v;      // floats of the caller's slab the most recent launch of this thread used (0: atomics)
 static inline float* dw_slab(float* scratch, long long scratch_floats, long long splits, long long total) {
-  return (scratch && splits * total <= scratch_floats) ? scratch : nullptr;
+  const bool ok = scratch && splits * total <= scratch_floats && splits * total < (1ll << 31);
+  cx_tl_slab_floats_v = ok ? (int)(splits * total) : 0;
+  return ok ? scratch : nullptr;
 }
 int cx_dw_reduce(float* dw, const float* slab, size_t total, int splits, hipStream_t st);      // elementwise.hip
 

@@ -1,6 +1,7 @@
 // HBM-bound glue kernels of the DenseNet hot path: layout conversion, weight packing, BatchNorm
 // coefficient bookkeeping, stem pooling, head, loss, un-pooling and the fused optimisers.
 // All activation traffic is 16 B per lane along the channel axis (NHWC bf16).
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -101,11 +102,11 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16* __restric
 // dw[i] += sum over the slabs, in a fixed association (bit-reproducible): eight threads per group of four elements each add a
 // contiguous range of slabs in order (four loads in flight), then lane 0 of the eight adds the eight partial sums in order.
 template <bool VEC>
-__global__ __launch_bounds__(256) void dw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slab, size_t total, int splits) {
+__device__ __forceinline__ void dw_reduce_body(float* __restrict__ dw, const float* __restrict__ slab, size_t total, int splits,
+                                               unsigned block, float (*part)[8][4]) {
   constexpr int E = VEC ? 4 : 1;
-  __shared__ float part[32][8][4];
   const int oi = threadIdx.x >> 3, j = threadIdx.x & 7;
-  const size_t i = ((size_t)blockIdx.x * 32 + oi) * E;
+  const size_t i = ((size_t)block * 32 + oi) * E;
   const int per = (splits + 7) >> 3;
   const int s0 = j * per, s1 = (s0 + per < splits) ? s0 + per : splits;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -136,6 +137,29 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(float* __restrict__ dw, 
       dw[i] += t[0];
     }
   }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void dw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slab, size_t total, int splits) {
+  __shared__ float part[32][8][4];
+  dw_reduce_body<VEC>(dw, slab, total, splits, blockIdx.x, part);
+}
+
+// The same sums for MANY weight gradients in one launch (cx_dw_reduce_table): descriptor d owns blocks [first_block_d,
+// first_block_{d+1}); a block finds its descriptor by bisection (uniform per block) and runs the body above, so every dw element
+// sees exactly the additions, in exactly the order, of its own cx_dw_reduce launch.
+__global__ __launch_bounds__(256) void dw_reduce_table_kernel(const CxReduceDesc* __restrict__ tab, int n) {
+  __shared__ float part[32][8][4];
+  int lo = 0, hi = n - 1;
+  const int b = (int)blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const CxReduceDesc d = tab[lo];
+  const unsigned block = (unsigned)(b - d.first_block);
+  if (d.vec) dw_reduce_body<true>(d.dw, d.slab, (size_t)d.total, d.splits, block, part);
+  else dw_reduce_body<false>(d.dw, d.slab, (size_t)d.total, d.splits, block, part);
 }
 
 // one launch for every conv weight of a model: blockIdx.y = descriptor, blockIdx.x strides over its (output, input) channel pairs.
@@ -746,20 +770,22 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
                                                              const float* __restrict__ r_a, const bf16* __restrict__ b,
                                                              const float* __restrict__ mu_b, const float* __restrict__ r_b,
                                                              bf16* __restrict__ dz, float* S1, float* S2a, float* S2b, size_t rows,
-                                                             int C, int det, const uint8_t* __restrict__ mask) {
+                                                             int C, int det, const uint8_t* __restrict__ mask, int T) {
   extern __shared__ float lds[];          // [3][C] (atomic mode) / [256][24] (deterministic rows)
   const int CP = C / 8;
   if (!det) {
     for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) lds[i] = 0.f;
   }
   __syncthreads();
-  // CP may exceed the block: thread handles chunk columns cq = tid % CP only when CP divides 256, else strided generic path
+  // A thread keeps ONE chunk column cq for the whole grid-stride loop (its means / rstds live in registers): the T = (256 / CP) * CP
+  // leading threads of a workgroup are active, so the stride gridDim.x * T is a multiple of CP for any C % 8 == 0 (C <= 2048) --
+  // e.g. the 160 / 320 / 640-wide joins of WRN-28-10 (attn_aug_conv.py:311-404) run 240 threads of 256
   float s1[8], s2[8], s3[8];
   const size_t total = rows * CP;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // stride is a multiple of CP when CP | 256 (CP in {8,16,32,64,128,256}); C <= 2048
-  const int cq = idx % CP;
+  const size_t stride = (size_t)gridDim.x * T;
+  const bool active = (int)threadIdx.x < T;
+  size_t idx = active ? (size_t)blockIdx.x * T + threadIdx.x : total;
+  const int cq = active ? (int)(idx % CP) : 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
   float ma[8], ra_[8], mb[8], rb_[8];
@@ -798,7 +824,7 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       const int chunk = c >> 3, j = c & 7;
       float t1 = 0.f, t2 = 0.f, t3 = 0.f;
-      for (int t = chunk; t < (int)blockDim.x; t += CP) {
+      for (int t = chunk; t < T; t += CP) {
         t1 += lds[t * 24 + j];
         t2 += lds[t * 24 + 8 + j];
         t3 += lds[t * 24 + 16 + j];
@@ -809,11 +835,13 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
     }
     return;
   }
+  if (active) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    atomicAdd(&lds[cq * 8 + j], s1[j]);
-    atomicAdd(&lds[C + cq * 8 + j], s2[j]);
-    if (b) atomicAdd(&lds[2 * C + cq * 8 + j], s3[j]);
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&lds[cq * 8 + j], s1[j]);
+      atomicAdd(&lds[C + cq * 8 + j], s2[j]);
+      if (b) atomicAdd(&lds[2 * C + cq * 8 + j], s3[j]);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -1174,8 +1202,26 @@ extern "C" void dbg_pre_reduce_event(void* ev) {
 }
 extern "C" int dbg_pre_reduce_event_taken(void) { return g_pre_reduce_taken; }
 
+// Deferred slab sums (cx_wgrad_defer): while the calling thread has deferral on, a weight-gradient launch leaves its partial tiles
+// in the caller's slab and only records what has to be added; cx_wgrad_defer_take hands the records to the caller, who runs them
+// all with ONE cx_dw_reduce_table launch once the producing streams have been joined.
+thread_local int cx_tl_slab_floats_v = 0;
+namespace {
+struct DeferState { bool on = false; std::vector<CxReduceDesc> list; };
+thread_local DeferState g_defer;
+inline bool reduce_vec(const float* dw, const float* slab, size_t total) { return (total & 3) == 0 && aligned16(dw) && aligned16(slab); }
+}
+
 int cx_dw_reduce(float* dw, const float* slab, size_t total, int splits, hipStream_t st) {
   if (!dw || !slab || total == 0 || splits <= 0) return CX_EINVAL;
+  if (g_defer.on) {
+    CxReduceDesc d;
+    d.dw = dw; d.slab = slab; d.total = (int64_t)total; d.splits = splits;
+    d.vec = reduce_vec(dw, slab, total) ? 1 : 0;
+    d.first_block = 0;
+    g_defer.list.push_back(d);
+    return 0;
+  }
   if (g_pre_reduce_event) {
     (void)hipEventRecord(g_pre_reduce_event, st);
     g_pre_reduce_event = nullptr;
@@ -1191,6 +1237,39 @@ int cx_dw_reduce(float* dw, const float* slab, size_t total, int splits, hipStre
 }
 
 extern "C" {
+
+int cx_wgrad_defer(int on) {
+  const int was = g_defer.on ? 1 : 0;
+  g_defer.on = on > 0;
+  if (on < 0) g_defer.list.clear();
+  return was;
+}
+
+int cx_wgrad_defer_take(CxReduceDesc* out, int capacity, int64_t* total_blocks) {
+  const int n = (int)g_defer.list.size();
+  if (!out || n > capacity) return -n;
+  int64_t blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    CxReduceDesc d = g_defer.list[i];
+    if (blocks >= (1ll << 31) - (1 << 24)) return CX_ESHAPE;
+    d.first_block = (int32_t)blocks;
+    const int64_t units = d.vec ? d.total / 4 : d.total;
+    blocks += (units + 31) / 32;
+    out[i] = d;
+  }
+  if (total_blocks) *total_blocks = blocks;
+  g_defer.list.clear();
+  return n;
+}
+
+int cx_last_slab_floats(void) { return cx_tl_slab_floats_v; }
+
+int cx_dw_reduce_table(const CxReduceDesc* table_dev, int n, int64_t total_blocks, void* stream) {
+  if (n == 0) return 0;
+  if (!table_dev || n < 0 || total_blocks <= 0 || total_blocks >= (1ll << 31)) return CX_EINVAL;
+  hipLaunchKernelGGL(dw_reduce_table_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), table_dev, n);
+  return launch_status();
+}
 
 int cx_abi_version(void) { return CX_ABI_VERSION; }
 
@@ -1405,14 +1484,14 @@ int cx_relu_bwd_stats_mask(const void* dout, const void* out, const uint8_t* mas
                            int C, int stat_rows, void* stream) {
   if (!dout || (!out && !mask) || !a || !mu_a || !r_a || !dz || !S1 || !S2a) return CX_EINVAL;
   if (b && (!mu_b || !r_b || !S2b)) return CX_EINVAL;
-  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8)) return CX_ESHAPE;
-  if (C / 8 > 256) return CX_ESHAPE;
+  if (C % 8 || C > 2048) return CX_ESHAPE;
+  const int T = 256 / (C / 8) * (C / 8);          // active threads per workgroup (see the kernel)
   int grid = grid_for(rows * (C / 8), 256, 2048);
   if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
   const size_t lds_bytes = (stat_rows > 0 ? (size_t)256 * 24 : (size_t)3 * C) * sizeof(float);
   hipLaunchKernelGGL(relu_bwd_stats_kernel, dim3(grid), dim3(256), lds_bytes,
                      as_stream(stream), (const bf16*)dout, (const bf16*)out, (const bf16*)a, mu_a, r_a, (const bf16*)b, mu_b, r_b,
-                     (bf16*)dz, S1, S2a, S2b, rows, C, stat_rows > 0 ? 1 : 0, mask);
+                     (bf16*)dz, S1, S2a, S2b, rows, C, stat_rows > 0 ? 1 : 0, mask, T);
   return launch_status();
 }
 

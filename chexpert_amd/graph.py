@@ -63,5 +63,10 @@ class GraphedTrainStep:
             self.target.copy_(target, non_blocking=True)
         self.graph.replay()
         self.replays += 1
+        # the captured optimiser kernel has just changed the fp32 masters without touching tensor versions: an eval forward that
+        # follows must repack the weights (Engine.pack(train=False) compares versions)
+        eng = self.model._eng()
+        if hasattr(eng, "packed_version"):
+            eng.packed_version = None
         self.model._nbt_pending += 1           # BatchNorm num_batches_tracked is host-side bookkeeping (flushed by state_dict())
         return self.loss, self.logits

@@ -561,6 +561,18 @@ class _Engine:
     # ---- backward
     def backward(self, ws, dlogits):
         ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
+        # the ordered sums of the weight-gradient slabs run as ONE table-driven launch at the end of the pass (ops.wgrad_defer_*);
+        # data-parallel runs keep the immediate sums: their buckets leave while backward is still running
+        deferred = self.reducer is None and os.environ.get("CHEXPERT_WGRAD_DEFER", "1") != "0" and ops.wgrad_defer_begin(self.device)
+        try:
+            self._backward(ws, dlogits)
+            if deferred:
+                ops.wgrad_defer_flush(self.device)
+        finally:
+            if deferred:
+                ops.wgrad_defer_abort(self.device)
+
+    def _backward(self, ws, dlogits):
         m, f, s = self.model, self.model.features, self.slots
         R = self.stat_replicas
         B = ws.B
@@ -651,8 +663,14 @@ class _Engine:
                 gs, xs = gbuf[..., cin:cin + g_], buf[..., cin:cin + g_]
                 S2 = s["S2"][bi][li]
                 dz2 = dz2s[k & 1]
+                fused = os.environ.get("CHEXPERT_1X1_BWD", "fused") != "split" and self.dtype == torch.bfloat16
                 if k - 2 in w1_done:
-                    main.wait_event(w1_done.pop(k - 2))        # the side stream has finished reading this dz2 buffer
+                    # split mode: the side stream's conv1 weight gradient of two layers ago has finished reading this dz2 buffer.
+                    # (In the fused mode nothing on the side stream reads dz2: no cross-stream edge on the main chain -- in the
+                    # replayed graph each such edge was a ~10 us stall of the main queue, 58 per step)
+                    ev_ = w1_done.pop(k - 2)
+                    if not fused:
+                        main.wait_event(ev_)
                 rows = ops.conv_gemm(gs, self.w_bwd(layer.conv2), dz2, N=self.mid, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=xs,
                                      pa=qa, pb=qb, pc=qc, epilogue=ops.EPI_MASK, ex=y1, e_sc=v(n2[0]), e_sh=v(n2[1]), e_mu=v(n2[2]),
                                      e_r=v(n2[3]), e_scale=ws.ones[:self.mid], **self._sp(ws, S2, self.mid))
@@ -664,23 +682,24 @@ class _Engine:
                 pa, pb, pc = (v(t) for t in s["pl"][bi][li])
                 ops.bn_bwd_coef(red2[0], red2[1], cnt, layer.norm2.weight, v(n2[2]), v(n2[3]), G(layer.norm2.weight),
                                 G(layer.norm2.bias), None, None, pa, pb, pc, self.mid, replicas=red2[2], rstride=red2[3])
-                ev_p = torch.cuda.Event()
-                ev_p.record(main)
+                if not fused:
+                    ev_p = torch.cuda.Event()
+                    ev_p.record(main)
                 S1 = s["S1"][bi][li]
                 # input gradient + weight gradient of conv1 in one pass over dz2 / y1 / the buffer slice (conv1x1_bwd.hip);
                 # (6-37 % less kernel time than the two separate kernels; whole step 37.6 vs 39.0 ms);
                 # CHEXPERT_1X1_BWD=split keeps them, with the weight gradient on the side stream
-                fused = os.environ.get("CHEXPERT_1X1_BWD", "fused") != "split" and self.dtype == torch.bfloat16
                 rows = ops.conv_gemm(dz2, self.w_bwd(layer.conv1), gbuf[..., :cin], N=cin, prologue=ops.PRO_AFFINE2, x2=y1, pa=pa,
                                      pb=pb, pc=pc, epilogue=ops.EPI_MASK, ex=buf[..., :cin], e_sc=v(n1[0]), e_sh=v(n1[1]),
                                      e_mu=v(bmean)[:cin], e_r=v(brstd)[:cin], e_scale=v(n1[0]), accumulate=True,
                                      fused_dw=G(layer.conv1.weight) if fused else None, **self._sp(ws, S1, cin))
                 red1 = self._sc(ws, S1, cin, rows)
-                side.wait_event(ev_p)
-                with torch.cuda.stream(side):
-                    if not fused:
+                if not fused:
+                    side.wait_event(ev_p)
+                    with torch.cuda.stream(side):
                         ops.conv_wgrad(dz2, buf[..., :cin], G(layer.conv1.weight), g_prologue=ops.PRO_AFFINE2, g2=y1, ga=pa, gb=pb,
                                        gc=pc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n1[0]), pb=v(n1[1]))
+                if not fused or red is not None:
                     w1_done[k] = torch.cuda.Event()
                     w1_done[k].record(side)
                 ops.bn_bwd_coef(red1[0], red1[1], cnt, layer.norm1.weight, v(bmean), v(brstd), G(layer.norm1.weight),

@@ -49,6 +49,104 @@ def wgrad_scratch(device):
     return t
 
 
+# ---- deferred slab sums (cx_wgrad_defer): one table-driven launch per backward pass instead of one small launch per weight gradient
+class _WgradArena:
+    """Slab memory of one backward pass: every weight-gradient launch between defer_begin() and defer_flush() gets its own
+    region (bump allocation in launch order, so the addresses -- and with them the descriptor table -- repeat from step to step),
+    and the ordered sums into dw run in ONE launch at the flush.  The table lives on the device, keyed by its content: a repeated
+    schedule uploads nothing (which also makes the flush capturable in a hipGraph after a warm-up step).  The arena grows to what
+    a pass needed (DenseNet121 at 256 images: ~2 GB of the 288): a launch that does not fit runs its sum at once, as without
+    deferral, and the next pass finds a larger arena."""
+    START = int(os.environ.get("CHEXPERT_WGRAD_ARENA_MB", "256")) * (1 << 20) // 4
+    MIN_FREE = 16 << 20            # a launch is only deferred while this much is left (what covers every layer, see above)
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = torch.empty(self.START, dtype=torch.float32, device=device)
+        self.off = 0
+        self.need = 0
+        self.tables = {}
+        self.active = False
+
+
+_arenas = {}
+
+
+def _arena(device):
+    a = _arenas.get(device.index)
+    if a is None:
+        a = _arenas[device.index] = _WgradArena(device)
+    return a
+
+
+def wgrad_defer_begin(device):
+    """Start deferring the slab sums of this thread's weight-gradient launches (no-op without the slab workspace)."""
+    if WGRAD_SCRATCH_FLOATS <= 0:
+        return False
+    a = _arena(device)
+    if a.need > a.buf.numel():                       # the previous pass did not fit
+        a.buf = None
+        a.buf = torch.empty(int(a.need * 1.05) + a.MIN_FREE, dtype=torch.float32, device=device)
+        a.tables.clear()
+    a.off, a.need, a.active = 0, 0, True
+    lib().cx_wgrad_defer(1)
+    return True
+
+
+def _wgrad_ws(device):
+    """(tensor to hand to the launch as scratch, arena or None, deferred?)."""
+    a = _arenas.get(device.index)
+    if a is not None and a.active:
+        if a.buf.numel() - a.off >= a.MIN_FREE:
+            return a.buf[a.off:], a, True
+        lib().cx_wgrad_defer(0)                      # this launch sums at once from the per-stream scratch
+        return wgrad_scratch(device), a, False
+    return wgrad_scratch(device), None, False
+
+
+def _wgrad_used(a, deferred):
+    if a is not None:
+        n = (lib().cx_last_slab_floats() + 63) // 64 * 64
+        a.need += n
+        if deferred:
+            a.off += n
+        else:
+            lib().cx_wgrad_defer(1)
+
+
+def wgrad_defer_flush(device):
+    """Add every deferred slab to its dw (one launch on the current stream, which must have been joined with the producers) and
+    return to immediate sums."""
+    a = _arenas.get(device.index)
+    if a is None or not a.active:
+        return
+    a.active = False
+    cap = 1024
+    arr = (L.CxReduceDesc * cap)()
+    blocks = C.c_int64(0)
+    n = lib().cx_wgrad_defer_take(arr, cap, C.byref(blocks))
+    lib().cx_wgrad_defer(-1)
+    if n < 0:
+        raise RuntimeError("more than %d deferred weight-gradient sums" % cap)
+    if n == 0:
+        return
+    key = bytes(memoryview(arr).cast("B")[:n * C.sizeof(L.CxReduceDesc)])
+    t = a.tables.get(key)
+    if t is None:
+        if len(a.tables) > 16:
+            a.tables.clear()
+        t = a.tables[key] = torch.frombuffer(bytearray(key), dtype=torch.uint8).to(device)
+    check(lib().cx_dw_reduce_table(ptr(t), n, blocks.value, stream_ptr()), "cx_dw_reduce_table")
+
+
+def wgrad_defer_abort(device):
+    """Leave deferral without running the sums (error paths; no-op after a flush)."""
+    a = _arenas.get(device.index)
+    if a is not None and a.active:
+        a.active = False
+        lib().cx_wgrad_defer(-1)
+
+
 def conv_gemm(x, w_packed, y, *, fused_dw=None, **kw):
     """cx_conv_gemm; with `fused_dw` (fp32 OIHW gradient of the forward 1x1 weight) cx_conv1x1_dgrad_wgrad instead: the input
     gradient with the mask epilogue AND the weight gradient of the same bottleneck convolution in one pass."""
@@ -59,9 +157,10 @@ def conv_gemm(x, w_packed, y, *, fused_dw=None, **kw):
         require_cuda(fused_dw)
         assert x.dtype == torch.bfloat16, "the fused 1x1 input + weight gradient is a bf16 kernel"
         assert fused_dw.dtype == torch.float32 and fused_dw.is_contiguous()
-        ws = wgrad_scratch(fused_dw.device)
+        ws, arena, dfr = _wgrad_ws(fused_dw.device)
         check(lib().cx_conv1x1_dgrad_wgrad_ws(C.byref(p), ptr(fused_dw), ptr(ws), 0 if ws is None else ws.numel(), stream_ptr()),
               "cx_conv1x1_dgrad_wgrad_ws")
+        _wgrad_used(arena, dfr)
     return lib().cx_last_stat_rows() if p.stat_det else None      # stat_det: rows the consumer has to sum
 
 
@@ -123,10 +222,11 @@ def conv_wgrad(g, x, dw, *, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, g_prolo
     p.g_prologue, p.x_prologue, p.mode, p.splits = g_prologue, x_prologue, mode, splits
     p.dtype = 1 if g.dtype == torch.float32 else 0
     assert x.dtype == g.dtype and (g2 is None or g2.dtype == g.dtype)
-    ws = wgrad_scratch(dw.device)
+    ws, arena, dfr = _wgrad_ws(dw.device)
     if ws is not None:
         p.scratch, p.scratch_floats = ptr(ws), ws.numel()
     check(lib().cx_conv_wgrad(C.byref(p), stream_ptr()), "cx_conv_wgrad")
+    _wgrad_used(arena, dfr)
 
 
 def pack_weights(w, transpose=False, stem=False, out=None):

@@ -70,6 +70,10 @@ class _Flat:
         if getattr(self, "_hyper", None) is not None:
             h = self._hyper.cpu()
             self.lr, self.step_count = float(h[0]), int(h[1])
+            # cx_optim_tick steps the scheduler inside the graph: after minibatch number `step` it has been stepped
+            # step - max(warm-up, 1) + 1 times (chexpert.py:157-165), which is what an eager resume continues from
+            if int(h[2]) != 0:
+                self.sched_steps = max(0, int(h[1]) - max(int(h[4]), 1) + 1)
 
 
 class FusedAdam(_Flat):

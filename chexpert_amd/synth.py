@@ -102,3 +102,19 @@ def fill_state_dict_(sd: dict, seed: int) -> dict:
             fan_in = int(np.prod(t.shape[1:]))
             t.copy_(symmetric(s, t.shape, std=(2.0 / fan_in) ** 0.5))
     return sd
+
+
+def smooth_state_dict_(sd: dict, bias: float, gain_seed: int = 7) -> dict:
+    """The well-conditioned ("smooth") regime of the parity fixtures, applied in place to a filled state_dict: every BatchNorm
+    gain in [0.8, 1.2], every BatchNorm bias = `bias` (2.5 for the DenseNets, 1.0 for ResNets / EfficientNets: most
+    activations stay on the linear side of their non-linearity, so storage rounding does not flip ReLU / max-pool decisions);
+    convolution / linear weights keep their kaiming-scale hash fill.  A BatchNorm is recognised by its running_mean entry."""
+    for k in list(sd.keys()):
+        prefix, _, leaf = k.rpartition(".")
+        if prefix + ".running_mean" not in sd:
+            continue
+        if leaf == "bias":
+            sd[k] = torch.full_like(sd[k], float(bias))
+        elif leaf == "weight":
+            sd[k] = uniform(gain_seed, sd[k].shape, 0.8, 1.2)
+    return sd

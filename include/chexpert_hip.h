@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 5
+#define CX_ABI_VERSION 6
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4, CX_ESTATROWS = -5 };
 
@@ -107,6 +107,26 @@ typedef struct CxWgrad {
   float* scratch;
   int64_t scratch_floats;
 } CxWgrad;
+
+/* Deferred slab sums (ABI 6).  A training step issues ~120 weight-gradient launches whose partial tiles (CxWgrad.scratch) each
+ * need a small ordered sum into dw; one launch per sum puts ~60 of them on the critical stream (6-7 us each on DenseNet121).
+ * cx_wgrad_defer(1) switches the calling thread to deferral: every weight-gradient entry point (cx_conv_wgrad,
+ * cx_conv1x1_dgrad_wgrad_ws) then only stores its partial tiles -- the caller must hand each launch a scratch region that
+ * stays untouched until the sums have run (cx_last_slab_floats() tells how much of it the launch used; 0 = it fell back to atomics)
+ * -- and records {dw, slab, total, splits}.  cx_wgrad_defer_take() returns the records (first_block filled in), which the caller
+ * copies to the device once per distinct schedule, and cx_dw_reduce_table() adds them all in ONE launch on a stream that has
+ * been joined with the producers: every dw element receives exactly the additions, in the order, of its own immediate sum,
+ * so results are bit-identical to the immediate form.  cx_wgrad_defer(0) returns to immediate sums and keeps the pending records
+ * (a single launch can be taken out of the deferral that way), cx_wgrad_defer(-1) also drops them.                              */
+typedef struct CxReduceDesc {
+  float* dw; const float* slab;      /* dw[i] += slab[0*total + i] + slab[1*total + i] + ... (fixed association)             */
+  int64_t total;                     /* elements of dw                                                                        */
+  int32_t splits, vec, first_block, pad_;
+} CxReduceDesc;
+int cx_wgrad_defer(int on);                                            /* returns the previous state                          */
+int cx_wgrad_defer_take(CxReduceDesc* out_host, int capacity, int64_t* total_blocks);   /* n records, or -n if capacity < n   */
+int cx_last_slab_floats(void);
+int cx_dw_reduce_table(const CxReduceDesc* table_dev, int n, int64_t total_blocks, void* stream);
 
 int cx_abi_version(void);
 const char* cx_error_string(int code);

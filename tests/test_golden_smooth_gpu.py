@@ -1,0 +1,133 @@
+"""GPU: the bf16 HIP schedule against WELL-CONDITIONED fixtures recorded from the REAL reference (tests/golden/nets_smooth.json,
+written by tests/golden/make_golden.py `smooth`): BatchNorm gains in [0.8, 1.2], biases 2.5 / 1.0, kaiming-scale convolutions,
+B = 8 -- the regime in which north_star's 1e-2 (relative to the logit abs-max) is a statement about the kernels and not about
+what bf16 storage does to a chaotic fixture.  Every bound below is a literal.
+
+Two families of checks:
+  * one training step (chexpert.py:159-163) at the fixture's own batch: train logits, loss, every parameter-gradient norm, running
+    statistics;
+  * the same step at the BASELINE batch geometry (256 / 128 / 64 images: other grids, split counts, 32-bit offsets against GB-sized
+    buffers): the batch is the fixture's 8 images repeated, which has the SAME batch statistics, so every copy must reproduce the
+    golden logits and the loss / gradients must equal the golden ones (mean over the batch).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from chexpert_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+ATTN = {"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (320, 320)}      # chexpert.py:476
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from chexpert_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.load(open(os.path.join(G, "nets_smooth.json")))
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+
+
+def _make(tag, n_cls):
+    """(model, state_dict) of a fixture tag: the drop-in constructors of the reference (chexpert.py:461-500)."""
+    from chexpert_amd.models import Bottleneck, DenseNet, ResNet, construct_model
+    from chexpert_amd.models.efficientnet import DropMarker
+    from oracle import nets
+    attn = dict(k=.2, v=.1, nh=8)
+    if tag.startswith("densenet121"):
+        spec, model, bias = nets.densenet_spec(n_cls), DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls), 2.5
+    elif tag.startswith("aadensenet121"):
+        spec, model, bias = nets.densenet_spec(n_cls, attn=attn), DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls, attn_params=dict(ATTN)), 2.5
+    elif tag.startswith("resnet152"):
+        spec, model, bias = nets.resnet_spec(n_cls), ResNet(Bottleneck, [3, 8, 36, 3], num_classes=n_cls), 1.0
+    elif tag.startswith("aaresnet152"):
+        spec, model, bias = nets.resnet_spec(n_cls, attn=attn), ResNet(Bottleneck, [3, 8, 36, 3], num_classes=n_cls, attn_params=dict(ATTN)), 1.0
+    else:
+        name = tag.split("_")[0]
+        spec, model, bias = nets.efficientnet_spec(name, n_cls), construct_model(name, n_cls), 1.0
+        for mod in model.modules():                 # deterministic part, as recorded (make_golden.py sets p = 0)
+            if isinstance(mod, DropMarker):
+                mod.p = 0.0
+    sd = synth.smooth_state_dict_(synth.fill_state_dict_(nets.zeros_state_dict(spec), 21), bias)
+    assert list(model.state_dict().keys()) == list(spec.keys())
+    model.load_state_dict(sd, strict=True)
+    return model, sd
+
+
+def _check_step(tag, rec, model, dev, copies, lim_logits, lim_loss, lim_norm, lim_norm_1d):
+    n_cls = rec["n_classes"]
+    x8 = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"])
+    t8 = synth.targets(rec["t_seed"], rec["B"], n_cls)
+    x, t = x8.repeat(copies, 1, 1, 1).to(dev), t8.repeat(copies, 1).to(dev)
+    model.train()
+    model.zero_grad()
+    loss, logits = model.forward_backward(x, t)
+    want = torch.tensor(rec["logits_train"])
+    lg = logits.cpu().view(copies, rec["B"], n_cls)
+    e = max(_rel(lg[i], want) for i in range(copies))
+    e_loss = abs(loss.item() - rec["loss"]) / abs(rec["loss"])
+    gmax = max(r["l2"] for r in rec["grads"].values())
+    worst = []
+    for k, p in model.named_parameters():
+        r = rec["grads"][k]
+        assert p.grad is not None and torch.isfinite(p.grad).all().item(), k
+        if r["l2"] < 1e-3 * gmax:
+            continue
+        worst.append((abs(p.grad.double().norm().item() / r["l2"] - 1.0), k))
+    worst.sort(reverse=True)
+    w_nd = [w for w in worst if dict(model.named_parameters())[w[1]].dim() > 1][:3]
+    w_1d = [w for w in worst if dict(model.named_parameters())[w[1]].dim() == 1][:3]
+    print("%s x%d: train logits rel %.3e, loss rel %.3e, worst grad-norm deviation weights %s, norm parameters %s"
+          % (tag, copies, e, e_loss, [(round(a, 4), b) for a, b in w_nd], [(round(a, 4), b) for a, b in w_1d]))
+    assert e < lim_logits, "train logits %.3e of the abs-max" % e
+    assert e_loss < lim_loss
+    assert not w_nd or w_nd[0][0] < lim_norm, w_nd
+    assert not w_1d or w_1d[0][0] < lim_norm_1d, w_1d
+    return model
+
+
+# tag -> (logits, loss, weight-gradient norm, norm-parameter gradient norm) literal limits
+CASES = {
+    "densenet121_320_b8": (1e-2, 1e-2, 0.05, 0.05),
+    "aadensenet121_320_b8": (1e-2, 1e-2, 0.05, 0.05),
+    "resnet152_320_b8": (1e-2, 1e-2, 0.05, 0.05),
+    "aaresnet152_320_b8": (1e-2, 1e-2, 0.05, 0.05),
+    "efficientnet-b0_224_b8": (1e-2, 1e-2, 0.05, 0.05),
+    "efficientnet-b4_380_b8": (1e-2, 1e-2, 0.05, 0.05),
+}
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_train_step_matches_reference_smooth_fixture(dev, golden, tag):
+    rec = golden[tag]
+    model, sd = _make(tag, rec["n_classes"])
+    assert sum(p.numel() for p in model.parameters()) == rec["n_params"]
+    model = model.to(dev)
+    _check_step(tag, rec, model, dev, 1, *CASES[tag])
+    after = model.state_dict()
+    for k, r in rec["running"].items():                          # BatchNorm running statistics after the step
+        f = after[k].detach().double().flatten().cpu()
+        assert abs(float(f.norm()) - r["l2"]) <= 1e-2 * r["l2"], (k, float(f.norm()), r["l2"])
+        assert (f[:8] - torch.tensor(r["head"], dtype=torch.float64)).abs().max().item() <= 1e-2 * r["l2"] / max(1.0, r["n"] ** 0.5) + 1e-3, k
+
+
+# BASELINE.json configs[1..4]: per-GPU batches 256 / 128 / 128 / 64
+@pytest.mark.parametrize("tag,copies", [("densenet121_320_b8", 32), ("aadensenet121_320_b8", 16), ("resnet152_320_b8", 16),
+                                        ("efficientnet-b4_380_b8", 8)])
+def test_baseline_batch_geometry_reproduces_the_fixture(dev, golden, tag, copies):
+    rec = golden[tag]
+    model, sd = _make(tag, rec["n_classes"])
+    _check_step(tag, rec, model.to(dev), dev, copies, *CASES[tag])

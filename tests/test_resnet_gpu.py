@@ -270,7 +270,7 @@ def test_grad_cam_resnet_matches_reference_fixture(dev):
 def _basic_net(tag, n_cls, seed, dev, smooth, S=None):
     from chexpert_amd.models import BasicBlock, ResNet, WideResNet
     from oracle import nets
-    wide = (16, 4) if "wrn" in tag else None
+    wide = ((10, 10) if "wrn10_10" in tag else (16, 4)) if "wrn" in tag else None      # wrn10_10: widths 160 / 320 / 640 (C/8 not 2^k)
     aa = tag.startswith("aa")
     attn = dict(k=.2, v=.1, nh=8) if aa else None
     ap = dict(k=.2, v=.1, nh=8, relative=True, input_dims=(S, S)) if aa else None
@@ -282,7 +282,7 @@ def _basic_net(tag, n_cls, seed, dev, smooth, S=None):
                 sd[k] = torch.full_like(sd[k], 1.0)
             if k.endswith(".weight") and sd[k].dim() == 1:
                 sd[k] = synth.uniform(7, sd[k].shape, 0.8, 1.2)
-    model = WideResNet(BasicBlock, 16, 4, num_classes=n_cls, attn_params=ap) if wide else \
+    model = WideResNet(BasicBlock, wide[0], wide[1], num_classes=n_cls, attn_params=ap) if wide else \
         ResNet(BasicBlock, [2, 2, 2, 2], num_classes=n_cls, attn_params=ap)
     assert list(model.state_dict().keys()) == list(spec.keys())
     model.load_state_dict(sd, strict=True)
@@ -325,7 +325,7 @@ def test_basic_block_networks_match_reference_golden_fixture(dev, tag):
             assert 0.5 < p.grad.norm().item() / rec["grads"][k]["l2"] < 2.0, k
 
 
-@pytest.mark.parametrize("tag,B,S", [("resnet18", 8, 128), ("wrn16_4", 16, 32)])
+@pytest.mark.parametrize("tag,B,S", [("resnet18", 8, 128), ("wrn16_4", 16, 32), ("wrn10_10", 8, 32)])
 def test_basic_block_networks_smooth_regime_match_fp32_oracle(dev, tag, B, S):
     """Same networks in the well-conditioned regime of test_resnet_smooth_regime_matches_fp32_oracle: every gradient and the
     running statistics against the fp32 oracle, and a repeated step bit for bit (statistic rows + weight-gradient slabs)."""
