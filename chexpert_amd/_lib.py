@@ -102,9 +102,10 @@ SIGNATURES = {
     "cx_optim_tick": [_vp, _vp],
     "cx_aa_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_aa_attention_weights": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "cx_aa_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "cx_aa_outproj_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _vp],
-    "cx_aa_outproj_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_aa_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_int64, _vp],
+    "cx_aa_outproj_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp],
+    "cx_aa_outproj_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, C.c_int64, _vp],
+    "cx_rows_reduce": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cx_stats_bc": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_affine_relu_bc": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_in_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

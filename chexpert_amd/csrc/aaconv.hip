@@ -15,7 +15,9 @@
 
 // aaconv_row.hip: row-streamed kernels for map widths 40 and 20 (which: 0 forward, 1 the whole backward)
 int cx_try_aa_row(int which, const void* qkv, const float* rel_h, const float* rel_w, float* o, const float* d_o, float* lse, float* dqkv,
-                  float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq, hipStream_t st, bool* handled);
+                  float* d_rel_h, float* d_rel_w, float* slab_h, float* slab_w, int B, int H, int W, int nh, int dk, int dv, int ldq,
+                  hipStream_t st, bool* handled);
+int cx_rows_reduce_add_impl(float* dst, const float* rows, int n_rows, int C, int rstride, hipStream_t st);     // elementwise.hip
 
 namespace {
 
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restric
                                                           const float* __restrict__ rel_w, const float* __restrict__ o,
                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, float* __restrict__ d_rel_h,
-                                                          float* __restrict__ d_rel_w, const AAGeo g) {
+                                                          float* __restrict__ d_rel_w, float* __restrict__ slab_h,
+                                                          float* __restrict__ slab_w, const AAGeo g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int H = g.H, W = g.W, HW = H * W;
   const int LH = 2 * H - 1, LW = 2 * W - 1;
@@ -287,7 +290,10 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restric
 #pragma unroll
   for (int d = 0; d < DKH; ++d) dq[d] = 0.f;
   float* drw = Kt + TK * DKH + TK * DVH + DKH * (LH + LW);      // [AQ][W+1], behind dRW
+  float* drh_s = drw + AQ * (W + 1);                            // [AQ][H+1]
+  float* Qs = drh_s + AQ * (H + 1);                             // [AQ][DKH+1]
   for (int kx = 0; kx < W; ++kx) drw[tid * (W + 1) + kx] = 0.f;
+  for (int ky = 0; ky < H; ++ky) drh_s[tid * (H + 1) + ky] = 0.f;
   const int kofs = g.dk + n * DKH, vofs = 2 * g.dk + n * DVH;
   float drh_run = 0.f;
   for (int j0 = 0; j0 < HW; j0 += TK) {
@@ -339,9 +345,9 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restric
 #pragma unroll
           for (int d = 0; d < DKH; ++d) {
             dq[d] = fmaf(drh_run, RH[d * LH + r], dq[d]);
-            atomicAdd(&dRH[d * LH + r], drh_run * q[d]);
           }
         }
+        drh_s[tid * (H + 1) + ky] = qvalid ? drh_run : 0.f;      // d rh_i[ky]: folded into the table gradient after the key loop
         drh_run = 0.f;
         kx = 0;
         ++ky;
@@ -353,18 +359,46 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restric
       const float dsum = drw[tid * (W + 1) + kx];
       const int r = kx - qx + W - 1;
 #pragma unroll
-      for (int d = 0; d < DKH; ++d) {
-        dq[d] = fmaf(dsum, RW[d * LW + r], dq[d]);
-        atomicAdd(&dRW[d * LW + r], dsum * q[d]);
-      }
+      for (int d = 0; d < DKH; ++d) dq[d] = fmaf(dsum, RW[d * LW + r], dq[d]);
     }
     float* dqp = dqkv + ((size_t)b * HW + i) * (2 * g.dk + g.dv) + n * DKH;
 #pragma unroll
     for (int d = 0; d < DKH; ++d) dqp[d] = dq[d] * scale;       // q~ = q * scale
+  } else {
+    for (int kx = 0; kx < W; ++kx) drw[tid * (W + 1) + kx] = 0.f;
+  }
+#pragma unroll
+  for (int d = 0; d < DKH; ++d) Qs[tid * (DKH + 1) + d] = q[d];
+  __syncthreads();
+  // table gradients, owner-computes (a fixed order of additions: LDS float atomics from many lanes are not): the thread that owns
+  // word (d, r) walks the workgroup's queries; query l meets offset r at key row ky = r - (H-1) + qy_l
+  const int i0 = blockIdx.x * AQ;
+  for (int t = tid; t < DKH * LH; t += AQ) {
+    const int d = t / LH, r = t - d * LH;
+    int yq = i0 / W, xq = i0 - yq * W;
+    float a = 0.f;
+    for (int l = 0; l < AQ; ++l) {
+      const int ky = r - (H - 1) + yq;
+      if (ky >= 0 && ky < H) a = fmaf(drh_s[l * (H + 1) + ky], Qs[l * (DKH + 1) + d], a);
+      if (++xq == W) { xq = 0; ++yq; }
+    }
+    dRH[t] = a;
+  }
+  for (int t = tid; t < DKH * LW; t += AQ) {
+    const int d = t / LW, r = t - d * LW;
+    int xq = i0 % W;
+    float a = 0.f;
+    for (int l = 0; l < AQ; ++l) {
+      const int kx = r - (W - 1) + xq;
+      if (kx >= 0 && kx < W) a = fmaf(drw[l * (W + 1) + kx], Qs[l * (DKH + 1) + d], a);
+      if (++xq == W) xq = 0;
+    }
+    dRW[t] = a;
   }
   __syncthreads();
-  for (int t = tid; t < DKH * LH; t += AQ) atomicAdd(&d_rel_h[t], dRH[t]);
-  for (int t = tid; t < DKH * LW; t += AQ) atomicAdd(&d_rel_w[t], dRW[t]);
+  const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  for (int t = tid; t < DKH * LH; t += AQ) { if (slab_h) slab_h[wg * (DKH * LH) + t] = dRH[t]; else atomicAdd(&d_rel_h[t], dRH[t]); }
+  for (int t = tid; t < DKH * LW; t += AQ) { if (slab_w) slab_w[wg * (DKH * LW) + t] = dRW[t]; else atomicAdd(&d_rel_w[t], dRW[t]); }
 }
 
 template <int DVH>
@@ -485,71 +519,102 @@ __global__ void affine_relu_bc_kernel(const bf16* __restrict__ x, const float* _
   }
 }
 
-// per-(b,c) sums over the pixels of an image: sum, sum of squares (InstanceNorm statistics)
-__global__ void stats_bc_kernel(const bf16* __restrict__ x, float* __restrict__ sum, float* __restrict__ sq,
-                                                      int HW, int C, int ldx, int splits) {
-  extern __shared__ float lds[];          // [2][C]
-  const int CP = C / 8;
-  const int b = blockIdx.y, sp = blockIdx.x;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+// per-(b,c) sums over the pixels of an image: sum, sum of squares (InstanceNorm statistics).
+// Deterministic: a workgroup owns (image b, a group of 8 channel chunks = 64 channels) and ALL pixels of the image -- 32 pixel lanes x
+// 8 chunk lanes, four pixels in flight per thread; the 32 pixel-lane partial sums meet in LDS and are added in lane order; one
+// plain store per (b, c): no atomics, no zero-fill, the same bits every run.
+template <typename F>
+__device__ __forceinline__ void bc_fold_store(float (*part)[8][17], const float (&s1)[8], const float (&s2)[8], float* __restrict__ o1,
+                                              float* __restrict__ o2, int b, int C, int cbase, F) {
+  const int cq = threadIdx.x & 7, rr = threadIdx.x >> 3;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { part[rr][cq][j] = s1[j]; part[rr][cq][8 + j] = s2[j]; }
   __syncthreads();
-  const int cq = threadIdx.x % CP, rr = threadIdx.x / CP, rpp = blockDim.x / CP;
-  const int len = (HW + splits - 1) / splits;
-  const int p0 = sp * len, p1 = min(HW, p0 + len);
-  float s1[8], s2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-  for (int p = p0 + rr; p < p1; p += rpp) {
-    U128 v;
-    v.u = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + p) * ldx + cq * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float f = bf2f(v.e[j]);
-      s1[j] += f;
-      s2[j] += f * f;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    atomicAdd(&lds[cq * 8 + j], s1[j]);
-    atomicAdd(&lds[C + cq * 8 + j], s2[j]);
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    atomicAdd(&sum[(size_t)b * C + c], lds[c]);
-    atomicAdd(&sq[(size_t)b * C + c], lds[C + c]);
+  if (threadIdx.x < 128) {
+    const int c8 = threadIdx.x >> 4, k = threadIdx.x & 15;       // chunk lane, (sum | sq) x channel-in-chunk
+    float t = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) t += part[r][c8][k];
+    const int c = cbase + c8 * 8 + (k & 7);
+    if (c < C) (k < 8 ? o1 : o2)[(size_t)b * C + c] = t;
   }
 }
 
-// out_proj (dv x dv 1x1 conv, :92) on the fp32 attention output, written as bf16 into the block-buffer slice
-// [+ per-channel statistics of the rounded output]
-__global__ void aa_outproj_fwd_kernel(const float* __restrict__ o, const float* __restrict__ w, bf16* __restrict__ y, int ldy,
-                                      float* stat_sum, float* stat_sq, size_t npix, int dv) {
-  __shared__ float ws[48 * 48];
-  __shared__ float st[2 * 48];
-  for (int t = threadIdx.x; t < dv * dv; t += blockDim.x) ws[t] = w[t];
-  for (int t = threadIdx.x; t < 2 * dv; t += blockDim.x) st[t] = 0.f;
-  __syncthreads();
-  // thread = (pixel, output channel)
-  const size_t total = npix * dv;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t pix = idx / dv;
-    const int c = idx - pix * dv;
-    const float* op = o + pix * dv;
-    float a = 0.f;
-    for (int d = 0; d < dv; ++d) a = fmaf(ws[c * dv + d], op[d], a);
-    const bf16 r = f2bf(a);
-    y[pix * ldy + c] = r;
-    const float rv = bf2f(r);
-    atomicAdd(&st[c], rv);
-    atomicAdd(&st[dv + c], rv * rv);
+__global__ __launch_bounds__(256) void stats_bc_kernel(const bf16* __restrict__ x, float* __restrict__ sum, float* __restrict__ sq,
+                                                       int HW, int C, int ldx) {
+  __shared__ float part[32][8][17];
+  const int b = blockIdx.y, cbase = blockIdx.x * 64;
+  const int cq = threadIdx.x & 7, rr = threadIdx.x >> 3;
+  const int c0 = cbase + cq * 8;
+  const bool cok = c0 < C;
+  const bf16* xp = x + (size_t)b * HW * ldx + (cok ? c0 : 0);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  int p = rr;
+  for (; p + 96 < HW; p += 128) {
+    U128 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u].u = *reinterpret_cast<const uint4*>(xp + (size_t)(p + 32 * u) * ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = bf2f(v[u].e[j]); s1[j] += f; s2[j] += f * f; }
   }
+  for (; p < HW; p += 32) {
+    U128 v;
+    v.u = *reinterpret_cast<const uint4*>(xp + (size_t)p * ldx);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = bf2f(v.e[j]); s1[j] += f; s2[j] += f * f; }
+  }
+  if (!cok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  }
+  bc_fold_store(part, s1, s2, sum, sq, b, C, cbase, 0);
+}
+
+// out_proj (dv x dv 1x1 conv, :92) on the fp32 attention output, written as bf16 into the block-buffer slice
+// [+ per-channel statistics of the rounded output].  T = (256 / dv) * dv threads are active: a thread keeps ONE output channel
+// (tid % dv) and walks pixels, so its two sums are registers; they meet in LDS and are added in pixel-lane order.  det: the
+// workgroup plain-stores its row (stat_sum[row * rstride + c], CxConv.stat_det convention), else one atomic per channel.
+__global__ __launch_bounds__(256) void aa_outproj_fwd_kernel(const float* __restrict__ o, const float* __restrict__ w, bf16* __restrict__ y,
+                                                             int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv, int T, int det,
+                                                             int rstride) {
+  __shared__ float ws[48 * 48];
+  __shared__ float st[2][256];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < dv * dv; t += blockDim.x) ws[t] = w[t];
   __syncthreads();
-  if (stat_sum)
-    for (int t = threadIdx.x; t < dv; t += blockDim.x) {
-      atomicAdd(&stat_sum[t], st[t]);
-      atomicAdd(&stat_sq[t], st[dv + t]);
+  const bool active = tid < T;
+  const int c = tid % dv, pl = tid / dv, npl = T / dv;
+  float s1 = 0.f, s2 = 0.f;
+  if (active) {
+    for (size_t pix = (size_t)blockIdx.x * npl + pl; pix < npix; pix += (size_t)gridDim.x * npl) {
+      const float* op = o + pix * dv;
+      float a = 0.f;
+      for (int d = 0; d < dv; ++d) a = fmaf(ws[c * dv + d], op[d], a);
+      const bf16 r = f2bf(a);
+      y[pix * ldy + c] = r;
+      const float rv = bf2f(r);
+      s1 += rv;
+      s2 += rv * rv;
     }
+  }
+  st[0][tid] = s1;
+  st[1][tid] = s2;
+  __syncthreads();
+  if (stat_sum && tid < dv) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int l = 0; l < npl; ++l) { t1 += st[0][l * dv + tid]; t2 += st[1][l * dv + tid]; }
+    if (det) {
+      stat_sum[(size_t)blockIdx.x * rstride + tid] = t1;
+      stat_sq[(size_t)blockIdx.x * rstride + tid] = t2;
+    } else {
+      atomicAdd(&stat_sum[tid], t1);
+      atomicAdd(&stat_sq[tid], t2);
+    }
+  }
 }
 
 // backward of out_proj: dO[pix][d] = sum_c dY[pix][c] * W[c][d];  dW[c][d] += sum_pix dY[pix][c] * O[pix][d]
@@ -558,7 +623,7 @@ __global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const bf16* __restr
                                                              const float* __restrict__ ga, const float* __restrict__ gb,
                                                              const float* __restrict__ gc, const float* __restrict__ o,
                                                              const float* __restrict__ w, float* __restrict__ d_o,
-                                                             float* __restrict__ dw, size_t npix, int dv) {
+                                                             float* __restrict__ dw, float* __restrict__ slab, size_t npix, int dv) {
   // Two small GEMMs per 64-pixel chunk staged in LDS: dO = dY W (thread per (pixel, d)) and dW += dY^T O (thread per (c, d)
   // pair, which it owns: plain LDS accumulation, no atomics -- a pixel-per-thread outer product sent 64 lanes to the same
   // LDS word dv*dv times per pixel: 2.2 ms per call).
@@ -594,7 +659,7 @@ __global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const bf16* __restr
     }
   }
   __syncthreads();
-  for (int t = tid; t < dv * dv; t += 256) atomicAdd(&dw[t], dws[t]);
+  for (int t = tid; t < dv * dv; t += 256) dw_out(dw, slab, (size_t)dv * dv, (int)blockIdx.x, t, dws[t]);
 }
 
 // fp32 (B,HW,C) -> bf16 same shape
@@ -604,44 +669,56 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16* __restrict
 
 // InstanceNorm + ReLU backward: dz = dA * [a > 0];  dx = r * (dz - mean_hw(dz) - xhat * mean_hw(dz * xhat)) per (b,c)
 // pass 1: S1[b][c] = sum dz, S2[b][c] = sum dz*xhat      pass 2: write dx
-__global__ void in_relu_bwd_stats_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
-                                                               const float* __restrict__ sc, const float* __restrict__ sh,
-                                                               float* __restrict__ S1, float* __restrict__ S2, int HW, int C, int ldx,
-                                                               int splits) {
-  extern __shared__ float lds[];
-  const int CP = C / 8;
-  const int b = blockIdx.y, sp = blockIdx.x;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
-  __syncthreads();
-  const int cq = threadIdx.x % CP, rr = threadIdx.x / CP, rpp = blockDim.x / CP;
-  const int len = (HW + splits - 1) / splits;
-  const int p0 = sp * len, p1 = min(HW, p0 + len);
+__global__ __launch_bounds__(256) void in_relu_bwd_stats_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
+                                                                const float* __restrict__ sc, const float* __restrict__ sh,
+                                                                float* __restrict__ S1, float* __restrict__ S2, int HW, int C, int ldx) {
+  // same ownership as stats_bc_kernel: (image, 64 channels) per workgroup, every pixel, ordered fold, plain stores
+  __shared__ float part[32][8][17];
+  const int b = blockIdx.y, cbase = blockIdx.x * 64;
+  const int cq = threadIdx.x & 7, rr = threadIdx.x >> 3;
+  const int c0 = cbase + cq * 8;
+  const bool cok = c0 < C;
+  const int cc = cok ? c0 : 0;
   float s1[8], s2[8], fs[8], fh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; fs[j] = sc[(size_t)b * C + cq * 8 + j]; fh[j] = sh[(size_t)b * C + cq * 8 + j]; }
-  for (int p = p0 + rr; p < p1; p += rpp) {
+  for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; fs[j] = sc[(size_t)b * C + cc + j]; fh[j] = sh[(size_t)b * C + cc + j]; }
+  const bf16* xp = x + (size_t)b * HW * ldx + cc;
+  const bf16* dp = da + (size_t)b * HW * C + cc;
+  int p = rr;
+  for (; p + 32 < HW; p += 64) {
+    U128 v[2], d[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      v[u].u = *reinterpret_cast<const uint4*>(xp + (size_t)(p + 32 * u) * ldx);
+      d[u].u = *reinterpret_cast<const uint4*>(dp + (size_t)(p + 32 * u) * C);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = fmaf(bf2f(v[u].e[j]), fs[j], fh[j]);          // xhat = (x-mean)*rstd
+        const float dz = xh > 0.f ? bf2f(d[u].e[j]) : 0.f;
+        s1[j] += dz;
+        s2[j] += dz * xh;
+      }
+  }
+  for (; p < HW; p += 32) {
     U128 v, d;
-    const size_t pix = (size_t)b * HW + p;
-    v.u = *reinterpret_cast<const uint4*>(x + pix * ldx + cq * 8);
-    d.u = *reinterpret_cast<const uint4*>(da + pix * C + cq * 8);
+    v.u = *reinterpret_cast<const uint4*>(xp + (size_t)p * ldx);
+    d.u = *reinterpret_cast<const uint4*>(dp + (size_t)p * C);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xh = fmaf(bf2f(v.e[j]), fs[j], fh[j]);          // xhat = (x-mean)*rstd
+      const float xh = fmaf(bf2f(v.e[j]), fs[j], fh[j]);
       const float dz = xh > 0.f ? bf2f(d.e[j]) : 0.f;
       s1[j] += dz;
       s2[j] += dz * xh;
     }
   }
+  if (!cok) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    atomicAdd(&lds[cq * 8 + j], s1[j]);
-    atomicAdd(&lds[C + cq * 8 + j], s2[j]);
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    atomicAdd(&S1[(size_t)b * C + c], lds[c]);
-    atomicAdd(&S2[(size_t)b * C + c], lds[C + c]);
-  }
+  bc_fold_store(part, s1, s2, S1, S2, b, C, cbase, 0);
 }
 
 __global__ void in_relu_bwd_apply_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x, const float* __restrict__ sc,
@@ -690,7 +767,8 @@ int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w,
   hipStream_t st = as_stream(stream);
   {
     bool handled = false;
-    const int rc = cx_try_aa_row(0, qkv, rel_h, rel_w, o, nullptr, lse, nullptr, nullptr, nullptr, B, H, W, nh, dk, dv, ldq, st, &handled);
+    const int rc = cx_try_aa_row(0, qkv, rel_h, rel_w, o, nullptr, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, nh, dk, dv,
+                                 ldq, st, &handled);
     if (handled) return rc;
   }
   const size_t smem = attn_lds_floats(H, W, dvh) * 4;
@@ -723,12 +801,13 @@ int cx_aa_attention_weights(const void* qkv, const float* rel_h, const float* re
 
 int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w, const float* o, const float* d_o, const float* lse,
                         float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq,
-                        void* stream) {
+                        float* scratch, int64_t scratch_floats, void* stream) {
   if (!qkv || !rel_h || !rel_w || !o || !d_o || !lse || !dqkv || !d_rel_h || !d_rel_w) return CX_EINVAL;
   if (nh <= 0 || dk != nh * DKH || dv % nh || dv / nh > MAXDV || (ldq % 4)) return CX_ESHAPE;
   const int dvh = dv / nh;
   AAGeo g{B, H, W, nh, dk, dv, ldq};
-  const size_t smem_q = (attn_lds_floats(H, W, dvh) + (size_t)DKH * (2 * H - 1 + 2 * W - 1) + (size_t)AQ * (W + 1)) * 4;
+  const size_t smem_q = (attn_lds_floats(H, W, dvh) + (size_t)DKH * (2 * H - 1 + 2 * W - 1) + (size_t)AQ * (W + 1) + (size_t)AQ * (H + 1) +
+                         (size_t)AQ * (DKH + 1)) * 4;
   const size_t smem_k = ((size_t)DKH * (2 * H - 1 + 2 * W - 1) + TK * (DKH + dvh + 2)) * 4;
   if (smem_q > 160 * 1024) return CX_ESHAPE;
   dim3 grid((H * W + AQ - 1) / AQ, B * nh);
@@ -742,37 +821,48 @@ int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
+  // Reproducible relative-table gradients: every query-side workgroup plain-stores its two partial tables into the caller's
+  // workspace (one slab per workgroup: 128 queries of one (image, head)) and the slabs are added in workgroup order afterwards.
+  // Without (enough) workspace the partial tables are added with fp32 atomics, whose order changes from run to run.
+  const int TH = DKH * (2 * H - 1), TW = DKH * (2 * W - 1);
+  const long long nwg = (long long)((H * W + 127) / 128) * B * nh;        // AQ = AQM = 128 queries per workgroup in every q-side kernel
+  float *slab_h = nullptr, *slab_w = nullptr;
+  if (scratch && nwg * (TH + TW) <= scratch_floats && nwg < (1ll << 30)) {
+    slab_h = scratch;
+    slab_w = scratch + nwg * TH;
+  }
   bool row_q = false;
   {
-    const int rc = cx_try_aa_row(1, qkv, rel_h, rel_w, const_cast<float*>(o), d_o, const_cast<float*>(lse), dqkv, d_rel_h, d_rel_w, B, H, W,
-                                 nh, dk, dv, ldq, st, &row_q);
-    if (row_q) return rc;               // dq, dk, dv and the table gradients all done there
+    const int rc = cx_try_aa_row(1, qkv, rel_h, rel_w, const_cast<float*>(o), d_o, const_cast<float*>(lse), dqkv, d_rel_h, d_rel_w, slab_h,
+                                 slab_w, B, H, W, nh, dk, dv, ldq, st, &row_q);
+    if (row_q && rc) return rc;          // dq, dk, dv and the table partials all done there
   }
+  if (!row_q) {
 #define LAUNCH(D)                                                                                                              \
-  if (!row_q)                                                                                                                  \
     hipLaunchKernelGGL(aa_attn_bwd_q_kernel<D>, grid, dim3(AQ), smem_q, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, \
-                       d_rel_h, d_rel_w, g);                                                                                  \
-  hipLaunchKernelGGL(aa_attn_bwd_k_kernel<D>, grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g)
-  switch (dvh) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 3: LAUNCH(3); break;
-    case 4: LAUNCH(4); break;
-    case 6: LAUNCH(6); break;
-    default: return CX_EUNSUPPORTED;
-  }
+                       d_rel_h, d_rel_w, slab_h, slab_w, g);                                                                  \
+    hipLaunchKernelGGL(aa_attn_bwd_k_kernel<D>, grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g)
+    switch (dvh) {
+      case 1: LAUNCH(1); break;
+      case 2: LAUNCH(2); break;
+      case 3: LAUNCH(3); break;
+      case 4: LAUNCH(4); break;
+      case 6: LAUNCH(6); break;
+      default: return CX_EUNSUPPORTED;
+    }
 #undef LAUNCH
-  return launch_status();
+    if (const int e = launch_status()) return e;
+  }
+  if (slab_h) {
+    if (const int e = cx_rows_reduce_add_impl(d_rel_h, slab_h, (int)nwg, TH, TH, st)) return e;
+    return cx_rows_reduce_add_impl(d_rel_w, slab_w, (int)nwg, TW, TW, st);
+  }
+  return 0;
 }
 
 int cx_stats_bc(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream) {
   if (!x || !sum || !sq || C % 8 || C > 2048 || ldx % 8) return CX_EINVAL;
-  int splits = 2048 / B;
-  if (splits < 1) splits = 1;
-  if (splits > HW / 32 + 1) splits = HW / 32 + 1;
-  const int CP = C / 8, threads = CP * (256 / CP > 0 ? 256 / CP : 1);       // a whole number of pixel rows per block
-  hipLaunchKernelGGL(stats_bc_kernel, dim3(splits, B), dim3(threads), 2 * C * sizeof(float), as_stream(stream), (const bf16*)x, sum, sq,
-                     HW, C, ldx, splits);
+  hipLaunchKernelGGL(stats_bc_kernel, dim3((C + 63) / 64, B), dim3(256), 0, as_stream(stream), (const bf16*)x, sum, sq, HW, C, ldx);
   return launch_status();
 }
 
@@ -785,19 +875,28 @@ int cx_affine_relu_bc(const void* x, const float* sc, const float* sh, void* y, 
 }
 
 int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
-                      void* stream) {
+                      int stat_rows, int stat_rstride, void* stream) {
   if (!o || !w || !y || dv <= 0 || dv > 48) return CX_EINVAL;
-  hipLaunchKernelGGL(aa_outproj_fwd_kernel, dim3(grid_for(npix * dv, 256, 2048)), dim3(256), 0, as_stream(stream), o, w, (bf16*)y, ldy,
-                     stat_sum, stat_sq, npix, dv);
+  if ((stat_sum == nullptr) != (stat_sq == nullptr)) return CX_EINVAL;
+  if (stat_rows > 0 && (!stat_sum || stat_rstride < dv)) return CX_EINVAL;
+  const int T = 256 / dv * dv;
+  int grid = grid_for(npix * dv, 256, 2048);
+  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  hipLaunchKernelGGL(aa_outproj_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), o, w, (bf16*)y, ldy, stat_sum, stat_sq, npix, dv,
+                     T, stat_rows > 0 ? 1 : 0, stat_rstride);
   return launch_status();
 }
 
 int cx_aa_outproj_bwd(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
-                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, void* stream) {
+                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, float* scratch, int64_t scratch_floats,
+                      void* stream) {
   if (!g || !gx || !ga || !gb || !gc || !o || !w || !d_o || !dw || dv <= 0 || dv > 48) return CX_EINVAL;
-  hipLaunchKernelGGL(aa_outproj_bwd_kernel, dim3(grid_for(npix, 64, 1024)), dim3(256), 0, as_stream(stream), (const bf16*)g, ldg,
-                     (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, npix, dv);
-  return launch_status();
+  const int grid = grid_for(npix, 64, 1024);
+  float* slab = dw_slab(scratch, scratch_floats, grid, (long long)dv * dv);
+  hipLaunchKernelGGL(aa_outproj_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)g, ldg,
+                     (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(dw, slab, (size_t)dv * dv, grid, as_stream(stream)) : 0;
 }
 
 int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {
@@ -810,13 +909,9 @@ int cx_in_relu_bwd(const void* da, const void* x, const float* sc, const float* 
                    int C, int ldx, int ldg, void* stream) {
   if (!da || !x || !sc || !sh || !S1 || !S2 || !gout) return CX_EINVAL;
   if (C % 8 || C > 2048 || ldx % 8 || ldg % 8) return CX_ESHAPE;
-  int splits = 2048 / B;
-  if (splits < 1) splits = 1;
-  if (splits > HW / 32 + 1) splits = HW / 32 + 1;
   hipStream_t st = as_stream(stream);
-  const int CP = C / 8, threads = CP * (256 / CP > 0 ? 256 / CP : 1);
-  hipLaunchKernelGGL(in_relu_bwd_stats_kernel, dim3(splits, B), dim3(threads), 2 * C * sizeof(float), st, (const bf16*)da, (const bf16*)x,
-                     sc, sh, S1, S2, HW, C, ldx, splits);
+  hipLaunchKernelGGL(in_relu_bwd_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, (const bf16*)da, (const bf16*)x, sc, sh, S1, S2,
+                     HW, C, ldx);
   const size_t total = (size_t)B * HW * (C / 8);
   hipLaunchKernelGGL(in_relu_bwd_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, (const bf16*)da, (const bf16*)x, sc,
                      sh, S1, S2, (bf16*)gout, HW, C, ldx, ldg, total);

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_row_kernel(const bf16* __res
                                                               const float* __restrict__ rel_w, const float* __restrict__ o,
                                                               const float* __restrict__ d_o, const float* __restrict__ lse,
                                                               float* __restrict__ dqkv, float* __restrict__ d_rel_h,
-                                                              float* __restrict__ d_rel_w, const AAGeo g) {
+                                                              float* __restrict__ d_rel_w, float* __restrict__ slab_h, float* __restrict__ slab_w, const AAGeo g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int H = g.H, HW = H * WW;
   const int LH = 2 * H - 1;
@@ -269,8 +269,11 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_row_kernel(const bf16* __res
     for (int d = 0; d < DKH; ++d) dqp[d] = dq[d] * scale;       // q~ = q * scale
   }
   __syncthreads();
-  for (int t = tid; t < DKH * LH; t += AQ) atomicAdd(&d_rel_h[t], dRH[t]);
-  for (int t = tid; t < DKH * LW; t += AQ) atomicAdd(&d_rel_w[t], dRW[t]);
+  {   // the workgroup's partial tables: one slab per workgroup (summed in workgroup order afterwards) or fp32 atomics
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int t = tid; t < DKH * LH; t += AQ) { if (slab_h) slab_h[wg * (DKH * LH) + t] = dRH[t]; else atomicAdd(&d_rel_h[t], dRH[t]); }
+    for (int t = tid; t < DKH * LW; t += AQ) { if (slab_w) slab_w[wg * (DKH * LW) + t] = dRW[t]; else atomicAdd(&d_rel_w[t], dRW[t]); }
+  }
 }
 
 // dk, dv: one lane per KEY, queries stream one query ROW at a time.  aaconv.hip re-reads the two relative tables per
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
                                                                 const float* __restrict__ rel_w, const float* __restrict__ o,
                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                 float* __restrict__ dqkv, float* __restrict__ d_rel_h,
-                                                                float* __restrict__ d_rel_w, const AAGeo g) {
+                                                                float* __restrict__ d_rel_w, float* __restrict__ slab_h, float* __restrict__ slab_w, const AAGeo g) {
   // WW = 40: 16 + 4 keys per lane (two 32-key tiles, the second one a quarter full); WW = 20: 12 slots per lane in one tile, the
   // last four of the upper lane half (kx 20..23) past the row: their logit offset is -inf, so p = ds = 0
   static_assert(WW == 40 || WW == 20, "key rows of 40 or 20");
@@ -657,8 +660,11 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
       }
     }
   }
-  for (int t = tid; t < DKH * LH; t += NT) atomicAdd(&d_rel_h[t], dRH[t]);
-  for (int t = tid; t < DKH * LW; t += NT) atomicAdd(&d_rel_w[t], dRW[t]);
+  {
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int t = tid; t < DKH * LH; t += NT) { if (slab_h) slab_h[wg * (DKH * LH) + t] = dRH[t]; else atomicAdd(&d_rel_h[t], dRH[t]); }
+    for (int t = tid; t < DKH * LW; t += NT) { if (slab_w) slab_w[wg * (DKH * LW) + t] = dRW[t]; else atomicAdd(&d_rel_w[t], dRW[t]); }
+  }
 }
 
 // Forward on the same tiles: S^T = K Q^T per key row by MFMA, online softmax per query over the lane's 20 (12) accumulator slots
@@ -794,7 +800,7 @@ __global__ __launch_bounds__(256) void aa_attn_fwd_mfma_kernel(const bf16* __res
 
 template <int DVH, int WW>
 int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_w, float* o, const float* d_o, float* lse, float* dqkv,
-               float* d_rel_h, float* d_rel_w, const AAGeo& g, hipStream_t st) {
+               float* d_rel_h, float* d_rel_w, float* slab_h, float* slab_w, const AAGeo& g, hipStream_t st) {
   const dim3 grid((g.H * WW + AQ - 1) / AQ, g.B * g.nh);
   const size_t tables = (size_t)DKH * (2 * g.H - 1 + 2 * WW - 1);
   if (which == 0) {
@@ -818,11 +824,11 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
         attr_m = true;
       }
       hipLaunchKernelGGL((aa_attn_bwd_q_mfma_kernel<DVH, WW>), dim3((g.H * WW + AQM - 1) / AQM, g.B * g.nh), dim3(256), smem_m, st,
-                         (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g);
+                         (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, slab_h, slab_w, g);
     } else {
       const size_t smem = (2 * tables + (size_t)WW * (DKH + DVH) + (size_t)AQ * (DKH + 2 + WW + 1)) * 4;
       hipLaunchKernelGGL((aa_attn_bwd_q_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv,
-                         d_rel_h, d_rel_w, g);
+                         d_rel_h, d_rel_w, slab_h, slab_w, g);
     }
     const size_t smem_k = (tables + (size_t)WW * (DKH + DVH + 2 + WW + 1)) * 4;
     hipLaunchKernelGGL((aa_attn_bwd_k_row_kernel<DVH, WW>), grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g);
@@ -832,14 +838,14 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
 
 template <int WW>
 int launch_row_w(int which, int dvh, const void* qkv, const float* rel_h, const float* rel_w, float* o, const float* d_o, float* lse,
-                 float* dqkv, float* d_rel_h, float* d_rel_w, const AAGeo& g, hipStream_t st, bool* handled) {
+                 float* dqkv, float* d_rel_h, float* d_rel_w, float* slab_h, float* slab_w, const AAGeo& g, hipStream_t st, bool* handled) {
   *handled = true;
   switch (dvh) {
-    case 1: return launch_row<1, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g, st);
-    case 2: return launch_row<2, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g, st);
-    case 3: return launch_row<3, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g, st);
-    case 4: return launch_row<4, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g, st);
-    case 6: return launch_row<6, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g, st);
+    case 1: return launch_row<1, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, slab_h, slab_w, g, st);
+    case 2: return launch_row<2, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, slab_h, slab_w, g, st);
+    case 3: return launch_row<3, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, slab_h, slab_w, g, st);
+    case 4: return launch_row<4, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, slab_h, slab_w, g, st);
+    case 6: return launch_row<6, WW>(which, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, slab_h, slab_w, g, st);
     default: *handled = false; return 0;
   }
 }
@@ -848,12 +854,13 @@ int launch_row_w(int which, int dvh, const void* qkv, const float* rel_h, const 
 
 // which: 0 forward (o, lse), 1 the whole backward (dq, dk, dv, d key_rel_h, d key_rel_w).  *handled = false: width not covered.
 int cx_try_aa_row(int which, const void* qkv, const float* rel_h, const float* rel_w, float* o, const float* d_o, float* lse, float* dqkv,
-                  float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq, hipStream_t st, bool* handled) {
+                  float* d_rel_h, float* d_rel_w, float* slab_h, float* slab_w, int B, int H, int W, int nh, int dk, int dv, int ldq,
+                  hipStream_t st, bool* handled) {
   *handled = false;
   if (H > 64) return 0;                  // tables: 20 * (2H-1 + 2W-1) floats per copy
   const AAGeo g{B, H, W, nh, dk, dv, ldq};
   const int dvh = dv / nh;
-  if (W == 40) return launch_row_w<40>(which, dvh, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g, st, handled);
-  if (W == 20) return launch_row_w<20>(which, dvh, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, g, st, handled);
+  if (W == 40) return launch_row_w<40>(which, dvh, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, slab_h, slab_w, g, st, handled);
+  if (W == 20) return launch_row_w<20>(which, dvh, qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, slab_h, slab_w, g, st, handled);
   return 0;
 }

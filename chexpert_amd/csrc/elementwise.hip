@@ -371,6 +371,20 @@ __global__ __launch_bounds__(1024) void bn_coef_moments_kernel(float* mean, floa
   }
 }
 
+// dst[c] += sum over rows (row order): the tall ordered sum behind per-workgroup partial vectors (attention table gradients,
+// EfficientNet per-channel sums)
+__global__ __launch_bounds__(1024) void rows_reduce_add_kernel(float* __restrict__ dst, const float* __restrict__ rows, int n_rows, int C,
+                                                               int rstride, int assign) {
+  __shared__ float part[2][64][17];
+  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + j;
+  const int cc = c < C ? c : C - 1;
+  float s, unused;
+  reduce_rows16<float>(rows, rows, n_rows, rstride, cc, part, s, unused);
+  if (q != 0 || c >= C) return;
+  dst[c] = assign ? s : dst[c] + s;
+}
+
 __global__ void bn_coef_eval_kernel(const float* rmean, const float* rvar, const float* gamma, const float* beta,
                                     float eps, float* scale, float* shift, float* mean, float* rstd, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1236,7 +1250,20 @@ int cx_dw_reduce(float* dw, const float* slab, size_t total, int splits, hipStre
   return launch_status();
 }
 
+int cx_rows_reduce_add_impl(float* dst, const float* rows, int n_rows, int C, int rstride, hipStream_t st) {
+  if (!dst || !rows || n_rows <= 0 || C <= 0 || rstride < C) return CX_EINVAL;
+  hipLaunchKernelGGL(rows_reduce_add_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, dst, rows, n_rows, C, rstride, 0);
+  return launch_status();
+}
+
 extern "C" {
+
+int cx_rows_reduce(float* dst, const float* rows, int n_rows, int C, int rstride, int accumulate, void* stream) {
+  if (!dst || !rows || n_rows <= 0 || C <= 0 || rstride < C) return CX_EINVAL;
+  hipLaunchKernelGGL(rows_reduce_add_kernel, dim3((C + 15) / 16), dim3(1024), 0, as_stream(stream), dst, rows, n_rows, C, rstride,
+                     accumulate ? 0 : 1);
+  return launch_status();
+}
 
 int cx_wgrad_defer(int on) {
   const int was = g_defer.on ? 1 : 0;

@@ -274,7 +274,9 @@ class _Engine:
         # losses and input gradients from run to run).  The AA transitions feed a block's first channels from two different
         # kernels (conv branch + attention out-projection) and stay on the atomic path; CHEXPERT_DET=0 forces it everywhere.
         has_aa = any(isinstance(getattr(f, "transition%d" % (i + 1)).conv, AAConv2d) for i in range(len(model.block_config) - 1))
-        self.det = (not has_aa) and os.environ.get("CHEXPERT_DET", "1") != "0"
+        # (the AA transitions feed a block's first channels from two kernels -- conv branch and attention out-projection: their
+        # statistic rows are reduced one after the other, see _aa_forward)
+        self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
         if has_aa and self.dtype != torch.bfloat16:
             raise NotImplementedError("the fp32 storage mode covers the plain DenseNet path (the attention kernels are bf16)")
         self._plan_vectors()
@@ -494,13 +496,15 @@ class _Engine:
             nt = s["nt"][bi]
             if bi != nb - 1 and isinstance(getattr(f, "transition%d" % (bi + 1)).conv, AAConv2d):
                 # block statistics are still needed by backward (mean / rstd of the buffer channels)
-                if train:
+                bmean, brstd = s["bmr"][bi]
+                if train and det:          # no BatchNorm consumes the block: finish the moments of its last slice here
+                    ops.bn_coef_moments(ws.v(bmean)[:ct], ws.v(brstd)[:ct], cnt, None, None, 1e-5, 0.0, None, None, None, None, ct, fresh)
+                elif train:
                     bsum, bsq = s["bst"][bi]
-                    bmean, brstd = s["bmr"][bi]
                     ops.bn_coef(ws.v(bsum), ws.v(bsq), cnt, None, None, 1e-5, 0.0, None, None, None, None, ws.v(bmean), ws.v(brstd), ct,
                                 replicas=self.stat_replicas, rstride=bsum[1])
                 st = (lambda a: ws.v(a)) if train else (lambda a: None)
-                self._aa_forward(ws, bi, getattr(f, "transition%d" % (bi + 1)).conv, st)
+                fresh = self._aa_forward(ws, bi, getattr(f, "transition%d" % (bi + 1)).conv, st, det)
             elif bi != nb - 1:
                 tr = getattr(f, "transition%d" % (bi + 1))
                 self._bn_block(ws, bi, ct, cnt, tr.norm, nt, train, fresh)
@@ -516,24 +520,39 @@ class _Engine:
             m._nbt_pending += 1
         return ws
 
-    def _aa_forward(self, ws, bi, aa, st):
-        """InstanceNorm -> ReLU -> AAConv2d(3x3, stride 2) from block buffer bi into the first channels of buffer bi+1."""
+    def _aa_forward(self, ws, bi, aa, st, det=False):
+        """InstanceNorm -> ReLU -> AAConv2d(3x3, stride 2) from block buffer bi into the first channels of buffer bi+1.  Returns the
+        pending statistic rows of the attention channels (deterministic mode), which the next norm1 reduces."""
         s = self.slots
         buf, nxt, T = ws.buf[bi], ws.buf[bi + 1], ws.aa[bi]
         B, h, w, ct = buf.shape
         cout = ct // 2
         cc = cout - aa.dv
-        T.stat.zero_()
-        ops.stats_bc(buf, T.stat[0], T.stat[1])
+        ops.stats_bc(buf, T.stat[0], T.stat[1])                 # one owner per (image, channel): plain stores
         ops.bn_coef(T.stat[0], T.stat[1], h * w, None, None, 1e-5, 0.0, None, None, T.coef[0], T.coef[1], None, None, B * ct)
         ops.affine_relu_bc(buf, T.coef[0], T.coef[1], T.A)
         nsum, nsq = s["bst"][bi + 1]
-        ops.conv_gemm(T.A, self.w_fwd(aa.conv), nxt[..., :cc], N=cc, kh=3, kw=3, stride=2, pad=1,
-                      stat_sum=st((nsum[0], cc)), stat_sq=st((nsq[0], cc)))
+        fresh = None
+        if det:
+            # the block's first channels come from two kernels: the conv branch's rows become moments at once (they share the
+            # scratch pair with the out-projection's rows), the attention channels' rows stay pending for the next norm1
+            rows = ops.conv_gemm(T.A, self.w_fwd(aa.conv), nxt[..., :cc], N=cc, kh=3, kw=3, stride=2, pad=1, **self._sp(ws, None, cc))
+            nmean, nrstd = s["bmr"][bi + 1]
+            ops.bn_coef_moments(ws.v(nmean)[:cc], ws.v(nrstd)[:cc], B * (h // 2) * (w // 2), None, None, 1e-5, 0.0, None, None, None, None, cc,
+                                (ws.slab[0], ws.slab[1], rows, cc, 0, cc))
+        else:
+            ops.conv_gemm(T.A, self.w_fwd(aa.conv), nxt[..., :cc], N=cc, kh=3, kw=3, stride=2, pad=1,
+                          stat_sum=st((nsum[0], cc)), stat_sq=st((nsq[0], cc)))
         ops.conv_gemm(T.A, self.w_fwd(aa.in_proj_qkv), T.QKV, N=2 * aa.dk + aa.dv, stride=2)
         ops.aa_attention_fwd(T.QKV, aa.key_rel_h, aa.key_rel_w, T.O, T.LSE, aa.nh, aa.dk, aa.dv)
         object.__setattr__(aa, "_last", (T.QKV, T.LSE))
-        ops.aa_outproj_fwd(T.O, aa.out_proj.weight, nxt[..., cc:cout], st((nsum[0] + cc, aa.dv)), st((nsq[0] + cc, aa.dv)))
+        if det:
+            rows = ops.aa_outproj_fwd(T.O, aa.out_proj.weight, nxt[..., cc:cout], ws.slab[0], ws.slab[1],
+                                      stat_rows=min(self.EW_ROWS, self.SLAB // aa.dv), stat_rstride=aa.dv)
+            fresh = (ws.slab[0], ws.slab[1], rows, aa.dv, cc, aa.dv)
+        else:
+            ops.aa_outproj_fwd(T.O, aa.out_proj.weight, nxt[..., cc:cout], st((nsum[0] + cc, aa.dv)), st((nsq[0] + cc, aa.dv)))
+        return fresh
 
     def _aa_backward(self, ws, bi, aa, qa, qb, qc, G):
         """Backward of the AA transition feeding block bi (from block bi-1); qa/qb/qc apply the deferred BN correction
@@ -555,8 +574,7 @@ class _Engine:
         ops.conv_wgrad(T.dQKV, T.A, G(aa.in_proj_qkv.weight), stride=2)
         ops.conv_wgrad(gs_c, T.A, G(aa.conv.weight), kh=3, kw=3, stride=2, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs_c, ga=qa[:cc],
                        gb=qb[:cc], gc=qc[:cc])
-        T.S.zero_()
-        ops.in_relu_bwd(T.dA, pbuf, T.coef[0], T.coef[1], T.S[0], T.S[1], pg)
+        ops.in_relu_bwd(T.dA, pbuf, T.coef[0], T.coef[1], T.S[0], T.S[1], pg)       # S: one owner per (image, channel), plain stores
 
     # ---- backward
     def backward(self, ws, dlogits):

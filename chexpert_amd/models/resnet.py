@@ -111,7 +111,9 @@ class _Engine:
         self.model = model
         # deterministic statistics (per-workgroup rows summed in row order, as in the DenseNet engine); the attention-augmented
         # bottlenecks feed bn2 from two kernels (conv branch + out-projection) and stay on the atomic path
-        self.det = not any(isinstance(m_, AAConv2d) for m_ in model.modules()) and os.environ.get("CHEXPERT_DET", "1") != "0"
+        # (attention-augmented blocks feed one BatchNorm from two kernels: their statistic rows are reduced per channel range,
+        # _aa_fwd_stats; the two input-gradient branches stack their rows, _stacked)
+        self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
         self.flat = None
         self.device = None
         self.pool = {}
@@ -325,6 +327,51 @@ class _Engine:
             ops.bn_coef_eval(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, v(ws, S.sc), v(ws, S.sh), v(ws, S.mean),
                              v(ws, S.rstd), S.C)
 
+    def _bn_coef_part(self, ws, bn, count, rows, lo, n):
+        """_bn_coef for channels [lo, lo + n) of `bn` from `rows` statistic rows of pitch n (deterministic mode: an AAConv2d's
+        conv branch and its attention out-projection each produce the rows of their own channel range)."""
+        S, v = self.bn[id(bn)], self._v
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        c = lambda t_: t_[lo:lo + n]
+        ops.bn_coef(ws.slab[0], ws.slab[1], count, c(bn.weight), c(bn.bias), bn.eps, mom, c(bn.running_mean), c(bn.running_var),
+                    c(v(ws, S.sc)), c(v(ws, S.sh)), c(v(ws, S.mean)), c(v(ws, S.rstd)), n, replicas=rows, rstride=n)
+
+    def _aa_fwd(self, ws, aa, xin, yout, qkv_t, bn, S, stride, count, train, pro):
+        """AAConv2d forward (attn_aug_conv.py:65-97) into `yout` = [conv branch | attention], with the statistics of the BatchNorm
+        that follows.  Returns True when the coefficients of `bn` have been computed here (deterministic training mode)."""
+        v = self._v
+        p_ = yout.shape[3]
+        cc = p_ - aa.dv
+        det = train and self.det
+        sub = lambda slot, lo, n: None if slot is None else slot[lo:lo + n]
+        st = (lambda s_: v(ws, s_)) if train else (lambda s_: None)
+        if det:
+            rows = ops.conv_gemm(xin, self.w_fwd(aa.conv), yout[..., :cc], N=cc, kh=3, kw=3, stride=stride, pad=1, stat_sum=ws.slab[0],
+                                 stat_sq=ws.slab[1], stat_det=True, stat_replicas=self.SLAB // cc, stat_rstride=cc, **pro)
+            self._bn_coef_part(ws, bn, count, rows, 0, cc)
+        else:
+            ops.conv_gemm(xin, self.w_fwd(aa.conv), yout[..., :cc], N=cc, kh=3, kw=3, stride=stride, pad=1,
+                          stat_sum=sub(st(S.sum), 0, cc), stat_sq=sub(st(S.sq), 0, cc), **pro)
+        ops.conv_gemm(xin, self.w_fwd(aa.in_proj_qkv), qkv_t["QKV"], N=2 * aa.dk + aa.dv, stride=stride, **pro)
+        ops.aa_attention_fwd(qkv_t["QKV"], aa.key_rel_h, aa.key_rel_w, qkv_t["O"], qkv_t["LSE"], aa.nh, aa.dk, aa.dv)
+        object.__setattr__(aa, "_last", (qkv_t["QKV"], qkv_t["LSE"]))
+        if det:
+            rows = ops.aa_outproj_fwd(qkv_t["O"], aa.out_proj.weight, yout[..., cc:], ws.slab[0], ws.slab[1],
+                                      stat_rows=min(self.EW_ROWS, self.SLAB // aa.dv), stat_rstride=aa.dv)
+            self._bn_coef_part(ws, bn, count, rows, cc, aa.dv)
+            return True
+        ops.aa_outproj_fwd(qkv_t["O"], aa.out_proj.weight, yout[..., cc:], sub(st(S.sum), cc, aa.dv), sub(st(S.sq), cc, aa.dv))
+        return False
+
+    def _stacked(self, ws, kw, rows, C):
+        """Mask-epilogue arguments for a SECOND producer of the same backward sums (deterministic mode): its statistic rows go
+        behind the `rows` rows of the first one, so one reduction over rows + rows2 adds both."""
+        if not self.det:
+            return kw
+        kw = dict(kw)
+        kw.update(stat_sum=ws.slab[0][rows * C:], stat_sq=ws.slab[1][rows * C:], stat_replicas=self.SLAB // C - rows)
+        return kw
+
     # ---- forward
     def forward(self, x, train):
         m, v = self.model, self._v
@@ -371,20 +418,15 @@ class _Engine:
             if self.basic:
                 # attn_aug_conv.py:135-156: conv3x3(stride) - bn1 - relu - conv3x3 - bn2, + identity | downsample(x), relu
                 S1, S2 = self.bn[id(b.bn1)], self.bn[id(b.bn2)]
+                coef_done = False
                 if isinstance(b.conv1, AAConv2d):
                     # attn_aug_conv.py:124-131, :65-97: the first 3x3 is attention-augmented (conv branch || attention, on the raw input)
-                    aa, sub = b.conv1, (lambda slot, lo, n: None if slot is None else slot[lo:lo + n])
-                    cc = p_ - aa.dv
-                    ops.conv_gemm(xin, self.w_fwd(aa.conv), t["y1"][..., :cc], N=cc, kh=3, kw=3, stride=s_, pad=1,
-                                  stat_sum=sub(st(S1.sum), 0, cc), stat_sq=sub(st(S1.sq), 0, cc))
-                    ops.conv_gemm(xin, self.w_fwd(aa.in_proj_qkv), t["QKV"], N=2 * aa.dk + aa.dv, stride=s_)
-                    ops.aa_attention_fwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], t["LSE"], aa.nh, aa.dk, aa.dv)
-                    object.__setattr__(aa, "_last", (t["QKV"], t["LSE"]))
-                    ops.aa_outproj_fwd(t["O"], aa.out_proj.weight, t["y1"][..., cc:], sub(st(S1.sum), cc, aa.dv), sub(st(S1.sq), cc, aa.dv))
+                    coef_done = self._aa_fwd(ws, b.conv1, xin, t["y1"], t, b.bn1, S1, s_, B * ho * wo, train, {})
                     rows = None
                 else:
                     rows = ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, kh=3, kw=3, stride=s_, pad=1, **sp(S1))
-                self._bn_coef(ws, b.bn1, B * ho * wo, train, rows)
+                if not coef_done:
+                    self._bn_coef(ws, b.bn1, B * ho * wo, train, rows)
                 rows = ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=1, pad=1,
                                      prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh), **sp(S2))
                 self._bn_coef(ws, b.bn2, B * ho * wo, train, rows)
@@ -402,23 +444,17 @@ class _Engine:
             S1, S2, S3 = self.bn[id(b.bn1)], self.bn[id(b.bn2)], self.bn[id(b.bn3)]
             rows = ops.conv_gemm(xin, self.w_fwd(b.conv1), t["y1"], N=p_, **sp(S1))
             self._bn_coef(ws, b.bn1, B * hi * wi, train, rows)
+            coef_done = False
             if isinstance(b.conv2, AAConv2d):
                 # attn_aug_conv.py:65-97: 3x3 conv branch || multi-head attention over the stride-s grid, concatenated on channels
-                aa, sub = b.conv2, (lambda slot, lo, n: None if slot is None else slot[lo:lo + n])
-                cc = p_ - aa.dv
-                ops.conv_gemm(t["y1"], self.w_fwd(aa.conv), t["y2"][..., :cc], N=cc, kh=3, kw=3, stride=s_, pad=1,
-                              prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh), stat_sum=sub(st(S2.sum), 0, cc),
-                              stat_sq=sub(st(S2.sq), 0, cc))
-                ops.conv_gemm(t["y1"], self.w_fwd(aa.in_proj_qkv), t["QKV"], N=2 * aa.dk + aa.dv, stride=s_,
-                              prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh))
-                ops.aa_attention_fwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], t["LSE"], aa.nh, aa.dk, aa.dv)
-                object.__setattr__(aa, "_last", (t["QKV"], t["LSE"]))
-                ops.aa_outproj_fwd(t["O"], aa.out_proj.weight, t["y2"][..., cc:], sub(st(S2.sum), cc, aa.dv), sub(st(S2.sq), cc, aa.dv))
+                coef_done = self._aa_fwd(ws, b.conv2, t["y1"], t["y2"], t, b.bn2, S2, s_, B * ho * wo, train,
+                                         dict(prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh)))
                 rows = None
             else:
                 rows = ops.conv_gemm(t["y1"], self.w_fwd(b.conv2), t["y2"], N=p_, kh=3, kw=3, stride=s_, pad=1,
                                      prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh), **sp(S2))
-            self._bn_coef(ws, b.bn2, B * ho * wo, train, rows)
+            if not coef_done:
+                self._bn_coef(ws, b.bn2, B * ho * wo, train, rows)
             rows = ops.conv_gemm(t["y2"], self.w_fwd(b.conv3), t["y3"], N=4 * p_, prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S2.sc),
                                  pb=v(ws, S2.sh), **sp(S3))
             self._bn_coef(ws, b.bn3, B * ho * wo, train, rows)
@@ -562,9 +598,11 @@ class _Engine:
                                      G(aa.key_rel_w), aa.nh, aa.dk, aa.dv)
                 ops.f32_to_bf16(dQ32, dQ)
                 # both branches end in the same bn1 + ReLU mask: the conv branch writes dz1, the attention branch adds to it
-                ops.conv_gemm(gs_c, self.w_bwd(aa.conv), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=ys_c,
-                              pa=qa[:cc], pb=qb[:cc], pc=qc[:cc], **mask1)
-                ops.conv_gemm(dQ, self.w_bwd(aa.in_proj_qkv), dz1, N=p_, tstride=s_, accumulate=True, **mask1)
+                rows = ops.conv_gemm(gs_c, self.w_bwd(aa.conv), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=ys_c,
+                                     pa=qa[:cc], pb=qb[:cc], pc=qc[:cc], **mask1)
+                rows2 = ops.conv_gemm(dQ, self.w_bwd(aa.in_proj_qkv), dz1, N=p_, tstride=s_, accumulate=True,
+                                      **self._stacked(ws, mask1, rows or 0, S1.C))
+                rows = (rows or 0) + (rows2 or 0) if det else None
                 ops.conv_wgrad(gs_c, t["y1"], G(aa.conv.weight), kh=3, kw=3, stride=s_, pad=1, g_prologue=ops.PRO_AFFINE2, g2=ys_c,
                                ga=qa[:cc], gb=qb[:cc], gc=qc[:cc], x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc), pb=v(ws, S1.sh))
                 ops.conv_wgrad(dQ, t["y1"], G(aa.in_proj_qkv.weight), stride=s_, x_prologue=ops.PRO_AFFINE_RELU, pa=v(ws, S1.sc),

@@ -458,20 +458,47 @@ def aa_attention_weights(qkv, key_rel_h, key_rel_w, lse, nh, dk, dv):
 
 
 def aa_attention_bwd(qkv, key_rel_h, key_rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, nh, dk, dv):
+    """With the slab workspace on (set_det_wgrad) the relative-table gradients are summed in workgroup order (reproducible)."""
     B, H, W, Cq, ldq = _nhwc(qkv)
+    ws = wgrad_scratch(qkv.device)                 # partial tables are consumed inside the call: the per-stream scratch is enough
+    need = ((H * W + 127) // 128) * B * nh * (dk // nh) * (2 * H - 1 + 2 * W - 1)
+    if ws is not None and ws.numel() < need:
+        ws = _big_scratch(qkv.device, need)
     check(lib().cx_aa_attention_bwd(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(o), ptr(d_o), ptr(lse), ptr(dqkv), ptr(d_rel_h),
-                                    ptr(d_rel_w), B, H, W, nh, dk, dv, ldq, stream_ptr()), "cx_aa_attention_bwd")
+                                    ptr(d_rel_w), B, H, W, nh, dk, dv, ldq, ptr(ws), 0 if ws is None else ws.numel(), stream_ptr()),
+          "cx_aa_attention_bwd")
 
 
-def aa_outproj_fwd(o, w, y, stat_sum, stat_sq):
+_big = {}
+
+
+def _big_scratch(device, floats):
+    """A larger per-(device, stream) workspace for the few calls whose partial results exceed the default slab buffer."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _big.get(key)
+    if t is None or t.numel() < floats:
+        t = _big[key] = torch.empty(int(floats), dtype=torch.float32, device=device)
+    return t
+
+
+def aa_outproj_fwd(o, w, y, stat_sum, stat_sq, stat_rows=0, stat_rstride=0):
+    """stat_rows > 0: deterministic statistic rows (returns the number written), else atomics into stat_sum / stat_sq."""
     B, H, W, dv, ldy = _nhwc(y)
-    check(lib().cx_aa_outproj_fwd(ptr(o), ptr(w), ptr(y), ldy, ptr(stat_sum), ptr(stat_sq), B * H * W, dv, stream_ptr()), "cx_aa_outproj_fwd")
+    check(lib().cx_aa_outproj_fwd(ptr(o), ptr(w), ptr(y), ldy, ptr(stat_sum), ptr(stat_sq), B * H * W, dv, stat_rows, stat_rstride,
+                                  stream_ptr()), "cx_aa_outproj_fwd")
+    return lib().cx_last_stat_rows() if stat_rows > 0 else None
 
 
 def aa_outproj_bwd(g, gx, ga, gb, gc, o, w, d_o, dw):
     B, H, W, dv, ldg = _nhwc(g)
+    ws, arena, dfr = _wgrad_ws(dw.device)
     check(lib().cx_aa_outproj_bwd(ptr(g), ldg, ptr(gx), _nhwc(gx)[4], ptr(ga), ptr(gb), ptr(gc), ptr(o), ptr(w), ptr(d_o), ptr(dw),
-                                  B * H * W, dv, stream_ptr()), "cx_aa_outproj_bwd")
+                                  B * H * W, dv, ptr(ws), 0 if ws is None else ws.numel(), stream_ptr()), "cx_aa_outproj_bwd")
+    _wgrad_used(arena, dfr)
+
+
+def rows_reduce(dst, rows, n_rows, C, rstride, accumulate=True):
+    check(lib().cx_rows_reduce(ptr(dst), ptr(rows), n_rows, C, rstride, int(accumulate), stream_ptr()), "cx_rows_reduce")
 
 
 def stats_bc(x, s, q):

@@ -295,16 +295,25 @@ int cx_aa_attention_fwd(const void* qkv, const float* key_rel_h, const float* ke
  * AAConv2d.weights after a forward (:87) and vis_attn reads (chexpert.py:383); visualisation only                   */
 int cx_aa_attention_weights(const void* qkv, const float* key_rel_h, const float* key_rel_w, const float* lse, float* weights, int B,
                             int H, int W, int nh, int dk, int dv, int ldq, void* stream);
-/* dqkv: fp32 (B, H*W, 2dk+dv) fully written; d_rel_h / d_rel_w (dkh, 2H-1 / 2W-1) accumulated with atomics */
+/* dqkv: fp32 (B, H*W, 2dk+dv) fully written; d_rel_h / d_rel_w (dkh, 2H-1 / 2W-1) ACCUMULATED.  With a workspace of
+ * ceil(HW/128)*B*nh * dkh*(2H-1 + 2W-1) floats every query-side workgroup stores its partial tables and they are added in
+ * workgroup order (bit-reproducible); scratch == NULL or too small: fp32 atomics                                          */
 int cx_aa_attention_bwd(const void* qkv, const float* key_rel_h, const float* key_rel_w, const float* o, const float* d_o,
                         const float* lse, float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv,
-                        int ldq, void* stream);
-/* out_proj (dv x dv, :92) forward into a bf16 channel slice (+stats) and its backward (dY = g*ga+gx*gb+gc) */
+                        int ldq, float* scratch, int64_t scratch_floats, void* stream);
+/* out_proj (dv x dv, :92) forward into a bf16 channel slice (+stats) and its backward (dY = g*ga+gx*gb+gc).
+ * stat_rows > 0: deterministic statistic rows as CxConv.stat_det (row r at stat_sum[r*stat_rstride + c], at most stat_rows rows,
+ * cx_last_stat_rows() tells how many); 0: one fp32 atomic per channel and workgroup.  The backward's dW partial tiles go
+ * through the CxWgrad.scratch protocol (and the deferred sums) when a workspace is given.                                  */
 int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
-                      void* stream);
+                      int stat_rows, int stat_rstride, void* stream);
 int cx_aa_outproj_bwd(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
-                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, void* stream);
-/* InstanceNorm2d + ReLU ahead of the AAConv2d (:438-439): per-(b,c) sums, per-(b,c) affine+ReLU, and the backward */
+                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, float* scratch, int64_t scratch_floats,
+                      void* stream);
+/* dst[c] (+)= rows[0*rstride + c] + rows[1*rstride + c] + ... in row order (accumulate != 0: added to dst, else assigned)      */
+int cx_rows_reduce(float* dst, const float* rows, int n_rows, int C, int rstride, int accumulate, void* stream);
+/* InstanceNorm2d + ReLU ahead of the AAConv2d (:438-439): per-(b,c) sums, per-(b,c) affine+ReLU, and the backward.  The sums are
+ * plain stores from one owner per (b, c) (no atomics, no zero-fill needed, bit-reproducible)                                 */
 int cx_stats_bc(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream);
 int cx_affine_relu_bc(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream);
 int cx_in_relu_bwd(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,

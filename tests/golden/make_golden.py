@@ -317,8 +317,8 @@ def gen_smooth(out_dir, which):
             from oracle import step as ostep
             _, lq, _ = ostep.train_step(lambda s, xx: fwd(s, xx, train=True, q=nets.bf16_storage), {k: v.clone() for k, v in sd.items()}, x, t)
             want = torch.tensor(out[tag]["logits_train"])
-            print("[%s] storage-rounded oracle vs reference: train logits %.2e of absmax" % (
-                tag, (lq - want).abs().max() / want.abs().max()))
+            out[tag]["bf16_storage_logits_rel"] = float((lq - want).abs().max() / want.abs().max())
+            print("[%s] storage-rounded oracle vs reference: train logits %.2e of absmax" % (tag, out[tag]["bf16_storage_logits_rel"]))
         json.dump(out, open(path, "w"))
 
 

@@ -303,6 +303,48 @@ def test_resnet_training_step_is_reproducible_bit_for_bit(dev):
             assert torch.equal(g0, runs[i][2][k]), "%s differs between runs" % k
 
 
+def _three_identical_steps(model, x, t):
+    runs = []
+    for _ in range(3):
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        model.zero_grad()
+        loss, logits = model.forward_backward(x, t)
+        runs.append((loss.clone(), logits.clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()},
+                     {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+        model.load_state_dict(sd)
+    for i in (1, 2):
+        assert torch.equal(runs[0][0], runs[i][0]) and torch.equal(runs[0][1], runs[i][1]), "loss / logits differ between runs"
+        for k in runs[0][3]:
+            assert torch.equal(runs[0][3][k], runs[i][3][k]), k
+        for k, g0 in runs[0][2].items():
+            assert torch.equal(g0, runs[i][2][k]), "%s differs between runs" % k
+
+
+@pytest.mark.parametrize("cfg,B,S", [((6, 4, 2, 2), 4, 64), ((6, 12, 24, 16), 2, 320)])
+def test_aa_densenet_training_step_is_reproducible_bit_for_bit(dev, cfg, B, S):
+    """The attention-augmented DenseNet (chexpert.py:475-480): InstanceNorm sums with one owner per (image, channel), the two
+    producers of a block's first channels reduced one after the other, attention table gradients and the out-projection weight
+    gradient through slabs summed in workgroup order."""
+    from chexpert_amd.models import DenseNet
+    torch.manual_seed(13)
+    model = DenseNet(32, cfg, 64, num_classes=5, attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (S, S)})
+    model = model.to(dev).train()
+    assert model._eng().det
+    _three_identical_steps(model, synth.xray_batch(520, B, S).to(dev), synth.targets(521, B, 5).to(dev))
+
+
+@pytest.mark.parametrize("kind,layers,B,S", [("bottleneck", [1, 2, 2, 1], 4, 64), ("bottleneck", [3, 8, 36, 3], 1, 320),
+                                             ("basic", [2, 2, 2, 2], 4, 128)])
+def test_aa_resnet_training_step_is_reproducible_bit_for_bit(dev, kind, layers, B, S):
+    """aaresnet (chexpert.py:486-494; BasicBlock form: models/test_model.py --attn): AAConv2d inside the blocks."""
+    from chexpert_amd.models import BasicBlock, Bottleneck, ResNet
+    torch.manual_seed(14)
+    model = ResNet(Bottleneck if kind == "bottleneck" else BasicBlock, layers, num_classes=5,
+                   attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (S, S)}).to(dev).train()
+    assert model._eng().det
+    _three_identical_steps(model, synth.xray_batch(530, B, S).to(dev), synth.targets(531, B, 5).to(dev))
+
+
 @pytest.mark.parametrize("case", ["fused_1x1", "fused_1x1_narrow", "strip_3x3", "strip_3x3_wide", "ring_3x3", "pool2", "stem", "generic_3x3s2",
                                   "wgrad_mm"])
 def test_weight_gradient_slabs_equal_atomics_and_repeat_bit_for_bit(dev, det_wgrad, case):
