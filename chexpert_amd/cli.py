@@ -65,6 +65,8 @@ def build_parser():
     p.add_argument("--fused_optimizer", action="store_true", help="one-kernel optimiser on the flat parameter buffer")
     p.add_argument("--graph", action="store_true", help="capture the training step as a hipGraph (needs --fused_optimizer)")
     p.add_argument("--jitter", action="store_true", help="brightness / contrast jitter +-0.25 on the uint8 image (GPU)")
+    p.add_argument("--num_workers", type=int, default=int(os.environ.get("CHEXPERT_NUM_WORKERS", "16")), help="decode / crop worker processes of the training loader (chexpert.py:77: "
+                   "16); 0 = in-process")
     return p
 
 
@@ -248,17 +250,10 @@ def main(argv=None):
         cfg_path = os.path.join(args.output_dir, "config.json")
         if not os.path.exists(cfg_path):
             json.dump(args.__dict__, open(cfg_path, "w"), indent=4)
-    if not torch.cuda.is_available():
-        raise RuntimeError("chexpert_amd needs an MI355X (no CPU fallback)")
-    device = torch.device("cuda:%d" % (args.cuda or 0))
-    torch.cuda.set_device(device)
-    if args.seed:
-        torch.manual_seed(args.seed)
-        np.random.seed(args.seed)
-    model, optimizer, scheduler = make_model(args, device)
-    if args.restore and os.path.isfile(args.restore):
-        restore(args, model, optimizer, scheduler, device)
+    # datasets and the training loader come BEFORE the first GPU call: its worker processes are forked from a process that has
+    # not initialised the GPU runtime and never touch the card (chexpert_amd/loader.py)
     size = args.resize or 320
+    device = torch.device("cuda:%d" % (args.cuda or 0))
     if args.synthetic:
         n_valid = max(args.batch_size, args.synthetic // 5)
         train_ds = SyntheticXrays(args.mini_data or args.synthetic, size, args.n_classes, 7)
@@ -269,6 +264,19 @@ def main(argv=None):
             raise RuntimeError("pass --data_path <folder holding CheXpert-v1.0-small> or --synthetic N (no download here)")
         train_ds = ChexpertCSV(args.data_path, "train", args.resize, mini_data=args.mini_data)
         valid_ds = ChexpertCSV(args.data_path, "valid", args.resize, mini_data=args.mini_data)
+    train_loader = None
+    if args.train:
+        from .loader import RingLoader
+        train_loader = RingLoader(train_ds, args.batch_size, num_workers=args.num_workers, slots=4, device=device)
+    if not torch.cuda.is_available():
+        raise RuntimeError("chexpert_amd needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(device)
+    if args.seed:
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
+    model, optimizer, scheduler = make_model(args, device)
+    if args.restore and os.path.isfile(args.restore):
+        restore(args, model, optimizer, scheduler, device)
     loss_fn = nn.BCEWithLogitsLoss(reduction="none")
     if rank == 0:
         print("Loaded %s (number of parameters: %s; weights trained to step %d)" % (
@@ -298,16 +306,26 @@ def main(argv=None):
         for epoch in range(args.n_epochs):
             model.train()
             idx = P.shard_indices(len(train_ds), rank, world, seed=args.seed or 1, epoch=epoch)
-            for x, t, _ in batches(train_ds, idx, args.batch_size, True):
+            if not idx:
+                raise RuntimeError("the training set (%d images over %d ranks) yields no minibatch" % (len(train_ds), world))
+            # every image is seen each epoch, as with the reference's DataLoader (drop_last=False, chexpert.py:76): the last,
+            # partial minibatch runs as an eager step (the hipGraph is captured on the full batch's shapes)
+            for x, t, _ in train_loader.batches(idx, drop_last=False):
                 args.step += 1
-                x, t = x.to(device), t.to(device)
                 if args.jitter:
                     x = jitter(x, args.step)
-                if args.graph and fused and world == 1:
-                    if gstep is None:                       # captured on the first minibatch's shapes
+                if args.graph and fused and world == 1 and (gstep is not None or x.shape[0] == args.batch_size):
+                    if gstep is None:                       # captured on the first full minibatch's shapes
                         from .graph import GraphedTrainStep
                         gstep = GraphedTrainStep(model, optimizer, x, t, warmup_steps=int(args.lr_warmup_steps))
-                    loss, _ = gstep.replay(x, t)
+                    if x.shape[0] == args.batch_size:
+                        loss, _ = gstep.replay(x, t)
+                    else:                                   # same device-resident optimiser / scheduler state, launched one by one
+                        optimizer.zero_grad()
+                        loss, _ = model.forward_backward(x, t)
+                        optimizer.step_dev()
+                        optimizer.tick()
+                        model._eng().packed_version = None
                 elif fused:
                     optimizer.zero_grad()
                     loss, _ = model.forward_backward(x, t)  # chexpert.py:159-163 as one fused schedule
@@ -335,6 +353,7 @@ def main(argv=None):
                                         optimizer.state_dict(), sched_state, args)
                     model.train()
             run_eval("eval_results_step_%d" % args.step)
+        train_loader.close()
     if args.evaluate_single_model:
         run_eval("eval_results_step_%d" % args.step)
     if args.evaluate_ensemble:

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("CHEXPERT_NUM_WORKERS", "2")      # CLI runs inside the suite: two loader workers (the default is the reference's 16)
 
 
 def pytest_configure(config):

@@ -322,6 +322,69 @@ def gen_smooth(out_dir, which):
         json.dump(out, open(path, "w"))
 
 
+def gen_dataset(out_dir):
+    """The dataset logic of the reference on a generated table (tests/golden/dataset.json): U-Ones processing with and without a
+    data filter (dataset.py:134-153), the `vis` subset (:50-68), `mini_data`, `test` mode (:33-37), item labels / source indices
+    (:73-89) and extract_patient_ids (:156-160).  The table itself (hash-made, the reference's csv columns) is part of the fixture.
+    torch >= 2.6 refuses to unpickle the DataFrame the reference caches with torch.save (weights_only default): torch.load is
+    wrapped to pass weights_only=False -- an environment adaptation, every dataset statement executed is the reference's own."""
+    import tempfile
+    import pandas as pd
+    import dataset as ref_ds
+    _load = torch.load
+    ref_ds.torch.load = lambda f, *a, **k: _load(f, *a, **dict(k, weights_only=False))
+    C = ref_ds.ChexpertSmall
+    cols = ["Path", "Sex", "Age", "Frontal/Lateral", "AP/PA"] + C.attr_all_names
+
+    def table(n, seed, split, complete):
+        u = synth.uniform01(seed, n * (len(C.attr_all_names) + 2)).reshape(n, -1)
+        rows = []
+        for i in range(n):
+            lat = u[i, 0] < 0.25
+            labs = []
+            for j in range(len(C.attr_all_names)):
+                v = u[i, 2 + j]
+                if complete:
+                    labs.append(1.0 if v < 0.3 else 0.0)
+                else:
+                    labs.append(1.0 if v < 0.22 else (0.0 if v < 0.5 else (-1.0 if v < 0.65 else None)))
+            rows.append(["%s/%s/patient%05d/study%d/view1_%s.jpg" % (C.dir_name, split, 100 + i // 2, 1 + i % 2, "lateral" if lat else "frontal"),
+                         "Male" if u[i, 1] < 0.5 else "Female", 20 + int(60 * u[i, 1]), "Lateral" if lat else "Frontal",
+                         None if lat else ("AP" if u[i, 1] < 0.7 else "PA")] + labs)
+        return rows
+
+    train_rows, valid_rows = table(48, 4242, "train", False), table(40, 4343, "valid", True)
+    rec = {"columns": cols, "train_rows": train_rows, "valid_rows": valid_rows, "attr_names": C.attr_names}
+    flt = {"Frontal/Lateral": "Frontal"}
+    for tag, data_filter in (("plain", None), ("filtered", flt)):
+        with tempfile.TemporaryDirectory() as root:
+            d = os.path.join(root, C.dir_name)
+            os.makedirs(d)
+            pd.DataFrame(train_rows, columns=cols).to_csv(os.path.join(d, "train.csv"), index=False)
+            pd.DataFrame(valid_rows, columns=cols).to_csv(os.path.join(d, "valid.csv"), index=False)
+            tr = C(root, "train", data_filter=data_filter)
+            r = {"train_index": [int(i) for i in tr.data.index], "train_labels": tr.data[C.attr_names].values.astype(float).tolist()}
+            # labels / source index of items as __getitem__ returns them (:81-87), without opening the image file
+            r["train_items"] = [[tr.data.iloc[k, tr.attr_idxs].values.astype(np.float32).tolist(), int(tr.data.index[k])] for k in (0, 5, len(tr) - 1)]
+            if data_filter is None:
+                mini = C(root, "train", mini_data=7)
+                r["mini_len"] = len(mini)
+                va = C(root, "valid")
+                r["valid_len"], r["valid_labels_head"] = len(va), va.data[C.attr_names].values[:6].astype(float).tolist()
+                vis = C(root, "vis")
+                r["vis_attrs"], r["vis_idxs"] = vis.vis_attrs, [[int(i) for i in g] for g in vis.vis_idxs]
+                r["vis_index"] = [int(i) for i in vis.data.index]
+                r["patient_ids"] = ref_ds.extract_patient_ids(va, [0, 3, 17]).tolist()
+                tcsv = os.path.join(root, "paths.csv")
+                pd.DataFrame({"Path": [row[0] for row in valid_rows[:5]]}).to_csv(tcsv, index=False)
+                te = C(tcsv, "test")
+                r["test_len"], r["test_labels"] = len(te), te.data[C.attr_names].values.astype(float).tolist()
+            rec[tag] = r
+    json.dump(rec, open(os.path.join(out_dir, "dataset.json"), "w"))
+    print("[dataset] %d train rows -> %d after the Frontal filter; vis groups %s" % (
+        len(rec["plain"]["train_index"]), len(rec["filtered"]["train_index"]), [len(g) for g in rec["plain"]["vis_idxs"]]))
+
+
 def gen_gradcam(out_dir):
     """Runs the reference `grad_cam` itself.  torch 2.10 rejects its in-place normalisation of an
     autograd view (chexpert.py:290-294), so `chexpert.F.relu` alone is wrapped to hand back a detached
@@ -419,10 +482,14 @@ if __name__ == "__main__":
         gen_auroc(HERE)
     if not which or "gradcam" in which:
         gen_gradcam(HERE)
+    if not which or "dataset" in which:
+        gen_dataset(HERE)
+        if which == ["dataset"]:
+            sys.exit(0)
     if "smooth" in which:              # python make_golden.py smooth [tag substrings]
         gen_smooth(HERE, [w for w in which if w != "smooth"])
         sys.exit(0)
-    net_sel = [w for w in which if w not in ("aaconv", "auroc", "gradcam", "nets")]
+    net_sel = [w for w in which if w not in ("aaconv", "auroc", "gradcam", "nets", "dataset")]
     if not which or "nets" in which or net_sel:
         gen_nets(HERE, net_sel)
     if not which:

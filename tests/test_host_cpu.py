@@ -382,3 +382,78 @@ def test_cifar_harness_host_logic(tmp_path):
     assert xs.shape == (10, 3, 32, 32) and ys.tolist() == [1, 8, 2, 7, 3, 6, 4, 5, 5, 4] and int(xs[4, 0, 0, 0]) == 3
     lb = cifar.Batches(xs, ys, 4, shuffle=False, aug=False, seed=0)
     assert len(lb) == 3 and [b[1].tolist() for b in lb][2] == [5, 4]
+
+
+def test_ring_loader_workers_fill_shared_ring(tmp_path):
+    """chexpert_amd/loader.py: worker processes decode into the shared uint8 ring; batches arrive in order, the last one partial
+    (the reference's DataLoader keeps it, chexpert.py:76), a pass abandoned half-way does not leak into the next one, and the
+    decoded bytes equal the dataset's own __getitem__ (generated JPEG folder with the reference's csv columns)."""
+    from chexpert_amd.cli import SyntheticXrays
+    from chexpert_amd.data import ChexpertCSV
+    from chexpert_amd.loader import RingLoader, make_jpeg_folder
+    ds = SyntheticXrays(21, 32, 5, 3)
+    ld = RingLoader(ds, 8, num_workers=3, slots=2)
+    try:
+        assert ld.start_method == "fork"                         # nothing has touched a GPU here: workers are plain forks
+        for epoch in range(2):
+            idx = list(range(21)) if epoch == 0 else list(range(20, -1, -1))
+            got = list(ld.batches(idx))
+            assert [b[0].shape[0] for b in got] == [8, 8, 5]
+            flat = [i for b in got for i in b[2].tolist()]
+            assert flat == idx
+            for x, t, ii in got:
+                for j, i in enumerate(ii.tolist()):
+                    assert torch.equal(x[j], ds[i][0]) and torch.equal(t[j], ds[i][1])
+        it = ld.batches(list(range(21)))
+        next(it)                                                 # abandon the pass after one batch
+        del it
+        got = list(ld.batches(list(range(16)), drop_last=True))
+        assert [b[2].tolist() for b in got] == [list(range(8)), list(range(8, 16))]
+        assert torch.equal(got[1][0][3], ds[11][0])
+    finally:
+        ld.close()
+    make_jpeg_folder(str(tmp_path), n=12, w=78, h=64)
+    dj = ChexpertCSV(str(tmp_path), "train", resize=48)
+    lj = RingLoader(dj, 5, num_workers=2)
+    try:
+        for x, t, ii in lj.batches(list(range(12))):
+            for j, i in enumerate(ii.tolist()):
+                assert torch.equal(x[j], dj[i][0]) and torch.equal(t[j], dj[i][1])
+            assert set(t.flatten().tolist()) <= {0.0, 1.0}      # U-Ones: blanks -> 0, uncertain -> 1 (dataset.py:139-142)
+    finally:
+        lj.close()
+
+
+def test_dataset_logic_against_reference_fixture(tmp_path):
+    """chexpert_amd.data.ChexpertCSV against what the REAL reference's ChexpertSmall produced on the same table
+    (tests/golden/dataset.json, written by make_golden.py `dataset`): U-Ones processing with / without a data filter
+    (dataset.py:134-153), the vis subset (:50-68), mini_data, test mode (:33-37), item labels / source indices (:73-89),
+    extract_patient_ids (:156-160)."""
+    import json
+    import pandas as pd
+    from chexpert_amd.data import ChexpertCSV, DIR_NAME, extract_patient_ids
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "dataset.json")))
+    assert rec["attr_names"] == ChexpertCSV.attr_names
+    d = tmp_path / DIR_NAME
+    d.mkdir()
+    pd.DataFrame(rec["train_rows"], columns=rec["columns"]).to_csv(d / "train.csv", index=False)
+    pd.DataFrame(rec["valid_rows"], columns=rec["columns"]).to_csv(d / "valid.csv", index=False)
+    for tag, flt in (("plain", None), ("filtered", {"Frontal/Lateral": "Frontal"})):
+        want = rec[tag]
+        tr = ChexpertCSV(str(tmp_path), "train", data_filter=flt)
+        assert [int(i) for i in tr.data.index] == want["train_index"]
+        assert tr.targets.tolist() == want["train_labels"]
+        for k, (lab, src) in zip((0, 5, len(tr) - 1), want["train_items"]):
+            assert tr.targets[k].tolist() == lab and int(tr.data.index[k]) == src
+    want = rec["plain"]
+    assert len(ChexpertCSV(str(tmp_path), "train", mini_data=7)) == want["mini_len"] == 7
+    va = ChexpertCSV(str(tmp_path), "valid")
+    assert len(va) == want["valid_len"] and va.targets[:6].tolist() == want["valid_labels_head"]
+    vis = ChexpertCSV(str(tmp_path), "vis")
+    assert vis.vis_attrs == want["vis_attrs"] and vis.vis_idxs == want["vis_idxs"]
+    assert [int(i) for i in vis.data.index] == want["vis_index"]
+    assert list(extract_patient_ids(va, [0, 3, 17])) == want["patient_ids"]
+    tcsv = tmp_path / "paths.csv"
+    pd.DataFrame({"Path": [r[0] for r in rec["valid_rows"][:5]]}).to_csv(tcsv, index=False)
+    te = ChexpertCSV(str(tcsv), "test")
+    assert len(te) == want["test_len"] and te.targets.tolist() == want["test_labels"]

@@ -109,18 +109,17 @@ def test_resnet152_matches_reference_golden_fixture(dev):
     e = _rel(le, torch.tensor(rec["logits_eval"]))
     print("resnet152 golden eval logits rel %.3e" % e)
     assert e < 1e-2
-    # train mode at B=2: 152 layers of batch-statistic BatchNorm amplify bf16 storage rounding chaotically with
-    # hash-filled weights; the fp32 oracle with storage rounding only (q=bf16_storage) is the yardstick
-    from oracle import step
-    xc, tc = x.cpu(), t.cpu()
-    fwd = lambda q: (lambda s, xx: nets.resnet_forward(s, xx, train=True, q=q))
-    _, lq, _ = step.train_step(fwd(nets.bf16_storage), {k: v.clone() for k, v in sd.items()}, xc, tc)
+    # train mode at B=2 with hash-filled weights (negative gains) over 152 layers of batch-statistic BatchNorm: storage rounding is
+    # amplified chaotically (the storage-rounded fp32 oracle is itself 2e-1 away).  Order-of-magnitude smoke only, literal bound
+    # (measured 2.4e-1); the train-mode parity statement is tests/test_golden_smooth_gpu.py (resnet152_320_b8: 1.1e-2).
     want = torch.tensor(rec["logits_train"])
     model.train()
     loss, logits = model.forward_backward(x, t)
-    e, eq = _rel(logits.cpu(), want), _rel(lq, want)
-    print("resnet152 golden train logits (B=2): HIP vs reference %.3e; storage-rounded oracle vs reference %.3e" % (e, eq))
-    assert e < max(2e-2, 2.0 * eq)
+    e = _rel(logits.cpu(), want)
+    print("resnet152 golden train logits (B=2, hash weights): HIP vs reference %.3e" % e)
+    assert torch.isfinite(logits).all() and e < 0.6
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
 @pytest.mark.parametrize("layers,B,S", [((1, 1, 1, 1), 8, 128), ((1, 2, 2, 1), 8, 128)])
@@ -217,34 +216,15 @@ def test_aaresnet152_reference_golden_train_step(dev):
     want = torch.tensor(rec["logits_train"])
     e = _rel(logits.cpu(), want)
     print("aaresnet152 golden train logits rel %.3e loss %.5f (ref %.5f)" % (e, loss.item(), rec["loss"]))
-    # B = 1 and 100 values per channel in layer4: the fp32 oracle with bf16 rounding of the stored activations alone
-    # (oracle.nets.bf16_storage) is e_q = 9.7e-2 away from the reference on this fixture, and the fp32 oracle itself differs from
-    # the reference by 2.5 % on gradient norms (make_golden.py prints it): limits are set by that conditioning
-    from oracle.step import bce_sum_mean
-    checked = ("fc.weight", "fc.bias", "layer4.2.conv2.key_rel_h", "layer3.5.conv2.in_proj_qkv.weight", "layer2.0.conv2.conv.weight")
-    sdq = {k: (v.clone().requires_grad_(True) if k in checked else v.clone()) for k, v in sd.items()}
-    lq = nets.resnet_forward(sdq, x.cpu(), train=True, nh=8, q=nets.bf16_storage)
-    bce_sum_mean(lq, t.cpu()).backward()
-    lq = lq.detach()
-    e_q = _rel(lq, want)
-    print("aaresnet152 golden train logits: storage-rounded oracle vs reference %.3e" % e_q)
-    # (the AA engine's statistics and attention gradients still leave their kernels through fp32 atomics: on this fixture two runs
-    # of the same step gave 5.6e-2 and 1.2e-1 on the logits, and 1.01 .. 1.34 on the norm of the 39 x 40 relative-position gradient)
-    assert e < max(1e-2, 2.5 * e_q)
-    # the loss follows the logits: |d loss| <= sum_c |sigmoid(z_c) - t_c| * |d z| (BCE, summed over classes), so with logits
-    # e * scale away the loss may be that far away (2 % of slack on top; on this fixture runs gave 0.3 % .. 2.4 %)
-    sens = (torch.sigmoid(want) - t.cpu()).abs().sum(1).mean(0).item()
-    assert abs(loss.item() - rec["loss"]) < 2e-2 * rec["loss"] + sens * e * want.abs().max().item()
+    # B = 1, hash-filled weights, 100 values per channel in layer4: the storage-rounded fp32 oracle is 1e-1 away on this fixture.
+    # Order-of-magnitude smoke with literal bounds (measured 8.7e-2; the engine is deterministic now, so this is one number);
+    # the train-mode parity statement for this network is tests/test_golden_smooth_gpu.py (aaresnet152_320_b8).
+    assert torch.isfinite(logits).all() and e < 0.3
+    assert abs(loss.item() - rec["loss"]) < 0.1 * rec["loss"]
     named = dict(model.named_parameters())
-    rows = [(k, named[k].grad.double().norm().item() / rec["grads"][k]["l2"], sdq[k].grad.double().norm().item() / rec["grads"][k]["l2"])
-            for k in checked]
-    print("aaresnet152 golden grad l2 ratios (HIP, storage-rounded oracle): %s" % rows)
-    for k, r, rq in rows:
-        # what bf16 storage alone does to this gradient norm calibrates the bound, as for the logits; the floor covers the run-to-run
-        # spread of the atomic path on this B = 1 fixture, measured over seven runs of one build: 0.95 .. 1.07 on the convolution
-        # weights, 1.01 .. 1.34 on the relative-position table (a 39 x 40 sum of signed terms over 100 positions)
-        floor = 0.05 if k.startswith("fc") else (0.5 if "key_rel" in k else 0.25)
-        assert abs(r - 1) < max(floor, 2.5 * abs(rq - 1)), (k, r, rq)
+    for k in ("fc.weight", "fc.bias", "layer4.2.conv2.key_rel_h", "layer3.5.conv2.in_proj_qkv.weight", "layer2.0.conv2.conv.weight"):
+        r = named[k].grad.double().norm().item() / rec["grads"][k]["l2"]
+        assert 0.5 < r < 2.0, (k, r)
     for k, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all().item(), k
 
@@ -310,14 +290,11 @@ def test_basic_block_networks_match_reference_golden_fixture(dev, tag):
     model.zero_grad()
     loss.backward()
     e_train = _rel(out.detach().cpu(), torch.tensor(rec["logits_train"]))
-    fwd_q = lambda s, xx: nets.basic_resnet_forward(s, xx, wide=wide, train=True, q=nets.bf16_storage)
-    loss_q, lq, _ = step.train_step(fwd_q, {k: v.clone() for k, v in sd.items()}, x, t)
-    e_q = _rel(lq, torch.tensor(rec["logits_train"]))
-    print("%s: eval logits rel %.3e, train logits rel %.3e (storage-rounded oracle %.3e), loss %.5f (reference %.5f, oracle_q %.5f)"
-          % (tag, e_eval, e_train, e_q, loss.item(), rec["loss"], float(loss_q)))
+    print("%s: eval logits rel %.3e, train logits rel %.3e, loss %.5f (reference %.5f)" % (tag, e_eval, e_train, loss.item(), rec["loss"]))
     assert e_eval < 1e-2
-    assert e_train < max(2e-2, 2.0 * e_q)
-    assert abs(loss.item() - rec["loss"]) < max(1e-2, 2.0 * abs(float(loss_q) - rec["loss"]) / abs(rec["loss"])) * abs(rec["loss"])
+    # hash-weight fixtures in train mode: literal order-of-magnitude bounds (the sharp checks are the smooth-regime tests below)
+    assert e_train < 5e-2
+    assert abs(loss.item() - rec["loss"]) < 3e-2 * abs(rec["loss"])
     gmax = max(r["l2"] for r in rec["grads"].values())
     for k, p in model.named_parameters():          # every parameter receives a gradient of the reference's magnitude
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
@@ -386,11 +363,10 @@ def test_attention_augmented_basic_block_networks(dev, tag, B, S):
     model.zero_grad()
     loss.backward()
     want = torch.tensor(rec["logits_train"])
-    loss_q, lq, _ = step.train_step(fwd(nets.bf16_storage), {k: v.clone() for k, v in sd.items()}, x, t)
-    e, e_q = _rel(out.detach().cpu(), want), _rel(lq, want)
-    print("%s golden: train logits rel %.3e (storage-rounded oracle %.3e), loss %.5f (reference %.5f)" % (tag, e, e_q, loss.item(), rec["loss"]))
-    assert e < max(2e-2, 2.0 * e_q)
-    assert abs(loss.item() - rec["loss"]) < max(1e-2, 2.0 * abs(float(loss_q) - rec["loss"]) / abs(rec["loss"])) * abs(rec["loss"])
+    e = _rel(out.detach().cpu(), want)
+    print("%s golden: train logits rel %.3e, loss %.5f (reference %.5f)" % (tag, e, loss.item(), rec["loss"]))
+    assert e < 5e-2                                   # hash-weight fixture: literal order-of-magnitude bound
+    assert abs(loss.item() - rec["loss"]) < 3e-2 * abs(rec["loss"])
     for k, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
     # smooth regime: gradients against the fp32 oracle (16 images: the 4 x 4 maps of ResNet18's last stage at 128 px give 64 values
