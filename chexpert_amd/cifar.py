@@ -10,7 +10,7 @@ Data: the python-pickle CIFAR batches under --data_dir (`cifar-10-batches-py/` o
 no torchvision here), `--synthetic N` otherwise: N random normalised images with random labels -- enough to exercise the loop.
 
 The attention-augmented WideResNet (`--attn`: AAConv2d as conv1 of the BasicBlocks of stages 2-3, test_model.py:265-269) runs on the
-HIP attention kernels where they cover the head sizes (dk/nh = 20, dv/nh in {1,2,3,4,6}: e.g. WRN-16-4, WRN-28-4 at 8 heads), and
+HIP attention kernels where they cover the head sizes (dk/nh = 20, dv/nh in {1,2,3,4,6,8}: e.g. WRN-16-4, WRN-28-10 at 8 heads), and
 `--vis_attn` draws its attention maps (:201-234).  Not on the HIP schedule (raises with the reason): `densenet` with the three-block
 CIFAR configuration (the DenseNet engine is the four-block ImageNet-shaped one).
 """

@@ -308,6 +308,7 @@ def main(argv=None):
             idx = P.shard_indices(len(train_ds), rank, world, seed=args.seed or 1, epoch=epoch)
             if not idx:
                 raise RuntimeError("the training set (%d images over %d ranks) yields no minibatch" % (len(train_ds), world))
+            t_epoch = time.perf_counter()
             # every image is seen each epoch, as with the reference's DataLoader (drop_last=False, chexpert.py:76): the last,
             # partial minibatch runs as an eager step (the hipGraph is captured on the full batch's shapes)
             for x, t, _ in train_loader.batches(idx, drop_last=False):
@@ -352,6 +353,10 @@ def main(argv=None):
                                          "avg_auc": M.mean_auc(res), "state_dict": model.state_dict()},
                                         optimizer.state_dict(), sched_state, args)
                     model.train()
+            torch.cuda.synchronize()
+            if rank == 0:        # input pipeline + step, end to end (the figure to hold against bench.py's device-resident rate)
+                print(json.dumps({"epoch": epoch, "images_per_sec": round(len(idx) * world / (time.perf_counter() - t_epoch), 1),
+                                  "loader_workers": args.num_workers}), flush=True)
             run_eval("eval_results_step_%d" % args.step)
         train_loader.close()
     if args.evaluate_single_model:

@@ -24,7 +24,7 @@ namespace {
 constexpr int AQ = 128;      // queries per workgroup (one per thread)
 constexpr int TK = 64;       // keys per LDS tile
 constexpr int DKH = 20;      // head dim of q/k for every AA layer of the reference (dk = max(20*nh, ...) = 160, nh = 8)
-constexpr int MAXDV = 6;
+constexpr int MAXDV = 8;        // dv/nh in {1,2,3,4,6,8}: every AA layer chexpert.py trains, and WRN-28-10's third stage (dv 64 at 8 heads)
 
 struct AAGeo {
   int B, H, W, nh, dk, dv, ldq;     // qkv tensor: (B, H*W, ldq) bf16, channels [q dk | k dk | v dv]
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void stats_bc_kernel(const bf16* __restrict__ 
 __global__ __launch_bounds__(256) void aa_outproj_fwd_kernel(const float* __restrict__ o, const float* __restrict__ w, bf16* __restrict__ y,
                                                              int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv, int T, int det,
                                                              int rstride) {
-  __shared__ float ws[48 * 48];
+  __shared__ float ws[64 * 64];
   __shared__ float st[2][256];
   const int tid = threadIdx.x;
   for (int t = tid; t < dv * dv; t += blockDim.x) ws[t] = w[t];
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(256) void aa_outproj_fwd_kernel(const float* __rest
 
 // backward of out_proj: dO[pix][d] = sum_c dY[pix][c] * W[c][d];  dW[c][d] += sum_pix dY[pix][c] * O[pix][d]
 // dY = g*ga + gx*gb + gc (deferred BN correction of the gradient-buffer slice)
+template <int DM, int CH>
 __global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const bf16* __restrict__ g, int ldg, const bf16* __restrict__ gx, int ldgx,
                                                              const float* __restrict__ ga, const float* __restrict__ gb,
                                                              const float* __restrict__ gc, const float* __restrict__ o,
@@ -627,9 +628,9 @@ __global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const bf16* __restr
   // Two small GEMMs per 64-pixel chunk staged in LDS: dO = dY W (thread per (pixel, d)) and dW += dY^T O (thread per (c, d)
   // pair, which it owns: plain LDS accumulation, no atomics -- a pixel-per-thread outer product sent 64 lanes to the same
   // LDS word dv*dv times per pixel: 2.2 ms per call).
-  constexpr int CH = 64, PT = 49;                      // pixels per chunk, padded row pitch (dv <= 48)
-  __shared__ float ws[48 * 48];
-  __shared__ float dws[48 * 48];
+  constexpr int PT = DM + 1;                           // CH pixels per chunk, padded row pitch (dv <= DM): <48, 64> or <64, 32> (64 KB of LDS)
+  __shared__ float ws[DM * DM];
+  __shared__ float dws[DM * DM];
   __shared__ float dyS[CH * PT];
   __shared__ float oS[CH * PT];
   const int tid = threadIdx.x;
@@ -781,6 +782,7 @@ int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w,
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;
     case 6: LAUNCH(6); break;
+    case 8: LAUNCH(8); break;
     default: return CX_EUNSUPPORTED;
   }
 #undef LAUNCH
@@ -819,6 +821,7 @@ int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   // Reproducible relative-table gradients: every query-side workgroup plain-stores its two partial tables into the caller's
@@ -848,6 +851,7 @@ int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w,
       case 3: LAUNCH(3); break;
       case 4: LAUNCH(4); break;
       case 6: LAUNCH(6); break;
+      case 8: LAUNCH(8); break;
       default: return CX_EUNSUPPORTED;
     }
 #undef LAUNCH
@@ -876,7 +880,7 @@ int cx_affine_relu_bc(const void* x, const float* sc, const float* sh, void* y, 
 
 int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
                       int stat_rows, int stat_rstride, void* stream) {
-  if (!o || !w || !y || dv <= 0 || dv > 48) return CX_EINVAL;
+  if (!o || !w || !y || dv <= 0 || dv > 64) return CX_EINVAL;
   if ((stat_sum == nullptr) != (stat_sq == nullptr)) return CX_EINVAL;
   if (stat_rows > 0 && (!stat_sum || stat_rstride < dv)) return CX_EINVAL;
   const int T = 256 / dv * dv;
@@ -890,11 +894,15 @@ int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* s
 int cx_aa_outproj_bwd(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
                       const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, float* scratch, int64_t scratch_floats,
                       void* stream) {
-  if (!g || !gx || !ga || !gb || !gc || !o || !w || !d_o || !dw || dv <= 0 || dv > 48) return CX_EINVAL;
+  if (!g || !gx || !ga || !gb || !gc || !o || !w || !d_o || !dw || dv <= 0 || dv > 64) return CX_EINVAL;
   const int grid = grid_for(npix, 64, 1024);
   float* slab = dw_slab(scratch, scratch_floats, grid, (long long)dv * dv);
-  hipLaunchKernelGGL(aa_outproj_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)g, ldg,
-                     (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
+  if (dv <= 48)
+    hipLaunchKernelGGL((aa_outproj_bwd_kernel<48, 64>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)g, ldg,
+                       (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
+  else
+    hipLaunchKernelGGL((aa_outproj_bwd_kernel<64, 32>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)g, ldg,
+                       (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
   if (const int e = launch_status()) return e;
   return slab ? cx_dw_reduce(dw, slab, (size_t)dv * dv, grid, as_stream(stream)) : 0;
 }

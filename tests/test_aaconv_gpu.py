@@ -30,7 +30,8 @@ def close(got, want, rel, what=""):
     assert err <= rel * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
 
 
-@pytest.mark.parametrize("B,H,W,dv", [(2, 5, 7, 8), (1, 10, 10, 48), (2, 20, 20, 24), (1, 40, 40, 8), (2, 12, 20, 16), (1, 9, 40, 8)])
+@pytest.mark.parametrize("B,H,W,dv", [(2, 5, 7, 8), (1, 10, 10, 48), (2, 20, 20, 24), (1, 40, 40, 8), (2, 12, 20, 16), (1, 9, 40, 8),
+                                      (2, 8, 8, 64)])        # dv/nh = 8: the third stage of WRN-28-10 at 8 heads (attn_aug_conv.py:602)
 def test_attention_forward_backward(dev, B, H, W, dv):
     from chexpert_amd import ops
     from oracle import aaconv

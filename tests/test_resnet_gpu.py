@@ -407,3 +407,36 @@ def test_attention_augmented_basic_block_networks(dev, tag, B, S):
     with torch.no_grad():                      # AAConv2d.weights after the forward (the harness's --vis_attn reads them)
         wts = model.layer2[0].conv1.weights
     assert wts.shape[1] == 8 and abs(float(wts[0, 0, 0].sum()) - 1.0) < 1e-3
+
+
+def test_aa_wideresnet_head_size_8_matches_fp32_oracle(dev):
+    """The third stage of the attention-augmented WRN-x-10 (the architecture of the reference's CIFAR-100 attention row,
+    models/readme.md:37, attn_aug_conv.py:602): 640 channels at 8 heads give dv = 64, dv/nh = 8 -- the widest head of any reference
+    configuration -- on widths 160 / 320 / 640 (C/8 not a power of two).  WRN-10-10 at 32x32 in the smooth regime against the fp32
+    oracle, every gradient finite, the out-projection and relative-table gradients of the dv = 64 layer close, a repeated step
+    bit for bit."""
+    from oracle import nets, step
+    n_cls, B, S = 5, 8, 32
+    model, sd, wide = _basic_net("aawrn10_10", n_cls, 21, dev, smooth=True, S=S)
+    aa3 = model.layer3[0].conv1
+    assert (aa3.dk, aa3.dv, aa3.nh) == (160, 64, 8)
+    x, t = synth.xray_batch(1234, B, S), synth.targets(99, B, n_cls)
+    fwd = lambda s, xx: nets.basic_resnet_forward(s, xx, wide=wide, train=True, nh=8)
+    loss_o, logits_o, grads_o = step.train_step(fwd, {k: v.clone() for k, v in sd.items()}, x, t)
+    model.train()
+    loss, logits = model.forward_backward(x.to(dev), t.to(dev))
+    e = _rel(logits.cpu(), logits_o)
+    print("aawrn10_10 smooth: train logits rel %.3e" % e)
+    assert e < 2e-2 and abs(loss.item() - loss_o.item()) < 1e-2 * abs(loss_o.item())
+    g1 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    for k in ("layer3.0.conv1.out_proj.weight", "layer3.0.conv1.key_rel_h", "layer3.0.conv1.key_rel_w", "layer3.0.conv1.in_proj_qkv.weight",
+              "layer2.0.conv1.out_proj.weight"):
+        c, n = _cos(g1[k].cpu(), grads_o[k])
+        print("  %s cos %.4f norm ratio %.4f" % (k, c, n))
+        assert c > 0.95 and abs(n - 1) < 0.08, (k, c, n)
+    for k, g in g1.items():
+        assert torch.isfinite(g).all(), k
+    model.zero_grad()
+    model.forward_backward(x.to(dev), t.to(dev))
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, g1[k]), k
