@@ -92,7 +92,9 @@ SIGNATURES = {
     "cx_affine2_relu": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_relu_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
     "cx_affine2_relu_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_affine2_relu_mask_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_relu_bwd_stats_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
+    "cx_relu_bwd_stats_mask_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp],
     "cx_adam_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp],
     "cx_sgd_nesterov_step": [_vp, _vp, _vp, _sz, _f, _f, _f, _i, _f, _vp],
     "cx_rmsprop_step": [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp],

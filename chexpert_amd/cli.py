@@ -108,8 +108,8 @@ def make_model(args, device):
         model = model.storage_dtype(args.dtype).to(device)
         opt = O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)
         return model, opt, None
-    if args.dtype != "bf16":
-        raise RuntimeError("--dtype fp32 covers densenet121")
+    if args.dtype != "bf16" and name != "resnet152":
+        raise RuntimeError("--dtype fp32 covers densenet121 and resnet152")
     if name in ("aadensenet121", "densenet121_attn_aug"):      # chexpert.py:474-480 (README row name accepted too)
         from .models import DenseNet
         size = args.resize or 320
@@ -123,7 +123,7 @@ def make_model(args, device):
         from .models import resnet152
         model = resnet152(pretrained=args.pretrained)
         model.fc = nn.Linear(model.fc.in_features, args.n_classes)
-        model = model.to(device)
+        model = model.storage_dtype(args.dtype).to(device)
         return model, (O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)), None
     if "efficientnet" in name:                                # chexpert.py:496-500
         from .models import construct_model

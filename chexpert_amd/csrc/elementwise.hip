@@ -754,51 +754,49 @@ __global__ void affine2_inplace_kernel(bf16* __restrict__ dz, const bf16* __rest
 // residual join: out = relu(a*pa + b*pb + pc)
 // mask (optional): one bit per element, byte idx = chunk of 8 channels, bit j = out[8 idx + j] > 0 -- what the backward of the join
 // needs of `out` (relu_bwd_stats_kernel), at 1/16 of its bytes
-__global__ void affine2_relu_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const float* __restrict__ pa,
-                                    const float* __restrict__ pb, const float* __restrict__ pc, bf16* __restrict__ out,
+template <typename T>
+__global__ void affine2_relu_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ pa,
+                                    const float* __restrict__ pb, const float* __restrict__ pc, T* __restrict__ out,
                                     uint8_t* __restrict__ mask, size_t rows, int C) {
   const int CP = C / 8;
   const size_t total = rows * CP;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int cq = idx % CP;
-    U128 u, v, o;
-    u.u = *reinterpret_cast<const uint4*>(a + idx * 8);
-    v.u = *reinterpret_cast<const uint4*>(b + idx * 8);
+    const typename V8<T>::raw u = V8<T>::ld(a + idx * 8), v = V8<T>::ld(b + idx * 8);
+    float o[8];
+    unsigned m = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = cq * 8 + j;
-      o.e[j] = f2bf(fmaxf(fmaf(bf2f(u.e[j]), pa[c], fmaf(bf2f(v.e[j]), pb[c], pc[c])), 0.f));
+      o[j] = V8<T>::rnd(fmaxf(fmaf(V8<T>::get(u, j), pa[c], fmaf(V8<T>::get(v, j), pb[c], pc[c])), 0.f));
+      m |= (o[j] > 0.f ? 1u : 0u) << j;
     }
-    *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
-    if (mask) {
-      unsigned m = 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) m |= (bf2f(o.e[j]) > 0.f ? 1u : 0u) << j;
-      mask[idx] = (uint8_t)m;
-    }
+    V8<T>::st(out + idx * 8, o);
+    if (mask) mask[idx] = (uint8_t)m;
   }
 }
 
-__global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
-                                                             const bf16* __restrict__ a, const float* __restrict__ mu_a,
-                                                             const float* __restrict__ r_a, const bf16* __restrict__ b,
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                             const T* __restrict__ a, const float* __restrict__ mu_a,
+                                                             const float* __restrict__ r_a, const T* __restrict__ b,
                                                              const float* __restrict__ mu_b, const float* __restrict__ r_b,
-                                                             bf16* __restrict__ dz, float* S1, float* S2a, float* S2b, size_t rows,
-                                                             int C, int det, const uint8_t* __restrict__ mask, int T) {
+                                                             T* __restrict__ dz, float* S1, float* S2a, float* S2b, size_t rows,
+                                                             int C, int det, const uint8_t* __restrict__ mask, int TA) {
   extern __shared__ float lds[];          // [3][C] (atomic mode) / [256][24] (deterministic rows)
   const int CP = C / 8;
   if (!det) {
     for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) lds[i] = 0.f;
   }
   __syncthreads();
-  // A thread keeps ONE chunk column cq for the whole grid-stride loop (its means / rstds live in registers): the T = (256 / CP) * CP
+  // A thread keeps ONE chunk column cq for the whole grid-stride loop (its means / rstds live in registers): the TA = (256 / CP) * CP
   // leading threads of a workgroup are active, so the stride gridDim.x * T is a multiple of CP for any C % 8 == 0 (C <= 2048) --
   // e.g. the 160 / 320 / 640-wide joins of WRN-28-10 (attn_aug_conv.py:311-404) run 240 threads of 256
   float s1[8], s2[8], s3[8];
   const size_t total = rows * CP;
-  const size_t stride = (size_t)gridDim.x * T;
-  const bool active = (int)threadIdx.x < T;
-  size_t idx = active ? (size_t)blockIdx.x * T + threadIdx.x : total;
+  const size_t stride = (size_t)gridDim.x * TA;
+  const bool active = (int)threadIdx.x < TA;
+  size_t idx = active ? (size_t)blockIdx.x * TA + threadIdx.x : total;
   const int cq = active ? (int)(idx % CP) : 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = s3[j] = 0.f;
@@ -809,23 +807,24 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
     mb[j] = b ? mu_b[cq * 8 + j] : 0.f; rb_[j] = b ? r_b[cq * 8 + j] : 0.f;
   }
   for (; idx < total; idx += stride) {
-    U128 g, o, av, bv, d;
-    g.u = *reinterpret_cast<const uint4*>(dout + idx * 8);
+    typename V8<T>::raw o, bv;
+    const typename V8<T>::raw g = V8<T>::ld(dout + idx * 8);
     unsigned mk = 0;
-    if (mask) mk = mask[idx];                 // the forward's sign bits instead of the 16-B read of `out`
-    else o.u = *reinterpret_cast<const uint4*>(out + idx * 8);
-    av.u = *reinterpret_cast<const uint4*>(a + idx * 8);
-    if (b) bv.u = *reinterpret_cast<const uint4*>(b + idx * 8);
+    if (mask) mk = mask[idx];                 // the forward's sign bits instead of the read of `out`
+    else o = V8<T>::ld(out + idx * 8);
+    const typename V8<T>::raw av = V8<T>::ld(a + idx * 8);
+    if (b) bv = V8<T>::ld(b + idx * 8);
+    float d[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool on = mask ? ((mk >> j) & 1u) != 0 : bf2f(o.e[j]) > 0.f;
-      const float dzv = on ? bf2f(g.e[j]) : 0.f;
+      const bool on = mask ? ((mk >> j) & 1u) != 0 : V8<T>::get(o, j) > 0.f;
+      const float dzv = on ? V8<T>::get(g, j) : 0.f;
       s1[j] += dzv;
-      s2[j] += dzv * (bf2f(av.e[j]) - ma[j]) * ra_[j];
-      if (b) s3[j] += dzv * (bf2f(bv.e[j]) - mb[j]) * rb_[j];
-      d.e[j] = f2bf(dzv);
+      s2[j] += dzv * (V8<T>::get(av, j) - ma[j]) * ra_[j];
+      if (b) s3[j] += dzv * (V8<T>::get(bv, j) - mb[j]) * rb_[j];
+      d[j] = dzv;
     }
-    *reinterpret_cast<uint4*>(dz + idx * 8) = d.u;
+    V8<T>::st(dz + idx * 8, d);
   }
   if (det) {               // one row per workgroup, partial sums of the threads sharing a chunk folded in thread order
 #pragma unroll
@@ -838,7 +837,7 @@ __global__ __launch_bounds__(256) void relu_bwd_stats_kernel(const bf16* __restr
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       const int chunk = c >> 3, j = c & 7;
       float t1 = 0.f, t2 = 0.f, t3 = 0.f;
-      for (int t = chunk; t < T; t += CP) {
+      for (int t = chunk; t < TA; t += CP) {
         t1 += lds[t * 24 + j];
         t2 += lds[t * 24 + 8 + j];
         t3 += lds[t * 24 + 16 + j];
@@ -1250,6 +1249,30 @@ int cx_dw_reduce(float* dw, const float* slab, size_t total, int splits, hipStre
   return launch_status();
 }
 
+template <typename T>
+static int affine2_relu_mask_t(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, uint8_t* mask,
+                               size_t rows, int C, void* stream) {
+  if (!a || !b || !pa || !pb || !pc || !out || C % 8) return CX_EINVAL;
+  hipLaunchKernelGGL(affine2_relu_kernel<T>, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const T*)a,
+                     (const T*)b, pa, pb, pc, (T*)out, mask, rows, C);
+  return launch_status();
+}
+template <typename T>
+static int relu_bwd_stats_mask_t(const void* dout, const void* out, const uint8_t* mask, const void* a, const float* mu_a, const float* r_a,
+                                 const void* b, const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b,
+                                 size_t rows, int C, int stat_rows, void* stream) {
+  if (!dout || (!out && !mask) || !a || !mu_a || !r_a || !dz || !S1 || !S2a) return CX_EINVAL;
+  if (b && (!mu_b || !r_b || !S2b)) return CX_EINVAL;
+  if (C % 8 || C > 2048) return CX_ESHAPE;
+  const int T_ = 256 / (C / 8) * (C / 8);          // active threads per workgroup (see the kernel)
+  int grid = grid_for(rows * (C / 8), 256, 2048);
+  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  const size_t lds_bytes = (stat_rows > 0 ? (size_t)256 * 24 : (size_t)3 * C) * sizeof(float);
+  hipLaunchKernelGGL(relu_bwd_stats_kernel<T>, dim3(grid), dim3(256), lds_bytes,
+                     as_stream(stream), (const T*)dout, (const T*)out, (const T*)a, mu_a, r_a, (const T*)b, mu_b, r_b,
+                     (T*)dz, S1, S2a, S2b, rows, C, stat_rows > 0 ? 1 : 0, mask, T_);
+  return launch_status();
+}
 int cx_rows_reduce_add_impl(float* dst, const float* rows, int n_rows, int C, int rstride, hipStream_t st) {
   if (!dst || !rows || n_rows <= 0 || C <= 0 || rstride < C) return CX_EINVAL;
   hipLaunchKernelGGL(rows_reduce_add_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, dst, rows, n_rows, C, rstride, 0);
@@ -1489,10 +1512,11 @@ int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb
 
 int cx_affine2_relu_mask(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, uint8_t* mask,
                          size_t rows, int C, void* stream) {
-  if (!a || !b || !pa || !pb || !pc || !out || C % 8) return CX_EINVAL;
-  hipLaunchKernelGGL(affine2_relu_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)a,
-                     (const bf16*)b, pa, pb, pc, (bf16*)out, mask, rows, C);
-  return launch_status();
+  return affine2_relu_mask_t<bf16>(a, b, pa, pb, pc, out, mask, rows, C, stream);
+}
+int cx_affine2_relu_mask_f32(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, uint8_t* mask,
+                             size_t rows, int C, void* stream) {
+  return affine2_relu_mask_t<float>(a, b, pa, pb, pc, out, mask, rows, C, stream);
 }
 
 int cx_affine2_relu(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, size_t rows, int C,
@@ -1509,17 +1533,12 @@ int cx_relu_bwd_stats(const void* dout, const void* out, const void* a, const fl
 int cx_relu_bwd_stats_mask(const void* dout, const void* out, const uint8_t* mask, const void* a, const float* mu_a, const float* r_a,
                            const void* b, const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b, size_t rows,
                            int C, int stat_rows, void* stream) {
-  if (!dout || (!out && !mask) || !a || !mu_a || !r_a || !dz || !S1 || !S2a) return CX_EINVAL;
-  if (b && (!mu_b || !r_b || !S2b)) return CX_EINVAL;
-  if (C % 8 || C > 2048) return CX_ESHAPE;
-  const int T = 256 / (C / 8) * (C / 8);          // active threads per workgroup (see the kernel)
-  int grid = grid_for(rows * (C / 8), 256, 2048);
-  if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
-  const size_t lds_bytes = (stat_rows > 0 ? (size_t)256 * 24 : (size_t)3 * C) * sizeof(float);
-  hipLaunchKernelGGL(relu_bwd_stats_kernel, dim3(grid), dim3(256), lds_bytes,
-                     as_stream(stream), (const bf16*)dout, (const bf16*)out, (const bf16*)a, mu_a, r_a, (const bf16*)b, mu_b, r_b,
-                     (bf16*)dz, S1, S2a, S2b, rows, C, stat_rows > 0 ? 1 : 0, mask, T);
-  return launch_status();
+  return relu_bwd_stats_mask_t<bf16>(dout, out, mask, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b, rows, C, stat_rows, stream);
+}
+int cx_relu_bwd_stats_mask_f32(const void* dout, const void* out, const uint8_t* mask, const void* a, const float* mu_a, const float* r_a,
+                               const void* b, const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b,
+                               size_t rows, int C, int stat_rows, void* stream) {
+  return relu_bwd_stats_mask_t<float>(dout, out, mask, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b, rows, C, stat_rows, stream);
 }
 
 int cx_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,

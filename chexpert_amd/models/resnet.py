@@ -114,6 +114,12 @@ class _Engine:
         # (attention-augmented blocks feed one BatchNorm from two kernels: their statistic rows are reduced per channel range,
         # _aa_fwd_stats; the two input-gradient branches stack their rows, _stacked)
         self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
+        # activation storage type: bf16, or fp32 = the parity mode of north_star ("1e-3 fp32"): the same schedule on fp32 tensors
+        # through the generic f32-MFMA convolutions (csrc/conv_f32.hip) and the templated element-wise kernels
+        self.dtype = getattr(model, "_storage_dtype", torch.bfloat16)
+        if self.dtype != torch.bfloat16 and (isinstance(model, WideResNet) or any(isinstance(m_, AAConv2d) for m_ in model.modules())):
+            raise NotImplementedError("the fp32 storage mode covers the ImageNet-stem ResNets without attention (resnet152 of "
+                                      "chexpert.py:482); the attention kernels and the 3-channel CIFAR stem are bf16")
         self.flat = None
         self.device = None
         self.pool = {}
@@ -200,7 +206,7 @@ class _Engine:
         def add(conv, transpose=False, stem=False):
             nonlocal cur
             O, I, kh, kw = conv.weight.shape
-            n = 7 * O * 32 if stem else O * I * kh * kw
+            n = ((49 * O * 4) if self.dtype == torch.float32 else 7 * O * 32) if stem else O * I * kh * kw
             descs.append(CxPackDesc(self.off_of[id(conv.weight)], cur, O, I, kh, kw, int(transpose), int(stem)))
             off = cur
             cur += (n + 7) // 8 * 8
@@ -214,7 +220,7 @@ class _Engine:
             if isinstance(mod, nn.Conv2d) and mod is not m.conv1:
                 self.wf[id(mod)] = add(mod)
                 self.wb[id(mod)] = add(mod, transpose=True)
-        self.packed = torch.empty(cur, dtype=torch.bfloat16, device=dev)
+        self.packed = torch.empty(cur, dtype=self.dtype, device=dev)
         arr = (CxPackDesc * len(descs))(*descs)
         self.desc_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self.n_desc = len(descs)
@@ -224,8 +230,7 @@ class _Engine:
         ver = None if train else sum(p._version for p in self.params)
         if ver is not None and ver == self.packed_version:
             return
-        check(lib().cx_pack_weights_table(ptr(self.flat), ptr(self.packed), ptr(self.desc_dev), self.n_desc, stream_ptr()),
-              "cx_pack_weights_table")
+        ops.pack_weights_table(self.flat, self.packed, self.desc_dev, self.n_desc)
         if self.cifar:
             w8 = torch.nn.functional.pad(self.model.conv1.weight.detach(), (0, 0, 0, 0, 0, 5)).contiguous()   # (O,3,3,3) -> (O,8,3,3)
             ops.pack_weights(w8, out=self.packed[self.stem_off:])
@@ -251,7 +256,7 @@ class _Engine:
         lst = self.pool.setdefault((B, H, W), [])
         if lst:
             return lst.pop()
-        dev, bf = self.device, torch.bfloat16
+        dev, bf = self.device, self.dtype
         e = lambda *s, dtype=bf: torch.empty(*s, dtype=dtype, device=dev)
         ws = _Engine.WS()
         ws.key, ws.B, ws.H, ws.W = (B, H, W), B, H, W
@@ -477,7 +482,7 @@ class _Engine:
     def _alloc_bwd(self, ws):
         if ws.bwd is not None:
             return
-        dev, bf, B = self.device, torch.bfloat16, ws.B
+        dev, bf, B = self.device, self.dtype, ws.B
         e = lambda *s: torch.empty(*s, dtype=bf, device=dev)
         bw = {}
         # one gradient buffer per block OUTPUT shape change (identity blocks accumulate in place)
@@ -780,9 +785,18 @@ class _EngineNet(nn.Module):
             if isinstance(mod, AAConv2d) and not mod.kernel_support:
                 raise NotImplementedError("AAConv2d(dk=%d, dv=%d, nh=%d): the HIP attention kernels cover dk/nh = 20, dv/nh in "
                                           "{1,2,3,4,6,8}, relative=True" % (mod.dk, mod.dv, mod.nh))
-        if self._engine is None:
+        if self._engine is None or self._engine.dtype != getattr(self, "_storage_dtype", torch.bfloat16):
             object.__setattr__(self, "_engine", _Engine(self))
         return self._engine
+
+    def storage_dtype(self, dtype):
+        """Storage type of the activations inside the fused schedule: torch.bfloat16 (default) or torch.float32 -- the parity
+        mode of north_star ("1e-3 fp32"; same method as DenseNet.storage_dtype).  Parameters are fp32 masters either way."""
+        dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(dtype, dtype)
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("storage dtype must be bf16 or fp32")
+        object.__setattr__(self, "_storage_dtype", dtype)
+        return self
 
     def state_dict(self, *args, **kwargs):
         if self._nbt_pending:

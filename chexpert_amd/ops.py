@@ -386,7 +386,7 @@ def affine2_relu(a, b, pa, pb, pc, out, mask=None):
     B, H, W, Cc, ld = _nhwc(a)
     assert ld == Cc and _nhwc(b)[4] == Cc and _nhwc(out)[4] == Cc
     assert mask is None or (mask.dtype == torch.uint8 and mask.numel() == B * H * W * Cc // 8)
-    check(lib().cx_affine2_relu_mask(ptr(a), ptr(b), ptr(pa), ptr(pb), ptr(pc), ptr(out), ptr(mask), B * H * W, Cc, stream_ptr()),
+    check(_fn("cx_affine2_relu_mask", a)(ptr(a), ptr(b), ptr(pa), ptr(pb), ptr(pc), ptr(out), ptr(mask), B * H * W, Cc, stream_ptr()),
           "cx_affine2_relu_mask")
 
 
@@ -394,8 +394,9 @@ def relu_bwd_stats(dout, out, a, mu_a, r_a, b, mu_b, r_b, dz, S1, S2a, S2b, stat
     """mask (optional): sign bits written by affine2_relu, read instead of `out`."""
     B, H, W, Cc, ld = _nhwc(dout)
     assert ld == Cc
-    check(lib().cx_relu_bwd_stats_mask(ptr(dout), ptr(out), ptr(mask), ptr(a), ptr(mu_a), ptr(r_a), ptr(b), ptr(mu_b), ptr(r_b), ptr(dz),
-                                       ptr(S1), ptr(S2a), ptr(S2b), B * H * W, Cc, stat_rows, stream_ptr()), "cx_relu_bwd_stats_mask")
+    check(_fn("cx_relu_bwd_stats_mask", dout)(ptr(dout), ptr(out), ptr(mask), ptr(a), ptr(mu_a), ptr(r_a), ptr(b), ptr(mu_b), ptr(r_b),
+                                              ptr(dz), ptr(S1), ptr(S2a), ptr(S2b), B * H * W, Cc, stat_rows, stream_ptr()),
+          "cx_relu_bwd_stats_mask")
     return lib().cx_last_stat_rows() if stat_rows else None
 
 

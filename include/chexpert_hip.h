@@ -258,6 +258,12 @@ int cx_affine2_relu_mask(const void* a, const void* b, const float* pa, const fl
 int cx_relu_bwd_stats_mask(const void* dout, const void* out, const uint8_t* mask, const void* a, const float* mu_a,
                            const float* r_a, const void* b, const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a,
                            float* S2b, size_t rows, int C, int stat_rows, void* stream);
+/* the same two in the fp32 storage mode (a, b, out, dout, dz fp32; north_star "1e-3 fp32" for the ResNets) */
+int cx_affine2_relu_mask_f32(const void* a, const void* b, const float* pa, const float* pb, const float* pc, void* out, uint8_t* mask,
+                             size_t rows, int C, void* stream);
+int cx_relu_bwd_stats_mask_f32(const void* dout, const void* out, const uint8_t* mask, const void* a, const float* mu_a, const float* r_a,
+                               const void* b, const float* mu_b, const float* r_b, void* dz, float* S1, float* S2a, float* S2b,
+                               size_t rows, int C, int stat_rows, void* stream);
 
 /* dz (B,H,W,C) bf16 -> dY = dz*pa + x*pb + pc in place (BN0 backward ahead of the stem wgrad)      */
 int cx_affine2_inplace(void* dz, const void* x, const float* pa, const float* pb, const float* pc, size_t rows,
