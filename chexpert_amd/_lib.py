@@ -113,19 +113,31 @@ SIGNATURES = {
     "cx_in_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_f32_to_bf16": [_vp, _vp, _sz, _vp],
     "cx_nchw3_to_nhwc8": [_vp, _vp, _i, _i, _i, _vp],
+    "cx_nchw3_to_nhwc8_f32": [_vp, _vp, _i, _i, _i, _vp],
     "cx_u8_to_nhwc8": [_vp, _vp, _sz, _f, _f, _vp],
+    "cx_u8_to_nhwc8_f32": [_vp, _vp, _sz, _f, _f, _vp],
     "cx_dwconv_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_dwconv_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_dwconv_dgrad": [_vp] * 14 + [_i] * 8 + [_vp],
+    "cx_dwconv_dgrad_f32": [_vp] * 14 + [_i] * 8 + [_vp],
     "cx_dwconv_wgrad": [_vp] * 9 + [_i] * 7 + [_vp],
+    "cx_dwconv_wgrad_f32": [_vp] * 9 + [_i] * 7 + [_vp],
     "cx_gap_affine_act": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_gap_affine_act_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_se_fwd": [_vp] * 7 + [_i, _i, _i, _vp],
     "cx_se_bwd": [_vp] * 11 + [_i, _i, _i, _vp],
     "cx_scale_act_bc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cx_scale_act_bc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_se_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cx_se_bwd_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_se_act_bwd": [_vp] * 11 + [_i, _i, _i, _vp],
+    "cx_se_act_bwd_f32": [_vp] * 11 + [_i, _i, _i, _vp],
     "cx_bn_lin_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_bn_lin_bwd_stats_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
     "cx_affine2_out": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp],
+    "cx_affine2_out_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp],
     "cx_scale_rows": [_vp, _vp, _sz, _vp, _sz, _i, _vp],
+    "cx_scale_rows_f32": [_vp, _vp, _sz, _vp, _sz, _i, _vp],
     "cx_dropout_mask": [_vp, _sz, _f, C.c_ulonglong, _vp],
     "cx_mul_f32": [_vp, _vp, _vp, _sz, _vp],
     "cx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -108,8 +108,8 @@ def make_model(args, device):
         model = model.storage_dtype(args.dtype).to(device)
         opt = O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)
         return model, opt, None
-    if args.dtype != "bf16" and name != "resnet152":
-        raise RuntimeError("--dtype fp32 covers densenet121 and resnet152")
+    if args.dtype != "bf16" and name != "resnet152" and "efficientnet" not in name:
+        raise RuntimeError("--dtype fp32 covers densenet121, resnet152 and the EfficientNets")
     if name in ("aadensenet121", "densenet121_attn_aug"):      # chexpert.py:474-480 (README row name accepted too)
         from .models import DenseNet
         size = args.resize or 320
@@ -127,7 +127,7 @@ def make_model(args, device):
         return model, (O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)), None
     if "efficientnet" in name:                                # chexpert.py:496-500
         from .models import construct_model
-        model = construct_model(name, n_classes=args.n_classes).to(device)
+        model = construct_model(name, n_classes=args.n_classes).storage_dtype(args.dtype).to(device)
         if fused:
             return model, O.FusedRMSprop(model, lr=args.lr, decay=args.lr_decay_factor), "fused"
         opt = torch.optim.RMSprop(model.parameters(), lr=args.lr, momentum=0.9, eps=0.001)

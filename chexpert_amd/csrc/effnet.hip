@@ -4,6 +4,7 @@
 // backward glue.  All of it is HBM-bound elementwise / stencil work: 16 B per lane along the channel axis,
 // per-block LDS reduction before fp32 atomics.  The 1x1 expand / project / head convolutions go through
 // cx_conv_gemm / cx_conv_wgrad on materialised bf16 activations.
+#include <type_traits>
 #include "common.h"
 
 // dwconv.hip: tiled depthwise kernels for k in {3,5}, stride in {1,2}, pad = k/2 (which: 0 forward, 1 dgrad, 2 wgrad)
@@ -51,36 +52,39 @@ __device__ __forceinline__ void flush_partials(float (&s)[NS][8], int cq, int C,
       if (dst[k]) atomicAdd(&dst[k][c], lds[k * C + c]);
 }
 
-__global__ void nchw3_to_nhwc8_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t hw, size_t total) {
+template <typename T>
+__global__ void nchw3_to_nhwc8_kernel(const float* __restrict__ x, T* __restrict__ y, size_t hw, size_t total) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const size_t b = idx / hw, p = idx - b * hw;
   const float* src = x + b * 3 * hw + p;
-  U128 o;
-  o.e[0] = f2bf(src[0]);
-  o.e[1] = f2bf(src[hw]);
-  o.e[2] = f2bf(src[2 * hw]);
+  float o_f[8];
+  o_f[0] = V8<T>::rnd(src[0]);
+  o_f[1] = V8<T>::rnd(src[hw]);
+  o_f[2] = V8<T>::rnd(src[2 * hw]);
 #pragma unroll
-  for (int j = 3; j < 8; ++j) o.e[j] = f2bf(0.f);
-  *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+  for (int j = 3; j < 8; ++j) o_f[j] = V8<T>::rnd(0.f);
+  V8<T>::st(y + idx * 8, o_f);
 }
 
 // decoded grey bytes -> the three identical whitened channels (chexpert.py:70-72), NHWC8 bf16 (channels 3..7 zero)
-__global__ void u8_to_nhwc8_kernel(const uint8_t* __restrict__ x, bf16* __restrict__ y, float scale, float shift, size_t total) {
+template <typename T>
+__global__ void u8_to_nhwc8_kernel(const uint8_t* __restrict__ x, T* __restrict__ y, float scale, float shift, size_t total) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const bf16 g = f2bf(fmaf((float)x[idx], scale, shift));
-  U128 o;
-  o.e[0] = g; o.e[1] = g; o.e[2] = g;
+  const float g = V8<T>::rnd(fmaf((float)x[idx], scale, shift));
+  float o_f[8];
+  o_f[0] = g; o_f[1] = g; o_f[2] = g;
 #pragma unroll
-  for (int j = 3; j < 8; ++j) o.e[j] = f2bf(0.f);
-  *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+  for (int j = 3; j < 8; ++j) o_f[j] = V8<T>::rnd(0.f);
+  V8<T>::st(y + idx * 8, o_f);
 }
 
 // ---------------------------------------------------------------------------------------------- depthwise conv
 // forward: y[p][c] = sum_t act(x[p@t][c]) * w[c][t],  act = swish(x*sc+sh) or identity (sc == nullptr)
-__global__ void dwconv_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sc,
-                                  const float* __restrict__ sh, bf16* __restrict__ y, float* g1, float* g2, int B, int H, int W, int C,
+template <typename T>
+__global__ void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sc,
+                                  const float* __restrict__ sh, T* __restrict__ y, float* g1, float* g2, int B, int H, int W, int C,
                                   int Ho, int Wo, int k, int stride, int pad) {
   extern __shared__ float lds[];          // [2][C]
   const int CP = C / 8;
@@ -107,25 +111,25 @@ __global__ void dwconv_fwd_kernel(const bf16* __restrict__ x, const float* __res
       for (int dx = 0; dx < k; ++dx) {
         const int ix = ox * stride - pad + dx;
         if (ix < 0 || ix >= W) continue;
-        U128 v;
-        v.u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
+        typename V8<T>::raw v;
+        v = V8<T>::ld(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float a = bf2f(v.e[j]);
-          if (sc) a = bf2f(f2bf(swishf_(fmaf(a, fsc[j], fsh[j]))));       // same rounding as a materialised activation
+          float a = V8<T>::get(v, j);
+          if (sc) a = V8<T>::rnd(swishf_(fmaf(a, fsc[j], fsh[j])));       // same rounding as a materialised activation
           acc[j] = fmaf(a, w[(size_t)(cq * 8 + j) * k * k + dy * k + dx], acc[j]);
         }
       }
     }
-    U128 o;
+    float o_f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      o.e[j] = f2bf(acc[j]);
-      const float rv = bf2f(o.e[j]);
+      o_f[j] = V8<T>::rnd(acc[j]);
+      const float rv = o_f[j];
       s[0][j] += rv;
       s[1][j] += rv * rv;
     }
-    *reinterpret_cast<uint4*>(y + pix * C + cq * 8) = o.u;
+    V8<T>::st(y + pix * C + cq * 8, o_f);
   }
   float* const dst[2] = {g1, g2};
   if (g1) flush_partials<2>(s, cq, C, lds, dst);
@@ -133,10 +137,11 @@ __global__ void dwconv_fwd_kernel(const bf16* __restrict__ x, const float* __res
 
 // input gradient: da[p][c] = sum_t dY[(p + pad - t)/stride][c] * w[c][t];  dY = g*ga + g2*gb + gc
 //   dz = da * swish'(x*sc+sh) (or da when sc == nullptr);  S1 += dz, S2 += dz * (x-mean)*rstd
-__global__ void dwconv_dgrad_kernel(const bf16* __restrict__ g, const bf16* __restrict__ g2, const float* __restrict__ ga,
+template <typename T>
+__global__ void dwconv_dgrad_kernel(const T* __restrict__ g, const T* __restrict__ g2, const float* __restrict__ ga,
                                     const float* __restrict__ gb, const float* __restrict__ gc, const float* __restrict__ w,
-                                    const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd, bf16* __restrict__ dz, float* S1,
+                                    const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dz, float* S1,
                                     float* S2, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int accumulate) {
   extern __shared__ float lds[];
   const int CP = C / 8;
@@ -170,38 +175,40 @@ __global__ void dwconv_dgrad_kernel(const bf16* __restrict__ g, const bf16* __re
         const int ox = nx / stride;
         if (ox >= Wo) continue;
         const size_t op = ((size_t)b * Ho + oy) * Wo + ox;
-        U128 u, v;
-        u.u = *reinterpret_cast<const uint4*>(g + op * C + cq * 8);
-        v.u = *reinterpret_cast<const uint4*>(g2 + op * C + cq * 8);
+        typename V8<T>::raw u, v;
+        u = V8<T>::ld(g + op * C + cq * 8);
+        v = V8<T>::ld(g2 + op * C + cq * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float dy_ = bf2f(f2bf(fmaf(bf2f(u.e[j]), fa[j], fmaf(bf2f(v.e[j]), fb[j], fc[j]))));
+          const float dy_ = V8<T>::rnd(fmaf(V8<T>::get(u, j), fa[j], fmaf(V8<T>::get(v, j), fb[j], fc[j])));
           acc[j] = fmaf(dy_, w[(size_t)(cq * 8 + j) * k * k + dy * k + dx], acc[j]);
         }
       }
     }
-    U128 o, xv, old;
-    xv.u = *reinterpret_cast<const uint4*>(x + pix * C + cq * 8);
-    if (accumulate) old.u = *reinterpret_cast<const uint4*>(dz + pix * C + cq * 8);
+    typename V8<T>::raw xv, old;
+    float o_f[8];
+    xv = V8<T>::ld(x + pix * C + cq * 8);
+    if (accumulate) old = V8<T>::ld(dz + pix * C + cq * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xf = bf2f(xv.e[j]);
+      const float xf = V8<T>::get(xv, j);
       float d = acc[j];
       if (sc) d *= dswishf_(fmaf(xf, fsc[j], fsh[j]));
       s[0][j] += d;
       s[1][j] += d * (xf - fmu[j]) * fr[j];
-      if (accumulate) d += bf2f(old.e[j]);
-      o.e[j] = f2bf(d);
+      if (accumulate) d += V8<T>::get(old, j);
+      o_f[j] = V8<T>::rnd(d);
     }
-    *reinterpret_cast<uint4*>(dz + pix * C + cq * 8) = o.u;
+    V8<T>::st(dz + pix * C + cq * 8, o_f);
   }
   float* const dst[2] = {S1, S2};
   if (S1) flush_partials<2>(s, cq, C, lds, dst);
 }
 
 // weight gradient: dW[c][t] += sum_p dY[p][c] * act(x[p@t][c]); one tap per blockIdx.y
-__global__ void dwconv_wgrad_kernel(const bf16* __restrict__ g, const bf16* __restrict__ g2, const float* __restrict__ ga,
-                                    const float* __restrict__ gb, const float* __restrict__ gc, const bf16* __restrict__ x,
+template <typename T>
+__global__ void dwconv_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ g2, const float* __restrict__ ga,
+                                    const float* __restrict__ gb, const float* __restrict__ gc, const T* __restrict__ x,
                                     const float* __restrict__ sc, const float* __restrict__ sh, float* __restrict__ dw, int B, int H, int W,
                                     int C, int Ho, int Wo, int k, int stride, int pad) {
   extern __shared__ float lds[];          // [C]
@@ -225,15 +232,15 @@ __global__ void dwconv_wgrad_kernel(const bf16* __restrict__ g, const bf16* __re
     const int oy = rem / Wo, ox = rem - oy * Wo;
     const int iy = oy * stride - pad + dy, ix = ox * stride - pad + dx;
     if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-    U128 u, v, xv;
-    u.u = *reinterpret_cast<const uint4*>(g + pix * C + cq * 8);
-    v.u = *reinterpret_cast<const uint4*>(g2 + pix * C + cq * 8);
-    xv.u = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
+    typename V8<T>::raw u, v, xv;
+    u = V8<T>::ld(g + pix * C + cq * 8);
+    v = V8<T>::ld(g2 + pix * C + cq * 8);
+    xv = V8<T>::ld(x + ((size_t)(b * H + iy) * W + ix) * C + cq * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float dy_ = bf2f(f2bf(fmaf(bf2f(u.e[j]), fa[j], fmaf(bf2f(v.e[j]), fb[j], fc[j]))));
-      float a = bf2f(xv.e[j]);
-      if (sc) a = bf2f(f2bf(swishf_(fmaf(a, fsc[j], fsh[j]))));
+      const float dy_ = V8<T>::rnd(fmaf(V8<T>::get(u, j), fa[j], fmaf(V8<T>::get(v, j), fb[j], fc[j])));
+      float a = V8<T>::get(xv, j);
+      if (sc) a = V8<T>::rnd(swishf_(fmaf(a, fsc[j], fsh[j])));
       s[0][j] = fmaf(dy_, a, s[0][j]);
     }
   }
@@ -245,7 +252,8 @@ __global__ void dwconv_wgrad_kernel(const bf16* __restrict__ g, const bf16* __re
 
 // ---------------------------------------------------------------------------------------------- SE / activation glue
 // pooled[b][c] = mean_hw act(x*sc+sh), act: 0 none, 1 relu, 2 swish
-__global__ void gap_affine_act_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+template <typename T>
+__global__ void gap_affine_act_kernel(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                                       float* __restrict__ pooled, int HW, int C, int act, int splits) {
   // four pixel rows of a thread are requested before the first is consumed (one 16-B load in flight per lane left this kernel
   // at 0.8 TB/s); the rows of a workgroup meet in LDS, one global atomic per channel and workgroup
@@ -260,20 +268,20 @@ __global__ void gap_affine_act_kernel(const bf16* __restrict__ x, const float* _
   float a[8], fsc[8], fsh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a[j] = 0.f; fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; }
-  const bf16* __restrict__ xb = x + (size_t)b * HW * C + cq * 8;
+  const T* __restrict__ xb = x + (size_t)b * HW * C + cq * 8;
   for (int p = p0 + rr; p < p1; p += U * rpp) {
-    U128 v[U];
+    typename V8<T>::raw v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int pp = p + u * rpp;
-      v[u].u = *reinterpret_cast<const uint4*>(xb + (size_t)(pp < p1 ? pp : p1 - 1) * C);
+      v[u] = V8<T>::ld(xb + (size_t)(pp < p1 ? pp : p1 - 1) * C);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = p + u * rpp < p1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float z = fmaf(bf2f(v[u].e[j]), fsc[j], fsh[j]);
+        const float z = fmaf(V8<T>::get(v[u], j), fsc[j], fsh[j]);
         const float t = act == 2 ? swishf_(z) : (act == 1 ? fmaxf(z, 0.f) : z);
         a[j] += ok ? t : 0.f;
       }
@@ -312,27 +320,30 @@ __global__ __launch_bounds__(1024) void se_fwd_kernel(const float* __restrict__ 
 }
 
 // u = swish(x*sc+sh) * s[b][c]       (the tensor the projection conv consumes)
-__global__ void scale_act_bc_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
-                                    const float* __restrict__ s, bf16* __restrict__ u, int HW, int C, size_t total) {
+template <typename T>
+__global__ void scale_act_bc_kernel(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                    const float* __restrict__ s, T* __restrict__ u, int HW, int C, size_t total) {
   const int CP = C / 8;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int cq = idx % CP;
     const size_t pix = idx / CP;
     const int b = pix / HW;
-    U128 v, o;
-    v.u = *reinterpret_cast<const uint4*>(x + idx * 8);
+    typename V8<T>::raw v;
+    float o_f[8];
+    v = V8<T>::ld(x + idx * 8);
     float fsc[8], fsh[8], fs[8];
     load8(sc + cq * 8, fsc);
     load8(sh + cq * 8, fsh);
     if (s) load8(s + (size_t)b * C + cq * 8, fs);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(swishf_(fmaf(bf2f(v.e[j]), fsc[j], fsh[j])) * (s ? fs[j] : 1.f));
-    *reinterpret_cast<uint4*>(u + idx * 8) = o.u;
+    for (int j = 0; j < 8; ++j) o_f[j] = V8<T>::rnd(swishf_(fmaf(V8<T>::get(v, j), fsc[j], fsh[j])) * (s ? fs[j] : 1.f));
+    V8<T>::st(u + idx * 8, o_f);
   }
 }
 
 // linear BatchNorm backward statistics: S1 += sum g, S2 += sum g * (y-mean)*rstd
-__global__ void bn_lin_bwd_stats_kernel(const bf16* __restrict__ g, const bf16* __restrict__ y, const float* __restrict__ mean,
+template <typename T>
+__global__ void bn_lin_bwd_stats_kernel(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ mean,
                                         const float* __restrict__ rstd, float* S1, float* S2, size_t rows, int C) {
   extern __shared__ float lds[];
   const int CP = C / 8;
@@ -345,21 +356,21 @@ __global__ void bn_lin_bwd_stats_kernel(const bf16* __restrict__ g, const bf16* 
   const size_t ppb = blockDim.x / CP, stride = (size_t)gridDim.x * ppb;
   constexpr int U = 4;                       // pixel rows in flight per thread
   for (size_t pix0 = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix0 < rows; pix0 += U * stride) {
-    U128 u[U], v[U];
+    typename V8<T>::raw u[U], v[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const size_t pix = pix0 + i * stride < rows ? pix0 + i * stride : pix0;
-      u[i].u = *reinterpret_cast<const uint4*>(g + pix * C + cq * 8);
-      v[i].u = *reinterpret_cast<const uint4*>(y + pix * C + cq * 8);
+      u[i] = V8<T>::ld(g + pix * C + cq * 8);
+      v[i] = V8<T>::ld(y + pix * C + cq * 8);
     }
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const bool ok = pix0 + i * stride < rows;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float gf = ok ? bf2f(u[i].e[j]) : 0.f;
+        const float gf = ok ? V8<T>::get(u[i], j) : 0.f;
         s[0][j] += gf;
-        s[1][j] += gf * (bf2f(v[i].e[j]) - fmu[j]) * fr[j];
+        s[1][j] += gf * (V8<T>::get(v[i], j) - fmu[j]) * fr[j];
       }
     }
   }
@@ -368,7 +379,8 @@ __global__ void bn_lin_bwd_stats_kernel(const bf16* __restrict__ g, const bf16* 
 }
 
 // ds[b][c] = sum_hw du * swish(x*sc+sh)
-__global__ void se_bwd_reduce_kernel(const bf16* __restrict__ du, const bf16* __restrict__ x, const float* __restrict__ sc,
+template <typename T>
+__global__ void se_bwd_reduce_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ sc,
                                      const float* __restrict__ sh, float* __restrict__ ds, int HW, int C, int splits) {
   extern __shared__ float lds[];
   constexpr int U = 4;                       // pixel rows in flight per thread (see gap_affine_act_kernel)
@@ -383,20 +395,20 @@ __global__ void se_bwd_reduce_kernel(const bf16* __restrict__ du, const bf16* __
   for (int j = 0; j < 8; ++j) { a[j] = 0.f; fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; }
   const size_t base = (size_t)b * HW * C + cq * 8;
   for (int p = p0 + rr; p < p1; p += U * rpp) {
-    U128 v[U], d[U];
+    typename V8<T>::raw v[U], d[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int pp = p + u * rpp;
       const size_t off = base + (size_t)(pp < p1 ? pp : p1 - 1) * C;
-      v[u].u = *reinterpret_cast<const uint4*>(x + off);
-      d[u].u = *reinterpret_cast<const uint4*>(du + off);
+      v[u] = V8<T>::ld(x + off);
+      d[u] = V8<T>::ld(du + off);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = p + u * rpp < p1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float t = bf2f(d[u].e[j]) * swishf_(fmaf(bf2f(v[u].e[j]), fsc[j], fsh[j]));
+        const float t = V8<T>::get(d[u], j) * swishf_(fmaf(V8<T>::get(v[u], j), fsc[j], fsh[j]));
         a[j] += ok ? t : 0.f;
       }
     }
@@ -480,10 +492,10 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ 
 }
 
 // dz = (du * s[b][c] + dpooled[b][c]/HW) * swish'(x*sc+sh);  S1 += dz, S2 += dz * (x-mean)*rstd.   du / s may be null
-template <int U, int MAXT>
-__global__ __launch_bounds__(MAXT) void se_act_bwd_kernel(const bf16* __restrict__ du, const bf16* __restrict__ x, const float* __restrict__ sc,
+template <typename T, int U, int MAXT>
+__global__ __launch_bounds__(MAXT) void se_act_bwd_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ sc,
                                   const float* __restrict__ sh, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                  const float* __restrict__ s, const float* __restrict__ dpooled, bf16* __restrict__ dz, float* S1,
+                                  const float* __restrict__ s, const float* __restrict__ dpooled, T* __restrict__ dz, float* S1,
                                   float* S2, int B, int HW, int C) {
   extern __shared__ float lds[];
   const int CP = C / 8;
@@ -503,14 +515,14 @@ __global__ __launch_bounds__(MAXT) void se_act_bwd_kernel(const bf16* __restrict
   // first is consumed
   const unsigned np = (unsigned)npix, str = (unsigned)stride;
   for (unsigned pix0 = blockIdx.x * (unsigned)ppb + threadIdx.x / CP; pix0 < np; pix0 += U * str) {
-    U128 v[U], d[U];
+    typename V8<T>::raw v[U], d[U];
     float fdp[U][8], fs[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned pix = pix0 + u * str < np ? pix0 + u * str : pix0;
       const unsigned b = pix / (unsigned)HW;
-      v[u].u = *reinterpret_cast<const uint4*>(x + (size_t)pix * C + cq * 8);
-      if (du) d[u].u = *reinterpret_cast<const uint4*>(du + (size_t)pix * C + cq * 8);
+      v[u] = V8<T>::ld(x + (size_t)pix * C + cq * 8);
+      if (du) d[u] = V8<T>::ld(du + (size_t)pix * C + cq * 8);
       if (dpooled) load8(dpooled + (size_t)b * C + cq * 8, fdp[u]);
       if (du && s) load8(s + (size_t)b * C + cq * 8, fs[u]);
     }
@@ -518,18 +530,18 @@ __global__ __launch_bounds__(MAXT) void se_act_bwd_kernel(const bf16* __restrict
     for (int u = 0; u < U; ++u) {
       const unsigned pix = pix0 + u * str;
       const bool ok = pix < np;
-      U128 o;
+      float o_f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float xf = bf2f(v[u].e[j]);
+        const float xf = V8<T>::get(v[u], j);
         float da = dpooled ? fdp[u][j] * inv : 0.f;
-        if (du) da = fmaf(bf2f(d[u].e[j]), s ? fs[u][j] : 1.f, da);
+        if (du) da = fmaf(V8<T>::get(d[u], j), s ? fs[u][j] : 1.f, da);
         const float dzv = ok ? da * dswishf_(fmaf(xf, fsc[j], fsh[j])) : 0.f;
         st[0][j] += dzv;
         st[1][j] += dzv * (xf - fmu[j]) * fr[j];
-        o.e[j] = f2bf(dzv);
+        o_f[j] = V8<T>::rnd(dzv);
       }
-      if (ok) *reinterpret_cast<uint4*>(dz + (size_t)pix * C + cq * 8) = o.u;
+      if (ok) V8<T>::st(dz + (size_t)pix * C + cq * 8, o_f);
     }
   }
   float* const dst[2] = {S1, S2};
@@ -538,43 +550,47 @@ __global__ __launch_bounds__(MAXT) void se_act_bwd_kernel(const bf16* __restrict
 
 // out = a*pa + (b ? b : 0)*pb + pc   (BatchNorm output + optional skip, no activation)
 // ps (optional): per-sample scale of the a-branch = the DropConnect mask / keep probability (efficientnet.py:44-51)
-__global__ void affine2_out_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const float* __restrict__ pa,
+template <typename T>
+__global__ void affine2_out_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ pa,
                                    const float* __restrict__ pb, const float* __restrict__ pc, const float* __restrict__ ps,
-                                   size_t rows_per_sample, bf16* __restrict__ out, size_t rows, int C) {
+                                   size_t rows_per_sample, T* __restrict__ out, size_t rows, int C) {
   const int CP = C / 8;
   const size_t total = rows * CP;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int cq = idx % CP;
     const float sb = ps ? ps[(idx / CP) / rows_per_sample] : 1.f;
-    U128 u, v, o;
-    u.u = *reinterpret_cast<const uint4*>(a + idx * 8);
-    if (b) v.u = *reinterpret_cast<const uint4*>(b + idx * 8);
+    typename V8<T>::raw u, v;
+    float o_f[8];
+    u = V8<T>::ld(a + idx * 8);
+    if (b) v = V8<T>::ld(b + idx * 8);
     float fpa[8], fpb[8], fpc[8];
     load8(pa + cq * 8, fpa);
     load8(pc + cq * 8, fpc);
     if (b) load8(pb + cq * 8, fpb);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float r = sb * fmaf(bf2f(u.e[j]), fpa[j], fpc[j]);
-      if (b) r = fmaf(bf2f(v.e[j]), fpb[j], r);
-      o.e[j] = f2bf(r);
+      float r = sb * fmaf(V8<T>::get(u, j), fpa[j], fpc[j]);
+      if (b) r = fmaf(V8<T>::get(v, j), fpb[j], r);
+      o_f[j] = V8<T>::rnd(r);
     }
-    *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
+    V8<T>::st(out + idx * 8, o_f);
   }
 }
 
 // out[row][:] = ps[row / rows_per_sample] * g[row][:]   (gradient of the DropConnect-ed branch)
-__global__ void scale_rows_kernel(const bf16* __restrict__ g, const float* __restrict__ ps, size_t rows_per_sample, bf16* __restrict__ out,
+template <typename T>
+__global__ void scale_rows_kernel(const T* __restrict__ g, const float* __restrict__ ps, size_t rows_per_sample, T* __restrict__ out,
                                   size_t rows, int C) {
   const int CP = C / 8;
   const size_t total = rows * CP;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const float sb = ps[(idx / CP) / rows_per_sample];
-    U128 u, o;
-    u.u = *reinterpret_cast<const uint4*>(g + idx * 8);
+    typename V8<T>::raw u;
+    float o_f[8];
+    u = V8<T>::ld(g + idx * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(sb * bf2f(u.e[j]));
-    *reinterpret_cast<uint4*>(out + idx * 8) = o.u;
+    for (int j = 0; j < 8; ++j) o_f[j] = V8<T>::rnd(sb * V8<T>::get(u, j));
+    V8<T>::st(out + idx * 8, o_f);
   }
 }
 
@@ -609,78 +625,85 @@ __global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __re
 
 }  // namespace
 
-extern "C" {
+// ---- launchers, templated on the storage type (bf16 / the fp32 parity mode)
+namespace {
 
-int cx_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, void* stream) {
+template <typename T>
+int nchw3_to_nhwc8_t(const float* x, void* y, int B, int H, int W, void* stream) {
   if (!x || !y || B <= 0 || H <= 0 || W <= 0) return CX_EINVAL;
   const size_t hw = (size_t)H * W, total = hw * B;
-  hipLaunchKernelGGL(nchw3_to_nhwc8_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y, hw, total);
+  hipLaunchKernelGGL(nchw3_to_nhwc8_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), x, (T*)y, hw, total);
   return launch_status();
 }
 
-int cx_u8_to_nhwc8(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream) {
+template <typename T>
+int u8_to_nhwc8_t(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream) {
   if (!x || !y || std <= 0.f) return CX_EINVAL;
-  hipLaunchKernelGGL(u8_to_nhwc8_kernel, dim3((npix + 255) / 256), dim3(256), 0, as_stream(stream), x, (bf16*)y, 1.f / (255.f * std),
+  hipLaunchKernelGGL(u8_to_nhwc8_kernel<T>, dim3((npix + 255) / 256), dim3(256), 0, as_stream(stream), x, (T*)y, 1.f / (255.f * std),
                      -mean / std, npix);
   return launch_status();
 }
 
-int cx_dwconv_fwd(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
+template <typename T>
+int dwconv_fwd_t(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
                   int W, int C, int k, int stride, int pad, void* stream) {
   if (!x || !w || !y || C % 8 || C > 4096 || k < 1 || stride < 1 || (sc && !sh)) return CX_EINVAL;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
   if (CP > 1024) return CX_ESHAPE;
-  {
+  if constexpr (std::is_same<T, bf16>::value) {      // the tiled fast paths are bf16 kernels
     bool handled = false;
     const int rc = cx_try_dw_tile(0, x, w, sc, sh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, y, nullptr, stat_sum,
                                   stat_sq, nullptr, 0, B, H, W, C, k, stride, pad, as_stream(stream), &handled);
     if (handled) return rc;
   }
   const size_t npix = (size_t)B * Ho * Wo;
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
-                     (const bf16*)x, w, sc, sh, (bf16*)y, stat_sum, stat_sq, B, H, W, C, Ho, Wo, k, stride, pad);
+  hipLaunchKernelGGL(dwconv_fwd_kernel<T>, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+                     (const T*)x, w, sc, sh, (T*)y, stat_sum, stat_sq, B, H, W, C, Ho, Wo, k, stride, pad);
   return launch_status();
 }
 
-int cx_dwconv_dgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
+template <typename T>
+int dwconv_dgrad_t(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
                     const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
                     int W, int C, int k, int stride, int pad, int accumulate, void* stream) {
   if (!g || !g2 || !ga || !gb || !gc || !w || !x || !dz || C % 8 || C / 8 > 1024) return CX_EINVAL;
   if (sc && (!sh || !mean || !rstd || !S1 || !S2)) return CX_EINVAL;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
-  {
+  if constexpr (std::is_same<T, bf16>::value) {      // the tiled fast paths are bf16 kernels
     bool handled = false;
     const int rc = cx_try_dw_tile(1, x, w, sc, sh, mean, rstd, g, g2, ga, gb, gc, nullptr, dz, S1, S2, nullptr, accumulate, B, H, W, C, k,
                                   stride, pad, as_stream(stream), &handled);
     if (handled) return rc;
   }
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
-                     (const bf16*)g, (const bf16*)g2, ga, gb, gc, w, (const bf16*)x, sc, sh, mean, rstd, (bf16*)dz, S1, S2, B, H, W, C, Ho,
+  hipLaunchKernelGGL(dwconv_dgrad_kernel<T>, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+                     (const T*)g, (const T*)g2, ga, gb, gc, w, (const T*)x, sc, sh, mean, rstd, (T*)dz, S1, S2, B, H, W, C, Ho,
                      Wo, k, stride, pad, accumulate);
   return launch_status();
 }
 
-int cx_dwconv_wgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
+template <typename T>
+int dwconv_wgrad_t(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
                     const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream) {
   if (!g || !g2 || !ga || !gb || !gc || !x || !dw || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
-  {
+  if constexpr (std::is_same<T, bf16>::value) {      // the tiled fast paths are bf16 kernels
     bool handled = false;
     const int rc = cx_try_dw_tile(2, x, nullptr, sc, sh, nullptr, nullptr, g, g2, ga, gb, gc, nullptr, nullptr, nullptr, nullptr, dw, 0, B,
                                   H, W, C, k, stride, pad, as_stream(stream), &handled);
     if (handled) return rc;
   }
   const size_t npix = (size_t)B * Ho * Wo;
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(grid_for(npix, th / CP, 256), k * k), dim3(th), C * sizeof(float), as_stream(stream),
-                     (const bf16*)g, (const bf16*)g2, ga, gb, gc, (const bf16*)x, sc, sh, dw, B, H, W, C, Ho, Wo, k, stride, pad);
+  hipLaunchKernelGGL(dwconv_wgrad_kernel<T>, dim3(grid_for(npix, th / CP, 256), k * k), dim3(th), C * sizeof(float), as_stream(stream),
+                     (const T*)g, (const T*)g2, ga, gb, gc, (const T*)x, sc, sh, dw, B, H, W, C, Ho, Wo, k, stride, pad);
   return launch_status();
 }
 
-int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream) {
+template <typename T>
+int gap_affine_act_t(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream) {
   if (!x || !sc || !sh || !pooled || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int CP = C / 8, th = threads_for(CP);
   int splits = 1024 / B;
@@ -688,9 +711,128 @@ int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* po
   if (splits > HW / 16 + 1) splits = HW / 16 + 1;
   hipError_t e = hipMemsetAsync(pooled, 0, (size_t)B * C * sizeof(float), as_stream(stream));
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gap_affine_act_kernel, dim3(splits, B), dim3(th), C * sizeof(float), as_stream(stream), (const bf16*)x, sc, sh, pooled, HW, C, act,
+  hipLaunchKernelGGL(gap_affine_act_kernel<T>, dim3(splits, B), dim3(th), C * sizeof(float), as_stream(stream), (const T*)x, sc, sh, pooled, HW, C, act,
                      splits);
   return launch_status();
+}
+
+template <typename T>
+int scale_act_bc_t(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream) {
+  if (!x || !sc || !sh || !u || C % 8) return CX_EINVAL;
+  const size_t total = (size_t)B * HW * (C / 8);
+  hipLaunchKernelGGL(scale_act_bc_kernel<T>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(stream), (const T*)x, sc, sh, s,
+                     (T*)u, HW, C, total);
+  return launch_status();
+}
+
+template <typename T>
+int bn_lin_bwd_stats_t(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
+                        void* stream) {
+  if (!g || !y || !mean || !rstd || !S1 || !S2 || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  hipLaunchKernelGGL(bn_lin_bwd_stats_kernel<T>, dim3(grid_for(rows, 8 * (th / CP), 1024)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+                     (const T*)g, (const T*)y, mean, rstd, S1, S2, rows, C);
+  return launch_status();
+}
+
+template <typename T>
+int se_bwd_reduce_t(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream) {
+  if (!du || !x || !sc || !sh || !ds || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  int splits = 1024 / B;
+  if (splits < 1) splits = 1;
+  if (splits > HW / 16 + 1) splits = HW / 16 + 1;
+  hipError_t e = hipMemsetAsync(ds, 0, (size_t)B * C * sizeof(float), as_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(se_bwd_reduce_kernel<T>, dim3(splits, B), dim3(th), C * sizeof(float), as_stream(stream), (const T*)du, (const T*)x, sc, sh, ds, HW,
+                     C, splits);
+  return launch_status();
+}
+
+template <typename T>
+int se_act_bwd_t(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream) {
+  if (!x || !sc || !sh || !mean || !rstd || !dz || !S1 || !S2 || (!du && !dpooled) || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  if ((size_t)B * HW >= (1u << 31)) return CX_ESHAPE;
+  if (th <= 512)
+    hipLaunchKernelGGL((se_act_bwd_kernel<T, 4, 512>), dim3(grid_for((size_t)B * HW, 8 * (th / CP), 1024)), dim3(th), 2 * C * sizeof(float),
+                       as_stream(stream), (const T*)du, (const T*)x, sc, sh, mean, rstd, s, dpooled, (T*)dz, S1, S2, B, HW, C);
+  else
+    hipLaunchKernelGGL((se_act_bwd_kernel<T, 1, 1024>), dim3(grid_for((size_t)B * HW, th / CP, 2048)), dim3(th), 2 * C * sizeof(float),
+                       as_stream(stream), (const T*)du, (const T*)x, sc, sh, mean, rstd, s, dpooled, (T*)dz, S1, S2, B, HW, C);
+  return launch_status();
+}
+
+template <typename T>
+int affine2_out_t(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,
+                   size_t rows_per_sample, void* out, size_t rows, int C, void* stream) {
+  if (!a || !pa || !pc || !out || (b && !pb) || C % 8 || (sample_scale && rows_per_sample == 0)) return CX_EINVAL;
+  hipLaunchKernelGGL(affine2_out_kernel<T>, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const T*)a,
+                     (const T*)b, pa, pb, pc, sample_scale, sample_scale ? rows_per_sample : (size_t)1, (T*)out, rows, C);
+  return launch_status();
+}
+
+template <typename T>
+int scale_rows_t(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream) {
+  if (!g || !sample_scale || !out || rows_per_sample == 0 || C % 8) return CX_EINVAL;
+  hipLaunchKernelGGL(scale_rows_kernel<T>, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const T*)g,
+                     sample_scale, rows_per_sample, (T*)out, rows, C);
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cx_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, void* stream) {
+  return nchw3_to_nhwc8_t<bf16>(x, y, B, H, W, stream);
+}
+int cx_nchw3_to_nhwc8_f32(const float* x, void* y, int B, int H, int W, void* stream) {
+  return nchw3_to_nhwc8_t<float>(x, y, B, H, W, stream);
+}
+
+int cx_u8_to_nhwc8(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream) {
+  return u8_to_nhwc8_t<bf16>(x, y, npix, mean, std, stream);
+}
+int cx_u8_to_nhwc8_f32(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream) {
+  return u8_to_nhwc8_t<float>(x, y, npix, mean, std, stream);
+}
+
+int cx_dwconv_fwd(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
+                  int W, int C, int k, int stride, int pad, void* stream) {
+  return dwconv_fwd_t<bf16>(x, w, sc, sh, y, stat_sum, stat_sq, B, H, W, C, k, stride, pad, stream);
+}
+int cx_dwconv_fwd_f32(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
+                  int W, int C, int k, int stride, int pad, void* stream) {
+  return dwconv_fwd_t<float>(x, w, sc, sh, y, stat_sum, stat_sq, B, H, W, C, k, stride, pad, stream);
+}
+
+int cx_dwconv_dgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
+                    const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
+                    int W, int C, int k, int stride, int pad, int accumulate, void* stream) {
+  return dwconv_dgrad_t<bf16>(g, g2, ga, gb, gc, w, x, sc, sh, mean, rstd, dz, S1, S2, B, H, W, C, k, stride, pad, accumulate, stream);
+}
+int cx_dwconv_dgrad_f32(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
+                    const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
+                    int W, int C, int k, int stride, int pad, int accumulate, void* stream) {
+  return dwconv_dgrad_t<float>(g, g2, ga, gb, gc, w, x, sc, sh, mean, rstd, dz, S1, S2, B, H, W, C, k, stride, pad, accumulate, stream);
+}
+
+int cx_dwconv_wgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream) {
+  return dwconv_wgrad_t<bf16>(g, g2, ga, gb, gc, x, sc, sh, dw, B, H, W, C, k, stride, pad, stream);
+}
+int cx_dwconv_wgrad_f32(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream) {
+  return dwconv_wgrad_t<float>(g, g2, ga, gb, gc, x, sc, sh, dw, B, H, W, C, k, stride, pad, stream);
+}
+
+int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream) {
+  return gap_affine_act_t<bf16>(x, sc, sh, pooled, B, HW, C, act, stream);
+}
+int cx_gap_affine_act_f32(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream) {
+  return gap_affine_act_t<float>(x, sc, sh, pooled, B, HW, C, act, stream);
 }
 
 int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
@@ -701,33 +843,26 @@ int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float
 }
 
 int cx_scale_act_bc(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream) {
-  if (!x || !sc || !sh || !u || C % 8) return CX_EINVAL;
-  const size_t total = (size_t)B * HW * (C / 8);
-  hipLaunchKernelGGL(scale_act_bc_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)x, sc, sh, s,
-                     (bf16*)u, HW, C, total);
-  return launch_status();
+  return scale_act_bc_t<bf16>(x, sc, sh, s, u, B, HW, C, stream);
+}
+int cx_scale_act_bc_f32(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream) {
+  return scale_act_bc_t<float>(x, sc, sh, s, u, B, HW, C, stream);
 }
 
 int cx_bn_lin_bwd_stats(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
                         void* stream) {
-  if (!g || !y || !mean || !rstd || !S1 || !S2 || C % 8 || C / 8 > 1024) return CX_EINVAL;
-  const int CP = C / 8, th = threads_for(CP);
-  hipLaunchKernelGGL(bn_lin_bwd_stats_kernel, dim3(grid_for(rows, 8 * (th / CP), 1024)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
-                     (const bf16*)g, (const bf16*)y, mean, rstd, S1, S2, rows, C);
-  return launch_status();
+  return bn_lin_bwd_stats_t<bf16>(g, y, mean, rstd, S1, S2, rows, C, stream);
+}
+int cx_bn_lin_bwd_stats_f32(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
+                        void* stream) {
+  return bn_lin_bwd_stats_t<float>(g, y, mean, rstd, S1, S2, rows, C, stream);
 }
 
 int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream) {
-  if (!du || !x || !sc || !sh || !ds || C % 8 || C / 8 > 1024) return CX_EINVAL;
-  const int CP = C / 8, th = threads_for(CP);
-  int splits = 1024 / B;
-  if (splits < 1) splits = 1;
-  if (splits > HW / 16 + 1) splits = HW / 16 + 1;
-  hipError_t e = hipMemsetAsync(ds, 0, (size_t)B * C * sizeof(float), as_stream(stream));
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(splits, B), dim3(th), C * sizeof(float), as_stream(stream), (const bf16*)du, (const bf16*)x, sc, sh, ds, HW,
-                     C, splits);
-  return launch_status();
+  return se_bwd_reduce_t<bf16>(du, x, sc, sh, ds, B, HW, C, stream);
+}
+int cx_se_bwd_reduce_f32(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream) {
+  return se_bwd_reduce_t<float>(du, x, sc, sh, ds, B, HW, C, stream);
 }
 
 int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
@@ -750,31 +885,27 @@ int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* poo
 
 int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
                   const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream) {
-  if (!x || !sc || !sh || !mean || !rstd || !dz || !S1 || !S2 || (!du && !dpooled) || C % 8 || C / 8 > 1024) return CX_EINVAL;
-  const int CP = C / 8, th = threads_for(CP);
-  if ((size_t)B * HW >= (1u << 31)) return CX_ESHAPE;
-  if (th <= 512)
-    hipLaunchKernelGGL((se_act_bwd_kernel<4, 512>), dim3(grid_for((size_t)B * HW, 8 * (th / CP), 1024)), dim3(th), 2 * C * sizeof(float),
-                       as_stream(stream), (const bf16*)du, (const bf16*)x, sc, sh, mean, rstd, s, dpooled, (bf16*)dz, S1, S2, B, HW, C);
-  else
-    hipLaunchKernelGGL((se_act_bwd_kernel<1, 1024>), dim3(grid_for((size_t)B * HW, th / CP, 2048)), dim3(th), 2 * C * sizeof(float),
-                       as_stream(stream), (const bf16*)du, (const bf16*)x, sc, sh, mean, rstd, s, dpooled, (bf16*)dz, S1, S2, B, HW, C);
-  return launch_status();
+  return se_act_bwd_t<bf16>(du, x, sc, sh, mean, rstd, s, dpooled, dz, S1, S2, B, HW, C, stream);
+}
+int cx_se_act_bwd_f32(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream) {
+  return se_act_bwd_t<float>(du, x, sc, sh, mean, rstd, s, dpooled, dz, S1, S2, B, HW, C, stream);
 }
 
 int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,
                    size_t rows_per_sample, void* out, size_t rows, int C, void* stream) {
-  if (!a || !pa || !pc || !out || (b && !pb) || C % 8 || (sample_scale && rows_per_sample == 0)) return CX_EINVAL;
-  hipLaunchKernelGGL(affine2_out_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)a,
-                     (const bf16*)b, pa, pb, pc, sample_scale, sample_scale ? rows_per_sample : (size_t)1, (bf16*)out, rows, C);
-  return launch_status();
+  return affine2_out_t<bf16>(a, b, pa, pb, pc, sample_scale, rows_per_sample, out, rows, C, stream);
+}
+int cx_affine2_out_f32(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,
+                   size_t rows_per_sample, void* out, size_t rows, int C, void* stream) {
+  return affine2_out_t<float>(a, b, pa, pb, pc, sample_scale, rows_per_sample, out, rows, C, stream);
 }
 
 int cx_scale_rows(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream) {
-  if (!g || !sample_scale || !out || rows_per_sample == 0 || C % 8) return CX_EINVAL;
-  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)g,
-                     sample_scale, rows_per_sample, (bf16*)out, rows, C);
-  return launch_status();
+  return scale_rows_t<bf16>(g, sample_scale, rows_per_sample, out, rows, C, stream);
+}
+int cx_scale_rows_f32(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream) {
+  return scale_rows_t<float>(g, sample_scale, rows_per_sample, out, rows, C, stream);
 }
 
 int cx_dropout_mask(float* out, size_t n, float keep_prob, unsigned long long seed, void* stream) {

@@ -40,38 +40,7 @@ __device__ __forceinline__ void block_stats_flush(const float (&s1)[8], const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// 8-channel vector I/O of the element-wise kernels for both storage types (bf16: one 16-B access; fp32: two)
-template <typename T> struct V8;
-template <> struct V8<bf16> {
-  typedef uint4 raw;
-  static __device__ __forceinline__ raw ld(const bf16* p) { return *reinterpret_cast<const uint4*>(p); }
-  static __device__ __forceinline__ float get(const raw& r, int j) { U128 u; u.u = r; return bf2f(u.e[j]); }
-  static __device__ __forceinline__ void st(bf16* p, const float (&v)[8]) {
-    U128 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(v[j]);
-    *reinterpret_cast<uint4*>(p) = o.u;
-  }
-  static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }      // the value as stored
-};
-template <> struct V8<float> {
-  struct raw { float4 a, b; };
-  static __device__ __forceinline__ raw ld(const float* p) {
-    raw r;
-    r.a = *reinterpret_cast<const float4*>(p);
-    r.b = *reinterpret_cast<const float4*>(p + 4);
-    return r;
-  }
-  static __device__ __forceinline__ float get(const raw& r, int j) {
-    const float v[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
-    return v[j];
-  }
-  static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  }
-  static __device__ __forceinline__ float rnd(float v) { return v; }
-};
+// (8-channel vector I/O for both storage types: V8<T> in common.h)
 
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, bf16* __restrict__ out, int O, int I, int kh, int kw,

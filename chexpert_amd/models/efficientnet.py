@@ -105,9 +105,22 @@ class _Region:
         return (off, n)
 
 
+class _LibF32:
+    """The C ABI with the `_f32` twin of an entry point where one exists (the fp32 storage mode)."""
+
+    def __init__(self, l):
+        self._l = l
+
+    def __getattr__(self, name):
+        return getattr(self._l, name + "_f32", None) or getattr(self._l, name)
+
+
 class _Engine:
     def __init__(self, model):
         self.model = model
+        # activation storage type: bf16, or fp32 = north_star's "1e-3 fp32" parity mode (generic f32-MFMA convolutions, the
+        # storage-typed depthwise / squeeze-excite / Swish kernels of csrc/effnet.hip; no tiled fast paths)
+        self.dtype = getattr(model, "_storage_dtype", torch.bfloat16)
         self.flat = None
         self.device = None
         self.pool = {}
@@ -170,16 +183,18 @@ class _Engine:
                     self.wb[id(mod)] = add(mod, transpose=True)
         self.stem_off = cur
         cur += 9 * m.stem[0].out_channels * 8
-        self.packed = torch.empty(cur, dtype=torch.bfloat16, device=dev)
+        self.packed = torch.empty(cur, dtype=self.dtype, device=dev)
         arr = (CxPackDesc * len(descs))(*descs)
         self.desc_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self.n_desc = len(descs)
 
     def pack(self):
-        check(lib().cx_pack_weights_table(ptr(self.flat), ptr(self.packed), ptr(self.desc_dev), self.n_desc, stream_ptr()),
-              "cx_pack_weights_table")
+        ops.pack_weights_table(self.flat, self.packed, self.desc_dev, self.n_desc)
         w8 = F.pad(self.model.stem[0].weight.detach(), (0, 0, 0, 0, 0, 5)).contiguous()       # (O,3,3,3) -> (O,8,3,3)
-        ops.pack_weights(w8, out=self.packed[self.stem_off:])
+        if self.dtype == torch.float32:         # [tap][O][I] fp32: a 3 K-element layout copy
+            self.packed[self.stem_off:self.stem_off + w8.numel()].copy_(w8.permute(2, 3, 0, 1).reshape(-1))
+        else:
+            ops.pack_weights(w8, out=self.packed[self.stem_off:])
 
     def w_fwd(self, conv):
         off, n = self.wf[id(conv)]
@@ -198,7 +213,7 @@ class _Engine:
         lst = self.pool.setdefault((B, H, W), [])
         if lst:
             return lst.pop()
-        dev, bf, f32 = self.device, torch.bfloat16, torch.float32
+        dev, bf, f32 = self.device, self.dtype, torch.float32
         e = lambda *s, dtype=bf: torch.empty(*s, dtype=dtype, device=dev)
         m = self.model
         ws = type("WS", (), {})()
@@ -263,7 +278,7 @@ class _Engine:
 
     # ---- forward
     def forward(self, x, train):
-        m, v, lb = self.model, self._v, lib()
+        m, v, lb = self.model, self._v, (_LibF32(lib()) if self.dtype == torch.float32 else lib())
         u8 = x.dtype == torch.uint8             # decoded grey bytes (B,1,H,W): whitened + expanded on the GPU (cx_u8_to_nhwc8)
         if x.dim() != 4 or x.shape[1] != (1 if u8 else 3):
             raise RuntimeError("expected a (B,3,H,W) float input or a (B,1,H,W) uint8 image")
@@ -356,7 +371,7 @@ class _Engine:
     def _alloc_bwd(self, ws):
         if ws.bwd is not None:
             return
-        dev, bf, B = self.device, torch.bfloat16, ws.B
+        dev, bf, B = self.device, self.dtype, ws.B
         bw = {"g": []}
         shapes = {}
         for t in ws.blk:
@@ -374,7 +389,7 @@ class _Engine:
 
     def backward(self, ws, dlogits):
         ops.set_det_wgrad(False)               # (this engine's statistics still use atomics: no point in slab sums)
-        m, v, G, lb = self.model, self._v, self.G, lib()
+        m, v, G, lb = self.model, self._v, self.G, (_LibF32(lib()) if self.dtype == torch.float32 else lib())
         B = ws.B
         sp = stream_ptr()
         self._alloc_bwd(ws)
@@ -541,9 +556,17 @@ class EfficientNet(nn.Module):
         self.drop_seed = 0           # seed of the Dropout / DropConnect masks (with the forward counter and the block index)
 
     def _eng(self):
-        if self._engine is None:
+        if self._engine is None or self._engine.dtype != getattr(self, "_storage_dtype", torch.bfloat16):
             object.__setattr__(self, "_engine", _Engine(self))
         return self._engine
+
+    def storage_dtype(self, dtype):
+        """torch.bfloat16 (default) or torch.float32: the fp32 parity mode (same method as DenseNet.storage_dtype)."""
+        dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(dtype, dtype)
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("storage dtype must be bf16 or fp32")
+        object.__setattr__(self, "_storage_dtype", dtype)
+        return self
 
     def state_dict(self, *args, **kwargs):
         if self._nbt_pending:

@@ -362,6 +362,26 @@ int cx_affine2_out(const void* a, const void* b, const float* pa, const float* p
 /* out[row][:] = sample_scale[row / rows_per_sample] * g[row][:]: gradient entering a DropConnect-ed branch            */
 int cx_scale_rows(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream);
 /* out[i] in {0, 1/keep_prob}: counter-based (splitmix64 of seed and index) Bernoulli mask for Dropout (:170) and DropConnect */
+/* fp32 storage-mode twins of the EfficientNet entry points above (activations fp32; the generic kernels, no tiled fast paths) */
+int cx_nchw3_to_nhwc8_f32(const float* x, void* y, int B, int H, int W, void* stream);
+int cx_u8_to_nhwc8_f32(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream);
+int cx_dwconv_fwd_f32(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
+                  int W, int C, int k, int stride, int pad, void* stream);
+int cx_dwconv_dgrad_f32(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
+                    const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
+                    int W, int C, int k, int stride, int pad, int accumulate, void* stream);
+int cx_dwconv_wgrad_f32(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream);
+int cx_gap_affine_act_f32(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream);
+int cx_scale_act_bc_f32(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream);
+int cx_bn_lin_bwd_stats_f32(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
+                        void* stream);
+int cx_se_bwd_reduce_f32(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream);
+int cx_se_act_bwd_f32(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream);
+int cx_affine2_out_f32(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,
+                   size_t rows_per_sample, void* out, size_t rows, int C, void* stream);
+int cx_scale_rows_f32(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream);
 int cx_dropout_mask(float* out, size_t n, float keep_prob, unsigned long long seed, void* stream);
 int cx_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream);
 int cx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int N, void* stream);

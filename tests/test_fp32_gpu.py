@@ -328,3 +328,52 @@ def test_fp32_resnet152_matches_reference_golden_fixture(dev, tag, smooth):
     # away -- 152 layers of ReLU / max-pool decisions within fp32 rounding of their threshold (the fp32 oracle differs from the same
     # oracle in fp64 by as much there, cf. the DenseNet note above)
     assert worst[0] < (1e-2 if smooth else 1e-1)
+
+
+def _effnet(name, n_cls, seed, dev, smooth):
+    from chexpert_amd.models import construct_model
+    from chexpert_amd.models.efficientnet import DropMarker
+    from oracle import nets
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(nets.efficientnet_spec(name, n_cls)), seed)
+    if smooth:
+        synth.smooth_state_dict_(sd, 1.0)
+    model = construct_model(name, n_cls).storage_dtype("fp32")
+    model.load_state_dict(sd, strict=True)
+    for mod in model.modules():                          # deterministic part, as the goldens were recorded
+        if isinstance(mod, DropMarker):
+            mod.p = 0.0
+    return model.to(dev), sd
+
+
+@pytest.mark.parametrize("tag,smooth", [("efficientnet-b0_224_b2", False), ("efficientnet-b0_224_b8", True), ("efficientnet-b4_380_b2", False),
+                                        ("efficientnet-b4_380_b8", True)])
+def test_fp32_efficientnet_matches_reference_golden_fixture(dev, tag, smooth):
+    """EfficientNet (models/efficientnet.py:78-185) in the fp32 storage mode against the REAL reference: depthwise convolutions,
+    squeeze-excite, Swish and the linear BatchNorm glue on fp32 tensors (csrc/effnet.hip templated on the storage type), the 1x1
+    convolutions through conv_f32_kernel; north_star's 1e-3 on eval and train logits, loss to 1e-4, gradient norms to 1e-2."""
+    rec = json.load(open(os.path.join(G, "nets_smooth.json" if smooth else "nets.json")))[tag]
+    name = tag.split("_")[0]
+    model, sd = _effnet(name, rec["n_classes"], rec["sd_seed"], dev, smooth)
+    assert model._eng().dtype == torch.float32
+    x = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"]).to(dev)
+    t = synth.targets(rec["t_seed"], rec["B"], rec["n_classes"]).to(dev)
+    want_e = torch.tensor(rec["logits_eval"])
+    model.eval()
+    with torch.no_grad():
+        e_eval = _rel(model(x).cpu(), want_e)
+    model.train()
+    loss, logits = model.forward_backward(x, t)
+    e_train = _rel(logits.cpu(), torch.tensor(rec["logits_train"]))
+    worst = (0.0, "")
+    gmax = max(r["l2"] for r in rec["grads"].values())
+    for k, p in model.named_parameters():
+        ref = rec["grads"][k]
+        if ref["l2"] > 1e-4 * gmax:
+            worst = max(worst, (abs(p.grad.double().norm().item() / ref["l2"] - 1), k))
+    print("fp32 %s: eval logits rel %.3e, train logits rel %.3e, loss %.6f (ref %.6f), worst gradient l2 deviation %.3e (%s)" % (
+        tag, e_eval, e_train, loss.item(), rec["loss"], worst[0], worst[1]))
+    if want_e.abs().max().item() < 1e3:      # (eval logits of the smooth states with hash running statistics reach 1e3 .. 1e6: skipped there)
+        assert e_eval < 1e-3
+    assert e_train < 1e-3
+    assert abs(loss.item() - rec["loss"]) < 1e-4 * rec["loss"]
+    assert worst[0] < 1e-2

@@ -23,6 +23,13 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     assert _lib.lib().cx_abi_version() == 6
     assert _lib.lib().cx_error_string(-3) == b"unsupported shape"
+    # every binding passes exactly the parameters the header declares (a short argtypes list makes ctypes pass the rest as 32-bit
+    # ints: truncated device pointers, i.e. a GPU memory fault instead of an error)
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(cx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", code, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("", "void") else args.count(",") + 1
+        assert len(_lib.SIGNATURES[name]) == n, "%s: header declares %d parameters, the binding passes %d" % (name, n, len(_lib.SIGNATURES[name]))
 
 
 def test_validation_codes_without_launching():
