@@ -25,9 +25,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALG_BYTES_PER_IMG = 283.1e6    # densenet121@320 bf16, fwd+bwd
-ALG_BYTES_FP32 = {"densenet121": 566.2e6, "resnet152": 1110.0e6, "efficientnet-b4": 1189.0e6, "efficientnet-b0": 332.4e6}     # SURVEY.md section 8d, fp32 column
 ALG_BYTES = {"densenet121": 283.1e6, "aadensenet121": 295.4e6, "resnet152": 555.0e6, "aaresnet152": 555.0e6, "efficientnet-b4": 594.5e6,
              "efficientnet-b0": 166.2e6}
+ALG_BYTES_FP32 = {k_: 2.0 * v_ for k_, v_ in ALG_BYTES.items()}   # fp32 storage: twice the bf16 bytes (SURVEY.md section 8d, fp32 column)
 
 
 class KernelTimer:
@@ -332,21 +332,22 @@ def main():
             dist.init_process_group(backend)
 
     torch.manual_seed(1234)
-    if args.dtype == "fp32" and args.model not in ("densenet121", "resnet152", "efficientnet-b4", "efficientnet-b0"):
-        sys.exit("the fp32 storage mode covers densenet121, resnet152 and the EfficientNets")
+    # (the fp32 storage mode -- north_star's 1e-3 parity mode -- covers every model family)
     if args.model == "densenet121":
         model = densenet121(num_classes=args.classes).storage_dtype(args.dtype).to(dev)
     elif args.model == "aadensenet121":
         from chexpert_amd.models import DenseNet
         model = DenseNet(32, (6, 12, 24, 16), 64, num_classes=args.classes,
-                         attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (args.size, args.size)}).to(dev)
+                         attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (args.size, args.size)})
+        model = model.storage_dtype(args.dtype).to(dev)
     elif args.model == "resnet152":
         from chexpert_amd.models import resnet152
         model = resnet152(num_classes=args.classes).storage_dtype(args.dtype).to(dev)
     elif args.model == "aaresnet152":
         from chexpert_amd.models import Bottleneck, ResNet
         model = ResNet(Bottleneck, [3, 8, 36, 3], num_classes=args.classes,
-                       attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (args.size, args.size)}).to(dev)
+                       attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (args.size, args.size)})
+        model = model.storage_dtype(args.dtype).to(dev)
     else:
         from chexpert_amd.models import construct_model
         model = construct_model(args.model, args.classes).storage_dtype(args.dtype).to(dev)

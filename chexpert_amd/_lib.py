@@ -103,14 +103,22 @@ SIGNATURES = {
     "cx_rmsprop_step_dev": [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _vp],
     "cx_optim_tick": [_vp, _vp],
     "cx_aa_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_aa_attention_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_aa_attention_weights": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "cx_aa_attention_weights_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_aa_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_int64, _vp],
+    "cx_aa_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_int64, _vp],
     "cx_aa_outproj_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp],
+    "cx_aa_outproj_fwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp],
     "cx_aa_outproj_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, C.c_int64, _vp],
+    "cx_aa_outproj_bwd_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, C.c_int64, _vp],
     "cx_rows_reduce": [_vp, _vp, _i, _i, _i, _i, _vp],
     "cx_stats_bc": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_stats_bc_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_affine_relu_bc": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_affine_relu_bc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cx_in_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cx_in_relu_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_f32_to_bf16": [_vp, _vp, _sz, _vp],
     "cx_nchw3_to_nhwc8": [_vp, _vp, _i, _i, _i, _vp],
     "cx_nchw3_to_nhwc8_f32": [_vp, _vp, _i, _i, _i, _vp],

@@ -108,13 +108,12 @@ def make_model(args, device):
         model = model.storage_dtype(args.dtype).to(device)
         opt = O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)
         return model, opt, None
-    if args.dtype != "bf16" and name != "resnet152" and "efficientnet" not in name:
-        raise RuntimeError("--dtype fp32 covers densenet121, resnet152 and the EfficientNets")
     if name in ("aadensenet121", "densenet121_attn_aug"):      # chexpert.py:474-480 (README row name accepted too)
         from .models import DenseNet
         size = args.resize or 320
         model = DenseNet(32, (6, 12, 24, 16), 64, num_classes=args.n_classes,
-                         attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (size, size)}).to(device)
+                         attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (size, size)})
+        model = model.storage_dtype(args.dtype).to(device)
         if fused:
             return model, O.FusedSGDNesterov(model, lr=args.lr), "fused"
         opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, nesterov=True)
@@ -136,7 +135,8 @@ def make_model(args, device):
         from .models import Bottleneck, ResNet
         size = args.resize or 320
         model = ResNet(Bottleneck, [3, 8, 36, 3], num_classes=args.n_classes,
-                       attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (size, size)}).to(device)
+                       attn_params={"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (size, size)})
+        model = model.storage_dtype(args.dtype).to(device)
         return model, (O.FusedAdam(model, lr=args.lr) if fused else torch.optim.Adam(model.parameters(), lr=args.lr)), None
     raise RuntimeError("Model architecture not supported.")
 

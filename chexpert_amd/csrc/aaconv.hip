@@ -11,6 +11,7 @@
 // through LDS tiles and are read as broadcasts, softmax is online (one exp per key).  dkh = 20 and
 // dvh in {1,3,6} make the matrix cores pointless here (hard part 3): this is VALU work
 // bounded by LDS broadcast reads.  The backward pass recomputes P from the saved log-sum-exp.
+#include <type_traits>
 #include "common.h"
 
 // aaconv_row.hip: row-streamed kernels for map widths 40 and 20 (which: 0 forward, 1 the whole backward)
@@ -31,8 +32,8 @@ struct AAGeo {
 };
 
 // ---------------------------------------------------------------------------------------------- forward
-template <int DVH>
-__global__ __launch_bounds__(AQ) void aa_attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+template <typename T, int DVH>
+__global__ __launch_bounds__(AQ) void aa_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                                         const float* __restrict__ rel_w, float* __restrict__ o,
                                                         float* __restrict__ lse, const AAGeo g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -50,20 +51,19 @@ __global__ __launch_bounds__(AQ) void aa_attn_fwd_kernel(const bf16* __restrict_
   const bool qvalid = i < HW;
   const int ic = qvalid ? i : HW - 1;
   const int qy = ic / W, qx = ic - qy * W;
-  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  const T* base = qkv + (size_t)b * HW * g.ldq;
 
   for (int t = tid; t < DKH * LH; t += AQ) RH[t] = rel_h[t];
   for (int t = tid; t < DKH * LW; t += AQ) RW[t] = rel_w[t];
   float q[DKH];
   const float scale = rsqrtf((float)DKH);
   {
-    const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
+    const T* qp = base + (size_t)ic * g.ldq + n * DKH;
 #pragma unroll
     for (int d = 0; d < DKH; d += 4) {
-      U64 v;
-      v.u = *reinterpret_cast<const uint2*>(qp + d);
+      const typename V4<T>::raw v = V4<T>::ld(qp + d);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) q[d + e] = bf2f(v.e[e]) * scale;
+      for (int e = 0; e < 4; ++e) q[d + e] = V4<T>::get(v, e) * scale;
     }
   }
   __syncthreads();
@@ -90,15 +90,14 @@ __global__ __launch_bounds__(AQ) void aa_attn_fwd_kernel(const bf16* __restrict_
     for (int t = tid; t < TK * 5; t += AQ) {
       const int j = t / 5, c = t - j * 5;
       const int jj = min(j0 + j, HW - 1);
-      U64 v;
-      v.u = *reinterpret_cast<const uint2*>(base + (size_t)jj * g.ldq + kofs + c * 4);
+      const typename V4<T>::raw v = V4<T>::ld(base + (size_t)jj * g.ldq + kofs + c * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = bf2f(v.e[e]);
+      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = V4<T>::get(v, e);
     }
     for (int t = tid; t < TK * DVH; t += AQ) {
       const int j = t / DVH, d = t - j * DVH;
       const int jj = min(j0 + j, HW - 1);
-      Vt[t] = bf2f(base[(size_t)jj * g.ldq + vofs + d]);
+      Vt[t] = V4<T>::ld1(base + (size_t)jj * g.ldq + vofs + d);
     }
     __syncthreads();
     const int jn = min(TK, HW - j0);
@@ -141,7 +140,8 @@ __global__ __launch_bounds__(AQ) void aa_attn_fwd_kernel(const bf16* __restrict_
 // The reference keeps softmax(logits) of the last forward in AAConv2d.weights, (B, nh, HW, HW), for vis_attn
 // (chexpert.py:363-383).  The training path never materialises it; this kernel rebuilds it on request from the saved
 // log-sum-exp: one lane per query writes its row P[i][:] = exp(S[i][:] - lse[i]).  Visualisation only, not tuned.
-__global__ __launch_bounds__(AQ) void aa_attn_weights_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+template <typename T>
+__global__ __launch_bounds__(AQ) void aa_attn_weights_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                                             const float* __restrict__ rel_w, const float* __restrict__ lse,
                                                             float* __restrict__ wts, const AAGeo g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -158,19 +158,18 @@ __global__ __launch_bounds__(AQ) void aa_attn_weights_kernel(const bf16* __restr
   const bool qvalid = i < HW;
   const int ic = qvalid ? i : HW - 1;
   const int qy = ic / W, qx = ic - qy * W;
-  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  const T* base = qkv + (size_t)b * HW * g.ldq;
   for (int t = tid; t < DKH * LH; t += AQ) RH[t] = rel_h[t];
   for (int t = tid; t < DKH * LW; t += AQ) RW[t] = rel_w[t];
   float q[DKH];
   const float scale = rsqrtf((float)DKH);
   {
-    const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
+    const T* qp = base + (size_t)ic * g.ldq + n * DKH;
 #pragma unroll
     for (int d = 0; d < DKH; d += 4) {
-      U64 v;
-      v.u = *reinterpret_cast<const uint2*>(qp + d);
+      const typename V4<T>::raw v = V4<T>::ld(qp + d);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) q[d + e] = bf2f(v.e[e]) * scale;
+      for (int e = 0; e < 4; ++e) q[d + e] = V4<T>::get(v, e) * scale;
     }
   }
   __syncthreads();
@@ -194,10 +193,9 @@ __global__ __launch_bounds__(AQ) void aa_attn_weights_kernel(const bf16* __restr
     for (int t = tid; t < TK * 5; t += AQ) {
       const int j = t / 5, c = t - j * 5;
       const int jj = min(j0 + j, HW - 1);
-      U64 v;
-      v.u = *reinterpret_cast<const uint2*>(base + (size_t)jj * g.ldq + kofs + c * 4);
+      const typename V4<T>::raw v = V4<T>::ld(base + (size_t)jj * g.ldq + kofs + c * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = bf2f(v.e[e]);
+      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = V4<T>::get(v, e);
     }
     __syncthreads();
     const int jn = min(TK, HW - j0);
@@ -222,8 +220,8 @@ __global__ __launch_bounds__(AQ) void aa_attn_weights_kernel(const bf16* __restr
 //   dq_i = scale * sum_j dS_ij (k_j + RH[:, ky-qy+H-1] + RW[:, kx-qx+W-1])
 //   dRH / dRW : sum_{i,j} dS_ij q~_i at the relative offsets (reduced per workgroup in LDS, then atomics)
 // Pass K (one lane per key): dk_j = sum_i dS_ij q~_i, dv_j = sum_i P_ij dO_i.
-template <int DVH>
-__global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+template <typename T, int DVH>
+__global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                                           const float* __restrict__ rel_w, const float* __restrict__ o,
                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, float* __restrict__ d_rel_h,
@@ -246,20 +244,19 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restric
   const bool qvalid = i < HW;
   const int ic = qvalid ? i : HW - 1;
   const int qy = ic / W, qx = ic - qy * W;
-  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  const T* base = qkv + (size_t)b * HW * g.ldq;
 
   for (int t = tid; t < DKH * LH; t += AQ) { RH[t] = rel_h[t]; dRH[t] = 0.f; }
   for (int t = tid; t < DKH * LW; t += AQ) { RW[t] = rel_w[t]; dRW[t] = 0.f; }
   float q[DKH];
   const float scale = rsqrtf((float)DKH);
   {
-    const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
+    const T* qp = base + (size_t)ic * g.ldq + n * DKH;
 #pragma unroll
     for (int d = 0; d < DKH; d += 4) {
-      U64 v;
-      v.u = *reinterpret_cast<const uint2*>(qp + d);
+      const typename V4<T>::raw v = V4<T>::ld(qp + d);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) q[d + e] = bf2f(v.e[e]) * scale;
+      for (int e = 0; e < 4; ++e) q[d + e] = V4<T>::get(v, e) * scale;
     }
   }
   float dO[DVH], delta = 0.f;
@@ -301,15 +298,14 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restric
     for (int t = tid; t < TK * 5; t += AQ) {
       const int j = t / 5, c = t - j * 5;
       const int jj = min(j0 + j, HW - 1);
-      U64 v;
-      v.u = *reinterpret_cast<const uint2*>(base + (size_t)jj * g.ldq + kofs + c * 4);
+      const typename V4<T>::raw v = V4<T>::ld(base + (size_t)jj * g.ldq + kofs + c * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = bf2f(v.e[e]);
+      for (int e = 0; e < 4; ++e) Kt[j * DKH + c * 4 + e] = V4<T>::get(v, e);
     }
     for (int t = tid; t < TK * DVH; t += AQ) {
       const int j = t / DVH, d = t - j * DVH;
       const int jj = min(j0 + j, HW - 1);
-      Vt[t] = bf2f(base[(size_t)jj * g.ldq + vofs + d]);
+      Vt[t] = V4<T>::ld1(base + (size_t)jj * g.ldq + vofs + d);
     }
     __syncthreads();
     const int jn = min(TK, HW - j0);
@@ -401,8 +397,8 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_q_kernel(const bf16* __restric
   for (int t = tid; t < DKH * LW; t += AQ) { if (slab_w) slab_w[wg * (DKH * LW) + t] = dRW[t]; else atomicAdd(&d_rel_w[t], dRW[t]); }
 }
 
-template <int DVH>
-__global__ __launch_bounds__(AQ) void aa_attn_bwd_k_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+template <typename T, int DVH>
+__global__ __launch_bounds__(AQ) void aa_attn_bwd_k_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                                           const float* __restrict__ rel_w, const float* __restrict__ o,
                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, const AAGeo g) {
@@ -425,21 +421,20 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_k_kernel(const bf16* __restric
   const bool kvalid = j < HW;
   const int jc = kvalid ? j : HW - 1;
   const int ky = jc / W, kx = jc - ky * W;
-  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  const T* base = qkv + (size_t)b * HW * g.ldq;
   for (int t = tid; t < DKH * LH; t += AQ) RH[t] = rel_h[t];
   for (int t = tid; t < DKH * LW; t += AQ) RW[t] = rel_w[t];
   float k[DKH], v[DVH], dk[DKH], dv[DVH];
   {
-    const bf16* kp = base + (size_t)jc * g.ldq + g.dk + n * DKH;
+    const T* kp = base + (size_t)jc * g.ldq + g.dk + n * DKH;
 #pragma unroll
     for (int d = 0; d < DKH; d += 4) {
-      U64 u;
-      u.u = *reinterpret_cast<const uint2*>(kp + d);
+      const typename V4<T>::raw u = V4<T>::ld(kp + d);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) k[d + e] = bf2f(u.e[e]);
+      for (int e = 0; e < 4; ++e) k[d + e] = V4<T>::get(u, e);
     }
 #pragma unroll
-    for (int d = 0; d < DVH; ++d) v[d] = bf2f(base[(size_t)jc * g.ldq + 2 * g.dk + n * DVH + d]);
+    for (int d = 0; d < DVH; ++d) v[d] = V4<T>::ld1(base + (size_t)jc * g.ldq + 2 * g.dk + n * DVH + d);
   }
 #pragma unroll
   for (int d = 0; d < DKH; ++d) dk[d] = 0.f;
@@ -451,10 +446,9 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_k_kernel(const bf16* __restric
     for (int t = tid; t < TK * 5; t += AQ) {
       const int ii = t / 5, c = t - ii * 5;
       const int iq = min(i0 + ii, HW - 1);
-      U64 u;
-      u.u = *reinterpret_cast<const uint2*>(base + (size_t)iq * g.ldq + n * DKH + c * 4);
+      const typename V4<T>::raw u = V4<T>::ld(base + (size_t)iq * g.ldq + n * DKH + c * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Qt[ii * DKH + c * 4 + e] = bf2f(u.e[e]) * scale;
+      for (int e = 0; e < 4; ++e) Qt[ii * DKH + c * 4 + e] = V4<T>::get(u, e) * scale;
     }
     for (int t = tid; t < TK; t += AQ) {
       const int iq = min(i0 + t, HW - 1);
@@ -502,20 +496,22 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_k_kernel(const bf16* __restric
 
 // ---------------------------------------------------------------------------------------------- elementwise glue
 // per-(b,c) affine + ReLU (InstanceNorm2d + ReLU ahead of the AAConv2d, attn_aug_conv.py:438-439)
-__global__ void affine_relu_bc_kernel(const bf16* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
-                                      bf16* __restrict__ y, int HW, int C, int ldx, size_t total) {
+template <typename T>
+__global__ void affine_relu_bc_kernel(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                      T* __restrict__ y, int HW, int C, int ldx, size_t total) {
   const int CP = C / 8;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int cq = idx % CP;
     const size_t pix = idx / CP;
     const int b = pix / HW;
-    U128 v, o;
-    v.u = *reinterpret_cast<const uint4*>(x + pix * ldx + cq * 8);
+    typename V8<T>::raw v;
+    float o_f[8];
+    v = V8<T>::ld(x + pix * ldx + cq * 8);
     const float* s = sc + (size_t)b * C + cq * 8;
     const float* h = sh + (size_t)b * C + cq * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), s[j], h[j]), 0.f));
-    *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+    for (int j = 0; j < 8; ++j) o_f[j] = V8<T>::rnd(fmaxf(fmaf(V8<T>::get(v, j), s[j], h[j]), 0.f));
+    V8<T>::st(y + idx * 8, o_f);
   }
 }
 
@@ -540,32 +536,33 @@ __device__ __forceinline__ void bc_fold_store(float (*part)[8][17], const float 
   }
 }
 
-__global__ __launch_bounds__(256) void stats_bc_kernel(const bf16* __restrict__ x, float* __restrict__ sum, float* __restrict__ sq,
+template <typename T>
+__global__ __launch_bounds__(256) void stats_bc_kernel(const T* __restrict__ x, float* __restrict__ sum, float* __restrict__ sq,
                                                        int HW, int C, int ldx) {
   __shared__ float part[32][8][17];
   const int b = blockIdx.y, cbase = blockIdx.x * 64;
   const int cq = threadIdx.x & 7, rr = threadIdx.x >> 3;
   const int c0 = cbase + cq * 8;
   const bool cok = c0 < C;
-  const bf16* xp = x + (size_t)b * HW * ldx + (cok ? c0 : 0);
+  const T* xp = x + (size_t)b * HW * ldx + (cok ? c0 : 0);
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   int p = rr;
   for (; p + 96 < HW; p += 128) {
-    U128 v[4];
+    typename V8<T>::raw v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u].u = *reinterpret_cast<const uint4*>(xp + (size_t)(p + 32 * u) * ldx);
+    for (int u = 0; u < 4; ++u) v[u] = V8<T>::ld(xp + (size_t)(p + 32 * u) * ldx);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = bf2f(v[u].e[j]); s1[j] += f; s2[j] += f * f; }
+      for (int j = 0; j < 8; ++j) { const float f = V8<T>::get(v[u], j); s1[j] += f; s2[j] += f * f; }
   }
   for (; p < HW; p += 32) {
-    U128 v;
-    v.u = *reinterpret_cast<const uint4*>(xp + (size_t)p * ldx);
+    typename V8<T>::raw v;
+    v = V8<T>::ld(xp + (size_t)p * ldx);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float f = bf2f(v.e[j]); s1[j] += f; s2[j] += f * f; }
+    for (int j = 0; j < 8; ++j) { const float f = V8<T>::get(v, j); s1[j] += f; s2[j] += f * f; }
   }
   if (!cok) {
 #pragma unroll
@@ -575,28 +572,28 @@ __global__ __launch_bounds__(256) void stats_bc_kernel(const bf16* __restrict__ 
 }
 
 // out_proj (dv x dv 1x1 conv, :92) on the fp32 attention output, written as bf16 into the block-buffer slice
-// [+ per-channel statistics of the rounded output].  T = (256 / dv) * dv threads are active: a thread keeps ONE output channel
+// [+ per-channel statistics of the rounded output].  TA = (256 / dv) * dv threads are active: a thread keeps ONE output channel
 // (tid % dv) and walks pixels, so its two sums are registers; they meet in LDS and are added in pixel-lane order.  det: the
 // workgroup plain-stores its row (stat_sum[row * rstride + c], CxConv.stat_det convention), else one atomic per channel.
-__global__ __launch_bounds__(256) void aa_outproj_fwd_kernel(const float* __restrict__ o, const float* __restrict__ w, bf16* __restrict__ y,
-                                                             int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv, int T, int det,
+template <typename T>
+__global__ __launch_bounds__(256) void aa_outproj_fwd_kernel(const float* __restrict__ o, const float* __restrict__ w, T* __restrict__ y,
+                                                             int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv, int TA, int det,
                                                              int rstride) {
   __shared__ float ws[64 * 64];
   __shared__ float st[2][256];
   const int tid = threadIdx.x;
   for (int t = tid; t < dv * dv; t += blockDim.x) ws[t] = w[t];
   __syncthreads();
-  const bool active = tid < T;
-  const int c = tid % dv, pl = tid / dv, npl = T / dv;
+  const bool active = tid < TA;
+  const int c = tid % dv, pl = tid / dv, npl = TA / dv;
   float s1 = 0.f, s2 = 0.f;
   if (active) {
     for (size_t pix = (size_t)blockIdx.x * npl + pl; pix < npix; pix += (size_t)gridDim.x * npl) {
       const float* op = o + pix * dv;
       float a = 0.f;
       for (int d = 0; d < dv; ++d) a = fmaf(ws[c * dv + d], op[d], a);
-      const bf16 r = f2bf(a);
-      y[pix * ldy + c] = r;
-      const float rv = bf2f(r);
+      const float rv = V8<T>::rnd(a);
+      V4<T>::st1(y + pix * ldy + c, rv);
       s1 += rv;
       s2 += rv * rv;
     }
@@ -619,8 +616,8 @@ __global__ __launch_bounds__(256) void aa_outproj_fwd_kernel(const float* __rest
 
 // backward of out_proj: dO[pix][d] = sum_c dY[pix][c] * W[c][d];  dW[c][d] += sum_pix dY[pix][c] * O[pix][d]
 // dY = g*ga + gx*gb + gc (deferred BN correction of the gradient-buffer slice)
-template <int DM, int CH>
-__global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const bf16* __restrict__ g, int ldg, const bf16* __restrict__ gx, int ldgx,
+template <typename T, int DM, int CH>
+__global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ gx, int ldgx,
                                                              const float* __restrict__ ga, const float* __restrict__ gb,
                                                              const float* __restrict__ gc, const float* __restrict__ o,
                                                              const float* __restrict__ w, float* __restrict__ d_o,
@@ -641,7 +638,7 @@ __global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const bf16* __restr
       const int px = idx / dv, c = idx - px * dv;
       const size_t pix = p0 + px;
       const bool ok = pix < npix;
-      dyS[px * PT + c] = ok ? fmaf(bf2f(g[pix * ldg + c]), ga[c], fmaf(bf2f(gx[pix * ldgx + c]), gb[c], gc[c])) : 0.f;
+      dyS[px * PT + c] = ok ? fmaf(V4<T>::ld1(g + pix * ldg + c), ga[c], fmaf(V4<T>::ld1(gx + pix * ldgx + c), gb[c], gc[c])) : 0.f;
       oS[px * PT + c] = ok ? o[pix * dv + c] : 0.f;
     }
     __syncthreads();
@@ -670,7 +667,8 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16* __restrict
 
 // InstanceNorm + ReLU backward: dz = dA * [a > 0];  dx = r * (dz - mean_hw(dz) - xhat * mean_hw(dz * xhat)) per (b,c)
 // pass 1: S1[b][c] = sum dz, S2[b][c] = sum dz*xhat      pass 2: write dx
-__global__ __launch_bounds__(256) void in_relu_bwd_stats_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_bwd_stats_kernel(const T* __restrict__ da, const T* __restrict__ x,
                                                                 const float* __restrict__ sc, const float* __restrict__ sh,
                                                                 float* __restrict__ S1, float* __restrict__ S2, int HW, int C, int ldx) {
   // same ownership as stats_bc_kernel: (image, 64 channels) per workgroup, every pixel, ordered fold, plain stores
@@ -683,34 +681,34 @@ __global__ __launch_bounds__(256) void in_relu_bwd_stats_kernel(const bf16* __re
   float s1[8], s2[8], fs[8], fh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; fs[j] = sc[(size_t)b * C + cc + j]; fh[j] = sh[(size_t)b * C + cc + j]; }
-  const bf16* xp = x + (size_t)b * HW * ldx + cc;
-  const bf16* dp = da + (size_t)b * HW * C + cc;
+  const T* xp = x + (size_t)b * HW * ldx + cc;
+  const T* dp = da + (size_t)b * HW * C + cc;
   int p = rr;
   for (; p + 32 < HW; p += 64) {
-    U128 v[2], d[2];
+    typename V8<T>::raw v[2], d[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      v[u].u = *reinterpret_cast<const uint4*>(xp + (size_t)(p + 32 * u) * ldx);
-      d[u].u = *reinterpret_cast<const uint4*>(dp + (size_t)(p + 32 * u) * C);
+      v[u] = V8<T>::ld(xp + (size_t)(p + 32 * u) * ldx);
+      d[u] = V8<T>::ld(dp + (size_t)(p + 32 * u) * C);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float xh = fmaf(bf2f(v[u].e[j]), fs[j], fh[j]);          // xhat = (x-mean)*rstd
-        const float dz = xh > 0.f ? bf2f(d[u].e[j]) : 0.f;
+        const float xh = fmaf(V8<T>::get(v[u], j), fs[j], fh[j]);          // xhat = (x-mean)*rstd
+        const float dz = xh > 0.f ? V8<T>::get(d[u], j) : 0.f;
         s1[j] += dz;
         s2[j] += dz * xh;
       }
   }
   for (; p < HW; p += 32) {
-    U128 v, d;
-    v.u = *reinterpret_cast<const uint4*>(xp + (size_t)p * ldx);
-    d.u = *reinterpret_cast<const uint4*>(dp + (size_t)p * C);
+    typename V8<T>::raw v, d;
+    v = V8<T>::ld(xp + (size_t)p * ldx);
+    d = V8<T>::ld(dp + (size_t)p * C);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xh = fmaf(bf2f(v.e[j]), fs[j], fh[j]);
-      const float dz = xh > 0.f ? bf2f(d.e[j]) : 0.f;
+      const float xh = fmaf(V8<T>::get(v, j), fs[j], fh[j]);
+      const float dz = xh > 0.f ? V8<T>::get(d, j) : 0.f;
       s1[j] += dz;
       s2[j] += dz * xh;
     }
@@ -722,27 +720,29 @@ __global__ __launch_bounds__(256) void in_relu_bwd_stats_kernel(const bf16* __re
   bc_fold_store(part, s1, s2, S1, S2, b, C, cbase, 0);
 }
 
-__global__ void in_relu_bwd_apply_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x, const float* __restrict__ sc,
+template <typename T>
+__global__ void in_relu_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ x, const float* __restrict__ sc,
                                          const float* __restrict__ sh, const float* __restrict__ S1, const float* __restrict__ S2,
-                                         bf16* __restrict__ gout, int HW, int C, int ldx, int ldg, size_t total) {
+                                         T* __restrict__ gout, int HW, int C, int ldx, int ldg, size_t total) {
   const int CP = C / 8;
   const float inv = 1.f / HW;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int cq = idx % CP;
     const size_t pix = idx / CP;
     const int b = pix / HW;
-    U128 v, d, o;
-    v.u = *reinterpret_cast<const uint4*>(x + pix * ldx + cq * 8);
-    d.u = *reinterpret_cast<const uint4*>(da + pix * C + cq * 8);
+    typename V8<T>::raw v, d;
+    float o_f[8];
+    v = V8<T>::ld(x + pix * ldx + cq * 8);
+    d = V8<T>::ld(da + pix * C + cq * 8);
     const size_t bc = (size_t)b * C + cq * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float r = sc[bc + j];
-      const float xh = fmaf(bf2f(v.e[j]), r, sh[bc + j]);
-      const float dz = xh > 0.f ? bf2f(d.e[j]) : 0.f;
-      o.e[j] = f2bf(r * (dz - S1[bc + j] * inv - xh * S2[bc + j] * inv));
+      const float xh = fmaf(V8<T>::get(v, j), r, sh[bc + j]);
+      const float dz = xh > 0.f ? V8<T>::get(d, j) : 0.f;
+      o_f[j] = V8<T>::rnd(r * (dz - S1[bc + j] * inv - xh * S2[bc + j] * inv));
     }
-    *reinterpret_cast<uint4*>(gout + pix * ldg + cq * 8) = o.u;
+    V8<T>::st(gout + pix * ldg + cq * 8, o_f);
   }
 }
 
@@ -757,9 +757,12 @@ inline size_t attn_lds_floats(int H, int W, int dvh) { return (size_t)DKH * (2 *
 
 }  // namespace
 
-extern "C" {
+// ---- launchers, templated on the storage type (bf16 / the fp32 parity mode)
+template <typename T>
+static inline const void* as_qkv(const void* p) { return p; }
 
-int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w, float* o, float* lse, int B, int H, int W, int nh,
+template <typename T>
+int aa_attention_fwd_t(const void* qkv, const float* rel_h, const float* rel_w, float* o, float* lse, int B, int H, int W, int nh,
                         int dk, int dv, int ldq, void* stream) {
   if (!qkv || !rel_h || !rel_w || !o || !lse) return CX_EINVAL;
   if (nh <= 0 || dk != nh * DKH || dv % nh || dv / nh > MAXDV || (ldq % 4)) return CX_ESHAPE;
@@ -768,14 +771,14 @@ int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w,
   hipStream_t st = as_stream(stream);
   {
     bool handled = false;
-    const int rc = cx_try_aa_row(0, qkv, rel_h, rel_w, o, nullptr, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, nh, dk, dv,
+    const int rc = !std::is_same<T, bf16>::value ? 0 : cx_try_aa_row(0, qkv, rel_h, rel_w, o, nullptr, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, nh, dk, dv,
                                  ldq, st, &handled);
     if (handled) return rc;
   }
   const size_t smem = attn_lds_floats(H, W, dvh) * 4;
   if (smem > 64 * 1024) return CX_ESHAPE;
   dim3 grid((H * W + AQ - 1) / AQ, B * nh);
-#define LAUNCH(D) hipLaunchKernelGGL(aa_attn_fwd_kernel<D>, grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, lse, g)
+#define LAUNCH(D) hipLaunchKernelGGL((aa_attn_fwd_kernel<T, D>), grid, dim3(AQ), smem, st, (const T*)qkv, rel_h, rel_w, o, lse, g)
   switch (dvh) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -789,19 +792,21 @@ int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w,
   return launch_status();
 }
 
-int cx_aa_attention_weights(const void* qkv, const float* rel_h, const float* rel_w, const float* lse, float* weights, int B, int H,
+template <typename T>
+int aa_attention_weights_t(const void* qkv, const float* rel_h, const float* rel_w, const float* lse, float* weights, int B, int H,
                             int W, int nh, int dk, int dv, int ldq, void* stream) {
   if (!qkv || !rel_h || !rel_w || !lse || !weights) return CX_EINVAL;
   if (nh <= 0 || dk != nh * DKH || dv % nh || (ldq % 4)) return CX_ESHAPE;
   AAGeo g{B, H, W, nh, dk, dv, ldq};
   const size_t smem = attn_lds_floats(H, W, 0) * 4;
   if (smem > 64 * 1024) return CX_ESHAPE;
-  hipLaunchKernelGGL(aa_attn_weights_kernel, dim3((H * W + AQ - 1) / AQ, B * nh), dim3(AQ), smem, as_stream(stream),
-                     (const bf16*)qkv, rel_h, rel_w, lse, weights, g);
+  hipLaunchKernelGGL(aa_attn_weights_kernel<T>, dim3((H * W + AQ - 1) / AQ, B * nh), dim3(AQ), smem, as_stream(stream),
+                     (const T*)qkv, rel_h, rel_w, lse, weights, g);
   return launch_status();
 }
 
-int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w, const float* o, const float* d_o, const float* lse,
+template <typename T>
+int aa_attention_bwd_t(const void* qkv, const float* rel_h, const float* rel_w, const float* o, const float* d_o, const float* lse,
                         float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq,
                         float* scratch, int64_t scratch_floats, void* stream) {
   if (!qkv || !rel_h || !rel_w || !o || !d_o || !lse || !dqkv || !d_rel_h || !d_rel_w) return CX_EINVAL;
@@ -816,12 +821,12 @@ int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w,
   hipStream_t st = as_stream(stream);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   // Reproducible relative-table gradients: every query-side workgroup plain-stores its two partial tables into the caller's
@@ -836,15 +841,15 @@ int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w,
   }
   bool row_q = false;
   {
-    const int rc = cx_try_aa_row(1, qkv, rel_h, rel_w, const_cast<float*>(o), d_o, const_cast<float*>(lse), dqkv, d_rel_h, d_rel_w, slab_h,
+    const int rc = !std::is_same<T, bf16>::value ? 0 : cx_try_aa_row(1, qkv, rel_h, rel_w, const_cast<float*>(o), d_o, const_cast<float*>(lse), dqkv, d_rel_h, d_rel_w, slab_h,
                                  slab_w, B, H, W, nh, dk, dv, ldq, st, &row_q);
     if (row_q && rc) return rc;          // dq, dk, dv and the table partials all done there
   }
   if (!row_q) {
 #define LAUNCH(D)                                                                                                              \
-    hipLaunchKernelGGL(aa_attn_bwd_q_kernel<D>, grid, dim3(AQ), smem_q, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, \
+    hipLaunchKernelGGL((aa_attn_bwd_q_kernel<T, D>), grid, dim3(AQ), smem_q, st, (const T*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, \
                        d_rel_h, d_rel_w, slab_h, slab_w, g);                                                                  \
-    hipLaunchKernelGGL(aa_attn_bwd_k_kernel<D>, grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g)
+    hipLaunchKernelGGL((aa_attn_bwd_k_kernel<T, D>), grid, dim3(AQ), smem_k, st, (const T*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g)
     switch (dvh) {
       case 1: LAUNCH(1); break;
       case 2: LAUNCH(2); break;
@@ -864,47 +869,130 @@ int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w,
   return 0;
 }
 
-int cx_stats_bc(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream) {
+template <typename T>
+int stats_bc_t(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream) {
   if (!x || !sum || !sq || C % 8 || C > 2048 || ldx % 8) return CX_EINVAL;
-  hipLaunchKernelGGL(stats_bc_kernel, dim3((C + 63) / 64, B), dim3(256), 0, as_stream(stream), (const bf16*)x, sum, sq, HW, C, ldx);
+  hipLaunchKernelGGL(stats_bc_kernel<T>, dim3((C + 63) / 64, B), dim3(256), 0, as_stream(stream), (const T*)x, sum, sq, HW, C, ldx);
   return launch_status();
 }
 
-int cx_affine_relu_bc(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream) {
+template <typename T>
+int affine_relu_bc_t(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream) {
   if (!x || !sc || !sh || !y || C % 8 || ldx % 8) return CX_EINVAL;
   const size_t total = (size_t)B * HW * (C / 8);
-  hipLaunchKernelGGL(affine_relu_bc_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(stream), (const bf16*)x, sc, sh,
-                     (bf16*)y, HW, C, ldx, total);
+  hipLaunchKernelGGL(affine_relu_bc_kernel<T>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(stream), (const T*)x, sc, sh,
+                     (T*)y, HW, C, ldx, total);
   return launch_status();
 }
 
-int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
+template <typename T>
+int aa_outproj_fwd_t(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
                       int stat_rows, int stat_rstride, void* stream) {
   if (!o || !w || !y || dv <= 0 || dv > 64) return CX_EINVAL;
   if ((stat_sum == nullptr) != (stat_sq == nullptr)) return CX_EINVAL;
   if (stat_rows > 0 && (!stat_sum || stat_rstride < dv)) return CX_EINVAL;
-  const int T = 256 / dv * dv;
+  const int TA = 256 / dv * dv;
   int grid = grid_for(npix * dv, 256, 2048);
   if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
-  hipLaunchKernelGGL(aa_outproj_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), o, w, (bf16*)y, ldy, stat_sum, stat_sq, npix, dv,
-                     T, stat_rows > 0 ? 1 : 0, stat_rstride);
+  hipLaunchKernelGGL(aa_outproj_fwd_kernel<T>, dim3(grid), dim3(256), 0, as_stream(stream), o, w, (T*)y, ldy, stat_sum, stat_sq, npix, dv,
+                     TA, stat_rows > 0 ? 1 : 0, stat_rstride);
   return launch_status();
 }
 
-int cx_aa_outproj_bwd(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
+template <typename T>
+int aa_outproj_bwd_t(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
                       const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, float* scratch, int64_t scratch_floats,
                       void* stream) {
   if (!g || !gx || !ga || !gb || !gc || !o || !w || !d_o || !dw || dv <= 0 || dv > 64) return CX_EINVAL;
   const int grid = grid_for(npix, 64, 1024);
   float* slab = dw_slab(scratch, scratch_floats, grid, (long long)dv * dv);
   if (dv <= 48)
-    hipLaunchKernelGGL((aa_outproj_bwd_kernel<48, 64>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)g, ldg,
-                       (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
+    hipLaunchKernelGGL((aa_outproj_bwd_kernel<T, 48, 64>), dim3(grid), dim3(256), 0, as_stream(stream), (const T*)g, ldg,
+                       (const T*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
   else
-    hipLaunchKernelGGL((aa_outproj_bwd_kernel<64, 32>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)g, ldg,
-                       (const bf16*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
+    hipLaunchKernelGGL((aa_outproj_bwd_kernel<T, 64, 32>), dim3(grid), dim3(256), 0, as_stream(stream), (const T*)g, ldg,
+                       (const T*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
   if (const int e = launch_status()) return e;
   return slab ? cx_dw_reduce(dw, slab, (size_t)dv * dv, grid, as_stream(stream)) : 0;
+}
+
+template <typename T>
+int in_relu_bwd_t(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,
+                   int C, int ldx, int ldg, void* stream) {
+  if (!da || !x || !sc || !sh || !S1 || !S2 || !gout) return CX_EINVAL;
+  if (C % 8 || C > 2048 || ldx % 8 || ldg % 8) return CX_ESHAPE;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(in_relu_bwd_stats_kernel<T>, dim3((C + 63) / 64, B), dim3(256), 0, st, (const T*)da, (const T*)x, sc, sh, S1, S2,
+                     HW, C, ldx);
+  const size_t total = (size_t)B * HW * (C / 8);
+  hipLaunchKernelGGL(in_relu_bwd_apply_kernel<T>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, (const T*)da, (const T*)x, sc,
+                     sh, S1, S2, (T*)gout, HW, C, ldx, ldg, total);
+  return launch_status();
+}
+
+extern "C" {
+
+int cx_aa_attention_fwd(const void* qkv, const float* rel_h, const float* rel_w, float* o, float* lse, int B, int H, int W, int nh,
+                        int dk, int dv, int ldq, void* stream) {
+  return aa_attention_fwd_t<bf16>(qkv, rel_h, rel_w, o, lse, B, H, W, nh, dk, dv, ldq, stream);
+}
+int cx_aa_attention_fwd_f32(const void* qkv, const float* rel_h, const float* rel_w, float* o, float* lse, int B, int H, int W, int nh,
+                        int dk, int dv, int ldq, void* stream) {
+  return aa_attention_fwd_t<float>(qkv, rel_h, rel_w, o, lse, B, H, W, nh, dk, dv, ldq, stream);
+}
+
+int cx_aa_attention_weights(const void* qkv, const float* rel_h, const float* rel_w, const float* lse, float* weights, int B, int H,
+                            int W, int nh, int dk, int dv, int ldq, void* stream) {
+  return aa_attention_weights_t<bf16>(qkv, rel_h, rel_w, lse, weights, B, H, W, nh, dk, dv, ldq, stream);
+}
+int cx_aa_attention_weights_f32(const void* qkv, const float* rel_h, const float* rel_w, const float* lse, float* weights, int B, int H,
+                            int W, int nh, int dk, int dv, int ldq, void* stream) {
+  return aa_attention_weights_t<float>(qkv, rel_h, rel_w, lse, weights, B, H, W, nh, dk, dv, ldq, stream);
+}
+
+int cx_aa_attention_bwd(const void* qkv, const float* rel_h, const float* rel_w, const float* o, const float* d_o, const float* lse,
+                        float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq,
+                        float* scratch, int64_t scratch_floats, void* stream) {
+  return aa_attention_bwd_t<bf16>(qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, B, H, W, nh, dk, dv, ldq, scratch, scratch_floats, stream);
+}
+int cx_aa_attention_bwd_f32(const void* qkv, const float* rel_h, const float* rel_w, const float* o, const float* d_o, const float* lse,
+                        float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq,
+                        float* scratch, int64_t scratch_floats, void* stream) {
+  return aa_attention_bwd_t<float>(qkv, rel_h, rel_w, o, d_o, lse, dqkv, d_rel_h, d_rel_w, B, H, W, nh, dk, dv, ldq, scratch, scratch_floats, stream);
+}
+
+int cx_stats_bc(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream) {
+  return stats_bc_t<bf16>(x, sum, sq, B, HW, C, ldx, stream);
+}
+int cx_stats_bc_f32(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream) {
+  return stats_bc_t<float>(x, sum, sq, B, HW, C, ldx, stream);
+}
+
+int cx_affine_relu_bc(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream) {
+  return affine_relu_bc_t<bf16>(x, sc, sh, y, B, HW, C, ldx, stream);
+}
+int cx_affine_relu_bc_f32(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream) {
+  return affine_relu_bc_t<float>(x, sc, sh, y, B, HW, C, ldx, stream);
+}
+
+int cx_aa_outproj_fwd(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
+                      int stat_rows, int stat_rstride, void* stream) {
+  return aa_outproj_fwd_t<bf16>(o, w, y, ldy, stat_sum, stat_sq, npix, dv, stat_rows, stat_rstride, stream);
+}
+int cx_aa_outproj_fwd_f32(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
+                      int stat_rows, int stat_rstride, void* stream) {
+  return aa_outproj_fwd_t<float>(o, w, y, ldy, stat_sum, stat_sq, npix, dv, stat_rows, stat_rstride, stream);
+}
+
+int cx_aa_outproj_bwd(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
+                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, float* scratch, int64_t scratch_floats,
+                      void* stream) {
+  return aa_outproj_bwd_t<bf16>(g, ldg, gx, ldgx, ga, gb, gc, o, w, d_o, dw, npix, dv, scratch, scratch_floats, stream);
+}
+int cx_aa_outproj_bwd_f32(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
+                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, float* scratch, int64_t scratch_floats,
+                      void* stream) {
+  return aa_outproj_bwd_t<float>(g, ldg, gx, ldgx, ga, gb, gc, o, w, d_o, dw, npix, dv, scratch, scratch_floats, stream);
 }
 
 int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {
@@ -915,15 +1003,11 @@ int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {
 
 int cx_in_relu_bwd(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,
                    int C, int ldx, int ldg, void* stream) {
-  if (!da || !x || !sc || !sh || !S1 || !S2 || !gout) return CX_EINVAL;
-  if (C % 8 || C > 2048 || ldx % 8 || ldg % 8) return CX_ESHAPE;
-  hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(in_relu_bwd_stats_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, (const bf16*)da, (const bf16*)x, sc, sh, S1, S2,
-                     HW, C, ldx);
-  const size_t total = (size_t)B * HW * (C / 8);
-  hipLaunchKernelGGL(in_relu_bwd_apply_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, (const bf16*)da, (const bf16*)x, sc,
-                     sh, S1, S2, (bf16*)gout, HW, C, ldx, ldg, total);
-  return launch_status();
+  return in_relu_bwd_t<bf16>(da, x, sc, sh, S1, S2, gout, B, HW, C, ldx, ldg, stream);
+}
+int cx_in_relu_bwd_f32(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,
+                   int C, int ldx, int ldg, void* stream) {
+  return in_relu_bwd_t<float>(da, x, sc, sh, S1, S2, gout, B, HW, C, ldx, ldg, stream);
 }
 
 }  // extern "C"

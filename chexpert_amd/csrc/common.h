@@ -60,6 +60,23 @@ template <> struct V8<float> {
   static __device__ __forceinline__ float rnd(float v) { return v; }
 };
 
+// four consecutive channels (attention heads: dkh = 20 = 5 x 4) and one scalar, in the storage type T
+template <typename T> struct V4;
+template <> struct V4<bf16> {
+  typedef uint2 raw;
+  static __device__ __forceinline__ raw ld(const bf16* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ float get(const raw& r, int j) { U64 u; u.u = r; return bf2f(u.e[j]); }
+  static __device__ __forceinline__ float ld1(const bf16* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st1(bf16* p, float v) { *p = f2bf(v); }
+};
+template <> struct V4<float> {
+  typedef float4 raw;
+  static __device__ __forceinline__ raw ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ float get(const raw& r, int j) { const float v[4] = {r.x, r.y, r.z, r.w}; return v[j]; }
+  static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+  static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+};
+
 // XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
 // contiguous range of tile ids so neighbouring tiles (same A rows / same weights) hit one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -277,8 +277,6 @@ class _Engine:
         # (the AA transitions feed a block's first channels from two kernels -- conv branch and attention out-projection: their
         # statistic rows are reduced one after the other, see _aa_forward)
         self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
-        if has_aa and self.dtype != torch.bfloat16:
-            raise NotImplementedError("the fp32 storage mode covers the plain DenseNet path (the attention kernels are bf16)")
         self._plan_vectors()
 
     # ---- coefficient-vector layout
@@ -565,7 +563,10 @@ class _Engine:
         ops.aa_outproj_bwd(gs_a, xs_a, qa[cc:], qb[cc:], qc[cc:], T.O, aa.out_proj.weight, T.dO, G(aa.out_proj.weight))
         ops.aa_attention_bwd(T.QKV, aa.key_rel_h, aa.key_rel_w, T.O, T.dO, T.LSE, T.dQKV32, G(aa.key_rel_h), G(aa.key_rel_w), aa.nh,
                              aa.dk, aa.dv)
-        ops.f32_to_bf16(T.dQKV32, T.dQKV)
+        if self.dtype == torch.float32:         # fp32 storage mode: the fp32 gradient is the convolution operand as it is
+            T.dQKV = T.dQKV32
+        else:
+            ops.f32_to_bf16(T.dQKV32, T.dQKV)
         # (the 3x3 branch reaches every pixel and stores; the 1x1 branch only reaches the even-even ones: accumulating, its
         # other parity classes are nothing to do)
         ops.conv_gemm(gs_c, self.w_bwd(aa.conv), T.dA, N=Cp, kh=3, kw=3, pad=1, tstride=2, prologue=ops.PRO_AFFINE2, x2=xs_c,

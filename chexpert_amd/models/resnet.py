@@ -117,9 +117,9 @@ class _Engine:
         # activation storage type: bf16, or fp32 = the parity mode of north_star ("1e-3 fp32"): the same schedule on fp32 tensors
         # through the generic f32-MFMA convolutions (csrc/conv_f32.hip) and the templated element-wise kernels
         self.dtype = getattr(model, "_storage_dtype", torch.bfloat16)
-        if self.dtype != torch.bfloat16 and (isinstance(model, WideResNet) or any(isinstance(m_, AAConv2d) for m_ in model.modules())):
-            raise NotImplementedError("the fp32 storage mode covers the ImageNet-stem ResNets without attention (resnet152 of "
-                                      "chexpert.py:482); the attention kernels and the 3-channel CIFAR stem are bf16")
+        if self.dtype != torch.bfloat16 and isinstance(model, WideResNet):
+            raise NotImplementedError("the fp32 storage mode covers the ImageNet-stem ResNets (resnet152 / aaresnet152 of "
+                                      "chexpert.py:482-494); the 3-channel CIFAR stem is packed for bf16")
         self.flat = None
         self.device = None
         self.pool = {}
@@ -601,7 +601,10 @@ class _Engine:
                 ops.aa_outproj_bwd(gs_a, ys_a, qa[cc:], qb[cc:], qc[cc:], t["O"], aa.out_proj.weight, dO, G(aa.out_proj.weight))
                 ops.aa_attention_bwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], dO, t["LSE"], dQ32, G(aa.key_rel_h),
                                      G(aa.key_rel_w), aa.nh, aa.dk, aa.dv)
-                ops.f32_to_bf16(dQ32, dQ)
+                if self.dtype == torch.float32:
+                    dQ = dQ32
+                else:
+                    ops.f32_to_bf16(dQ32, dQ)
                 # both branches end in the same bn1 + ReLU mask: the conv branch writes dz1, the attention branch adds to it
                 rows = ops.conv_gemm(gs_c, self.w_bwd(aa.conv), dz1, N=p_, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=ys_c,
                                      pa=qa[:cc], pb=qb[:cc], pc=qc[:cc], **mask1)
@@ -730,7 +733,10 @@ class _Engine:
             ops.aa_outproj_bwd(gs_a, ys_a, qa[cc:], qb[cc:], qc[cc:], t["O"], aa.out_proj.weight, dO, G(aa.out_proj.weight))
             ops.aa_attention_bwd(t["QKV"], aa.key_rel_h, aa.key_rel_w, t["O"], dO, t["LSE"], dQ32, G(aa.key_rel_h), G(aa.key_rel_w),
                                  aa.nh, aa.dk, aa.dv)
-            ops.f32_to_bf16(dQ32, dQ)
+            if self.dtype == torch.float32:
+                dQ = dQ32
+            else:
+                ops.f32_to_bf16(dQ32, dQ)
             ops.conv_gemm(gs_c, self.w_bwd(aa.conv), gx, N=cin, kh=3, kw=3, pad=1, tstride=s_, prologue=ops.PRO_AFFINE2, x2=ys_c,
                           pa=qa[:cc], pb=qb[:cc], pc=qc[:cc], accumulate=identity)
             ops.conv_gemm(dQ, self.w_bwd(aa.in_proj_qkv), gx, N=cin, tstride=s_, accumulate=True)

@@ -445,7 +445,7 @@ def bf16_to_f32_nchw(x, out=None):
 # ---- attention-augmented convolution pieces (csrc/aaconv.hip)
 def aa_attention_fwd(qkv, key_rel_h, key_rel_w, o, lse, nh, dk, dv):
     B, H, W, Cq, ldq = _nhwc(qkv)
-    check(lib().cx_aa_attention_fwd(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(o), ptr(lse), B, H, W, nh, dk, dv, ldq, stream_ptr()),
+    check(_fn("cx_aa_attention_fwd", qkv)(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(o), ptr(lse), B, H, W, nh, dk, dv, ldq, stream_ptr()),
           "cx_aa_attention_fwd")
 
 
@@ -453,7 +453,7 @@ def aa_attention_weights(qkv, key_rel_h, key_rel_w, lse, nh, dk, dv):
     """softmax(logits) (B, nh, HW, HW) fp32 of the forward that produced `qkv` / `lse` (AAConv2d.weights, attn_aug_conv.py:87)."""
     B, H, W, Cq, ldq = _nhwc(qkv)
     out = torch.empty(B, nh, H * W, H * W, dtype=torch.float32, device=qkv.device)
-    check(lib().cx_aa_attention_weights(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(lse), ptr(out), B, H, W, nh, dk, dv, ldq,
+    check(_fn("cx_aa_attention_weights", qkv)(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(lse), ptr(out), B, H, W, nh, dk, dv, ldq,
                                         stream_ptr()), "cx_aa_attention_weights")
     return out
 
@@ -465,7 +465,7 @@ def aa_attention_bwd(qkv, key_rel_h, key_rel_w, o, d_o, lse, dqkv, d_rel_h, d_re
     need = ((H * W + 127) // 128) * B * nh * (dk // nh) * (2 * H - 1 + 2 * W - 1)
     if ws is not None and ws.numel() < need:
         ws = _big_scratch(qkv.device, need)
-    check(lib().cx_aa_attention_bwd(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(o), ptr(d_o), ptr(lse), ptr(dqkv), ptr(d_rel_h),
+    check(_fn("cx_aa_attention_bwd", qkv)(ptr(qkv), ptr(key_rel_h), ptr(key_rel_w), ptr(o), ptr(d_o), ptr(lse), ptr(dqkv), ptr(d_rel_h),
                                     ptr(d_rel_w), B, H, W, nh, dk, dv, ldq, ptr(ws), 0 if ws is None else ws.numel(), stream_ptr()),
           "cx_aa_attention_bwd")
 
@@ -485,7 +485,7 @@ def _big_scratch(device, floats):
 def aa_outproj_fwd(o, w, y, stat_sum, stat_sq, stat_rows=0, stat_rstride=0):
     """stat_rows > 0: deterministic statistic rows (returns the number written), else atomics into stat_sum / stat_sq."""
     B, H, W, dv, ldy = _nhwc(y)
-    check(lib().cx_aa_outproj_fwd(ptr(o), ptr(w), ptr(y), ldy, ptr(stat_sum), ptr(stat_sq), B * H * W, dv, stat_rows, stat_rstride,
+    check(_fn("cx_aa_outproj_fwd", y)(ptr(o), ptr(w), ptr(y), ldy, ptr(stat_sum), ptr(stat_sq), B * H * W, dv, stat_rows, stat_rstride,
                                   stream_ptr()), "cx_aa_outproj_fwd")
     return lib().cx_last_stat_rows() if stat_rows > 0 else None
 
@@ -493,7 +493,7 @@ def aa_outproj_fwd(o, w, y, stat_sum, stat_sq, stat_rows=0, stat_rstride=0):
 def aa_outproj_bwd(g, gx, ga, gb, gc, o, w, d_o, dw):
     B, H, W, dv, ldg = _nhwc(g)
     ws, arena, dfr = _wgrad_ws(dw.device)
-    check(lib().cx_aa_outproj_bwd(ptr(g), ldg, ptr(gx), _nhwc(gx)[4], ptr(ga), ptr(gb), ptr(gc), ptr(o), ptr(w), ptr(d_o), ptr(dw),
+    check(_fn("cx_aa_outproj_bwd", g)(ptr(g), ldg, ptr(gx), _nhwc(gx)[4], ptr(ga), ptr(gb), ptr(gc), ptr(o), ptr(w), ptr(d_o), ptr(dw),
                                   B * H * W, dv, ptr(ws), 0 if ws is None else ws.numel(), stream_ptr()), "cx_aa_outproj_bwd")
     _wgrad_used(arena, dfr)
 
@@ -504,19 +504,19 @@ def rows_reduce(dst, rows, n_rows, C, rstride, accumulate=True):
 
 def stats_bc(x, s, q):
     B, H, W, Cc, ldx = _nhwc(x)
-    check(lib().cx_stats_bc(ptr(x), ptr(s), ptr(q), B, H * W, Cc, ldx, stream_ptr()), "cx_stats_bc")
+    check(_fn("cx_stats_bc", x)(ptr(x), ptr(s), ptr(q), B, H * W, Cc, ldx, stream_ptr()), "cx_stats_bc")
 
 
 def affine_relu_bc(x, sc, sh, y):
     B, H, W, Cc, ldx = _nhwc(x)
     assert _nhwc(y)[4] == Cc
-    check(lib().cx_affine_relu_bc(ptr(x), ptr(sc), ptr(sh), ptr(y), B, H * W, Cc, ldx, stream_ptr()), "cx_affine_relu_bc")
+    check(_fn("cx_affine_relu_bc", x)(ptr(x), ptr(sc), ptr(sh), ptr(y), B, H * W, Cc, ldx, stream_ptr()), "cx_affine_relu_bc")
 
 
 def in_relu_bwd(da, x, sc, sh, S1, S2, gout):
     B, H, W, Cc, ldx = _nhwc(x)
     assert _nhwc(da)[4] == Cc
-    check(lib().cx_in_relu_bwd(ptr(da), ptr(x), ptr(sc), ptr(sh), ptr(S1), ptr(S2), ptr(gout), B, H * W, Cc, ldx, _nhwc(gout)[4],
+    check(_fn("cx_in_relu_bwd", da)(ptr(da), ptr(x), ptr(sc), ptr(sh), ptr(S1), ptr(S2), ptr(gout), B, H * W, Cc, ldx, _nhwc(gout)[4],
                                stream_ptr()), "cx_in_relu_bwd")
 
 

@@ -324,6 +324,23 @@ int cx_stats_bc(const void* x, float* sum, float* sq, int B, int HW, int C, int 
 int cx_affine_relu_bc(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream);
 int cx_in_relu_bwd(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,
                    int C, int ldx, int ldg, void* stream);
+/* fp32 storage-mode twins of the AAConv2d entry points (qkv / activations fp32; the per-query VALU kernels, no MFMA row kernels) */
+int cx_aa_attention_fwd_f32(const void* qkv, const float* rel_h, const float* rel_w, float* o, float* lse, int B, int H, int W, int nh,
+                        int dk, int dv, int ldq, void* stream);
+int cx_aa_attention_weights_f32(const void* qkv, const float* rel_h, const float* rel_w, const float* lse, float* weights, int B, int H,
+                            int W, int nh, int dk, int dv, int ldq, void* stream);
+int cx_aa_attention_bwd_f32(const void* qkv, const float* rel_h, const float* rel_w, const float* o, const float* d_o, const float* lse,
+                        float* dqkv, float* d_rel_h, float* d_rel_w, int B, int H, int W, int nh, int dk, int dv, int ldq,
+                        float* scratch, int64_t scratch_floats, void* stream);
+int cx_stats_bc_f32(const void* x, float* sum, float* sq, int B, int HW, int C, int ldx, void* stream);
+int cx_affine_relu_bc_f32(const void* x, const float* sc, const float* sh, void* y, int B, int HW, int C, int ldx, void* stream);
+int cx_aa_outproj_fwd_f32(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
+                      int stat_rows, int stat_rstride, void* stream);
+int cx_aa_outproj_bwd_f32(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
+                      const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, float* scratch, int64_t scratch_floats,
+                      void* stream);
+int cx_in_relu_bwd_f32(const void* da, const void* x, const float* sc, const float* sh, float* S1, float* S2, void* gout, int B, int HW,
+                   int C, int ldx, int ldg, void* stream);
 int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream);
 
 /* ---- EfficientNet blocks (models/efficientnet.py:27-131): depthwise conv, squeeze-excitation, Swish glue ----------

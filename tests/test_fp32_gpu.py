@@ -377,3 +377,53 @@ def test_fp32_efficientnet_matches_reference_golden_fixture(dev, tag, smooth):
     assert e_train < 1e-3
     assert abs(loss.item() - rec["loss"]) < 1e-4 * rec["loss"]
     assert worst[0] < 1e-2
+
+
+ATTN = {"k": 0.2, "v": 0.1, "nh": 8, "relative": True}
+
+
+@pytest.mark.parametrize("tag,smooth", [("aadensenet_tiny_64_b2", False), ("aadensenet121_320_b1", False), ("aadensenet121_320_b8", True),
+                                        ("aaresnet152_320_b8", True)])
+def test_fp32_attention_augmented_nets_match_reference_golden_fixture(dev, tag, smooth):
+    """The attention-augmented networks (AAConv2d, attn_aug_conv.py:19-100; chexpert.py:475-494) in the fp32 storage mode against
+    the REAL reference: q / k / v, the InstanceNorm tensors and the out-projection on fp32 tensors (the per-query attention kernels
+    templated on the storage type), north_star's 1e-3 on the train logits, loss to 1e-4, gradient norms to 1e-2."""
+    from chexpert_amd.models import Bottleneck, DenseNet, ResNet
+    from oracle import nets
+    rec = json.load(open(os.path.join(G, "nets_smooth.json" if smooth else "nets.json")))[tag]
+    n_cls, S = rec["n_classes"], rec["S"]
+    attn = dict(k=.2, v=.1, nh=8)
+    ap = dict(ATTN, input_dims=(S, S))
+    if tag.startswith("aadensenet"):
+        cfg = (6, 4, 2, 2) if "tiny" in tag else (6, 12, 24, 16)
+        spec, model, bias = nets.densenet_spec(n_cls, block_config=cfg, attn=attn, input_hw=(S, S)), DenseNet(32, cfg, 64, num_classes=n_cls, attn_params=ap), 2.5
+    else:
+        spec, model, bias = nets.resnet_spec(n_cls, attn=attn), ResNet(Bottleneck, [3, 8, 36, 3], num_classes=n_cls, attn_params=ap), 1.0
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(spec), rec["sd_seed"])
+    if smooth:
+        synth.smooth_state_dict_(sd, bias)
+    model.storage_dtype("fp32").load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = synth.xray_batch(rec["x_seed"], rec["B"], S).to(dev)
+    t = synth.targets(rec["t_seed"], rec["B"], n_cls).to(dev)
+    if not smooth and "tiny" in tag:                 # eval logits (before the step moves the running statistics) where the hash
+        model.eval()                                 # running statistics leave them O(1..100)
+        with torch.no_grad():
+            e_eval = _rel(model(x).cpu(), torch.tensor(rec["logits_eval"]))
+        print("fp32 %s: eval logits rel %.3e" % (tag, e_eval))
+        assert e_eval < 1e-3
+    model.train()
+    loss, logits = model.forward_backward(x, t)
+    assert model._eng().dtype == torch.float32
+    e_train = _rel(logits.cpu(), torch.tensor(rec["logits_train"]))
+    worst = (0.0, "")
+    gmax = max(r["l2"] for r in rec["grads"].values())
+    for k, p in model.named_parameters():
+        ref = rec["grads"][k]
+        if ref["l2"] > 1e-4 * gmax:
+            worst = max(worst, (abs(p.grad.double().norm().item() / ref["l2"] - 1), k))
+    print("fp32 %s: train logits rel %.3e, loss %.6f (ref %.6f), worst gradient l2 deviation %.3e (%s)" % (tag, e_train, loss.item(), rec["loss"],
+                                                                                                    worst[0], worst[1]))
+    assert e_train < 1e-3
+    assert abs(loss.item() - rec["loss"]) < 1e-4 * rec["loss"]
+    assert worst[0] < 1e-2
