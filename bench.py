@@ -41,69 +41,8 @@ class KernelTimer:
         self.only = None
         self.enabled = False
 
-    # Tags are the names of the kernel instantiations cx_conv_gemm / cx_conv_wgrad dispatch to (conv_gemm.hip launch_bn,
-    # conv_wgrad.hip launch_tile, conv3x3_strip.hip cx_try_strip_*), i.e. what rocprofv3 --kernel-trace lists.
-    @staticmethod
-    def gemm_kernel_name(x, kw):
-        mode, kh, pro, epi, N = kw.get("mode", 0), kw.get("kh", 1), kw.get("prologue", 0), kw.get("epilogue", 0), kw["N"]
-        K = kw.get("K") or x.shape[3]
-        if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and kw.get("tstride", 1) == 1:
-            if (pro, epi, K, N) == (1, 0, 128, 32):
-                return "conv3x3_ring_fwd_kernel"
-            if (pro, epi, K, N) == (2, 1, 32, 128):
-                return "conv3x3_ring_dgrad_kernel"
-        if mode == 0 and kh == 1 and epi == 1 and K == 128 and pro in (0, 2) and kw.get("stride", 1) == 1:
-            return "pw_dgrad_kernel<%d, %s>" % (pro, "true" if kw.get("accumulate") else "false")
-        if mode == 0 and kh == 1 and epi == 0 and N == 128 and K <= 256 and K % 32 == 0 and pro in (0, 1) and \
-                kw.get("stride", 1) == 1 and not kw.get("accumulate"):
-            return "pw_fwd_kernel<%d>" % pro
-        if mode == 0 and kh == 1 and epi == 0 and N == 128 and 256 < K <= 1280 and pro in (0, 1) and kw.get("stride", 1) == 1 and \
-                not kw.get("accumulate") and x.shape[0] * x.shape[1] * x.shape[2] <= 200000:
-            return "pw_fwdk_kernel<128, %d>" % pro
-        if mode == 2:
-            return "stem_fwd_kernel"
-        # conv_mm.hip (cx_try_conv_mm): wide channel counts; 128 x 256 tiles where N allows and a tile has more than four k-steps
-        ts, taps = kw.get("tstride", 1), kh * kw.get("kw", 1)
-        if mode == 0 and K % 8 == 0 and K >= 64 and N % 8 == 0 and ts <= 2 and taps <= 32 and \
-                ((epi == 0 and pro in (0, 1, 2)) or (epi == 1 and pro in (0, 2))):
-            nsteps = ((taps + 3) // 4 if ts == 2 else taps) * ((K + 63) // 64)
-            zero_tap_classes = ts == 2 and (kh < 2 or kw.get("kw", 1) < 2)
-            partial_ok = N % 128 == 0 or (nsteps >= 14 and N >= 96)          # partial last N tile: only with >= 14 k-steps per tile
-            if partial_ok and not (ts == 1 and nsteps <= 2) and not (zero_tap_classes and not kw.get("accumulate")):
-                wide = (N + 255) // 256 * 256 == (N + 127) // 128 * 128 and nsteps > 4 and \
-                    (3 * ((K + 63) // 64 * 64) * 4 + 2 * (128 + 256) * 144 <= 160 * 1024)
-                # (a stride-2 input gradient is up to four launches of the kernel, one per parity class: timed as one unit)
-                return "conv_mm_kernel<2, %d, %d, %d, false>%s" % (4 if wide else 2, pro, epi, " x parity classes" if ts == 2 else "")
-        bn = 128 if N % 128 == 0 else (32 if N == 32 else 64)
-        return "conv_gemm_kernel<%d, %d, %d, %d>" % (bn, pro, mode, epi)
-
-    @staticmethod
-    def wgrad_kernel_name(g, x, kw):
-        mode, kh, gp, xp, N = kw.get("mode", 0), kw.get("kh", 1), kw.get("g_prologue", 0), kw.get("x_prologue", 0), g.shape[3]
-        K = kw.get("K") or x.shape[3]
-        if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and (gp, xp, K, N) == (2, 1, 128, 32):
-            return "conv3x3_ring_wgrad_kernel" if x.shape[2] >= 56 and x.shape[1] * x.shape[2] >= 3136 else "conv3x3_strip_wgrad_kernel"
-        if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and K % 128 == 0 and N % 128 == 0 and \
-                gp in (0, 2) and xp in (0, 1):
-            # wgrad_mm.hip wgrad3_kernel: needs the slab workspace (ops.wgrad_scratch) for its splits x 9 x N x K partial sums
-            from chexpert_amd import ops as _ops
-            steps = (g.shape[0] * g.shape[1] * (g.shape[2] + 2) + 63) // 64
-            splits = min(max(1, 256 // ((K // 128) * (N // 128) * 3)), steps)
-            sps = -(-steps // splits)
-            if -(-steps // sps) * 9 * N * K <= _ops.WGRAD_SCRATCH_FLOATS:
-                return "wgrad3_kernel<%d, %d>" % (gp, xp)
-        if mode == 0 and kh == 3 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 1 and K % 32 == 0 and N % 8 == 0 and \
-                K <= 2048 and N <= 2048 and xp == 1 and gp in (0, 2) and 4 <= x.shape[2] <= 126:
-            return "conv3x3_strip_wgrad_kernel"               # (cx_try_strip_wgrad: any tile pairs of 32 x 32 channels)
-        M = g.shape[0] * g.shape[1] * g.shape[2]
-        if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and kw.get("pad", 0) == 0 and N % 8 == 0 and N >= 24 and K % 8 == 0 and \
-                K >= 64 and M % 64 == 0 and gp in (0, 2) and xp in (0, 1):
-            return "wgrad_mm_kernel<2, 4, %d, %d>" % (gp, xp)  # wgrad_mm.hip (cx_try_wgrad_mm)
-        if mode == 0 and kh == 1 and kw.get("stride", 1) == 1 and N % 128 == 0 and K >= 64 and M * K >= (1 << 23):
-            return "pw_wgrad_kernel<%d, %d>" % (gp, xp)
-        t = (64, 32) if mode == 2 else ((32, 128) if N == 32 else ((128, 64) if N % 128 == 0 else (64, 64)))
-        return "wgrad_kernel<%d, %d, %d, %d, %d>" % (t[0], t[1], gp, xp, mode)
-
+    # Tags are the names of the kernel instantiations the library dispatched to, as the library itself reports them
+    # (cx_last_kernel(), include/chexpert_hip.h): what rocprofv3 --kernel-trace lists, with no second copy of the dispatch rules.
     @staticmethod
     def _dims(t):
         B, H, W, C = t.shape
@@ -116,44 +55,28 @@ class KernelTimer:
         def conv_gemm(x, w, y, **kw):
             if not self.enabled:
                 return og(x, w, y, **kw)
-            tag = self.gemm_kernel_name(x, kw)
             mi, ci = self._dims(x)
             mo, co = self._dims(y)
             alg = (4.0 if x.dtype == torch.float32 else 2.0) * (mi * ci + mo * co)      # |X| + |Y| elements (SURVEY 8d rule, per kernel)
-            if x.dtype == torch.float32:
-                tag = "conv_f32_kernel<%d, %d, %d>" % (kw.get("prologue", 0), 0 if kw.get("mode", 0) == 2 else kw.get("mode", 0),
-                                                       kw.get("epilogue", 0))
-            if kw.get("fused_dw") is not None:       # conv1x1_bwd.hip launch_bwd: the v2 kernel (128-channel tiles) from 64 channels on
-                wide = kw["N"] >= 64
-                v1 = os.environ.get("CX_PW_BWD_V1", "0") not in ("", "0")
-                acc_s = "true" if kw.get("accumulate") else "false"
-                tag = ("pw_bwd2_kernel<%d, %s, 0>" % (kw.get("prologue", 0), acc_s)) if wide and not v1 else \
-                    ("pw_bwd_kernel<%d, %s, %d>" % (kw.get("prologue", 0), acc_s, 128 if wide else 64))
+            if kw.get("fused_dw") is not None:
                 alg += 2.0 * mo * co                 # the weight-gradient half also needs the layer input (|dZ| counted once)
-            if self.only is not None and tag != self.only:
-                return og(x, w, y, **kw)
-            return self._timed(tag, alg, og, x, w, y, **kw)
+            return self._timed(alg, og, x, w, y, **kw)
 
         def conv_wgrad(g, x, dw, **kw):
             if not self.enabled:
                 return ow(g, x, dw, **kw)
-            tag = self.wgrad_kernel_name(g, x, kw)
             mg, cg = self._dims(g)
             mx, cx = self._dims(x)
-            if g.dtype == torch.float32:
-                tag = "wgrad_f32_kernel<%d, %d, %d>" % (kw.get("g_prologue", 0), kw.get("x_prologue", 0),
-                                                        0 if kw.get("mode", 0) == 2 else kw.get("mode", 0))
-            if self.only is not None and tag != self.only:
-                return ow(g, x, dw, **kw)
-            return self._timed(tag, (4.0 if g.dtype == torch.float32 else 2.0) * (mg * cg + mx * cx), ow, g, x, dw, **kw)
+            return self._timed((4.0 if g.dtype == torch.float32 else 2.0) * (mg * cg + mx * cx), ow, g, x, dw, **kw)
         ops.conv_gemm, ops.conv_wgrad = conv_gemm, conv_wgrad
 
-    def _timed(self, tag, alg, fn, *a, **kw):
-        """Events around the kernel of one call.  A weight-gradient call with reproducible sums is the kernel plus a slab-reduce
-        launch: the library records `em` right before that reduce (dbg_pre_reduce_event), so the figure is the kernel's own
-        duration -- what rocprofv3 reports for it -- not kernel + reduce."""
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        em = self._mid_event()
+    def _timed(self, alg, fn, *a, **kw):
+        """Events around the kernel of one call, filed under the kernel name the library reports for it (`only`: other kernels'
+        records are dropped).  A weight-gradient call with immediate reproducible sums is the kernel plus a slab-reduce launch: the
+        library records `em` right before that reduce (dbg_pre_reduce_event), so the figure is the kernel's own duration -- what
+        rocprofv3 reports for it -- not kernel + reduce."""
+        e0, e1 = self._event(), self._event()
+        em = self._event()
         e0.record()
         raw = self._raw()
         raw.dbg_pre_reduce_event(ctypes.c_void_p(em.cuda_event))
@@ -161,10 +84,12 @@ class KernelTimer:
         taken = raw.dbg_pre_reduce_event_taken()
         raw.dbg_pre_reduce_event(None)
         e1.record()
-        self.records.setdefault(tag, []).append((e0, em if taken else e1, alg))
+        tag = raw.cx_last_kernel().decode()
+        if self.only is None or tag == self.only:
+            self.records.setdefault(tag, []).append((e0, em if taken else e1, alg))
         return r
 
-    def _mid_event(self):
+    def _event(self):
         """An event whose hipEvent already exists (torch creates it at the first record): created in batches outside the brackets."""
         pool = getattr(self, "_pool", None)
         if not pool:
@@ -179,6 +104,7 @@ class KernelTimer:
             self._rawlib = ctypes.CDLL(_lib.LIB_PATH)
             self._rawlib.dbg_pre_reduce_event.argtypes = [ctypes.c_void_p]
             self._rawlib.dbg_pre_reduce_event_taken.restype = ctypes.c_int
+            self._rawlib.cx_last_kernel.restype = ctypes.c_char_p
         return self._rawlib
 
     def summary(self):

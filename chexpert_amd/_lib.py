@@ -53,6 +53,7 @@ class CxReduceDesc(C.Structure):
 _f, _sz, _i = C.c_float, C.c_size_t, C.c_int
 SIGNATURES = {
     "cx_abi_version": [],
+    "cx_last_kernel": [],
     "cx_wgrad_defer": [C.c_int],
     "cx_wgrad_defer_take": [C.POINTER(CxReduceDesc), C.c_int, C.POINTER(C.c_int64)],
     "cx_last_slab_floats": [],
@@ -124,24 +125,24 @@ SIGNATURES = {
     "cx_nchw3_to_nhwc8_f32": [_vp, _vp, _i, _i, _i, _vp],
     "cx_u8_to_nhwc8": [_vp, _vp, _sz, _f, _f, _vp],
     "cx_u8_to_nhwc8_f32": [_vp, _vp, _sz, _f, _f, _vp],
-    "cx_dwconv_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "cx_dwconv_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "cx_dwconv_dgrad": [_vp] * 14 + [_i] * 8 + [_vp],
-    "cx_dwconv_dgrad_f32": [_vp] * 14 + [_i] * 8 + [_vp],
-    "cx_dwconv_wgrad": [_vp] * 9 + [_i] * 7 + [_vp],
-    "cx_dwconv_wgrad_f32": [_vp] * 9 + [_i] * 7 + [_vp],
-    "cx_gap_affine_act": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "cx_gap_affine_act_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "cx_dwconv_fwd": [_vp] * 7 + [_i] * 8 + [_vp],
+    "cx_dwconv_fwd_f32": [_vp] * 7 + [_i] * 8 + [_vp],
+    "cx_dwconv_dgrad": [_vp] * 14 + [_i] * 9 + [_vp],
+    "cx_dwconv_dgrad_f32": [_vp] * 14 + [_i] * 9 + [_vp],
+    "cx_dwconv_wgrad": [_vp] * 9 + [_i] * 7 + [_vp, C.c_int64, _vp],
+    "cx_dwconv_wgrad_f32": [_vp] * 9 + [_i] * 7 + [_vp, C.c_int64, _vp],
+    "cx_gap_affine_act": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_int64, _vp],
+    "cx_gap_affine_act_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_int64, _vp],
     "cx_se_fwd": [_vp] * 7 + [_i, _i, _i, _vp],
-    "cx_se_bwd": [_vp] * 11 + [_i, _i, _i, _vp],
+    "cx_se_bwd": [_vp] * 11 + [_i, _i, _i, _vp, C.c_int64, _vp],
     "cx_scale_act_bc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_scale_act_bc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "cx_se_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "cx_se_bwd_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "cx_se_act_bwd": [_vp] * 11 + [_i, _i, _i, _vp],
-    "cx_se_act_bwd_f32": [_vp] * 11 + [_i, _i, _i, _vp],
-    "cx_bn_lin_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
-    "cx_bn_lin_bwd_stats_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp],
+    "cx_se_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, C.c_int64, _vp],
+    "cx_se_bwd_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, C.c_int64, _vp],
+    "cx_se_act_bwd": [_vp] * 11 + [_i, _i, _i, _i, _vp],
+    "cx_se_act_bwd_f32": [_vp] * 11 + [_i, _i, _i, _i, _vp],
+    "cx_bn_lin_bwd_stats": [_vp] * 6 + [_sz, _i, _i, _vp],
+    "cx_bn_lin_bwd_stats_f32": [_vp] * 6 + [_sz, _i, _i, _vp],
     "cx_affine2_out": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp],
     "cx_affine2_out_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp],
     "cx_scale_rows": [_vp, _vp, _sz, _vp, _sz, _i, _vp],
@@ -171,7 +172,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args
-            fn.restype = C.c_char_p if name == "cx_error_string" else C.c_int
+            fn.restype = C.c_char_p if name in ("cx_error_string", "cx_last_kernel") else C.c_int
         if l.cx_abi_version() != 6:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l

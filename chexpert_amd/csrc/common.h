@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/chexpert_hip.h"
 
 typedef __bf16 bf16;
@@ -83,6 +84,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
+
+// the kernel instantiation the most recent conv / weight-gradient entry point of this thread dispatched to, as rocprofv3 spells it
+// (cx_last_kernel(): bench.py tags its per-kernel event timings with it instead of mirroring the dispatch rules)
+extern thread_local char cx_tl_kernel[112];
+#define CX_KTAG(...) snprintf(cx_tl_kernel, sizeof(cx_tl_kernel), __VA_ARGS__)
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int launch_status() {

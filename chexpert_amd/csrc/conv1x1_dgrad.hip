@@ -268,6 +268,7 @@ int launch_pw(const CxConv& p, hipStream_t st) {
                               (int)smem);
     attr_set = true;
   }
+  CX_KTAG("pw_dgrad_kernel<%d, %s>", PRO, ACC ? "true" : "false");
   hipLaunchKernelGGL((pw_dgrad_kernel<PRO, ACC>), dim3(m_tiles * n_chunks), dim3(256), smem, st, p, (int)M, n_tiles, tpc, n_chunks);
   return launch_status();
 }

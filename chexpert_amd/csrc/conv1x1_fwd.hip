@@ -252,6 +252,7 @@ int launch_fwd(const CxConv& p, hipStream_t st) {
   }
   if (smem > 80 * 1024) return CX_ESHAPE;
   if (const int e = stat_rows_check(p, grid)) return e;
+  CX_KTAG("pw_fwd_kernel<%d>", PRO);
   hipLaunchKernelGGL((pw_fwd_kernel<PRO>), dim3(grid), dim3(256), smem, st, p, (int)M, m_tiles, nkb, kc, wpitch);
   return launch_status();
 }

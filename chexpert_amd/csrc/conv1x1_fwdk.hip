@@ -179,6 +179,7 @@ int launch_fwdk(const CxConv& p, hipStream_t st) {
   }
   if (smem > 80 * 1024) return CX_ESHAPE;
   if (const int e = stat_rows_check(p, m_tiles)) return e;
+  CX_KTAG("pw_fwdk_kernel<%d, %d>", BK, PRO);
   hipLaunchKernelGGL((pw_fwdk_kernel<BK, PRO>), dim3(m_tiles), dim3(256), smem, st, p, (int)M);
   return launch_status();
 }

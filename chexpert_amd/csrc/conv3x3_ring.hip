@@ -280,6 +280,7 @@ int launch_ring(const CxConv& p, hipStream_t st, const RingGeo& g) {
   const int total = g.B * g.spi;
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   if (const int e = stat_rows_check(p, grid)) return e;
+  CX_KTAG("conv3x3_ring_fwd_kernel<%d, %d>", NCH, DEPTH);
   hipLaunchKernelGGL((conv3x3_ring_fwd_kernel<NCH, DEPTH>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, p.pa, p.pb,
                      (const bf16*)p.w, (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
   return launch_status();
@@ -542,6 +543,7 @@ int launch_ring_dgrad(const CxConv& p, hipStream_t st, const RingGeo& g) {
   const int total = g.B * g.spi;
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   if (const int e = stat_rows_check(p, grid)) return e;
+  CX_KTAG("conv3x3_ring_dgrad_kernel<%d>", NCH);
   hipLaunchKernelGGL((conv3x3_ring_dgrad_kernel<NCH>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2,
                      p.ldx2, p.pa, p.pb, p.pc, (const bf16*)p.w, (const bf16*)p.ex, p.ldex, p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale,
                      (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
@@ -766,6 +768,7 @@ int launch_ring_wgrad(const CxWgrad& p, hipStream_t st, const RingGeo& g, size_t
   const bool a2 = p.g_prologue == CX_PRO_AFFINE2;
   const size_t wtotal = (size_t)32 * 128 * 9;
   float* slab = dw_slab(p.scratch, p.scratch_floats, grid, (long long)wtotal);
+  CX_KTAG("conv3x3_ring_wgrad_kernel<%d, %d>", NX, NG);
   hipLaunchKernelGGL((conv3x3_ring_wgrad_kernel<NX, NG>), dim3(grid), dim3(WNT), smem, st, (const bf16*)p.g, p.ldg,
                      (const bf16*)(a2 ? p.g2 : p.g), a2 ? p.ldg2 : p.ldg, p.ga, p.gb, p.gc, (int)a2, (const bf16*)p.x, p.ldx, p.pa, p.pb,
                      p.dw, g, slab);

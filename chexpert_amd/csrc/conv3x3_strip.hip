@@ -675,6 +675,7 @@ int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   *handled = true;
   if (const int e = stat_rows_check(p, grid)) return e;
+  CX_KTAG("conv3x3_strip_fwd_kernel");
   hipLaunchKernelGGL(conv3x3_strip_fwd_kernel, dim3(grid), dim3(192), smem, st, (const bf16*)p.x, p.ldx, p.pa, p.pb,
                      (const bf16*)p.w, (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
   return launch_status();
@@ -699,6 +700,7 @@ int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   *handled = true;
   if (const int e = stat_rows_check(p, grid)) return e;
+  CX_KTAG("conv3x3_strip_dgrad_kernel");
   hipLaunchKernelGGL(conv3x3_strip_dgrad_kernel, dim3(grid), dim3(192), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2, p.ldx2,
                      p.pa, p.pb, p.pc, (const bf16*)p.w, (const bf16*)p.ex, p.ldex, p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale,
                      (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
@@ -738,6 +740,7 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
       const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
       const size_t wtotal = (size_t)p.N * p.K * 9;
       float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
+      CX_KTAG("conv3x3_strip_wgrad_kernel<4, %d>", NCHW4);
       hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<4, NCHW4>), dim3(splits * pairs), dim3(768), smem, st, (const bf16*)p.g, p.ldg,
                          (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx,
                          p.pa, p.pb, p.dw, p.K, p.N, c_tiles, n_tiles, g, slab);
@@ -762,6 +765,7 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   const size_t wtotal = (size_t)p.N * p.K * 9;
   float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
+  CX_KTAG("conv3x3_strip_wgrad_kernel<1, %d>", NCHW1);
   hipLaunchKernelGGL((conv3x3_strip_wgrad_kernel<1, NCHW1>), dim3(splits * pairs), dim3(192), smem, st, (const bf16*)p.g, p.ldg,
                      (const bf16*)p.g2, p.ldg2, p.ga, p.gb, p.gc, (int)(p.g_prologue == CX_PRO_AFFINE2), (const bf16*)p.x, p.ldx, p.pa, p.pb,
                      p.dw, p.K, p.N, c_tiles, n_tiles, g, slab);

@@ -257,6 +257,7 @@ int launch_f32(const CxConv& p, hipStream_t st) {
   const size_t smem = ((size_t)NCoefF<PRO>::v * p.K + FBM * FP + FBN * FP + 64 * EPITCH) * 4;
   if (smem > 64 * 1024) return CX_ESHAPE;
   if (const int e = stat_rows_check(p, m_tiles)) return e;
+  CX_KTAG("conv_f32_kernel<%d, %d, %d>", PRO, MODE, EPI);
   hipLaunchKernelGGL((conv_f32_kernel<PRO, MODE, EPI>), dim3(m_tiles * n_tiles), dim3(256), smem, st, p, (int)M, n_tiles);
   return launch_status();
 }
@@ -383,6 +384,7 @@ int launch_wgrad_f32(const CxWgrad& p, hipStream_t st, int dw_k) {
   long long pps = (M + splits - 1) / splits;
   pps = (pps + 15) / 16 * 16;
   splits = (M + pps - 1) / pps;
+  CX_KTAG("wgrad_f32_kernel<%d, %d, %d>", GPRO, XPRO, MODE);
   hipLaunchKernelGGL((wgrad_f32_kernel<GPRO, XPRO, MODE>), dim3((unsigned)(base * splits)), dim3(256), 0, st, p, (int)M, n_tiles, c_tiles,
                      (int)pps, dw_k);
   return launch_status();

@@ -388,6 +388,7 @@ int launch(const CxConv& p, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  CX_KTAG("conv_gemm_kernel<%d, %d, %d, %d>", BN, PRO, MODE, EPI);
   hipLaunchKernelGGL((conv_gemm_kernel<BN, PRO, MODE, EPI>), dim3(m_tiles * n_tiles), dim3(256), smem, st, p, (int)M,
                      n_tiles);
   return launch_status();
@@ -414,6 +415,8 @@ int cx_conv_gemm_f32(const CxConv& p, hipStream_t st);                      // c
 int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled);         // conv_mm.hip
 
 thread_local int cx_tl_stat_rows = 0;
+thread_local char cx_tl_kernel[112] = "";
+extern "C" const char* cx_last_kernel(void) { return cx_tl_kernel; }
 extern "C" int cx_last_stat_rows(void) { return cx_tl_stat_rows; }
 
 extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {

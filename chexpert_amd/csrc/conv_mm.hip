@@ -530,6 +530,7 @@ int launch(const CxConv& p, const Cls& c, hipStream_t st) {
     hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, DP, CX_EPI_STORE, true>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, c, n_tiles);
     return launch_status();
   }
+  CX_KTAG("conv_mm_kernel<%d, %d, %d, %d, false>%s", WMW, WNW, PRO, EPI, p.tstride > 1 ? " x parity classes" : "");
   hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, PRO, EPI>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, c, n_tiles);
   return launch_status();
 }

@@ -167,6 +167,7 @@ int cx_try_stem_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   const int grid = m_tiles < 512 ? m_tiles : 512;
   *handled = true;
   if (const int e = stat_rows_check(p, grid)) return e;
+  CX_KTAG("stem_fwd_kernel");
   hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), SW_ROWS * SP, st, p, (int)M, m_tiles);
   *handled = true;
   return launch_status();

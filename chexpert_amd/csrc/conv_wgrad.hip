@@ -281,6 +281,7 @@ int launch(const CxWgrad& p, hipStream_t st) {
   const size_t wtotal = (MODE == CX_MODE_STEM) ? (size_t)p.N * 147 : (size_t)p.N * p.K * taps;
   const int slabs = splits * G::WAVES_K;
   float* slab = dw_slab(p.scratch, p.scratch_floats, slabs, (long long)wtotal);
+  CX_KTAG("wgrad_kernel<%d, %d, %d, %d, %d>", BNW, BCW, GPRO, XPRO, MODE);
   hipLaunchKernelGGL((wgrad_kernel<BNW, BCW, GPRO, XPRO, MODE>), dim3(n_tiles * c_tiles * taps * splits), dim3(256), smem,
                      st, p, M, n_tiles, c_tiles, taps, splits, sps, slab);
   if (const int e = launch_status()) return e;
@@ -438,6 +439,7 @@ int launch_stem(const CxWgrad& p, hipStream_t st) {
   splits = (total_steps + sps - 1) / sps;
   const size_t wtotal = (size_t)64 * 147;
   float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
+  CX_KTAG("stem_wgrad_kernel<%d>", GPRO);
   hipLaunchKernelGGL((stem_wgrad_kernel<GPRO>), dim3(splits), dim3(256), 2 * ST_STAGE, st, p, M, sps, slab);
   if (const int e = launch_status()) return e;
   return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;
@@ -599,6 +601,7 @@ int launch_pw_wgrad(const CxWgrad& p, hipStream_t st) {
   }
   const size_t wtotal = (size_t)p.N * p.K;
   float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
+  CX_KTAG("pw_wgrad_kernel<%d, %d>", GPRO, XPRO);
   hipLaunchKernelGGL((pw_wgrad_kernel<GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(512), smem, st, p, M, c_tiles, n_tiles, sps, slab);
   if (const int e = launch_status()) return e;
   return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;

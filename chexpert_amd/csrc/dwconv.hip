@@ -30,6 +30,7 @@ __device__ __forceinline__ float dswish(float z) {
 struct DwGeo {
   int B, H, W, C, Ho, Wo;
   int tiles_x, tiles_y;        // tiles of the walked map (output map for forward / weight gradient, input map for the input gradient)
+  int det, rstride;            // det: the workgroup plain-stores its statistic row blockIdx.x (row pitch rstride) instead of atomics
 };
 
 // ---------------------------------------------------------------------------------------------------------------- forward
@@ -188,6 +189,19 @@ __global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict
   }
   if (g1) {
     __syncthreads();
+    if (g.det) {        // deterministic: per-thread slots (the stencil tile is free now), folded in thread order, one plain-stored row
+      float* slot = reinterpret_cast<float*>(smem);          // [256][16]: the launcher sizes the dynamic LDS for it
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { slot[tid * 16 + e] = s1[e]; slot[tid * 16 + 8 + e] = s2[e]; }
+      __syncthreads();
+      for (int i = tid; i < 2 * CB; i += 256) {
+        const int which = i / CB, c = i - which * CB, chunk = c >> 3, e = c & 7;
+        float t = 0.f;
+        for (int th = chunk; th < 256; th += NCQ) t += slot[th * 16 + which * 8 + e];
+        if (c0 + c < C) (which ? g2 : g1)[(size_t)blockIdx.x * g.rstride + c0 + c] = t;
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       atomicAdd(&red[cq * 8 + e], s1[e]);
@@ -341,6 +355,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   if (S1) {
     __syncthreads();
+    if (g.det) {        // as in the forward kernel: slots in the (now free) gradient tile, ordered fold, plain-stored row
+      float* slot = reinterpret_cast<float*>(smem);          // [256][16]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { slot[tid * 16 + e] = s1[e]; slot[tid * 16 + 8 + e] = s2[e]; }
+      __syncthreads();
+      for (int i = tid; i < 2 * CB; i += 256) {
+        const int which = i / CB, c = i - which * CB, chunk = c >> 3, e = c & 7;
+        float t = 0.f;
+        for (int th = chunk; th < 256; th += NCQ) t += slot[th * 16 + which * 8 + e];
+        if (c0 + c < C && (which == 0 || S2)) (which ? S2 : S1)[(size_t)blockIdx.x * g.rstride + c0 + c] = t;
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       atomicAdd(&red[cq * 8 + e], s1[e]);
@@ -363,7 +390,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const bf16* __restri
                                                             const float* __restrict__ ga, const float* __restrict__ gb,
                                                             const float* __restrict__ gc, const bf16* __restrict__ x,
                                                             const float* __restrict__ sc, const float* __restrict__ sh,
-                                                            float* __restrict__ dw, const DwGeo g) {
+                                                            float* __restrict__ dw, float* __restrict__ slab, const DwGeo g) {
   constexpr int PAD = K / 2, IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, CB = NCQ * 8, PP = CB * 2 + 16;
   constexpr int NCOMB = NCQ * K, NSUB = 256 / NCOMB, NPX = TH * TW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -463,6 +490,23 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const bf16* __restri
     }
   }
   __syncthreads();
+  if (slab) {       // reproducible: per-thread slots, the pixel subsets of a (tap, channel) folded in subset order, one plain-stored
+                    // partial tile per workgroup (slab row blockIdx.x; cx_dw_reduce adds the rows in row order)
+    float* slot = reinterpret_cast<float*>(smem);             // [256][K*8]: the launcher sizes the dynamic LDS for it
+#pragma unroll
+    for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) slot[tid * (K * 8) + dx * 8 + e] = acc[dx][e];
+    __syncthreads();
+    const size_t total = (size_t)C * K * K;
+    for (int i = tid; i < K * K * CB; i += 256) {
+      const int t = i / CB, c = i - t * CB, ty_ = t / K, dx = t - ty_ * K, chunk = c >> 3, e = c & 7;
+      float a = 0.f;
+      for (int sb = 0; sb < NSUB; ++sb) a += slot[(sb * NCOMB + ty_ * NCQ + chunk) * (K * 8) + dx * 8 + e];
+      if (c0 + c < C) slab[(size_t)blockIdx.x * total + (size_t)(c0 + c) * K * K + t] = a;
+    }
+    return;
+  }
   if (sub < NSUB) {
 #pragma unroll
     for (int dx = 0; dx < K; ++dx)
@@ -505,6 +549,9 @@ struct DwArgs {
   bf16 *y, *dz;
   float *s1, *s2, *dw;
   int accumulate;
+  int stat_rows;                 // > 0: deterministic statistic rows (capacity), cx_last_stat_rows() reports the rows written
+  float* scratch;                // weight gradient: slab workspace (CxWgrad.scratch protocol) or null (atomics)
+  long long scratch_floats;
 };
 
 template <int K, int S, int TH, int NCQ>
@@ -517,10 +564,17 @@ int launch_cfg(int which, const DwArgs& a, DwGeo g, hipStream_t st) {
   int gx = 2048 / cblocks;                       // workgroups stay persistent: one flush of statistics / dW each
   if (gx < 64) gx = 64;
   if (gx > ntiles) gx = ntiles;
+  g.det = 0; g.rstride = g.C;
+  if (which != 2 && a.stat_rows > 0 && a.s1) {       // one statistic row per blockIdx.x (every channel block writes its part of it)
+    if (gx > a.stat_rows) gx = a.stat_rows;
+    g.det = 1;
+    cx_tl_stat_rows = gx;
+  }
   const dim3 grid(gx, cblocks);
   static bool attr[3] = {false, false, false};       // per instantiation
   if (which == 0) {
-    const size_t smem = fwd_smem<K, S, TH, NCQ>();
+    size_t smem = fwd_smem<K, S, TH, NCQ>();
+    if (g.det && smem < 256 * 16 * 4) smem = 256 * 16 * 4;
     static const bool pipe = getenv("CX_DW_PIPE") && atoi(getenv("CX_DW_PIPE")) == 1;    // measured: no gain (LDS-issue bound, not latency bound)
     static bool attr_np = false;
     if (pipe) {
@@ -531,15 +585,21 @@ int launch_cfg(int which, const DwArgs& a, DwGeo g, hipStream_t st) {
       hipLaunchKernelGGL((dw_fwd_tile_kernel<K, S, TH, NCQ, false>), grid, dim3(256), smem, st, a.x, a.w, a.sc, a.sh, a.y, a.s1, a.s2, g);
     }
   } else if (which == 1) {
-    const size_t smem = dgrad_smem<K, S, TH, NCQ>();
+    size_t smem = dgrad_smem<K, S, TH, NCQ>();
+    if (g.det && smem < 256 * 16 * 4) smem = 256 * 16 * 4;
     allow_smem(&dw_dgrad_tile_kernel<K, S, TH, NCQ>, smem, &attr[1]);
     hipLaunchKernelGGL((dw_dgrad_tile_kernel<K, S, TH, NCQ>), grid, dim3(256), smem, st, a.g, a.g2, a.ga, a.gb, a.gc, a.w, a.x, a.sc,
                        a.sh, a.mean, a.rstd, a.dz, a.s1, a.s2, a.accumulate, g);
   } else {
-    const size_t smem = wgrad_smem<K, S, TH, NCQ>();
+    size_t smem = wgrad_smem<K, S, TH, NCQ>();
+    if (smem < (size_t)256 * K * 8 * 4) smem = (size_t)256 * K * 8 * 4;
+    const long long total = (long long)g.C * K * K;
+    float* slab = dw_slab(a.scratch, a.scratch_floats, gx, total);
     allow_smem(&dw_wgrad_tile_kernel<K, S, TH, NCQ>, smem, &attr[2]);
     hipLaunchKernelGGL((dw_wgrad_tile_kernel<K, S, TH, NCQ>), grid, dim3(256), smem, st, a.g, a.g2, a.ga, a.gb, a.gc, a.x, a.sc, a.sh,
-                       a.dw, g);
+                       a.dw, slab, g);
+    if (const int e = launch_status()) return e;
+    return slab ? cx_dw_reduce(a.dw, slab, (size_t)total, gx, st) : 0;
   }
   return launch_status();
 }
@@ -559,8 +619,8 @@ int launch_ks(int which, const DwArgs& a, const DwGeo& g, hipStream_t st) {
 // which: 0 forward, 1 input gradient, 2 weight gradient.  *handled = false: shape not covered, the caller keeps its own kernel.
 int cx_try_dw_tile(int which, const void* x, const float* w, const float* sc, const float* sh, const float* mean, const float* rstd,
                    const void* gq, const void* g2, const float* ga, const float* gb, const float* gc, void* y, void* dz, float* s1,
-                   float* s2, float* dw, int accumulate, int B, int H, int W, int C, int k, int stride, int pad, hipStream_t st,
-                   bool* handled) {
+                   float* s2, float* dw, int accumulate, int B, int H, int W, int C, int k, int stride, int pad, int stat_rows,
+                   float* scratch, long long scratch_floats, hipStream_t st, bool* handled) {
   *handled = false;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2) || pad != k / 2 || C % 8) return 0;
   DwGeo g;
@@ -572,6 +632,7 @@ int cx_try_dw_tile(int which, const void* x, const float* w, const float* sc, co
   a.x = (const bf16*)x; a.g = (const bf16*)gq; a.g2 = (const bf16*)g2;
   a.w = w; a.sc = sc; a.sh = sh; a.mean = mean; a.rstd = rstd; a.ga = ga; a.gb = gb; a.gc = gc;
   a.y = (bf16*)y; a.dz = (bf16*)dz; a.s1 = s1; a.s2 = s2; a.dw = dw; a.accumulate = accumulate;
+  a.stat_rows = stat_rows; a.scratch = scratch; a.scratch_floats = scratch_floats;
   *handled = true;
   if (k == 3) return stride == 1 ? launch_ks<3, 1>(which, a, g, st) : launch_ks<3, 2>(which, a, g, st);
   return stride == 1 ? launch_ks<5, 1>(which, a, g, st) : launch_ks<5, 2>(which, a, g, st);

@@ -10,8 +10,8 @@
 // dwconv.hip: tiled depthwise kernels for k in {3,5}, stride in {1,2}, pad = k/2 (which: 0 forward, 1 dgrad, 2 wgrad)
 int cx_try_dw_tile(int which, const void* x, const float* w, const float* sc, const float* sh, const float* mean, const float* rstd,
                    const void* gq, const void* g2, const float* ga, const float* gb, const float* gc, void* y, void* dz, float* s1,
-                   float* s2, float* dw, int accumulate, int B, int H, int W, int C, int k, int stride, int pad, hipStream_t st,
-                   bool* handled);
+                   float* s2, float* dw, int accumulate, int B, int H, int W, int C, int k, int stride, int pad, int stat_rows,
+                   float* scratch, long long scratch_floats, hipStream_t st, bool* handled);
 
 namespace {
 
@@ -38,9 +38,33 @@ inline int grid_for(size_t n, int block, int cap) {
 }
 inline int threads_for(int CP) { return CP * (256 / CP > 0 ? 256 / CP : 1); }
 
-// shared reduction of per-thread 8-channel partials (thread's chunk column cq is loop invariant)
+// shared reduction of per-thread 8-channel partials (thread's chunk column cq is loop invariant).
+// det == 0: LDS atomics, then one global atomic per channel (lds = NS * C floats, zeroed by the caller).
+// det != 0: every thread parks its partials in its own LDS slot (lds = blockDim.x * NS * 8 floats), the threads sharing a chunk are
+// added in thread order and the workgroup plain-stores statistic row `row` (dst[k][row * C + c], CxConv.stat_det convention):
+// the same bits every run.
 template <int NS>
-__device__ __forceinline__ void flush_partials(float (&s)[NS][8], int cq, int C, float* lds, float* const (&dst)[NS]) {
+__device__ __forceinline__ void flush_partials(float (&s)[NS][8], int cq, int C, float* lds, float* const (&dst)[NS], int det = 0,
+                                               int row = 0) {
+  if (det) {
+    const int CP = C / 8;
+    __syncthreads();                       // (the atomic mode's zero-fill of lds may still be in flight in other waves)
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lds[(threadIdx.x * NS + k) * 8 + j] = s[k][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const int chunk = c >> 3, j = c & 7;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        float t = 0.f;
+        for (int th = chunk; th < (int)blockDim.x; th += CP) t += lds[(th * NS + k) * 8 + j];
+        if (dst[k]) dst[k][(size_t)row * C + c] = t;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < NS; ++k)
 #pragma unroll
@@ -85,7 +109,7 @@ __global__ void u8_to_nhwc8_kernel(const uint8_t* __restrict__ x, T* __restrict_
 template <typename T>
 __global__ void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sc,
                                   const float* __restrict__ sh, T* __restrict__ y, float* g1, float* g2, int B, int H, int W, int C,
-                                  int Ho, int Wo, int k, int stride, int pad) {
+                                  int Ho, int Wo, int k, int stride, int pad, int det) {
   extern __shared__ float lds[];          // [2][C]
   const int CP = C / 8;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
@@ -132,7 +156,7 @@ __global__ void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restri
     V8<T>::st(y + pix * C + cq * 8, o_f);
   }
   float* const dst[2] = {g1, g2};
-  if (g1) flush_partials<2>(s, cq, C, lds, dst);
+  if (g1) flush_partials<2>(s, cq, C, lds, dst, det, (int)blockIdx.x);
 }
 
 // input gradient: da[p][c] = sum_t dY[(p + pad - t)/stride][c] * w[c][t];  dY = g*ga + g2*gb + gc
@@ -142,7 +166,8 @@ __global__ void dwconv_dgrad_kernel(const T* __restrict__ g, const T* __restrict
                                     const float* __restrict__ gb, const float* __restrict__ gc, const float* __restrict__ w,
                                     const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                                     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dz, float* S1,
-                                    float* S2, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int accumulate) {
+                                    float* S2, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int accumulate,
+                                    int det) {
   extern __shared__ float lds[];
   const int CP = C / 8;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
@@ -202,7 +227,7 @@ __global__ void dwconv_dgrad_kernel(const T* __restrict__ g, const T* __restrict
     V8<T>::st(dz + pix * C + cq * 8, o_f);
   }
   float* const dst[2] = {S1, S2};
-  if (S1) flush_partials<2>(s, cq, C, lds, dst);
+  if (S1) flush_partials<2>(s, cq, C, lds, dst, det, (int)blockIdx.x);
 }
 
 // weight gradient: dW[c][t] += sum_p dY[p][c] * act(x[p@t][c]); one tap per blockIdx.y
@@ -210,7 +235,7 @@ template <typename T>
 __global__ void dwconv_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ g2, const float* __restrict__ ga,
                                     const float* __restrict__ gb, const float* __restrict__ gc, const T* __restrict__ x,
                                     const float* __restrict__ sc, const float* __restrict__ sh, float* __restrict__ dw, int B, int H, int W,
-                                    int C, int Ho, int Wo, int k, int stride, int pad) {
+                                    int C, int Ho, int Wo, int k, int stride, int pad, float* __restrict__ slab) {
   extern __shared__ float lds[];          // [C]
   const int CP = C / 8;
   for (int i = threadIdx.x; i < C; i += blockDim.x) lds[i] = 0.f;
@@ -244,6 +269,20 @@ __global__ void dwconv_wgrad_kernel(const T* __restrict__ g, const T* __restrict
       s[0][j] = fmaf(dy_, a, s[0][j]);
     }
   }
+  if (slab) {        // reproducible: thread slots folded in thread order, one partial (row blockIdx.x of the slab) per workgroup and tap
+    const int CPs = C / 8;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[threadIdx.x * 8 + j] = s[0][j];
+    __syncthreads();
+    const size_t total = (size_t)C * k * k;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float t = 0.f;
+      for (int th = c >> 3; th < (int)blockDim.x; th += CPs) t += lds[th * 8 + (c & 7)];
+      slab[(size_t)blockIdx.x * total + (size_t)c * k * k + tap] = t;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) atomicAdd(&lds[cq * 8 + j], s[0][j]);
   __syncthreads();
@@ -254,7 +293,7 @@ __global__ void dwconv_wgrad_kernel(const T* __restrict__ g, const T* __restrict
 // pooled[b][c] = mean_hw act(x*sc+sh), act: 0 none, 1 relu, 2 swish
 template <typename T>
 __global__ void gap_affine_act_kernel(const T* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
-                                      float* __restrict__ pooled, int HW, int C, int act, int splits) {
+                                      float* __restrict__ pooled, int HW, int C, int act, int splits, float* __restrict__ rows) {
   // four pixel rows of a thread are requested before the first is consumed (one 16-B load in flight per lane left this kernel
   // at 0.8 TB/s); the rows of a workgroup meet in LDS, one global atomic per channel and workgroup
   extern __shared__ float lds[];
@@ -287,10 +326,22 @@ __global__ void gap_affine_act_kernel(const T* __restrict__ x, const float* __re
       }
     }
   }
+  const float inv = 1.f / HW;
+  if (rows) {        // reproducible: pixel lanes folded in lane order, the split's partial mean plain-stored into row `sp` (rows summed in
+                     // row order by the launch that follows)
+    __syncthreads();
+    for (int j = 0; j < 8; ++j) lds[threadIdx.x * 8 + j] = a[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float t = 0.f;
+      for (int th = c >> 3; th < (int)blockDim.x; th += CP) t += lds[th * 8 + (c & 7)];
+      rows[((size_t)sp * gridDim.y + b) * C + c] = t * inv;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) atomicAdd(&lds[cq * 8 + j], a[j]);
   __syncthreads();
-  const float inv = 1.f / HW;
   for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&pooled[(size_t)b * C + c], lds[c] * inv);
 }
 
@@ -344,7 +395,7 @@ __global__ void scale_act_bc_kernel(const T* __restrict__ x, const float* __rest
 // linear BatchNorm backward statistics: S1 += sum g, S2 += sum g * (y-mean)*rstd
 template <typename T>
 __global__ void bn_lin_bwd_stats_kernel(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ mean,
-                                        const float* __restrict__ rstd, float* S1, float* S2, size_t rows, int C) {
+                                        const float* __restrict__ rstd, float* S1, float* S2, size_t rows, int C, int det) {
   extern __shared__ float lds[];
   const int CP = C / 8;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
@@ -375,13 +426,13 @@ __global__ void bn_lin_bwd_stats_kernel(const T* __restrict__ g, const T* __rest
     }
   }
   float* const dst[2] = {S1, S2};
-  flush_partials<2>(s, cq, C, lds, dst);
+  flush_partials<2>(s, cq, C, lds, dst, det, (int)blockIdx.x);
 }
 
 // ds[b][c] = sum_hw du * swish(x*sc+sh)
 template <typename T>
 __global__ void se_bwd_reduce_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ sc,
-                                     const float* __restrict__ sh, float* __restrict__ ds, int HW, int C, int splits) {
+                                     const float* __restrict__ sh, float* __restrict__ ds, int HW, int C, int splits, float* __restrict__ rows) {
   extern __shared__ float lds[];
   constexpr int U = 4;                       // pixel rows in flight per thread (see gap_affine_act_kernel)
   const int CP = C / 8;
@@ -413,6 +464,17 @@ __global__ void se_bwd_reduce_kernel(const T* __restrict__ du, const T* __restri
       }
     }
   }
+  if (rows) {        // reproducible (see gap_affine_act_kernel)
+    __syncthreads();
+    for (int j = 0; j < 8; ++j) lds[threadIdx.x * 8 + j] = a[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float t = 0.f;
+      for (int th = c >> 3; th < (int)blockDim.x; th += CP) t += lds[th * 8 + (c & 7)];
+      rows[((size_t)sp * gridDim.y + b) * C + c] = t;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) atomicAdd(&lds[cq * 8 + j], a[j]);
   __syncthreads();
@@ -422,12 +484,14 @@ __global__ void se_bwd_reduce_kernel(const T* __restrict__ du, const T* __restri
 // SE backward through the two FCs: one block per sample
 // Workgroup = (group of G images, slice of CS channels).  The weight-gradient outer products are summed over the group before
 // they meet the global atomics (one workgroup per image sent B*C*R contended atomics per matrix: 224 us per call at B = 128);
-// every slice recomputes the group's dlogit2 / dh1 (a few hundred thousand FMAs) rather than exchanging them.
+// every slice recomputes the group's dlogit2 / dh1 (a few hundred thousand FMAs) rather than exchanging them.  With a slab
+// workspace (sl_*: one slab per image group) the group sums are plain-stored and added in group order afterwards (reproducible);
+// without, they meet in fp32 atomics.
 __global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
                                                       const float* __restrict__ h1, const float* __restrict__ pooled,
                                                       const float* __restrict__ w1, const float* __restrict__ w2, float* dw1, float* db1,
                                                       float* dw2, float* db2, float* __restrict__ dpooled, int B, int C, int R, int G,
-                                                      int CS) {
+                                                      int CS, float* sl_w1, float* sl_b1, float* sl_w2, float* sl_b2) {
   extern __shared__ float lds[];          // [G][C] dlogit2, [G][R] a1 = swish(h1), [G][R] dh1
   float* dl2 = lds;
   float* a1 = lds + (size_t)G * C;
@@ -463,25 +527,25 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ 
     const int cl = i / R, r = i - cl * R, c = cs0 + cl;
     float a = 0.f;
     for (int gi = 0; gi < ng; ++gi) a = fmaf(dl2[gi * C + c], a1[gi * R + r], a);
-    atomicAdd(&dw2[(size_t)c * R + r], a);
+    dw_out(dw2, sl_w2, (size_t)C * R, (int)blockIdx.x, (size_t)c * R + r, a);
   }
   for (int cl = tid; cl < ncs; cl += nt) {
     float a = 0.f;
     for (int gi = 0; gi < ng; ++gi) a += dl2[gi * C + cs0 + cl];
-    atomicAdd(&db2[cs0 + cl], a);
+    dw_out(db2, sl_b2, (size_t)C, (int)blockIdx.x, (size_t)(cs0 + cl), a);
   }
   __syncthreads();
   if (blockIdx.y == 0)
     for (int r = tid; r < R; r += nt) {
       float a = 0.f;
       for (int gi = 0; gi < ng; ++gi) a += dh1[gi * R + r];
-      atomicAdd(&db1[r], a);
+      dw_out(db1, sl_b1, (size_t)R, (int)blockIdx.x, (size_t)r, a);
     }
   for (int i = tid; i < R * ncs; i += nt) {           // dW1[r][c] += sum_g dh1[g][r] * pooled[g][c]
     const int r = i / ncs, c = cs0 + i - r * ncs;
     float a = 0.f;
     for (int gi = 0; gi < ng; ++gi) a = fmaf(dh1[gi * R + r], pooled[(size_t)(b0 + gi) * C + c], a);
-    atomicAdd(&dw1[(size_t)r * C + c], a);
+    dw_out(dw1, sl_w1, (size_t)R * C, (int)blockIdx.x, (size_t)r * C + c, a);
   }
   for (int i = tid; i < ng * ncs; i += nt) {
     const int gi = i / ncs, c = cs0 + i - gi * ncs;
@@ -496,7 +560,7 @@ template <typename T, int U, int MAXT>
 __global__ __launch_bounds__(MAXT) void se_act_bwd_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ sc,
                                   const float* __restrict__ sh, const float* __restrict__ mean, const float* __restrict__ rstd,
                                   const float* __restrict__ s, const float* __restrict__ dpooled, T* __restrict__ dz, float* S1,
-                                  float* S2, int B, int HW, int C) {
+                                  float* S2, int B, int HW, int C, int det) {
   extern __shared__ float lds[];
   const int CP = C / 8;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
@@ -545,7 +609,7 @@ __global__ __launch_bounds__(MAXT) void se_act_bwd_kernel(const T* __restrict__ 
     }
   }
   float* const dst[2] = {S1, S2};
-  flush_partials<2>(st, cq, C, lds, dst);
+  flush_partials<2>(st, cq, C, lds, dst, det, (int)blockIdx.x);
 }
 
 // out = a*pa + (b ? b : 0)*pb + pc   (BatchNorm output + optional skip, no activation)
@@ -644,76 +708,110 @@ int u8_to_nhwc8_t(const uint8_t* x, void* y, size_t npix, float mean, float std,
   return launch_status();
 }
 
+// stat_rows > 0 (forward / input gradient / the two statistics kernels below): DETERMINISTIC statistic rows as CxConv.stat_det --
+// row r at stat_sum[r * C + c], at most stat_rows rows, cx_last_stat_rows() tells how many; 0: fp32 atomics into [C] vectors.
+inline size_t det_smem(size_t base, int th, int ns, int det) {
+  const size_t need = (size_t)th * ns * 8 * sizeof(float);
+  return det && need > base ? need : base;
+}
+
 template <typename T>
 int dwconv_fwd_t(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
-                  int W, int C, int k, int stride, int pad, void* stream) {
+                 int W, int C, int k, int stride, int pad, int stat_rows, void* stream) {
   if (!x || !w || !y || C % 8 || C > 4096 || k < 1 || stride < 1 || (sc && !sh)) return CX_EINVAL;
+  if (stat_rows > 0 && (!stat_sum || !stat_sq)) return CX_EINVAL;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
   if (CP > 1024) return CX_ESHAPE;
   if constexpr (std::is_same<T, bf16>::value) {      // the tiled fast paths are bf16 kernels
     bool handled = false;
     const int rc = cx_try_dw_tile(0, x, w, sc, sh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, y, nullptr, stat_sum,
-                                  stat_sq, nullptr, 0, B, H, W, C, k, stride, pad, as_stream(stream), &handled);
+                                  stat_sq, nullptr, 0, B, H, W, C, k, stride, pad, stat_rows, nullptr, 0, as_stream(stream), &handled);
     if (handled) return rc;
   }
   const size_t npix = (size_t)B * Ho * Wo;
-  hipLaunchKernelGGL(dwconv_fwd_kernel<T>, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
-                     (const T*)x, w, sc, sh, (T*)y, stat_sum, stat_sq, B, H, W, C, Ho, Wo, k, stride, pad);
+  int grid = grid_for(npix, th / CP, 4096);
+  const int det = stat_rows > 0 ? 1 : 0;
+  if (det) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  const size_t smem = det_smem(2 * C * sizeof(float), th, 2, det);
+  if (smem > 64 * 1024) return CX_ESHAPE;
+  hipLaunchKernelGGL(dwconv_fwd_kernel<T>, dim3(grid), dim3(th), smem, as_stream(stream),
+                     (const T*)x, w, sc, sh, (T*)y, stat_sum, stat_sq, B, H, W, C, Ho, Wo, k, stride, pad, det);
   return launch_status();
 }
 
 template <typename T>
 int dwconv_dgrad_t(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
-                    const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
-                    int W, int C, int k, int stride, int pad, int accumulate, void* stream) {
+                   const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
+                   int W, int C, int k, int stride, int pad, int accumulate, int stat_rows, void* stream) {
   if (!g || !g2 || !ga || !gb || !gc || !w || !x || !dz || C % 8 || C / 8 > 1024) return CX_EINVAL;
   if (sc && (!sh || !mean || !rstd || !S1 || !S2)) return CX_EINVAL;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
+  const int det = (stat_rows > 0 && S1) ? 1 : 0;
   if constexpr (std::is_same<T, bf16>::value) {      // the tiled fast paths are bf16 kernels
     bool handled = false;
     const int rc = cx_try_dw_tile(1, x, w, sc, sh, mean, rstd, g, g2, ga, gb, gc, nullptr, dz, S1, S2, nullptr, accumulate, B, H, W, C, k,
-                                  stride, pad, as_stream(stream), &handled);
+                                  stride, pad, det ? stat_rows : 0, nullptr, 0, as_stream(stream), &handled);
     if (handled) return rc;
   }
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(dwconv_dgrad_kernel<T>, dim3(grid_for(npix, th / CP, 4096)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
+  int grid = grid_for(npix, th / CP, 4096);
+  if (det) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  const size_t smem = det_smem(2 * C * sizeof(float), th, 2, det);
+  if (smem > 64 * 1024) return CX_ESHAPE;
+  hipLaunchKernelGGL(dwconv_dgrad_kernel<T>, dim3(grid), dim3(th), smem, as_stream(stream),
                      (const T*)g, (const T*)g2, ga, gb, gc, w, (const T*)x, sc, sh, mean, rstd, (T*)dz, S1, S2, B, H, W, C, Ho,
-                     Wo, k, stride, pad, accumulate);
+                     Wo, k, stride, pad, accumulate, det);
   return launch_status();
 }
 
+// scratch (optional): slab workspace of the CxWgrad.scratch protocol -- the partial dW of every workgroup is plain-stored and added
+// in workgroup order (immediately, or by the deferred table sum); null / too small: fp32 atomics
 template <typename T>
 int dwconv_wgrad_t(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
-                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream) {
+                   const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, float* scratch,
+                   int64_t scratch_floats, void* stream) {
   if (!g || !g2 || !ga || !gb || !gc || !x || !dw || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int CP = C / 8, th = threads_for(CP);
   if constexpr (std::is_same<T, bf16>::value) {      // the tiled fast paths are bf16 kernels
     bool handled = false;
     const int rc = cx_try_dw_tile(2, x, nullptr, sc, sh, nullptr, nullptr, g, g2, ga, gb, gc, nullptr, nullptr, nullptr, nullptr, dw, 0, B,
-                                  H, W, C, k, stride, pad, as_stream(stream), &handled);
+                                  H, W, C, k, stride, pad, 0, scratch, scratch_floats, as_stream(stream), &handled);
     if (handled) return rc;
   }
   const size_t npix = (size_t)B * Ho * Wo;
-  hipLaunchKernelGGL(dwconv_wgrad_kernel<T>, dim3(grid_for(npix, th / CP, 256), k * k), dim3(th), C * sizeof(float), as_stream(stream),
-                     (const T*)g, (const T*)g2, ga, gb, gc, (const T*)x, sc, sh, dw, B, H, W, C, Ho, Wo, k, stride, pad);
-  return launch_status();
+  const int gx = grid_for(npix, th / CP, 256);
+  const long long total = (long long)C * k * k;
+  float* slab = dw_slab(scratch, scratch_floats, gx, total);
+  const size_t smem = det_smem(C * sizeof(float), th, 1, slab != nullptr);
+  hipLaunchKernelGGL(dwconv_wgrad_kernel<T>, dim3(gx, k * k), dim3(th), smem, as_stream(stream),
+                     (const T*)g, (const T*)g2, ga, gb, gc, (const T*)x, sc, sh, dw, B, H, W, C, Ho, Wo, k, stride, pad, slab);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(dw, slab, (size_t)total, gx, as_stream(stream)) : 0;
 }
 
+// scratch (cx_gap_affine_act / cx_se_bwd_reduce): splits * B * C floats make the per-(image, channel) sums reproducible -- every pixel
+// split plain-stores its partial into its own row, a second launch adds the rows in order; NULL / too small: fp32 atomics
 template <typename T>
-int gap_affine_act_t(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream) {
+int gap_affine_act_t(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, float* scratch,
+                     int64_t scratch_floats, void* stream) {
   if (!x || !sc || !sh || !pooled || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int CP = C / 8, th = threads_for(CP);
   int splits = 1024 / B;
   if (splits < 1) splits = 1;
   if (splits > HW / 16 + 1) splits = HW / 16 + 1;
-  hipError_t e = hipMemsetAsync(pooled, 0, (size_t)B * C * sizeof(float), as_stream(stream));
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gap_affine_act_kernel<T>, dim3(splits, B), dim3(th), C * sizeof(float), as_stream(stream), (const T*)x, sc, sh, pooled, HW, C, act,
-                     splits);
-  return launch_status();
+  float* rows = (scratch && (int64_t)splits * B * C <= scratch_floats) ? scratch : nullptr;
+  if (!rows) {
+    hipError_t e = hipMemsetAsync(pooled, 0, (size_t)B * C * sizeof(float), as_stream(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  const size_t smem = det_smem(C * sizeof(float), th, 1, rows != nullptr);
+  hipLaunchKernelGGL(gap_affine_act_kernel<T>, dim3(splits, B), dim3(th), smem, as_stream(stream), (const T*)x, sc, sh, pooled, HW, C, act,
+                     splits, rows);
+  if (const int e = launch_status()) return e;
+  return rows ? cx_rows_reduce(pooled, rows, splits, B * C, B * C, 0, stream) : 0;
 }
 
 template <typename T>
@@ -727,40 +825,59 @@ int scale_act_bc_t(const void* x, const float* sc, const float* sh, const float*
 
 template <typename T>
 int bn_lin_bwd_stats_t(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
-                        void* stream) {
+                       int stat_rows, void* stream) {
   if (!g || !y || !mean || !rstd || !S1 || !S2 || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int CP = C / 8, th = threads_for(CP);
-  hipLaunchKernelGGL(bn_lin_bwd_stats_kernel<T>, dim3(grid_for(rows, 8 * (th / CP), 1024)), dim3(th), 2 * C * sizeof(float), as_stream(stream),
-                     (const T*)g, (const T*)y, mean, rstd, S1, S2, rows, C);
+  int grid = grid_for(rows, 8 * (th / CP), 1024);
+  const int det = stat_rows > 0 ? 1 : 0;
+  if (det) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+  const size_t smem = det_smem(2 * C * sizeof(float), th, 2, det);
+  if (smem > 64 * 1024) return CX_ESHAPE;
+  hipLaunchKernelGGL(bn_lin_bwd_stats_kernel<T>, dim3(grid), dim3(th), smem, as_stream(stream),
+                     (const T*)g, (const T*)y, mean, rstd, S1, S2, rows, C, det);
   return launch_status();
 }
 
 template <typename T>
-int se_bwd_reduce_t(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream) {
+int se_bwd_reduce_t(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, float* scratch,
+                    int64_t scratch_floats, void* stream) {
   if (!du || !x || !sc || !sh || !ds || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int CP = C / 8, th = threads_for(CP);
   int splits = 1024 / B;
   if (splits < 1) splits = 1;
   if (splits > HW / 16 + 1) splits = HW / 16 + 1;
-  hipError_t e = hipMemsetAsync(ds, 0, (size_t)B * C * sizeof(float), as_stream(stream));
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(se_bwd_reduce_kernel<T>, dim3(splits, B), dim3(th), C * sizeof(float), as_stream(stream), (const T*)du, (const T*)x, sc, sh, ds, HW,
-                     C, splits);
-  return launch_status();
+  float* rows = (scratch && (int64_t)splits * B * C <= scratch_floats) ? scratch : nullptr;
+  if (!rows) {
+    hipError_t e = hipMemsetAsync(ds, 0, (size_t)B * C * sizeof(float), as_stream(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  const size_t smem = det_smem(C * sizeof(float), th, 1, rows != nullptr);
+  hipLaunchKernelGGL(se_bwd_reduce_kernel<T>, dim3(splits, B), dim3(th), smem, as_stream(stream), (const T*)du, (const T*)x, sc, sh, ds,
+                     HW, C, splits, rows);
+  if (const int e = launch_status()) return e;
+  return rows ? cx_rows_reduce(ds, rows, splits, B * C, B * C, 0, stream) : 0;
 }
 
 template <typename T>
 int se_act_bwd_t(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
-                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream) {
+                 const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, int stat_rows, void* stream) {
   if (!x || !sc || !sh || !mean || !rstd || !dz || !S1 || !S2 || (!du && !dpooled) || C % 8 || C / 8 > 1024) return CX_EINVAL;
   const int CP = C / 8, th = threads_for(CP);
   if ((size_t)B * HW >= (1u << 31)) return CX_ESHAPE;
-  if (th <= 512)
-    hipLaunchKernelGGL((se_act_bwd_kernel<T, 4, 512>), dim3(grid_for((size_t)B * HW, 8 * (th / CP), 1024)), dim3(th), 2 * C * sizeof(float),
-                       as_stream(stream), (const T*)du, (const T*)x, sc, sh, mean, rstd, s, dpooled, (T*)dz, S1, S2, B, HW, C);
-  else
-    hipLaunchKernelGGL((se_act_bwd_kernel<T, 1, 1024>), dim3(grid_for((size_t)B * HW, th / CP, 2048)), dim3(th), 2 * C * sizeof(float),
-                       as_stream(stream), (const T*)du, (const T*)x, sc, sh, mean, rstd, s, dpooled, (T*)dz, S1, S2, B, HW, C);
+  const int det = stat_rows > 0 ? 1 : 0;
+  const size_t smem = det_smem(2 * C * sizeof(float), th, 2, det);
+  if (smem > 64 * 1024) return CX_ESHAPE;
+  if (th <= 512) {
+    int grid = grid_for((size_t)B * HW, 8 * (th / CP), 1024);
+    if (det) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+    hipLaunchKernelGGL((se_act_bwd_kernel<T, 4, 512>), dim3(grid), dim3(th), smem,
+                       as_stream(stream), (const T*)du, (const T*)x, sc, sh, mean, rstd, s, dpooled, (T*)dz, S1, S2, B, HW, C, det);
+  } else {
+    int grid = grid_for((size_t)B * HW, th / CP, 2048);
+    if (det) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
+    hipLaunchKernelGGL((se_act_bwd_kernel<T, 1, 1024>), dim3(grid), dim3(th), smem,
+                       as_stream(stream), (const T*)du, (const T*)x, sc, sh, mean, rstd, s, dpooled, (T*)dz, S1, S2, B, HW, C, det);
+  }
   return launch_status();
 }
 
@@ -800,39 +917,43 @@ int cx_u8_to_nhwc8_f32(const uint8_t* x, void* y, size_t npix, float mean, float
 }
 
 int cx_dwconv_fwd(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
-                  int W, int C, int k, int stride, int pad, void* stream) {
-  return dwconv_fwd_t<bf16>(x, w, sc, sh, y, stat_sum, stat_sq, B, H, W, C, k, stride, pad, stream);
+                  int W, int C, int k, int stride, int pad, int stat_rows, void* stream) {
+  return dwconv_fwd_t<bf16>(x, w, sc, sh, y, stat_sum, stat_sq, B, H, W, C, k, stride, pad, stat_rows, stream);
 }
 int cx_dwconv_fwd_f32(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
-                  int W, int C, int k, int stride, int pad, void* stream) {
-  return dwconv_fwd_t<float>(x, w, sc, sh, y, stat_sum, stat_sq, B, H, W, C, k, stride, pad, stream);
+                  int W, int C, int k, int stride, int pad, int stat_rows, void* stream) {
+  return dwconv_fwd_t<float>(x, w, sc, sh, y, stat_sum, stat_sq, B, H, W, C, k, stride, pad, stat_rows, stream);
 }
 
 int cx_dwconv_dgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
                     const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
-                    int W, int C, int k, int stride, int pad, int accumulate, void* stream) {
-  return dwconv_dgrad_t<bf16>(g, g2, ga, gb, gc, w, x, sc, sh, mean, rstd, dz, S1, S2, B, H, W, C, k, stride, pad, accumulate, stream);
+                    int W, int C, int k, int stride, int pad, int accumulate, int stat_rows, void* stream) {
+  return dwconv_dgrad_t<bf16>(g, g2, ga, gb, gc, w, x, sc, sh, mean, rstd, dz, S1, S2, B, H, W, C, k, stride, pad, accumulate, stat_rows, stream);
 }
 int cx_dwconv_dgrad_f32(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
                     const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
-                    int W, int C, int k, int stride, int pad, int accumulate, void* stream) {
-  return dwconv_dgrad_t<float>(g, g2, ga, gb, gc, w, x, sc, sh, mean, rstd, dz, S1, S2, B, H, W, C, k, stride, pad, accumulate, stream);
+                    int W, int C, int k, int stride, int pad, int accumulate, int stat_rows, void* stream) {
+  return dwconv_dgrad_t<float>(g, g2, ga, gb, gc, w, x, sc, sh, mean, rstd, dz, S1, S2, B, H, W, C, k, stride, pad, accumulate, stat_rows, stream);
 }
 
 int cx_dwconv_wgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
-                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream) {
-  return dwconv_wgrad_t<bf16>(g, g2, ga, gb, gc, x, sc, sh, dw, B, H, W, C, k, stride, pad, stream);
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, float* scratch,
+                    int64_t scratch_floats, void* stream) {
+  return dwconv_wgrad_t<bf16>(g, g2, ga, gb, gc, x, sc, sh, dw, B, H, W, C, k, stride, pad, scratch, scratch_floats, stream);
 }
 int cx_dwconv_wgrad_f32(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
-                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream) {
-  return dwconv_wgrad_t<float>(g, g2, ga, gb, gc, x, sc, sh, dw, B, H, W, C, k, stride, pad, stream);
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, float* scratch,
+                    int64_t scratch_floats, void* stream) {
+  return dwconv_wgrad_t<float>(g, g2, ga, gb, gc, x, sc, sh, dw, B, H, W, C, k, stride, pad, scratch, scratch_floats, stream);
 }
 
-int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream) {
-  return gap_affine_act_t<bf16>(x, sc, sh, pooled, B, HW, C, act, stream);
+int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, float* scratch,
+                      int64_t scratch_floats, void* stream) {
+  return gap_affine_act_t<bf16>(x, sc, sh, pooled, B, HW, C, act, scratch, scratch_floats, stream);
 }
-int cx_gap_affine_act_f32(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream) {
-  return gap_affine_act_t<float>(x, sc, sh, pooled, B, HW, C, act, stream);
+int cx_gap_affine_act_f32(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, float* scratch,
+                      int64_t scratch_floats, void* stream) {
+  return gap_affine_act_t<float>(x, sc, sh, pooled, B, HW, C, act, scratch, scratch_floats, stream);
 }
 
 int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
@@ -850,23 +971,26 @@ int cx_scale_act_bc_f32(const void* x, const float* sc, const float* sh, const f
 }
 
 int cx_bn_lin_bwd_stats(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
-                        void* stream) {
-  return bn_lin_bwd_stats_t<bf16>(g, y, mean, rstd, S1, S2, rows, C, stream);
+                        int stat_rows, void* stream) {
+  return bn_lin_bwd_stats_t<bf16>(g, y, mean, rstd, S1, S2, rows, C, stat_rows, stream);
 }
 int cx_bn_lin_bwd_stats_f32(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
-                        void* stream) {
-  return bn_lin_bwd_stats_t<float>(g, y, mean, rstd, S1, S2, rows, C, stream);
+                        int stat_rows, void* stream) {
+  return bn_lin_bwd_stats_t<float>(g, y, mean, rstd, S1, S2, rows, C, stat_rows, stream);
 }
 
-int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream) {
-  return se_bwd_reduce_t<bf16>(du, x, sc, sh, ds, B, HW, C, stream);
+int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, float* scratch,
+                     int64_t scratch_floats, void* stream) {
+  return se_bwd_reduce_t<bf16>(du, x, sc, sh, ds, B, HW, C, scratch, scratch_floats, stream);
 }
-int cx_se_bwd_reduce_f32(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream) {
-  return se_bwd_reduce_t<float>(du, x, sc, sh, ds, B, HW, C, stream);
+int cx_se_bwd_reduce_f32(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, float* scratch,
+                     int64_t scratch_floats, void* stream) {
+  return se_bwd_reduce_t<float>(du, x, sc, sh, ds, B, HW, C, scratch, scratch_floats, stream);
 }
 
 int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
-              float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, void* stream) {
+              float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, float* scratch, int64_t scratch_floats,
+              void* stream) {
   if (!ds || !s || !h1 || !pooled || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpooled || R <= 0) return CX_EINVAL;
   int G = (int)((120 * 1024) / ((size_t)(C + 2 * R) * sizeof(float)));      // images per workgroup: what 120 KB of LDS hold, at most 16
   if (G > 16) G = 16;
@@ -877,19 +1001,34 @@ int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* poo
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&se_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     attr = true;
   }
-  const int CS = 64;
-  hipLaunchKernelGGL(se_bwd_kernel, dim3((B + G - 1) / G, (C + CS - 1) / CS), dim3(1024), smem, as_stream(stream), ds, s, h1, pooled, w1, w2,
-                     dw1, db1, dw2, db2, dpooled, B, C, R, G, CS);
-  return launch_status();
+  const int CS = 64, groups = (B + G - 1) / G;
+  // slab workspace (CxWgrad.scratch protocol): one slab per image group for each of dW1 (R x C), db1 (R), dW2 (C x R), db2 (C)
+  const long long per = 2ll * C * R + C + R;
+  float* slab = dw_slab(scratch, scratch_floats, groups, per);
+  float *s1 = nullptr, *sb1 = nullptr, *s2 = nullptr, *sb2 = nullptr;
+  if (slab) {
+    s1 = slab; sb1 = s1 + (size_t)groups * R * C; s2 = sb1 + (size_t)groups * R; sb2 = s2 + (size_t)groups * C * R;
+  }
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(se_bwd_kernel, dim3(groups, (C + CS - 1) / CS), dim3(1024), smem, st, ds, s, h1, pooled, w1, w2,
+                     dw1, db1, dw2, db2, dpooled, B, C, R, G, CS, s1, sb1, s2, sb2);
+  if (const int e = launch_status()) return e;
+  if (slab) {
+    if (const int e = cx_dw_reduce(dw1, s1, (size_t)R * C, groups, st)) return e;
+    if (const int e = cx_dw_reduce(db1, sb1, (size_t)R, groups, st)) return e;
+    if (const int e = cx_dw_reduce(dw2, s2, (size_t)C * R, groups, st)) return e;
+    return cx_dw_reduce(db2, sb2, (size_t)C, groups, st);
+  }
+  return 0;
 }
 
 int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
-                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream) {
-  return se_act_bwd_t<bf16>(du, x, sc, sh, mean, rstd, s, dpooled, dz, S1, S2, B, HW, C, stream);
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, int stat_rows, void* stream) {
+  return se_act_bwd_t<bf16>(du, x, sc, sh, mean, rstd, s, dpooled, dz, S1, S2, B, HW, C, stat_rows, stream);
 }
 int cx_se_act_bwd_f32(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
-                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream) {
-  return se_act_bwd_t<float>(du, x, sc, sh, mean, rstd, s, dpooled, dz, S1, S2, B, HW, C, stream);
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, int stat_rows, void* stream) {
+  return se_act_bwd_t<float>(du, x, sc, sh, mean, rstd, s, dpooled, dz, S1, S2, B, HW, C, stat_rows, stream);
 }
 
 int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,

@@ -554,6 +554,7 @@ int launch3(const CxWgrad& p, hipStream_t st) {
   }
   const size_t nk = (size_t)p.N * p.K;
   float* slab = p.scratch;                               // (the dispatcher checked its size)
+  CX_KTAG("wgrad3_kernel<%d, %d>", GPRO, XPRO);
   hipLaunchKernelGGL((wgrad3_kernel<GPRO, XPRO>), dim3(c_tiles * n_tiles * 3 * splits), dim3(512), smem, st, p, g, c_tiles, n_tiles, total_steps,
                      sps, slab);
   if (const int e = launch_status()) return e;
@@ -594,6 +595,7 @@ int launch(const CxWgrad& p, hipStream_t st, int wgs_target) {
   if (nostore) q.splits = -7;
   const size_t total = (size_t)p.N * p.K;
   float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)total);
+  CX_KTAG("wgrad_mm_kernel<%d, %d, %d, %d>", WA, WB, GPRO, XPRO);
   hipLaunchKernelGGL((wgrad_mm_kernel<WA, WB, GPRO, XPRO>), dim3(c_tiles * n_tiles * splits), dim3(G::NT), smem, st, q, c_tiles, n_tiles,
                      total_steps, sps, slab);
   if (const int e = launch_status()) return e;

@@ -121,6 +121,10 @@ class _Engine:
         # activation storage type: bf16, or fp32 = north_star's "1e-3 fp32" parity mode (generic f32-MFMA convolutions, the
         # storage-typed depthwise / squeeze-excite / Swish kernels of csrc/effnet.hip; no tiled fast paths)
         self.dtype = getattr(model, "_storage_dtype", torch.bfloat16)
+        # deterministic statistics and weight gradients (statistic rows summed in row order, slab sums, one owner per squeeze-excite
+        # sum): two steps on the same batch give the same bits; CHEXPERT_DET=0 keeps the fp32 atomics
+        import os
+        self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
         self.flat = None
         self.device = None
         self.pool = {}
@@ -242,6 +246,7 @@ class _Engine:
         ws.pooled = e(B, 1280, dtype=f32)
         ws.logits = e(B, self.n_classes, dtype=f32)
         ws.vec = torch.zeros(self.vec_size, dtype=f32, device=dev)
+        ws.slab = torch.empty(2, self.SLAB, dtype=f32, device=dev) if self.det else None
         o, n = self.ones
         ws.vec[o:o + n].fill_(1.0)
         ws.bwd = None
@@ -257,11 +262,18 @@ class _Engine:
         off, m = slot
         return ws.vec[off:off + (m if n is None else n)]
 
-    def _bn_coef(self, ws, bn, count, train):
+    SLAB = 1 << 22               # floats per half of the statistic-row scratch
+    ROWS = 2048                  # most statistic rows an element-wise / depthwise producer writes
+
+    def _rows_cap(self, C):
+        return min(self.ROWS, self.SLAB // C)
+
+    def _bn_coef(self, ws, bn, count, train, rows=None):
         S, v = self.bn[id(bn)], self._v
         if train:
-            ops.bn_coef(v(ws, S.sum), v(ws, S.sq), count, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                        v(ws, S.sc), v(ws, S.sh), v(ws, S.mean), v(ws, S.rstd), S.C)
+            ssum, ssq, reps, rstride = (ws.slab[0], ws.slab[1], rows, S.C) if self.det else (v(ws, S.sum), v(ws, S.sq), 1, 0)
+            ops.bn_coef(ssum, ssq, count, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                        v(ws, S.sc), v(ws, S.sh), v(ws, S.mean), v(ws, S.rstd), S.C, replicas=reps, rstride=rstride)
         else:
             ops.bn_coef_eval(bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, v(ws, S.sc), v(ws, S.sh), v(ws, S.mean),
                              v(ws, S.rstd), S.C)
@@ -289,20 +301,28 @@ class _Engine:
         self.last_masks = {}
         self.n_forward = getattr(self, "n_forward", 0) + 1
         ws.step = self.n_forward
-        z0, zn = self.fwd_zero
-        ws.vec[z0:z0 + zn].zero_()
+        det = self.det and train
+        if train and not det:
+            z0, zn = self.fwd_zero
+            ws.vec[z0:z0 + zn].zero_()
         st = (lambda s: v(ws, s)) if train else (lambda s: None)
+        # statistics arguments of a convolution feeding BatchNorm S_, of a depthwise producer (sum, sq, stat_rows)
+        csp = (lambda S_: dict(stat_sum=ws.slab[0], stat_sq=ws.slab[1], stat_det=True, stat_replicas=self.SLAB // S_.C, stat_rstride=S_.C)) \
+            if det else (lambda S_: dict(stat_sum=st(S_.sum), stat_sq=st(S_.sq)))
+        dsp = (lambda S_: (ptr(ws.slab[0]), ptr(ws.slab[1]), self._rows_cap(S_.C))) if det else \
+            (lambda S_: (ptr(st(S_.sum)), ptr(st(S_.sq)), 0))
         sp = stream_ptr()
+        # row scratch of the per-(image, channel) sums (free between a coefficient launch and the next statistics producer)
+        rsc = (ptr(ws.slab[0]), self.SLAB) if self.det else (None, 0)
         S0 = self.bn[id(m.stem[1])]
         if u8:
             check(lb.cx_u8_to_nhwc8(ptr(x.contiguous()), ptr(ws.x8), B * H * W, 0.5330, 0.0349, sp), "cx_u8_to_nhwc8")
         else:
             check(lb.cx_nchw3_to_nhwc8(ptr(x.contiguous().float()), ptr(ws.x8), B, H, W, sp), "cx_nchw3_to_nhwc8")
         c0 = m.stem[0].out_channels
-        ops.conv_gemm(ws.x8, self.packed[self.stem_off:], ws.ys, N=c0, kh=3, kw=3, stride=2, pad=ws.stem_pad, stat_sum=st(S0.sum),
-                      stat_sq=st(S0.sq))
+        rows = ops.conv_gemm(ws.x8, self.packed[self.stem_off:], ws.ys, N=c0, kh=3, kw=3, stride=2, pad=ws.stem_pad, **csp(S0))
         hs, wsz = ws.ys.shape[1:3]
-        self._bn_coef(ws, m.stem[1], B * hs * wsz, train)
+        self._bn_coef(ws, m.stem[1], B * hs * wsz, train, rows)
         check(lb.cx_scale_act_bc(ptr(ws.ys), ptr(v(ws, S0.sc)), ptr(v(ws, S0.sh)), None, ptr(ws.x0), B, hs * wsz, c0, sp), "cx_scale_act_bc")
         xin = ws.x0
         for bi, b in enumerate(self.mb):
@@ -312,22 +332,23 @@ class _Engine:
             Sd, Sp = self.bn[id(bn_d)], self.bn[id(bn_p)]
             if conv_e is not None:
                 Se = self.bn[id(bn_e)]
-                ops.conv_gemm(xin, self.w_fwd(conv_e), t["ye"], N=c["ce"], stat_sum=st(Se.sum), stat_sq=st(Se.sq))
-                self._bn_coef(ws, bn_e, B * hi * wi, train)
+                rows = ops.conv_gemm(xin, self.w_fwd(conv_e), t["ye"], N=c["ce"], **csp(Se))
+                self._bn_coef(ws, bn_e, B * hi * wi, train, rows)
                 xdw, sc, sh = t["ye"], v(ws, Se.sc), v(ws, Se.sh)
             else:
                 xdw, sc, sh = xin, None, None
-            check(lb.cx_dwconv_fwd(ptr(xdw), ptr(dw.weight), ptr(sc), ptr(sh), ptr(t["yd"]), ptr(st(Sd.sum)), ptr(st(Sd.sq)), B, hi, wi,
-                                   c["ce"], c["k"], c["stride"], t["pad"], sp), "cx_dwconv_fwd")
-            self._bn_coef(ws, bn_d, B * ho * wo, train)
-            check(lb.cx_gap_affine_act(ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(t["pooled"]), B, ho * wo, c["ce"], 2, sp),
-                  "cx_gap_affine_act")
+            d1, d2, dcap = dsp(Sd)
+            check(lb.cx_dwconv_fwd(ptr(xdw), ptr(dw.weight), ptr(sc), ptr(sh), ptr(t["yd"]), d1, d2, B, hi, wi,
+                                   c["ce"], c["k"], c["stride"], t["pad"], dcap, sp), "cx_dwconv_fwd")
+            self._bn_coef(ws, bn_d, B * ho * wo, train, lib().cx_last_stat_rows() if det else None)
+            check(lb.cx_gap_affine_act(ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(t["pooled"]), B, ho * wo, c["ce"], 2,
+                                       *rsc, sp), "cx_gap_affine_act")
             check(lb.cx_se_fwd(ptr(t["pooled"]), ptr(se[1].weight), ptr(se[1].bias), ptr(se[3].weight), ptr(se[3].bias), ptr(t["h1"]),
                                ptr(t["s"]), B, c["ce"], t["R"], sp), "cx_se_fwd")
             check(lb.cx_scale_act_bc(ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(t["s"]), ptr(t["u"]), B, ho * wo, c["ce"], sp),
                   "cx_scale_act_bc")
-            ops.conv_gemm(t["u"], self.w_fwd(conv_p), t["yp"], N=c["cout"], stat_sum=st(Sp.sum), stat_sq=st(Sp.sq))
-            self._bn_coef(ws, bn_p, B * ho * wo, train)
+            rows = ops.conv_gemm(t["u"], self.w_fwd(conv_p), t["yp"], N=c["cout"], **csp(Sp))
+            self._bn_coef(ws, bn_p, B * ho * wo, train, rows)
             # DropConnect (efficientnet.py:44-51, :100-101): train mode only, on blocks with a skip; the per-image mask / keep
             # probability is drawn by cx_dropout_mask from the model's step counter (reproducible, independent of torch's RNG)
             p_dc = list(b)[-1].p if (train and c["skip"] and isinstance(list(b)[-1], DropMarker)) else 0.0
@@ -341,9 +362,9 @@ class _Engine:
             xin = t["out"]
         Sh = self.bn[id(m.head[1])]
         hl, wl = ws.hw_last
-        ops.conv_gemm(xin, self.w_fwd(m.head[0]), ws.yh, N=1280, stat_sum=st(Sh.sum), stat_sq=st(Sh.sq))
-        self._bn_coef(ws, m.head[1], B * hl * wl, train)
-        check(lb.cx_gap_affine_act(ptr(ws.yh), ptr(v(ws, Sh.sc)), ptr(v(ws, Sh.sh)), ptr(ws.pooled), B, hl * wl, 1280, 2, sp),
+        rows = ops.conv_gemm(xin, self.w_fwd(m.head[0]), ws.yh, N=1280, **csp(Sh))
+        self._bn_coef(ws, m.head[1], B * hl * wl, train, rows)
+        check(lb.cx_gap_affine_act(ptr(ws.yh), ptr(v(ws, Sh.sc)), ptr(v(ws, Sh.sh)), ptr(ws.pooled), B, hl * wl, 1280, 2, *rsc, sp),
               "cx_gap_affine_act")
         # Dropout in front of the classifier (efficientnet.py:169-171), train mode only
         p_do = m.head[5].p if train else 0.0
@@ -388,14 +409,26 @@ class _Engine:
         ws.bwd = bw
 
     def backward(self, ws, dlogits):
-        ops.set_det_wgrad(False)               # (this engine's statistics still use atomics: no point in slab sums)
+        ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
+        deferred = self.det and self.reducer is None and ops.wgrad_defer_begin(self.device)
+        try:
+            self._backward(ws, dlogits)
+            if deferred:
+                ops.wgrad_defer_flush(self.device)
+        finally:
+            if deferred:
+                ops.wgrad_defer_abort(self.device)
+
+    def _backward(self, ws, dlogits):
         m, v, G, lb = self.model, self._v, self.G, (_LibF32(lib()) if self.dtype == torch.float32 else lib())
+        det = self.det
         B = ws.B
         sp = stream_ptr()
         self._alloc_bwd(ws)
         bw = ws.bwd
-        z0, zn = self.bwd_zero
-        ws.vec[z0:z0 + zn].zero_()
+        if not det:
+            z0, zn = self.bwd_zero
+            ws.vec[z0:z0 + zn].zero_()
         fresh = any(p.grad is None for p in self.params)
         if fresh:
             self.flat_grad.zero_()
@@ -407,8 +440,23 @@ class _Engine:
         done = (lambda p: red.ready(self.off_of[id(p)])) if red is not None else (lambda p: None)
 
         def bn_bwd(S, bn, count):
-            ops.bn_bwd_coef(v(ws, S.S1), v(ws, S.S2), count, bn.weight, v(ws, S.mean), v(ws, S.rstd), G(bn.weight), G(bn.bias), None, None,
-                            v(ws, S.pa), v(ws, S.pb), v(ws, S.pc), S.C)
+            """BatchNorm backward coefficients of `bn` from the sums its producer has just written (deterministic mode: the rows of
+            the scratch pair, counted by cx_last_stat_rows)."""
+            if det:
+                ops.bn_bwd_coef(ws.slab[0], ws.slab[1], count, bn.weight, v(ws, S.mean), v(ws, S.rstd), G(bn.weight), G(bn.bias), None, None,
+                                v(ws, S.pa), v(ws, S.pb), v(ws, S.pc), S.C, replicas=lib().cx_last_stat_rows(), rstride=S.C)
+            else:
+                ops.bn_bwd_coef(v(ws, S.S1), v(ws, S.S2), count, bn.weight, v(ws, S.mean), v(ws, S.rstd), G(bn.weight), G(bn.bias), None, None,
+                                v(ws, S.pa), v(ws, S.pb), v(ws, S.pc), S.C)
+
+        def ssp(S):      # (S1, S2, stat_rows) of an element-wise / depthwise producer of S's backward sums
+            return (ptr(ws.slab[0]), ptr(ws.slab[1]), self._rows_cap(S.C)) if det else (ptr(v(ws, S.S1)), ptr(v(ws, S.S2)), 0)
+
+        def dw_wgrad(*args):
+            """cx_dwconv_wgrad with the slab workspace of ops (deferred sums when backward defers them)."""
+            wsb, arena, dfr = ops._wgrad_ws(self.device)
+            check(lb.cx_dwconv_wgrad(*args, ptr(wsb), 0 if wsb is None else wsb.numel(), sp), "cx_dwconv_wgrad")
+            ops._wgrad_used(arena, dfr)
         # ---- head
         fc, Sh = m.head[6], self.bn[id(m.head[1])]
         hl, wl = ws.hw_last
@@ -418,7 +466,7 @@ class _Engine:
             check(lb.cx_mul_f32(ptr(dpool), ptr(ws.drop), ptr(dpool), B * 1280, sp), "cx_mul_f32")
         dzh = bw["dze"][:ws.yh.numel()].view(ws.yh.shape)
         check(lb.cx_se_act_bwd(None, ptr(ws.yh), ptr(v(ws, Sh.sc)), ptr(v(ws, Sh.sh)), ptr(v(ws, Sh.mean)), ptr(v(ws, Sh.rstd)), None,
-                               ptr(dpool), ptr(dzh), ptr(v(ws, Sh.S1)), ptr(v(ws, Sh.S2)), B, hl * wl, 1280, sp), "cx_se_act_bwd")
+                               ptr(dpool), ptr(dzh), *ssp(Sh)[:2], B, hl * wl, 1280, ssp(Sh)[2], sp), "cx_se_act_bwd")
         bn_bwd(Sh, m.head[1], B * hl * wl)
         g = bw["g"][-1]
         xlast = ws.blk[-1]["out"]
@@ -443,8 +491,8 @@ class _Engine:
                 gb = bw["gdc"][:g.numel()].view(g.shape)
                 check(lb.cx_scale_rows(ptr(g), ptr(t["dc"]), ho * wo, ptr(gb), rows_o, c["cout"], sp), "cx_scale_rows")
                 g = gb
-            check(lb.cx_bn_lin_bwd_stats(ptr(g), ptr(t["yp"]), ptr(v(ws, Sp.mean)), ptr(v(ws, Sp.rstd)), ptr(v(ws, Sp.S1)), ptr(v(ws, Sp.S2)),
-                                         rows_o, c["cout"], sp), "cx_bn_lin_bwd_stats")
+            check(lb.cx_bn_lin_bwd_stats(ptr(g), ptr(t["yp"]), ptr(v(ws, Sp.mean)), ptr(v(ws, Sp.rstd)), *ssp(Sp)[:2],
+                                         rows_o, c["cout"], ssp(Sp)[2], sp), "cx_bn_lin_bwd_stats")
             bn_bwd(Sp, bn_p, rows_o)
             du = bw["du"][:rows_o * ce].view(B, ho, wo, ce)
             dzd = bw["dzd"][:rows_o * ce].view(B, ho, wo, ce)
@@ -454,33 +502,34 @@ class _Engine:
                            gc=v(ws, Sp.pc))
             ds = torch.empty(B, ce, dtype=torch.float32, device=self.device)
             dpl = torch.empty(B, ce, dtype=torch.float32, device=self.device)
-            check(lb.cx_se_bwd_reduce(ptr(du), ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(ds), B, ho * wo, ce, sp),
-                  "cx_se_bwd_reduce")
+            check(lb.cx_se_bwd_reduce(ptr(du), ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(ds), B, ho * wo, ce,
+                                      *((ptr(ws.slab[0]), self.SLAB) if det else (None, 0)), sp), "cx_se_bwd_reduce")
+            wsb, arena, dfr = ops._wgrad_ws(self.device)
             check(lb.cx_se_bwd(ptr(ds), ptr(t["s"]), ptr(t["h1"]), ptr(t["pooled"]), ptr(se[1].weight), ptr(se[3].weight),
-                               ptr(G(se[1].weight)), ptr(G(se[1].bias)), ptr(G(se[3].weight)), ptr(G(se[3].bias)), ptr(dpl), B, ce, t["R"], sp),
-                  "cx_se_bwd")
+                               ptr(G(se[1].weight)), ptr(G(se[1].bias)), ptr(G(se[3].weight)), ptr(G(se[3].bias)), ptr(dpl), B, ce, t["R"],
+                               ptr(wsb), 0 if wsb is None else wsb.numel(), sp), "cx_se_bwd")
+            ops._wgrad_used(arena, dfr)
             check(lb.cx_se_act_bwd(ptr(du), ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(v(ws, Sd.mean)), ptr(v(ws, Sd.rstd)),
-                                   ptr(t["s"]), ptr(dpl), ptr(dzd), ptr(v(ws, Sd.S1)), ptr(v(ws, Sd.S2)), B, ho * wo, ce, sp), "cx_se_act_bwd")
+                                   ptr(t["s"]), ptr(dpl), ptr(dzd), *ssp(Sd)[:2], B, ho * wo, ce, ssp(Sd)[2], sp), "cx_se_act_bwd")
             bn_bwd(Sd, bn_d, rows_o)
             dargs = (ptr(dzd), ptr(t["yd"]), ptr(v(ws, Sd.pa)), ptr(v(ws, Sd.pb)), ptr(v(ws, Sd.pc)))
             if conv_e is not None:
                 Se = self.bn[id(bn_e)]
                 dze = bw["dze"][:B * hi * wi * ce].view(B, hi, wi, ce)
                 check(lb.cx_dwconv_dgrad(*dargs, ptr(dw.weight), ptr(t["ye"]), ptr(v(ws, Se.sc)), ptr(v(ws, Se.sh)), ptr(v(ws, Se.mean)),
-                                         ptr(v(ws, Se.rstd)), ptr(dze), ptr(v(ws, Se.S1)), ptr(v(ws, Se.S2)), B, hi, wi, ce, c["k"],
-                                         c["stride"], t["pad"], 0, sp), "cx_dwconv_dgrad")
-                check(lb.cx_dwconv_wgrad(*dargs, ptr(t["ye"]), ptr(v(ws, Se.sc)), ptr(v(ws, Se.sh)), ptr(G(dw.weight)), B, hi, wi, ce, c["k"],
-                                         c["stride"], t["pad"], sp), "cx_dwconv_wgrad")
-                bn_bwd(Se, bn_e, B * hi * wi)
+                                         ptr(v(ws, Se.rstd)), ptr(dze), *ssp(Se)[:2], B, hi, wi, ce, c["k"],
+                                         c["stride"], t["pad"], 0, ssp(Se)[2], sp), "cx_dwconv_dgrad")
+                bn_bwd(Se, bn_e, B * hi * wi)           # (before the next producer re-uses the statistic rows)
+                dw_wgrad(*dargs, ptr(t["ye"]), ptr(v(ws, Se.sc)), ptr(v(ws, Se.sh)), ptr(G(dw.weight)), B, hi, wi, ce, c["k"],
+                         c["stride"], t["pad"])
                 ops.conv_gemm(dze, self.w_bwd(conv_e), gin, N=c["cin"], prologue=ops.PRO_AFFINE2, x2=t["ye"], pa=v(ws, Se.pa),
                               pb=v(ws, Se.pb), pc=v(ws, Se.pc), accumulate=c["skip"])
                 ops.conv_wgrad(dze, xin, G(conv_e.weight), g_prologue=ops.PRO_AFFINE2, g2=t["ye"], ga=v(ws, Se.pa), gb=v(ws, Se.pb),
                                gc=v(ws, Se.pc))
             else:
                 check(lb.cx_dwconv_dgrad(*dargs, ptr(dw.weight), ptr(xin), None, None, None, None, ptr(gin), None, None, B, hi, wi, ce,
-                                         c["k"], c["stride"], t["pad"], int(c["skip"]), sp), "cx_dwconv_dgrad")
-                check(lb.cx_dwconv_wgrad(*dargs, ptr(xin), None, None, ptr(G(dw.weight)), B, hi, wi, ce, c["k"], c["stride"], t["pad"], sp),
-                      "cx_dwconv_wgrad")
+                                         c["k"], c["stride"], t["pad"], int(c["skip"]), 0, sp), "cx_dwconv_dgrad")
+                dw_wgrad(*dargs, ptr(xin), None, None, ptr(G(dw.weight)), B, hi, wi, ce, c["k"], c["stride"], t["pad"])
             done(list(b.parameters())[0])
         # ---- stem: x0 = swish(bn(ys))
         S0 = self.bn[id(m.stem[1])]
@@ -488,11 +537,12 @@ class _Engine:
         c0 = m.stem[0].out_channels
         dzs = bw["dze"][:ws.ys.numel()].view(ws.ys.shape)
         check(lb.cx_se_act_bwd(ptr(bw["g0"]), ptr(ws.ys), ptr(v(ws, S0.sc)), ptr(v(ws, S0.sh)), ptr(v(ws, S0.mean)), ptr(v(ws, S0.rstd)), None,
-                               None, ptr(dzs), ptr(v(ws, S0.S1)), ptr(v(ws, S0.S2)), B, hs * wsz, c0, sp), "cx_se_act_bwd")
+                               None, ptr(dzs), *ssp(S0)[:2], B, hs * wsz, c0, ssp(S0)[2], sp), "cx_se_act_bwd")
         bn_bwd(S0, m.stem[1], B * hs * wsz)
         dw8 = torch.zeros(c0, 8, 3, 3, dtype=torch.float32, device=self.device)
         ops.conv_wgrad(dzs, ws.x8, dw8, kh=3, kw=3, stride=2, pad=ws.stem_pad, g_prologue=ops.PRO_AFFINE2, g2=ws.ys, ga=v(ws, S0.pa),
                        gb=v(ws, S0.pb), gc=v(ws, S0.pc))
+        ops.wgrad_defer_flush(self.device)       # the stem gradient is read back right here: run the deferred slab sums now
         G(m.stem[0].weight).view(c0, 3, 3, 3).add_(dw8[:, :3])
         if red is not None:
             red.finish()

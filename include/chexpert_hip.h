@@ -130,6 +130,10 @@ int cx_dw_reduce_table(const CxReduceDesc* table_dev, int n, int64_t total_block
 
 int cx_abi_version(void);
 const char* cx_error_string(int code);
+/* name of the kernel instantiation the most recent cx_conv_gemm / cx_conv1x1_dgrad_wgrad* / cx_conv_wgrad call of this thread
+ * dispatched to, spelled as rocprofv3 lists it (e.g. "pw_bwd2_kernel<2, true, 0>"; a stride-2 input gradient that runs as up to
+ * four parity-class launches carries the suffix " x parity classes").  For measurement tools: valid until the next call.       */
+const char* cx_last_kernel(void);
 /* rows written by the most recent successful stat_det launch issued from the calling thread */
 int cx_last_stat_rows(void);
 
@@ -349,29 +353,40 @@ int cx_f32_to_bf16(const float* x, void* y, size_t n, void* stream);
 int cx_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, void* stream);
 /* uint8 grey image (npix pixels) -> whitened, channel-expanded (.., 8) bf16 for the EfficientNet stem (chexpert.py:70-72 on the GPU) */
 int cx_u8_to_nhwc8(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream);
+/* stat_rows (cx_dwconv_fwd / cx_dwconv_dgrad / cx_bn_lin_bwd_stats / cx_se_act_bwd): > 0 = DETERMINISTIC statistic rows with the
+ * CxConv.stat_det convention (row r at sum[r * C + c], at most stat_rows rows, cx_last_stat_rows() tells how many; the consumer
+ * cx_bn_coef / cx_bn_bwd_coef sums them in row order), 0 = fp32 atomics into [C] vectors the caller zeroed.
+ * cx_dwconv_wgrad: scratch / scratch_floats = the CxWgrad.scratch slab protocol (reproducible sums, deferrable), NULL = atomics.
+ * cx_gap_affine_act / cx_se_bwd_reduce: scratch of splits * B * C floats (splits <= 1024 / B) = every pixel split plain-stores its
+ * partial per-(image, channel) sum and a second launch adds the rows in order; cx_se_bwd: scratch = slab workspace, one slab per
+ * group of images for dW1 / db1 / dW2 / db2.  NULL: fp32 atomics.                                                             */
 int cx_dwconv_fwd(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
-                  int W, int C, int k, int stride, int pad, void* stream);
+                  int W, int C, int k, int stride, int pad, int stat_rows, void* stream);
 /* dY = g*ga + g2*gb + gc;  dz = (sum_t dY w) * swish'(x*sc+sh), S1 += dz, S2 += dz*(x-mean)*rstd (sc==NULL: dz = sum) */
 int cx_dwconv_dgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
                     const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
-                    int W, int C, int k, int stride, int pad, int accumulate, void* stream);
+                    int W, int C, int k, int stride, int pad, int accumulate, int stat_rows, void* stream);
 int cx_dwconv_wgrad(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
-                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream);
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, float* scratch,
+                    int64_t scratch_floats, void* stream);
 /* pooled[b][c] = mean_hw act(x*sc+sh) (act 0 none / 1 relu / 2 swish): SELayer pool (:69), head pool (:162)      */
-int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream);
+int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, float* scratch,
+                      int64_t scratch_floats, void* stream);
 /* SELayer FCs (:70-73): h1 = W1 pooled + b1, s = sigmoid(W2 swish(h1) + b2); and their backward                */
 int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
               int R, void* stream);
 int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
-              float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, void* stream);
+              float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, float* scratch, int64_t scratch_floats,
+              void* stream);
 /* u = swish(x*sc+sh) * s[b][c] (s NULL: no SE scaling)                                                          */
 int cx_scale_act_bc(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream);
-int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream);
+int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, float* scratch,
+                     int64_t scratch_floats, void* stream);
 /* dz = (du*s[b][c] + dpooled[b][c]/HW) * swish'(x*sc+sh) + BN backward sums (du or dpooled may be NULL)          */
 int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
-                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream);
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, int stat_rows, void* stream);
 int cx_bn_lin_bwd_stats(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
-                        void* stream);
+                        int stat_rows, void* stream);
 /* out = s*(a*pa + pc) + b*pb (b may be NULL): projection BatchNorm output, DropConnect, skip (:105-110).  sample_scale
  * (optional, one float per image, rows_per_sample rows each) is the DropConnect mask / keep probability (:44-51)     */
 int cx_affine2_out(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,
@@ -383,19 +398,22 @@ int cx_scale_rows(const void* g, const float* sample_scale, size_t rows_per_samp
 int cx_nchw3_to_nhwc8_f32(const float* x, void* y, int B, int H, int W, void* stream);
 int cx_u8_to_nhwc8_f32(const uint8_t* x, void* y, size_t npix, float mean, float std, void* stream);
 int cx_dwconv_fwd_f32(const void* x, const float* w, const float* sc, const float* sh, void* y, float* stat_sum, float* stat_sq, int B, int H,
-                  int W, int C, int k, int stride, int pad, void* stream);
+                  int W, int C, int k, int stride, int pad, int stat_rows, void* stream);
 int cx_dwconv_dgrad_f32(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const float* w, const void* x,
                     const float* sc, const float* sh, const float* mean, const float* rstd, void* dz, float* S1, float* S2, int B, int H,
-                    int W, int C, int k, int stride, int pad, int accumulate, void* stream);
+                    int W, int C, int k, int stride, int pad, int accumulate, int stat_rows, void* stream);
 int cx_dwconv_wgrad_f32(const void* g, const void* g2, const float* ga, const float* gb, const float* gc, const void* x, const float* sc,
-                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, void* stream);
-int cx_gap_affine_act_f32(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, void* stream);
+                    const float* sh, float* dw, int B, int H, int W, int C, int k, int stride, int pad, float* scratch,
+                    int64_t scratch_floats, void* stream);
+int cx_gap_affine_act_f32(const void* x, const float* sc, const float* sh, float* pooled, int B, int HW, int C, int act, float* scratch,
+                      int64_t scratch_floats, void* stream);
 int cx_scale_act_bc_f32(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream);
 int cx_bn_lin_bwd_stats_f32(const void* g, const void* y, const float* mean, const float* rstd, float* S1, float* S2, size_t rows, int C,
-                        void* stream);
-int cx_se_bwd_reduce_f32(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, void* stream);
+                        int stat_rows, void* stream);
+int cx_se_bwd_reduce_f32(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, float* scratch,
+                     int64_t scratch_floats, void* stream);
 int cx_se_act_bwd_f32(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,
-                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, void* stream);
+                  const float* dpooled, void* dz, float* S1, float* S2, int B, int HW, int C, int stat_rows, void* stream);
 int cx_affine2_out_f32(const void* a, const void* b, const float* pa, const float* pb, const float* pc, const float* sample_scale,
                    size_t rows_per_sample, void* out, size_t rows, int C, void* stream);
 int cx_scale_rows_f32(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream);

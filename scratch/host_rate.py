@@ -1,24 +1,41 @@
+"""Host-side enqueue cost of one eager training step (zero_grad + forward + loss + backward + fused optimiser) per model: the step at
+a batch so small that the GPU finishes long before the host does is pure Python / ctypes / launch time.  This is what every rank of a
+data-parallel run pays per step (collectives are issued from Python between the kernels, so N > 1 cannot replay one graph):
+    python scratch/host_rate.py            ->  one line per model (profiles/r03_host_enqueue.txt)"""
 import sys, time, torch
 sys.path.insert(0, '.')
-from chexpert_amd.models import densenet121
 from chexpert_amd import synth
+from chexpert_amd.models import DenseNet, Bottleneck, ResNet, construct_model, densenet121, resnet152
+from chexpert_amd.optim import FusedAdam
 dev = torch.device('cuda:0')
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-m = densenet121(num_classes=14).to(dev)
-x = torch.rand(B, 3, 320, 320, device=dev)
-t = (torch.rand(B, 14, device=dev) > 0.5).float()
-for _ in range(3):
-    m.zero_grad(); m.forward_backward(x, t)
-torch.cuda.synchronize()
-for bs in (B, 8):
-    xx, tt = x[:bs].contiguous(), t[:bs].contiguous()
-    for _ in range(2):
-        m.zero_grad(); m.forward_backward(xx, tt)
+ATT = lambda s: {"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (s, s)}
+MODELS = {
+    "densenet121": (lambda: densenet121(num_classes=14), 320, 256, 31.6),
+    "aadensenet121": (lambda: DenseNet(32, (6, 12, 24, 16), 64, num_classes=14, attn_params=ATT(320)), 320, 128, 33.4),
+    "resnet152": (lambda: resnet152(num_classes=14), 320, 128, 56.0),
+    "efficientnet-b4": (lambda: construct_model("efficientnet-b4", 14), 380, 64, 47.7),
+}
+for name, (ctor, S, B, gpu_ms) in MODELS.items():
+    m = ctor().to(dev).train()
+    x, t = synth.xray_batch(1, 2, S).to(dev), synth.targets(2, 2, 14).to(dev)
+    opt = None
+    for _ in range(3):
+        m.zero_grad(); m.forward_backward(x, t)
+        if opt is None:
+            try:
+                opt = FusedAdam(m, lr=1e-4); opt.step()
+            except Exception:
+                opt = False
     torch.cuda.synchronize()
+    n = 10
     t0 = time.perf_counter()
-    for _ in range(5):
-        m.zero_grad(); m.forward_backward(xx, tt)
+    for _ in range(n):
+        m.zero_grad(); m.forward_backward(x, t)
+        if opt:
+            opt.step()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print("bs=%d host enqueue %.1f ms/step, total %.1f ms/step" % (bs, (t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3), flush=True)
+    print("%-16s host enqueue %.1f ms/step (batch 2: the GPU is idle most of the step); GPU step at batch %d: %.1f ms" % (
+        name, (t1 - t0) / n * 1e3, B, gpu_ms), flush=True)
+    del m
+    torch.cuda.empty_cache()

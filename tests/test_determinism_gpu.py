@@ -345,6 +345,22 @@ def test_aa_resnet_training_step_is_reproducible_bit_for_bit(dev, kind, layers, 
     _three_identical_steps(model, synth.xray_batch(530, B, S).to(dev), synth.targets(531, B, 5).to(dev))
 
 
+@pytest.mark.parametrize("name,B,S", [("efficientnet-b0", 4, 96), ("efficientnet-b0", 2, 224), ("efficientnet-b4", 2, 380)])
+def test_efficientnet_training_step_is_reproducible_bit_for_bit(dev, name, B, S):
+    """EfficientNet (models/efficientnet.py:78-185): depthwise / Swish / BatchNorm statistics as rows, squeeze-excite sums with one
+    owner each, depthwise and 1x1 weight gradients through slabs -- with the stochastic parts (Dropout / DropConnect masks) fixed by
+    the model's counter-based seeds, two steps are the same bits."""
+    from chexpert_amd.models import construct_model
+    from chexpert_amd.models.efficientnet import DropMarker
+    torch.manual_seed(15)
+    model = construct_model(name, 5).to(dev).train()
+    for mod in model.modules():
+        if isinstance(mod, DropMarker):
+            mod.p = 0.0
+    assert model._eng().det
+    _three_identical_steps(model, synth.xray_batch(540, B, S).to(dev), synth.targets(541, B, 5).to(dev))
+
+
 @pytest.mark.parametrize("case", ["fused_1x1", "fused_1x1_narrow", "strip_3x3", "strip_3x3_wide", "ring_3x3", "pool2", "stem", "generic_3x3s2",
                                   "wgrad_mm"])
 def test_weight_gradient_slabs_equal_atomics_and_repeat_bit_for_bit(dev, det_wgrad, case):

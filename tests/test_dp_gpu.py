@@ -89,11 +89,9 @@ def test_data_parallel_backward_two_ranks_one_gpu(tmp_path, kind):
         rel = float((g - w).norm() / w.norm())
         print("rank %d: cos %.6f rel %.3e buckets %d; the same local step twice differs by %.3e" % (r, cos, rel, rec["n_buckets"],
                                                                                                rec["noise"]))
-        if kind == "efficientnet":       # this engine's statistics still leave their kernels through fp32 atomics
-            assert cos > 0.995 and rel < max(5e-2, 4 * rec["noise"])
-        else:                            # deterministic engines: the same local step twice is the same bits, the reduced gradient the mean
-            assert rec["noise"] == 0.0, "the same local step twice differs by %.3e" % rec["noise"]
-            assert rel < 1e-6, rel
+        # every engine is deterministic: the same local step twice is the same bits, the reduced gradient the mean of the local ones
+        assert rec["noise"] == 0.0, "the same local step twice differs by %.3e" % rec["noise"]
+        assert cos > 0.999999 and rel < 1e-6, rel
         # a `ready()` fired before a range was final (or a range never reduced) is a gross error on whole tensors, not noise
         gmax = max(float(w[o:o + n].norm()) for _, o, n in rec["spans"])
         bad = []

@@ -71,11 +71,23 @@ def test_dwconv_forward(dev, k, s, B, H, W, C, act):
     st = torch.zeros(2, C, device=dev)
     wd, scd, shd = w.to(dev), sc.to(dev), sh.to(dev)
     check(lib().cx_dwconv_fwd(ptr(xb), ptr(wd), ptr(scd) if act else None, ptr(shd) if act else None, ptr(y), ptr(st[0]), ptr(st[1]),
-                              B, H, W, C, k, s, pad, stream_ptr()), "cx_dwconv_fwd")
+                              B, H, W, C, k, s, pad, 0, stream_ptr()), "cx_dwconv_fwd")
     got = nchw(y)
     close(got, want, 6e-3, "y")
     close(st[0].cpu(), got.double().sum((0, 2, 3)).float(), 2e-3, "sum")
     close(st[1].cpu(), (got.double() ** 2).sum((0, 2, 3)).float(), 2e-3, "sumsq")
+    # deterministic statistic rows: the rows add up to the same sums, and two launches give the same bits
+    outs = []
+    for _ in range(2):
+        rows = torch.full((2, 512, C), 7.0, device=dev)
+        check(lib().cx_dwconv_fwd(ptr(xb), ptr(wd), ptr(scd) if act else None, ptr(shd) if act else None, ptr(y), ptr(rows[0]), ptr(rows[1]),
+                                  B, H, W, C, k, s, pad, 512, stream_ptr()), "cx_dwconv_fwd")
+        n = lib().cx_last_stat_rows()
+        assert 0 < n <= 512
+        outs.append(rows[:, :n].clone())
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0][0].sum(0).cpu(), st[0].cpu(), 1e-4, "row sums")
+    close(outs[0][1].sum(0).cpu(), st[1].cpu(), 1e-4, "row sums of squares")
 
 
 @pytest.mark.parametrize("k,s,B,H,W,C,act", CASES)
@@ -103,12 +115,24 @@ def test_dwconv_input_gradient(dev, k, s, B, H, W, C, act, accumulate):
     gq, g2q, xq = nhwc(g, dev), nhwc(g2, dev), nhwc(x, dev)
     opt = lambda v: ptr(v) if act else None
     check(lib().cx_dwconv_dgrad(ptr(gq), ptr(g2q), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(t[3]), ptr(xq), opt(t[4]), opt(t[5]), opt(t[6]),
-                                opt(t[7]), ptr(out), ptr(st[0]), ptr(st[1]), B, H, W, C, k, s, pad, accumulate, stream_ptr()),
+                                opt(t[7]), ptr(out), ptr(st[0]), ptr(st[1]), B, H, W, C, k, s, pad, accumulate, 0, stream_ptr()),
           "cx_dwconv_dgrad")
     close(nchw(out), want, 8e-3, "dz")
     close(st[0].cpu(), S1, 2e-3, "S1")
     if act:
         close(st[1].cpu(), S2, 3e-3, "S2")
+        outs = []                            # deterministic statistic rows (the engine asks for them where a BatchNorm precedes)
+        for _ in range(2):
+            out2 = nhwc(old, dev) if accumulate else torch.full((B, H, W, C), 7.0, device=dev, dtype=torch.bfloat16)
+            rows = torch.full((2, 512, C), 7.0, device=dev)
+            check(lib().cx_dwconv_dgrad(ptr(gq), ptr(g2q), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(t[3]), ptr(xq), opt(t[4]), opt(t[5]), opt(t[6]),
+                                        opt(t[7]), ptr(out2), ptr(rows[0]), ptr(rows[1]), B, H, W, C, k, s, pad, accumulate, 512, stream_ptr()),
+                  "cx_dwconv_dgrad")
+            n = lib().cx_last_stat_rows()
+            outs.append(rows[:, :n].clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(out2, out)
+        close(outs[0][0].sum(0).cpu(), st[0].cpu(), 1e-4, "S1 rows")
+        close(outs[0][1].sum(0).cpu(), st[1].cpu(), 1e-4, "S2 rows")
 
 
 @pytest.mark.parametrize("k,s,B,H,W,C,act", CASES)
@@ -129,8 +153,19 @@ def test_dwconv_weight_gradient(dev, k, s, B, H, W, C, act):
     t = [v.to(dev) for v in (ga, gb, gc, sc, sh)]
     gq, g2q, xq = nhwc(g, dev), nhwc(g2, dev), nhwc(x, dev)
     check(lib().cx_dwconv_wgrad(ptr(gq), ptr(g2q), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(xq), ptr(t[3]) if act else None,
-                                ptr(t[4]) if act else None, ptr(dw), B, H, W, C, k, s, pad, stream_ptr()), "cx_dwconv_wgrad")
+                                ptr(t[4]) if act else None, ptr(dw), B, H, W, C, k, s, pad, None, 0, stream_ptr()), "cx_dwconv_wgrad")
     close(dw.cpu() - dw0, want, 2e-3, "dW")
+    scratch = torch.empty(16 << 20, device=dev)          # slab workspace: reproducible sums
+    outs = []
+    for _ in range(2):
+        dws = dw0.clone().to(dev)
+        check(lib().cx_dwconv_wgrad(ptr(gq), ptr(g2q), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(xq), ptr(t[3]) if act else None,
+                                    ptr(t[4]) if act else None, ptr(dws), B, H, W, C, k, s, pad, ptr(scratch), scratch.numel(), stream_ptr()),
+              "cx_dwconv_wgrad")
+        assert lib().cx_last_slab_floats() > 0
+        outs.append(dws)
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0].cpu() - dw0, (dw.cpu() - dw0), 1e-4, "dW through slabs")
 
 
 @pytest.mark.parametrize("B,C,R", [(5, 96, 4), (37, 240, 10), (128, 672, 28), (3, 2688, 112)])
@@ -148,8 +183,18 @@ def test_se_backward(dev, B, C, R):
     d = [t.clone().to(dev) for t in init]
     dpooled = torch.full((B, C), 7.0, device=dev)
     args = [t.detach().to(dev).contiguous() for t in (ds, s, h1, pooled, w1, w2)]
-    check(lib().cx_se_bwd(*[ptr(t) for t in args], ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(dpooled), B, C, R, stream_ptr()),
+    check(lib().cx_se_bwd(*[ptr(t) for t in args], ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(dpooled), B, C, R, None, 0, stream_ptr()),
           "cx_se_bwd")
     for got, i0, ref, what in zip(d, init, (w1, b1, w2, b2), ("dW1", "db1", "dW2", "db2")):
         close(got.cpu() - i0, ref.grad, 1e-4, what)
     close(dpooled.cpu(), pooled.grad, 1e-4, "dpooled")
+    scratch = torch.empty(8 << 20, device=dev)            # slab workspace: image groups added in order, the same bits every time
+    outs = []
+    for _ in range(2):
+        d2 = [t.clone().to(dev) for t in init]
+        check(lib().cx_se_bwd(*[ptr(t) for t in args], ptr(d2[0]), ptr(d2[1]), ptr(d2[2]), ptr(d2[3]), ptr(dpooled), B, C, R, ptr(scratch),
+                              scratch.numel(), stream_ptr()), "cx_se_bwd")
+        outs.append(d2)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[0], outs[1]))
+    for got, i0, ref, what in zip(outs[0], init, (w1, b1, w2, b2), ("dW1", "db1", "dW2", "db2")):
+        close(got.cpu() - i0, ref.grad, 1e-4, what + " through slabs")

@@ -111,8 +111,11 @@ CASES = {
     "aadensenet121_320_b8": (1e-2, 1e-2, 0.05, 0.05),
     "resnet152_320_b8": (1.3e-2, 1e-2, 0.05, 0.05),
     "aaresnet152_320_b8": (6e-2, 1e-2, 0.2, 0.1),
-    "efficientnet-b0_224_b8": (1e-2, 1e-2, 0.05, 0.05),
-    "efficientnet-b4_380_b8": (2e-2, 1e-2, 0.08, 0.08),       # atomic statistics: 0.8e-2 .. 1.5e-2 between runs / batch geometries
+    # EfficientNets: logits 4.5e-3 / 7.4e-3 (deterministic engine: the same at every batch geometry).  Gradient norms agree to 5 % except
+    # the squeeze-excite reduce convolutions (blocks.*.6.1 / .3.1: 7.6 % on b0, 10.2 % on b4): ds = sum_hw du * swish(bn(y)) is a sum
+    # with heavy cancellation over bf16-rounded du -- the same tensors are 1e-5 from the reference in the fp32 mode (test_fp32_gpu.py)
+    "efficientnet-b0_224_b8": (1e-2, 1e-2, 0.12, 0.06),
+    "efficientnet-b4_380_b8": (1e-2, 1e-2, 0.12, 0.06),
 }
 
 
