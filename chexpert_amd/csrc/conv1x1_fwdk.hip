@@ -5,6 +5,7 @@
 // (128 pixels x 128 channels, 4 waves, mfma 32x32x16) with BK = 128 channels per step: a quarter of the dependent round
 // trips, 64 KB of operands per workgroup in flight, ONE LDS stage (rows of 272 B) + register prefetch so that two
 // workgroups still share a CU.  Epilogue as in conv_gemm.hip (fp32 tile through LDS, 16-B stores, channel sums).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -165,6 +166,192 @@ __global__ __launch_bounds__(256, 2) void pw_fwdk_kernel(const CxConv p, const i
   }
 }
 
+// Pipelined form: the same tile with BK = 64 channels per step and the operands of the next D steps in flight in D register sets
+// (4 + 4 sixteen-byte loads per thread and step).  The single-set kernel above overlaps one step's loads with one step's MFMAs
+// (~0.25 us against 2-3 us of load latency under load): a workgroup spends most of a step waiting.  Here a step's loads have D
+// steps of time; the loop body is unrolled D-fold so every register set is indexed statically and the wait counts are exact
+// (loads beyond the last step are harmless re-reads of it: unconditional requests, see DESIGN.md lesson 15).
+template <int PRO, int D>
+__global__ __launch_bounds__(256, 2) void pw_fwdp_kernel(const CxConv p, const int M) {
+  constexpr int BK = 64;
+  constexpr int PITCH = BK * 2 + 16;                 // 144 B
+  constexpr int CPR = BK / 8;                        // 8 chunks per row
+  constexpr int RPP = 256 / CPR;                     // 32 rows per pass
+  constexpr int NL = 128 / RPP;                      // 4 loads per thread and operand
+  constexpr int A_BYTES = BM * PITCH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem);                       // [2][K]
+  char* At = smem + 2 * p.K * 4;
+  char* Bt = At + A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int mt = xcd_remap(blockIdx.x, gridDim.x);
+  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const bf16* __restrict__ Wp = reinterpret_cast<const bf16*>(p.w);
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+  if (PRO == CX_PRO_AFFINE_RELU)
+    for (int i = tid; i < p.K; i += 256) { coef[i] = p.pa[i]; coef[p.K + i] = p.pb[i]; }
+  const int q = tid % CPR, r0 = tid / CPR;
+  const int nsteps = (p.K + BK - 1) / BK;
+  // row bases of this thread's four rows (clamped: unconditional loads)
+  const bf16* xr[NL];
+  const bf16* wr[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int row = r0 + RPP * i;
+    const int m = mt * BM + row;
+    xr[i] = X + (size_t)(m < M ? m : M - 1) * p.ldx + q * 8;
+    wr[i] = Wp + (size_t)row * p.K + q * 8;
+  }
+  uint4 ra[D][NL], rw[D][NL];
+  auto issue = [&](uint4 (&a)[NL], uint4 (&w)[NL], int s) __attribute__((always_inline)) {
+    const int sc = s < nsteps ? s : nsteps - 1;
+    int c = sc * BK;
+    if (c + q * 8 >= p.K) c = p.K - BK;             // partial last step (K % 64 == 32): re-read in-bounds channels, masked when staged
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      a[i] = *reinterpret_cast<const uint4*>(xr[i] + c);
+      w[i] = *reinterpret_cast<const uint4*>(wr[i] + c);
+    }
+  };
+  auto stage = [&](const uint4 (&a)[NL], const uint4 (&w)[NL], int s) __attribute__((always_inline)) {
+    const int c0 = s * BK + q * 8;
+    const bool kok = c0 < p.K;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int row = r0 + RPP * i;
+      U128 o;
+      if (!kok || mt * BM + row >= M) {
+        o.u = make_uint4(0, 0, 0, 0);
+      } else if (PRO == CX_PRO_NONE) {
+        o.u = a[i];
+      } else {
+        U128 v;
+        v.u = a[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[c0 + j], coef[p.K + c0 + j]), 0.f));
+      }
+      *reinterpret_cast<uint4*>(At + row * PITCH + q * 16) = o.u;
+      *reinterpret_cast<uint4*>(Bt + row * PITCH + q * 16) = kok ? w[i] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(ra[d], rw[d], d);
+  __syncthreads();                                    // coefficient table visible
+  const int lrow = lane & 31, lh = lane >> 5;
+  for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int s = s0 + d;
+      if (s < nsteps) {                               // workgroup-uniform
+        stage(ra[d], rw[d], s);
+        __syncthreads();
+        issue(ra[d], rw[d], s + D);                   // D steps ahead, into the set just consumed
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          bf16x8 af[TM], bfr[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(At + ((wm * TM + i) * 32 + lrow) * PITCH + kk * 32 + lh * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bt + ((wn * TN + j) * 32 + lrow) * PITCH + kk * 32 + lh * 16);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // ---------------------------------------------------------------- epilogue (as pw_fwdk_kernel)
+  constexpr int ECPR = BN / 8, ERPP = 256 / ECPR, NPASS = 64 / ERPP;
+  const int cq = tid % ECPR, rr = tid / ECPR;
+  float* etile = reinterpret_cast<float*>(At);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  const bool want_stats = p.stat_sum != nullptr;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int col = (wn * TN + j) * 32 + lrow;
+            etile[row * EPITCH + col] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * ERPP + rr;
+      const int m = mt * BM + half * 64 + row;
+      if (m < M) {
+        const float4 v0 = *reinterpret_cast<const float4*>(etile + row * EPITCH + cq * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(etile + row * EPITCH + cq * 8 + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        U128 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o.e[j] = f2bf(v[j]);
+          const float rv = bf2f(o.e[j]);
+          s1[j] += rv;
+          s2[j] += rv * rv;
+        }
+        *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + cq * 8) = o.u;
+      }
+    }
+    __syncthreads();
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int d = ECPR; d < 64; d <<= 1) {
+        s1[j] += __shfl_xor(s1[j], d);
+        s2[j] += __shfl_xor(s2[j], d);
+      }
+    }
+    float* scratch = reinterpret_cast<float*>(At);               // tile buffers are free now
+    wg_stat_begin<4>(scratch, BN, tid, 256);
+    if (lane < ECPR) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wg_stat_put(scratch, BN, wave, cq * 8 + j, s1[j], s2[j]);
+    }
+    wg_stat_end<4>(scratch, BN, tid, 256, p.stat_sum, p.stat_sq, p.stat_det, (int)blockIdx.x, p.stat_replicas, p.stat_rstride, 0, p.N);
+  }
+}
+
+template <int PRO, int D>
+int launch_fwdp(const CxConv& p, hipStream_t st) {
+  const long long M = (long long)p.B * p.Ho * p.Wo;
+  const int m_tiles = (int)((M + BM - 1) / BM);
+  const size_t stage = (size_t)2 * BM * (64 * 2 + 16);
+  const size_t epi = (size_t)64 * EPITCH * 4;
+  const size_t smem = (size_t)2 * p.K * 4 + (stage > epi ? stage : epi) + 2 * BN * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_fwdp_kernel<PRO, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr = true;
+  }
+  if (smem > 80 * 1024) return CX_ESHAPE;
+  if (const int e = stat_rows_check(p, m_tiles)) return e;
+  CX_KTAG("pw_fwdp_kernel<%d, %d>", PRO, D);
+  hipLaunchKernelGGL((pw_fwdp_kernel<PRO, D>), dim3(m_tiles), dim3(256), smem, st, p, (int)M);
+  return launch_status();
+}
+
 template <int BK, int PRO>
 int launch_fwdk(const CxConv& p, hipStream_t st) {
   const long long M = (long long)p.B * p.Ho * p.Wo;
@@ -195,5 +382,15 @@ int cx_try_pw_fwdk(const CxConv& p, hipStream_t st, bool* handled) {
   // pays where the launch is latency bound, i.e. few tiles (measured: 20x20 and 10x10 maps at bs=256 -10..-30 %, 40x40 +5 %)
   if ((long long)p.B * p.Ho * p.Wo > 200000) return 0;
   *handled = true;
+  // measured at bs = 256 (scratch/bench_pw.py fwd, one box): two sets in flight 85 -> 75 us at K = 992 on 20x20 maps, 55 -> 50 at
+  // K = 512, nothing below that and nothing on 10x10 maps (one tile per CU there: the step is bound by its barrier-separated
+  // stage / MFMA phases with one wave per SIMD, not by load latency); three and four sets are no better than two
+  static const int pipe = []() { const char* e = getenv("CX_FWDK_PIPE"); return e ? atoi(e) : 2; }();     // 0: the single-set kernel
+  if (pipe == 2 && p.K % 32 == 0 && p.K >= 512)
+    return p.prologue == CX_PRO_AFFINE_RELU ? launch_fwdp<CX_PRO_AFFINE_RELU, 2>(p, st) : launch_fwdp<CX_PRO_NONE, 2>(p, st);
+  if (pipe == 3 && p.K % 32 == 0 && p.K >= 192)
+    return p.prologue == CX_PRO_AFFINE_RELU ? launch_fwdp<CX_PRO_AFFINE_RELU, 3>(p, st) : launch_fwdp<CX_PRO_NONE, 3>(p, st);
+  if (pipe == 4 && p.K % 32 == 0 && p.K >= 256)
+    return p.prologue == CX_PRO_AFFINE_RELU ? launch_fwdp<CX_PRO_AFFINE_RELU, 4>(p, st) : launch_fwdp<CX_PRO_NONE, 4>(p, st);
   return p.prologue == CX_PRO_AFFINE_RELU ? launch_fwdk<128, CX_PRO_AFFINE_RELU>(p, st) : launch_fwdk<128, CX_PRO_NONE>(p, st);
 }

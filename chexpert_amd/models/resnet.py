@@ -510,6 +510,18 @@ class _Engine:
 
     def backward(self, ws, dlogits):
         ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
+        # the ordered slab sums run as one table-driven launch at the end of the pass (ops.wgrad_defer_*); data-parallel runs keep
+        # the immediate sums (their buckets leave while backward is still running), and so does the CIFAR stem (read back at once)
+        deferred = self.det and self.reducer is None and not self.cifar and ops.wgrad_defer_begin(self.device)
+        try:
+            self._backward(ws, dlogits)
+            if deferred:
+                ops.wgrad_defer_flush(self.device)
+        finally:
+            if deferred:
+                ops.wgrad_defer_abort(self.device)
+
+    def _backward(self, ws, dlogits):
         m, v, G = self.model, self._v, self.G
         B = ws.B
         self._alloc_bwd(ws)
