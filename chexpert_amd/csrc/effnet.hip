@@ -363,10 +363,13 @@ __global__ __launch_bounds__(1024) void se_fwd_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float a = b2[c];
-    for (int r = 0; r < R; ++r) a = fmaf(w2[(size_t)c * R + r], lds[r], a);
-    s[(size_t)b * C + c] = sigmoidf_(a);
+  // eight lanes per channel: a W2 row (R contiguous floats) is read 32 B at a time, the partial sums meet in a fixed butterfly
+  const int l8 = threadIdx.x & 7;
+  for (int c = threadIdx.x >> 3; c < C; c += blockDim.x >> 3) {
+    float a = 0.f;
+    for (int r = l8; r < R; r += 8) a = fmaf(w2[(size_t)c * R + r], lds[r], a);
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+    if (l8 == 0) s[(size_t)b * C + c] = sigmoidf_(a + b2[c]);
   }
 }
 
@@ -505,22 +508,47 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ 
     dl2[i] = ds[(size_t)b0 * C + i] * sv * (1.f - sv);
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-  for (int r = wave; r < R; r += nw) {                // a wave per hidden unit: each W2 element is read once for the whole group
+  if (R <= nt) {
+    // lanes run over the hidden units (W2 rows are R contiguous floats: coalesced), nt / R channel subsets per unit; the subsets'
+    // partial sums meet in dh1 one subset at a time (a fixed order)
+    const int nsub = nt / R, sub = tid / R, r = tid - sub * R;
     float a[16];
 #pragma unroll
     for (int gi = 0; gi < 16; ++gi) a[gi] = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float wv = w2[(size_t)c * R + r];
+    if (sub < nsub)
+      for (int c = sub; c < C; c += nsub) {
+        const float wv = w2[(size_t)c * R + r];
 #pragma unroll
-      for (int gi = 0; gi < 16; ++gi)
-        if (gi < ng) a[gi] = fmaf(wv, dl2[gi * C + c], a[gi]);
+        for (int gi = 0; gi < 16; ++gi)
+          if (gi < ng) a[gi] = fmaf(wv, dl2[gi * C + c], a[gi]);
+      }
+    for (int sx = 0; sx < nsub; ++sx) {
+      if (sub == sx) {
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi)
+          if (gi < ng) dh1[gi * R + r] = (sx ? dh1[gi * R + r] : 0.f) + a[gi];
+      }
+      __syncthreads();
     }
+    for (int i = tid; i < ng * R; i += nt) dh1[i] *= dswishf_(h1[(size_t)b0 * R + i]);
+  } else {
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int r = wave; r < R; r += nw) {                // a wave per hidden unit: each W2 element is read once for the whole group
+      float a[16];
 #pragma unroll
-    for (int gi = 0; gi < 16; ++gi) {
+      for (int gi = 0; gi < 16; ++gi) a[gi] = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float wv = w2[(size_t)c * R + r];
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) a[gi] += __shfl_xor(a[gi], d);
-      if (lane == 0 && gi < ng) dh1[gi * R + r] = a[gi] * dswishf_(h1[(size_t)(b0 + gi) * R + r]);
+        for (int gi = 0; gi < 16; ++gi)
+          if (gi < ng) a[gi] = fmaf(wv, dl2[gi * C + c], a[gi]);
+      }
+#pragma unroll
+      for (int gi = 0; gi < 16; ++gi) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a[gi] += __shfl_xor(a[gi], d);
+        if (lane == 0 && gi < ng) dh1[gi * R + r] = a[gi] * dswishf_(h1[(size_t)(b0 + gi) * R + r]);
+      }
     }
   }
   for (int i = tid; i < ncs * R; i += nt) {           // dW2[c][r] += sum_g dlogit2[g][c] * a1[g][r]
