@@ -1,14 +1,22 @@
 #!/bin/bash
-# one gpurun call that refreshes every committed measurement of round 2: tests, bench lines, kernel stats, PMC traffic, SQ counters
-# usage: bash scratch/refresh.sh            (then copy gpurun_out/refresh/* into profiles/ as r02_*)
-set -e
+# one gpurun call that refreshes every committed measurement of round 3: tests, bench lines, kernel stats, PMC traffic, SQ counters,
+# host enqueue cost, input-pipeline rate.  The refresh STOPS when the GPU suite fails or a kernel faults: numbers of a broken
+# build are not produced.
+# usage: bash scratch/refresh.sh [notests]     (then: bash scratch/refresh_copy.sh copies gpurun_out/refresh/* into profiles/r03_*)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
-timeout -k 10 600 python -m pytest tests -m gpu -q > $O/tests.log 2>&1 || true
+if [ "$1" != "notests" ]; then
+  timeout -k 10 900 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; rc=$?
+  tail -3 $O/tests.log
+  if grep -q "Memory access fault" $O/tests.log; then echo "GPU FAULT in the suite: refresh aborted"; exit 3; fi
+  if [ $rc -ne 0 ]; then echo "GPU suite rc=$rc: refresh aborted"; grep -h "FAILED\|Error" $O/tests.log | head -10; exit $rc; fi
+fi
+set -e
 timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 python bench.py --dtype fp32 --steps 3 --warmup 1 > $O/bench_fp32.json 2>> $O/bench.err
-CHEXPERT_SERIAL_WGRAD=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-graph > $O/bench_prof.json 2>> $O/bench.err
-cp $(ls $O/stats/*/*_kernel_stats.csv) $O/kernel_stats.csv; rm -rf $O/stats
+CHEXPERT_SERIAL_WGRAD=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-graph --steps 10 --warmup 3 > $O/bench_prof.json 2>> $O/bench.err
+cp $(ls $O/stats/*/*_kernel_stats.csv) $O/kernel_stats.csv
+python scratch/kstats.py $O/stats 13 40 > $O/kstats_densenet121.txt; rm -rf $O/stats
 pmc() {   # model dtype batch size
   local M=$1 D=$2 B=$3 S=$4 T=$O/pmc_$1
   timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $T/fetch -- python bench.py --model $M --dtype $D --batch $B --size $S --no-cpu-baseline --no-graph --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
@@ -21,7 +29,12 @@ pmc() {   # model dtype batch size
 pmc densenet121 bf16 256 320
 for spec in "aadensenet121 128 320" "resnet152 128 320" "efficientnet-b4 64 380"; do
   set -- $spec
-  timeout -k 10 300 python bench.py --model $1 --batch $2 --size $3 --no-cpu-baseline > $O/bench_$1.json 2>> $O/bench.err || true
-  pmc $1 bf16 $2 $3 || true
+  timeout -k 10 300 python bench.py --model $1 --batch $2 --size $3 --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_$1.json 2>> $O/bench.err
+  CHEXPERT_SERIAL_WGRAD=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --model $1 --batch $2 --size $3 --no-cpu-baseline --no-graph --steps 4 --warmup 1 > /dev/null 2>> $O/bench.err
+  python scratch/kstats.py $O/stats 5 30 > $O/kstats_$1.txt; rm -rf $O/stats
+  pmc $1 bf16 $2 $3
 done
-tail -2 $O/tests.log; cat $O/bench.json; cat $O/sq_densenet121.txt
+timeout -k 10 300 python scratch/host_rate.py > $O/host_enqueue.txt 2>> $O/bench.err
+timeout -k 10 300 python -m chexpert_amd.loader --bench > $O/loader_bench.json 2>> $O/bench.err
+if grep -q "Memory access fault" $O/bench.err; then echo "GPU FAULT"; exit 3; fi
+cat $O/bench.json; cat $O/sq_densenet121.txt; cat $O/host_enqueue.txt $O/loader_bench.json

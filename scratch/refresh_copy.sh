@@ -1,0 +1,20 @@
+#!/bin/bash
+# copy the files of the last scratch/refresh.sh run into profiles/ under this round's names
+R=${1:-r03}; O=gpurun_out/refresh; P=profiles
+cp $O/bench.json $P/${R}_bench_bs256.json
+cp $O/bench_fp32.json $P/${R}_bench_fp32_bs256.json
+cp $O/kernel_stats.csv $P/${R}_bench_bs256_kernel_stats.csv
+cp $O/kstats_densenet121.txt $P/${R}_densenet121_kernel_stats.txt
+for m in aadensenet121 resnet152 efficientnet-b4; do
+  cp $O/bench_$m.json $P/${R}_bench_$m.json
+  cp $O/kstats_$m.txt $P/${R}_${m}_kernel_stats.txt
+done
+for m in densenet121 aadensenet121 resnet152 efficientnet-b4; do
+  cp $O/pmc_traffic_$m.json $P/${R}_pmc_traffic_$m.json
+  cp $O/sq_counters_$m.json $P/${R}_sq_counters_$m.json
+done
+cat $O/pmc_*.txt $O/sq_*.txt > $P/${R}_pmc_summary.txt
+cp $O/host_enqueue.txt $P/${R}_host_enqueue.txt
+cp $O/loader_bench.json $P/${R}_loader_bench.json
+[ -f $O/tests.log ] && tail -3 $O/tests.log > $P/${R}_gpu_suite.txt
+ls $P | grep $R
