@@ -508,47 +508,22 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ 
     dl2[i] = ds[(size_t)b0 * C + i] * sv * (1.f - sv);
   }
   __syncthreads();
-  if (R <= nt) {
-    // lanes run over the hidden units (W2 rows are R contiguous floats: coalesced), nt / R channel subsets per unit; the subsets'
-    // partial sums meet in dh1 one subset at a time (a fixed order)
-    const int nsub = nt / R, sub = tid / R, r = tid - sub * R;
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  for (int r = wave; r < R; r += nw) {                // a wave per hidden unit: each W2 element is read once for the whole group
     float a[16];
 #pragma unroll
     for (int gi = 0; gi < 16; ++gi) a[gi] = 0.f;
-    if (sub < nsub)
-      for (int c = sub; c < C; c += nsub) {
-        const float wv = w2[(size_t)c * R + r];
+    for (int c = lane; c < C; c += 64) {
+      const float wv = w2[(size_t)c * R + r];
 #pragma unroll
-        for (int gi = 0; gi < 16; ++gi)
-          if (gi < ng) a[gi] = fmaf(wv, dl2[gi * C + c], a[gi]);
-      }
-    for (int sx = 0; sx < nsub; ++sx) {
-      if (sub == sx) {
-#pragma unroll
-        for (int gi = 0; gi < 16; ++gi)
-          if (gi < ng) dh1[gi * R + r] = (sx ? dh1[gi * R + r] : 0.f) + a[gi];
-      }
-      __syncthreads();
+      for (int gi = 0; gi < 16; ++gi)
+        if (gi < ng) a[gi] = fmaf(wv, dl2[gi * C + c], a[gi]);
     }
-    for (int i = tid; i < ng * R; i += nt) dh1[i] *= dswishf_(h1[(size_t)b0 * R + i]);
-  } else {
-    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    for (int r = wave; r < R; r += nw) {                // a wave per hidden unit: each W2 element is read once for the whole group
-      float a[16];
 #pragma unroll
-      for (int gi = 0; gi < 16; ++gi) a[gi] = 0.f;
-      for (int c = lane; c < C; c += 64) {
-        const float wv = w2[(size_t)c * R + r];
+    for (int gi = 0; gi < 16; ++gi) {
 #pragma unroll
-        for (int gi = 0; gi < 16; ++gi)
-          if (gi < ng) a[gi] = fmaf(wv, dl2[gi * C + c], a[gi]);
-      }
-#pragma unroll
-      for (int gi = 0; gi < 16; ++gi) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) a[gi] += __shfl_xor(a[gi], d);
-        if (lane == 0 && gi < ng) dh1[gi * R + r] = a[gi] * dswishf_(h1[(size_t)(b0 + gi) * R + r]);
-      }
+      for (int d = 32; d >= 1; d >>= 1) a[gi] += __shfl_xor(a[gi], d);
+      if (lane == 0 && gi < ng) dh1[gi * R + r] = a[gi] * dswishf_(h1[(size_t)(b0 + gi) * R + r]);
     }
   }
   for (int i = tid; i < ncs * R; i += nt) {           // dW2[c][r] += sum_g dlogit2[g][c] * a1[g][r]
@@ -570,6 +545,86 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ 
       dw_out(db1, sl_b1, (size_t)R, (int)blockIdx.x, (size_t)r, a);
     }
   for (int i = tid; i < R * ncs; i += nt) {           // dW1[r][c] += sum_g dh1[g][r] * pooled[g][c]
+    const int r = i / ncs, c = cs0 + i - r * ncs;
+    float a = 0.f;
+    for (int gi = 0; gi < ng; ++gi) a = fmaf(dh1[gi * R + r], pooled[(size_t)(b0 + gi) * C + c], a);
+    dw_out(dw1, sl_w1, (size_t)R * C, (int)blockIdx.x, (size_t)r * C + c, a);
+  }
+  for (int i = tid; i < ng * ncs; i += nt) {
+    const int gi = i / ncs, c = cs0 + i - gi * ncs;
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a = fmaf(w1[(size_t)r * C + c], dh1[gi * R + r], a);
+    dpooled[(size_t)(b0 + gi) * C + c] = a;
+  }
+}
+
+// The same in two passes over (group of 16 images, slice of CS channels) workgroups, for callers with a workspace.  The single
+// kernel above makes every slice recompute the group's dh1 = W2^T dlogit2 over ALL C channels (3 M multiply-adds behind
+// broadcast LDS reads: 50-480 us per call on EfficientNet-B4's shapes, measured in scratch/bench_se.py); here a slice only
+// multiplies its own CS channels (pass A, partial dh1 rows to the workspace) and pass B adds the slices' rows in slice order.
+//   A: part[group][slice][g][r] = sum_{c in slice} W2[c][r] dlogit2[g][c];  dW2 / db2 of the slice
+//   B: dh1 = (sum_slices part) * swish'(h1);  dW1 / db1;  dpooled of the slice
+__global__ __launch_bounds__(512) void se_bwd_a_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                       const float* __restrict__ h1, const float* __restrict__ w2, float* dw2,
+                                                       float* db2, float* __restrict__ part, int B, int C, int R, int CS,
+                                                       float* sl_w2, float* sl_b2) {
+  extern __shared__ float lds[];          // [16][CS] dlogit2 of the slice, [16][R] a1 = swish(h1)
+  float* dl2 = lds;
+  float* a1 = lds + 16 * CS;
+  const int b0 = blockIdx.x * 16, ng = min(16, B - b0);
+  const int cs0 = blockIdx.y * CS, ncs = min(CS, C - cs0);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < ng * R; i += nt) a1[i] = swishf_(h1[(size_t)b0 * R + i]);
+  for (int i = tid; i < ng * ncs; i += nt) {
+    const int gi = i / ncs, cl = i - gi * ncs;
+    const size_t at = (size_t)(b0 + gi) * C + cs0 + cl;
+    const float sv = s[at];
+    dl2[gi * CS + cl] = ds[at] * sv * (1.f - sv);
+  }
+  __syncthreads();
+  float* prow = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 * R;
+  for (int i = tid; i < ng * R; i += nt) {             // consecutive threads = consecutive r: W2 rows are read along their length
+    const int gi = i / R, r = i - gi * R;
+    float a = 0.f;
+    for (int cl = 0; cl < ncs; ++cl) a = fmaf(w2[(size_t)(cs0 + cl) * R + r], dl2[gi * CS + cl], a);
+    prow[i] = a;
+  }
+  for (int i = tid; i < ncs * R; i += nt) {            // dW2[c][r] += sum_g dlogit2[g][c] * a1[g][r]
+    const int cl = i / R, r = i - cl * R;
+    float a = 0.f;
+    for (int gi = 0; gi < ng; ++gi) a = fmaf(dl2[gi * CS + cl], a1[gi * R + r], a);
+    dw_out(dw2, sl_w2, (size_t)C * R, (int)blockIdx.x, (size_t)(cs0 + cl) * R + r, a);
+  }
+  for (int cl = tid; cl < ncs; cl += nt) {
+    float a = 0.f;
+    for (int gi = 0; gi < ng; ++gi) a += dl2[gi * CS + cl];
+    dw_out(db2, sl_b2, (size_t)C, (int)blockIdx.x, (size_t)(cs0 + cl), a);
+  }
+}
+
+__global__ __launch_bounds__(512) void se_bwd_b_kernel(const float* __restrict__ part, const float* __restrict__ h1,
+                                                       const float* __restrict__ pooled, const float* __restrict__ w1, float* dw1,
+                                                       float* db1, float* __restrict__ dpooled, int B, int C, int R, int CS,
+                                                       float* sl_w1, float* sl_b1) {
+  extern __shared__ float lds[];          // [16][R] dh1
+  float* dh1 = lds;
+  const int b0 = blockIdx.x * 16, ng = min(16, B - b0);
+  const int cs0 = blockIdx.y * CS, ncs = min(CS, C - cs0);
+  const int tid = threadIdx.x, nt = blockDim.x, nsl = gridDim.y;
+  const float* prow = part + (size_t)blockIdx.x * nsl * 16 * R;
+  for (int i = tid; i < ng * R; i += nt) {
+    float a = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) a += prow[(size_t)sl * 16 * R + i];
+    dh1[i] = a * dswishf_(h1[(size_t)b0 * R + i]);
+  }
+  __syncthreads();
+  if (blockIdx.y == 0)
+    for (int r = tid; r < R; r += nt) {
+      float a = 0.f;
+      for (int gi = 0; gi < ng; ++gi) a += dh1[gi * R + r];
+      dw_out(db1, sl_b1, (size_t)R, (int)blockIdx.x, (size_t)r, a);
+    }
+  for (int i = tid; i < R * ncs; i += nt) {            // dW1[r][c] += sum_g dh1[g][r] * pooled[g][c]
     const int r = i / ncs, c = cs0 + i - r * ncs;
     float a = 0.f;
     for (int gi = 0; gi < ng; ++gi) a = fmaf(dh1[gi * R + r], pooled[(size_t)(b0 + gi) * C + c], a);
@@ -987,6 +1042,7 @@ int cx_gap_affine_act_f32(const void* x, const float* sc, const float* sh, float
 int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
               int R, void* stream) {
   if (!pooled || !w1 || !b1 || !w2 || !b2 || !h1 || !s || R <= 0 || R > 1024) return CX_EINVAL;
+  CX_KTAG("se_fwd_kernel");
   hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(1024), R * sizeof(float), as_stream(stream), pooled, w1, b1, w2, b2, h1, s, C, R);
   return launch_status();
 }
@@ -1020,6 +1076,31 @@ int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* poo
               float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, float* scratch, int64_t scratch_floats,
               void* stream) {
   if (!ds || !s || !h1 || !pooled || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpooled || R <= 0) return CX_EINVAL;
+  hipStream_t st = as_stream(stream);
+  {
+    // two-pass form: needs a workspace for the slabs (one per group of 16 images) and the slices' partial dh1 rows
+    const int CS = 64, groups = (B + 15) / 16, slices = (C + CS - 1) / CS;
+    const long long per = 2ll * C * R + C + R, nslab = (long long)groups * per, npart = (long long)groups * slices * 16 * R;
+    float* wsb = dw_slab(scratch, scratch_floats, 1, nslab + npart);
+    const size_t smem_a = (size_t)16 * (CS + R) * sizeof(float), smem_b = (size_t)16 * R * sizeof(float);
+    if (wsb && smem_a <= 48 * 1024) {
+      float *s1 = wsb, *sb1 = s1 + (size_t)groups * R * C, *s2 = sb1 + (size_t)groups * R, *sb2 = s2 + (size_t)groups * C * R;
+      float* part = wsb + nslab;
+      CX_KTAG("se_bwd_a_kernel");
+      hipLaunchKernelGGL(se_bwd_a_kernel, dim3(groups, slices), dim3(512), smem_a, st, ds, s, h1, w2, dw2, db2, part, B, C, R, CS, s2,
+                         sb2);
+      hipLaunchKernelGGL(se_bwd_b_kernel, dim3(groups, slices), dim3(512), smem_b, st, (const float*)part, h1, pooled, w1, dw1, db1,
+                         dpooled, B, C, R, CS, s1, sb1);
+      if (const int e = launch_status()) return e;
+      if (const int e = cx_dw_reduce(dw1, s1, (size_t)R * C, groups, st)) return e;
+      if (const int e = cx_dw_reduce(db1, sb1, (size_t)R, groups, st)) return e;
+      if (const int e = cx_dw_reduce(dw2, s2, (size_t)C * R, groups, st)) return e;
+      const int e = cx_dw_reduce(db2, sb2, (size_t)C, groups, st);
+      cx_tl_slab_floats_v = (int)(nslab + npart);
+      return e;
+    }
+  }
+  // no workspace: one kernel, fp32 atomics for the weight gradients
   int G = (int)((120 * 1024) / ((size_t)(C + 2 * R) * sizeof(float)));      // images per workgroup: what 120 KB of LDS hold, at most 16
   if (G > 16) G = 16;
   if (G < 1) return CX_ESHAPE;
@@ -1030,24 +1111,10 @@ int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* poo
     attr = true;
   }
   const int CS = 64, groups = (B + G - 1) / G;
-  // slab workspace (CxWgrad.scratch protocol): one slab per image group for each of dW1 (R x C), db1 (R), dW2 (C x R), db2 (C)
-  const long long per = 2ll * C * R + C + R;
-  float* slab = dw_slab(scratch, scratch_floats, groups, per);
-  float *s1 = nullptr, *sb1 = nullptr, *s2 = nullptr, *sb2 = nullptr;
-  if (slab) {
-    s1 = slab; sb1 = s1 + (size_t)groups * R * C; s2 = sb1 + (size_t)groups * R; sb2 = s2 + (size_t)groups * C * R;
-  }
-  hipStream_t st = as_stream(stream);
+  cx_tl_slab_floats_v = 0;
   hipLaunchKernelGGL(se_bwd_kernel, dim3(groups, (C + CS - 1) / CS), dim3(1024), smem, st, ds, s, h1, pooled, w1, w2,
-                     dw1, db1, dw2, db2, dpooled, B, C, R, G, CS, s1, sb1, s2, sb2);
-  if (const int e = launch_status()) return e;
-  if (slab) {
-    if (const int e = cx_dw_reduce(dw1, s1, (size_t)R * C, groups, st)) return e;
-    if (const int e = cx_dw_reduce(db1, sb1, (size_t)R, groups, st)) return e;
-    if (const int e = cx_dw_reduce(dw2, s2, (size_t)C * R, groups, st)) return e;
-    return cx_dw_reduce(db2, sb2, (size_t)C, groups, st);
-  }
-  return 0;
+                     dw1, db1, dw2, db2, dpooled, B, C, R, G, CS, nullptr, nullptr, nullptr, nullptr);
+  return launch_status();
 }
 
 int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,

@@ -271,11 +271,9 @@ class _Engine:
         self.dtype = getattr(model, "_storage_dtype", torch.bfloat16)
         self.stat_replicas = 16      # legacy (atomic) statistics: copies of every conv-produced vector (memory-side contention)
         # Deterministic statistics: per-workgroup rows summed in a fixed order instead of fp32 atomics (bit-identical activations,
-        # losses and input gradients from run to run).  The AA transitions feed a block's first channels from two different
-        # kernels (conv branch + attention out-projection) and stay on the atomic path; CHEXPERT_DET=0 forces it everywhere.
-        has_aa = any(isinstance(getattr(f, "transition%d" % (i + 1)).conv, AAConv2d) for i in range(len(model.block_config) - 1))
-        # (the AA transitions feed a block's first channels from two kernels -- conv branch and attention out-projection: their
-        # statistic rows are reduced one after the other, see _aa_forward)
+        # losses and gradients from run to run); CHEXPERT_DET=0 brings the atomics back.  The AA transitions feed a block's first
+        # channels from two kernels -- conv branch and attention out-projection: their statistic rows are reduced one after the
+        # other, see _aa_forward.
         self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
         self._plan_vectors()
 
