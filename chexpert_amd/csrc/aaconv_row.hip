@@ -667,6 +667,271 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------ key side on MFMA
+// The mirror image of the query-side kernel: a wave owns 32 KEYS (B operand, registers for the whole kernel), queries stream as
+// flat 32-query tiles:  S = Q K^T  (queries in accumulator rows, keys in lanes), per element  p = exp2(S*sl + G + U),
+// ds = p (dO . v - delta),  dv += p dO  on the vector pipe (lane = key),  dK += dS^T Q  by MFMA with dS moved from accumulator
+// to operand layout by v_permlane32_swap and split into hi + lo bf16, exactly as the query side does for dQ.
+// What the query side keeps in registers per lane -- the relative logits of ITS query -- is here a function of (query, key)
+// with the query changing per accumulator row, so the two relative terms of a tile are built as small tables in LDS, one tile
+// ahead, also on the matrix pipe:
+//   G[q][kx] = scale * q . key_rel_w[:, kx - qx + W - 1]   = a skewed window of Q (32 x 20) x RW (20 x 2W-1): waves 0..2 own
+//              one 32-column tile of the product each (RW as hi + lo bf16 fragments in registers) and store the entries that
+//              fall into their query's window at [q][kx]
+//   U[q][kyl] = scale * q . key_rel_h[:, ky0 + kyl - qy + H - 1] - lse[q]  for the (at most NKR) key rows the workgroup's 128
+//              keys touch: wave 3, Q x (32 consecutive columns of RH, hi + lo bf16 images in LDS)
+// so the pair loop reads two table words and one [dO | delta] broadcast per pair: ~14 vector instructions per (query, key)
+// against ~50 of aa_attn_bwd_k_row_kernel.  Each key's sums run over the query tiles in index order inside one workgroup:
+// no atomics, nothing order-dependent.
+template <int DVH, int WW>
+__global__ __launch_bounds__(256) void aa_attn_bwd_k_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                                const float* __restrict__ rel_w, const float* __restrict__ o,
+                                                                const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                                float* __restrict__ dqkv, const AAGeo g) {
+  static_assert(WW == 40 || WW == 20, "key rows of 40 or 20");
+  constexpr int LW = 2 * WW - 1, NT = 256;
+  constexpr int NGT = (LW + 31) / 32;                  // 32-column tiles of Q x RW: 3 / 2
+  constexpr int NKR = 127 / WW + 2;                    // key rows 128 consecutive keys can touch: 5 / 8
+  constexpr int DP = DVH + 1;                          // [dO | delta] per query
+  constexpr int GP = WW + 1, UP = NKR + 6;             // table pitches (G: one dump column; U: the row shifts)
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = g.H, HW = H * WW, LH = 2 * H - 1;
+  char* Qi = reinterpret_cast<char*>(lds);                                   // 3 x bf16 [32][KB_PITCH] raw queries of a tile
+  float* Gs = reinterpret_cast<float*>(Qi + 3 * 32 * KB_PITCH);              // 2 x [32][GP]
+  float* Us = Gs + 2 * 32 * GP;                                              // 2 x [32][UP]
+  float* Dd = Us + 2 * 32 * UP;                                              // 3 x [32][DP]
+  float* Ls = Dd + 3 * 32 * DP;                                              // 3 x [32]: -lse * log2(e) of the tile's queries (-1e30 past the map)
+  char* RHhi = reinterpret_cast<char*>(Ls + 3 * 32);                         // bf16 [LH][KB_PITCH]: key_rel_h^T, hi and lo parts
+  char* RHlo = RHhi + (size_t)LH * KB_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
+  const int j0 = blockIdx.x * 128;
+  const int j = j0 + wave * 32 + lrow;                                       // this lane's key (both lane halves)
+  const bool kvalid = j < HW;
+  const int jc = kvalid ? j : HW - 1;
+  const int ky0 = j0 / WW;
+  const int kyl = jc / WW - ky0, kxl = jc - (jc / WW) * WW;
+  const bf16* base = qkv + (size_t)b * HW * g.ldq;
+  const float scale = rsqrtf((float)DKH);
+  const float sl = scale * LOG2E;
+  const int ntl = (HW + 31) / 32;
+
+  for (int t = tid; t < 3 * 32 * KB_PITCH / 4; t += NT) reinterpret_cast<uint32_t*>(Qi)[t] = 0u;
+  for (int t = tid; t < LH * 32; t += NT) {
+    const int r = t >> 5, d = t & 31;
+    const float v = d < DKH ? rel_h[d * LH + r] : 0.f;
+    const bf16 hi = f2bf(v);
+    *reinterpret_cast<bf16*>(RHhi + r * KB_PITCH + d * 2) = hi;
+    *reinterpret_cast<bf16*>(RHlo + r * KB_PITCH + d * 2) = f2bf(v - bf2f(hi));
+  }
+  // key_rel_w columns 32 * wave + lrow as B-operand fragments (k = d), hi + lo
+  bf16x8 rwhi[2], rwlo[2];
+  {
+    const int rr = min(32 * wave + lrow, LW - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int d = kk * 16 + lh * 8 + e;
+        const float v = (d < DKH && wave < NGT) ? rel_w[d * LW + rr] : 0.f;
+        const bf16 hi = f2bf(v);
+        rwhi[kk][e] = hi;
+        rwlo[kk][e] = f2bf(v - bf2f(hi));
+      }
+  }
+  // the key: operand fragments (B operand of S = Q K^T: d = kk * 16 + lh * 8 + 0..7) and the fp32 values
+  bf16x8 kf[2];
+  float v[DVH], dv[DVH];
+  {
+    const bf16* kp = base + (size_t)jc * g.ldq + g.dk + n * DKH;
+    bf16 kb[DKH];
+#pragma unroll
+    for (int d = 0; d < DKH; d += 4) {
+      U64 u;
+      u.u = *reinterpret_cast<const uint2*>(kp + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) kb[d + e] = u.e[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      kf[0][e] = lh ? kb[8 + e] : kb[e];
+      kf[1][e] = (lh == 0 && e < 4) ? kb[16 + e] : f2bf(0.f);
+    }
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) { v[d] = bf2f(base[(size_t)jc * g.ldq + 2 * g.dk + n * DVH + d]); dv[d] = 0.f; }
+  }
+  f32x16 dka;                            // D[key][d]: rows = the wave's keys, columns = d (lane & 31)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dka[r] = 0.f;
+
+  // a tile's raw inputs: threads 0..159 one 8-byte chunk of a query, threads 160..191 one query's dO / o / lse
+  const int sq = tid < 160 ? tid / 5 : (tid - 160) & 31, sc = tid - (tid / 5) * 5;
+  uint2 qreg = make_uint2(0u, 0u);
+  float dreg[DP], lreg = 0.f;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) dreg[d] = 0.f;
+  auto load_tile = [&](int u) __attribute__((always_inline)) {
+    const int i = min(u * 32 + sq, HW - 1);
+    if (tid < 160) {
+      qreg = *reinterpret_cast<const uint2*>(base + (size_t)i * g.ldq + n * DKH + sc * 4);
+    } else if (tid < 192) {
+      const float* op = o + ((size_t)b * HW + i) * g.dv + n * DVH;
+      const float* dp = d_o + ((size_t)b * HW + i) * g.dv + n * DVH;
+      float de = 0.f;
+#pragma unroll
+      for (int d = 0; d < DVH; ++d) { dreg[d] = dp[d]; de = fmaf(dp[d], op[d], de); }
+      dreg[DVH] = de;
+      lreg = u * 32 + sq < HW ? -lse[(size_t)bn * HW + i] * LOG2E : -1.0e30f;
+    }
+  };
+  auto store_tile = [&](int u) __attribute__((always_inline)) {
+    const int bq = u % 3;
+    if (tid < 160) {
+      *reinterpret_cast<uint2*>(Qi + (bq * 32 + sq) * KB_PITCH + sc * 8) = qreg;
+    } else if (tid < 192) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d) Dd[(bq * 32 + sq) * DP + d] = dreg[d];
+      Ls[bq * 32 + sq] = lreg;
+    }
+  };
+  // the relative-logit tables of tile u (its queries are in Qi[u % 3]).  Every store is unconditional: an entry outside its query's
+  // window goes to the row's dump column, the row shifts of U are an index offset.
+  const int role = __builtin_amdgcn_readfirstlane(wave);
+  auto build_tables = [&](int u) __attribute__((always_inline)) {
+    const int bq = u % 3, bt = u & 1;
+    const int y0 = (u * 32) / WW, x0 = u * 32 - y0 * WW;
+    const int m = x0 + 4 * lh;                                        // query column before wrapping = m + qo
+    if (role < NGT) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, rwhi[kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, rwlo[kk], acc, 0, 0, 0);
+      }
+      const int kb = 32 * role + lrow - (WW - 1) + m;                 // kx = kb + qo - WW * wraps
+      float* gdst = Gs + (bt * 32 + 4 * lh) * GP;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int qo = (e & 3) + 8 * (e >> 2);
+        int kx = kb + qo;
+        kx -= m + qo >= WW ? WW : 0;
+        if (WW < 32) kx -= m + qo >= 2 * WW ? WW : 0;
+        gdst[qo * GP + ((unsigned)kx < (unsigned)WW ? kx : WW)] = acc[e] * sl;
+      }
+    } else if (role == 3) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      const int dmax = min(u * 32 + 31, HW - 1) / WW - y0;            // image rows of the tile's queries: y0 .. y0 + dmax
+      const int rrow = min(ky0 - (y0 + dmax) + H - 1 + lrow, LH - 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(RHhi + rrow * KB_PITCH + kk * 32 + lh * 16);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(RHlo + rrow * KB_PITCH + kk * 32 + lh * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc, 0, 0, 0);
+      }
+      // column n of the product is key row ky0 + n - (dmax - wraps): stored at n - dmax + wraps + 2, read at kyl + 2
+      if (lrow < NKR + 2) {
+        float* udst = Us + (bt * 32 + 4 * lh) * UP + lrow - dmax + 2;
+        const float* nl = Ls + bq * 32 + 4 * lh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int qo = (e & 3) + 8 * (e >> 2);
+          int c = m + qo >= WW ? 1 : 0;
+          if (WW < 32) c += m + qo >= 2 * WW ? 1 : 0;
+          c = min(c, dmax);                                            // (queries past the map wrap further: same window, nl = -1e30)
+          udst[qo * UP + c] = fmaf(acc[e], sl, nl[qo]);
+        }
+      }
+    }
+  };
+
+  load_tile(0);
+  __syncthreads();                         // zero fill of Qi done
+  store_tile(0);
+  load_tile(min(1, ntl - 1));
+  __syncthreads();
+  store_tile(1);
+  build_tables(0);
+  load_tile(min(2, ntl - 1));
+  __syncthreads();
+  for (int t = 0; t < ntl; ++t) {
+    // tiles t and t + 1 are in Qi, the tables of tile t are built, tile t + 2 is in registers
+    store_tile(t + 2);
+    load_tile(min(t + 3, ntl - 1));
+    if (t + 1 < ntl) build_tables(t + 1);
+    const int bq = t % 3, bt = t & 1;
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[kk], st, 0, 0, 0);
+    }
+    const float* gp = Gs + (bt * 32 + 4 * lh) * GP + kxl;
+    const float* up = Us + (bt * 32 + 4 * lh) * UP + kyl + 2;
+    const float* dp = Dd + (bq * 32 + 4 * lh) * DP;
+    float ds[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qo = (e & 3) + 8 * (e >> 2);
+      const float p = __builtin_amdgcn_exp2f(fmaf(st[e], sl, gp[qo * GP] + up[qo * UP]));
+      float a = -dp[qo * DP + DVH];
+#pragma unroll
+      for (int d = 0; d < DVH; ++d) {
+        const float dd = dp[qo * DP + d];
+        a = fmaf(dd, v[d], a);
+        dv[d] = fmaf(p, dd, dv[d]);
+      }
+      ds[e] = p * a;
+    }
+    // dK += dS^T Q over the query groups [0,16), [16,32): accumulator rows -> 8 consecutive queries per lane, hi + lo bf16
+#pragma unroll
+    for (int g16 = 0; g16 < 2; ++g16) {
+      float w[8];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ds[8 * g16 + r4]), __float_as_uint(ds[8 * g16 + 4 + r4]), false, false);
+        w[r4] = __uint_as_float(sw[0]);
+        w[4 + r4] = __uint_as_float(sw[1]);
+      }
+      union { bf16x8 h; uint32_t u[4]; } hi, lo;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        hi.u[jj] = pk_bf16(w[2 * jj], w[2 * jj + 1]);
+        lo.u[jj] = pk_bf16(w[2 * jj] - __uint_as_float(hi.u[jj] << 16), w[2 * jj + 1] - __uint_as_float(hi.u[jj] & 0xffff0000u));
+      }
+      const bf16x8 qt = tr_frag_k(Qi + bq * 32 * KB_PITCH, KB_PITCH, g16 * 16, lane);
+      dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi.h, qt, dka, 0, 0, 0);
+      dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo.h, qt, dka, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int ctot = 2 * g.dk + g.dv;
+#pragma unroll
+  for (int d = 0; d < DVH; ++d) dv[d] += __shfl_xor(dv[d], 32);
+  if (kvalid && lh == 0) {
+    float* op = dqkv + ((size_t)b * HW + j) * ctot + 2 * g.dk + n * DVH;
+#pragma unroll
+    for (int d = 0; d < DVH; ++d) op[d] = dv[d];
+  }
+  if (lrow < DKH) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = j0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (kk < HW) dqkv[((size_t)b * HW + kk) * ctot + g.dk + n * DKH + lrow] = dka[r] * scale;
+    }
+  }
+}
+
 // Forward on the same tiles: S^T = K Q^T per key row by MFMA, online softmax per query over the lane's 20 (12) accumulator slots
 // and its partner half (the two halves of a query share the running maximum), p V on the vector pipe (DVH <= 6).
 template <int DVH, int WW>
@@ -830,8 +1095,17 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
       hipLaunchKernelGGL((aa_attn_bwd_q_row_kernel<DVH, WW>), grid, dim3(AQ), smem, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv,
                          d_rel_h, d_rel_w, slab_h, slab_w, g);
     }
-    const size_t smem_k = (tables + (size_t)WW * (DKH + DVH + 2 + WW + 1)) * 4;
-    hipLaunchKernelGGL((aa_attn_bwd_k_row_kernel<DVH, WW>), grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g);
+    static const bool k_row = getenv("CX_AA_K_ROW") != nullptr;          // diagnostic: the one-lane-per-key VALU kernel
+    if ((WW == 40 || WW == 20) && !k_row) {
+      constexpr int NKR = 127 / WW + 2;
+      const size_t smem_k = (size_t)3 * 32 * KB_PITCH + ((size_t)2 * 32 * (WW + 1) + 2 * 32 * (NKR + 6) + 3 * 32 * (DVH + 1) + 3 * 32) * 4 +
+                            (size_t)2 * (2 * g.H - 1) * KB_PITCH;
+      hipLaunchKernelGGL((aa_attn_bwd_k_mfma_kernel<DVH, WW>), dim3((g.H * WW + 127) / 128, g.B * g.nh), dim3(256), smem_k, st,
+                         (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g);
+    } else {
+      const size_t smem_k = (tables + (size_t)WW * (DKH + DVH + 2 + WW + 1)) * 4;
+      hipLaunchKernelGGL((aa_attn_bwd_k_row_kernel<DVH, WW>), grid, dim3(AQ), smem_k, st, (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g);
+    }
   }
   return launch_status();
 }

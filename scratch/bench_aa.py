@@ -2,7 +2,7 @@ import sys, torch
 sys.path.insert(0, '.')
 from chexpert_amd import ops
 dev = torch.device('cuda:0'); bf = torch.bfloat16
-B, nh, dk = 32, 8, 160
+B, nh, dk = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 8, 160
 def timeit(fn, reps=3):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
