@@ -39,13 +39,15 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const CxConv p, const 
     const int row = i >> 2, c = i & 3;
     *reinterpret_cast<uint4*>(wl + row * SP + c * 16) = *reinterpret_cast<const uint4*>(Wp + (size_t)row * 32 + c * 8);
   }
-  const int my_tiles = (m_tiles - (int)blockIdx.x + G - 1) / G;
+  // tiles of neighbouring image rows re-read the same input rows (7x7 windows): the remap keeps them on one XCD's L2
+  const int lb = xcd_remap(blockIdx.x, G);
+  const int my_tiles = (m_tiles - lb + G - 1) / G;
   const int hw = p.Ho * p.Wo;
 
   // the 14 fragments (7 row-taps x 2 k16 steps) of this lane's output pixel in tile `tl`; bit 2t+s of the mask = fragment valid
   auto load_x = [&](uint4 (&xr)[7][2], int& mask, int& m_out, int tl) __attribute__((always_inline)) {
     const int tc = tl < my_tiles ? tl : my_tiles - 1;                 // clamped: loads are unconditional
-    const int m = (blockIdx.x + tc * G) * 128 + wave * 32 + lrow;
+    const int m = (lb + tc * G) * 128 + wave * 32 + lrow;
     m_out = m;
     const int mc = m < M ? m : M - 1;
     const int b = mc / hw;

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ga[j] = p.ga[gcq * 8 + j]; gb[j] = p.gb[gcq * 8 + j]; gc[j] = p.gc[gcq * 8 + j]; }
   }
-  const int step0 = blockIdx.x * steps_per_split;
+  const int step0 = xcd_remap(blockIdx.x, gridDim.x) * steps_per_split;      // (consecutive pixel ranges share input rows: one XCD)
   int nsteps = (M + PX - 1) / PX - step0;
   if (nsteps > steps_per_split) nsteps = steps_per_split;
 

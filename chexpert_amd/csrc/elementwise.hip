@@ -425,7 +425,8 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_kernel(const T* __rest
   for (int j = 0; j < 8; ++j) { fsc[j] = sc[cq * 8 + j]; fsh[j] = sh[cq * 8 + j]; s1[j] = s2[j] = 0.f; }
   const size_t npix = (size_t)B * Ho * Wo;
   const size_t ppb = blockDim.x / CP;
-  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+  // (neighbouring image rows share window reads: the remap keeps them on one XCD's L2 instead of eight)
+  for (size_t pix = (size_t)xcd_remap(blockIdx.x, gridDim.x) * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
     const int b = pix / ((size_t)Ho * Wo);
     const int rem = pix - (size_t)b * Ho * Wo;
     const int oy = rem / Wo, ox = rem - oy * Wo;
@@ -488,7 +489,8 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_bwd_kernel(
   }
   const size_t npix = (size_t)B * H * W;
   const size_t ppb = blockDim.x / CP;
-  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+  // (neighbouring image rows share window reads: the remap keeps them on one XCD's L2 instead of eight)
+  for (size_t pix = (size_t)xcd_remap(blockIdx.x, gridDim.x) * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
     const int b = pix / ((size_t)H * W);
     const int rem = pix - (size_t)b * H * W;
     const int iy = rem / W, ix = rem - iy * W;
@@ -681,7 +683,8 @@ __global__ __launch_bounds__(256) void unpool2_mask_kernel(const T* __restrict__
   const size_t npix = (size_t)B * H * W;
   const size_t ppb = blockDim.x / CP;
   const int Ho = H / 2, Wo = W / 2;
-  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+  // (neighbouring image rows share window reads: the remap keeps them on one XCD's L2 instead of eight)
+  for (size_t pix = (size_t)xcd_remap(blockIdx.x, gridDim.x) * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
     const int b = pix / ((size_t)H * W);
     const int rem = pix - (size_t)b * H * W;
     const int iy = rem / W, ix = rem - iy * W;
