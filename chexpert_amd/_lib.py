@@ -26,7 +26,8 @@ class CxConv(C.Structure):
                 ("ldx", _i32), ("ldx2", _i32), ("ldy", _i32), ("ldex", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32), ("tstride", _i32),
-                ("stat_replicas", _i32), ("stat_rstride", _i32), ("stat_det", _i32), ("dtype", _i32)]
+                ("stat_replicas", _i32), ("stat_rstride", _i32), ("stat_det", _i32), ("dtype", _i32),
+                ("pro_out", _vp), ("ldpo", _i32), ("pad_", _i32)]
 
 
 class CxWgrad(C.Structure):
@@ -53,6 +54,7 @@ class CxReduceDesc(C.Structure):
 _f, _sz, _i = C.c_float, C.c_size_t, C.c_int
 SIGNATURES = {
     "cx_abi_version": [],
+    "cx_last_pro_out": [],
     "cx_last_kernel": [],
     "cx_wgrad_defer": [C.c_int],
     "cx_wgrad_defer_take": [C.POINTER(CxReduceDesc), C.c_int, C.POINTER(C.c_int64)],
@@ -173,7 +175,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name in ("cx_error_string", "cx_last_kernel") else C.c_int
-        if l.cx_abi_version() != 6:
+        if l.cx_abi_version() != 7:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l
     return _lib

@@ -103,6 +103,7 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 // (CxConv.stat_det: one writer per element, consumers sum the rows in row order) or added to a replica with ONE atomic per
 // channel (legacy mode).  `scratch` = NW * 2 * CW floats of LDS that nothing else uses any more.
 extern thread_local int cx_tl_stat_rows;
+extern thread_local int cx_tl_pro_out;       // 1: the launch wrote CxConv.pro_out
 
 template <int NW>
 __device__ __forceinline__ void wg_stat_begin(float* scratch, int CW, int tid, int nthreads) {

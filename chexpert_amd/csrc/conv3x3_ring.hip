@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     const float* __restrict__ gb, const float* __restrict__ gc, const bf16* __restrict__ wpk, const bf16* __restrict__ ex, int ldex,
     const float* __restrict__ e_sc, const float* __restrict__ e_sh, const float* __restrict__ e_mu, const float* __restrict__ e_r,
     const float* __restrict__ e_scale, bf16* __restrict__ y, int ldy, float* S1, float* S2, int stat_replicas, int stat_rstride,
-    int stat_det, const RingGeo g) {
+    int stat_det, bf16* __restrict__ po, int ldpo, const RingGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ecoef = reinterpret_cast<float*>(smem);               // e_sc, e_sh, e_mu, e_r, e_scale [128] each
   char* wl = smem + EC_BYTES;                                  // [9*128][80 B]
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
       pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + cc4 * 8);
     }
   };
-  auto write_rows = [&](int y0, int n) __attribute__((always_inline)) {
+  auto write_rows = [&](int b, int y0, int n) __attribute__((always_inline)) {
     int slot_y0 = (y0 - base_row) % (R + 2);
     if (slot_y0 < 0) slot_y0 += R + 2;
 #pragma unroll
@@ -372,6 +372,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           o.e[j] = f2bf(fmaf(bf2f(u.e[j]), kco[j], fmaf(bf2f(v.e[j]), kco[32 + j], kco[64 + j])));
+        // side output (CxConv.pro_out): the corrected gradient slice as a dense tensor for the weight-gradient kernel.  Halo rows
+        // are staged -- and stored -- by two workgroups: the same bits twice.
+        if (po && gv[i]) *reinterpret_cast<uint4*>(po + ((size_t)(b * H + y0 + crow[i]) * W + cpx[i]) * ldpo + cc4 * 8) = o.u;
         { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
         *reinterpret_cast<uint4*>(ring + (size_t)pos * GP + cc4 * 16) = o.u;
@@ -395,12 +398,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     if (u == u0 || yc == 0) {
       base_row = yc - 1;
       issue_rows(b, yc - 1, 1);
-      write_rows(yc - 1, 1);
+      write_rows(b, yc - 1, 1);
       issue_rows(b, yc, 1);
-      write_rows(yc, 1);
+      write_rows(b, yc, 1);
       issue_rows(b, yc + 1, R);
     }
-    write_rows(yc + 1, R);
+    write_rows(b, yc + 1, R);
     __syncthreads();                                   // the window of this step is complete
     const bool next_cont = (u + 1 < u1) && ((u + 1) / g.spi == b);
     if (next_cont) issue_rows(b, yc + R + 1, R);
@@ -546,7 +549,8 @@ int launch_ring_dgrad(const CxConv& p, hipStream_t st, const RingGeo& g) {
   CX_KTAG("conv3x3_ring_dgrad_kernel<%d>", NCH);
   hipLaunchKernelGGL((conv3x3_ring_dgrad_kernel<NCH>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2,
                      p.ldx2, p.pa, p.pb, p.pc, (const bf16*)p.w, (const bf16*)p.ex, p.ldex, p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale,
-                     (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, g);
+                     (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, (bf16*)p.pro_out, p.ldpo, g);
+  cx_tl_pro_out = p.pro_out ? 1 : 0;
   return launch_status();
 }
 

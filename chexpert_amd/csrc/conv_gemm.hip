@@ -415,13 +415,16 @@ int cx_conv_gemm_f32(const CxConv& p, hipStream_t st);                      // c
 int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled);         // conv_mm.hip
 
 thread_local int cx_tl_stat_rows = 0;
+thread_local int cx_tl_pro_out = 0;
 thread_local char cx_tl_kernel[112] = "";
 extern "C" const char* cx_last_kernel(void) { return cx_tl_kernel; }
 extern "C" int cx_last_stat_rows(void) { return cx_tl_stat_rows; }
+extern "C" int cx_last_pro_out(void) { return cx_tl_pro_out; }
 
 extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
   if (!pp) return CX_EINVAL;
   const CxConv& p = *pp;
+  cx_tl_pro_out = 0;
   if (!p.x || !p.w || !p.y) return CX_EINVAL;
   if (p.B <= 0 || p.H <= 0 || p.W <= 0 || p.Ho <= 0 || p.Wo <= 0) return CX_ESHAPE;
   if (p.dtype == CX_DT_F32) {             // fp32 storage mode: one generic kernel family (conv_f32.hip)

@@ -215,6 +215,12 @@ class _Workspace:
         self.gbuf = [torch.empty_like(b) for b in self.buf]
         h, w = self.hw[0]
         self.dz2 = [torch.empty(B, h, w, eng.mid, dtype=bf, device=dev) for _ in range(2)]
+        # dense copies of the layers' corrected output-gradient slices (CxConv.pro_out of the 3x3 input-gradient kernel): one per
+        # layer, so that the weight-gradient kernels on the side stream never wait for -- or hold up -- the main chain
+        self.dyc = None
+        if bf == torch.bfloat16 and os.environ.get("CHEXPERT_DENSE_DY", "1") != "0":
+            self.dyc = [[torch.empty(B, hh, ww, eng.growth, dtype=bf, device=dev) for _ in range(nl)]
+                        for (hh, ww), nl in zip(self.hw, eng.model.block_config)]
         if len(self.buf) > 1:
             n = max(self.hw[i + 1][0] * self.hw[i + 1][1] * self.buf[i].shape[3] for i in range(len(self.buf) - 1))
             self.dpool = torch.empty(B * n, dtype=bf, device=dev)
@@ -643,13 +649,15 @@ class _Engine:
         ops.bn_bwd_coef(sred[0], sred[1], B * h * w, f.norm5.weight, v(bmean), v(brstd), G(f.norm5.weight), G(f.norm5.bias),
                         v(A), v(Bc), None, None, None, ct, replicas=sred[2], rstride=sred[3], q=slice_q(bi, n_layers - 1))
         q, pv = s["q"], s["p"]
-        # weight-gradient kernels only feed the flat gradient buffer: they run on a side stream, concurrently
-        # with the input-gradient chain of the following layers (two dz2 buffers, per-layer coefficient slots)
+        # The 3x3 weight-gradient kernels only feed the flat gradient buffer.  Rounds 1-2 ran them on a side stream beside the
+        # input-gradient chain (CHEXPERT_SERIAL_WGRAD=0 still does); since the slab sums are deferred and the fused 1x1 backward
+        # runs near the copy rate, one stream is as fast (30.31 vs 30.37 ms, interleaved A/B on one box) and lets the weight
+        # gradient read the DENSE corrected slice its own layer's input-gradient kernel leaves behind (CxConv.pro_out:
+        # 30.0 ms) -- on two streams that dependency pushes it beside the bandwidth-bound 1x1 backward and costs 0.5 ms.
         main = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream(device=dev)
-        # CHEXPERT_SERIAL_WGRAD=1: profiling aid, everything on one stream so per-kernel durations are not stretched by overlap
-        side = main if os.environ.get("CHEXPERT_SERIAL_WGRAD") == "1" else self.side
+        side = main if os.environ.get("CHEXPERT_SERIAL_WGRAD", "1") == "1" else self.side
         side.wait_stream(main)
         w1_done = {}
         k = 0
@@ -668,6 +676,8 @@ class _Engine:
                 cl = c0 + (n_layers - 1) * self.growth
                 ops.bn_bwd_slice_coef(v(sub(A, cl, self.growth)), v(sub(Bc, cl, self.growth)), v(sub(bmean, cl, self.growth)),
                                       v(sub(brstd, cl, self.growth)), *(v(t) for t in s["ql"][bi][n_layers - 1]), self.growth)
+            w2_pending = None
+            dense_dy_lag = os.environ.get("CHEXPERT_DENSE_DY", "1") == "2" and red is None     # (a reducer needs every gradient of a layer enqueued before done())
             for li in range(n_layers - 1, -1, -1):
                 layer = getattr(block, "denselayer%d" % (li + 1))
                 cin = c0 + li * self.growth
@@ -688,14 +698,34 @@ class _Engine:
                     ev_ = w1_done.pop(k - 2)
                     if not fused:
                         main.wait_event(ev_)
+                dyc = ws.dyc[bi][li] if ws.dyc is not None else None
                 rows = ops.conv_gemm(gs, self.w_bwd(layer.conv2), dz2, N=self.mid, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=xs,
                                      pa=qa, pb=qb, pc=qc, epilogue=ops.EPI_MASK, ex=y1, e_sc=v(n2[0]), e_sh=v(n2[1]), e_mu=v(n2[2]),
-                                     e_r=v(n2[3]), e_scale=ws.ones[:self.mid], **self._sp(ws, S2, self.mid))
+                                     e_r=v(n2[3]), e_scale=ws.ones[:self.mid], pro_out=dyc, **self._sp(ws, S2, self.mid))
                 red2 = self._sc(ws, S2, self.mid, rows)
-                side.wait_event(ev_q)
-                with torch.cuda.stream(side):
-                    ops.conv_wgrad(gs, y1, G(layer.conv2.weight), kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa,
-                                   gb=qb, gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
+                if dyc is not None and ops.last_pro_out():
+                    # the input-gradient kernel left the corrected slice as a dense (M, 32) tensor: the weight gradient reads 64
+                    # contiguous bytes per pixel instead of two 64-byte pieces of the block buffers' rows (half of every line wasted)
+                    def w2_launch(dyc=dyc, y1=y1, wgt=layer.conv2.weight, n2=n2):
+                        with torch.cuda.stream(side):
+                            ops.conv_wgrad(dyc, y1, G(wgt), kh=3, kw=3, pad=1, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
+                    if dense_dy_lag:
+                        # one layer behind: it then runs beside the NEXT layer's 3x3 input gradient (as the strided form does beside
+                        # its own), not beside the bandwidth-bound fused 1x1 backward
+                        if w2_pending is not None:
+                            side.wait_event(ev_q)
+                            w2_pending()
+                        w2_pending = w2_launch
+                    else:
+                        ev_d = torch.cuda.Event()
+                        ev_d.record(main)
+                        side.wait_event(ev_d)
+                        w2_launch()
+                else:
+                    side.wait_event(ev_q)
+                    with torch.cuda.stream(side):
+                        ops.conv_wgrad(gs, y1, G(layer.conv2.weight), kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa,
+                                       gb=qb, gc=qc, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
                 pa, pb, pc = (v(t) for t in s["pl"][bi][li])
                 ops.bn_bwd_coef(red2[0], red2[1], cnt, layer.norm2.weight, v(n2[2]), v(n2[3]), G(layer.norm2.weight),
                                 G(layer.norm2.bias), None, None, pa, pb, pc, self.mid, replicas=red2[2], rstride=red2[3])
@@ -726,6 +756,11 @@ class _Engine:
                     main.wait_event(w1_done[k])
                 k += 1
                 done(layer.norm1.weight)      # every gradient from this layer to the end of the buffer is final
+            if w2_pending is not None:
+                ev_d = torch.cuda.Event()
+                ev_d.record(main)
+                side.wait_event(ev_d)
+                w2_pending()
             # the block's first c0 channels were produced by the previous transition (or the stem)
             qa, qb, qc = (v(t)[:c0] for t in q)               # written by layer 0's norm1 coefficient launch
             gs, xs = gbuf[..., :c0], buf[..., :c0]

@@ -168,10 +168,15 @@ def last_stat_rows():
     return lib().cx_last_stat_rows()
 
 
+def last_pro_out():
+    """True when the last conv_gemm of this thread wrote its `pro_out` side tensor (the selected kernel supports it)."""
+    return bool(lib().cx_last_pro_out())
+
+
 def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
                  pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
                  e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1, stat_replicas=1, stat_rstride=0,
-                 stat_det=False):
+                 stat_det=False, pro_out=None):
     require_cuda(x, w_packed, y)
     p = CxConv()
     B, H, W, Cx, ldx = _nhwc(x)
@@ -198,7 +203,11 @@ def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CO
         assert ex.shape == y.shape
         p.ex, p.ldex = ptr(ex), _nhwc(ex)[4]
     p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale = ptr(e_sc), ptr(e_sh), ptr(e_mu), ptr(e_r), ptr(e_scale)
-    p._keep = (x, w_packed, y, pa, pb, pc, x2, stat_sum, stat_sq, ex, e_sc, e_sh, e_mu, e_r, e_scale)      # keep the views alive
+    if pro_out is not None:              # dense side output of the prologue (CxConv.pro_out); last_pro_out() says whether it was written
+        require_cuda(pro_out)
+        assert pro_out.dtype == x.dtype and tuple(pro_out.shape) == tuple(x.shape)
+        p.pro_out, p.ldpo = ptr(pro_out), _nhwc(pro_out)[4]
+    p._keep = (x, w_packed, y, pa, pb, pc, x2, stat_sum, stat_sq, ex, e_sc, e_sh, e_mu, e_r, e_scale, pro_out)      # keep the views alive
     return p
 
 

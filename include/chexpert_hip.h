@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 6
+#define CX_ABI_VERSION 7
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4, CX_ESTATROWS = -5 };
 
@@ -82,6 +82,14 @@ typedef struct CxConv {
                          /* consumer sums exactly those rows in row order (cx_bn_coef / cx_bn_bwd_coef with      */
                          /* replicas = rows): bit-identical results from run to run.  No zero-fill is needed      */
   int32_t dtype;         /* CX_DT_BF16 (0) or CX_DT_F32: x, x2, y, ex are fp32, w is fp32 [tap][N][K]; K, N, ld* % 4 */
+  /* ABI 7.  Optional side output of the prologue: the transformed input (what the convolution actually consumes, e.g. the     */
+  /* dense-layer output gradient after the deferred BatchNorm correction) stored as a dense bf16 (B,H,W,ldpo) tensor, K        */
+  /* channels per pixel.  The 3x3 weight gradient of the same layer then reads ONE dense 64-byte row per pixel               */
+  /* (g_prologue NONE) instead of two 64-byte pieces of 512..2048-byte rows of the block buffers.  Kernels that cannot        */
+  /* write it ignore the field: cx_last_pro_out() says whether the last cx_conv_gemm of this thread did.                     */
+  void* pro_out;
+  int32_t ldpo;
+  int32_t pad_;
 } CxConv;
 
 /* Weight gradient of the same convolution:  dW[n][c][ky][kx] += sum_m G[m][n] * A[m@tap][c]
@@ -129,6 +137,7 @@ int cx_last_slab_floats(void);
 int cx_dw_reduce_table(const CxReduceDesc* table_dev, int n, int64_t total_blocks, void* stream);
 
 int cx_abi_version(void);
+int cx_last_pro_out(void);      /* 1: the last cx_conv_gemm of the calling thread wrote CxConv.pro_out */
 const char* cx_error_string(int code);
 /* name of the kernel instantiation the most recent cx_conv_gemm / cx_conv1x1_dgrad_wgrad* / cx_conv_wgrad call of this thread
  * dispatched to, spelled as rocprofv3 lists it (e.g. "pw_bwd2_kernel<2, true, 0>"; a stride-2 input gradient that runs as up to

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libchexpert_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.lib().cx_abi_version() == 6
+    assert _lib.lib().cx_abi_version() == 7
     assert _lib.lib().cx_error_string(-3) == b"unsupported shape"
     # every binding passes exactly the parameters the header declares (a short argtypes list makes ctypes pass the rest as 32-bit
     # ints: truncated device pointers, i.e. a GPU memory fault instead of an error)
