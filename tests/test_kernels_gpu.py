@@ -186,6 +186,46 @@ def test_dgrad_affine2_mask_epilogue(dev, ksz, K, N, acc, B, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,ring", [(3, 10, 80, True), (2, 9, 40, True), (5, 20, 20, True), (2, 10, 10, True), (2, 3, 3, False)])
+def test_dgrad_3x3_dense_side_output_of_the_prologue(dev, B, H, W, ring):
+    """CxConv.pro_out (ABI 7): the 3x3 input-gradient kernel of a dense layer also stores its prologue result -- the gradient slice
+    after the deferred BatchNorm correction -- as a dense (M, 32) tensor, bit-equal to the bf16 rounding of the fp32 expression,
+    and the weight gradient computed from it (g_prologue NONE) equals the one computed from the two strided slices (AFFINE2).
+    Kernels without the side output leave the tensor alone and say so (last_pro_out)."""
+    from chexpert_amd import ops
+    K, N = 32, 128
+    ub, u = nhwc_buf(40, B, H, W, K + 96, dev)            # slices of wider buffers, as in a dense block
+    vb, v = nhwc_buf(41, B, H, W, K + 96, dev)
+    exb, ex = nhwc_buf(42, B, H, W, N, dev)
+    w = bf(rnd(43, (K, N, 3, 3), -0.1, 0.1))
+    pa, pb, pc = rnd(44, (K,), 0.5, 1.5), rnd(45, (K,), -0.3, 0.3), rnd(46, (K,), -0.2, 0.2)
+    ones, zeros = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    out = torch.zeros(B, H, W, N, dtype=torch.bfloat16, device=dev)
+    side = torch.full((B, H, W, K), 7.0, dtype=torch.bfloat16, device=dev)
+    s1, s2 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    us, vs = ub[..., 64:64 + K], vb[..., 64:64 + K]
+    ops.conv_gemm(us, ops.pack_weights(w.to(dev), transpose=True), out, N=N, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=vs,
+                  pa=pa.to(dev), pb=pb.to(dev), pc=pc.to(dev), epilogue=ops.EPI_MASK, ex=exb, e_sc=ones, e_sh=ones * 100, e_mu=zeros,
+                  e_r=ones, e_scale=ones, stat_sum=s1, stat_sq=s2, pro_out=side)
+    assert ops.last_pro_out() == ring
+    if not ring:
+        assert (side == 7.0).all().item()
+        return
+    cv = lambda t: t.view(1, 1, 1, -1).to(dev)
+    want = torch.addcmul(torch.addcmul(cv(pc), vs.float(), cv(pb)), us.float(), cv(pa)).to(torch.bfloat16)   # fmaf(u, a, fmaf(v, b, c))
+    assert (side.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()    # (one bf16 ulp: fma contraction)
+    assert (side == want).float().mean().item() > 0.99
+    # the weight gradient from the dense tensor against the one from the strided pair
+    y1b, _ = nhwc_buf(47, B, H, W, N, dev)
+    pa2, pb2 = rnd(48, (N,), 0.5, 1.5).to(dev), rnd(49, (N,), -0.3, 0.3).to(dev)
+    dw_a, dw_b = torch.zeros(K, N, 3, 3, device=dev), torch.zeros(K, N, 3, 3, device=dev)
+    ops.conv_wgrad(us, y1b, dw_a, kh=3, kw=3, pad=1, g_prologue=ops.PRO_AFFINE2, g2=vs, ga=pa.to(dev), gb=pb.to(dev), gc=pc.to(dev),
+                   x_prologue=ops.PRO_AFFINE_RELU, pa=pa2, pb=pb2)
+    ops.conv_wgrad(side, y1b, dw_b, kh=3, kw=3, pad=1, x_prologue=ops.PRO_AFFINE_RELU, pa=pa2, pb=pb2)
+    close(dw_b.cpu(), dw_a.cpu(), rel=2e-3, what="dW from the dense slice")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pro,acc", [(2, True), (0, False)])
 def test_dgrad_1x1_many_tiles_replicated_stats(dev, pro, acc):
     """The dZ-resident 1x1 input-gradient kernel with several N tiles per workgroup (grid large enough for 4), a partial
