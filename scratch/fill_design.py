@@ -7,6 +7,12 @@ rows = {'aad': '| aadensenet121 bs=128 |', 'rn': '| resnet152 bs=128 |', 'ef': '
 for a in sys.argv[1:]:
     k, f = a.split('=')
     d = json.load(open(f))
+    if k == 'dn':                       # the committed DenseNet121 line: last row of the stage table
+        i = s.index('| + dense corrected gradient slices'); j = s.index('\n', i)
+        cells = s[i:j].rstrip(' |').split(' | ')
+        cells[-3:] = ['**%d**' % round(d['value']), '**%.2f**' % d['ms_per_step'], '**%.1f %%**' % (100 * d['config']['model_hbm_roofline_frac'])]
+        s = s[:i] + ' | '.join(cells) + ' |' + s[j:]
+        continue
     img, ms, fr = "%d" % round(d['value']), "%.1f" % d['ms_per_step'], "%.1f %%" % (100 * d['config']['model_hbm_roofline_frac'])
     i = s.index(rows[k]); j = s.index('\n', i)
     line = s[i:j]
