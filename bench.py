@@ -251,7 +251,10 @@ def main():
     local_dev = local if backend == "nccl" else local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    # CHEXPERT_BENCH_FORCE_DP=1 (under torch.distributed.run --nproc-per-node 1): the data-parallel code path -- reducer, RCCL
+    # all-reduce launches between the graph segments -- on a communicator of ONE rank: what a one-GPU box can rehearse of it
+    dp = world > 1 or os.environ.get("CHEXPERT_BENCH_FORCE_DP") == "1"
+    if dp:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -289,7 +292,7 @@ def main():
         return model.forward_backward(x, t)
 
     log("model + data ready")
-    if world > 1:                               # replicas start identical and average their gradients from the first step on
+    if dp:                                      # replicas start identical and average their gradients from the first step on
         from chexpert_amd.parallel import broadcast_module_state
         model._eng().bind(dev)
         broadcast_module_state(model)
@@ -341,21 +344,42 @@ def main():
     # launches of a step cost ~18 ms of host time when enqueued one by one.  N > 1 enqueues eagerly (RCCL collectives are
     # issued from Python between the kernels).  HIP events cannot be recorded inside a captured graph, so the dominant
     # kernel's launch time is taken with events in an eager replica of the same K steps right after the timed region.
-    use_graph = (world == 1 and opt is not None and not args.no_graph and os.environ.get("CHEXPERT_BENCH_GRAPH", "1") != "0"
-                 and not args.model.startswith("efficientnet"))
+    use_graph = opt is not None and not args.no_graph and os.environ.get("CHEXPERT_BENCH_GRAPH", "1") != "0"
     gstep = None
     if use_graph:
-        from chexpert_amd.graph import GraphedTrainStep
+        # N > 1: the same step as a chain of graph segments cut where a gradient bucket is complete; the all-reduces between
+        # them are enqueued from Python exactly as in the eager step (graph.SegmentedTrainStep)
+        from chexpert_amd.graph import GraphedTrainStep, SegmentedTrainStep
         timer.enabled = False
         try:
-            gstep = GraphedTrainStep(model, opt, x, t)
+            gstep = GraphedTrainStep(model, opt, x, t) if not dp else SegmentedTrainStep(model, opt, x, t)
             for _ in range(max(1, args.warmup)):
                 gstep.replay()
             torch.cuda.synchronize()
-            log("hipGraph captured and warmed up")
+            log("hipGraph captured and warmed up" + ("" if not dp else " (%d segments)" % len(gstep.segs)))
+            if dp:
+                # Both forms issue the same kernels and collectives; which is faster depends on how the backend's collectives
+                # share the queues with the replayed segments -- measured here on a few steps, decided for all ranks alike
+                def timed(fn, n):
+                    barrier()
+                    a = time.perf_counter()
+                    fn(n)
+                    torch.cuda.synchronize()
+                    tt_ = torch.tensor([time.perf_counter() - a], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    return tt_.item() / n
+                n_probe = max(2, min(5, args.warmup))
+                t_seg = timed(lambda n: [gstep.replay() for _ in range(n)], n_probe)
+                opt.sync_from_device()
+                t_eag = timed(eager_steps, n_probe)
+                log("probe: %.1f ms/step as graph segments, %.1f ms/step enqueued eagerly" % (t_seg * 1e3, t_eag * 1e3))
+                if t_eag < t_seg:
+                    gstep = None
         except Exception as e:                   # capture is an optimisation of the host side only: fall back loudly
             log("graph capture failed (%s: %s); timing the eager step" % (type(e).__name__, e))
             gstep = None
+            if dp:                               # (ranks that captured ran their warm-up replays, collectives included)
+                eager_steps(max(1, args.warmup))
     barrier()
     t0 = time.perf_counter()
     if gstep is not None:
@@ -364,16 +388,16 @@ def main():
     else:
         # N = 1 eager (--no-graph): the dominant kernel's events are taken inside the timed region.  N > 1: nothing but the step
         # runs between the barriers; the events come from an eager replica afterwards, as for the graph
-        timer.enabled, timer.only = world == 1, only
+        timer.enabled, timer.only = not dp, only
         loss = eager_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     log("timed region done: %.1f ms/step (%s)" % (dt / args.steps * 1e3, "graph replay" if gstep is not None else "eager"))
-    if gstep is not None or world > 1:
+    if gstep is not None or dp:
         if gstep is not None:
             opt.sync_from_device()
         timer.enabled, timer.only, timer.records = True, only, {}
@@ -416,22 +440,27 @@ def main():
                            args.model] / (HBM_PEAK_GBS * 1e9), 4),
                        "optimizer_step_ms": round(opt_ms, 3), "loss": round(float(loss.item()), 5),
                        "measured_copy_GBs": round(copy_gbs, 1),
-                       "launch": "hipGraph replay" if gstep is not None else "eager enqueue"},
+                       "launch": ("hipGraph replay" if not dp else "hipGraph segments between the all-reduces") if gstep is not None else "eager enqueue"},
             "roofline": {"bound": "hbm", "kernel": only, "launches_per_step": ksum["launches"] // args.steps,
                          "avg_launch_ms": round(avg_ms, 4), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(only, args), "alg_bytes_per_launch": round(ksum["alg_bytes"] / ksum["launches"]),
                          "mfma_util": committed_counter(only, args, "mfma_util"),
-                         "timing": "hip events around each kernel launch (a slab reduce behind it excluded), eager replica of the timed steps" if (gstep is not None or world > 1)
+                         "timing": "hip events around each kernel launch (a slab reduce behind it excluded), eager replica of the timed steps" if (gstep is not None or dp)
                          else "hip events around each kernel launch (a slab reduce behind it excluded) inside the timed region"},
         }
         if not args.no_cpu_baseline and args.model == "densenet121" and args.dtype == "bf16" and world == 1:
             log("cpu baseline on %d cores ..." % host_cores())
             out["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.barrier()                 # rank 0 is still measuring the copy bandwidth / printing: leave together
         dist.destroy_process_group()
+    from chexpert_amd import graph as _graph
+    if _graph.FAILED_CAPTURES:         # a failed capture's graph objects must not be torn down by the interpreter (see graph.py)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -150,6 +150,8 @@ SIGNATURES = {
     "cx_scale_rows": [_vp, _vp, _sz, _vp, _sz, _i, _vp],
     "cx_scale_rows_f32": [_vp, _vp, _sz, _vp, _sz, _i, _vp],
     "cx_dropout_mask": [_vp, _sz, _f, C.c_ulonglong, _vp],
+    "cx_dropout_mask_dev": [_vp, _sz, _f, C.c_ulonglong, _vp, _vp],
+    "cx_counter_add": [_vp, C.c_ulonglong, _vp],
     "cx_mul_f32": [_vp, _vp, _vp, _sz, _vp],
     "cx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_gradcam_map": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

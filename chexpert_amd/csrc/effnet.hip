@@ -753,6 +753,23 @@ __global__ void dropout_mask_kernel(float* __restrict__ out, size_t n, float kee
   out[i] = u < keep ? 1.f / keep : 0.f;
 }
 
+// the same with the seed assembled on the device: seed = base + step * 1000003, step read from device memory (a captured graph
+// draws fresh masks at every replay)
+__global__ void dropout_mask_dev_kernel(float* __restrict__ out, size_t n, float keep, unsigned long long base,
+                                        const unsigned long long* __restrict__ step) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = base + step[0] * 1000003ull + 0x9E3779B97F4A7C15ull * (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  out[i] = u < keep ? 1.f / keep : 0.f;
+}
+__global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += inc;
+}
+
 __global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] * b[i];
@@ -1145,6 +1162,18 @@ int cx_scale_rows_f32(const void* g, const float* sample_scale, size_t rows_per_
 int cx_dropout_mask(float* out, size_t n, float keep_prob, unsigned long long seed, void* stream) {
   if (!out || !(keep_prob > 0.f) || keep_prob > 1.f) return CX_EINVAL;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), out, n, keep_prob, seed);
+  return launch_status();
+}
+
+int cx_dropout_mask_dev(float* out, size_t n, float keep_prob, unsigned long long base, const unsigned long long* step, void* stream) {
+  if (!out || !step || !(keep_prob > 0.f) || keep_prob > 1.f) return CX_EINVAL;
+  hipLaunchKernelGGL(dropout_mask_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), out, n, keep_prob, base, step);
+  return launch_status();
+}
+
+int cx_counter_add(unsigned long long* counter, unsigned long long inc, void* stream) {
+  if (!counter) return CX_EINVAL;
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, as_stream(stream), counter, inc);
   return launch_status();
 }
 

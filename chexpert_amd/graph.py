@@ -21,8 +21,8 @@ class GraphedTrainStep:
         eng = model._eng()
         if getattr(eng, "reducer", None) is not None:
             raise RuntimeError("graph capture of the data-parallel step is not supported (collectives are enqueued eagerly)")
-        if any(getattr(m_, "p", 0) for m_ in model.modules() if type(m_).__name__ == "DropMarker"):
-            raise RuntimeError("graph capture would freeze the Dropout / DropConnect seeds (host-drawn per step); use the eager step")
+        # (Dropout / DropConnect masks: their step counter lives in device memory and is bumped inside the captured step --
+        # efficientnet.py, cx_dropout_mask_dev -- so every replay draws new masks)
         model.train()
         # construction is free of side effects on the model: the warm-up steps below really run (they update BatchNorm running
         # statistics), so the module buffers and the num_batches_tracked bookkeeping are put back afterwards
@@ -69,4 +69,115 @@ class GraphedTrainStep:
         if hasattr(eng, "packed_version"):
             eng.packed_version = None
         self.model._nbt_pending += 1           # BatchNorm num_batches_tracked is host-side bookkeeping (flushed by state_dict())
+        return self.loss, self.logits
+
+
+FAILED_CAPTURES = []
+
+
+class SegmentedTrainStep:
+    """The data-parallel training step as a CHAIN of hipGraphs.
+
+    Collectives are enqueued from Python (parallel.GradReducer), so the whole step cannot be one graph.  Enqueued launch by
+    launch it pays a dependent-launch gap at every kernel boundary that a graph does not have: 37.7 ms instead of 30.3 ms per
+    DenseNet121 step on one MI355X, 66.5 instead of 56.6 for ResNet152 (bench.py's eager replica against its graph replay).
+    Here the step is captured once with the reducer in capture mode: wherever backward completes a gradient bucket
+    (`GradReducer.ready`) the capture is cut, so a replay is
+
+        segment 0 (zero_grad, forward, loss, backward up to bucket 0) -> all-reduce(bucket 0) on the reducer's stream
+        segment 1 (backward up to bucket 1)                            -> all-reduce(bucket 1) ...
+        ...                                                            -> wait for the collectives
+        last segment (whatever backward does after the join, optimiser step, scheduler tick)
+
+    with the same launches, the same order and the same collectives as the eager data-parallel step: the kernels between two
+    cuts run as a graph, the all-reduces overlap the following segments as before.  All segments share one memory pool."""
+
+    def __init__(self, model, optimizer, x, target, warmup_steps=0, warmup_iters=2):
+        if not x.is_cuda:
+            raise RuntimeError("SegmentedTrainStep needs device tensors (no CPU path)")
+        eng = model._eng()
+        red = getattr(eng, "reducer", None)
+        if red is None:
+            raise RuntimeError("SegmentedTrainStep is the data-parallel form (engine.enable_data_parallel() first); a single process uses GraphedTrainStep")
+        self.model, self.opt, self.red = model, optimizer, red
+        self.x, self.target = x.clone(), target.clone()
+        model.train()
+        saved = [(b, b.detach().clone()) for b in model.buffers()]
+        nbt = getattr(model, "_nbt_pending", 0)
+        s = torch.cuda.Stream(device=x.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(max(1, warmup_iters)):                  # eager warm-up: real collectives, every rank alike
+                model.zero_grad()
+                self.loss, self.logits = model.forward_backward(self.x, self.target)
+            if optimizer is not None:
+                optimizer._bufs(2 if hasattr(optimizer, "betas") or hasattr(optimizer, "alpha") else 1)
+                optimizer.hyper(warmup_steps)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.segs = []                                              # [(graph, actions)]; an action: ("launch", lo, hi) | ("finish",)
+        self._pool = torch.cuda.graph_pool_handle()
+        self._g = None
+        red.capture = self
+        try:
+            with torch.cuda.stream(s):
+                self._begin()
+                model.zero_grad()
+                self.loss, self.logits = model.forward_backward(self.x, self.target)
+                if optimizer is not None:
+                    optimizer.step_dev()
+                    optimizer.tick()
+                self._g.capture_end()
+                self.segs.append((self._g, ()))
+                self._g = None
+        except BaseException:
+            # leave capture mode before the caller falls back to the eager step; the graph objects of a failed capture are parked
+            # for the life of the process (destroying one while the runtime still counts the stream as capturing aborts)
+            if self._g is not None:
+                try:
+                    self._g.capture_end()
+                except Exception:
+                    pass
+            FAILED_CAPTURES.append((self._g, self.segs))
+            self._g, self.segs = None, []
+            raise
+        finally:
+            red.capture = None
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.no_grad():
+            for b, v in saved:
+                b.copy_(v)
+        if hasattr(model, "_nbt_pending"):
+            model._nbt_pending = nbt
+        self.replays = 0
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self._pool)
+
+    def cut(self, *actions):
+        """Called by the reducer in capture mode: end the current segment here; `actions` run at this point of every replay."""
+        self._g.capture_end()
+        self.segs.append((self._g, actions))
+        self._begin()
+
+    def replay(self, x=None, target=None):
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        red = self.red
+        red.begin()
+        for g, actions in self.segs:
+            g.replay()
+            for action in actions:
+                if action[0] == "launch":
+                    red._launch(action[1], action[2])
+                else:
+                    red.wait()
+        self.replays += 1
+        eng = self.model._eng()
+        if hasattr(eng, "packed_version"):
+            eng.packed_version = None
+        self.model._nbt_pending += 1
         return self.loss, self.logits

@@ -585,8 +585,8 @@ class _Engine:
     def backward(self, ws, dlogits):
         ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
         # the ordered sums of the weight-gradient slabs run as ONE table-driven launch at the end of the pass (ops.wgrad_defer_*);
-        # data-parallel runs keep the immediate sums: their buckets leave while backward is still running
-        deferred = self.reducer is None and os.environ.get("CHEXPERT_WGRAD_DEFER", "1") != "0" and ops.wgrad_defer_begin(self.device)
+        # a data-parallel run flushes them before each gradient bucket leaves (GradReducer.pre_launch)
+        deferred = os.environ.get("CHEXPERT_WGRAD_DEFER", "1") != "0" and ops.wgrad_defer_begin(self.device)
         try:
             self._backward(ws, dlogits)
             if deferred:
@@ -820,6 +820,8 @@ class _Engine:
         if self.flat_grad is None:
             raise RuntimeError("bind the engine first (run one forward)")
         self.reducer = GradReducer(self.flat_grad, bucket_bytes, group)
+        # the deferred weight-gradient slab sums (ops.wgrad_defer_*) run before each bucket leaves, so that the bucket is final
+        self.reducer.pre_launch = lambda: ops.wgrad_defer_flush(self.device, keep=True)
 
 
 class _Fn(torch.autograd.Function):

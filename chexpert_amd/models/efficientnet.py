@@ -12,7 +12,7 @@ Schedule per MBConv block (NHWC bf16):
   -> SE: global pool of swish(bn(.)), two tiny FCs -> u = swish(bn(y_d)) * s[b][c] (one pass)
   -> project 1x1 (implicit GEMM) -> x_out = bn(y_p) (+ x_in).
 DropConnect (efficientnet.py:44-51, :100-101) and the classifier Dropout (:169-171) are applied in train mode: per-image /
-per-element keep masks drawn on the GPU by `cx_dropout_mask` from (model.drop_seed, forward counter, block) -- reproducible and
+per-element keep masks drawn on the GPU by `cx_dropout_mask_dev` from (model.drop_seed, device-side count of training forwards, block) -- reproducible and
 independent of torch's RNG; the parity tests feed the drawn masks (`engine.last_masks`) to the oracle.
 """
 import math
@@ -301,6 +301,12 @@ class _Engine:
         self.last_masks = {}
         self.n_forward = getattr(self, "n_forward", 0) + 1
         ws.step = self.n_forward
+        if train:
+            # the masks' step counter lives in device memory and is bumped by a kernel: a captured step (graph.py) draws new
+            # Dropout / DropConnect masks at every replay, and the eager step draws the same ones
+            if getattr(self, "step_dev", None) is None or self.step_dev.device != x.device:
+                self.step_dev = torch.zeros(1, dtype=torch.int64, device=x.device)
+            check(lb.cx_counter_add(ptr(self.step_dev), 1, stream_ptr()), "cx_counter_add")
         det = self.det and train
         if train and not det:
             z0, zn = self.fwd_zero
@@ -355,7 +361,7 @@ class _Engine:
             t["dc"] = None
             if p_dc > 0.0:
                 t["dc"] = torch.empty(B, dtype=torch.float32, device=self.device)
-                check(lb.cx_dropout_mask(ptr(t["dc"]), B, 1.0 - p_dc, self._seed(ws, bi), sp), "cx_dropout_mask")
+                check(lb.cx_dropout_mask_dev(ptr(t["dc"]), B, 1.0 - p_dc, self._seed_base(bi), ptr(self.step_dev), sp), "cx_dropout_mask_dev")
                 self.last_masks[self.mb_names[bi]] = t["dc"]
             check(lb.cx_affine2_out(ptr(t["yp"]), ptr(xin) if c["skip"] else None, ptr(v(ws, Sp.sc)), ptr(v(ws, self.ones)),
                                     ptr(v(ws, Sp.sh)), ptr(t["dc"]), ho * wo, ptr(t["out"]), B * ho * wo, c["cout"], sp), "cx_affine2_out")
@@ -372,7 +378,8 @@ class _Engine:
         fc_in = ws.pooled
         if p_do > 0.0:
             ws.drop = torch.empty(B, 1280, dtype=torch.float32, device=self.device)
-            check(lb.cx_dropout_mask(ptr(ws.drop), B * 1280, 1.0 - p_do, self._seed(ws, len(self.mb)), sp), "cx_dropout_mask")
+            check(lb.cx_dropout_mask_dev(ptr(ws.drop), B * 1280, 1.0 - p_do, self._seed_base(len(self.mb)), ptr(self.step_dev), sp),
+                  "cx_dropout_mask_dev")
             ws.pooled_d = torch.empty_like(ws.pooled)
             check(lb.cx_mul_f32(ptr(ws.pooled), ptr(ws.drop), ptr(ws.pooled_d), B * 1280, sp), "cx_mul_f32")
             fc_in = ws.pooled_d
@@ -384,9 +391,10 @@ class _Engine:
             m._nbt_pending += 1
         return ws
 
-    def _seed(self, ws, idx):
-        """64-bit seed of the mask of block `idx` in this forward: (model seed, forward counter, block)."""
-        return (int(self.model.drop_seed) * 0x9E3779B1 + ws.step * 1000003 + idx * 7919 + 12345) & 0xFFFFFFFFFFFFFFFF
+    def _seed_base(self, idx):
+        """Host part of the 64-bit seed of the mask of block `idx`: (model seed, block); the kernel adds the device-side count of
+        training forwards * 1000003."""
+        return (int(self.model.drop_seed) * 0x9E3779B1 + idx * 7919 + 12345) & 0xFFFFFFFFFFFFFFFF
 
     # ---- backward
     def _alloc_bwd(self, ws):
@@ -410,7 +418,7 @@ class _Engine:
 
     def backward(self, ws, dlogits):
         ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
-        deferred = self.det and self.reducer is None and ops.wgrad_defer_begin(self.device)
+        deferred = self.det and ops.wgrad_defer_begin(self.device)
         try:
             self._backward(ws, dlogits)
             if deferred:
@@ -539,7 +547,10 @@ class _Engine:
         check(lb.cx_se_act_bwd(ptr(bw["g0"]), ptr(ws.ys), ptr(v(ws, S0.sc)), ptr(v(ws, S0.sh)), ptr(v(ws, S0.mean)), ptr(v(ws, S0.rstd)), None,
                                None, ptr(dzs), *ssp(S0)[:2], B, hs * wsz, c0, ssp(S0)[2], sp), "cx_se_act_bwd")
         bn_bwd(S0, m.stem[1], B * hs * wsz)
-        dw8 = torch.zeros(c0, 8, 3, 3, dtype=torch.float32, device=self.device)
+        # (persistent: its address is part of the deferred slab-sum table, which must not change from step to step)
+        if getattr(ws, "dw8", None) is None:
+            ws.dw8 = torch.empty(c0, 8, 3, 3, dtype=torch.float32, device=self.device)
+        dw8 = ws.dw8.zero_()
         ops.conv_wgrad(dzs, ws.x8, dw8, kh=3, kw=3, stride=2, pad=ws.stem_pad, g_prologue=ops.PRO_AFFINE2, g2=ws.ys, ga=v(ws, S0.pa),
                        gb=v(ws, S0.pb), gc=v(ws, S0.pc))
         ops.wgrad_defer_flush(self.device)       # the stem gradient is read back right here: run the deferred slab sums now
@@ -555,6 +566,8 @@ class _Engine:
         if self.flat_grad is None:
             raise RuntimeError("bind the engine first (run one forward)")
         self.reducer = GradReducer(self.flat_grad, bucket_bytes, group)
+        # the deferred weight-gradient slab sums (ops.wgrad_defer_*) run before each bucket leaves, so that the bucket is final
+        self.reducer.pre_launch = lambda: ops.wgrad_defer_flush(self.device, keep=True)
 
 
 class _Fn(torch.autograd.Function):

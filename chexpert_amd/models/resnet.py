@@ -510,9 +510,9 @@ class _Engine:
 
     def backward(self, ws, dlogits):
         ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
-        # the ordered slab sums run as one table-driven launch at the end of the pass (ops.wgrad_defer_*); data-parallel runs keep
-        # the immediate sums (their buckets leave while backward is still running), and so does the CIFAR stem (read back at once)
-        deferred = self.det and self.reducer is None and not self.cifar and ops.wgrad_defer_begin(self.device)
+        # the ordered slab sums run as one table-driven launch at the end of the pass (ops.wgrad_defer_*); a data-parallel run
+        # flushes them before each gradient bucket leaves (GradReducer.pre_launch); the CIFAR stem keeps immediate sums (read back at once)
+        deferred = self.det and not self.cifar and ops.wgrad_defer_begin(self.device)
         try:
             self._backward(ws, dlogits)
             if deferred:
@@ -773,6 +773,8 @@ class _Engine:
         if self.flat_grad is None:
             raise RuntimeError("bind the engine first (run one forward)")
         self.reducer = GradReducer(self.flat_grad, bucket_bytes, group)
+        # the deferred weight-gradient slab sums (ops.wgrad_defer_*) run before each bucket leaves, so that the bucket is final
+        self.reducer.pre_launch = lambda: ops.wgrad_defer_flush(self.device, keep=True)
 
 
 class _Fn(torch.autograd.Function):

@@ -114,18 +114,20 @@ def _wgrad_used(a, deferred):
             lib().cx_wgrad_defer(1)
 
 
-def wgrad_defer_flush(device):
+def wgrad_defer_flush(device, keep=False):
     """Add every deferred slab to its dw (one launch on the current stream, which must have been joined with the producers) and
-    return to immediate sums."""
+    return to immediate sums -- or, with `keep`, go on deferring (a data-parallel backward flushes before each bucket's
+    all-reduce: the gradients of the bucket are then final, the slabs of the later layers keep collecting)."""
     a = _arenas.get(device.index)
     if a is None or not a.active:
         return
-    a.active = False
+    a.active = bool(keep)
     cap = 1024
     arr = (L.CxReduceDesc * cap)()
     blocks = C.c_int64(0)
     n = lib().cx_wgrad_defer_take(arr, cap, C.byref(blocks))
-    lib().cx_wgrad_defer(-1)
+    if not keep:
+        lib().cx_wgrad_defer(-1)
     if n < 0:
         raise RuntimeError("more than %d deferred weight-gradient sums" % cap)
     if n == 0:
@@ -133,8 +135,10 @@ def wgrad_defer_flush(device):
     key = bytes(memoryview(arr).cast("B")[:n * C.sizeof(L.CxReduceDesc)])
     t = a.tables.get(key)
     if t is None:
-        if len(a.tables) > 16:
+        if len(a.tables) > 256:
             a.tables.clear()
+        # (an upload from pageable memory: not legal while a hipGraph is being captured -- the tables of a captured step are those
+        # of the warm-up steps, every address in them is a persistent buffer)
         t = a.tables[key] = torch.frombuffer(bytearray(key), dtype=torch.uint8).to(device)
     check(lib().cx_dw_reduce_table(ptr(t), n, blocks.value, stream_ptr()), "cx_dw_reduce_table")
 

@@ -17,6 +17,9 @@ class GradReducer:
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # rehearsal on a one-GPU box: issue the collectives also on a communicator of one rank (bench.py CHEXPERT_BENCH_FORCE_DP)
+        import os
+        self.force = dist.is_initialized() and os.environ.get("CHEXPERT_FORCE_COLLECTIVES") == "1"
         self.bucket = max(1, bucket_bytes // flat_grad.element_size())
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
@@ -24,13 +27,24 @@ class GradReducer:
         self.hi = flat_grad.numel()
         self.works = []
         self.ranges = []
+        # set by graph.SegmentedTrainStep while it captures the step: a bucket that becomes complete does not start a collective,
+        # it CUTS the capture there (the collective is enqueued at that point of every replay)
+        self.capture = None
+        # called right before a bucket leaves (engine: run the deferred weight-gradient slab sums, so that the bucket is final)
+        self.pre_launch = None
 
     def begin(self):
         self.hi = self.flat.numel()
         self.works, self.ranges = [], []
 
     def _launch(self, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.force) or hi <= lo:
+            return
+        if self.pre_launch is not None:
+            self.pre_launch()
+        if self.capture is not None:
+            self.ranges.append((lo, hi))
+            self.capture.cut(("launch", lo, hi))
             return
         view = self.flat[lo:hi]
         self.ranges.append((lo, hi))
@@ -54,7 +68,21 @@ class GradReducer:
 
     def finish(self):
         """Flush the tail and make the reduced gradients visible to the compute stream."""
+        if self.capture is not None:
+            # (one cut for the tail bucket and the join: nothing is enqueued between them)
+            tail = (self.world > 1 or self.force) and self.hi > 0
+            if tail:
+                if self.pre_launch is not None:
+                    self.pre_launch()
+                self.ranges.append((0, self.hi))
+            self.capture.cut(*([("launch", 0, self.hi)] if tail else []), ("finish",))
+            self.hi = 0
+            return
         self.ready(0)
+        self.wait()
+
+    def wait(self):
+        """The part of finish() after the last launch: join the collectives (a segmented replay calls it between two segments)."""
         for w in self.works:
             w.wait()
         if self.cuda and self.works:

@@ -427,6 +427,10 @@ int cx_affine2_out_f32(const void* a, const void* b, const float* pa, const floa
                    size_t rows_per_sample, void* out, size_t rows, int C, void* stream);
 int cx_scale_rows_f32(const void* g, const float* sample_scale, size_t rows_per_sample, void* out, size_t rows, int C, void* stream);
 int cx_dropout_mask(float* out, size_t n, float keep_prob, unsigned long long seed, void* stream);
+/* ABI 7: the same mask with seed = base + step[0] * 1000003 assembled on the device, and the one-element counter bump that goes  */
+/* with it -- a captured training step (hipGraph) then draws new Dropout / DropConnect masks at every replay                  */
+int cx_dropout_mask_dev(float* out, size_t n, float keep_prob, unsigned long long base, const unsigned long long* step, void* stream);
+int cx_counter_add(unsigned long long* counter, unsigned long long inc, void* stream);
 int cx_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream);
 int cx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int N, void* stream);
 

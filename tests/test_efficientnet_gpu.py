@@ -184,6 +184,40 @@ def test_efficientnet_dropout_and_dropconnect_train_mode(dev):
     assert _rel(a.cpu(), b.cpu()) < 1e-2 and not eng.last_masks                  # (fp32 atomic pooling sums: not bitwise)
 
 
+def test_efficientnet_captured_step_draws_new_masks_at_every_replay(dev):
+    """graph.GraphedTrainStep on a network with Dropout / DropConnect: the masks' step counter lives in device memory and is bumped
+    inside the captured step (cx_counter_add, cx_dropout_mask_dev), so two replays on the same batch draw different masks, and the
+    masks of replay k are the ones the eager step draws at the same count of training forwards."""
+    from chexpert_amd.graph import GraphedTrainStep
+    from chexpert_amd.optim import FusedAdam
+    name, n_cls, B, S = "efficientnet-b0", 5, 8, 96
+    x, t = synth.xray_batch(1234, B, S).to(dev), synth.targets(99, B, n_cls).to(dev)
+    # eager: masks of training forwards 1..6
+    model_e, _ = _build(name, n_cls, 21, dev, stochastic=True)
+    model_e.train()
+    eager = []
+    for _ in range(6):
+        model_e.zero_grad()
+        model_e.forward_backward(x, t)
+        eager.append({k: v.detach().cpu().clone() for k, v in model_e._eng().last_masks.items()})
+    assert not torch.equal(eager[0]["head"], eager[1]["head"])
+    # captured: warm-up forwards, the capture pass (records, does not run) and then the replays
+    model_g, _ = _build(name, n_cls, 21, dev, stochastic=True)
+    gs = GraphedTrainStep(model_g, FusedAdam(model_g, lr=1e-4), x, t, warmup_iters=2)
+    eng = model_g._eng()
+    seen = []
+    for _ in range(3):
+        gs.replay()
+        torch.cuda.synchronize()
+        seen.append({k: v.detach().cpu().clone() for k, v in eng.last_masks.items()})
+    count = int(eng.step_dev.item())                       # training forwards so far on this engine (2 warm-up + 3 replays)
+    assert count == 5, count
+    assert not torch.equal(seen[0]["head"], seen[1]["head"]) and not torch.equal(seen[1]["head"], seen[2]["head"])
+    for k in range(3):                                     # replay k ran with counter 3 + k: the masks of the eager forward with that count
+        for name_, m in seen[k].items():
+            assert torch.equal(m, eager[2 + k][name_]), (k, name_)
+
+
 def test_efficientnet_uint8_input_path(dev):
     """SURVEY.md section 8f rank 1 for EfficientNet: decoded grey bytes in, whitening + channel expansion on the GPU."""
     model, sd = _build("efficientnet-b0", 5, 21, dev)
