@@ -315,10 +315,12 @@ def main(argv=None):
                 args.step += 1
                 if args.jitter:
                     x = jitter(x, args.step)
-                if args.graph and fused and world == 1 and (gstep is not None or x.shape[0] == args.batch_size):
+                if args.graph and fused and (gstep is not None or x.shape[0] == args.batch_size):
                     if gstep is None:                       # captured on the first full minibatch's shapes
-                        from .graph import GraphedTrainStep
-                        gstep = GraphedTrainStep(model, optimizer, x, t, warmup_steps=int(args.lr_warmup_steps))
+                        # (data-parallel: graph segments cut at the gradient buckets, the all-reduces enqueued between them)
+                        from .graph import GraphedTrainStep, SegmentedTrainStep
+                        gstep = (GraphedTrainStep if world == 1 else SegmentedTrainStep)(model, optimizer, x, t,
+                                                                                          warmup_steps=int(args.lr_warmup_steps))
                     if x.shape[0] == args.batch_size:
                         loss, _ = gstep.replay(x, t)
                     else:                                   # same device-resident optimiser / scheduler state, launched one by one
