@@ -153,7 +153,8 @@ class SegmentedTrainStep:
 
     def _begin(self):
         self._g = torch.cuda.CUDAGraph()
-        self._g.capture_begin(pool=self._pool)
+        # thread_local: the process group's watchdog / proxy threads may query events while this thread captures
+        self._g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
 
     def cut(self, *actions):
         """Called by the reducer in capture mode: end the current segment here; `actions` run at this point of every replay."""
