@@ -13,7 +13,7 @@ MODELS = {
     "densenet121": (lambda: densenet121(num_classes=14), 320, 256, 30.8),
     "aadensenet121": (lambda: DenseNet(32, (6, 12, 24, 16), 64, num_classes=14, attn_params=ATT(320)), 320, 128, 30.9),
     "resnet152": (lambda: resnet152(num_classes=14), 320, 128, 56.6),
-    "efficientnet-b4": (lambda: construct_model("efficientnet-b4", 14), 380, 64, 40.5),
+    "efficientnet-b4": (lambda: construct_model("efficientnet-b4", 14), 380, 64, 36.9),
 }
 for name, (ctor, S, B, gpu_ms) in MODELS.items():
     m = ctor().to(dev).train()
