@@ -299,7 +299,12 @@ constexpr int ST_G_BYTES = PX * ST_GP;
 constexpr int ST_X_BYTES = PX * ST_XP;
 constexpr int ST_STAGE = ST_G_BYTES + 7 * ST_X_BYTES;
 
-template <int GPRO>
+// STRIP (Wo a multiple of 32: a step is 32 consecutive outputs of ONE image row): the seven input rows of the step are staged
+// once as flat 72-pixel strips (8 B per pixel) and the MFMA operand of output pixel px is the strip read at a pitch of 16 B --
+// rows that overlap by six pixels -- instead of 32 separate 8-pixel windows per row (14 KB through L1 per step; 4 KB now, one
+// 16-B chunk per thread).
+constexpr int ST_SROW = 36 * 16;            // strip row: 72 pixels
+template <int GPRO, bool STRIP>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const int M, const int steps_per_split,
                                                          float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -331,6 +336,17 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const 
       rg = *reinterpret_cast<const uint4*>(Gp + (size_t)mc * p.ldg + gcq * 8);
       if (GPRO == CX_PRO_AFFINE2) rg2 = *reinterpret_cast<const uint4*>(G2 + (size_t)mc * p.ldg2 + gcq * 8);
     }
+    if (STRIP) {
+      const int cc = tid < 252 ? tid : 0;
+      const int tap = cc / 36, q = cc - tap * 36;
+      const int b = mbase / hw;
+      const int rem = mbase - b * hw;
+      const int oy = rem / p.Wo, ox0 = rem - oy * p.Wo;
+      const int iy = 2 * oy - 3 + tap, ix = 2 * ox0 - 4 + 2 * q;
+      xv[0] = tid < 252 && mbase < M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int cy = xv[0] ? iy : 0, cx = xv[0] ? ix : 0;
+      rx[0] = *reinterpret_cast<const uint4*>(X + ((size_t)(b * p.H + cy) * p.W + cx) * 4);
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ci = tid + 256 * i;                // < 896 for i < 3; i == 3 only for tid < 128
@@ -363,6 +379,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const 
       for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), ga[j], fmaf(bf2f(v.e[j]), gb[j], gc[j])));
     }
     *reinterpret_cast<uint4*>(Gt + grow * ST_GP + gcq * 16) = o.u;
+    if (STRIP) {
+      if (tid < 252) *reinterpret_cast<uint4*>(Xt + tid * 16) = xv[0] ? rx[0] : make_uint4(0, 0, 0, 0);     // [tap][36 chunks]
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ci = tid + 256 * i;
@@ -400,7 +419,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const 
         for (int t = 0; t < 2; ++t) {
           const int tap = wave + 4 * t;
           if (tap < 7) {
-            const bf16x8 bfr = tr_frag(Xt + tap * ST_X_BYTES, ST_XP, kk * 16, 0, lane);
+            const bf16x8 bfr = STRIP ? tr_frag(Xt + tap * ST_SROW, 16, kk * 16, 0, lane)
+                                     : tr_frag(Xt + tap * ST_X_BYTES, ST_XP, kk * 16, 0, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[t][i], 0, 0, 0);
           }
@@ -439,8 +459,14 @@ int launch_stem(const CxWgrad& p, hipStream_t st) {
   splits = (total_steps + sps - 1) / sps;
   const size_t wtotal = (size_t)64 * 147;
   float* slab = dw_slab(p.scratch, p.scratch_floats, splits, (long long)wtotal);
-  CX_KTAG("stem_wgrad_kernel<%d>", GPRO);
-  hipLaunchKernelGGL((stem_wgrad_kernel<GPRO>), dim3(splits), dim3(256), 2 * ST_STAGE, st, p, M, sps, slab);
+  static const int strip_on = [] { const char* e = getenv("CX_STEM_STRIP"); return e ? atoi(e) : 1; }();
+  if (strip_on && p.Wo % PX == 0 && (p.W & 1) == 0) {
+    CX_KTAG("stem_wgrad_kernel<%d, true>", GPRO);
+    hipLaunchKernelGGL((stem_wgrad_kernel<GPRO, true>), dim3(splits), dim3(256), 2 * ST_STAGE, st, p, M, sps, slab);
+  } else {
+    CX_KTAG("stem_wgrad_kernel<%d, false>", GPRO);
+    hipLaunchKernelGGL((stem_wgrad_kernel<GPRO, false>), dim3(splits), dim3(256), 2 * ST_STAGE, st, p, M, sps, slab);
+  }
   if (const int e = launch_status()) return e;
   return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;
 }

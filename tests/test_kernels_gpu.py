@@ -559,6 +559,31 @@ def test_wgrad_1x1_bottleneck_large(dev, gpro, xpro, K, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Ws", [64, 128])
+def test_wgrad_stem_row_strips(dev, Ws):
+    """Stem weight gradient on maps whose output width is a multiple of the 32-pixel step: the input rows of a step are staged as
+    strips and read at an overlapping 16-B pitch (stem_wgrad_kernel<., true>); image borders on every side, two tensors."""
+    from chexpert_amd import ops, _lib
+    B, Hs = 2, 12
+    xs = bf(rnd(164, (B, 3, Hs, Ws), -2, 2))
+    ub, u = nhwc_buf(165, B, Hs // 2, Ws // 2, 64, dev)
+    vb, v = nhwc_buf(166, B, Hs // 2, Ws // 2, 64, dev)
+    ga, gb_, gc = rnd(167, (64,), 0.5, 1.5), rnd(168, (64,), -0.5, 0.5), rnd(169, (64,), -0.2, 0.2)
+    cv = lambda t: t.view(1, -1, 1, 1)
+    gs = bf(u * cv(ga) + v * cv(gb_) + cv(gc))
+    want = torch.nn.grad.conv2d_weight(xs, (64, 3, 7, 7), gs, stride=2, padding=3)
+    dw = torch.zeros(64, 3, 7, 7, device=dev)
+    ops.conv_wgrad(ub, ops.nchw3_to_nhwc4(xs.to(dev)), dw, mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=vb, ga=ga.to(dev),
+                   gb=gb_.to(dev), gc=gc.to(dev), splits=3)
+    assert "true" in _lib.lib().cx_last_kernel().decode(), _lib.lib().cx_last_kernel().decode()
+    close(dw.cpu(), want, rel=2e-3, what="dW stem strips")
+    want1 = torch.nn.grad.conv2d_weight(xs, (64, 3, 7, 7), u, stride=2, padding=3)
+    dw1 = torch.zeros(64, 3, 7, 7, device=dev)
+    ops.conv_wgrad(ub, ops.nchw3_to_nhwc4(xs.to(dev)), dw1, mode=ops.MODE_STEM)
+    close(dw1.cpu(), want1, rel=2e-3, what="dW stem strips, one tensor")
+
+
+@pytest.mark.gpu
 def test_wgrad_stem_affine2_odd_pixel_count(dev):
     """Stem weight gradient with the two-tensor BN-backward form of dY (conv0 under norm0) and a pixel count that is not a
     multiple of the 32-pixel step (partial last step, splits > 1)."""
