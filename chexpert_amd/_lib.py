@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libchexpert_hip.so")
 
 PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE2 = 0, 1, 2
 MODE_CONV, MODE_POOL2, MODE_STEM = 0, 1, 2
-EPI_STORE, EPI_MASK = 0, 1
+EPI_STORE, EPI_MASK, EPI_JOIN = 0, 1, 2
 
 _vp, _fp, _i32 = C.c_void_p, C.c_void_p, C.c_int32
 
@@ -27,7 +27,7 @@ class CxConv(C.Structure):
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32), ("tstride", _i32),
                 ("stat_replicas", _i32), ("stat_rstride", _i32), ("stat_det", _i32), ("dtype", _i32),
-                ("pro_out", _vp), ("ldpo", _i32), ("pad_", _i32)]
+                ("pro_out", _vp), ("ldpo", _i32), ("pad_", _i32), ("emask", _vp)]
 
 
 class CxWgrad(C.Structure):
@@ -177,7 +177,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name in ("cx_error_string", "cx_last_kernel") else C.c_int
-        if l.cx_abi_version() != 7:
+        if l.cx_abi_version() != 8:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l
     return _lib

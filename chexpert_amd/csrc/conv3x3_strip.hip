@@ -446,11 +446,11 @@ constexpr int WP = 64;          // bytes per ring / strip pixel: 32 channels; ro
 // k-steps round-robin, so a step can be NG times longer (up to a whole image: more bytes in flight per barrier) while its
 // MFMA and staging phases shrink by NG; the groups' tiles meet in LDS before the atomics.
 template <int NG, int NCHW>
-__global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
+__device__ __forceinline__ void strip_wgrad_body(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
     const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const int K, const int N,
-    const int c_tiles, const int n_tiles, const StripGeo g, float* __restrict__ slab) {
+    const int c_tiles, const int n_tiles, const StripGeo& g, float* __restrict__ slab, const int wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = g.P, R = g.R, Q = g.Q, W = g.W, H = g.H;
   const int nk = (R * P + 15) / 16;
@@ -461,7 +461,6 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
   constexpr int NTHR = 192 * NG;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) % 3, grp = (tid >> 6) / 3;           // wave = kernel row dy, grp = k-step residue
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
   // (32 input channels, 32 output channels) tile pairs of one pixel range are neighbours, input tile fastest: the dense
   // layers are 4 x 1 pairs (K = 128, N = 32), a ResNet 256 -> 256 conv is 8 x 8
   const int pairs = c_tiles * n_tiles;
@@ -637,6 +636,41 @@ __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
   }
 }
 
+template <int NG, int NCHW>
+__global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_kernel(
+    const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
+    const float* __restrict__ gb, const float* __restrict__ gc, int g_affine2, const bf16* __restrict__ x, int ldx,
+    const float* __restrict__ pa, const float* __restrict__ pb, float* __restrict__ dw, const int K, const int N,
+    const int c_tiles, const int n_tiles, const StripGeo g, float* __restrict__ slab) {
+  strip_wgrad_body<NG, NCHW>(gsl, ldg, g2, ldg2, ga, gb, gc, g_affine2, x, ldx, pa, pb, dw, K, N, c_tiles, n_tiles, g, slab,
+                             xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// The 3x3 weight gradients of SEVERAL dense layers of one block in one launch (cx_conv3x3_wgrad_batch).  A dense layer's weight
+// gradient feeds nothing but the flat gradient buffer, so it need not run between its layer's input-gradient kernels: with the
+// corrected gradient slice left behind as a dense tensor (CxConv.pro_out) and the saved bottleneck tensor, the launches of a whole
+// block are independent of each other.  On the 20x20 / 10x10 maps one such launch is 24-36 us for 2-9 us of memory traffic --
+// launch, first-window latency and the partial-tile epilogue of 256 workgroups; batched, workgroup = (layer, split, channel tile),
+// the workgroups of the next layer start while the slow ones of this layer finish, each workgroup walks a longer pixel range
+// (fewer partial tiles: parallelism comes from the layers), and nothing sits on the input-gradient chain.
+struct StripBatch {
+  const bf16* g[CX_WGRAD_BATCH_MAX];
+  const bf16* x[CX_WGRAD_BATCH_MAX];
+  const float* pa[CX_WGRAD_BATCH_MAX];
+  const float* pb[CX_WGRAD_BATCH_MAX];
+  float* slab[CX_WGRAD_BATCH_MAX];
+};
+
+template <int NG, int NCHW>
+__global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_batch_kernel(const StripBatch bt, const int per_layer, int ldg, int ldx,
+                                                                             const int K, const int N, const int c_tiles,
+                                                                             const int n_tiles, const StripGeo g) {
+  const int layer = blockIdx.x / per_layer;                        // per_layer % 8 == 0: the low bits stay the XCD
+  const int r = blockIdx.x - layer * per_layer;
+  strip_wgrad_body<NG, NCHW>(bt.g[layer], ldg, bt.g[layer], ldg, nullptr, nullptr, nullptr, 0, bt.x[layer], ldx, bt.pa[layer],
+                             bt.pb[layer], nullptr, K, N, c_tiles, n_tiles, g, bt.slab[layer], xcd_remap(r, per_layer));
+}
+
 inline StripGeo make_geo(int B, int H, int W, int target_wgs, int min_steps, int max_flat) {
   StripGeo g;
   g.B = B; g.H = H; g.W = W; g.P = W + 2;
@@ -773,3 +807,61 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   if (const int e = launch_status()) return e;
   return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;
 }
+
+// ABI 8.  See StripBatch above; include/chexpert_hip.h has the contract.
+int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* stream) {
+  if (!geo || !items) return CX_EINVAL;
+  const CxWgrad& p = *geo;
+  const int n = items->n;
+  if (n <= 0 || n > CX_WGRAD_BATCH_MAX) return CX_EINVAL;
+  if (p.dtype != CX_DT_BF16 || p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1) return CX_EUNSUPPORTED;
+  if (p.K != 128 || p.N != 32 || p.x_prologue != CX_PRO_AFFINE_RELU || p.g_prologue != CX_PRO_NONE) return CX_EUNSUPPORTED;
+  if (p.W + 2 > 128 || p.W < 4 || p.Ho != p.H || p.Wo != p.W || (p.ldg % 8) || (p.ldx % 8)) return CX_EUNSUPPORTED;
+  for (int i = 0; i < n; ++i)
+    if (!items->g[i] || !items->x[i] || !items->pa[i] || !items->pb[i] || !items->dw[i]) return CX_EINVAL;
+  if (!p.scratch) return CX_EUNSUPPORTED;             // partial tiles go to slabs (ordered sums); no atomic form
+  hipStream_t st = as_stream(stream);
+  const int c_tiles = 4, n_tiles = 1, pairs = 4;
+  static const int env_splits = [] { const char* e = getenv("CX_SW_BATCH_SPLITS"); return e ? atoi(e) : 0; }();
+  // pixel-range splits per layer: the layers supply the parallelism, so a workgroup walks a long range (16 images or more) and the
+  // partial tiles (147 KB per split and layer) stay a small fraction of the operands
+  int target = env_splits > 0 ? env_splits : 16;
+  int flat = NCHW4 * 768 / (p.W * 4) * (p.W + 2);
+  if (flat > 880) flat = 880;
+  StripGeo g = make_geo(p.B, p.H, p.W, target, 1, flat);
+  const int nk = (g.R * g.P + 15) / 16;
+  size_t smem = 160 * 4 + (size_t)(g.Q + 2) * WP + (size_t)nk * 16 * WP;
+  if (smem < 160 * 4 + 32 * 288 * 4) smem = 160 * 4 + 32 * 288 * 4;
+  if (!(g.R * p.W * 4 <= NCHW4 * 768 && 2 * p.W * 4 <= NCHW4 * 768 && g.Q >= 64 && smem <= 150 * 1024)) return CX_EUNSUPPORTED;
+  const int total = g.B * g.spi;
+  int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
+  if (splits & 1) return CX_EUNSUPPORTED;             // (per_layer % 8 == 0 keeps the XCD remap per layer)
+  const long long wtotal = (long long)p.N * p.K * 9;
+  const long long need = (long long)n * splits * wtotal;
+  if (need > p.scratch_floats || need >= (1ll << 31)) return CX_EUNSUPPORTED;
+  StripBatch bt;
+  for (int i = 0; i < CX_WGRAD_BATCH_MAX; ++i) {
+    const int j = i < n ? i : 0;
+    bt.g[i] = (const bf16*)items->g[j];
+    bt.x[i] = (const bf16*)items->x[j];
+    bt.pa[i] = items->pa[j];
+    bt.pb[i] = items->pb[j];
+    bt.slab[i] = p.scratch + (size_t)j * splits * wtotal;
+  }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_wgrad_batch_kernel<4, NCHW4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  const int per_layer = splits * pairs;
+  CX_KTAG("conv3x3_strip_wgrad_batch_kernel<4, %d>", NCHW4);
+  hipLaunchKernelGGL((conv3x3_strip_wgrad_batch_kernel<4, NCHW4>), dim3(per_layer * n), dim3(768), smem, st, bt, per_layer, p.ldg, p.ldx,
+                     p.K, p.N, c_tiles, n_tiles, g);
+  if (const int e = launch_status()) return e;
+  for (int i = 0; i < n; ++i)
+    if (const int e = cx_dw_reduce(items->dw[i], bt.slab[i], (size_t)wtotal, splits, st)) return e;
+  cx_tl_slab_floats_v = (int)need;
+  return 0;
+}
+

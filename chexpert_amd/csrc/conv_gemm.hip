@@ -462,6 +462,10 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
     if (!p.ex || !p.e_sc || !p.e_sh || !p.e_mu || !p.e_r || !p.e_scale || !p.stat_sum || !p.stat_sq) return CX_EINVAL;
     if ((p.ldex % 8) || !aligned16(p.ex)) return CX_EALIGN;
   }
+  if (p.epilogue == CX_EPI_JOIN) {
+    if (!p.ex || !p.emask || !p.e_mu || !p.e_r || !p.stat_sum || !p.stat_sq || !p.accumulate) return CX_EINVAL;
+    if ((p.ldex % 8) || !aligned16(p.ex)) return CX_EALIGN;
+  }
   if ((p.stat_sum == nullptr) != (p.stat_sq == nullptr)) return CX_EINVAL;
   if (p.stat_replicas < 0 || (p.stat_replicas > 1 && p.stat_rstride < p.N)) return CX_EINVAL;
   hipStream_t st = as_stream(stream);

@@ -408,6 +408,14 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
       escale[j] = p.e_scale[nch + j];
     }
   }
+  if (EPI == CX_EPI_JOIN) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      emu[j] = p.e_mu[nch + j];
+      er[j] = p.e_r[nch + j];
+    }
+  }
+  unsigned mkb[NGRP][NPASS];               // CX_EPI_JOIN: the forward join's sign bits of this row's 8 channels
   const bool want_stats = p.stat_sum != nullptr;
 
   U128 xv[NGRP][NPASS], old[NGRP][NPASS];
@@ -426,7 +434,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
         mc = (b * p.Ho + oy * c.o_mul + c.oy_add) * p.Wo + ox * c.o_mul + c.ox_add;
       }
       mo[g][pass] = mc;
-      if (EPI == CX_EPI_MASK) xv[g][pass].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + nch);
+      if (EPI == CX_EPI_MASK || EPI == CX_EPI_JOIN) xv[g][pass].u = *reinterpret_cast<const uint4*>(EX + (size_t)mc * p.ldex + nch);
+      if (EPI == CX_EPI_JOIN) mkb[g][pass] = p.emask[(size_t)mc * (p.N >> 3) + (nch >> 3)];
       if (p.accumulate)
         old[g][pass].u = *reinterpret_cast<const uint4*>(Y + (size_t)mc * p.ldy + nch);
       else
@@ -464,6 +473,18 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
             const float rv = bf2f(o.e[j]);
             s1[j] += rv;
             s2[j] += rv * rv;
+          }
+        } else if (EPI == CX_EPI_JOIN) {
+          // the gradient of the join's output, rounded as CX_EPI_STORE would have stored it, then the join's ReLU mask and
+          // the sums of its BatchNorm's backward
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bf16 t = f2bf(v[j] + bf2f(old[g][pass].e[j]));
+            const bool on = ((mkb[g][pass] >> j) & 1u) != 0;
+            o.e[j] = on ? t : f2bf(0.f);
+            const float dz = on ? bf2f(t) : 0.f;
+            s1[j] += dz;
+            s2[j] += dz * (bf2f(xv[g][pass].e[j]) - emu[j]) * er[j];
           }
         } else {
 #pragma unroll
@@ -549,6 +570,7 @@ int launch_any(const CxConv& p, const Cls& c, hipStream_t st, int form) {
     if (p.prologue == CX_PRO_AFFINE_RELU) return launch_form<CX_PRO_AFFINE_RELU, CX_EPI_STORE>(p, c, st, form);
     return launch_form<CX_PRO_AFFINE2, CX_EPI_STORE>(p, c, st, form);
   }
+  if (p.epilogue == CX_EPI_JOIN) return launch_form<CX_PRO_AFFINE2, CX_EPI_JOIN>(p, c, st, form);
   if (p.prologue == CX_PRO_AFFINE2) return launch_form<CX_PRO_AFFINE2, CX_EPI_MASK>(p, c, st, form);
   return launch_form<CX_PRO_NONE, CX_EPI_MASK>(p, c, st, form);
 }
@@ -573,12 +595,14 @@ int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   *handled = false;
   static const int env_on0 = [] { const char* e = getenv("CX_MM"); return e ? atoi(e) : 1; }();
   static const int env_form0 = [] { const char* e = getenv("CX_MM_FORM"); return e ? atoi(e) : 0; }();
-  const int env_on = g_mm_on >= 0 ? g_mm_on : env_on0;
+  const int env_on = p.epilogue == CX_EPI_JOIN ? 1 : g_mm_on >= 0 ? g_mm_on : env_on0;
   const int env_form = g_mm_form >= 0 ? g_mm_form : env_form0;
   if (!env_on || p.mode != CX_MODE_CONV || p.tstride > 2 || (p.K % 8) || p.K < BK || (p.N % 8) || p.kh * p.kw > 32 || p.dtype != CX_DT_BF16) return 0;
   const bool ok_combo = (p.epilogue == CX_EPI_STORE && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE_RELU || p.prologue == CX_PRO_AFFINE2)) ||
-                        (p.epilogue == CX_EPI_MASK && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE2));
+                        (p.epilogue == CX_EPI_MASK && (p.prologue == CX_PRO_NONE || p.prologue == CX_PRO_AFFINE2)) ||
+                        (p.epilogue == CX_EPI_JOIN && p.prologue == CX_PRO_AFFINE2 && p.tstride <= 1 && (p.N % 128) == 0);
   if (!ok_combo) return 0;
+  const bool join = p.epilogue == CX_EPI_JOIN;      // this file has the only join epilogue: taken whatever the tile heuristics say
   // 32-bit byte offsets inside every tensor
   if ((unsigned long long)p.B * p.H * p.W * (unsigned long long)(p.ldx > p.ldx2 ? p.ldx : p.ldx2) * 2 >= (1ull << 32)) return 0;
   if ((unsigned long long)p.kh * p.kw * p.N * p.K * 2 >= (1ull << 32)) return 0;
@@ -587,7 +611,7 @@ int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   // k-steps (1.9-2.7x the generic kernel); with at most four steps a tile is prologue + epilogue, the smaller tile wins, and with
   // one or two steps the generic kernel (32-channel steps, three workgroups per CU) is as fast.
   const int nsteps = (ts == 2 ? (p.kh * p.kw + 3) / 4 : p.kh * p.kw) * ((p.K + BK - 1) / BK);
-  if (!env_form && ts == 1 && nsteps <= 2) return 0;
+  if (!env_form && !join && ts == 1 && nsteps <= 2) return 0;
   // Partial last tiles (N a multiple of 8, not of 128: EfficientNet widths, AAConv branches).  Measured on the EfficientNet-B4
   // shapes (scratch/bench_mm_eff.py): with at least 14 k-steps per tile this kernel is 1.3-2x the generic one (K = 960 .. 2688
   // projections and their gradients), with fewer the padded part of the tile costs more than the pipeline gains.

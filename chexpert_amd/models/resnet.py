@@ -114,6 +114,7 @@ class _Engine:
         # (attention-augmented blocks feed one BatchNorm from two kernels: their statistic rows are reduced per channel range,
         # _aa_fwd_stats; the two input-gradient branches stack their rows, _stacked)
         self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
+        self.join_fuse = os.environ.get("CHEXPERT_JOIN_FUSE", "1") != "0"      # residual-join backward in the conv1 input gradient's epilogue
         # activation storage type: bf16, or fp32 = the parity mode of north_star ("1e-3 fp32"): the same schedule on fp32 tensors
         # through the generic f32-MFMA convolutions (csrc/conv_f32.hip) and the templated element-wise kernels
         self.dtype = getattr(model, "_storage_dtype", torch.bfloat16)
@@ -558,6 +559,7 @@ class _Engine:
         Cl = last.shape[3]
         ops.gap_relu_bn_bwd(dpooled, last, ones(Cl), zeros(Cl), zeros(Cl), ones(Cl), ones(Cl), g, v(ws, self.scratch[0], Cl),
                             v(ws, self.scratch[1], Cl))
+        join_rows = None        # statistic rows of a join backward that ran in the epilogue of the block above (CX_EPI_JOIN)
         for bi in range(len(self.blocks) - 1, -1, -1):
             b, t = self.blocks[bi], ws.blk[bi]
             s_, p_ = b.stride, b.bn1.num_features
@@ -573,7 +575,10 @@ class _Engine:
             g = bw["g"][bi]
             # residual join backward: dz = dOut * [out > 0] (in place), statistics for bn3 (and the downsample BN)
             cnt_o, cnt_i = B * ho * wo, B * hi * wi
-            if det:
+            if join_rows is not None:
+                # the conv1 input gradient of the block above finished dOut and ran this join in its epilogue (CX_EPI_JOIN)
+                rows, join_rows = join_rows, None
+            elif det:
                 rows = ops.relu_bwd_stats(g, t["out"], t["y3"], v(ws, S3.mean), v(ws, S3.rstd), t["yd"], v(ws, Sd.mean) if Sd else None,
                                           v(ws, Sd.rstd) if Sd else None, g, ws.slab[0], ws.slab[1], ws.slab[2] if Sd else None,
                                           stat_rows=ew(S3.C), mask=t["mask"])
@@ -640,8 +645,18 @@ class _Engine:
             identity = Sd is None
             if identity and gx is not g:
                 gx.copy_(g)                      # first block of layer1 never is an identity block; defensive
-            ops.conv_gemm(dz1, self.w_bwd(b.conv1), gx, N=cin, prologue=ops.PRO_AFFINE2, x2=t["y1"], pa=v(ws, S1.pa), pb=v(ws, S1.pb),
-                          pc=v(ws, S1.pc), accumulate=identity)
+            prev = self.blocks[bi - 1] if bi > 0 else None
+            if (self.join_fuse and det and identity and prev is not None and prev.downsample is None and cin % 128 == 0
+                    and self.dtype == torch.bfloat16):
+                # dOut of the block below is complete with this launch (identity path already in gx): its join backward -- ReLU
+                # mask from the forward's sign bits, bn3 sums -- runs in the epilogue instead of a pass of its own over gx
+                tp, Sp = ws.blk[bi - 1], self.bn[id(prev.bn3)]
+                join_rows = ops.conv_gemm(dz1, self.w_bwd(b.conv1), gx, N=cin, prologue=ops.PRO_AFFINE2, x2=t["y1"], pa=v(ws, S1.pa),
+                                          pb=v(ws, S1.pb), pc=v(ws, S1.pc), accumulate=True, epilogue=ops.EPI_JOIN, ex=tp["y3"],
+                                          e_mu=v(ws, Sp.mean), e_r=v(ws, Sp.rstd), emask=tp["mask"], **msp(Sp))
+            else:
+                ops.conv_gemm(dz1, self.w_bwd(b.conv1), gx, N=cin, prologue=ops.PRO_AFFINE2, x2=t["y1"], pa=v(ws, S1.pa), pb=v(ws, S1.pb),
+                              pc=v(ws, S1.pc), accumulate=identity)
             ops.conv_wgrad(dz1, xin, G(b.conv1.weight), g_prologue=ops.PRO_AFFINE2, g2=t["y1"], ga=v(ws, S1.pa), gb=v(ws, S1.pb),
                            gc=v(ws, S1.pc))
             if Sd is not None:

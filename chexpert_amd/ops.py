@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_MASK, EPI_STORE, MODE_CONV, MODE_POOL2, MODE_STEM, PRO_AFFINE2, PRO_AFFINE_RELU, PRO_NONE,
+from ._lib import (EPI_JOIN, EPI_MASK, EPI_STORE, MODE_CONV, MODE_POOL2, MODE_STEM, PRO_AFFINE2, PRO_AFFINE_RELU, PRO_NONE,
                    CxConv, CxWgrad, check, lib, ptr, require_cuda, stream_ptr)
 import ctypes as C
 
@@ -180,7 +180,7 @@ def last_pro_out():
 def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
                  pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
                  e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1, stat_replicas=1, stat_rstride=0,
-                 stat_det=False, pro_out=None):
+                 stat_det=False, pro_out=None, emask=None):
     require_cuda(x, w_packed, y)
     p = CxConv()
     B, H, W, Cx, ldx = _nhwc(x)
@@ -211,7 +211,11 @@ def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CO
         require_cuda(pro_out)
         assert pro_out.dtype == x.dtype and tuple(pro_out.shape) == tuple(x.shape)
         p.pro_out, p.ldpo = ptr(pro_out), _nhwc(pro_out)[4]
-    p._keep = (x, w_packed, y, pa, pb, pc, x2, stat_sum, stat_sq, ex, e_sc, e_sh, e_mu, e_r, e_scale, pro_out)      # keep the views alive
+    if emask is not None:                # CX_EPI_JOIN: sign bits of the forward join (affine2_relu's mask)
+        require_cuda(emask)
+        assert emask.dtype == torch.uint8 and emask.is_contiguous() and emask.numel() * 8 == B * Ho * Wo * N
+        p.emask = ptr(emask)
+    p._keep = (x, w_packed, y, pa, pb, pc, x2, stat_sum, stat_sq, ex, e_sc, e_sh, e_mu, e_r, e_scale, pro_out, emask)      # keep the views alive
     return p
 
 

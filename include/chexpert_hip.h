@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 7
+#define CX_ABI_VERSION 8
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4, CX_ESTATROWS = -5 };
 
@@ -51,8 +51,13 @@ enum {
 /* epilogues */
 enum {
   CX_EPI_STORE = 0,   /* y = bf16(acc); optional per-channel sum / sum of squares (fp32 atomics)   */
-  CX_EPI_MASK = 1     /* dz = acc * [ex*e_sc + e_sh > 0]; S1 += sum dz; S2 += sum dz*(ex-e_mu)*e_r;
+  CX_EPI_MASK = 1,    /* dz = acc * [ex*e_sc + e_sh > 0]; S1 += sum dz; S2 += sum dz*(ex-e_mu)*e_r;
                          y = (accumulate ? y : 0) + e_scale*dz            (ReLU+BN backward)      */
+  CX_EPI_JOIN = 2     /* ABI 8, residual join backward folded into the input gradient that completes the join's output
+                         gradient (attn_aug_conv.py:191-211: out = relu(bn3(z3) + identity)): t = bf16(y + acc) is the gradient of
+                         `out` (y holds the part that arrived through the identity path: accumulate must be set),
+                         dz = t * [bit of emask], S1 += sum dz, S2 += sum dz*(ex-e_mu)*e_r with ex = z3 (the join BatchNorm's
+                         input), y = dz.  Bit for bit what CX_EPI_STORE + cx_relu_bwd_stats_mask leave in y.  bf16, stride 1. */
 };
 
 typedef struct CxConv {
@@ -90,6 +95,8 @@ typedef struct CxConv {
   void* pro_out;
   int32_t ldpo;
   int32_t pad_;
+  /* ABI 8.  CX_EPI_JOIN: the forward join's sign bits as cx_affine2_relu_mask wrote them: byte m*(N/8) + n/8, bit n%8 = [out[m][n] > 0] */
+  const uint8_t* emask;
 } CxConv;
 
 /* Weight gradient of the same convolution:  dW[n][c][ky][kx] += sum_m G[m][n] * A[m@tap][c]
@@ -115,6 +122,27 @@ typedef struct CxWgrad {
   float* scratch;
   int64_t scratch_floats;
 } CxWgrad;
+
+/* ABI 8.  The 3x3 weight gradients (K = 128 -> N = 32, stride 1, pad 1) of up to CX_WGRAD_BATCH_MAX dense layers of ONE dense block
+ * (same B, H, W, pitches) in one launch: torchvision `_DenseLayer.conv2` as restated at attn_aug_conv.py:13, weight gradient of
+ * every layer of a `_DenseBlock` (:476-483).  A dense layer's 3x3 weight gradient feeds only the flat gradient buffer, so the
+ * launches of a block do not depend on each other once every layer's output-gradient slice exists as a dense tensor
+ * (CxConv.pro_out) -- batched they leave the input-gradient chain and share one grid (workgroup = layer x pixel range x 32-channel
+ * tile).  `geo` gives the common geometry and prologue (g_prologue NONE, x_prologue AFFINE_RELU), the slab workspace (scratch:
+ * n * splits * 36864 floats are used, cx_last_slab_floats() reports them) and dtype; its g / x / dw / pa / pb are ignored.
+ * items[i]: g = dense (B,H,W,ldg) gradient slice, x = saved bottleneck tensor (B,H,W,ldx), pa / pb = its norm2 scale / shift [128],
+ * dw = fp32 OIHW gradient (32,128,3,3), added in split order (immediately or through cx_wgrad_defer like cx_conv_wgrad).
+ * CX_EUNSUPPORTED: shape / workspace outside the kernel's range -- call cx_conv_wgrad per layer instead.                          */
+#define CX_WGRAD_BATCH_MAX 24
+typedef struct CxWgradBatch {
+  const void* g[CX_WGRAD_BATCH_MAX];
+  const void* x[CX_WGRAD_BATCH_MAX];
+  const float* pa[CX_WGRAD_BATCH_MAX];
+  const float* pb[CX_WGRAD_BATCH_MAX];
+  float* dw[CX_WGRAD_BATCH_MAX];
+  int32_t n, pad_;
+} CxWgradBatch;
+int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* stream);
 
 /* Deferred slab sums (ABI 6).  A training step issues ~120 weight-gradient launches whose partial tiles (CxWgrad.scratch) each
  * need a small ordered sum into dw; one launch per sum puts ~60 of them on the critical stream (6-7 us each on DenseNet121).

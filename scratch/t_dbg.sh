@@ -1,5 +1,5 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/dbg; rm -rf $O; mkdir -p $O
-HIP_LAUNCH_BLOCKING=1 AMD_SERIALIZE_KERNEL=3 timeout -k 10 200 python -m pytest "tests/test_efficientnet_gpu.py::test_efficientnet_matches_oracle" -q -s -x > $O/tests.log 2>&1; echo "tests rc=$?"
-grep -n "Memory access\|File \"/tmp/code\|passed\|failed" $O/tests.log | head -12
+mkdir -p gpurun_out/dbg
+timeout -k 10 300 python scratch/dbg_join.py 1,3,1,1 > gpurun_out/dbg/join.txt 2>&1; echo rc=$?
+head -60 gpurun_out/dbg/join.txt

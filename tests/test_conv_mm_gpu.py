@@ -291,3 +291,53 @@ def test_random_shapes_agree_with_the_kernels_they_replace(dev, select, select_w
                 assert err <= 2e-3 * scale, ("wgrad", it, ksz, K, N, B, H, W, err / scale)
     finally:
         ops.WGRAD_SCRATCH_FLOATS = keep
+
+
+@pytest.mark.parametrize("form", [1, 3])
+@pytest.mark.parametrize("B,H,W,K,N", [(2, 9, 10, 64, 256), (3, 10, 12, 128, 512), (1, 20, 20, 256, 1024), (2, 7, 7, 512, 128)])
+def test_join_epilogue_equals_store_plus_relu_bwd_stats(dev, select, form, B, H, W, K, N):
+    """CX_EPI_JOIN (ABI 8): the 1x1 input gradient that completes a residual join's output gradient also runs the join's backward
+    (ReLU mask from the forward's sign bits + the sums of its BatchNorm's backward).  y must equal, bit for bit, what the
+    accumulating CX_EPI_STORE launch followed by cx_relu_bwd_stats_mask leaves; the sums agree to fp32 summation order; against
+    torch: dz = (g_identity + conv(dz1')) * [out > 0]."""
+    from chexpert_amd import ops
+    select(1, form)
+    gb_, g = nhwc(31, B, H, W, K, dev)                 # dz1 and its second tensor (AFFINE2 prologue: BN1 backward)
+    g2b, g2 = nhwc(32, B, H, W, K, dev)
+    ga, gbv, gc = rnd(33, (K,), 0.5, 1.5), rnd(34, (K,), -0.5, 0.5), rnd(35, (K,), -0.2, 0.2)
+    w = bf(rnd(36, (K, N, 1, 1), -0.1, 0.1))           # forward conv1: N -> K; its input gradient maps K -> N
+    wt = w.permute(1, 0, 2, 3).contiguous()
+    idb, idg = nhwc(37, B, H, W, N, dev)               # gradient that arrived through the identity path
+    y3b, y3 = nhwc(38, B, H, W, N, dev)                # the join BatchNorm's input
+    outb, out = nhwc(39, B, H, W, N, dev, -1.0, 1.0)   # join output before the ReLU (sign decides the mask)
+    mu, r = rnd(40, (N,), -0.5, 0.5), rnd(41, (N,), 0.5, 2.0)
+    # sign bits exactly as the forward writes them
+    mask = torch.zeros(B * H * W * N // 8, dtype=torch.uint8, device=dev)
+    jo = torch.empty_like(outb)
+    ones, zeros = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    ops.affine2_relu(outb, outb, ones, zeros, zeros, jo, mask)
+    rows_cap = 64
+    wp = ops.pack_weights(wt.to(dev))
+    kw = dict(N=N, prologue=ops.PRO_AFFINE2, x2=g2b, pa=ga.to(dev), pb=gbv.to(dev), pc=gc.to(dev), accumulate=True)
+    # reference path: store (accumulating) then the join pass
+    y_ref = idb.clone()
+    ops.conv_gemm(gb_, wp, y_ref, **kw)
+    S = torch.zeros(3, rows_cap, N, device=dev)
+    rows_r = ops.relu_bwd_stats(y_ref, jo, y3b, mu.to(dev), r.to(dev), None, None, None, y_ref, S[0], S[1], None, stat_rows=rows_cap, mask=mask)
+    # fused
+    y = idb.clone()
+    T = torch.zeros(2, rows_cap, N, device=dev)
+    rows = ops.conv_gemm(gb_, wp, y, epilogue=ops.EPI_JOIN, ex=y3b, e_mu=mu.to(dev), e_r=r.to(dev), emask=mask, stat_sum=T[0], stat_sq=T[1],
+                         stat_det=True, stat_replicas=rows_cap, stat_rstride=N, **kw)
+    assert rows == (B * H * W + 127) // 128
+    assert torch.equal(y, y_ref), "fused join differs from store + relu_bwd_stats"
+    s1, s2 = T[0, :rows].sum(0).cpu(), T[1, :rows].sum(0).cpu()
+    close(s1, S[0, :rows_r].sum(0).cpu(), rel=1e-5, what="S1")
+    close(s2, S[1, :rows_r].sum(0).cpu(), rel=1e-5, what="S2")
+    # torch
+    a = bf(g * cv(ga) + g2 * cv(gbv) + cv(gc))
+    t = bf(idg + F.conv2d(a, wt))
+    dz = torch.where(out > 0, t, torch.zeros(()))
+    close(to_nchw(y), dz, what="dz")
+    close(s1, dz.sum((0, 2, 3)), rel=2e-3, what="S1 vs torch")
+    close(s2, (dz * (y3 - cv(mu)) * cv(r)).sum((0, 2, 3)), rel=2e-3, what="S2 vs torch")

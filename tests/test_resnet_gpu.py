@@ -440,3 +440,34 @@ def test_aa_wideresnet_head_size_8_matches_fp32_oracle(dev):
     model.forward_backward(x.to(dev), t.to(dev))
     for k, p in model.named_parameters():
         assert torch.equal(p.grad, g1[k]), k
+
+
+def test_join_backward_in_the_conv1_epilogue_equals_the_separate_pass(dev, monkeypatch):
+    """The residual-join backward folded into the conv1 input gradient of the block above (CX_EPI_JOIN, engine switch
+    CHEXPERT_JOIN_FUSE) against the separate cx_relu_bwd_stats pass, layers (1, 3, 1, 1): the fold happens once, in layer2.2's
+    conv1 input gradient, for the join of layer2.1.  Every gradient computed before it is bit-identical; the fold stores the same
+    bf16 gradient tensor (tests/test_conv_mm_gpu.py) and adds the BatchNorm sums in another order, so layer2.1.bn3's gradients
+    agree to fp32 rounding.  (Further down the difference grows ~10x per block -- 2e-7, 2e-6, ... 5e-3 at layer1, measured: bf16
+    rounding flips under small-batch BatchNorm backward -- which is why the check is made AT the fold and not on the stem.)"""
+    layers, n_cls, B, S = (1, 3, 1, 1), 5, 8, 128
+    x, t = synth.xray_batch(1234, B, S), synth.targets(99, B, n_cls)
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CHEXPERT_JOIN_FUSE", fuse)
+        model, _ = _build(layers, n_cls, 21, dev, smooth=True)
+        model.train()
+        out = model(x.to(dev))
+        loss = torch.nn.BCEWithLogitsLoss(reduction="none")(out, t.to(dev)).sum(1).mean(0)
+        model.zero_grad()
+        loss.backward()
+        assert model._eng().join_fuse == (fuse == "1")
+        res[fuse] = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
+    names = list(res["0"].keys())[::-1]             # backward order
+    cut = names.index("layer2.1.bn3.bias")
+    for k in names[:cut]:
+        assert torch.equal(res["1"][k], res["0"][k]), k
+    rel = lambda k: (res["1"][k] - res["0"][k]).norm().item() / res["0"][k].norm().item()
+    print("join fold: bn3 bias / weight / conv3 relative difference %.2e %.2e %.2e" % (rel("layer2.1.bn3.bias"), rel("layer2.1.bn3.weight"),
+                                                                                     rel("layer2.1.conv3.weight")))
+    assert rel("layer2.1.bn3.bias") < 1e-5 and rel("layer2.1.bn3.weight") < 1e-5
+    assert rel("layer2.1.conv3.weight") < 1e-4
