@@ -40,6 +40,14 @@ class CxWgrad(C.Structure):
                 ("scratch", _fp), ("scratch_floats", C.c_int64)]
 
 
+WGRAD_BATCH_MAX = 24
+
+
+class CxWgradBatch(C.Structure):
+    _fields_ = [("g", _vp * WGRAD_BATCH_MAX), ("x", _vp * WGRAD_BATCH_MAX), ("pa", _fp * WGRAD_BATCH_MAX), ("pb", _fp * WGRAD_BATCH_MAX),
+                ("dw", _fp * WGRAD_BATCH_MAX), ("n", _i32), ("pad_", _i32)]
+
+
 class CxPackDesc(C.Structure):
     _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("O", _i32), ("I", _i32), ("kh", _i32), ("kw", _i32),
                 ("transpose", _i32), ("stem", _i32)]
@@ -62,6 +70,7 @@ SIGNATURES = {
     "cx_dw_reduce_table": [_vp, C.c_int, C.c_int64, _vp],
     "cx_error_string": [_i],
     "cx_conv_gemm": [C.POINTER(CxConv), _vp],
+    "cx_conv3x3_wgrad_batch": [C.POINTER(CxWgrad), C.POINTER(CxWgradBatch), _vp],
     "cx_conv_wgrad": [C.POINTER(CxWgrad), _vp],
     "cx_conv1x1_dgrad_wgrad": [C.POINTER(CxConv), _vp, _vp],
     "cx_conv1x1_dgrad_wgrad_ws": [C.POINTER(CxConv), _vp, _vp, C.c_int64, _vp],

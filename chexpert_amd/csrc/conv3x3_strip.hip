@@ -665,10 +665,11 @@ template <int NG, int NCHW>
 __global__ __launch_bounds__(192 * NG) void conv3x3_strip_wgrad_batch_kernel(const StripBatch bt, const int per_layer, int ldg, int ldx,
                                                                              const int K, const int N, const int c_tiles,
                                                                              const int n_tiles, const StripGeo g) {
-  const int layer = blockIdx.x / per_layer;                        // per_layer % 8 == 0: the low bits stay the XCD
+  const int layer = blockIdx.x / per_layer;
   const int r = blockIdx.x - layer * per_layer;
+  const int wg = (per_layer & 7) ? r : xcd_remap(r, per_layer);    // per_layer % 8 == 0: the low bits of r are still the XCD
   strip_wgrad_body<NG, NCHW>(bt.g[layer], ldg, bt.g[layer], ldg, nullptr, nullptr, nullptr, 0, bt.x[layer], ldx, bt.pa[layer],
-                             bt.pb[layer], nullptr, K, N, c_tiles, n_tiles, g, bt.slab[layer], xcd_remap(r, per_layer));
+                             bt.pb[layer], nullptr, K, N, c_tiles, n_tiles, g, bt.slab[layer], wg);
 }
 
 inline StripGeo make_geo(int B, int H, int W, int target_wgs, int min_steps, int max_flat) {
@@ -825,7 +826,9 @@ int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* 
   static const int env_splits = [] { const char* e = getenv("CX_SW_BATCH_SPLITS"); return e ? atoi(e) : 0; }();
   // pixel-range splits per layer: the layers supply the parallelism, so a workgroup walks a long range (16 images or more) and the
   // partial tiles (147 KB per split and layer) stay a small fraction of the operands
-  int target = env_splits > 0 ? env_splits : 16;
+  // (scratch/bench_w2batch.py, 256 images: 40x40 maps 104 / 81 / 84 / 87 us per layer with 8 / 16 / 32 / 64 splits -- 97 per layer
+  // launched one by one --, 20x20 22.8 / 23.8 / 25.8 / 30.1 (33.0), 10x10 12.0 / 13.1 / 14.7 / 20.1 (21.3))
+  int target = env_splits > 0 ? env_splits : (p.H * p.W > 400 ? 16 : 8);
   int flat = NCHW4 * 768 / (p.W * 4) * (p.W + 2);
   if (flat > 880) flat = 880;
   StripGeo g = make_geo(p.B, p.H, p.W, target, 1, flat);
@@ -834,8 +837,7 @@ int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* 
   if (smem < 160 * 4 + 32 * 288 * 4) smem = 160 * 4 + 32 * 288 * 4;
   if (!(g.R * p.W * 4 <= NCHW4 * 768 && 2 * p.W * 4 <= NCHW4 * 768 && g.Q >= 64 && smem <= 150 * 1024)) return CX_EUNSUPPORTED;
   const int total = g.B * g.spi;
-  int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
-  if (splits & 1) return CX_EUNSUPPORTED;             // (per_layer % 8 == 0 keeps the XCD remap per layer)
+  const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   const long long wtotal = (long long)p.N * p.K * 9;
   const long long need = (long long)n * splits * wtotal;
   if (need > p.scratch_floats || need >= (1ll << 31)) return CX_EUNSUPPORTED;

@@ -281,6 +281,8 @@ class _Engine:
         # channels from two kernels -- conv branch and attention out-projection: their statistic rows are reduced one after the
         # other, see _aa_forward.
         self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
+        self.w2_batch = os.environ.get("CHEXPERT_W2_BATCH", "1") != "0"      # a block's 3x3 weight gradients in one launch (small maps)
+        self._w2_items = []
         self._plan_vectors()
 
     # ---- coefficient-vector layout
@@ -581,8 +583,19 @@ class _Engine:
                        gb=qb[:cc], gc=qc[:cc])
         ops.in_relu_bwd(T.dA, pbuf, T.coef[0], T.coef[1], T.S[0], T.S[1], pg)       # S: one owner per (image, channel), plain stores
 
+    def _flush_w2(self):
+        """Launch the collected 3x3 weight gradients of the current block (one batched launch per 24 layers; per layer when the
+        library declines the shape or the slab workspace)."""
+        items, self._w2_items = self._w2_items, []
+        for i in range(0, len(items), ops.L.WGRAD_BATCH_MAX):
+            part = items[i:i + ops.L.WGRAD_BATCH_MAX]
+            if not ops.conv3x3_wgrad_batch(part):
+                for dyc, y1, pa, pb, dw in part:
+                    ops.conv_wgrad(dyc, y1, dw, kh=3, kw=3, pad=1, x_prologue=ops.PRO_AFFINE_RELU, pa=pa, pb=pb)
+
     # ---- backward
     def backward(self, ws, dlogits):
+        self._w2_items = []
         ops.set_det_wgrad(self.det)            # reproducible weight-gradient sums with the deterministic statistics
         # the ordered sums of the weight-gradient slabs run as ONE table-driven launch at the end of the pass (ops.wgrad_defer_*);
         # a data-parallel run flushes them before each gradient bucket leaves (GradReducer.pre_launch)
@@ -678,6 +691,9 @@ class _Engine:
                                       v(sub(brstd, cl, self.growth)), *(v(t) for t in s["ql"][bi][n_layers - 1]), self.growth)
             w2_pending = None
             dense_dy_lag = os.environ.get("CHEXPERT_DENSE_DY", "1") == "2" and red is None     # (a reducer needs every gradient of a layer enqueued before done())
+            # (the maps the strip weight-gradient kernel serves: 40x40 and smaller at 320x320; the 80x80 maps keep the ring kernel)
+            batch_w2 = (self.w2_batch and side is main and self.dtype == torch.bfloat16 and self.growth == 32 and self.mid == 128
+                        and (w < 56 or h * w < 3136))
             for li in range(n_layers - 1, -1, -1):
                 layer = getattr(block, "denselayer%d" % (li + 1))
                 cin = c0 + li * self.growth
@@ -709,7 +725,11 @@ class _Engine:
                     def w2_launch(dyc=dyc, y1=y1, wgt=layer.conv2.weight, n2=n2):
                         with torch.cuda.stream(side):
                             ops.conv_wgrad(dyc, y1, G(wgt), kh=3, kw=3, pad=1, x_prologue=ops.PRO_AFFINE_RELU, pa=v(n2[0]), pb=v(n2[1]))
-                    if dense_dy_lag:
+                    if batch_w2:
+                        # small maps: the block's 3x3 weight gradients leave the input-gradient chain and run as ONE launch after
+                        # the block (cx_conv3x3_wgrad_batch); a data-parallel run flushes them before a gradient bucket leaves
+                        self._w2_items.append((dyc, y1, v(n2[0]), v(n2[1]), G(layer.conv2.weight)))
+                    elif dense_dy_lag:
                         # one layer behind: it then runs beside the NEXT layer's 3x3 input gradient (as the strided form does beside
                         # its own), not beside the bandwidth-bound fused 1x1 backward
                         if w2_pending is not None:
@@ -761,6 +781,7 @@ class _Engine:
                 ev_d.record(main)
                 side.wait_event(ev_d)
                 w2_pending()
+            self._flush_w2()
             # the block's first c0 channels were produced by the previous transition (or the stem)
             qa, qb, qc = (v(t)[:c0] for t in q)               # written by layer 0's norm1 coefficient launch
             gs, xs = gbuf[..., :c0], buf[..., :c0]
@@ -821,7 +842,7 @@ class _Engine:
             raise RuntimeError("bind the engine first (run one forward)")
         self.reducer = GradReducer(self.flat_grad, bucket_bytes, group)
         # the deferred weight-gradient slab sums (ops.wgrad_defer_*) run before each bucket leaves, so that the bucket is final
-        self.reducer.pre_launch = lambda: ops.wgrad_defer_flush(self.device, keep=True)
+        self.reducer.pre_launch = lambda: (self._flush_w2(), ops.wgrad_defer_flush(self.device, keep=True))
 
 
 class _Fn(torch.autograd.Function):

@@ -246,6 +246,43 @@ def conv_wgrad(g, x, dw, *, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, g_prolo
     _wgrad_used(arena, dfr)
 
 
+def conv3x3_wgrad_batch(items):
+    """cx_conv3x3_wgrad_batch: the 3x3 weight gradients of several dense layers of one block in ONE launch.
+    items: [(g dense (B,H,W,32) gradient slice, x saved bottleneck tensor (B,H,W,128), pa, pb norm2 scale / shift, dw fp32 OIHW)].
+    Returns False when the library declines the shape / workspace (the caller then launches cx_conv_wgrad per layer)."""
+    n = len(items)
+    if n == 0:
+        return True
+    g0, x0 = items[0][0], items[0][1]
+    if n > L.WGRAD_BATCH_MAX or g0.dtype != torch.bfloat16:
+        return False
+    p, bt = CxWgrad(), L.CxWgradBatch()
+    B, H, W, N, ldg = _nhwc(g0)
+    _, _, _, K, ldx = _nhwc(x0)
+    p.B, p.H, p.W, p.Ho, p.Wo, p.K, p.N = B, H, W, H, W, K, N
+    p.ldg, p.ldx = ldg, ldx
+    p.kh, p.kw, p.stride, p.pad = 3, 3, 1, 1
+    p.g_prologue, p.x_prologue, p.mode, p.dtype = PRO_NONE, PRO_AFFINE_RELU, MODE_CONV, 0
+    for i, (g, x, pa, pb, dw) in enumerate(items):
+        require_cuda(g, x, dw)
+        assert _nhwc(g) == (B, H, W, N, ldg) and _nhwc(x) == (B, H, W, K, ldx) and g.dtype == x.dtype == torch.bfloat16
+        assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == N * K * 9
+        bt.g[i], bt.x[i], bt.pa[i], bt.pb[i], bt.dw[i] = ptr(g), ptr(x), ptr(pa), ptr(pb), ptr(dw)
+    bt.n = n
+    ws, arena, dfr = _wgrad_ws(g0.device)
+    if ws is None:
+        return False
+    p.scratch, p.scratch_floats = ptr(ws), ws.numel()
+    rc = lib().cx_conv3x3_wgrad_batch(C.byref(p), C.byref(bt), stream_ptr())
+    if rc == -4:                               # CX_EUNSUPPORTED: nothing was launched
+        if arena is not None and not dfr:
+            lib().cx_wgrad_defer(1)
+        return False
+    check(rc, "cx_conv3x3_wgrad_batch")
+    _wgrad_used(arena, dfr)
+    return True
+
+
 def pack_weights(w, transpose=False, stem=False, out=None):
     """OIHW fp32 -> packed bf16 (see cx_pack_weights)."""
     require_cuda(w)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libchexpert_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.lib().cx_abi_version() == 7
+    assert _lib.lib().cx_abi_version() == 8
     assert _lib.lib().cx_error_string(-3) == b"unsupported shape"
     # every binding passes exactly the parameters the header declares (a short argtypes list makes ctypes pass the rest as 32-bit
     # ints: truncated device pointers, i.e. a GPU memory fault instead of an error)
@@ -39,6 +39,10 @@ def test_validation_codes_without_launching():
     assert _lib.lib().cx_conv_gemm(ctypes.byref(p), None) == -1           # CX_EINVAL: null pointers
     w = _lib.CxWgrad()
     assert _lib.lib().cx_conv_wgrad(ctypes.byref(w), None) == -1
+    bt = _lib.CxWgradBatch()
+    assert _lib.lib().cx_conv3x3_wgrad_batch(ctypes.byref(w), ctypes.byref(bt), None) == -1      # n = 0
+    assert ctypes.sizeof(_lib.CxWgradBatch) == 5 * 8 * _lib.WGRAD_BATCH_MAX + 8
+    assert ctypes.sizeof(_lib.CxConv) == 15 * 8 + 24 * 4 + 8 + 8 + 8     # ... pro_out, ldpo + pad_, emask (ABI 8)
     assert _lib.lib().cx_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 1, 1.0, None) == -1
 
 

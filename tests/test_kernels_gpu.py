@@ -669,3 +669,38 @@ def test_u8_brightness_contrast_jitter_matches_torch_restatement(dev):
     # the image mean is an fp32 sum in a different order: a product within 1e-5 of an integer may truncate the other way
     assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 1e-3, (diff.max().item(), (diff > 0).float().mean().item())
     assert got.float().std() > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,n", [(4, 10, 10, 3), (3, 20, 20, 5), (2, 40, 40, 2)])
+def test_conv3x3_wgrad_batch_equals_per_layer(dev, B, H, W, n):
+    """cx_conv3x3_wgrad_batch (ABI 8): the 3x3 weight gradients of several dense layers in one launch against torch per layer and
+    against cx_conv_wgrad per layer (other pixel-range splits: equal to fp32 summation order); dw is added to."""
+    from chexpert_amd import ops
+    ops.set_det_wgrad(True)           # the batch stores partial tiles in the slab workspace (no atomic form)
+    items, wants, dws0 = [], [], []
+    for i in range(n):
+        gb_, g = nhwc_buf(300 + i, B, H, W, 32, dev)
+        buf = bf(rnd(320 + i, (B, H, W, 160), -1.5, 1.5)).to(torch.bfloat16).to(dev)      # the bottleneck tensor as a slice of a wider buffer
+        xb = buf[..., 16:144]
+        x = xb.float().cpu().permute(0, 3, 1, 2).contiguous()
+        pa, pb = rnd(340 + i, (128,), -0.3, 1.5), rnd(360 + i, (128,), -0.5, 0.5)
+        cv = lambda t: t.view(1, -1, 1, 1)
+        a = bf(F.relu(x * cv(pa) + cv(pb)))
+        wants.append(torch.nn.grad.conv2d_weight(a, (32, 128, 3, 3), g, padding=1))
+        dw0 = rnd(380 + i, (32, 128, 3, 3), -1, 1)
+        dws0.append(dw0)
+        items.append((gb_, xb, pa.to(dev), pb.to(dev), dw0.clone().to(dev)))
+    assert ops.conv3x3_wgrad_batch(items), "the library declined a dense-layer shape"
+    assert "batch" in _kernel_name()
+    for i in range(n):
+        close(items[i][4].cpu() - dws0[i], wants[i], rel=2e-3, what="dW layer %d" % i)
+        ref = dws0[i].clone().to(dev)
+        ops.conv_wgrad(items[i][0], items[i][1], ref, kh=3, kw=3, pad=1, x_prologue=ops.PRO_AFFINE_RELU, pa=items[i][2], pb=items[i][3])
+        close(items[i][4].cpu() - dws0[i], ref.cpu() - dws0[i], rel=1e-5, what="batch vs per layer %d" % i)
+    ops.set_det_wgrad(False)
+
+
+def _kernel_name():
+    from chexpert_amd import _lib
+    return _lib.lib().cx_last_kernel().decode()
