@@ -48,6 +48,11 @@ class CxWgradBatch(C.Structure):
                 ("dw", _fp * WGRAD_BATCH_MAX), ("n", _i32), ("pad_", _i32)]
 
 
+class CxChanMapDesc(C.Structure):
+    _fields_ = [("real_off", C.c_int64), ("pad_off", C.c_int64), ("O", _i32), ("taps", _i32), ("Ireal", _i32), ("Ipad", _i32),
+                ("c0r", _i32), ("c0p", _i32), ("k", _i32), ("kp", _i32)]
+
+
 class CxPackDesc(C.Structure):
     _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("O", _i32), ("I", _i32), ("kh", _i32), ("kw", _i32),
                 ("transpose", _i32), ("stem", _i32)]
@@ -71,6 +76,7 @@ SIGNATURES = {
     "cx_error_string": [_i],
     "cx_conv_gemm": [C.POINTER(CxConv), _vp],
     "cx_conv3x3_wgrad_batch": [C.POINTER(CxWgrad), C.POINTER(CxWgradBatch), _vp],
+    "cx_chan_map_table": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_conv_wgrad": [C.POINTER(CxWgrad), _vp],
     "cx_conv1x1_dgrad_wgrad": [C.POINTER(CxConv), _vp, _vp],
     "cx_conv1x1_dgrad_wgrad_ws": [C.POINTER(CxConv), _vp, _vp, C.c_int64, _vp],

@@ -215,8 +215,12 @@ def build_model(args, n_classes):
         model = models.WideResNet(models.BasicBlock, *args.architecture, num_classes=n_classes, attn_params=attn)
         opt = optim.FusedSGDNesterov(model, lr=args.lr, weight_decay=args.weight_decay, momentum=0.9, milestones=())
     else:
-        raise NotImplementedError("the three-block CIFAR DenseNet-BC of test_model.py:272-282 is not on the HIP schedule "
-                                  "(the DenseNet engine is the four-block network chexpert.py trains)")
+        # Densenet-BC (test_model.py:304-311): DenseNet(k, ((L-4)//6,)*3, 2k), SGD nesterov, MultiStepLR at epochs 100 / 150.  Its
+        # widths (24 + 12 i at the default k = 12) run on the channel-padded twin (models/densenet.py _PaddedEngine)
+        k, L = args.architecture
+        n = (L - 4) // 6
+        model = models.DenseNet(k, (n, n, n), 2 * k, num_classes=n_classes, attn_params=attn)
+        opt = optim.FusedSGDNesterov(model, lr=args.lr, weight_decay=args.weight_decay, momentum=0.9, milestones=())   # lr_at(): MultiStepLR
     return model, opt
 
 

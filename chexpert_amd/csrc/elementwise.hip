@@ -698,8 +698,11 @@ __global__ __launch_bounds__(256) void unpool2_mask_kernel(const T* __restrict__
   const size_t npix = (size_t)B * H * W;
   const size_t ppb = blockDim.x / CP;
   const int Ho = H / 2, Wo = W / 2;
+  // (C / 8 need not divide the workgroup: the trailing blockDim % CP threads idle with zero sums -- the padded widths of the CIFAR
+  // DenseNet-BC twin, e.g. 280 channels = 35 chunks, run 245 threads of 256)
+  const bool active = threadIdx.x < ppb * CP;
   // (neighbouring image rows share window reads: the remap keeps them on one XCD's L2 instead of eight)
-  for (size_t pix = (size_t)xcd_remap(blockIdx.x, gridDim.x) * ppb + threadIdx.x / CP; pix < npix; pix += (size_t)gridDim.x * ppb) {
+  for (size_t pix = active ? (size_t)xcd_remap(blockIdx.x, gridDim.x) * ppb + threadIdx.x / CP : npix; pix < npix; pix += (size_t)gridDim.x * ppb) {
     const int b = pix / ((size_t)H * W);
     const int rem = pix - (size_t)b * H * W;
     const int iy = rem / W, ix = rem - iy * W;
@@ -1176,8 +1179,7 @@ int unpool2_mask_t(const void* d, const void* x, const float* sc, const float* s
                     const float* e_scale, void* g, float* S1, float* S2, int B, int H, int W, int C, int ldd, int ldx, int ldg,
                     int stat_rows, void* stream) {
   if (!d || !x || !sc || !sh || !mean || !rstd || !e_scale || !g || !S1 || !S2) return CX_EINVAL;
-  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || (H & 1) || (W & 1) || ldd % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
-  if (C / 8 > 256) return CX_ESHAPE;
+  if (C % 8 || C > 2048 || (H & 1) || (W & 1) || ldd % 8 || ldx % 8 || ldg % 8) return CX_ESHAPE;
   const size_t npix = (size_t)B * H * W;
   const int ppb = 256 / (C / 8);
   int grid = grid_for(npix, ppb, 2048);
@@ -1334,6 +1336,33 @@ int cx_pack_weights(const float* w, void* packed, int O, int I, int kh, int kw, 
 int cx_pack_weights_table(const float* flat, void* packed, const CxPackDesc* table_dev, int n_desc, void* stream) {
   if (!flat || !packed || !table_dev || n_desc <= 0) return CX_EINVAL;
   hipLaunchKernelGGL(pack_table_kernel, dim3(16, n_desc), dim3(256), 0, as_stream(stream), flat, (bf16*)packed, table_dev);
+  return launch_status();
+}
+
+// Channel-padded twin of a network whose widths are not multiples of 8 (the CIFAR DenseNet-BC of models/test_model.py:306: growth
+// 12).  Element (o, j, t) of a real OIHW tensor lives at (o, pos(j), t) of the padded one, pos(j) = j for j < c0r (a block's first
+// channels), else c0p + ((j - c0r) / k) * kp + (j - c0r) % k (dense layer (j - c0r) / k writes kp >= k channels).  dir 0: real ->
+// padded (store; positions no real element maps to keep their zeros), dir 1: padded -> real (add: gradients; or store).
+__global__ void chan_map_table_kernel(float* __restrict__ real, float* __restrict__ padded, const CxChanMapDesc* __restrict__ table,
+                                      int dir, int accumulate) {
+  const CxChanMapDesc d = table[blockIdx.x];
+  float* r = real + d.real_off;
+  float* q = padded + d.pad_off;
+  const int total = d.O * d.Ireal * d.taps;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int t = idx % d.taps, j = (idx / d.taps) % d.Ireal, o = idx / (d.taps * d.Ireal);
+    const int pj = j < d.c0r ? j : d.c0p + ((j - d.c0r) / d.k) * d.kp + (j - d.c0r) % d.k;
+    const size_t pi = ((size_t)o * d.Ipad + pj) * d.taps + t;
+    if (dir == 0) q[pi] = r[idx];
+    else r[idx] = accumulate ? r[idx] + q[pi] : q[pi];
+  }
+}
+
+int cx_chan_map_table(float* real_flat, float* padded_flat, const CxChanMapDesc* table_dev, int n_desc, int dir, int accumulate,
+                      void* stream) {
+  if (!real_flat || !padded_flat || !table_dev || n_desc <= 0 || dir < 0 || dir > 1) return CX_EINVAL;
+  hipLaunchKernelGGL(chan_map_table_kernel, dim3(n_desc), dim3(256), 0, as_stream(stream), real_flat, padded_flat, table_dev, dir,
+                     accumulate);
   return launch_status();
 }
 

@@ -158,12 +158,19 @@ class _Workspace:
         self.B, self.H, self.W = B, H, W
         g = eng.growth
         e = lambda *s, dtype=bf: torch.empty(*s, dtype=dtype, device=dev)
-        self.x4 = e(B, H, W, 4)
-        h, w = H // 2, W // 2
-        self.c0 = e(B, h, w, eng.c_init)
-        self.dz0 = None
-        h, w = h // 2, w // 2
-        self.amax = e(B, h, w, eng.c_init, dtype=u8)
+        if eng.cifar:                       # 5x5 stride-1 stem, no pooling: block 1 works on the input's own grid
+            self.x8 = e(B, H, W, 8)
+            h, w = H, W
+            self.c0 = e(B, h, w, eng.c_init)
+            self.dz0 = None
+            self.amax = None
+        else:
+            self.x4 = e(B, H, W, 4)
+            h, w = H // 2, W // 2
+            self.c0 = e(B, h, w, eng.c_init)
+            self.dz0 = None
+            h, w = h // 2, w // 2
+            self.amax = e(B, h, w, eng.c_init, dtype=u8)
         self.buf, self.gbuf, self.y1, self.hw = [], [], [], []
         for bi, (c_in, n_layers) in enumerate(eng.blocks):
             ct = c_in + n_layers * g
@@ -197,7 +204,7 @@ class _Workspace:
         self.pooled = torch.empty(B, eng.c_final, dtype=torch.float32, device=dev)
         self.logits = torch.empty(B, eng.n_classes, dtype=torch.float32, device=dev)
         self.vec = torch.zeros(eng.vec_size, dtype=torch.float32, device=dev)
-        self.ones = torch.ones(max(eng.mid, 64), dtype=torch.float32, device=dev)
+        self.ones = torch.ones(max(eng.mid, 64, eng.c_init), dtype=torch.float32, device=dev)
         # deterministic statistics (CxConv.stat_det): every producer writes per-workgroup rows into this scratch pair and the
         # coefficient kernel that follows on the same stream sums them in row order
         self.slab = torch.empty(2, eng.SLAB, dtype=torch.float32, device=dev) if eng.det else None
@@ -257,15 +264,20 @@ class _Engine:
         self.model = model
         f = model.features
         self.growth = model.growth_rate
-        self.mid = model.bn_size * model.growth_rate
+        self.mid = getattr(model, "_mid", None) or model.bn_size * model.growth_rate
         self.c_init = f.conv0.out_channels
+        # CIFAR form of the network (attn_aug_conv.py:469-474): 5x5 stride-1 stem without pooling, any number of blocks
+        self.cifar = not hasattr(f, "pool0")
         self.blocks = []
         c = self.c_init
         for n_layers in model.block_config:
             self.blocks.append((c, n_layers))
             c = c + n_layers * self.growth
             if len(self.blocks) != len(model.block_config):
-                c //= 2
+                tr = getattr(f, "transition%d" % len(self.blocks))
+                # (the width the transition's convolution produces: c // 2 in the reference; the channel-padded twin of a
+                # CIFAR DenseNet-BC rounds it up to a multiple of 8)
+                c = tr.conv.out_channels if isinstance(tr.conv, nn.Conv2d) else c // 2
         self.c_final = c
         self.flat = None
         self.flat_grad = None
@@ -363,12 +375,15 @@ class _Engine:
             cur += (n + 7) // 8 * 8
             return (off, n)
         f = m.features
-        self.wf[id(f.conv0)] = add(f.conv0, stem=True)
+        self.wf[id(f.conv0)] = add(f.conv0, stem=not self.cifar)
         for mod in f.modules():
             if isinstance(mod, nn.Conv2d) and mod is not f.conv0:
                 self.wf[id(mod)] = add(mod)
                 self.wb[id(mod)] = add(mod, transpose=True)
         self.packed = torch.empty(cur, dtype=self.dtype, device=dev)
+        # CIFAR stem: norm0 + relu0 write the first channels of block 1's buffer through a 1x1 identity convolution (BN + ReLU in
+        # its prologue, the block's statistic rows from its epilogue); its backward is the same convolution with the mask epilogue
+        self.eye = torch.eye(self.c_init, dtype=self.dtype, device=dev).reshape(-1) if self.cifar else None
         arr = (CxPackDesc * len(descs))(*descs)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.desc_dev = host.to(dev)
@@ -444,7 +459,13 @@ class _Engine:
         if x.dim() != 4 or x.shape[1] != (1 if u8 else 3):
             raise RuntimeError("expected a (B,3,H,W) float input or a (B,1,H,W) uint8 image")
         B, _, H, W = x.shape
-        if H % 32 or W % 32:
+        if self.cifar:
+            mult = 1 << (len(self.blocks) - 1)
+            if u8 or H % mult or W % mult:
+                raise RuntimeError("the CIFAR-stem network takes (B,3,H,W) float images with H, W multiples of %d" % mult)
+            if not self.det:
+                raise RuntimeError("the CIFAR-stem schedule uses the deterministic statistic rows (unset CHEXPERT_DET=0)")
+        elif H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d)" % (H, W))
         self.bind(x.device)
         self.pack(train)
@@ -453,21 +474,29 @@ class _Engine:
             z0, zn = self.fwd_zero
             ws.vec[z0:z0 + zn].zero_()
         sp = (lambda slots, C, sub=None: self._sp(ws, slots, C, sub)) if train else (lambda slots, C, sub=None: {})
-        if u8:
+        if self.cifar:
+            self._cifar_stem(ws, x, train, sp)
+            fresh = (ws.slab[0], ws.slab[1], self._stem_rows, self.c_init, 0, self.c_init) if det else None
+        elif u8:
             ops.u8_to_nhwc4(x.contiguous(), ws.x4)
         else:
             ops.nchw3_to_nhwc4(x.contiguous().float(), ws.x4)
         # stem: conv0 -> norm0 -> relu0 -> pool0 (attn_aug_conv.py:460-465)
-        if det:
+        if self.cifar:
+            pass
+        elif det:
             rows = ops.conv_gemm(ws.x4, self.w_fwd(f.conv0), ws.c0, N=self.c_init, mode=ops.MODE_STEM, **sp(None, self.c_init))
             st0 = (ws.slab[0], ws.slab[1], rows, self.c_init)
         else:
             ops.conv_gemm(ws.x4, self.w_fwd(f.conv0), ws.c0, N=self.c_init, mode=ops.MODE_STEM,
                           stat_sum=ws.v(s["st0"][0]) if train else None, stat_sq=ws.v(s["st0"][1]) if train else None)
             st0 = (ws.v(s["st0"][0]), ws.v(s["st0"][1]), 1, 0)
-        self._bn(ws, st0, B * (H // 2) * (W // 2), f.norm0, s["n0"][:2], self.c_init, train, s["n0"][2], s["n0"][3])
-        fresh = None                             # (sum rows, sq rows, rows, rstride, first channel, channels) of the newest slice
-        if det:
+        if not self.cifar:
+            self._bn(ws, st0, B * (H // 2) * (W // 2), f.norm0, s["n0"][:2], self.c_init, train, s["n0"][2], s["n0"][3])
+            fresh = None                         # (sum rows, sq rows, rows, rstride, first channel, channels) of the newest slice
+        if self.cifar:
+            pass
+        elif det:
             rows = ops.bnrelu_maxpool_fwd(ws.c0, ws.v(s["n0"][0]), ws.v(s["n0"][1]), ws.buf[0][..., :self.c_init], ws.amax,
                                           ws.slab[0], ws.slab[1], stat_rows=min(self.EW_ROWS, self.SLAB // self.c_init))
             fresh = (ws.slab[0], ws.slab[1], rows, self.c_init, 0, self.c_init)
@@ -512,17 +541,32 @@ class _Engine:
             elif bi != nb - 1:
                 tr = getattr(f, "transition%d" % (bi + 1))
                 self._bn_block(ws, bi, ct, cnt, tr.norm, nt, train, fresh)
-                rows = ops.conv_gemm(buf, self.w_fwd(tr.conv), ws.buf[bi + 1][..., :ct // 2], N=ct // 2, mode=ops.MODE_POOL2,
+                cn = self.blocks[bi + 1][0]          # channels the transition produces (ct // 2 in the reference's networks)
+                rows = ops.conv_gemm(buf, self.w_fwd(tr.conv), ws.buf[bi + 1][..., :cn], N=cn, mode=ops.MODE_POOL2,
                                      prologue=ops.PRO_AFFINE_RELU, pa=ws.v(nt[0]), pb=ws.v(nt[1]),
-                                     **sp(s["bst"][bi + 1], ct // 2, (0, ct // 2)))
+                                     **sp(s["bst"][bi + 1], cn, (0, cn)))
                 if det:
-                    fresh = (ws.slab[0], ws.slab[1], rows, ct // 2, 0, ct // 2)
+                    fresh = (ws.slab[0], ws.slab[1], rows, cn, 0, cn)
             else:
                 self._bn_block(ws, bi, ct, cnt, f.norm5, nt, train, fresh)
                 ops.head_fwd(buf, ws.v(nt[0]), ws.v(nt[1]), m.classifier.weight, m.classifier.bias, ws.pooled, ws.logits)
         if train:
             m._nbt_pending += 1
         return ws
+
+    def _cifar_stem(self, ws, x, train, sp):
+        """conv0 (5x5, stride 1, pad 2) -> norm0 -> relu0 of the CIFAR form (attn_aug_conv.py:469-474).  The image is held with 8
+        channels (3 + zeros), conv0 runs on the generic implicit GEMM; norm0 + relu0 ride in the prologue of a 1x1 identity
+        convolution that writes block 1's first channels and leaves their statistic rows."""
+        f, s = self.model.features, self.slots
+        B, H, W = ws.B, ws.H, ws.W
+        name = "cx_nchw3_to_nhwc8" if self.dtype == torch.bfloat16 else "cx_nchw3_to_nhwc8_f32"
+        check(getattr(lib(), name)(ptr(x.contiguous().float()), ptr(ws.x8), B, H, W, stream_ptr()), name)
+        rows = ops.conv_gemm(ws.x8, self.w_fwd(f.conv0), ws.c0, N=self.c_init, kh=5, kw=5, pad=2, **sp(None, self.c_init))
+        st0 = (ws.slab[0], ws.slab[1], rows, self.c_init) if train else None
+        self._bn(ws, st0, B * H * W, f.norm0, s["n0"][:2], self.c_init, train, s["n0"][2], s["n0"][3])
+        self._stem_rows = ops.conv_gemm(ws.c0, self.eye, ws.buf[0][..., :self.c_init], N=self.c_init, prologue=ops.PRO_AFFINE_RELU,
+                                        pa=ws.v(s["n0"][0]), pb=ws.v(s["n0"][1]), **sp(None, self.c_init))
 
     def _aa_forward(self, ws, bi, aa, st, det=False):
         """InstanceNorm -> ReLU -> AAConv2d(3x3, stride 2) from block buffer bi into the first channels of buffer bi+1.  Returns the
@@ -706,7 +750,7 @@ class _Engine:
                 gs, xs = gbuf[..., cin:cin + g_], buf[..., cin:cin + g_]
                 S2 = s["S2"][bi][li]
                 dz2 = dz2s[k & 1]
-                fused = os.environ.get("CHEXPERT_1X1_BWD", "fused") != "split" and self.dtype == torch.bfloat16
+                fused = os.environ.get("CHEXPERT_1X1_BWD", "fused") != "split" and self.dtype == torch.bfloat16 and self.mid == 128
                 if k - 2 in w1_done:
                     # split mode: the side stream's conv1 weight gradient of two layers ago has finished reading this dz2 buffer.
                     # (In the fused mode nothing on the side stream reads dz2: no cross-stream edge on the main chain -- in the
@@ -811,6 +855,20 @@ class _Engine:
                                 G(tr.norm.bias), v(pA), v(pB), None, None, None, cprev, replicas=sred[2], rstride=sred[3],
                                 q=slice_q(bi - 1, pn - 1))
                 done(tr.norm.weight)
+            elif self.cifar:
+                # stem backward of the CIFAR form: relu0 mask + norm0 sums in the mask epilogue of the identity convolution (its
+                # two-tensor prologue applies the deferred BatchNorm correction to the gradient slice), then conv0's weight gradient
+                n0, S0 = s["n0"], s["S0"]
+                ci = self.c_init
+                rows = ops.conv_gemm(gs, self.eye, ws.dz0, N=ci, prologue=ops.PRO_AFFINE2, x2=xs, pa=qa, pb=qb, pc=qc,
+                                     epilogue=ops.EPI_MASK, ex=ws.c0, e_sc=v(n0[0]), e_sh=v(n0[1]), e_mu=v(n0[2]), e_r=v(n0[3]),
+                                     e_scale=ws.ones[:ci], **self._sp(ws, S0, ci))
+                sred = self._sc(ws, S0, ci, rows)
+                pa, pb, pc = (v(t)[:ci] for t in pv)
+                ops.bn_bwd_coef(sred[0], sred[1], B * ws.H * ws.W, f.norm0.weight, v(n0[2]), v(n0[3]), G(f.norm0.weight),
+                                G(f.norm0.bias), None, None, pa, pb, pc, ci, replicas=sred[2], rstride=sred[3])
+                ops.conv_wgrad(ws.dz0, ws.x8, G(f.conv0.weight), kh=5, kw=5, pad=2, g_prologue=ops.PRO_AFFINE2, g2=ws.c0, ga=pa, gb=pb,
+                               gc=pc)
             else:
                 n0, S0 = s["n0"], s["S0"]
                 if det:
@@ -867,6 +925,200 @@ class _Fn(torch.autograd.Function):
         return None, None, None
 
 
+# --------------------------------------------------------------------------------------------- channel-padded twin
+def _up8(n):
+    return (n + 7) // 8 * 8
+
+
+class _TwinNet(nn.Module):
+    """The network the kernels run when the real one has widths that are not multiples of 8 (CIFAR DenseNet-BC, growth 12:
+    models/test_model.py:306): same topology, every dense layer writes kp = up8(k) channels and every transition up8 of its width;
+    the extra channels carry zero weights / BatchNorm gains / shifts, so they stay exactly zero forward and backward.  Only a
+    parameter holder for _Engine -- its tensors are filled from the real model's by cx_chan_map_table before every forward."""
+
+    def __init__(self, real):
+        super().__init__()
+        rf = real.features
+        k, kp = real.growth_rate, _up8(real.growth_rate)
+        mid, midp = real.bn_size * k, _up8(real.bn_size * k)
+        self.growth_rate, self.block_config, self.bn_size, self._mid = kp, real.block_config, real.bn_size, midp
+        ci = rf.conv0.out_channels
+        nb = len(real.block_config)
+
+        def padc(c, n):
+            """padded width of a block's first channels: a multiple of 8 such that the block's full width c + n * kp is a multiple of
+            32 (the pooled transition convolution walks its input in 32-channel steps)"""
+            c = _up8(c)
+            while (c + n * kp) % 32:
+                c += 8
+            return c
+        cip = padc(ci, real.block_config[0])
+        f = nn.Sequential()
+        kh = rf.conv0.kernel_size[0]
+        f.add_module("conv0", Conv2dParams(8, cip, kh, rf.conv0.stride[0], rf.conv0.padding[0], bias=False))
+        f.add_module("norm0", BatchNorm2dParams(cip))
+        # channel maps (c0r, c0p, k, kp) of every block buffer, and the (real tensor, twin tensor, rows, map) list of the sync tables
+        self.maps, self.pairs = [], []
+        ident = lambda n, npad: (n, npad, 1, 1)
+        self.pairs += [(rf.conv0.weight, f.conv0.weight, ci, (3, 8, 1, 1)), (rf.norm0, f.norm0, None, ident(ci, cip))]
+        cr, cp = ci, cip
+        for bi, n in enumerate(real.block_config):
+            m_ = (cr, cp, k, kp)
+            self.maps.append(m_)
+            rblock = getattr(rf, "denseblock%d" % (bi + 1))
+            block = nn.Sequential()
+            for li in range(n):
+                rl = getattr(rblock, "denselayer%d" % (li + 1))
+                cinr, cinp = cr + li * k, cp + li * kp
+                L = nn.Sequential()
+                L.add_module("norm1", BatchNorm2dParams(cinp))
+                L.add_module("conv1", Conv2dParams(cinp, midp, 1, 1, bias=False))
+                L.add_module("norm2", BatchNorm2dParams(midp))
+                L.add_module("conv2", Conv2dParams(midp, kp, 3, 1, 1, bias=False))
+                block.add_module("denselayer%d" % (li + 1), L)
+                self.pairs += [(rl.norm1, L.norm1, None, m_), (rl.conv1.weight, L.conv1.weight, mid, m_),
+                               (rl.norm2, L.norm2, None, ident(mid, midp)), (rl.conv2.weight, L.conv2.weight, k, ident(mid, midp))]
+            f.add_module("denseblock%d" % (bi + 1), block)
+            ctr, ctp = cr + n * k, cp + n * kp
+            if bi != nb - 1:
+                rt = getattr(rf, "transition%d" % (bi + 1))
+                cor = rt.conv.out_channels
+                cop = padc(cor, real.block_config[bi + 1])
+                T = nn.Sequential()
+                T.add_module("norm", BatchNorm2dParams(ctp))
+                T.add_module("conv", Conv2dParams(ctp, cop, 1, 1, bias=False))
+                f.add_module("transition%d" % (bi + 1), T)
+                self.pairs += [(rt.norm, T.norm, None, m_), (rt.conv.weight, T.conv.weight, cor, m_)]
+                cr, cp = cor, cop
+            else:
+                f.add_module("norm5", BatchNorm2dParams(ctp))
+                self.classifier = nn.Linear(ctp, real.classifier.out_features, bias=real.classifier.bias is not None)
+                self.pairs += [(rf.norm5, f.norm5, None, m_), (real.classifier.weight, self.classifier.weight, real.classifier.out_features, m_)]
+                if real.classifier.bias is not None:
+                    nc = real.classifier.out_features
+                    self.pairs += [(real.classifier.bias, self.classifier.bias, None, ident(nc, nc))]
+        self.features = f
+        for t in list(self.parameters()) + [b for b in self.buffers() if b.dtype == torch.float32]:
+            t.data.zero_()                        # the padded positions keep these zeros (running_var of a padded channel: 0 + eps)
+        self._nbt_pending = 0
+
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("parameter holder of the channel-padded schedule")
+
+
+class _PaddedEngine:
+    """Engine of a network with unaligned widths: binds the REAL parameters to a flat buffer (what optimisers and state_dict see),
+    runs the channel-padded twin on an inner _Engine and moves parameters / running statistics / gradients between the two flat
+    layouts with one table-driven launch each (cx_chan_map_table)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.twin = _TwinNet(model)
+        object.__setattr__(self.twin, "_storage_dtype", getattr(model, "_storage_dtype", torch.bfloat16))
+        self.inner = _Engine(self.twin)
+        self.dtype = self.inner.dtype
+        self.c_final = model.classifier.in_features
+        self.flat = self.flat_grad = self.device = None
+        self.reducer = None
+        self.packed_version = None
+
+    def bind(self, dev):
+        m = self.model
+        params = [p for _, p in m.named_parameters()]
+        if (self.flat is not None and self.device == dev and
+                all(p.data_ptr() == self.flat.data_ptr() + 4 * off for p, off in zip(params, self.offsets)) and
+                all(b.data_ptr() == self.stat.data_ptr() + 4 * off for b, off in zip(self.rbufs, self.boffs))):
+            return
+        if self.twin.classifier.weight.device != dev:
+            self.twin.to(dev)
+        self.inner.bind(dev)
+
+        def flatten(tensors):
+            offs, total = [], 0
+            for t in tensors:
+                offs.append(total)
+                total += (t.numel() + 3) // 4 * 4
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            for t, off in zip(tensors, offs):
+                flat[off:off + t.numel()].copy_(t.data.reshape(-1))
+                t.data = flat[off:off + t.numel()].view(t.shape)
+            return flat, offs
+        self.flat, self.offsets = flatten(params)
+        self.params = params
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.grad_views = [self.flat_grad[off:off + p.numel()].view(p.shape) for p, off in zip(params, self.offsets)]
+        self.off_of = {id(p): off for p, off in zip(params, self.offsets)}
+        # running statistics of both networks in flat buffers of their own
+        bn_pairs = [(r, t) for r, t, _, _ in self.twin.pairs if isinstance(r, nn.BatchNorm2d)]
+        self.rbufs = [b for r, _ in bn_pairs for b in (r.running_mean, r.running_var)]
+        tbufs = [b for _, t in bn_pairs for b in (t.running_mean, t.running_var)]
+        self.stat, self.boffs = flatten(self.rbufs)
+        self.tstat, tboffs = flatten(tbufs)
+        in_ = self.inner
+        from .._lib import CxChanMapDesc
+        pd, sd = [], []
+        bi = 0
+        for r, t, rows, (c0r, c0p, k, kp) in self.twin.pairs:
+            if isinstance(r, nn.BatchNorm2d):
+                C_r, C_p = r.num_features, t.num_features
+                for rp, tp in ((r.weight, t.weight), (r.bias, t.bias)):
+                    pd.append(CxChanMapDesc(self.off_of[id(rp)], in_.off_of[id(tp)], 1, 1, C_r, C_p, c0r, c0p, k, kp))
+                for j in range(2):
+                    sd.append(CxChanMapDesc(self.boffs[bi + j], tboffs[bi + j], 1, 1, C_r, C_p, c0r, c0p, k, kp))
+                bi += 2
+            else:
+                O_r = r.shape[0]
+                I_r = r.shape[1] if r.dim() > 1 else 1
+                I_p = t.shape[1] if t.dim() > 1 else 1
+                taps = r[0, 0].numel() if r.dim() == 4 else 1
+                if r.dim() == 1:                 # classifier bias: one row of O_r channels
+                    O_r, I_r, I_p = 1, r.shape[0], t.shape[0]
+                pd.append(CxChanMapDesc(self.off_of[id(r)], in_.off_of[id(t)], O_r, taps, I_r, I_p, c0r, c0p, k, kp))
+
+        def table(descs):
+            arr = (CxChanMapDesc * len(descs))(*descs)
+            return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev), len(descs)
+        self.ptab, self.stab = table(pd), table(sd)
+        self.device, self.n_classes = dev, m.classifier.out_features
+
+    def _map(self, real, padded, tab, direction, accumulate=0):
+        check(lib().cx_chan_map_table(ptr(real), ptr(padded), ptr(tab[0]), tab[1], direction, accumulate, stream_ptr()), "cx_chan_map_table")
+
+    def forward(self, x, train):
+        self.bind(x.device)
+        in_ = self.inner
+        self._map(self.flat, in_.flat, self.ptab, 0)              # parameters: real -> padded
+        self._map(self.stat, self.tstat, self.stab, 0)            # running statistics
+        in_.packed_version = None
+        ws = in_.forward(x, train)
+        if train:
+            self._map(self.stat, self.tstat, self.stab, 1)        # updated running statistics: padded -> real
+            self.twin._nbt_pending = 0
+            self.model._nbt_pending += 1
+        return ws
+
+    def backward(self, ws, dlogits):
+        in_ = self.inner
+        in_.flat_grad.zero_()
+        for p, gv in zip(in_.params, in_.grad_views):
+            p.grad = gv
+        fresh = any(p.grad is None for p in self.params)
+        if fresh:
+            self.flat_grad.zero_()
+        in_.backward(ws, dlogits)
+        self._map(self.flat_grad, in_.flat_grad, self.ptab, 1, 1)  # gradients: padded -> real, added
+        if fresh:
+            for p, gv in zip(self.params, self.grad_views):
+                p.grad = gv
+
+    def release(self, ws):
+        self.inner.release(ws)
+
+    def enable_data_parallel(self, *a, **k):
+        raise NotImplementedError("the channel-padded CIFAR DenseNet-BC schedule is single-device (models/test_model.py has no "
+                                  "data-parallel mode)")
+
+
 # --------------------------------------------------------------------------------------------- module
 class DenseNet(nn.Module):
     """Signature of /root/reference/models/attn_aug_conv.py:452-453 (torchvision DenseNet + attn_params)."""
@@ -920,16 +1172,19 @@ class DenseNet(nn.Module):
 
     # the engine is rebuilt lazily (the classifier may be replaced after construction, chexpert.py:464)
     def _eng(self):
-        if len(self.block_config) != 4:
-            raise NotImplementedError("the 3-block CIFAR DenseNets of models/test_model.py are constructible (parameter counts, "
-                                      "state_dict) but only the ImageNet-stem networks chexpert.py trains run on the HIP schedule")
+        padded = len(self.block_config) != 4 or self.growth_rate % 8 or self.features.conv0.out_channels % 8
+        if padded and any(isinstance(mod, AAConv2d) for mod in self.modules()):
+            raise NotImplementedError("attention-augmented transitions of the CIFAR DenseNet-BC (models/test_model.py:306 with "
+                                      "--attn) are constructible only; the plain DenseNet-BC runs on the HIP schedule")
+        if padded and len(self.block_config) == 4:
+            raise NotImplementedError("ImageNet-stem DenseNets need growth and stem widths that are multiples of 8")
         for mod in self.modules():
             if isinstance(mod, AAConv2d) and not mod.kernel_support:
                 raise NotImplementedError("AAConv2d(dk=%d, dv=%d, nh=%d, relative=%s): the HIP attention kernels cover dk/nh = 20, "
                                           "dv/nh in {1,2,3,4,6,8}, relative=True (chexpert.py:476)" % (mod.dk, mod.dv, mod.nh, mod.relative))
         if self._engine is None or self._engine.c_final != self.classifier.in_features or \
                 self._engine.dtype != getattr(self, "_storage_dtype", torch.bfloat16):
-            object.__setattr__(self, "_engine", _Engine(self))
+            object.__setattr__(self, "_engine", _PaddedEngine(self) if padded else _Engine(self))
         return self._engine
 
     def storage_dtype(self, dtype):

@@ -144,6 +144,20 @@ typedef struct CxWgradBatch {
 } CxWgradBatch;
 int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* stream);
 
+/* ABI 8.  Channel-padded twin (the CIFAR DenseNet-BC of models/test_model.py:306: growth 12, widths 24 + 12 i are not multiples of
+ * the kernels' 8-channel vectors).  The network runs on a twin whose dense layers write kp = 16 channels (12 real + 4 that stay
+ * zero: zero weights, zero BatchNorm gain and shift) and whose transitions are padded likewise; this entry point moves parameters
+ * / running statistics real -> padded (dir 0, store) and gradients / running statistics padded -> real (dir 1; accumulate: add)
+ * between two flat fp32 buffers, one descriptor per tensor, ONE launch.  Element (o, j, t) of the real [O][Ireal][taps] tensor is
+ * element (o, pos(j), t) of the padded [.][Ipad][taps] one, pos(j) = j for j < c0r, else c0p + ((j-c0r)/k)*kp + (j-c0r)%k.        */
+typedef struct CxChanMapDesc {
+  int64_t real_off, pad_off;         /* element offsets into the two flat buffers                                             */
+  int32_t O, taps, Ireal, Ipad;      /* rows copied (the padded tensor may have more), kh*kw, channels per row                   */
+  int32_t c0r, c0p, k, kp;           /* channel map (k = kp = 1, c0r = Ireal: identity with a wider row)                          */
+} CxChanMapDesc;
+int cx_chan_map_table(float* real_flat, float* padded_flat, const CxChanMapDesc* table_dev, int n_desc, int dir, int accumulate,
+                      void* stream);
+
 /* Deferred slab sums (ABI 6).  A training step issues ~120 weight-gradient launches whose partial tiles (CxWgrad.scratch) each
  * need a small ordered sum into dw; one launch per sum puts ~60 of them on the critical stream (6-7 us each on DenseNet121).
  * cx_wgrad_defer(1) switches the calling thread to deferral: every weight-gradient entry point (cx_conv_wgrad,

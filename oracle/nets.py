@@ -43,10 +43,11 @@ def densenet_spec(num_classes, growth=32, block_config=(6, 12, 24, 16), init_fea
     """name -> shape in torchvision key order.  `attn` = dict(k=, v=, nh=) enables the AA transitions
     (attn_aug_conv.py:436-440: InstanceNorm -> ReLU -> AAConv2d(3x3, stride 2))."""
     spec = OrderedDict()
-    spec["features.conv0.weight"] = (init_features, 3, 7, 7)
+    # four blocks: ImageNet stem (attn_aug_conv.py:459-465); otherwise the CIFAR stem, 5x5 stride 1 without pooling (:469-474)
+    spec["features.conv0.weight"] = (init_features, 3, 7, 7) if len(block_config) == 4 else (init_features, 3, 5, 5)
     _bn_spec(spec, "features.norm0", init_features)
     c = init_features
-    hw = (input_hw[0] // 4, input_hw[1] // 4)
+    hw = (input_hw[0] // 4, input_hw[1] // 4) if len(block_config) == 4 else tuple(input_hw)
     for b, n_layers in enumerate(block_config, 1):
         for l in range(1, n_layers + 1):
             p = "features.denseblock%d.denselayer%d" % (b, l)
@@ -256,9 +257,13 @@ def densenet_features(sd, x, block_config=(6, 12, 24, 16), train=True, nh=None, 
     q=None this is the plain fp32 restatement of the reference."""
     q = q or (lambda t: t)
     w = lambda k: q(sd[k])
-    x = q(F.conv2d(q(x), w("features.conv0.weight"), stride=2, padding=3))
-    x = F.relu(_bn(sd, "features.norm0", x, train))
-    x = q(F.max_pool2d(x, 3, 2, 1))
+    if len(block_config) == 4:
+        x = q(F.conv2d(q(x), w("features.conv0.weight"), stride=2, padding=3))
+        x = F.relu(_bn(sd, "features.norm0", x, train))
+        x = q(F.max_pool2d(x, 3, 2, 1))
+    else:                                        # CIFAR form (attn_aug_conv.py:469-474): conv0 5x5 / 1 / 2, norm0, relu0, no pooling
+        x = q(F.conv2d(q(x), w("features.conv0.weight"), stride=1, padding=2))
+        x = q(F.relu(_bn(sd, "features.norm0", x, train)))
     for b, n_layers in enumerate(block_config, 1):
         for l in range(1, n_layers + 1):
             p = "features.denseblock%d.denselayer%d" % (b, l)

@@ -297,6 +297,14 @@ def gen_smooth(out_dir, which):
         "aaresnet152_320_b8": lambda: (ResNet(Bottleneck, [3, 8, 36, 3], num_classes=n_cls, attn_params=ref_attn((320, 320))),
                                        nets.resnet_spec(n_cls, attn=attn), 8, 320, 1.0,
                                        lambda s, x, train, q=None: nets.resnet_forward(s, x, train=train, nh=8, q=q)),
+        # the CIFAR harness's Densenet-BC (models/test_model.py:304-306: DenseNet(k, ((L-4)//6,)*3, 2k)) at its default growth 12:
+        # L = 40 (6 layers per block) and the default L = 100 (16 per block), 32x32 images
+        "densenetbc_k12_L40_32_b8": lambda: (DenseNet(12, (6, 6, 6), 24, num_classes=n_cls),
+                                             nets.densenet_spec(n_cls, growth=12, block_config=(6, 6, 6), init_features=24), 8, 32, 2.5,
+                                             lambda s, x, train, q=None: nets.densenet_forward(s, x, (6, 6, 6), train=train, q=q)),
+        "densenetbc_k12_L100_32_b8": lambda: (DenseNet(12, (16, 16, 16), 24, num_classes=n_cls),
+                                              nets.densenet_spec(n_cls, growth=12, block_config=(16, 16, 16), init_features=24), 8, 32, 2.5,
+                                              lambda s, x, train, q=None: nets.densenet_forward(s, x, (16, 16, 16), train=train, q=q)),
     }
     for tag, job in jobs.items():
         if which and not any(w in tag for w in which):

@@ -47,7 +47,12 @@ def _make(tag, n_cls):
     from chexpert_amd.models.efficientnet import DropMarker
     from oracle import nets
     attn = dict(k=.2, v=.1, nh=8)
-    if tag.startswith("densenet121"):
+    if tag.startswith("densenetbc"):                # the CIFAR harness's Densenet-BC (models/test_model.py:304-306), growth 12
+        n = int(tag.split("_")[2][1:])
+        n = (n - 4) // 6
+        spec = nets.densenet_spec(n_cls, growth=12, block_config=(n, n, n), init_features=24)
+        model, bias = DenseNet(12, (n, n, n), 24, num_classes=n_cls), 2.5
+    elif tag.startswith("densenet121"):
         spec, model, bias = nets.densenet_spec(n_cls), DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls), 2.5
     elif tag.startswith("aadensenet121"):
         spec, model, bias = nets.densenet_spec(n_cls, attn=attn), DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls, attn_params=dict(ATTN)), 2.5
@@ -114,6 +119,9 @@ CASES = {
     # EfficientNets: logits 4.5e-3 / 7.4e-3 (deterministic engine: the same at every batch geometry).  Gradient norms agree to 5 % except
     # the squeeze-excite reduce convolutions (blocks.*.6.1 / .3.1: 7.6 % on b0, 10.2 % on b4): ds = sum_hw du * swish(bn(y)) is a sum
     # with heavy cancellation over bf16-rounded du -- the same tensors are 1e-5 from the reference in the fp32 mode (test_fp32_gpu.py)
+    # Densenet-BC k = 12 of the CIFAR harness on the channel-padded twin (models/densenet.py _PaddedEngine): widths 24 + 12 i
+    "densenetbc_k12_L40_32_b8": (1e-2, 1e-2, 0.05, 0.05),
+    "densenetbc_k12_L100_32_b8": (1e-2, 1e-2, 0.05, 0.05),
     "efficientnet-b0_224_b8": (1e-2, 1e-2, 0.12, 0.06),
     "efficientnet-b4_380_b8": (1e-2, 1e-2, 0.12, 0.06),
 }
@@ -140,3 +148,45 @@ def test_baseline_batch_geometry_reproduces_the_fixture(dev, golden, tag, copies
     rec = golden[tag]
     model, sd = _make(tag, rec["n_classes"])
     _check_step(tag, rec, model.to(dev), dev, copies, *CASES[tag])
+
+
+@pytest.mark.parametrize("tag", ["densenetbc_k12_L40_32_b8", "densenetbc_k12_L100_32_b8"])
+def test_densenet_bc_eval_and_second_step(dev, golden, tag):
+    """Channel-padded twin of the CIFAR Densenet-BC: eval-mode logits against the reference (running statistics mapped real ->
+    padded), two training steps in a row give the same gradients (the twin's gradient buffer is rebuilt, the real one accumulates
+    only what zero_grad left), the padded channels stay exactly zero, and state_dict round-trips into a fresh model."""
+    from chexpert_amd.models import DenseNet
+    rec = golden[tag]
+    n_cls = rec["n_classes"]
+    model, sd = _make(tag, n_cls)
+    model = model.to(dev)
+    x = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"]).to(dev)
+    t = synth.targets(rec["t_seed"], rec["B"], n_cls).to(dev)
+    model.eval()
+    with torch.no_grad():
+        le = model(x).cpu()
+    e = _rel(le, torch.tensor(rec["logits_eval"]))
+    print("%s eval logits rel %.3e" % (tag, e))
+    assert e < 1e-2
+    model.train()
+    model.zero_grad()
+    model.forward_backward(x, t)
+    g1 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    model.load_state_dict(sd, strict=True)                   # undo the running-statistics update
+    model.zero_grad()
+    model.forward_backward(x, t)
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, g1[k]), k
+    eng = model._eng()
+    twin = eng.twin
+    kp, k = twin.growth_rate, model.growth_rate
+    w = twin.features.denseblock1.denselayer2.conv2.weight       # rows k..kp of a padded 3x3 convolution: never written
+    assert (w[k:] == 0).all() and (w[:k] != 0).any()
+    assert (eng.inner.flat_grad[eng.inner.off_of[id(w)]:][:w.numel()].view(w.shape)[k:] == 0).all()
+    m2 = DenseNet(k, model.block_config, 2 * k, num_classes=n_cls).to(dev)
+    m2.load_state_dict(model.state_dict(), strict=True)
+    m2.eval()
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(m2(x), model(x))
+

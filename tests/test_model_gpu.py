@@ -437,8 +437,21 @@ def test_cifar_harness_trains_evaluates_and_restores(dev, tmp_path):
                            "--output_dir", o2] + arch) == 0
         r = js.loads(open(os.path.join(o2, "log.jsonl")).readline())
         assert np.isfinite(r["train_loss"])
-    with pytest.raises(NotImplementedError):
-        cifar.main(["--train", "--synthetic", "16", "--output_dir", str(tmp_path / "d"), "densenet", "12", "100"])
+    # the harness default of the reference's result rows (models/readme.md:34-38): Densenet-BC k = 12, L = 100 on the channel-padded
+    # twin -- memorises a batch through the fused SGD step, writes its checkpoints, and a restored run evaluates to the logged numbers
+    od = str(tmp_path / "d")
+    dbase = ["--dataset", "cifar10", "--synthetic", "32", "--mini_data", "--batch_size", "32", "--lr", "0.05", "--lr_warmup_epochs", "0",
+             "--eval_interval", "4", "--output_dir", od, "densenet", "12", "100"]
+    assert cifar.main(["--train", "--n_epochs", "8"] + dbase) == 0
+    recs = [js.loads(l) for l in open(os.path.join(od, "log.jsonl"))]
+    tr = [r["train_loss"] for r in recs if "train_loss" in r]
+    ev = [r for r in recs if "eval_loss" in r]
+    assert len(tr) == 8 and all(np.isfinite(tr)) and tr[-1] < 0.8 * tr[0], tr
+    assert cifar.main(["--evaluate", "--restore", os.path.join(od, "checkpoint.pt")] + dbase) == 0
+    last = js.loads(open(os.path.join(od, "log.jsonl")).readlines()[-1])
+    assert abs(last["eval_loss"] - ev[-1]["eval_loss"]) < 1e-5 and last["acc@top1"] == ev[-1]["acc@top1"]
+    with pytest.raises(NotImplementedError):          # its attention-augmented transitions (--attn) stay constructible only
+        cifar.main(["--train", "--attn", "--synthetic", "16", "--output_dir", str(tmp_path / "da"), "densenet", "12", "100"])
     # the harness's attention-augmented WideResNet: one step, then the attention maps of its four AAConv2d layers (--vis_attn)
     o3 = str(tmp_path / "aawrn")
     assert cifar.main(["--train", "--vis_attn", "--attn", "--dataset", "cifar10", "--synthetic", "16", "--mini_data", "--batch_size", "16",
