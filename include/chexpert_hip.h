@@ -54,7 +54,7 @@ enum {
   CX_EPI_MASK = 1,    /* dz = acc * [ex*e_sc + e_sh > 0]; S1 += sum dz; S2 += sum dz*(ex-e_mu)*e_r;
                          y = (accumulate ? y : 0) + e_scale*dz            (ReLU+BN backward)      */
   CX_EPI_JOIN = 2     /* ABI 8, residual join backward folded into the input gradient that completes the join's output
-                         gradient (attn_aug_conv.py:191-211: out = relu(bn3(z3) + identity)): t = bf16(y + acc) is the gradient of
+                         gradient (attn_aug_conv.py:202-209: out = relu(bn3(z3) + identity)): t = bf16(y + acc) is the gradient of
                          `out` (y holds the part that arrived through the identity path: accumulate must be set),
                          dz = t * [bit of emask], S1 += sum dz, S2 += sum dz*(ex-e_mu)*e_r with ex = z3 (the join BatchNorm's
                          input), y = dz.  Bit for bit what CX_EPI_STORE + cx_relu_bwd_stats_mask leave in y.  bf16, stride 1. */

@@ -427,3 +427,31 @@ def test_fp32_attention_augmented_nets_match_reference_golden_fixture(dev, tag, 
     assert e_train < 1e-3
     assert abs(loss.item() - rec["loss"]) < 1e-4 * rec["loss"]
     assert worst[0] < 1e-2
+
+
+@pytest.mark.parametrize("tag", ["densenetbc_k12_L40_32_b8", "densenetbc_k12_L100_32_b8"])
+def test_fp32_densenet_bc_matches_reference_golden_fixture(dev, tag):
+    """fp32 storage mode of the CIFAR Densenet-BC (channel-padded twin, models/test_model.py:304-306) against the fixture recorded from
+    the real reference: north_star's 1e-3 on train / eval logits and loss, gradient norms to 1 %."""
+    import json
+    import os
+    from test_golden_smooth_gpu import _make, _rel
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nets_smooth.json")))[tag]
+    n_cls = rec["n_classes"]
+    model, sd = _make(tag, n_cls)
+    model = model.storage_dtype("fp32").to(dev)
+    x = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"]).to(dev)
+    t = synth.targets(rec["t_seed"], rec["B"], n_cls).to(dev)
+    model.eval()
+    with torch.no_grad():
+        e_eval = _rel(model(x).cpu(), torch.tensor(rec["logits_eval"]))
+    model.train()
+    model.zero_grad()
+    loss, logits = model.forward_backward(x, t)
+    e = _rel(logits.cpu(), torch.tensor(rec["logits_train"]))
+    gmax = max(r["l2"] for r in rec["grads"].values())
+    worst = max((abs(p.grad.double().norm().item() / rec["grads"][k]["l2"] - 1.0), k) for k, p in model.named_parameters()
+                if rec["grads"][k]["l2"] > 1e-3 * gmax)
+    print("%s fp32: eval %.2e train %.2e loss %.2e worst gradient norm %s" % (tag, e_eval, e, abs(loss.item() - rec["loss"]) / rec["loss"], worst))
+    assert e_eval < 1e-3 and e < 1e-3 and abs(loss.item() - rec["loss"]) < 1e-3 * abs(rec["loss"])
+    assert worst[0] < 1e-2, worst
