@@ -23,19 +23,24 @@
 constexpr int NT = 512;
 
 __device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target, int* err) {
-  // all threads of the workgroup have finished their stores
+  // MI355X_MICROARCH.md's counter barrier: every storing wave drains its stores, the workgroup meets, ONE lane releases (L2
+  // write-back, agent scope), adds to the counter, polls it with relaxed sc1 loads, acquires once (L1 invalidate), waits for the
+  // invalidate; the other waves load after the workgroup barrier that lane then joins
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   bool ok = true;
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (wall_clock64() - t0 > 100000000ll) { *err = 1; ok = false; break; }     // 1 s at 100 MHz: never hang the GPU
       __builtin_amdgcn_s_sleep(1);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  __threadfence();           // acquire for the whole workgroup's later loads
   return ok;
 }
 
@@ -149,7 +154,7 @@ int main() {
     hipLaunchKernelGGL(barrier_only, dim3(G), dim3(NT), 0, st, counter, err, iters);
     CK(hipEventRecord(e1, st));
     CK(hipStreamSynchronize(st));
-    if (rep) printf("grid barrier alone (agent-scope add + sc1 poll, %d workgroups): %.2f us per barrier\n", G, elapsed_us(iters));
+    if (rep) printf("grid barrier alone (one lane: release, agent-scope add, relaxed sc1 poll, acquire; %d workgroups): %.2f us per barrier\n", G, elapsed_us(iters));
   }
   check_err("barrier_only");
 
