@@ -50,7 +50,7 @@ class CxWgradBatch(C.Structure):
 
 class CxChanMapDesc(C.Structure):
     _fields_ = [("real_off", C.c_int64), ("pad_off", C.c_int64), ("O", _i32), ("taps", _i32), ("Ireal", _i32), ("Ipad", _i32),
-                ("c0r", _i32), ("c0p", _i32), ("k", _i32), ("kp", _i32)]
+                ("c0r", _i32), ("c0p", _i32), ("k", _i32), ("kp", _i32), ("split", _i32), ("shift", _i32)]
 
 
 class CxPackDesc(C.Structure):

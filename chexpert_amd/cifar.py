@@ -11,8 +11,9 @@ no torchvision here), `--synthetic N` otherwise: N random normalised images with
 
 The attention-augmented WideResNet (`--attn`: AAConv2d as conv1 of the BasicBlocks of stages 2-3, test_model.py:265-269) runs on the
 HIP attention kernels where they cover the head sizes (dk/nh = 20, dv/nh in {1,2,3,4,6,8}: e.g. WRN-16-4, WRN-28-10 at 8 heads), and
-`--vis_attn` draws its attention maps (:201-234).  Not on the HIP schedule (raises with the reason): `densenet` with the three-block
-CIFAR configuration (the DenseNet engine is the four-block ImageNet-shaped one).
+`--vis_attn` draws its attention maps (:201-234).  `densenet k L` (Densenet-BC, :304-306; default 12 100) runs on the channel-padded
+twin of models/densenet.py, also with `--attn` at the harness defaults (dv/nh = 1); `--attn_v 0.7` of the reference's result rows
+(heads of 9 / 13 value channels) raises NotImplementedError.
 """
 import argparse
 import json
@@ -321,13 +322,16 @@ def main(argv=None):
         log({"step": args.step, "eval_loss": loss, "acc@top1": top1, "acc@top5": top5})
     if args.vis_attn:
         assert args.attn, "Enable --attn flag to visualize attention."
-        if args.model != "wideresnet":
-            raise RuntimeError("Model not supported.")                  # test_model.py:347-352 (the CIFAR DenseNet is not runnable here)
+        if args.model not in ("wideresnet", "densenet"):
+            raise RuntimeError("Model not supported.")                  # test_model.py:347-352
         x = next(iter(valid_loader))[0][:8]
         model.eval()
         with torch.no_grad():
             model(x.to(args.device))                                     # stores the attention operands of every AAConv2d
-        layers = [blk.conv1 for blk in model.layer2] + [blk.conv1 for blk in model.layer3]
+        if args.model == "wideresnet":
+            layers = [blk.conv1 for blk in model.layer2] + [blk.conv1 for blk in model.layer3]
+        else:
+            layers = [model.features.transition1.conv, model.features.transition2.conv]
         images = (x * STD.view(1, 3, 1, 1) + MEAN.view(1, 3, 1, 1)).clamp(0, 1)
         for i in range(len(x)):
             vis_attn(images, layers, args, i)

@@ -1341,7 +1341,8 @@ int cx_pack_weights_table(const float* flat, void* packed, const CxPackDesc* tab
 
 // Channel-padded twin of a network whose widths are not multiples of 8 (the CIFAR DenseNet-BC of models/test_model.py:306: growth
 // 12).  Element (o, j, t) of a real OIHW tensor lives at (o, pos(j), t) of the padded one, pos(j) = j for j < c0r (a block's first
-// channels), else c0p + ((j - c0r) / k) * kp + (j - c0r) % k (dense layer (j - c0r) / k writes kp >= k channels).  dir 0: real ->
+// channels; j + shift from j = split on: an attention-augmented transition writes its convolution branch, padded, then its
+// attention channels), else c0p + ((j - c0r) / k) * kp + (j - c0r) % k (dense layer (j - c0r) / k writes kp >= k channels).  dir 0: real ->
 // padded (store; positions no real element maps to keep their zeros), dir 1: padded -> real (add: gradients; or store).
 __global__ void chan_map_table_kernel(float* __restrict__ real, float* __restrict__ padded, const CxChanMapDesc* __restrict__ table,
                                       int dir, int accumulate) {
@@ -1351,7 +1352,7 @@ __global__ void chan_map_table_kernel(float* __restrict__ real, float* __restric
   const int total = d.O * d.Ireal * d.taps;
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     const int t = idx % d.taps, j = (idx / d.taps) % d.Ireal, o = idx / (d.taps * d.Ireal);
-    const int pj = j < d.c0r ? j : d.c0p + ((j - d.c0r) / d.k) * d.kp + (j - d.c0r) % d.k;
+    const int pj = j < d.c0r ? (j < d.split ? j : j + d.shift) : d.c0p + ((j - d.c0r) / d.k) * d.kp + (j - d.c0r) % d.k;
     const size_t pi = ((size_t)o * d.Ipad + pj) * d.taps + t;
     if (dir == 0) q[pi] = r[idx];
     else r[idx] = accumulate ? r[idx] + q[pi] : q[pi];

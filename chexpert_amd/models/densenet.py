@@ -174,7 +174,9 @@ class _Workspace:
         self.buf, self.gbuf, self.y1, self.hw = [], [], [], []
         for bi, (c_in, n_layers) in enumerate(eng.blocks):
             ct = c_in + n_layers * g
-            self.buf.append(e(B, h, w, ct))
+            # (twin of a CIFAR DenseNet-BC: the channels between an attention-augmented transition's output and the padded block
+            # entry are written by nobody and must read as zero)
+            self.buf.append(torch.zeros(B, h, w, ct, dtype=bf, device=dev) if eng.cifar else e(B, h, w, ct))
             self.gbuf.append(None)
             self.y1.append([e(B, h, w, eng.mid) for _ in range(n_layers)])
             self.hw.append((h, w))
@@ -274,10 +276,9 @@ class _Engine:
             self.blocks.append((c, n_layers))
             c = c + n_layers * self.growth
             if len(self.blocks) != len(model.block_config):
-                tr = getattr(f, "transition%d" % len(self.blocks))
-                # (the width the transition's convolution produces: c // 2 in the reference; the channel-padded twin of a
-                # CIFAR DenseNet-BC rounds it up to a multiple of 8)
-                c = tr.conv.out_channels if isinstance(tr.conv, nn.Conv2d) else c // 2
+                # (the width the next block starts from: c // 2 in the reference's networks; the channel-padded twin of a CIFAR
+                # DenseNet-BC rounds it up, and pads between the two branches of an attention-augmented transition)
+                c = getattr(f, "denseblock%d" % (len(self.blocks) + 1)).denselayer1.norm1.num_features
         self.c_final = c
         self.flat = None
         self.flat_grad = None
@@ -574,8 +575,8 @@ class _Engine:
         s = self.slots
         buf, nxt, T = ws.buf[bi], ws.buf[bi + 1], ws.aa[bi]
         B, h, w, ct = buf.shape
-        cout = ct // 2
-        cc = cout - aa.dv
+        cc = aa.conv.out_channels                               # convolution branch, then the attention channels
+        cout = cc + aa.dv                                       # (= ct // 2 in the reference's networks)
         ops.stats_bc(buf, T.stat[0], T.stat[1])                 # one owner per (image, channel): plain stores
         ops.bn_coef(T.stat[0], T.stat[1], h * w, None, None, 1e-5, 0.0, None, None, T.coef[0], T.coef[1], None, None, B * ct)
         ops.affine_relu_bc(buf, T.coef[0], T.coef[1], T.A)
@@ -606,11 +607,11 @@ class _Engine:
         """Backward of the AA transition feeding block bi (from block bi-1); qa/qb/qc apply the deferred BN correction
         to the gradient slice [0, c0) of block bi."""
         buf, gbuf, pbuf, pg, T = ws.buf[bi], ws.gbuf[bi], ws.buf[bi - 1], ws.gbuf[bi - 1], ws.aa[bi - 1]
-        c0 = self.blocks[bi][0]
-        cc = c0 - aa.dv
+        cc = aa.conv.out_channels
+        c0 = cc + aa.dv                          # (the block's entry width in the reference's networks; the padded twin's is wider)
         Cp = pbuf.shape[3]
         gs_c, xs_c, gs_a, xs_a = gbuf[..., :cc], buf[..., :cc], gbuf[..., cc:c0], buf[..., cc:c0]
-        ops.aa_outproj_bwd(gs_a, xs_a, qa[cc:], qb[cc:], qc[cc:], T.O, aa.out_proj.weight, T.dO, G(aa.out_proj.weight))
+        ops.aa_outproj_bwd(gs_a, xs_a, qa[cc:c0], qb[cc:c0], qc[cc:c0], T.O, aa.out_proj.weight, T.dO, G(aa.out_proj.weight))
         ops.aa_attention_bwd(T.QKV, aa.key_rel_h, aa.key_rel_w, T.O, T.dO, T.LSE, T.dQKV32, G(aa.key_rel_h), G(aa.key_rel_w), aa.nh,
                              aa.dk, aa.dv)
         if self.dtype == torch.float32:         # fp32 storage mode: the fp32 gradient is the convolution operand as it is
@@ -958,12 +959,13 @@ class _TwinNet(nn.Module):
         f.add_module("conv0", Conv2dParams(8, cip, kh, rf.conv0.stride[0], rf.conv0.padding[0], bias=False))
         f.add_module("norm0", BatchNorm2dParams(cip))
         # channel maps (c0r, c0p, k, kp) of every block buffer, and the (real tensor, twin tensor, rows, map) list of the sync tables
-        self.maps, self.pairs = [], []
-        ident = lambda n, npad: (n, npad, 1, 1)
-        self.pairs += [(rf.conv0.weight, f.conv0.weight, ci, (3, 8, 1, 1)), (rf.norm0, f.norm0, None, ident(ci, cip))]
+        self.maps, self.pairs, self.aa_pairs = [], [], []
+        ident = lambda n, npad: (n, npad, 1, 1, n, 0)
+        self.pairs += [(rf.conv0.weight, f.conv0.weight, ci, ident(3, 8)), (rf.norm0, f.norm0, None, ident(ci, cip))]
         cr, cp = ci, cip
+        split, shift = ci, 0                  # inside a block's first channels: real j >= split sits at j + shift (after an AA transition)
         for bi, n in enumerate(real.block_config):
-            m_ = (cr, cp, k, kp)
+            m_ = (cr, cp, k, kp, split, shift)
             self.maps.append(m_)
             rblock = getattr(rf, "denseblock%d" % (bi + 1))
             block = nn.Sequential()
@@ -980,7 +982,28 @@ class _TwinNet(nn.Module):
                                (rl.norm2, L.norm2, None, ident(mid, midp)), (rl.conv2.weight, L.conv2.weight, k, ident(mid, midp))]
             f.add_module("denseblock%d" % (bi + 1), block)
             ctr, ctp = cr + n * k, cp + n * kp
-            if bi != nb - 1:
+            if bi != nb - 1 and isinstance(getattr(rf, "transition%d" % (bi + 1)).conv, AAConv2d):
+                # attention-augmented transition (attn_aug_conv.py:436-440): InstanceNorm -> ReLU -> AAConv2d(3x3, stride 2).  Its
+                # output is [convolution branch | attention channels]: the branch is padded to a multiple of 8, the attention
+                # channels follow, the rest up to the next block's entry width reads as zero
+                raa = getattr(rf, "transition%d" % (bi + 1)).conv
+                ccr, dv = raa.conv.out_channels, raa.dv
+                ccp = _up8(ccr)
+                cor, cop = ccr + dv, padc(ccp + dv, real.block_config[bi + 1])
+                T = nn.Sequential()
+                T.add_module("norm", InstanceNormMarker(ctp))
+                taa = AAConv2d(ctp, ccp + dv, 3, 2, raa.dk, dv, raa.nh, raa.relative, raa.input_dims)
+                T.add_module("conv", taa)
+                f.add_module("transition%d" % (bi + 1), T)
+                self.pairs += [(raa.conv.weight, taa.conv.weight, ccr, m_), (raa.in_proj_qkv.weight, taa.in_proj_qkv.weight, 2 * raa.dk + dv, m_),
+                               (raa.out_proj.weight, taa.out_proj.weight, dv, ident(dv, dv))]
+                if raa.relative:
+                    for nm in ("key_rel_h", "key_rel_w"):
+                        rp, tp = getattr(raa, nm), getattr(taa, nm)
+                        self.pairs.append((rp, tp, rp.shape[0], ident(rp.shape[1], tp.shape[1])))
+                self.aa_pairs.append((raa, taa))
+                cr, cp, split, shift = cor, cop, ccr, ccp - ccr
+            elif bi != nb - 1:
                 rt = getattr(rf, "transition%d" % (bi + 1))
                 cor = rt.conv.out_channels
                 cop = padc(cor, real.block_config[bi + 1])
@@ -989,7 +1012,7 @@ class _TwinNet(nn.Module):
                 T.add_module("conv", Conv2dParams(ctp, cop, 1, 1, bias=False))
                 f.add_module("transition%d" % (bi + 1), T)
                 self.pairs += [(rt.norm, T.norm, None, m_), (rt.conv.weight, T.conv.weight, cor, m_)]
-                cr, cp = cor, cop
+                cr, cp, split, shift = cor, cop, cor, 0
             else:
                 f.add_module("norm5", BatchNorm2dParams(ctp))
                 self.classifier = nn.Linear(ctp, real.classifier.out_features, bias=real.classifier.bias is not None)
@@ -1058,13 +1081,13 @@ class _PaddedEngine:
         from .._lib import CxChanMapDesc
         pd, sd = [], []
         bi = 0
-        for r, t, rows, (c0r, c0p, k, kp) in self.twin.pairs:
+        for r, t, rows, (c0r, c0p, k, kp, split, shift) in self.twin.pairs:
             if isinstance(r, nn.BatchNorm2d):
                 C_r, C_p = r.num_features, t.num_features
                 for rp, tp in ((r.weight, t.weight), (r.bias, t.bias)):
-                    pd.append(CxChanMapDesc(self.off_of[id(rp)], in_.off_of[id(tp)], 1, 1, C_r, C_p, c0r, c0p, k, kp))
+                    pd.append(CxChanMapDesc(self.off_of[id(rp)], in_.off_of[id(tp)], 1, 1, C_r, C_p, c0r, c0p, k, kp, split, shift))
                 for j in range(2):
-                    sd.append(CxChanMapDesc(self.boffs[bi + j], tboffs[bi + j], 1, 1, C_r, C_p, c0r, c0p, k, kp))
+                    sd.append(CxChanMapDesc(self.boffs[bi + j], tboffs[bi + j], 1, 1, C_r, C_p, c0r, c0p, k, kp, split, shift))
                 bi += 2
             else:
                 O_r = r.shape[0]
@@ -1073,7 +1096,9 @@ class _PaddedEngine:
                 taps = r[0, 0].numel() if r.dim() == 4 else 1
                 if r.dim() == 1:                 # classifier bias: one row of O_r channels
                     O_r, I_r, I_p = 1, r.shape[0], t.shape[0]
-                pd.append(CxChanMapDesc(self.off_of[id(r)], in_.off_of[id(t)], O_r, taps, I_r, I_p, c0r, c0p, k, kp))
+                if rows is not None and r.dim() > 1:
+                    O_r = rows
+                pd.append(CxChanMapDesc(self.off_of[id(r)], in_.off_of[id(t)], O_r, taps, I_r, I_p, c0r, c0p, k, kp, split, shift))
 
         def table(descs):
             arr = (CxChanMapDesc * len(descs))(*descs)
@@ -1091,6 +1116,8 @@ class _PaddedEngine:
         self._map(self.stat, self.tstat, self.stab, 0)            # running statistics
         in_.packed_version = None
         ws = in_.forward(x, train)
+        for raa, taa in self.twin.aa_pairs:                       # AAConv2d.weights of the real module (attn_aug_conv.py:87)
+            object.__setattr__(raa, "_last", taa._last)
         if train:
             self._map(self.stat, self.tstat, self.stab, 1)        # updated running statistics: padded -> real
             self.twin._nbt_pending = 0
@@ -1173,9 +1200,6 @@ class DenseNet(nn.Module):
     # the engine is rebuilt lazily (the classifier may be replaced after construction, chexpert.py:464)
     def _eng(self):
         padded = len(self.block_config) != 4 or self.growth_rate % 8 or self.features.conv0.out_channels % 8
-        if padded and any(isinstance(mod, AAConv2d) for mod in self.modules()):
-            raise NotImplementedError("attention-augmented transitions of the CIFAR DenseNet-BC (models/test_model.py:306 with "
-                                      "--attn) are constructible only; the plain DenseNet-BC runs on the HIP schedule")
         if padded and len(self.block_config) == 4:
             raise NotImplementedError("ImageNet-stem DenseNets need growth and stem widths that are multiples of 8")
         for mod in self.modules():

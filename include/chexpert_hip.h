@@ -149,11 +149,14 @@ int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* 
  * zero: zero weights, zero BatchNorm gain and shift) and whose transitions are padded likewise; this entry point moves parameters
  * / running statistics real -> padded (dir 0, store) and gradients / running statistics padded -> real (dir 1; accumulate: add)
  * between two flat fp32 buffers, one descriptor per tensor, ONE launch.  Element (o, j, t) of the real [O][Ireal][taps] tensor is
- * element (o, pos(j), t) of the padded [.][Ipad][taps] one, pos(j) = j for j < c0r, else c0p + ((j-c0r)/k)*kp + (j-c0r)%k.        */
+ * element (o, pos(j), t) of the padded [.][Ipad][taps] one, pos(j) = j (+ shift from `split` on) for j < c0r, else
+ * c0p + ((j-c0r)/k)*kp + (j-c0r)%k.                                                                                             */
 typedef struct CxChanMapDesc {
   int64_t real_off, pad_off;         /* element offsets into the two flat buffers                                             */
   int32_t O, taps, Ireal, Ipad;      /* rows copied (the padded tensor may have more), kh*kw, channels per row                   */
   int32_t c0r, c0p, k, kp;           /* channel map (k = kp = 1, c0r = Ireal: identity with a wider row)                          */
+  int32_t split, shift;              /* inside the first c0r channels: j >= split sits at j + shift (split = c0r, shift = 0: none) --
+                                        the output of an attention-augmented transition is [conv branch | pad | attention channels] */
 } CxChanMapDesc;
 int cx_chan_map_table(float* real_flat, float* padded_flat, const CxChanMapDesc* table_dev, int n_desc, int dir, int accumulate,
                       void* stream);

@@ -305,6 +305,12 @@ def gen_smooth(out_dir, which):
         "densenetbc_k12_L100_32_b8": lambda: (DenseNet(12, (16, 16, 16), 24, num_classes=n_cls),
                                               nets.densenet_spec(n_cls, growth=12, block_config=(16, 16, 16), init_features=24), 8, 32, 2.5,
                                               lambda s, x, train, q=None: nets.densenet_forward(s, x, (16, 16, 16), train=train, q=q)),
+        # ... and with the harness's --attn defaults (k 0.2, v 0.1, 8 heads): both transitions are InstanceNorm -> ReLU ->
+        # AAConv2d(3x3, stride 2) with dk 160, dv 8 on 16x16 / 8x8 maps
+        "aadensenetbc_k12_L100_32_b8": lambda: (DenseNet(12, (16, 16, 16), 24, num_classes=n_cls, attn_params=ref_attn((32, 32))),
+                                                nets.densenet_spec(n_cls, growth=12, block_config=(16, 16, 16), init_features=24,
+                                                                   attn=attn, input_hw=(32, 32)), 8, 32, 2.5,
+                                                lambda s, x, train, q=None: nets.densenet_forward(s, x, (16, 16, 16), train=train, nh=8, q=q)),
     }
     for tag, job in jobs.items():
         if which and not any(w in tag for w in which):

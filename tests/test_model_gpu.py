@@ -450,8 +450,14 @@ def test_cifar_harness_trains_evaluates_and_restores(dev, tmp_path):
     assert cifar.main(["--evaluate", "--restore", os.path.join(od, "checkpoint.pt")] + dbase) == 0
     last = js.loads(open(os.path.join(od, "log.jsonl")).readlines()[-1])
     assert abs(last["eval_loss"] - ev[-1]["eval_loss"]) < 1e-5 and last["acc@top1"] == ev[-1]["acc@top1"]
-    with pytest.raises(NotImplementedError):          # its attention-augmented transitions (--attn) stay constructible only
-        cifar.main(["--train", "--attn", "--synthetic", "16", "--output_dir", str(tmp_path / "da"), "densenet", "12", "100"])
+    # ... and with --attn (harness defaults k 0.2, v 0.1, 8 heads): attention-augmented transitions on the padded twin, one step + maps
+    oa = str(tmp_path / "da")
+    assert cifar.main(["--train", "--vis_attn", "--attn", "--dataset", "cifar10", "--synthetic", "16", "--mini_data", "--batch_size", "16",
+                       "--output_dir", oa, "densenet", "12", "100"]) == 0
+    assert np.isfinite(js.loads(open(os.path.join(oa, "log.jsonl")).readline())["train_loss"])
+    assert len([f for f in os.listdir(oa) if f.startswith("vis_attn_image_")]) == 8 * 2
+    with pytest.raises(NotImplementedError):          # v = 0.7 of the reference's result rows: heads of 9 / 13 value channels
+        cifar.main(["--train", "--attn", "--attn_v", "0.7", "--synthetic", "16", "--output_dir", str(tmp_path / "db"), "densenet", "12", "100"])
     # the harness's attention-augmented WideResNet: one step, then the attention maps of its four AAConv2d layers (--vis_attn)
     o3 = str(tmp_path / "aawrn")
     assert cifar.main(["--train", "--vis_attn", "--attn", "--dataset", "cifar10", "--synthetic", "16", "--mini_data", "--batch_size", "16",
