@@ -17,6 +17,7 @@ as one schedule of fused kernels over NHWC bf16 buffers:
     share xhat, so they are accumulated as two per-channel coefficients and applied once by the
     channel's producer; the gradient buffer only receives gamma*rstd*dz contributions.
 """
+import contextlib
 import ctypes as C
 import math
 from collections import OrderedDict
@@ -632,11 +633,20 @@ class _Engine:
         """Launch the collected 3x3 weight gradients of the current block (one batched launch per 24 layers; per layer when the
         library declines the shape or the slab workspace)."""
         items, self._w2_items = self._w2_items, []
-        for i in range(0, len(items), ops.L.WGRAD_BATCH_MAX):
-            part = items[i:i + ops.L.WGRAD_BATCH_MAX]
-            if not ops.conv3x3_wgrad_batch(part):
-                for dyc, y1, pa, pb, dw in part:
-                    ops.conv_wgrad(dyc, y1, dw, kh=3, kw=3, pad=1, x_prologue=ops.PRO_AFFINE_RELU, pa=pa, pb=pb)
+        if not items:
+            return
+        # CHEXPERT_W2_SIDE=1 (experiment): the batch on the side stream, beside the next block's input-gradient chain; backward joins
+        # the streams at its end (the reducer-driven flush stays on the main stream: the bucket must be final)
+        side = self.side if (os.environ.get("CHEXPERT_W2_SIDE", "0") == "1" and self.reducer is None and self.side is not None) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        with ctx:
+            for i in range(0, len(items), ops.L.WGRAD_BATCH_MAX):
+                part = items[i:i + ops.L.WGRAD_BATCH_MAX]
+                if not ops.conv3x3_wgrad_batch(part):
+                    for dyc, y1, pa, pb, dw in part:
+                        ops.conv_wgrad(dyc, y1, dw, kh=3, kw=3, pad=1, x_prologue=ops.PRO_AFFINE_RELU, pa=pa, pb=pb)
 
     # ---- backward
     def backward(self, ws, dlogits):
@@ -887,6 +897,8 @@ class _Engine:
                 ops.conv_wgrad(ws.dz0, ws.x4, G(f.conv0.weight), mode=ops.MODE_STEM, g_prologue=ops.PRO_AFFINE2, g2=ws.c0,
                                ga=pa, gb=pb, gc=pc)
         main.wait_stream(side)
+        if side is main and os.environ.get("CHEXPERT_W2_SIDE", "0") == "1":
+            main.wait_stream(self.side)
         if red is not None:
             red.finish()
         if fresh:

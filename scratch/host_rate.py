@@ -10,10 +10,10 @@ from chexpert_amd.optim import FusedAdam
 dev = torch.device('cuda:0')
 ATT = lambda s: {"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (s, s)}
 MODELS = {
-    "densenet121": (lambda: densenet121(num_classes=14), 320, 256, 30.8),
-    "aadensenet121": (lambda: DenseNet(32, (6, 12, 24, 16), 64, num_classes=14, attn_params=ATT(320)), 320, 128, 30.9),
-    "resnet152": (lambda: resnet152(num_classes=14), 320, 128, 56.6),
-    "efficientnet-b4": (lambda: construct_model("efficientnet-b4", 14), 380, 64, 36.9),
+    "densenet121": (lambda: densenet121(num_classes=14), 320, 256, 30.0),
+    "aadensenet121": (lambda: DenseNet(32, (6, 12, 24, 16), 64, num_classes=14, attn_params=ATT(320)), 320, 128, 29.6),
+    "resnet152": (lambda: resnet152(num_classes=14), 320, 128, 54.8),
+    "efficientnet-b4": (lambda: construct_model("efficientnet-b4", 14), 380, 64, 36.4),
 }
 for name, (ctor, S, B, gpu_ms) in MODELS.items():
     m = ctor().to(dev).train()
@@ -35,6 +35,7 @@ for name, (ctor, S, B, gpu_ms) in MODELS.items():
             opt.step()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
+    # (the GPU step times are the committed bench lines of profiles/r03_bench_*.json, quoted for comparison)
     print("%-16s host enqueue %.1f ms/step (batch 2: the GPU is idle most of the step); GPU step at batch %d: %.1f ms" % (
         name, (t1 - t0) / n * 1e3, B, gpu_ms), flush=True)
     del m
