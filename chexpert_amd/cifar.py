@@ -12,8 +12,8 @@ no torchvision here), `--synthetic N` otherwise: N random normalised images with
 The attention-augmented WideResNet (`--attn`: AAConv2d as conv1 of the BasicBlocks of stages 2-3, test_model.py:265-269) runs on the
 HIP attention kernels where they cover the head sizes (dk/nh = 20, dv/nh in {1,2,3,4,6,8}: e.g. WRN-16-4, WRN-28-10 at 8 heads), and
 `--vis_attn` draws its attention maps (:201-234).  `densenet k L` (Densenet-BC, :304-306; default 12 100) runs on the channel-padded
-twin of models/densenet.py, also with `--attn` at the harness defaults (dv/nh = 1); `--attn_v 0.7` of the reference's result rows
-(heads of 9 / 13 value channels) raises NotImplementedError.
+twin of models/densenet.py, also with `--attn` at the harness defaults (dv/nh = 1) and at `--attn_v 0.7` of the reference's result
+rows (heads of 9 / 13 value channels); value ratios whose heads the attention kernels do not cover raise NotImplementedError.
 """
 import argparse
 import json

@@ -25,7 +25,8 @@ namespace {
 constexpr int AQ = 128;      // queries per workgroup (one per thread)
 constexpr int TK = 64;       // keys per LDS tile
 constexpr int DKH = 20;      // head dim of q/k for every AA layer of the reference (dk = max(20*nh, ...) = 160, nh = 8)
-constexpr int MAXDV = 8;        // dv/nh in {1,2,3,4,6,8}: every AA layer chexpert.py trains, and WRN-28-10's third stage (dv 64 at 8 heads)
+constexpr int MAXDV = 13;       // dv/nh in {1,2,3,4,6,8}: every AA layer chexpert.py trains, and WRN-28-10's third stage (dv 64 at 8 heads);
+                                // 9 and 13: the Densenet-BC transitions of the CIFAR harness at v = 0.7 (models/readme.md:34-38)
 
 struct AAGeo {
   int B, H, W, nh, dk, dv, ldq;     // qkv tensor: (B, H*W, ldq) bf16, channels [q dk | k dk | v dv]
@@ -575,11 +576,11 @@ __global__ __launch_bounds__(256) void stats_bc_kernel(const T* __restrict__ x, 
 // [+ per-channel statistics of the rounded output].  TA = (256 / dv) * dv threads are active: a thread keeps ONE output channel
 // (tid % dv) and walks pixels, so its two sums are registers; they meet in LDS and are added in pixel-lane order.  det: the
 // workgroup plain-stores its row (stat_sum[row * rstride + c], CxConv.stat_det convention), else one atomic per channel.
-template <typename T>
+template <typename T, int DM>
 __global__ __launch_bounds__(256) void aa_outproj_fwd_kernel(const float* __restrict__ o, const float* __restrict__ w, T* __restrict__ y,
                                                              int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv, int TA, int det,
                                                              int rstride) {
-  __shared__ float ws[64 * 64];
+  __shared__ float ws[DM * DM];          // DM = 64, or 104 for the 72- / 104-channel out-projections of the CIFAR Densenet-BC at v = 0.7
   __shared__ float st[2][256];
   const int tid = threadIdx.x;
   for (int t = tid; t < dv * dv; t += blockDim.x) ws[t] = w[t];
@@ -658,6 +659,58 @@ __global__ __launch_bounds__(256) void aa_outproj_bwd_kernel(const T* __restrict
   }
   __syncthreads();
   for (int t = tid; t < dv * dv; t += 256) dw_out(dw, slab, (size_t)dv * dv, (int)blockIdx.x, t, dws[t]);
+}
+
+// The same for 64 < dv <= 104 (Densenet-BC transitions of the CIFAR harness at v = 0.7: dv = 72 / 104): the dv x dv weight-gradient
+// sums do not fit LDS beside the weights, so a thread keeps its (c, d) pairs -- pair = tid + 256 i -- in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void aa_outproj_bwd_big_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ gx, int ldgx,
+                                                                 const float* __restrict__ ga, const float* __restrict__ gb,
+                                                                 const float* __restrict__ gc, const float* __restrict__ o,
+                                                                 const float* __restrict__ w, float* __restrict__ d_o,
+                                                                 float* __restrict__ dw, float* __restrict__ slab, size_t npix, int dv) {
+  constexpr int DM = 104, CH = 16, PT = DM + 1, NP = (DM * DM + 255) / 256;
+  __shared__ float ws[DM * DM];
+  __shared__ float dyS[CH * PT];
+  __shared__ float oS[CH * PT];
+  const int tid = threadIdx.x;
+  float acc[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) acc[i] = 0.f;
+  for (int t = tid; t < dv * dv; t += 256) ws[t] = w[t];
+  for (size_t p0 = (size_t)blockIdx.x * CH; p0 < npix; p0 += (size_t)gridDim.x * CH) {
+    __syncthreads();
+    for (int idx = tid; idx < CH * dv; idx += 256) {
+      const int px = idx / dv, c = idx - px * dv;
+      const size_t pix = p0 + px;
+      const bool ok = pix < npix;
+      dyS[px * PT + c] = ok ? fmaf(V4<T>::ld1(g + pix * ldg + c), ga[c], fmaf(V4<T>::ld1(gx + pix * ldgx + c), gb[c], gc[c])) : 0.f;
+      oS[px * PT + c] = ok ? o[pix * dv + c] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < CH * dv; idx += 256) {
+      const int px = idx / dv, d = idx - px * dv;
+      float a = 0.f;
+      for (int c = 0; c < dv; ++c) a = fmaf(dyS[px * PT + c], ws[c * dv + d], a);
+      if (p0 + px < npix) d_o[(p0 + px) * dv + d] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int pair = tid + 256 * i;
+      if (pair < dv * dv) {
+        const int c = pair / dv, d = pair - c * dv;
+        float a = 0.f;
+#pragma unroll
+        for (int px = 0; px < CH; ++px) a = fmaf(dyS[px * PT + c], oS[px * PT + d], a);
+        acc[i] += a;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pair = tid + 256 * i;
+    if (pair < dv * dv) dw_out(dw, slab, (size_t)dv * dv, (int)blockIdx.x, pair, acc[i]);
+  }
 }
 
 // fp32 (B,HW,C) -> bf16 same shape
@@ -786,6 +839,8 @@ int aa_attention_fwd_t(const void* qkv, const float* rel_h, const float* rel_w, 
     case 4: LAUNCH(4); break;
     case 6: LAUNCH(6); break;
     case 8: LAUNCH(8); break;
+    case 9: LAUNCH(9); break;
+    case 13: LAUNCH(13); break;
     default: return CX_EUNSUPPORTED;
   }
 #undef LAUNCH
@@ -827,6 +882,8 @@ int aa_attention_bwd_t(const void* qkv, const float* rel_h, const float* rel_w, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_kernel<T, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   // Reproducible relative-table gradients: every query-side workgroup plain-stores its two partial tables into the caller's
@@ -857,6 +914,8 @@ int aa_attention_bwd_t(const void* qkv, const float* rel_h, const float* rel_w, 
       case 4: LAUNCH(4); break;
       case 6: LAUNCH(6); break;
       case 8: LAUNCH(8); break;
+      case 9: LAUNCH(9); break;
+      case 13: LAUNCH(13); break;
       default: return CX_EUNSUPPORTED;
     }
 #undef LAUNCH
@@ -888,14 +947,18 @@ int affine_relu_bc_t(const void* x, const float* sc, const float* sh, void* y, i
 template <typename T>
 int aa_outproj_fwd_t(const float* o, const float* w, void* y, int ldy, float* stat_sum, float* stat_sq, size_t npix, int dv,
                       int stat_rows, int stat_rstride, void* stream) {
-  if (!o || !w || !y || dv <= 0 || dv > 64) return CX_EINVAL;
+  if (!o || !w || !y || dv <= 0 || dv > 104) return CX_EINVAL;
   if ((stat_sum == nullptr) != (stat_sq == nullptr)) return CX_EINVAL;
   if (stat_rows > 0 && (!stat_sum || stat_rstride < dv)) return CX_EINVAL;
   const int TA = 256 / dv * dv;
   int grid = grid_for(npix * dv, 256, 2048);
   if (stat_rows > 0) { if (grid > stat_rows) grid = stat_rows; cx_tl_stat_rows = grid; }
-  hipLaunchKernelGGL(aa_outproj_fwd_kernel<T>, dim3(grid), dim3(256), 0, as_stream(stream), o, w, (T*)y, ldy, stat_sum, stat_sq, npix, dv,
-                     TA, stat_rows > 0 ? 1 : 0, stat_rstride);
+  if (dv <= 64)
+    hipLaunchKernelGGL((aa_outproj_fwd_kernel<T, 64>), dim3(grid), dim3(256), 0, as_stream(stream), o, w, (T*)y, ldy, stat_sum, stat_sq, npix,
+                       dv, TA, stat_rows > 0 ? 1 : 0, stat_rstride);
+  else
+    hipLaunchKernelGGL((aa_outproj_fwd_kernel<T, 104>), dim3(grid), dim3(256), 0, as_stream(stream), o, w, (T*)y, ldy, stat_sum, stat_sq, npix,
+                       dv, TA, stat_rows > 0 ? 1 : 0, stat_rstride);
   return launch_status();
 }
 
@@ -903,10 +966,13 @@ template <typename T>
 int aa_outproj_bwd_t(const void* g, int ldg, const void* gx, int ldgx, const float* ga, const float* gb, const float* gc,
                       const float* o, const float* w, float* d_o, float* dw, size_t npix, int dv, float* scratch, int64_t scratch_floats,
                       void* stream) {
-  if (!g || !gx || !ga || !gb || !gc || !o || !w || !d_o || !dw || dv <= 0 || dv > 64) return CX_EINVAL;
+  if (!g || !gx || !ga || !gb || !gc || !o || !w || !d_o || !dw || dv <= 0 || dv > 104) return CX_EINVAL;
   const int grid = grid_for(npix, 64, 1024);
   float* slab = dw_slab(scratch, scratch_floats, grid, (long long)dv * dv);
-  if (dv <= 48)
+  if (dv > 64)
+    hipLaunchKernelGGL((aa_outproj_bwd_big_kernel<T>), dim3(grid), dim3(256), 0, as_stream(stream), (const T*)g, ldg, (const T*)gx, ldgx,
+                       ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
+  else if (dv <= 48)
     hipLaunchKernelGGL((aa_outproj_bwd_kernel<T, 48, 64>), dim3(grid), dim3(256), 0, as_stream(stream), (const T*)g, ldg,
                        (const T*)gx, ldgx, ga, gb, gc, o, w, d_o, dw, slab, npix, dv);
   else

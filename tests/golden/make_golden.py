@@ -311,6 +311,13 @@ def gen_smooth(out_dir, which):
                                                 nets.densenet_spec(n_cls, growth=12, block_config=(16, 16, 16), init_features=24,
                                                                    attn=attn, input_hw=(32, 32)), 8, 32, 2.5,
                                                 lambda s, x, train, q=None: nets.densenet_forward(s, x, (16, 16, 16), train=train, nh=8, q=q)),
+        # ... and with the value-channel ratio of the reference's CIFAR result rows (models/readme.md:34-38: Nh 8, k 0.2, v 0.7):
+        # heads of 9 / 13 value channels, out-projections of 72 / 104 channels
+        "aadensenetbcv07_k12_L100_32_b8": lambda: (DenseNet(12, (16, 16, 16), 24, num_classes=n_cls,
+                                                            attn_params=dict(ref_attn((32, 32)), v=0.7)),
+                                                   nets.densenet_spec(n_cls, growth=12, block_config=(16, 16, 16), init_features=24,
+                                                                      attn=dict(attn, v=0.7), input_hw=(32, 32)), 8, 32, 2.5,
+                                                   lambda s, x, train, q=None: nets.densenet_forward(s, x, (16, 16, 16), train=train, nh=8, q=q)),
     }
     for tag, job in jobs.items():
         if which and not any(w in tag for w in which):

@@ -31,7 +31,8 @@ def close(got, want, rel, what=""):
 
 
 @pytest.mark.parametrize("B,H,W,dv", [(2, 5, 7, 8), (1, 10, 10, 48), (2, 20, 20, 24), (1, 40, 40, 8), (2, 12, 20, 16), (1, 9, 40, 8),
-                                      (2, 8, 8, 64)])        # dv/nh = 8: the third stage of WRN-28-10 at 8 heads (attn_aug_conv.py:602)
+                                      (2, 8, 8, 64),         # dv/nh = 8: the third stage of WRN-28-10 at 8 heads (attn_aug_conv.py:602)
+                                      (2, 16, 16, 72), (2, 8, 8, 104)])     # dv/nh = 9 / 13: Densenet-BC transitions of the CIFAR harness at v = 0.7
 def test_attention_forward_backward(dev, B, H, W, dv):
     from chexpert_amd import ops
     from oracle import aaconv
@@ -254,3 +255,40 @@ def test_aadensenet121_reference_golden_train_step(dev):
     for k, r in rows:
         lim = 0.05 if k.startswith("classifier") or "norm5" in k else 0.15
         assert abs(r - 1) < lim, (k, r)
+
+
+@pytest.mark.parametrize("dv,det", [(8, True), (48, False), (64, True), (72, True), (104, True)])
+def test_out_projection_forward_backward(dev, dv, det):
+    """out_proj of AAConv2d (attn_aug_conv.py:92: a dv x dv 1x1 convolution on the attention output) and its backward against torch,
+    for the widths of chexpert.py's networks (<= 64) and of the CIFAR Densenet-BC at v = 0.7 (72 / 104: the weight-gradient sums of
+    the larger kernel live in registers); slice of a wider block buffer, deterministic statistic rows or atomics."""
+    from chexpert_amd import ops
+    B, H, W = 3, 6, 7
+    ops.set_det_wgrad(det)
+    o = synth.uniform(1, (B, H * W, dv), -1.0, 1.0)
+    w = synth.uniform(2, (dv, dv, 1, 1), -0.3, 0.3)
+    buf = torch.full((B, H, W, dv + 24), -3.0, dtype=torch.bfloat16, device=dev)
+    ys = buf[..., 16:16 + dv]
+    rows_cap = 64
+    S = torch.zeros(2, rows_cap, dv, device=dev)
+    rows = ops.aa_outproj_fwd(o.to(dev), w.to(dev), ys, S[0], S[1], stat_rows=rows_cap if det else 0, stat_rstride=dv)
+    want = torch.einsum("bpd,cd->bpc", o, w.view(dv, dv)).view(B, H, W, dv)
+    got = ys.float().cpu()
+    assert (got - want).abs().max().item() < 8e-3 * want.abs().max().item()
+    assert (buf[..., :16].float() == -3.0).all() and (buf[..., 16 + dv:].float() == -3.0).all()
+    ssum = S[0, :rows].sum(0).cpu() if det else S[0, 0].cpu()
+    assert (ssum - got.sum((0, 1, 2))).abs().max().item() < 1e-3 * got.abs().sum((0, 1, 2)).max().item()
+    # backward: dY = g*ga + gx*gb + gc; dO = dY W; dW += dY^T O
+    g = bf(synth.uniform(3, (B, H, W, dv), -1, 1))
+    gx = bf(synth.uniform(4, (B, H, W, dv), -1, 1))
+    ga, gb, gc = synth.uniform(5, (dv,), 0.5, 1.5), synth.uniform(6, (dv,), -0.5, 0.5), synth.uniform(7, (dv,), -0.2, 0.2)
+    dY = (g * ga + gx * gb + gc).view(B, H * W, dv)
+    dO_want = torch.einsum("bpc,cd->bpd", dY, w.view(dv, dv))
+    dW_want = torch.einsum("bpc,bpd->cd", dY, o)
+    dO = torch.zeros(B, H * W, dv, device=dev)
+    dw0 = synth.uniform(8, (dv, dv, 1, 1), -1, 1)
+    dW = dw0.clone().to(dev)
+    ops.aa_outproj_bwd(g.to(torch.bfloat16).to(dev), gx.to(torch.bfloat16).to(dev), ga.to(dev), gb.to(dev), gc.to(dev), o.to(dev), w.to(dev), dO, dW)
+    assert (dO.cpu() - dO_want).abs().max().item() < 1e-4 * dO_want.abs().max().item()
+    assert ((dW.cpu() - dw0).view(dv, dv) - dW_want).abs().max().item() < 1e-4 * dW_want.abs().max().item()
+    ops.set_det_wgrad(False)

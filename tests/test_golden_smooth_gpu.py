@@ -51,8 +51,10 @@ def _make(tag, n_cls):
         n = int(tag.split("_")[2][1:])
         n = (n - 4) // 6
         aa = tag.startswith("aa")                          # --attn with the harness defaults (k 0.2, v 0.1, 8 heads, 32x32 input)
-        spec = nets.densenet_spec(n_cls, growth=12, block_config=(n, n, n), init_features=24, attn=attn if aa else None, input_hw=(32, 32))
-        model = DenseNet(12, (n, n, n), 24, num_classes=n_cls, attn_params=dict(ATTN, input_dims=(32, 32)) if aa else None)
+        vv = 0.7 if "v07" in tag else 0.1                  # ... or the v = 0.7 of the reference's result rows (models/readme.md:34-38)
+        spec = nets.densenet_spec(n_cls, growth=12, block_config=(n, n, n), init_features=24, attn=dict(attn, v=vv) if aa else None,
+                                  input_hw=(32, 32))
+        model = DenseNet(12, (n, n, n), 24, num_classes=n_cls, attn_params=dict(ATTN, input_dims=(32, 32), v=vv) if aa else None)
         bias = 2.5
     elif tag.startswith("densenet121"):
         spec, model, bias = nets.densenet_spec(n_cls), DenseNet(32, (6, 12, 24, 16), 64, num_classes=n_cls), 2.5
@@ -125,6 +127,10 @@ CASES = {
     "densenetbc_k12_L40_32_b8": (1e-2, 1e-2, 0.05, 0.05),
     "densenetbc_k12_L100_32_b8": (1e-2, 1e-2, 0.05, 0.05),
     "aadensenetbc_k12_L100_32_b8": (1e-2, 1e-2, 0.05, 0.05),      # ... with attention-augmented transitions (--attn defaults)
+    # ... at v = 0.7 (heads of 9 / 13 value channels; 72 / 104 of the 108 / 150 transition channels are attention output): logits
+    # 3.4e-3 -- bf16 storage alone moves this fixture 3.9e-3 (`bf16_storage_logits_rel`, three times the v = 0.1 fixture) -- weight
+    # gradients 3.6 %, the BatchNorm gains of block 1's first layers 6.1 %
+    "aadensenetbcv07_k12_L100_32_b8": (1e-2, 1e-2, 0.06, 0.08),
     "efficientnet-b0_224_b8": (1e-2, 1e-2, 0.12, 0.06),
     "efficientnet-b4_380_b8": (1e-2, 1e-2, 0.12, 0.06),
 }
@@ -153,7 +159,8 @@ def test_baseline_batch_geometry_reproduces_the_fixture(dev, golden, tag, copies
     _check_step(tag, rec, model.to(dev), dev, copies, *CASES[tag])
 
 
-@pytest.mark.parametrize("tag", ["densenetbc_k12_L40_32_b8", "densenetbc_k12_L100_32_b8", "aadensenetbc_k12_L100_32_b8"])
+@pytest.mark.parametrize("tag", ["densenetbc_k12_L40_32_b8", "densenetbc_k12_L100_32_b8", "aadensenetbc_k12_L100_32_b8",
+                                 "aadensenetbcv07_k12_L100_32_b8"])
 def test_densenet_bc_eval_and_second_step(dev, golden, tag):
     """Channel-padded twin of the CIFAR Densenet-BC: eval-mode logits against the reference (running statistics mapped real ->
     padded), two training steps in a row give the same gradients (the twin's gradient buffer is rebuilt, the real one accumulates
@@ -186,7 +193,8 @@ def test_densenet_bc_eval_and_second_step(dev, golden, tag):
     w = twin.features.denseblock1.denselayer2.conv2.weight       # rows k..kp of a padded 3x3 convolution: never written
     assert (w[k:] == 0).all() and (w[:k] != 0).any()
     assert (eng.inner.flat_grad[eng.inner.off_of[id(w)]:][:w.numel()].view(w.shape)[k:] == 0).all()
-    m2 = DenseNet(k, model.block_config, 2 * k, num_classes=n_cls, attn_params=dict(ATTN, input_dims=(32, 32)) if tag.startswith("aa") else None).to(dev)
+    m2 = DenseNet(k, model.block_config, 2 * k, num_classes=n_cls,
+                  attn_params=dict(ATTN, input_dims=(32, 32), v=0.7 if "v07" in tag else 0.1) if tag.startswith("aa") else None).to(dev)
     m2.load_state_dict(model.state_dict(), strict=True)
     if tag.startswith("aa"):                                   # AAConv2d.weights of the REAL modules (attn_aug_conv.py:87; --vis_attn)
         w = model.features.transition1.conv.weights

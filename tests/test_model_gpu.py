@@ -456,8 +456,13 @@ def test_cifar_harness_trains_evaluates_and_restores(dev, tmp_path):
                        "--output_dir", oa, "densenet", "12", "100"]) == 0
     assert np.isfinite(js.loads(open(os.path.join(oa, "log.jsonl")).readline())["train_loss"])
     assert len([f for f in os.listdir(oa) if f.startswith("vis_attn_image_")]) == 8 * 2
-    with pytest.raises(NotImplementedError):          # v = 0.7 of the reference's result rows: heads of 9 / 13 value channels
-        cifar.main(["--train", "--attn", "--attn_v", "0.7", "--synthetic", "16", "--output_dir", str(tmp_path / "db"), "densenet", "12", "100"])
+    # ... and at the value-channel ratio of the reference's result rows (models/readme.md:34-38: v 0.7 -> heads of 9 / 13 channels)
+    ob = str(tmp_path / "db")
+    assert cifar.main(["--train", "--attn", "--attn_v", "0.7", "--dataset", "cifar10", "--synthetic", "16", "--mini_data", "--batch_size", "16",
+                       "--output_dir", ob, "densenet", "12", "100"]) == 0
+    assert np.isfinite(js.loads(open(os.path.join(ob, "log.jsonl")).readline())["train_loss"])
+    with pytest.raises(NotImplementedError):          # a value ratio whose heads the attention kernels do not cover (v 0.4: 5 / 7 channels)
+        cifar.main(["--train", "--attn", "--attn_v", "0.4", "--synthetic", "16", "--output_dir", str(tmp_path / "dc"), "densenet", "12", "100"])
     # the harness's attention-augmented WideResNet: one step, then the attention maps of its four AAConv2d layers (--vis_attn)
     o3 = str(tmp_path / "aawrn")
     assert cifar.main(["--train", "--vis_attn", "--attn", "--dataset", "cifar10", "--synthetic", "16", "--mini_data", "--batch_size", "16",

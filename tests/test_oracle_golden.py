@@ -82,14 +82,15 @@ def test_network_against_reference_fixture(tag, nets_golden):
         _summary_close(sd[k], r, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("tag,n", [("densenetbc_k12_L40_32_b8", 6), ("densenetbc_k12_L100_32_b8", 16), ("aadensenetbc_k12_L100_32_b8", 16)])
+@pytest.mark.parametrize("tag,n", [("densenetbc_k12_L40_32_b8", 6), ("densenetbc_k12_L100_32_b8", 16), ("aadensenetbc_k12_L100_32_b8", 16),
+                                   ("aadensenetbcv07_k12_L100_32_b8", 16)])
 def test_densenet_bc_against_reference_fixture(tag, n):
     """The CIFAR harness's Densenet-BC (models/test_model.py:304-306; 5x5 stride-1 stem, three blocks, growth 12) against the
     fixture recorded from the real reference in the well-conditioned state (tests/golden/nets_smooth.json)."""
     rec = json.load(open(os.path.join(G, "nets_smooth.json")))[tag]
     aa = tag.startswith("aa")
     spec = nets.densenet_spec(rec["n_classes"], growth=12, block_config=(n, n, n), init_features=24,
-                              attn=dict(k=.2, v=.1, nh=8) if aa else None, input_hw=(32, 32))
+                              attn=dict(k=.2, v=.7 if "v07" in tag else .1, nh=8) if aa else None, input_hw=(32, 32))
     assert nets.param_count(spec) == rec["n_params"] and len(spec) == rec["keys"]
     sd = synth.smooth_state_dict_(synth.fill_state_dict_(nets.zeros_state_dict(spec), rec["sd_seed"]), rec["smooth_bias"])
     x = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"])
