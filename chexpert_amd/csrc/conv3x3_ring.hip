@@ -113,10 +113,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
       if (crow[i] < n) {
         int slot = slot_y0 + crow[i];                   // crow <= R: one conditional subtract wraps it
         if (slot >= R + 2) slot -= R + 2;
-        U128 o, v;
-        v.u = pre[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), csc[j], csh[j]), 0.f));
+        U128 o;
+        o.u = cx_affine_relu8(pre[i], csc, csh);
         { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i];
         *reinterpret_cast<uint4*>(ring + (size_t)pos * XP + cc8 * 16) = o.u;
@@ -366,12 +364,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
       if (crow[i] < n) {
         int slot = slot_y0 + crow[i];
         if (slot >= R + 2) slot -= R + 2;
-        U128 o, u, v;
-        u.u = pg[i];
-        v.u = pg2[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          o.e[j] = f2bf(fmaf(bf2f(u.e[j]), kco[j], fmaf(bf2f(v.e[j]), kco[32 + j], kco[64 + j])));
+        U128 o;
+        o.u = cx_affine2_8(pg[i], pg2[i], kco, kco + 32, kco + 64);
         // side output (CxConv.pro_out): the corrected gradient slice as a dense tensor for the weight-gradient kernel.  Halo rows
         // are staged -- and stored -- by two workgroups: the same bits twice.
         if (po && gv[i]) *reinterpret_cast<uint4*>(po + ((size_t)(b * H + y0 + crow[i]) * W + cpx[i]) * ldpo + cc4 * 8) = o.u;
@@ -647,10 +641,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
       if (xrow[i] < n) {
         int slot = slot_y0 + xrow[i];
         if (slot >= R + 2) slot -= R + 2;
-        U128 o, v;
-        v.u = pre[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), xco[j], xco[128 + j]), 0.f));
+        U128 o;
+        o.u = cx_affine_relu8(pre[i], xco, xco + 128);
         { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + xpx[i] + 1;
         *reinterpret_cast<uint4*>(ring + (size_t)pos * WXP + cx8 * 16) = o.u;
@@ -673,12 +665,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
       if (grow[i] < R) {
-        U128 o, u, v;
-        u.u = pg[i];
-        v.u = pg2[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          o.e[j] = f2bf(fmaf(bf2f(u.e[j]), gco[j], fmaf(bf2f(v.e[j]), gco[32 + j], gco[64 + j])));
+        U128 o;
+        o.u = cx_affine2_8(pg[i], pg2[i], gco, gco + 32, gco + 64);
         { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         *reinterpret_cast<uint4*>(gst + (size_t)(grow[i] * P + gpx[i]) * WGP + cg4 * 16) = o.u;     // pad columns / tail stay zero
       }
