@@ -71,6 +71,49 @@ __device__ __forceinline__ uint4 cx_affine2_8(const uint4 u, const uint4 v, cons
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// Store epilogue on 8 channels: t -> bf16 (one conversion per dword) and, where `stats`, the channel sums of the values AS STORED
+// (masked by `valid`: a row past the end of the tensor contributes nothing).
+__device__ __forceinline__ uint4 cx_pack8_stats(const float (&t)[8], const bool valid, const bool stats, float (&s1)[8], float (&s2)[8]) {
+  uint32_t w[4];
+  const uint32_t keep = valid ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    w[j] = cx_packbf(t[2 * j], t[2 * j + 1]);
+    if (stats) {
+      const uint32_t m = w[j] & keep;
+      const float rl = cx_bf_lo(m), rh = cx_bf_hi(m);
+      s1[2 * j] += rl;
+      s1[2 * j + 1] += rh;
+      s2[2 * j] += rl * rl;
+      s2[2 * j + 1] += rh * rh;
+    }
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Mask epilogue of the fused 1x1 backward on 8 channels, dword pairs: pre = x*esc + esh (the forward's BN), dz = [pre > 0] * v,
+// S1 += dz, S2 += dz * x, o = bf16(esl * dz + old), xh = bf16(relu(pre)) (the weight-gradient operand); `pok` = the pixel exists.
+__device__ __forceinline__ void cx_mask_epi8(const float (&v)[8], const uint4 xv, const uint4 old, const float (&esc)[8], const float (&esh)[8],
+                                             const float (&esl)[8], const bool pok, float (&s1)[8], float (&s2)[8], uint4& o, uint4& xh) {
+  const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, ow[4] = {old.x, old.y, old.z, old.w};
+  const uint32_t keep = pok ? 0xffffffffu : 0u;
+  uint32_t oo[4], hh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xl = cx_bf_lo(xw[j]), xu = cx_bf_hi(xw[j]);
+    const float pl = fmaf(xl, esc[2 * j], esh[2 * j]), pu = fmaf(xu, esc[2 * j + 1], esh[2 * j + 1]);
+    const float dl = (pok && pl > 0.f) ? v[2 * j] : 0.f, du = (pok && pu > 0.f) ? v[2 * j + 1] : 0.f;
+    s1[2 * j] += dl;
+    s1[2 * j + 1] += du;
+    s2[2 * j] = fmaf(dl, xl, s2[2 * j]);
+    s2[2 * j + 1] = fmaf(du, xu, s2[2 * j + 1]);
+    oo[j] = cx_packbf(fmaf(esl[2 * j], dl, cx_bf_lo(ow[j])), fmaf(esl[2 * j + 1], du, cx_bf_hi(ow[j])));
+    hh[j] = cx_relu_pk(cx_packbf(pl, pu)) & keep;
+  }
+  o = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+  xh = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+}
+
 // eight consecutive channels of one pixel in the storage type T (bf16: one 16-B access; fp32 parity mode: two)
 template <typename T> struct V8;
 template <> struct V8<bf16> {

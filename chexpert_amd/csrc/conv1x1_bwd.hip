@@ -161,11 +161,7 @@ __global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const 
         if (PRO == CX_PRO_NONE) {
           o.u = ru[i];
         } else {
-          U128 u, v;
-          u.u = ru[i];
-          v.u = rv[i];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
+          o.u = cx_affine2_8(ru[i], rv[i], aco, aco + KD, aco + 2 * KD);
         }
         const unsigned keep = m0 + row < M ? 0xffffffffu : 0u;
         o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
@@ -216,17 +212,7 @@ __global__ __launch_bounds__(BC * 4, BC == 64 ? 2 : 1) void pw_bwd_kernel(const 
         const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
         U128 o, xh;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xf = bf2f(xv[j][cc].e[e]);
-          const float pre = fmaf(xf, esc[e], esh[e]);
-          const bool on = pok && pre > 0.f;
-          const float dz = on ? v[e] : 0.f;
-          s1[j][cc][e] += dz;
-          s2[j][cc][e] = fmaf(dz, xf, s2[j][cc][e]);      // S2 = r * (sum dz*x - mu * S1), affine part at the end
-          o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[j][cc].e[e])));
-          xh.e[e] = f2bf(on ? pre : 0.f);
-        }
+        cx_mask_epi8(v, xv[j][cc].u, old[j][cc].u, esc, esh, esl, pok, s1[j][cc], s2[j][cc], o.u, xh.u);      // S2 = r * (sum dz*x - mu * S1), affine part at the end
         if (pok && n < p.N) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + n) = o.u;
         *reinterpret_cast<uint4*>(Xh + (ch * 2 + j) * XH_BYTES + (pw * 32 + lrow) * XH_PITCH + (2 * cc + lh) * 16) = xh.u;
       }
@@ -441,11 +427,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
           o.u = ru[i];
           if (DBG & 64) { o.u.x ^= rv[i].x; o.u.y ^= rv[i].y; o.u.z ^= rv[i].z; o.u.w ^= rv[i].w; }
         } else {
-          U128 u, v;
-          u.u = ru[i];
-          v.u = rv[i];
-  #pragma unroll
-          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
+          o.u = cx_affine2_8(ru[i], rv[i], aco, aco + KD, aco + 2 * KD);
         }
         const unsigned keep = (tvalid && m0 + row < M) ? 0xffffffffu : 0u;
         o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
@@ -506,17 +488,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
         const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
         U128 o, xh;
-  #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xf = bf2f(xv[cc].e[e]);
-          const float pre = fmaf(xf, esc[e], esh[e]);
-          const bool on = pok && pre > 0.f;
-          const float dz = on ? v[e] : 0.f;
-          s1[cc][e] += dz;
-          s2[cc][e] = fmaf(dz, xf, s2[cc][e]);
-          o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[cc].e[e])));
-          xh.e[e] = f2bf(on ? pre : 0.f);
-        }
+        cx_mask_epi8(v, xv[cc].u, old[cc].u, esc, esh, esl, pok, s1[cc], s2[cc], o.u, xh.u);
         if constexpr (!(DBG & 1)) {
           if (pok && nok[cc]) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + ncl[cc]) = o.u;
         } else {
@@ -578,11 +550,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
           o.u = ru[i];
           if (DBG & 64) { o.u.x ^= rv[i].x; o.u.y ^= rv[i].y; o.u.z ^= rv[i].z; o.u.w ^= rv[i].w; }
         } else {
-          U128 u, v;
-          u.u = ru[i];
-          v.u = rv[i];
-  #pragma unroll
-          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), aco[j], fmaf(bf2f(v.e[j]), aco[KD + j], aco[2 * KD + j])));
+          o.u = cx_affine2_8(ru[i], rv[i], aco, aco + KD, aco + 2 * KD);
         }
         const unsigned keep = (tvalid && m0 + row < M) ? 0xffffffffu : 0u;
         o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
@@ -643,17 +611,7 @@ __global__ __launch_bounds__(512, 1) void pw_bwd2_kernel(const CxConv p, float* 
         const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
         U128 o, xh;
-  #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xf = bf2f(xv[cc].e[e]);
-          const float pre = fmaf(xf, esc[e], esh[e]);
-          const bool on = pok && pre > 0.f;
-          const float dz = on ? v[e] : 0.f;
-          s1[cc][e] += dz;
-          s2[cc][e] = fmaf(dz, xf, s2[cc][e]);
-          o.e[e] = f2bf(fmaf(esl[e], dz, bf2f(old[cc].e[e])));
-          xh.e[e] = f2bf(on ? pre : 0.f);
-        }
+        cx_mask_epi8(v, xv[cc].u, old[cc].u, esc, esh, esl, pok, s1[cc], s2[cc], o.u, xh.u);
         if constexpr (!(DBG & 1)) {
           if (pok && nok[cc]) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + ncl[cc]) = o.u;
         } else {

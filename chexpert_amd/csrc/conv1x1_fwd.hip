@@ -141,10 +141,8 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(const CxConv p, const in
         const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          U128 v, o;
-          v.u = xr[i][u];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o.e[e] = f2bf(fmaxf(fmaf(bf2f(v.e[e]), sc[e], sh[e]), 0.f));
+          U128 o;
+          o.u = cx_affine_relu8(xr[i][u], sc, sh);
           xf[i] = o.h;
         }
       } else {
@@ -175,21 +173,15 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(const CxConv p, const in
             // registers 8cc..8cc+3 / 8cc+4..8cc+7 of this lane: channels 16cc + 4*lh + e / 16cc + 8 + 4*lh + e; after the
             // swap of the upper half of the first group with the lower half of the second: channels 8*(2cc+lh) .. +7
             U128 o;
+            float t[8];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
               const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * cc + r4]),
                                                                __float_as_uint(acc[i][j][8 * cc + 4 + r4]), false, false);
-              o.e[r4] = f2bf(__uint_as_float(sw[0]));
-              o.e[4 + r4] = f2bf(__uint_as_float(sw[1]));
+              t[r4] = __uint_as_float(sw[0]);
+              t[4 + r4] = __uint_as_float(sw[1]);
             }
-            if (want_stats) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float rv = mv ? bf2f(o.e[e]) : 0.f;
-                s1[j][cc][e] += rv;
-                s2[j][cc][e] += rv * rv;
-              }
-            }
+            o.u = cx_pack8_stats(t, mv, want_stats, s1[j][cc], s2[j][cc]);
             if (mv) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + (wn * 2 + j) * 32 + 8 * (2 * cc + lh)) = o.u;
           }
       }

@@ -63,10 +63,7 @@ __global__ __launch_bounds__(256, 2) void pw_fwdk_kernel(const CxConv p, const i
       } else if (PRO == CX_PRO_NONE) {
         o.u = ra[i];
       } else {
-        U128 v;
-        v.u = ra[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[c0 + j], coef[p.K + c0 + j]), 0.f));
+        o.u = cx_affine_relu8(ra[i], coef + c0, coef + p.K + c0);
       }
       *reinterpret_cast<uint4*>(At + row * PITCH + q * 16) = o.u;
       *reinterpret_cast<uint4*>(Bt + row * PITCH + q * 16) = kok ? rw[i] : make_uint4(0, 0, 0, 0);
@@ -135,12 +132,18 @@ __global__ __launch_bounds__(256, 2) void pw_fwdk_kernel(const CxConv p, const i
         const float4 v1 = *reinterpret_cast<const float4*>(etile + row * EPITCH + cq * 8 + 4);
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         U128 o;
+        {
+          uint32_t w4[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          o.e[j] = f2bf(v[j]);
-          const float rv = bf2f(o.e[j]);
-          s1[j] += rv;
-          s2[j] += rv * rv;
+          for (int j = 0; j < 4; ++j) {
+            w4[j] = cx_packbf(v[2 * j], v[2 * j + 1]);
+            const float rl = cx_bf_lo(w4[j]), rh = cx_bf_hi(w4[j]);      // the values as stored
+            s1[2 * j] += rl;
+            s1[2 * j + 1] += rh;
+            s2[2 * j] += rl * rl;
+            s2[2 * j + 1] += rh * rh;
+          }
+          o.u = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
         *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + cq * 8) = o.u;
       }
@@ -226,10 +229,7 @@ __global__ __launch_bounds__(256, 2) void pw_fwdp_kernel(const CxConv p, const i
       } else if (PRO == CX_PRO_NONE) {
         o.u = a[i];
       } else {
-        U128 v;
-        v.u = a[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[c0 + j], coef[p.K + c0 + j]), 0.f));
+        o.u = cx_affine_relu8(a[i], coef + c0, coef + p.K + c0);
       }
       *reinterpret_cast<uint4*>(At + row * PITCH + q * 16) = o.u;
       *reinterpret_cast<uint4*>(Bt + row * PITCH + q * 16) = kok ? w[i] : make_uint4(0, 0, 0, 0);
@@ -302,12 +302,18 @@ __global__ __launch_bounds__(256, 2) void pw_fwdp_kernel(const CxConv p, const i
         const float4 v1 = *reinterpret_cast<const float4*>(etile + row * EPITCH + cq * 8 + 4);
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         U128 o;
+        {
+          uint32_t w4[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          o.e[j] = f2bf(v[j]);
-          const float rv = bf2f(o.e[j]);
-          s1[j] += rv;
-          s2[j] += rv * rv;
+          for (int j = 0; j < 4; ++j) {
+            w4[j] = cx_packbf(v[2 * j], v[2 * j + 1]);
+            const float rl = cx_bf_lo(w4[j]), rh = cx_bf_hi(w4[j]);      // the values as stored
+            s1[2 * j] += rl;
+            s1[2 * j + 1] += rh;
+            s2[2 * j] += rl * rl;
+            s2[2 * j + 1] += rh * rh;
+          }
+          o.u = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
         *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + cq * 8) = o.u;
       }

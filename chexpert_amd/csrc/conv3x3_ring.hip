@@ -197,19 +197,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
         // registers 8cc..8cc+3 / 8cc+4..8cc+7: channels 16cc + 4*lh + e / 16cc + 8 + 4*lh + e; the swap of the upper half of
         // the first group with the lower half of the second leaves channels 8*(2cc+lh) .. +7 of this lane's pixel
         U128 o;
+        float t[8];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * cc + r4]), __float_as_uint(acc[8 * cc + 4 + r4]),
                                                            false, false);
-          o.e[r4] = f2bf(__uint_as_float(sw[0]));
-          o.e[4 + r4] = f2bf(__uint_as_float(sw[1]));
+          t[r4] = __uint_as_float(sw[0]);
+          t[4 + r4] = __uint_as_float(sw[1]);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float rv = valid ? bf2f(o.e[j]) : 0.f;
-          s1[cc][j] += rv;
-          s2[cc][j] += rv * rv;
-        }
+        o.u = cx_pack8_stats(t, valid, true, s1[cc], s2[cc]);
         if (valid) *reinterpret_cast<uint4*>(yrow + 8 * (2 * cc + lh)) = o.u;
       }
     }
@@ -479,9 +475,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
               const float4 b0 = *reinterpret_cast<const float4*>(ecoef + 128 + n), b1 = *reinterpret_cast<const float4*>(ecoef + 128 + n + 4);
               const float esc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
               const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+              const uint32_t xw[4] = {xv[j][cc].u.x, xv[j][cc].u.y, xv[j][cc].u.z, xv[j][cc].u.w};
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
-                xf[e] = bf2f(xv[j][cc].e[e]);
+                xf[e] = (e & 1) ? cx_bf_hi(xw[e >> 1]) : cx_bf_lo(xw[e >> 1]);
                 dz[e] = (pok && fmaf(xf[e], esc[e], esh[e]) > 0.f) ? v[e] : 0.f;
                 s1[j][cc][e] += dz[e];
               }
@@ -495,8 +492,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
               asm volatile("" ::: "memory");
               const float4 e0 = *reinterpret_cast<const float4*>(ecoef + 512 + n), e1 = *reinterpret_cast<const float4*>(ecoef + 512 + n + 4);
               const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o.e[e] = f2bf(esl[e] * dz[e]);
+              o.u = make_uint4(cx_packbf(esl[0] * dz[0], esl[1] * dz[1]), cx_packbf(esl[2] * dz[2], esl[3] * dz[3]),
+                               cx_packbf(esl[4] * dz[4], esl[5] * dz[5]), cx_packbf(esl[6] * dz[6], esl[7] * dz[7]));
             }
             if (pok) *reinterpret_cast<uint4*>(yrow + n) = o.u;
           }

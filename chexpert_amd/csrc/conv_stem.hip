@@ -105,21 +105,15 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const CxConv p, const 
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         U128 o;
+        float t[8];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][8 * cc + r4]), __float_as_uint(acc[j][8 * cc + 4 + r4]),
                                                            false, false);
-          o.e[r4] = f2bf(__uint_as_float(sw[0]));
-          o.e[4 + r4] = f2bf(__uint_as_float(sw[1]));
+          t[r4] = __uint_as_float(sw[0]);
+          t[4 + r4] = __uint_as_float(sw[1]);
         }
-        if (want_stats) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float rv = mv ? bf2f(o.e[e]) : 0.f;
-            s1[j][cc][e] += rv;
-            s2[j][cc][e] += rv * rv;
-          }
-        }
+        o.u = cx_pack8_stats(t, mv, want_stats, s1[j][cc], s2[j][cc]);
         if (mv) *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + j * 32 + 8 * (2 * cc + lh)) = o.u;
       }
   };
