@@ -119,12 +119,12 @@ template <typename T> struct V8;
 template <> struct V8<bf16> {
   typedef uint4 raw;
   static __device__ __forceinline__ raw ld(const bf16* p) { return *reinterpret_cast<const uint4*>(p); }
-  static __device__ __forceinline__ float get(const raw& r, int j) { U128 u; u.u = r; return bf2f(u.e[j]); }
+  static __device__ __forceinline__ float get(const raw& r, int j) {
+    const uint32_t w = j < 2 ? r.x : j < 4 ? r.y : j < 6 ? r.z : r.w;
+    return (j & 1) ? cx_bf_hi(w) : cx_bf_lo(w);
+  }
   static __device__ __forceinline__ void st(bf16* p, const float (&v)[8]) {
-    U128 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o.e[j] = f2bf(v[j]);
-    *reinterpret_cast<uint4*>(p) = o.u;
+    *reinterpret_cast<uint4*>(p) = make_uint4(cx_packbf(v[0], v[1]), cx_packbf(v[2], v[3]), cx_packbf(v[4], v[5]), cx_packbf(v[6], v[7]));
   }
   static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }      // the value as stored
 };

@@ -179,21 +179,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
         for (int a = 0; a < NSRC; ++a) {
-          U128 v;
-          v.u = ra[i][a];
+          const uint32_t w4[4] = {ra[i][a].x, ra[i][a].y, ra[i][a].z, ra[i][a].w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            acc[j] += fmaxf(fmaf(bf2f(v.e[j]), coef[c0 + j], coef[p.K + c0 + j]), 0.f);
+          for (int j = 0; j < 4; ++j) {
+            acc[2 * j] += fmaxf(fmaf(cx_bf_lo(w4[j]), coef[c0 + 2 * j], coef[p.K + c0 + 2 * j]), 0.f);
+            acc[2 * j + 1] += fmaxf(fmaf(cx_bf_hi(w4[j]), coef[c0 + 2 * j + 1], coef[p.K + c0 + 2 * j + 1]), 0.f);
+          }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(NSRC == 4 ? acc[j] * 0.25f : acc[j]);
+        {
+          const float sc_ = NSRC == 4 ? 0.25f : 1.f;
+          o.u = make_uint4(cx_packbf(acc[0] * sc_, acc[1] * sc_), cx_packbf(acc[2] * sc_, acc[3] * sc_), cx_packbf(acc[4] * sc_, acc[5] * sc_),
+                           cx_packbf(acc[6] * sc_, acc[7] * sc_));
+        }
       } else {
-        U128 u, v;
-        u.u = ra[i][0];
-        v.u = ra2[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          o.e[j] = f2bf(fmaf(bf2f(u.e[j]), coef[c0 + j], fmaf(bf2f(v.e[j]), coef[p.K + c0 + j], coef[2 * p.K + c0 + j])));
+        o.u = cx_affine2_8(ra[i][0], ra2[i], coef + c0, coef + p.K + c0, coef + 2 * p.K + c0);
       }
       *reinterpret_cast<uint4*>(A + ((tid >> 2) + 64 * i) * PITCH + qa * 16) = o.u;
     }
@@ -327,23 +326,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CxConv p, const in
         const float4 v1 = *reinterpret_cast<const float4*>(etile + row * G::EPITCH + cq * 8 + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         U128 o;
+        const uint32_t ow[4] = {old[half][pass].u.x, old[half][pass].u.y, old[half][pass].u.z, old[half][pass].u.w};
         if (EPI == CX_EPI_STORE) {
+          float t[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            o.e[j] = f2bf(v[j] + bf2f(old[half][pass].e[j]));
-            const float rv = bf2f(o.e[j]);
-            s1[j] += rv;
-            s2[j] += rv * rv;
-          }
+          for (int j = 0; j < 4; ++j) { t[2 * j] = v[2 * j] + cx_bf_lo(ow[j]); t[2 * j + 1] = v[2 * j + 1] + cx_bf_hi(ow[j]); }
+          o.u = cx_pack8_stats(t, true, true, s1, s2);
         } else {
+          const uint32_t xw[4] = {xv[half][pass].u.x, xv[half][pass].u.y, xv[half][pass].u.z, xv[half][pass].u.w};
+          uint32_t w4[4];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float xf = bf2f(xv[half][pass].e[j]);
-            const float dz = (fmaf(xf, esc[j], esh[j]) > 0.f) ? v[j] : 0.f;
-            s1[j] += dz;
-            s2[j] += dz * (xf - emu[j]) * er[j];
-            o.e[j] = f2bf(fmaf(escale[j], dz, bf2f(old[half][pass].e[j])));
+          for (int j = 0; j < 4; ++j) {
+            const float xl = cx_bf_lo(xw[j]), xu = cx_bf_hi(xw[j]);
+            const float dl = (fmaf(xl, esc[2 * j], esh[2 * j]) > 0.f) ? v[2 * j] : 0.f;
+            const float du = (fmaf(xu, esc[2 * j + 1], esh[2 * j + 1]) > 0.f) ? v[2 * j + 1] : 0.f;
+            s1[2 * j] += dl;
+            s1[2 * j + 1] += du;
+            s2[2 * j] += dl * (xl - emu[2 * j]) * er[2 * j];
+            s2[2 * j + 1] += du * (xu - emu[2 * j + 1]) * er[2 * j + 1];
+            w4[j] = cx_packbf(fmaf(escale[2 * j], dl, cx_bf_lo(ow[j])), fmaf(escale[2 * j + 1], du, cx_bf_hi(ow[j])));
           }
+          o.u = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
         *reinterpret_cast<uint4*>(Y + (size_t)m * p.ldy + nch) = o.u;
       }

@@ -467,34 +467,45 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         U128 o;
         if (EPI == CX_EPI_STORE) {
+          const uint32_t ow[4] = {old[g][pass].u.x, old[g][pass].u.y, old[g][pass].u.z, old[g][pass].u.w};
+          float t[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            o.e[j] = f2bf(v[j] + bf2f(old[g][pass].e[j]));
-            const float rv = bf2f(o.e[j]);
-            s1[j] += rv;
-            s2[j] += rv * rv;
-          }
+          for (int j = 0; j < 4; ++j) { t[2 * j] = v[2 * j] + cx_bf_lo(ow[j]); t[2 * j + 1] = v[2 * j + 1] + cx_bf_hi(ow[j]); }
+          o.u = cx_pack8_stats(t, true, true, s1, s2);
         } else if (EPI == CX_EPI_JOIN) {
           // the gradient of the join's output, rounded as CX_EPI_STORE would have stored it, then the join's ReLU mask and
           // the sums of its BatchNorm's backward
+          const uint32_t ow[4] = {old[g][pass].u.x, old[g][pass].u.y, old[g][pass].u.z, old[g][pass].u.w};
+          const uint32_t xw[4] = {xv[g][pass].u.x, xv[g][pass].u.y, xv[g][pass].u.z, xv[g][pass].u.w};
+          uint32_t w4[4];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const bf16 t = f2bf(v[j] + bf2f(old[g][pass].e[j]));
-            const bool on = ((mkb[g][pass] >> j) & 1u) != 0;
-            o.e[j] = on ? t : f2bf(0.f);
-            const float dz = on ? bf2f(t) : 0.f;
-            s1[j] += dz;
-            s2[j] += dz * (bf2f(xv[g][pass].e[j]) - emu[j]) * er[j];
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t bits = mkb[g][pass] >> (2 * j);
+            const uint32_t keep = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+            w4[j] = cx_packbf(v[2 * j] + cx_bf_lo(ow[j]), v[2 * j + 1] + cx_bf_hi(ow[j])) & keep;
+            const float dl = cx_bf_lo(w4[j]), du = cx_bf_hi(w4[j]);
+            s1[2 * j] += dl;
+            s1[2 * j + 1] += du;
+            s2[2 * j] += dl * (cx_bf_lo(xw[j]) - emu[2 * j]) * er[2 * j];
+            s2[2 * j + 1] += du * (cx_bf_hi(xw[j]) - emu[2 * j + 1]) * er[2 * j + 1];
           }
+          o.u = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         } else {
+          const uint32_t ow[4] = {old[g][pass].u.x, old[g][pass].u.y, old[g][pass].u.z, old[g][pass].u.w};
+          const uint32_t xw[4] = {xv[g][pass].u.x, xv[g][pass].u.y, xv[g][pass].u.z, xv[g][pass].u.w};
+          uint32_t w4[4];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float xf = bf2f(xv[g][pass].e[j]);
-            const float dz = (fmaf(xf, esc[j], esh[j]) > 0.f) ? v[j] : 0.f;
-            s1[j] += dz;
-            s2[j] += dz * (xf - emu[j]) * er[j];
-            o.e[j] = f2bf(fmaf(escale[j], dz, bf2f(old[g][pass].e[j])));
+          for (int j = 0; j < 4; ++j) {
+            const float xl = cx_bf_lo(xw[j]), xu = cx_bf_hi(xw[j]);
+            const float dl = (fmaf(xl, esc[2 * j], esh[2 * j]) > 0.f) ? v[2 * j] : 0.f;
+            const float du = (fmaf(xu, esc[2 * j + 1], esh[2 * j + 1]) > 0.f) ? v[2 * j + 1] : 0.f;
+            s1[2 * j] += dl;
+            s1[2 * j + 1] += du;
+            s2[2 * j] += dl * (xl - emu[2 * j]) * er[2 * j];
+            s2[2 * j + 1] += du * (xu - emu[2 * j + 1]) * er[2 * j + 1];
+            w4[j] = cx_packbf(fmaf(escale[2 * j], dl, cx_bf_lo(ow[j])), fmaf(escale[2 * j + 1], du, cx_bf_hi(ow[j])));
           }
+          o.u = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
         *reinterpret_cast<uint4*>(Y + (size_t)mo[g][pass] * p.ldy + nch) = o.u;
       }

@@ -166,11 +166,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const CxWgrad p, const int M
         } else if (GPRO == CX_PRO_NONE) {
           o.u = rg[i];
         } else {
-          U128 u, v;
-          u.u = rg[i];
-          v.u = rg2[i];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), ga[i][j], fmaf(bf2f(v.e[j]), gb[i][j], gc[i][j])));
+          o.u = cx_affine2_8(rg[i], rg2[i], ga[i], gb[i], gc[i]);
         }
         *reinterpret_cast<uint4*>(Gt + grow[i] * G::GP + gcq[i] * 16) = o.u;
       }
@@ -189,13 +185,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const CxWgrad p, const int M
           for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
           for (int a = 0; a < NSRC; ++a) {
-            U128 v;
-            v.u = rx[i][a];
+            const uint32_t w4[4] = {rx[i][a].x, rx[i][a].y, rx[i][a].z, rx[i][a].w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf(bf2f(v.e[j]), xa[i][j], xb[i][j]), 0.f);
+            for (int j = 0; j < 4; ++j) {
+              acc[2 * j] += fmaxf(fmaf(cx_bf_lo(w4[j]), xa[i][2 * j], xb[i][2 * j]), 0.f);
+              acc[2 * j + 1] += fmaxf(fmaf(cx_bf_hi(w4[j]), xa[i][2 * j + 1], xb[i][2 * j + 1]), 0.f);
+            }
           }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o.e[j] = f2bf(NSRC == 4 ? acc[j] * 0.25f : acc[j]);
+          {
+            const float sc_ = NSRC == 4 ? 0.25f : 1.f;
+            o.u = make_uint4(cx_packbf(acc[0] * sc_, acc[1] * sc_), cx_packbf(acc[2] * sc_, acc[3] * sc_), cx_packbf(acc[4] * sc_, acc[5] * sc_),
+                             cx_packbf(acc[6] * sc_, acc[7] * sc_));
+          }
         }
         *reinterpret_cast<uint4*>(Xt + xrow[i] * G::XP + xcq[i] * 16) = o.u;
       }
@@ -372,11 +373,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const CxWgrad p, const 
     } else if (GPRO == CX_PRO_NONE) {
       o.u = rg;
     } else {
-      U128 u, v;
-      u.u = rg;
-      v.u = rg2;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u.e[j]), ga[j], fmaf(bf2f(v.e[j]), gb[j], gc[j])));
+      o.u = cx_affine2_8(rg, rg2, ga, gb, gc);
     }
     *reinterpret_cast<uint4*>(Gt + grow * ST_GP + gcq * 16) = o.u;
     if (STRIP) {
