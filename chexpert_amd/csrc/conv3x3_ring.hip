@@ -95,14 +95,23 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(csc[j]), "v"(csh[j]));
   // rows [y0, y0+n) of column tile bv = image * ntx + tile -> registers (ring position p of a row is image column x0 - 1 + p);
   // unconditional loads on clamped addresses, validity applied when staged
+  // A chunk's byte offset inside the row group is a constant of the thread (voff); the group's own offset is wave-uniform.  Chunks
+  // outside the image (or past the n rows asked for) read offset 0 and are zeroed when staged.  (Per chunk: one add, two range tests
+  // and a select -- clamping row and column and rebuilding the 64-bit address was ~22 vector instructions per chunk, 7 chunks per
+  // step, in a kernel that is bound by vector-instruction issue.)  32-bit offsets: the launcher checks the tensor is < 4 GB.
+  uint32_t voff[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) voff[i] = ((uint32_t)(crow[i] * W + cpx[i]) * (uint32_t)ldx + (uint32_t)cc8 * 8u) * 2u;
+  const char* __restrict__ xb = reinterpret_cast<const char*>(x);
   auto issue_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int bv, int y0, int n) __attribute__((always_inline)) {
     const int b = bv / ntx, x0 = (bv - b * ntx) * Wt - 1;
+    const uint32_t sbase = (uint32_t)((b * H + y0) * W + x0) * (uint32_t)ldx * 2u;      // (wraps for y0 = -1 / x0 = -1: only valid chunks use it)
+    const uint32_t r_lo = (uint32_t)max(-y0, 0), r_n = (uint32_t)max(min(n, H - y0), 0) - r_lo;      // rows  [r_lo, r_lo + r_n)
+    const uint32_t c_lo = (uint32_t)max(-x0, 0), c_n = (uint32_t)max(W - x0, 0) - c_lo;              // pixels [c_lo, c_lo + c_n)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int yy = y0 + crow[i], xx = x0 + cpx[i];
-      pv[i] = crow[i] < n && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const int yc_ = min(max(yy, 0), H - 1), xc_ = min(max(xx, 0), W - 1);
-      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + xc_) * ldx + cc8 * 8);
+      pv[i] = ((uint32_t)crow[i] - r_lo) < r_n && ((uint32_t)cpx[i] - c_lo) < c_n;
+      pre[i] = *reinterpret_cast<const uint4*>(xb + (size_t)(pv[i] ? sbase + voff[i] : 0u));
     }
   };
   auto write_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int y0, int n) __attribute__((always_inline)) {
@@ -341,15 +350,25 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
   }
   const float* kco = ecoef + 640 + cc4 * 8;          // ga | gb | gc of this thread's channel chunk (LDS)
 
+  // (chunk offsets inside the row group are constants of the thread, the group's offset is wave-uniform; rows outside the image
+  // read offset 0 and are zeroed when staged -- see the forward kernel)
+  uint32_t vog[NCH], vog2[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    vog[i] = ((uint32_t)(crow[i] * W + cpx[i]) * (uint32_t)ldg + (uint32_t)cc4 * 8u) * 2u;
+    vog2[i] = ((uint32_t)(crow[i] * W + cpx[i]) * (uint32_t)ldg2 + (uint32_t)cc4 * 8u) * 2u;
+  }
+  const char* __restrict__ gslb = reinterpret_cast<const char*>(gsl);
+  const char* __restrict__ g2b = reinterpret_cast<const char*>(g2);
   auto issue_rows = [&](int b, int y0, int n) __attribute__((always_inline)) {
+    const uint32_t row0 = (uint32_t)((b * H + y0) * W);
+    const uint32_t sg = row0 * (uint32_t)ldg * 2u, sg2 = row0 * (uint32_t)ldg2 * 2u;
+    const uint32_t r_lo = (uint32_t)max(-y0, 0), r_n = (uint32_t)max(min(n, H - y0), 0) - r_lo;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int yy = y0 + crow[i];
-      gv[i] = crow[i] < n && yy >= 0 && yy < H;
-      const int yc_ = min(max(yy, 0), H - 1);
-      const size_t pixel = (size_t)(b * H + yc_) * W + cpx[i];
-      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + cc4 * 8);
-      pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + cc4 * 8);
+      gv[i] = ((uint32_t)crow[i] - r_lo) < r_n;
+      pg[i] = *reinterpret_cast<const uint4*>(gslb + (size_t)(gv[i] ? sg + vog[i] : 0u));
+      pg2[i] = *reinterpret_cast<const uint4*>(g2b + (size_t)(gv[i] ? sg2 + vog2[i] : 0u));
     }
   };
   auto write_rows = [&](int b, int y0, int n) __attribute__((always_inline)) {
@@ -621,13 +640,25 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
     grow[i] = cid / gcpr;
     gpx[i] = (cid - grow[i] * gcpr) >> 2;
   }
+  // (chunk offsets inside the row group: constants of the thread; see the forward kernel)
+  uint32_t vox[NX], vog[NG], vog2[NG];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) vox[i] = ((uint32_t)(xrow[i] * W + xpx[i]) * (uint32_t)ldx + (uint32_t)cx8 * 8u) * 2u;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    vog[i] = ((uint32_t)(grow[i] * W + gpx[i]) * (uint32_t)ldg + (uint32_t)cg4 * 8u) * 2u;
+    vog2[i] = ((uint32_t)(grow[i] * W + gpx[i]) * (uint32_t)ldg2 + (uint32_t)cg4 * 8u) * 2u;
+  }
+  const char* __restrict__ xb = reinterpret_cast<const char*>(x);
+  const char* __restrict__ gslb = reinterpret_cast<const char*>(gsl);
+  const char* __restrict__ g2b = reinterpret_cast<const char*>(g2);
   auto issue_rows = [&](int b, int y0, int n) __attribute__((always_inline)) {
+    const uint32_t sx = (uint32_t)((b * H + y0) * W) * (uint32_t)ldx * 2u;
+    const uint32_t r_lo = (uint32_t)max(-y0, 0), r_n = (uint32_t)max(min(n, H - y0), 0) - r_lo;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int yy = y0 + xrow[i];
-      pv[i] = xrow[i] < n && yy >= 0 && yy < H;
-      const int yc_ = min(max(yy, 0), H - 1);
-      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + xpx[i]) * ldx + cx8 * 8);
+      pv[i] = ((uint32_t)xrow[i] - r_lo) < r_n;
+      pre[i] = *reinterpret_cast<const uint4*>(xb + (size_t)(pv[i] ? sx + vox[i] : 0u));
     }
   };
   auto write_rows = [&](int y0, int n) __attribute__((always_inline)) {
@@ -648,14 +679,14 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
     }
   };
   auto issue_g = [&](int b, int yc) __attribute__((always_inline)) {
+    const uint32_t row0 = (uint32_t)((b * H + yc) * W);
+    const uint32_t sg = row0 * (uint32_t)ldg * 2u, sg2 = row0 * (uint32_t)ldg2 * 2u;
+    const uint32_t r_n = (uint32_t)max(min(R, H - yc), 0);
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-      const int yy = yc + grow[i];
-      gv[i] = grow[i] < R && yy < H;
-      const int yc_ = min(yy, H - 1);
-      const size_t pixel = (size_t)(b * H + yc_) * W + gpx[i];
-      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + cg4 * 8);
-      pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + cg4 * 8);      // g2 == gsl when there is no second tensor
+      gv[i] = (uint32_t)grow[i] < r_n;
+      pg[i] = *reinterpret_cast<const uint4*>(gslb + (size_t)(gv[i] ? sg + vog[i] : 0u));
+      pg2[i] = *reinterpret_cast<const uint4*>(g2b + (size_t)(gv[i] ? sg2 + vog2[i] : 0u));      // g2 == gsl when there is no second tensor
     }
   };
   auto write_g = [&]() __attribute__((always_inline)) {
@@ -773,6 +804,7 @@ int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1 || p.tstride > 1) return 0;
   if (p.K != 128 || p.N != 32 || p.prologue != CX_PRO_AFFINE_RELU || p.epilogue != CX_EPI_STORE || p.accumulate) return 0;
   if (p.W < 4) return 0;
+  if ((unsigned long long)p.B * p.H * p.W * (unsigned long long)p.ldx * 2ull >= (1ull << 32)) return 0;      // 32-bit chunk offsets in the kernel
   RingGeo g;
   // Wide maps as two column tiles: an 80-pixel row is 2.5 sub-tiles for 8 waves and one row is all the ring holds, so a step was
   // 3 busy waves and ~3.6 us of fixed latency (290 us per launch at bs = 256); halves of 40 columns take 5 rows per step (7
@@ -809,6 +841,7 @@ int cx_try_ring_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
   if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1 || p.tstride > 1) return 0;
   if (p.K != 32 || p.N != 128 || p.prologue != CX_PRO_AFFINE2 || p.epilogue != CX_EPI_MASK || p.accumulate) return 0;
   if (p.W < 4 || p.W + 2 > 256) return 0;
+  if ((unsigned long long)p.B * p.H * p.W * (unsigned long long)(p.ldx > p.ldx2 ? p.ldx : p.ldx2) * 2ull >= (1ull << 32)) return 0;   // 32-bit chunk offsets
   RingGeo g;
   g.B = p.B; g.H = p.H; g.W = p.W; g.P = p.W + 2;
   int rmax = (32 * 4 * MAX_ITEMS) / g.P;             // at most 8 sub-tiles (16 work items over 8 waves) per step
@@ -838,6 +871,10 @@ int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   // every workgroup ends with 147 KB of fp32 atomics (~30 us at the per-CU atomic issue rate): pays off on large maps only
   // (measured 337 vs 556 us at 80x80, 128 vs 118 us at 40x40); smaller maps stay on the first-generation strip kernel
   if (p.W < 56 || (long long)p.H * p.W < 3136) return 0;
+  {
+    const unsigned long long ldm = (unsigned long long)(p.ldx > p.ldg ? p.ldx : p.ldg) > (unsigned long long)p.ldg2 ? (unsigned long long)(p.ldx > p.ldg ? p.ldx : p.ldg) : (unsigned long long)p.ldg2;
+    if ((unsigned long long)p.B * p.H * p.W * ldm * 2ull >= (1ull << 32)) return 0;      // 32-bit chunk offsets in the kernel
+  }
   RingGeo g;
   g.B = p.B; g.H = p.H; g.W = p.W; g.P = p.W + 2;
   // largest R with: <= 16 k-steps of 16 pixels, ring + strip in 160 KB, <= 5 / 2 chunks of new rows per thread, and the

@@ -499,13 +499,26 @@ __device__ __forceinline__ void strip_wgrad_body(
     cc8[i] = rem & 3;
   }
   // unconditional loads on clamped addresses; validity applied when staging (see forward kernel)
+  // (chunk offsets inside the row group: constants of the thread; the group's offset is wave-uniform; rows outside the image read
+  // offset 0 and are zeroed when staged -- conv3x3_ring.hip, forward kernel)
+  uint32_t vox[NCHW], vog[NCHW], vog2[NCHW];
+#pragma unroll
+  for (int i = 0; i < NCHW; ++i) {
+    vox[i] = ((uint32_t)(crow[i] * W + cpx[i]) * (uint32_t)ldx + (uint32_t)(c0 + cc8[i] * 8)) * 2u;
+    const int co = n0 + cc8[i] * 8 < N ? cc8[i] * 8 : 0;
+    vog[i] = ((uint32_t)(crow[i] * W + cpx[i]) * (uint32_t)ldg + (uint32_t)co) * 2u;
+    vog2[i] = ((uint32_t)(crow[i] * W + cpx[i]) * (uint32_t)ldg2 + (uint32_t)co) * 2u;
+  }
+  const char* __restrict__ xb = reinterpret_cast<const char*>(x);
+  const char* __restrict__ gslb = reinterpret_cast<const char*>(gsl);
+  const char* __restrict__ g2b = reinterpret_cast<const char*>(g2);
   auto issue_rows = [&](int b, int y0, int n) {
+    const uint32_t sx = (uint32_t)((b * H + y0) * W) * (uint32_t)ldx * 2u;
+    const uint32_t r_lo = (uint32_t)max(-y0, 0), r_n = (uint32_t)max(min(n, H - y0), 0) - r_lo;
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      const int yy = y0 + crow[i];
-      pv[i] = crow[i] < n && yy >= 0 && yy < H;
-      const int yc_ = min(max(yy, 0), H - 1);
-      pre[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(b * H + yc_) * W + cpx[i]) * ldx + c0 + cc8[i] * 8);
+      pv[i] = ((uint32_t)crow[i] - r_lo) < r_n;
+      pre[i] = *reinterpret_cast<const uint4*>(xb + (size_t)(pv[i] ? sx + vox[i] : 0u));
     }
   };
   auto write_rows = [&](int y0, int n) {
@@ -524,16 +537,15 @@ __device__ __forceinline__ void strip_wgrad_body(
     }
   };
   auto issue_g = [&](int b, int yc) {
+    const uint32_t row0 = (uint32_t)((b * H + yc) * W);
+    const uint32_t sg = row0 * (uint32_t)ldg * 2u, sg2 = row0 * (uint32_t)ldg2 * 2u;
+    const uint32_t r_n = (uint32_t)max(min(R, H - yc), 0);
 #pragma unroll
     for (int i = 0; i < NCHW; ++i) {
-      const int yy = yc + crow[i];
       const bool nok = n0 + cc8[i] * 8 < N;          // chunk of 8 output channels inside the tensor
-      gv[i] = crow[i] < R && yy < H && nok;
-      const int yc_ = min(yy, H - 1);
-      const size_t pixel = (size_t)(b * H + yc_) * W + cpx[i];
-      const int co = nok ? cc8[i] * 8 : 0;
-      pg[i] = *reinterpret_cast<const uint4*>(gsl + pixel * ldg + co);
-      if (g_affine2) pg2[i] = *reinterpret_cast<const uint4*>(g2 + pixel * ldg2 + co);
+      gv[i] = (uint32_t)crow[i] < r_n && nok;
+      pg[i] = *reinterpret_cast<const uint4*>(gslb + (size_t)(gv[i] ? sg + vog[i] : 0u));
+      if (g_affine2) pg2[i] = *reinterpret_cast<const uint4*>(g2b + (size_t)(gv[i] ? sg2 + vog2[i] : 0u));
     }
   };
   auto write_g = [&]() {
@@ -740,6 +752,11 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   if (p.K % 32 || p.N % 8 || p.K > 2048 || p.N > 2048 || p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
   if (p.g_prologue != CX_PRO_NONE && p.g_prologue != CX_PRO_AFFINE2) return 0;
   if (p.W + 2 > 128 || p.W < 4) return 0;
+  {
+    unsigned long long ldm = (unsigned long long)(p.ldx > p.ldg ? p.ldx : p.ldg);
+    if (p.g_prologue == CX_PRO_AFFINE2 && (unsigned long long)p.ldg2 > ldm) ldm = (unsigned long long)p.ldg2;
+    if ((unsigned long long)p.B * p.H * p.W * ldm * 2ull >= (1ull << 32)) return 0;      // 32-bit chunk offsets in the kernel
+  }
   const long long px = (long long)p.B * p.H * p.W;
   const int c_tiles = p.K / 32, n_tiles = (p.N + 31) / 32, pairs = c_tiles * n_tiles;
   // pixel-range splits: the dense layers (4 tile pairs) take 64; wider convolutions ~768 workgroups in all, at least 4 splits
@@ -810,6 +827,7 @@ int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* 
   if (p.dtype != CX_DT_BF16 || p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1) return CX_EUNSUPPORTED;
   if (p.K != 128 || p.N != 32 || p.x_prologue != CX_PRO_AFFINE_RELU || p.g_prologue != CX_PRO_NONE) return CX_EUNSUPPORTED;
   if (p.W + 2 > 128 || p.W < 4 || p.Ho != p.H || p.Wo != p.W || (p.ldg % 8) || (p.ldx % 8)) return CX_EUNSUPPORTED;
+  if ((unsigned long long)p.B * p.H * p.W * (unsigned long long)(p.ldx > p.ldg ? p.ldx : p.ldg) * 2ull >= (1ull << 32)) return CX_EUNSUPPORTED;
   for (int i = 0; i < n; ++i)
     if (!items->g[i] || !items->x[i] || !items->pa[i] || !items->pb[i] || !items->dw[i]) return CX_EINVAL;
   if (!p.scratch) return CX_EUNSUPPORTED;             // partial tiles go to slabs (ordered sums); no atomic form
