@@ -29,9 +29,14 @@ struct RingGeo {
   int Wt, ntx;                  // forward: column tiles of Wt pixels (P = Wt+2, ntx per row; B counts tiles = images * ntx)
   int spi;                      // steps per image = ceil(H/R)
   int steps_per_wg;
+  unsigned mP;                  // ceil(2^32 / P): m / P = umulhi(m, mP) for the flat pixel indices of a step (m < 2^16)
+  unsigned mSpi;                // ceil(2^32 / spi): step index / spi (exact while steps < 2^32 / spi: the launchers check)
+  int ntx_shift;                // ntx is 1 or 2
 };
 
 __device__ __forceinline__ int wrapq(int v, int q) { return v >= q ? v - q : v; }
+// step index / steps per image by multiply-high; spi == 1 (a whole image per step: small maps) has no 32-bit magic number (2^32)
+__device__ __forceinline__ int div_spi(const RingGeo& g, int v) { return g.spi == 1 ? v : (int)__umulhi((unsigned)v, g.mSpi); }
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   for (int i = 0; i < NCH; ++i) voff[i] = ((uint32_t)(crow[i] * W + cpx[i]) * (uint32_t)ldx + (uint32_t)cc8 * 8u) * 2u;
   const char* __restrict__ xb = reinterpret_cast<const char*>(x);
   auto issue_rows = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int bv, int y0, int n) __attribute__((always_inline)) {
-    const int b = bv / ntx, x0 = (bv - b * ntx) * Wt - 1;
+    const int b = bv >> g.ntx_shift, x0 = (bv - (b << g.ntx_shift)) * Wt - 1;
     const uint32_t sbase = (uint32_t)((b * H + y0) * W + x0) * (uint32_t)ldx * 2u;      // (wraps for y0 = -1 / x0 = -1: only valid chunks use it)
     const uint32_t r_lo = (uint32_t)max(-y0, 0), r_n = (uint32_t)max(min(n, H - y0), 0) - r_lo;      // rows  [r_lo, r_lo + r_n)
     const uint32_t c_lo = (uint32_t)max(-x0, 0), c_n = (uint32_t)max(W - x0, 0) - c_lo;              // pixels [c_lo, c_lo + c_n)
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   // new rows of step v (a continuation step of its image inside this workgroup's range), else a harmless clamped load
   int ulim = u1;              // end of the pass being walked (below)
   auto issue_step = [&](uint4 (&pre)[NCH], bool (&pv)[NCH], int v) __attribute__((always_inline)) {
-    const int bv = v / g.spi, sv = v - bv * g.spi;
+    const int bv = div_spi(g, v), sv = v - bv * g.spi;
     const bool ok = v < ulim && sv != 0;
     issue_rows(pre, pv, ok ? bv : 0, ok ? sv * R + 1 : 0, ok ? R : 0);
   };
@@ -151,8 +156,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
     constexpr int k = decltype(KI)::value;
     uint4 (&cur)[NCH] = pre[k];
     bool (&cv)[NCH] = pv[k];
-    const int bv = u / g.spi, yc = (u - bv * g.spi) * R;
-    const int b = bv / ntx, x0 = (bv - b * ntx) * Wt;
+    const int bv = div_spi(g, u), yc = (u - bv * g.spi) * R;
+    const int b = bv >> g.ntx_shift, x0 = (bv - (b << g.ntx_shift)) * Wt;
     write_rows(cur, cv, yc + 1, R);
     __syncthreads();                                   // the window of this step is complete
     issue_step(cur, cv, u + DEPTH);                    // in flight under the MFMAs of this and the next DEPTH-1 steps
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[gi % 3][j], fb[gi % 3][j], acc, 0, 0, 0);   // D[row = out channel][col = pixel]
         __builtin_amdgcn_sched_barrier(0);
       }
-      const int oy = m / P, ox = m - oy * P;
+      const int oy = (int)__umulhi((unsigned)m, g.mP), ox = m - oy * P;      // m / P without the ~20-instruction division
       const int yy = yc + oy;
       const bool valid = m < R * P && ox < Wt && x0 + ox < W && yy < H;
       bf16* yrow = y + ((size_t)(b * H + (valid ? yy : 0)) * W + (valid ? x0 + ox : 0)) * ldy;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   for (int pass = 0; pass < 2; ++pass) {
   ulim = pass == 0 ? u1 : u0 + rot;
   for (int ui = pass == 0 ? u0 + rot : u0; ui < ulim;) {
-    const int b = ui / g.spi, yc = (ui - b * g.spi) * R;
+    const int b = div_spi(g, ui), yc = (ui - b * g.spi) * R;
     const int ue = min(ulim, (b + 1) * g.spi);
     base_row = yc - 1;
     auto sync_rows = [&](int y0) __attribute__((always_inline)) {
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
   const char* wbase = wl + (size_t)(h2 * 64 + lrow) * GP + lh * 16;
 
   for (int u = u0; u < u1; ++u) {
-    const int b = u / g.spi, yc = (u - b * g.spi) * R;
+    const int b = div_spi(g, u), yc = (u - b * g.spi) * R;
     if (u == u0 || yc == 0) {
       base_row = yc - 1;
       issue_rows(b, yc - 1, 1);
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     }
     write_rows(b, yc + 1, R);
     __syncthreads();                                   // the window of this step is complete
-    const bool next_cont = (u + 1 < u1) && ((u + 1) / g.spi == b);
+    const bool next_cont = (u + 1 < u1) && (div_spi(g, u + 1) == b);
     if (next_cont) issue_rows(b, yc + R + 1, R);
     int slot0 = (yc - 1 - base_row) % (R + 2);
     if (slot0 < 0) slot0 += R + 2;
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
         // per lane in the accumulator's own lane = pixel layout
         U128 xv[2][2];
         const int m = s * 32 + lrow;
-        const int oy = m / P, ox = m - oy * P;
+        const int oy = (int)__umulhi((unsigned)m, g.mP), ox = m - oy * P;
         const int yy = yc + oy;
         const bool pok = m < R * P && ox < W && yy < H;
         const int poff = (b * H + min(yy, H - 1)) * W + min(ox, W - 1);
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
   const int QB = Q * WXP;
 
   for (int u = u0; u < u1; ++u) {
-    const int b = u / g.spi, yc = (u - b * g.spi) * R;
+    const int b = div_spi(g, u), yc = (u - b * g.spi) * R;
     if (u == u0 || yc == 0) {
       base_row = yc - 1;
       issue_rows(b, yc - 1, 1);
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
     write_rows(yc + 1, R);
     write_g();
     __syncthreads();
-    const bool next_cont = (u + 1 < u1) && ((u + 1) / g.spi == b);
+    const bool next_cont = (u + 1 < u1) && (div_spi(g, u + 1) == b);
     if (next_cont) {
       issue_rows(b, yc + R + 1, R);
       issue_g(b, yc + R);
@@ -823,6 +828,11 @@ int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   if (g.R * g.P * 16 > 7 * NT) return 0;
   g.spi = (p.H + g.R - 1) / g.R;
   g.Q = (g.R + 2) * g.P;
+  g.mP = 0xffffffffu / (unsigned)g.P + 1u;
+  g.mSpi = 0xffffffffu / (unsigned)g.spi + 1u;
+  g.ntx_shift = 0;
+  if ((unsigned long long)p.B * 2ull * g.spi * g.spi >= (1ull << 32)) return 0;      // exactness of the multiply-high divisions
+  g.ntx_shift = g.ntx - 1;
   const int total = g.B * g.spi;
   // one workgroup per CU; ranges aligned to whole images when there are enough of them (no window rebuild inside an image)
   int spw = (total + 255) / 256;
@@ -851,6 +861,10 @@ int cx_try_ring_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
   g.R = (p.H + g.spi - 1) / g.spi;
   g.spi = (p.H + g.R - 1) / g.R;
   g.Q = (g.R + 2) * g.P;
+  g.mP = 0xffffffffu / (unsigned)g.P + 1u;
+  g.mSpi = 0xffffffffu / (unsigned)g.spi + 1u;
+  g.ntx_shift = 0;
+  if ((unsigned long long)p.B * 2ull * g.spi * g.spi >= (1ull << 32)) return 0;      // exactness of the multiply-high divisions
   if (EC_BYTES + DW_BYTES + (size_t)(g.Q + 2) * GP > 160 * 1024) return 0;
   const int need = (g.R * p.W * 4 + NT - 1) / NT;
   if (need > 2) return 0;
@@ -891,6 +905,10 @@ int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   g.R = (p.H + g.spi - 1) / g.spi;
   g.spi = (p.H + g.R - 1) / g.R;
   g.Q = (g.R + 2) * g.P;
+  g.mP = 0xffffffffu / (unsigned)g.P + 1u;
+  g.mSpi = 0xffffffffu / (unsigned)g.spi + 1u;
+  g.ntx_shift = 0;
+  if ((unsigned long long)p.B * 2ull * g.spi * g.spi >= (1ull << 32)) return 0;      // exactness of the multiply-high divisions
   const int nk = (g.R * g.P + 15) / 16;
   size_t smem = WCOEF + (size_t)(g.Q + 2) * WXP + (size_t)nk * 16 * WGP;
   if (smem < WCOEF + 32 * 288 * 4) smem = WCOEF + 32 * 288 * 4;

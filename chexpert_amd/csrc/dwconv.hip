@@ -22,6 +22,16 @@ constexpr int TW = 16;
 // v_exp_f32 + v_rcp_f32 (1 ulp): the IEEE division sequence behind `1.f / x` was half of the staging instructions
 __device__ __forceinline__ float sigm(float z) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z)); }
 __device__ __forceinline__ float swish(float z) { return z * sigm(z); }
+// swish(x * sc + sh) of a staged 16-byte chunk, one conversion per dword (common.h: cx_packbf); !act: the chunk as loaded
+__device__ __forceinline__ uint4 affine_swish8(const uint4 v, const float (&sc)[8], const float (&sh)[8], const bool act) {
+  if (!act) return v;
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o[j] = cx_packbf(swish(fmaf(cx_bf_lo(w[j]), sc[2 * j], sh[2 * j])), swish(fmaf(cx_bf_hi(w[j]), sc[2 * j + 1], sh[2 * j + 1])));
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
 __device__ __forceinline__ float dswish(float z) {
   const float s = sigm(z);
   return s * (1.f + z * (1.f - s));
@@ -98,11 +108,7 @@ __global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict
       for (int u = 0; u < NLD; ++u) {
         const int i = u * 256 + tid, p = i / NCQ;
         U128 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float a = bf2f(pre[u].e[j]);
-          o.e[j] = act ? f2bf(swish(fmaf(a, fsc[j], fsh[j]))) : pre[u].e[j];
-        }
+        o.u = affine_swish8(pre[u].u, fsc, fsh, act);
         const unsigned keep = (pre_ok >> u) & 1u ? 0xffffffffu : 0u;
         o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
         if (i < NCHUNK) *reinterpret_cast<uint4*>(tile + (size_t)p * PP + cq * 16) = o.u;
@@ -126,11 +132,7 @@ __global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict
       for (int u = 0; u < 4; ++u) {
         const int i = base + u * 256 + tid, p = i / NCQ;
         U128 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float a = bf2f(v[u].e[j]);
-          o.e[j] = act ? f2bf(swish(fmaf(a, fsc[j], fsh[j]))) : v[u].e[j];       // the rounding of a materialised activation
-        }
+        o.u = affine_swish8(v[u].u, fsc, fsh, act);       // the rounding of a materialised activation
         const unsigned keep = ok[u] ? 0xffffffffu : 0u;
         o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
         if (i < NCHUNK) *reinterpret_cast<uint4*>(tile + (size_t)p * PP + cq * 16) = o.u;
@@ -176,13 +178,7 @@ __global__ __launch_bounds__(256) void dw_fwd_tile_kernel(const bf16* __restrict
       const int ox = ox0 + xg * 4 + j;
       if (cok && oy < g.Ho && ox < g.Wo) {
         U128 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          o.e[e] = f2bf(acc[j][e]);
-          const float rv = bf2f(o.e[e]);
-          s1[e] += rv;
-          s2[e] += rv * rv;
-        }
+        o.u = cx_pack8_stats(acc[j], true, true, s1, s2);
         *reinterpret_cast<uint4*>(y + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * C + cch) = o.u;
       }
     }
@@ -275,8 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int u = 0; u < 4; ++u) {
         const int i = base + u * 256 + tid, p = i / NCQ;
         U128 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u_[u].e[j]), fa[j], fmaf(bf2f(v_[u].e[j]), fb[j], fc[j])));
+        o.u = cx_affine2_8(u_[u].u, v_[u].u, fa, fb, fc);
         const unsigned keep = ok[u] ? 0xffffffffu : 0u;
         o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
         if (i < NCHUNK) *reinterpret_cast<uint4*>(tile + (size_t)p * PP + cq * 16) = o.u;
@@ -339,15 +334,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < 4; ++j) {
       if (pok[j]) {
         U128 o;
+        {
+          const uint32_t xw[4] = {xv[j].u.x, xv[j].u.y, xv[j].u.z, xv[j].u.w}, ow[4] = {old[j].u.x, old[j].u.y, old[j].u.z, old[j].u.w};
+          uint32_t w4[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xf = bf2f(xv[j].e[e]);
-          float d = acc[j][e];
-          if (act) d *= dswish(fmaf(xf, fsc[e], fsh[e]));
-          s1[e] += d;
-          s2[e] += d * (xf - fmu[e]) * fr[e];
-          if (accumulate) d += bf2f(old[j].e[e]);
-          o.e[e] = f2bf(d);
+          for (int e2 = 0; e2 < 4; ++e2) {
+            float dd[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int e = 2 * e2 + h;
+              const float xf = h ? cx_bf_hi(xw[e2]) : cx_bf_lo(xw[e2]);
+              float d = acc[j][e];
+              if (act) d *= dswish(fmaf(xf, fsc[e], fsh[e]));
+              s1[e] += d;
+              s2[e] += d * (xf - fmu[e]) * fr[e];
+              if (accumulate) d += h ? cx_bf_hi(ow[e2]) : cx_bf_lo(ow[e2]);
+              dd[h] = d;
+            }
+            w4[e2] = cx_packbf(dd[0], dd[1]);
+          }
+          o.u = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
         *reinterpret_cast<uint4*>(dz + ((size_t)(b * H + iy) * W + ix0 + xg * 4 + j) * C + cch) = o.u;
       }
@@ -438,8 +444,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const bf16* __restri
       for (int u = 0; u < 4; ++u) {
         const int i = base + u * 256 + tid, p = i / NCQ;
         U128 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = act ? f2bf(swish(fmaf(bf2f(v[u].e[j]), fsc[j], fsh[j]))) : v[u].e[j];
+        o.u = affine_swish8(v[u].u, fsc, fsh, act);
         const unsigned keep = ok[u] ? 0xffffffffu : 0u;
         o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
         if (i < NCHUNK) *reinterpret_cast<uint4*>(xt + (size_t)p * PP + cq * 16) = o.u;
@@ -462,8 +467,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const bf16* __restri
       for (int u = 0; u < 4; ++u) {
         const int i = base + u * 256 + tid, p = i / NCQ;
         U128 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f2bf(fmaf(bf2f(u_[u].e[j]), fa[j], fmaf(bf2f(v_[u].e[j]), fb[j], fc[j])));
+        o.u = cx_affine2_8(u_[u].u, v_[u].u, fa, fb, fc);
         const unsigned keep = ok[u] ? 0xffffffffu : 0u;
         o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep;
         if (i < GCHUNK) *reinterpret_cast<uint4*>(gt + (size_t)p * PP + cq * 16) = o.u;
