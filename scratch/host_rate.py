@@ -10,10 +10,10 @@ from chexpert_amd.optim import FusedAdam
 dev = torch.device('cuda:0')
 ATT = lambda s: {"k": 0.2, "v": 0.1, "nh": 8, "relative": True, "input_dims": (s, s)}
 MODELS = {
-    "densenet121": (lambda: densenet121(num_classes=14), 320, 256, 30.0),
-    "aadensenet121": (lambda: DenseNet(32, (6, 12, 24, 16), 64, num_classes=14, attn_params=ATT(320)), 320, 128, 29.6),
-    "resnet152": (lambda: resnet152(num_classes=14), 320, 128, 54.8),
-    "efficientnet-b4": (lambda: construct_model("efficientnet-b4", 14), 380, 64, 36.4),
+    "densenet121": (lambda: densenet121(num_classes=14), 320, 256, 29.2),
+    "aadensenet121": (lambda: DenseNet(32, (6, 12, 24, 16), 64, num_classes=14, attn_params=ATT(320)), 320, 128, 29.8),
+    "resnet152": (lambda: resnet152(num_classes=14), 320, 128, 55.3),
+    "efficientnet-b4": (lambda: construct_model("efficientnet-b4", 14), 380, 64, 36.1),
 }
 for name, (ctor, S, B, gpu_ms) in MODELS.items():
     m = ctor().to(dev).train()
