@@ -131,8 +131,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
         o.u = cx_affine_relu8(pre[i], csc, csh);
         { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i];
-        *reinterpret_cast<uint4*>(ring + (size_t)pos * XP + cc8 * 16) = o.u;
-        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * XP + cc8 * 16) = o.u;   // mirror of pixels 0,1
+        *reinterpret_cast<uint4*>(ring + pos * XP + cc8 * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (Q + pos) * XP + cc8 * 16) = o.u;   // mirror of pixels 0,1
       }
     }
   };
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
       // register sets), so the LDS latency hides under the matrix pipe even when this is the only computing
       // wave of its SIMD (W = 80: 3 sub-tiles per step for 8 waves).  Read-then-multiply per tap measured 130 cycles per
       // MFMA; the sched_barriers keep the scheduler from hoisting every read of the unrolled loop (it spilled).
-      const char* ap0 = ring + (size_t)wrapq(wrapq(ws + pix, Q), Q) * XP + lh * 16;
-      const char* ap1 = ring + (size_t)wrapq(wrapq(ws + pix + P, Q), Q) * XP + lh * 16;
-      const char* ap2 = ring + (size_t)wrapq(wrapq(ws + pix + 2 * P, Q), Q) * XP + lh * 16;
+      const char* ap0 = ring + wrapq(wrapq(ws + pix, Q), Q) * XP + lh * 16;
+      const char* ap1 = ring + wrapq(wrapq(ws + pix + P, Q), Q) * XP + lh * 16;
+      const char* ap2 = ring + wrapq(wrapq(ws + pix + 2 * P, Q), Q) * XP + lh * 16;
       // the 72 (tap, k-step) products in groups of 3, three register sets: the reads of group g+2 go out before the MFMAs of
       // group g (6 MFMAs = 192 cycles ahead; 72 fragment registers)
       constexpr int G = 3, NG = 72 / G;
@@ -391,8 +391,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
         if (po && gv[i]) *reinterpret_cast<uint4*>(po + ((size_t)(b * H + y0 + crow[i]) * W + cpx[i]) * ldpo + cc4 * 8) = o.u;
         { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
-        *reinterpret_cast<uint4*>(ring + (size_t)pos * GP + cc4 * 16) = o.u;
-        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * GP + cc4 * 16) = o.u;
+        *reinterpret_cast<uint4*>(ring + pos * GP + cc4 * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (Q + pos) * GP + cc4 * 16) = o.u;
       }
     }
   };
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
 #pragma unroll
       for (int e = 0; e < 8; ++e) s1[j][cc][e] = s2[j][cc][e] = 0.f;
   const int nsub = (R * P + 31) / 32;                 // <= 4 * MAX_ITEMS
-  const char* wbase = wl + (size_t)(h2 * 64 + lrow) * GP + lh * 16;
+  const char* wbase = wl + (h2 * 64 + lrow) * GP + lh * 16;
 
   for (int u = u0; u < u1; ++u) {
     const int b = div_spi(g, u), yc = (u - b * g.spi) * R;
@@ -450,19 +450,19 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
         const int pix = min(s * 32 + lrow, R * P - 1);
         // software pipeline over the nine taps inside the wave (as in the forward kernel): the 6 fragment reads of tap t+1 go
         // out before the 4 MFMAs of tap t (two register sets)
-        const char* ap0 = ring + (size_t)wrapq(wrapq(ws + pix, Q), Q) * GP + lh * 16;
-        const char* ap1 = ring + (size_t)wrapq(wrapq(ws + pix + P, Q), Q) * GP + lh * 16;
-        const char* ap2 = ring + (size_t)wrapq(wrapq(ws + pix + 2 * P, Q), Q) * GP + lh * 16;
+        const char* ap0 = ring + wrapq(wrapq(ws + pix, Q), Q) * GP + lh * 16;
+        const char* ap1 = ring + wrapq(wrapq(ws + pix + P, Q), Q) * GP + lh * 16;
+        const char* ap2 = ring + wrapq(wrapq(ws + pix + 2 * P, Q), Q) * GP + lh * 16;
         bf16x8 fb[2][2], fa[2][2][2];
         auto load_tap = [&](int t, bf16x8 (&B)[2], bf16x8 (&A)[2][2]) __attribute__((always_inline)) {
           const int dy = t / 3, dx = t - dy * 3;
           const char* ap = (dy == 0 ? ap0 : dy == 1 ? ap1 : ap2) + dx * GP;
-          const char* wp = wbase + (size_t)t * 128 * GP;
+          const char* wp = wbase + t * 128 * GP;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             B[ks] = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) A[ks][j] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(j * 32) * GP + ks * 32);
+            for (int j = 0; j < 2; ++j) A[ks][j] = *reinterpret_cast<const bf16x8*>(wp + (j * 32) * GP + ks * 32);
           }
         };
         load_tap(0, fb[0], fa[0]);
@@ -678,8 +678,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
         o.u = cx_affine_relu8(pre[i], xco, xco + 128);
         { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + xpx[i] + 1;
-        *reinterpret_cast<uint4*>(ring + (size_t)pos * WXP + cx8 * 16) = o.u;
-        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * WXP + cx8 * 16) = o.u;   // mirror of pixels 0,1
+        *reinterpret_cast<uint4*>(ring + pos * WXP + cx8 * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (Q + pos) * WXP + cx8 * 16) = o.u;   // mirror of pixels 0,1
       }
     }
   };
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
         U128 o;
         o.u = cx_affine2_8(pg[i], pg2[i], gco, gco + 32, gco + 64);
         { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
-        *reinterpret_cast<uint4*>(gst + (size_t)(grow[i] * P + gpx[i]) * WGP + cg4 * 16) = o.u;     // pad columns / tail stay zero
+        *reinterpret_cast<uint4*>(gst + (grow[i] * P + gpx[i]) * WGP + cg4 * 16) = o.u;     // pad columns / tail stay zero
       }
     }
   };
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_ring_wgrad_kernel(
     int o1 = wrapq(wrapq(ws + lrow + 4 + dy * P, Q), Q) * WXP;
 #pragma unroll 2
     for (int kk = 0; kk < nk; ++kk) {
-      const char* gbase = gst + (size_t)(kk * 16 + lrow) * WGP + gcol;
+      const char* gbase = gst + (kk * 16 + lrow) * WGP + gcol;
       const bf16x8 af = tr2(gbase, gbase + 4 * WGP);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {

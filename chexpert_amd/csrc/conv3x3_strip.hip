@@ -104,8 +104,8 @@ __global__ __launch_bounds__(192, 2) void conv3x3_strip_fwd_kernel(const bf16* _
           o.e[j] = f2bf(fmaxf(fmaf(bf2f(v.e[j]), coef[cc8[i] * 8 + j], coef[128 + cc8[i] * 8 + j]), 0.f));
         { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
-        *reinterpret_cast<uint4*>(ring + (size_t)pos * XP_FWD + cc8[i] * 16) = o.u;
-        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * XP_FWD + cc8[i] * 16) = o.u;   // mirror of pixels 0,1
+        *reinterpret_cast<uint4*>(ring + pos * XP_FWD + cc8[i] * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (Q + pos) * XP_FWD + cc8[i] * 16) = o.u;   // mirror of pixels 0,1
       }
     }
   };
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(192, 2) void conv3x3_strip_dgrad_kernel(
         }
         { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
-        *reinterpret_cast<uint4*>(ring + (size_t)pos * GP + cc8[i] * 16) = o.u;
-        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * GP + cc8[i] * 16) = o.u;
+        *reinterpret_cast<uint4*>(ring + pos * GP + cc8[i] * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (Q + pos) * GP + cc8[i] * 16) = o.u;
       }
     }
   };
@@ -531,8 +531,8 @@ __device__ __forceinline__ void strip_wgrad_body(
         o.u = cx_affine_relu8(pre[i], coef + cc8[i] * 8, coef + 32 + cc8[i] * 8);
         { const unsigned keep = pv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
         const int pos = slot * P + cpx[i] + 1;
-        *reinterpret_cast<uint4*>(ring + (size_t)pos * WP + cc8[i] * 16) = o.u;
-        if (pos < 2) *reinterpret_cast<uint4*>(ring + (size_t)(Q + pos) * WP + cc8[i] * 16) = o.u;   // mirror of pixels 0,1
+        *reinterpret_cast<uint4*>(ring + pos * WP + cc8[i] * 16) = o.u;
+        if (pos < 2) *reinterpret_cast<uint4*>(ring + (Q + pos) * WP + cc8[i] * 16) = o.u;   // mirror of pixels 0,1
       }
     }
   };
@@ -556,7 +556,7 @@ __device__ __forceinline__ void strip_wgrad_body(
         // (without the two-tensor prologue the staged values are the loaded ones: a = 1, b = c = 0 reproduces them exactly)
         o.u = g_affine2 ? cx_affine2_8(pg[i], pg2[i], coef + 64 + cc8[i] * 8, coef + 96 + cc8[i] * 8, coef + 128 + cc8[i] * 8) : pg[i];
         { const unsigned keep = gv[i] ? 0xffffffffu : 0u; o.u.x &= keep; o.u.y &= keep; o.u.z &= keep; o.u.w &= keep; }   // no per-element branch
-        *reinterpret_cast<uint4*>(gst + (size_t)(crow[i] * P + cpx[i]) * WP + cc8[i] * 16) = o.u;   // pad columns / tail stay zero
+        *reinterpret_cast<uint4*>(gst + (crow[i] * P + cpx[i]) * WP + cc8[i] * 16) = o.u;   // pad columns / tail stay zero
       }
     }
   };
@@ -602,7 +602,7 @@ __device__ __forceinline__ void strip_wgrad_body(
     int o1 = ((ws + lrow + 4 + wave * P + grp * 16) % Q) * WP;
 #pragma unroll 2
     for (int kk = grp; kk < nk; kk += NG) {
-      const char* gbase = gst + (size_t)(kk * 16 + lrow) * WP + gcol;
+      const char* gbase = gst + (kk * 16 + lrow) * WP + gcol;
       const bf16x8 af = tr2(gbase, gbase + 4 * WP);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
