@@ -5,7 +5,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 name = lambda r: re.sub(r'\(.*', '', r['Kernel_Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', ''))[:34]
 # take the last full step: between the last two adam kernels
 idx = [i for i, r in enumerate(rows) if 'adam' in r['Kernel_Name']]
-pairs = [(x, y) for x, y in zip(idx, idx[1:]) if y - x > 500]
+pairs = [(x, y) for x, y in zip(idx, idx[1:]) if y - x > 200]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(pairs) // 2      # a step from the middle of the run (graph replays)
 a, b = pairs[which]
 print("%d steps found, analysing step %d" % (len(pairs), which))
