@@ -103,6 +103,7 @@ SIGNATURES = {
     "cx_bnrelu_maxpool_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "cx_head_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cx_bce_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp],
+    "cx_softmax_ce_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp],
     "cx_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_gap_relu_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "cx_unpool2_mask": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

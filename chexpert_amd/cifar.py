@@ -225,6 +225,34 @@ def build_model(args, n_classes):
     return model, opt
 
 
+class _CEFn(torch.autograd.Function):
+    """loss and d loss / d logits in one HIP launch (cx_softmax_ce_fwd_bwd); backward scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        from . import ops
+        lg = logits.detach().float().contiguous()
+        loss = torch.empty(1, device=lg.device, dtype=torch.float32)
+        dl = torch.empty_like(lg) if logits.requires_grad else None
+        ops.softmax_ce_fwd_bwd(lg, target.contiguous(), loss, None, dl)
+        ctx.dl, ctx.dtype = dl, logits.dtype
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.dl * g).to(ctx.dtype), None
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() of the reference harness (models/test_model.py:331; mean reduction, class-index targets) on the HIP
+    kernel; fails loudly without the library, like every other op of the package."""
+
+    def forward(self, logits, target):
+        if not logits.is_cuda:
+            raise RuntimeError("chexpert_amd.cifar.CrossEntropyLoss runs on the GPU library only")
+        return _CEFn.apply(logits, target)
+
+
 def train_epoch(model, loader, loss_fn, opt, epoch, args, log):
     model.train()
     n_batches = len(loader)
@@ -299,7 +327,7 @@ def main(argv=None):
         op = os.path.join(os.path.dirname(args.restore), "optim_" + os.path.basename(args.restore))
         opt.load_state_dict(torch.load(op, map_location="cpu")["optimizer"])
     opt.lr = lr_at(args, args.step, len(train_loader))
-    loss_fn = nn.CrossEntropyLoss().to(args.device)
+    loss_fn = CrossEntropyLoss().to(args.device)
     logf = open(os.path.join(args.output_dir, "log.jsonl"), "a")
 
     def log(rec):

@@ -609,6 +609,42 @@ __global__ void bce_kernel(const float* __restrict__ logits, const float* __rest
   if (threadIdx.x == 0 && loss) *loss = red[0] * invB;
 }
 
+// one wave per sample: row maximum and sum of exponentials by DPP-free shuffles, loss = mean_b (logsumexp - logit[target]);
+// the per-sample terms are summed by ONE workgroup in sample order (bit-reproducible)
+__global__ void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ target, float* loss, float* loss_elem,
+                                  float* dlogits, float grad_scale, int B, int n) {
+  __shared__ float red[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const float invB = 1.f / B;
+  float acc = 0.f;                                       // lane 0 of each wave: its samples' losses
+  for (int b = wave; b < B; b += nw) {
+    const float* row = logits + (size_t)b * n;
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, row[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float se = 0.f;
+    for (int i = lane; i < n; i += 64) se += expf(row[i] - m);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    const int t = (int)target[b];
+    const float l = (t >= 0 && t < n) ? m + logf(se) - row[t] : 0.f;
+    if (lane == 0) {
+      acc += l;
+      if (loss_elem) loss_elem[b] = l;
+    }
+    if (dlogits) {
+      const float inv = 1.f / se;
+      for (int i = lane; i < n; i += 64) dlogits[(size_t)b * n + i] = (expf(row[i] - m) * inv - (i == t ? 1.f : 0.f)) * invB * grad_scale;
+    }
+  }
+  red[threadIdx.x] = lane == 0 ? acc : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) {
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += red[w * 64];
+    *loss = s * invB;
+  }
+}
+
 // grid (C/256, n + B): row y < n computes dW[y][:] (and db[y]), row y >= n computes dpooled[y-n][:]
 __global__ void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ pooled, const float* __restrict__ w,
                                 float* dw, float* db, float* __restrict__ dpooled, int B, int C, int n) {
@@ -1494,6 +1530,14 @@ int cx_bce_fwd_bwd(const float* logits, const float* target, float* loss, float*
   if (!logits || !target || B <= 0 || n_classes <= 0) return CX_EINVAL;
   hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, target, loss, loss_elem, dlogits, grad_scale, B,
                      n_classes);
+  return launch_status();
+}
+
+int cx_softmax_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss, float* loss_elem, float* dlogits, float grad_scale,
+                          int B, int n_classes, void* stream) {
+  if (!logits || !target || B <= 0 || n_classes <= 0) return CX_EINVAL;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, (const long long*)target, loss, loss_elem,
+                     dlogits, grad_scale, B, n_classes);
   return launch_status();
 }
 

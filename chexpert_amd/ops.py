@@ -408,6 +408,13 @@ def bce_fwd_bwd(logits, target, loss, loss_elem, dlogits, grad_scale=1.0):
                                stream_ptr()), "cx_bce_fwd_bwd")
 
 
+def softmax_ce_fwd_bwd(logits, target, loss, loss_elem, dlogits, grad_scale=1.0):
+    """CrossEntropyLoss forward + gradient in one launch (fp32 logits [B, n], int64 class indices [B])."""
+    B, n = logits.shape
+    check(lib().cx_softmax_ce_fwd_bwd(ptr(logits), ptr(target), ptr(loss), ptr(loss_elem), ptr(dlogits), grad_scale, B, n,
+                                      stream_ptr()), "cx_softmax_ce_fwd_bwd")
+
+
 def head_bwd(dlogits, pooled, w, dw, db, dpooled):
     B, n = dlogits.shape
     check(lib().cx_head_bwd(ptr(dlogits), ptr(pooled), ptr(w), ptr(dw), ptr(db), ptr(dpooled), B, pooled.shape[1], n,

@@ -285,6 +285,11 @@ int cx_head_fwd(const void* x, const float* scale, const float* shift, const flo
  * (chexpert.py:160, :530)                                                                         */
 int cx_bce_fwd_bwd(const float* logits, const float* target, float* loss, float* loss_elem, float* dlogits,
                    float grad_scale, int B, int n_classes, void* stream);
+/* loss = CrossEntropyLoss(logits, target) (mean over the batch of logsumexp - logit[target]);
+ * dlogits = (softmax - onehot)/B * grad_scale; loss_elem (optional) = the per-sample terms
+ * (models/test_model.py:118, :143, :331: the CIFAR harness criterion)                              */
+int cx_softmax_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss, float* loss_elem, float* dlogits,
+                          float grad_scale, int B, int n_classes, void* stream);
 /* head backward: dW += dlogits^T pooled, db += sum dlogits, dpooled = dlogits @ W;
  * then gradient into the block buffer through GAP + ReLU + norm5 (mask epilogue semantics):
  * dz = dpooled/HW * [x*scale+shift>0]; S1,S2 += ...; g = e_scale*dz (written, not accumulated)   */

@@ -412,6 +412,28 @@ def test_head_loss_and_backward(dev):
     close(S2.cpu(), (dz_ref * (xs - cv(mu)) * cv(r)).sum((0, 2, 3)), rel=1e-4)
 
 
+@pytest.mark.parametrize("B,n", [(5, 10), (64, 100), (300, 7), (2, 130)])
+def test_softmax_cross_entropy_matches_torch(dev, B, n):
+    """cx_softmax_ce_fwd_bwd against F.cross_entropy (the CIFAR harness criterion, models/test_model.py:331): loss, per-sample terms,
+    gradient; the module form goes through autograd.  fp32: 1e-5."""
+    from chexpert_amd import ops
+    from chexpert_amd.cifar import CrossEntropyLoss
+    logits = (rnd(90 + B, (B, n), -6.0, 6.0)).requires_grad_(True)
+    tgt = torch.randint(0, n, (B,), generator=torch.Generator().manual_seed(n))
+    le = F.cross_entropy(logits, tgt, reduction="none")
+    le.mean().backward()
+    loss, lel, dl = torch.zeros(1, device=dev), torch.zeros(B, device=dev), torch.zeros(B, n, device=dev)
+    ops.softmax_ce_fwd_bwd(logits.detach().to(dev), tgt.to(dev), loss, lel, dl, 3.0)
+    assert abs(loss.item() - le.mean().item()) < 1e-5 * max(1.0, le.mean().item())
+    close(lel.cpu(), le.detach(), rel=1e-5, what="per-sample loss")
+    close(dl.cpu(), 3.0 * logits.grad, rel=1e-5, what="dlogits")
+    lg = logits.detach().to(dev).requires_grad_(True)
+    out = CrossEntropyLoss()(lg, tgt.to(dev))
+    (2.0 * out).backward()
+    assert abs(out.item() - le.mean().item()) < 1e-5 * max(1.0, le.mean().item())
+    close(lg.grad.cpu(), 2.0 * logits.grad, rel=1e-5, what="autograd gradient")
+
+
 def test_unpool_mask_and_affine2(dev):
     from chexpert_amd import ops
     B, H, W, Cn = 2, 8, 6, 256
