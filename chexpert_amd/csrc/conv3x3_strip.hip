@@ -445,6 +445,20 @@ constexpr int WP = 64;          // bytes per ring / strip pixel: 32 channels; ro
 // NG > 1 (small maps, one workgroup per CU): NG groups of three waves share one staged strip and split its 16-pixel
 // k-steps round-robin, so a step can be NG times longer (up to a whole image: more bytes in flight per barrier) while its
 // MFMA and staging phases shrink by NG; the groups' tiles meet in LDS before the atomics.
+#ifdef CX_STRIP_STAMPS
+// diagnostic build (scratch/stamps_strip.py): s_memtime sums per phase of the weight-gradient body, wave 0 of each workgroup
+__device__ unsigned long long strip_stamps[1024 * 8];
+__device__ __forceinline__ unsigned long long sstamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define SSTAMP(i) { const unsigned long long t_ = sstamp(); st_acc[i] += t_ - st_prev; st_prev = t_; }
+#else
+#define SSTAMP(i)
+#endif
 template <int NG, int NCHW>
 __device__ __forceinline__ void strip_wgrad_body(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
@@ -512,14 +526,16 @@ __device__ __forceinline__ void strip_wgrad_body(
   const char* __restrict__ xb = reinterpret_cast<const char*>(x);
   const char* __restrict__ gslb = reinterpret_cast<const char*>(gsl);
   const char* __restrict__ g2b = reinterpret_cast<const char*>(g2);
+  // (one chunk at a time: the step loop requests the next step's chunks between its multiplications)
+  auto issue_rows_i = [&](int i, uint32_t sx, uint32_t r_lo, uint32_t r_n) __attribute__((always_inline)) {
+    pv[i] = ((uint32_t)crow[i] - r_lo) < r_n;
+    pre[i] = *reinterpret_cast<const uint4*>(xb + (size_t)(pv[i] ? sx + vox[i] : 0u));
+  };
   auto issue_rows = [&](int b, int y0, int n) {
     const uint32_t sx = (uint32_t)((b * H + y0) * W) * (uint32_t)ldx * 2u;
     const uint32_t r_lo = (uint32_t)max(-y0, 0), r_n = (uint32_t)max(min(n, H - y0), 0) - r_lo;
 #pragma unroll
-    for (int i = 0; i < NCHW; ++i) {
-      pv[i] = ((uint32_t)crow[i] - r_lo) < r_n;
-      pre[i] = *reinterpret_cast<const uint4*>(xb + (size_t)(pv[i] ? sx + vox[i] : 0u));
-    }
+    for (int i = 0; i < NCHW; ++i) issue_rows_i(i, sx, r_lo, r_n);
   };
   auto write_rows = [&](int y0, int n) {
 #pragma unroll
@@ -536,17 +552,18 @@ __device__ __forceinline__ void strip_wgrad_body(
       }
     }
   };
+  auto issue_g_i = [&](int i, uint32_t sg, uint32_t sg2, uint32_t r_n) __attribute__((always_inline)) {
+    const bool nok = n0 + cc8[i] * 8 < N;          // chunk of 8 output channels inside the tensor
+    gv[i] = (uint32_t)crow[i] < r_n && nok;
+    pg[i] = *reinterpret_cast<const uint4*>(gslb + (size_t)(gv[i] ? sg + vog[i] : 0u));
+    if (g_affine2) pg2[i] = *reinterpret_cast<const uint4*>(g2b + (size_t)(gv[i] ? sg2 + vog2[i] : 0u));
+  };
   auto issue_g = [&](int b, int yc) {
     const uint32_t row0 = (uint32_t)((b * H + yc) * W);
     const uint32_t sg = row0 * (uint32_t)ldg * 2u, sg2 = row0 * (uint32_t)ldg2 * 2u;
     const uint32_t r_n = (uint32_t)max(min(R, H - yc), 0);
 #pragma unroll
-    for (int i = 0; i < NCHW; ++i) {
-      const bool nok = n0 + cc8[i] * 8 < N;          // chunk of 8 output channels inside the tensor
-      gv[i] = (uint32_t)crow[i] < r_n && nok;
-      pg[i] = *reinterpret_cast<const uint4*>(gslb + (size_t)(gv[i] ? sg + vog[i] : 0u));
-      if (g_affine2) pg2[i] = *reinterpret_cast<const uint4*>(g2b + (size_t)(gv[i] ? sg2 + vog2[i] : 0u));
-    }
+    for (int i = 0; i < NCHW; ++i) issue_g_i(i, sg, sg2, r_n);
   };
   auto write_g = [&]() {
 #pragma unroll
@@ -575,6 +592,9 @@ __device__ __forceinline__ void strip_wgrad_body(
   bool have_window = false;
   int prev_b = -1, prev_yc = 0;
 
+#ifdef CX_STRIP_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = sstamp();
+#endif
   for (int u = u0; u < u1; ++u) {
     const int b = u / g.spi, yc = (u - b * g.spi) * R;
     const bool cont = have_window && b == prev_b && yc == prev_yc + R;
@@ -586,22 +606,21 @@ __device__ __forceinline__ void strip_wgrad_body(
       issue_rows(b, yc + 1, R);
       issue_g(b, yc);
     }
+    SSTAMP(0)                         // restart: halo round trip
     write_rows(yc + 1, R);
     write_g();
+    SSTAMP(1)                         // wait for the requested rows + staging
     __syncthreads();
+    SSTAMP(2)                         // barrier 1
     const bool next_cont = (u + 1 < u1) && ((u + 1) / g.spi == b);
-    if (next_cont) {
-      issue_rows(b, yc + R + 1, R);
-      issue_g(b, yc + R);
-    }
+    SSTAMP(3)
     int slot0 = (yc - 1 - base_row) % (R + 2);
     if (slot0 < 0) slot0 += R + 2;
     const int ws = slot0 * P;
     // running byte offsets of this lane's two pixel rows in kernel row dy = wave
     int o0 = ((ws + lrow + wave * P + grp * 16) % Q) * WP;
     int o1 = ((ws + lrow + 4 + wave * P + grp * 16) % Q) * WP;
-#pragma unroll 2
-    for (int kk = grp; kk < nk; kk += NG) {
+    auto kstep = [&](int kk) __attribute__((always_inline)) {
       const char* gbase = gst + (kk * 16 + lrow) * WP + gcol;
       const bf16x8 af = tr2(gbase, gbase + 4 * WP);
 #pragma unroll
@@ -613,12 +632,41 @@ __device__ __forceinline__ void strip_wgrad_body(
       while (o0 >= QB) o0 -= QB;
       o1 += 16 * NG * WP;
       while (o1 >= QB) o1 -= QB;
+    };
+    int kk = grp;
+    if (next_cont) {
+      // the next step's rows are requested one chunk per k-step: requested in one burst ahead of the loop, the 12 waves spent
+      // ~2000 cycles a step queueing 72 KB at the CU's vector-memory port with the matrix pipe idle (scratch/stamps_strip.py)
+      const int yn = yc + R + 1;
+      const uint32_t sx = (uint32_t)((b * H + yn) * W) * (uint32_t)ldx * 2u;
+      const uint32_t r_lo = (uint32_t)max(-yn, 0), r_nx = (uint32_t)max(min(R, H - yn), 0) - r_lo;
+      const uint32_t row0 = (uint32_t)((b * H + yc + R) * W);
+      const uint32_t sg = row0 * (uint32_t)ldg * 2u, sg2 = row0 * (uint32_t)ldg2 * 2u;
+      const uint32_t r_ng = (uint32_t)max(min(R, H - (yc + R)), 0);
+#pragma unroll
+      for (int i = 0; i < NCHW; ++i) {
+        issue_rows_i(i, sx, r_lo, r_nx);
+        issue_g_i(i, sg, sg2, r_ng);
+        if (kk < nk) { kstep(kk); kk += NG; }
+      }
     }
+    for (; kk < nk; kk += NG) kstep(kk);
+#ifdef CX_STRIP_STAMPS
+    asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
+#endif
+    SSTAMP(4)                         // multiply
     __syncthreads();
+    SSTAMP(5)                         // barrier 2
     have_window = true;
     prev_b = b;
     prev_yc = yc;
   }
+#ifdef CX_STRIP_STAMPS
+  if (tid == 0 && wg < 1024) {
+    for (int i = 0; i < 6; ++i) strip_stamps[wg * 8 + i] = st_acc[i];
+    strip_stamps[wg * 8 + 6] = (unsigned long long)(u1 - u0);
+  }
+#endif
 
   // ---- transpose through LDS into OIHW order, then atomics over contiguous runs (288 floats per output channel)
   for (int round = 0; round < NG; ++round) {
@@ -818,6 +866,12 @@ int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   return slab ? cx_dw_reduce(p.dw, slab, wtotal, splits, st) : 0;
 }
 
+#ifdef CX_STRIP_STAMPS
+extern "C" int dbg_strip_stamps(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(strip_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 // ABI 8.  See StripBatch above; include/chexpert_hip.h has the contract.
 int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* stream) {
   if (!geo || !items) return CX_EINVAL;
@@ -838,14 +892,17 @@ int cx_conv3x3_wgrad_batch(const CxWgrad* geo, const CxWgradBatch* items, void* 
   // partial tiles (147 KB per split and layer) stay a small fraction of the operands
   // (scratch/bench_w2batch.py, 256 images: 40x40 maps 104 / 81 / 84 / 87 us per layer with 8 / 16 / 32 / 64 splits -- 97 per layer
   // launched one by one --, 20x20 22.8 / 23.8 / 25.8 / 30.1 (33.0), 10x10 12.0 / 13.1 / 14.7 / 20.1 (21.3))
+  // (two half-size workgroups per CU -- 384 threads, half the rows per step -- measured 44 % SLOWER on the 40x40 maps, 1194 against
+  // 828 us for 12 layers: the kernel is bound by its phases, not by bytes in flight; scratch/stamps_strip.py has the shares)
+  constexpr int nthr = 768;
   int target = env_splits > 0 ? env_splits : (p.H * p.W > 400 ? 16 : 8);
-  int flat = NCHW4 * 768 / (p.W * 4) * (p.W + 2);
+  int flat = NCHW4 * nthr / (p.W * 4) * (p.W + 2);
   if (flat > 880) flat = 880;
   StripGeo g = make_geo(p.B, p.H, p.W, target, 1, flat);
   const int nk = (g.R * g.P + 15) / 16;
   size_t smem = 160 * 4 + (size_t)(g.Q + 2) * WP + (size_t)nk * 16 * WP;
   if (smem < 160 * 4 + 32 * 288 * 4) smem = 160 * 4 + 32 * 288 * 4;
-  if (!(g.R * p.W * 4 <= NCHW4 * 768 && 2 * p.W * 4 <= NCHW4 * 768 && g.Q >= 64 && smem <= 150 * 1024)) return CX_EUNSUPPORTED;
+  if (!(g.R * p.W * 4 <= NCHW4 * nthr && 2 * p.W * 4 <= NCHW4 * nthr && g.Q >= 64 && smem <= 150 * 1024)) return CX_EUNSUPPORTED;
   const int total = g.B * g.spi;
   const int splits = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   const long long wtotal = (long long)p.N * p.K * 9;
