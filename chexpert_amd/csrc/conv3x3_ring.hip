@@ -307,6 +307,20 @@ constexpr int DW_BYTES = DW_ROWS * GP;
 constexpr int EC_BYTES = 5 * 128 * 4 + 3 * 32 * 4;   // epilogue vectors [5][128] + AFFINE2 vectors [3][32]
 constexpr int MAX_ITEMS = 2;             // work items per wave and step
 
+#ifdef CX_RING_STAMPS
+// diagnostic build (scratch/stamps_ring.py): s_memtime sums per phase of the input-gradient kernel, wave 0 of each workgroup
+__device__ unsigned long long ring_stamps[1024 * 8];
+__device__ __forceinline__ unsigned long long rstamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define RSTAMP(i) { const unsigned long long t_ = rstamp(); st_acc[i] += t_ - st_prev; st_prev = t_; }
+#else
+#define RSTAMP(i)
+#endif
 template <int NCH>
 __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
@@ -407,6 +421,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
   const int nsub = (R * P + 31) / 32;                 // <= 4 * MAX_ITEMS
   const char* wbase = wl + (h2 * 64 + lrow) * GP + lh * 16;
 
+#ifdef CX_RING_STAMPS
+  unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = rstamp();
+#endif
   for (int u = u0; u < u1; ++u) {
     const int b = div_spi(g, u), yc = (u - b * g.spi) * R;
     if (u == u0 || yc == 0) {
@@ -417,10 +434,14 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
       write_rows(b, yc, 1);
       issue_rows(b, yc + 1, R);
     }
+    RSTAMP(0)
     write_rows(b, yc + 1, R);
+    RSTAMP(1)
     __syncthreads();                                   // the window of this step is complete
+    RSTAMP(2)
     const bool next_cont = (u + 1 < u1) && (div_spi(g, u + 1) == b);
     if (next_cont) issue_rows(b, yc + R + 1, R);
+    RSTAMP(3)
     int slot0 = (yc - 1 - base_row) % (R + 2);
     if (slot0 < 0) slot0 += R + 2;
     const int ws = slot0 * P;
@@ -477,6 +498,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
               acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][ks][j], fb[t & 1][ks], acc[j], 0, 0, 0);   // D[channel][pixel]
           __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef CX_RING_STAMPS
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]));
+#endif
+        RSTAMP(4)
         bf16* yrow = y + (size_t)poff * ldy;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -521,10 +546,18 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
             }
             if (pok) *reinterpret_cast<uint4*>(yrow + n) = o.u;
           }
+        RSTAMP(5)
       }
     }
     __syncthreads();                                   // every wave is done with the oldest rows of the ring
+    RSTAMP(6)
   }
+#ifdef CX_RING_STAMPS
+  if (tid == 0 && blockIdx.x < 1024) {
+    for (int i = 0; i < 7; ++i) ring_stamps[blockIdx.x * 8 + i] = st_acc[i];
+    ring_stamps[blockIdx.x * 8 + 7] = (unsigned long long)(u1 - u0);
+  }
+#endif
 
   {
     float* scratch = reinterpret_cast<float*>(wl);               // the weight slices are no longer read (ecoef stays)
@@ -923,3 +956,9 @@ int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
   if (nx <= 3) return launch_ring_wgrad<3, 2>(p, st, g, smem);
   return launch_ring_wgrad<5, 2>(p, st, g, smem);
 }
+
+#ifdef CX_RING_STAMPS
+extern "C" int dbg_ring_stamps(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ring_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -25,5 +25,5 @@ for hw, n in ((40, 12), (20, 24), (10, 16)):
     a = a[a[:, 6] > 0]
     per = a[:, :6] / a[:, 6:7]
     med = np.median(per, 0)
-    print("%dx%d: %d workgroups seen, steps/wg %.0f, s_memtime ticks (100 MHz) per step %.1f: " % (hw, hw, len(a), np.median(a[:, 6]), med.sum()) +
+    print("%dx%d: %d workgroups seen, steps/wg %.0f, core clocks (s_memtime) per step %.1f: " % (hw, hw, len(a), np.median(a[:, 6]), med.sum()) +
           ", ".join("%s %.1f" % (nm, v) for nm, v in zip(names, med)), flush=True)
