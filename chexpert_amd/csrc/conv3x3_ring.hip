@@ -321,12 +321,7 @@ __device__ __forceinline__ unsigned long long rstamp() {
 #else
 #define RSTAMP(i)
 #endif
-// QUART: a work item is (sub-tile, QUARTER of the output channels) = 18 MFMAs, four items per wave and step, wave w always takes
-// quarter w & 3.  Half the statistic accumulators, accumulator tile and weight fragments of the half-channel form: the registers
-// that frees hold the mask source of ALL FOUR items of a step, requested one step ahead (each set is requested again for the next
-// step as soon as its item is done) -- the half-channel form requests an item's mask source at the head of the item and its
-// epilogue waits ~3000 cycles for it on the 40x40 / 20x20 maps (scratch/stamps_ring.py).
-template <int NCH, bool QUART>
+template <int NCH>
 __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
     const float* __restrict__ gb, const float* __restrict__ gc, const bf16* __restrict__ wpk, const bf16* __restrict__ ex, int ldex,
@@ -416,33 +411,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     }
   };
 
-  constexpr int NJ = QUART ? 1 : 2;                   // 32-channel blocks per work item
-  float s1[NJ][2][8], s2[NJ][2][8];
+  float s1[2][2][8], s2[2][2][8];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
       for (int e = 0; e < 8; ++e) s1[j][cc][e] = s2[j][cc][e] = 0.f;
   const int nsub = (R * P + 31) / 32;                 // <= 4 * MAX_ITEMS
-  const int cb0 = QUART ? (wave & 3) : 2 * h2;        // first 32-channel block of this wave
-  const char* wbase = wl + (cb0 * 32 + lrow) * GP + lh * 16;
-  // QUART: mask source of the wave's four items (sub-tiles sp, sp + 2, sp + 4, sp + 6), two 16-B vectors each
-  const int sp = wave >> 2;
-  U128 xq[QUART ? 4 : 1][2];
-  auto issue_q = [&](U128 (&dst)[2], int b, int yc, int s) __attribute__((always_inline)) {
-    const int m = s * 32 + lrow;
-    const int oy = (int)__umulhi((unsigned)m, g.mP), ox = m - oy * P;
-    const int poff = (b * H + min(yc + oy, H - 1)) * W + min(ox, W - 1);
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-      dst[cc].u = *reinterpret_cast<const uint4*>(ex + (size_t)poff * ldex + cb0 * 32 + 8 * (2 * cc + lh));
-  };
-  if (QUART && u0 < u1) {
-    const int b0 = div_spi(g, u0), y0 = (u0 - b0 * g.spi) * R;
-#pragma unroll
-    for (int t = 0; t < (QUART ? 4 : 1); ++t) issue_q(xq[t], b0, y0, sp + 2 * t);
-  }
+  const char* wbase = wl + (h2 * 64 + lrow) * GP + lh * 16;
 
 #ifdef CX_RING_STAMPS
   unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = rstamp();
@@ -463,108 +440,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     __syncthreads();                                   // the window of this step is complete
     RSTAMP(2)
     const bool next_cont = (u + 1 < u1) && (div_spi(g, u + 1) == b);
-    // (always requested -- no rows when the next step starts another image: a request under a branch left the row registers
-    // behind a copy, and the copy behind a vmcnt wait for the rows just requested)
-    issue_rows(b, next_cont ? yc + R + 1 : 0, next_cont ? R : 0);
+    if (next_cont) issue_rows(b, yc + R + 1, R);
     RSTAMP(3)
     int slot0 = (yc - 1 - base_row) % (R + 2);
     if (slot0 < 0) slot0 += R + 2;
     const int ws = slot0 * P;
 
-    if constexpr (QUART) {
-      // next step of this workgroup (the last step requests its own rows again: harmless)
-      const int un = min(u + 1, u1 - 1);
-      const int bn = div_spi(g, un), ycn = (un - bn * g.spi) * R;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int s = sp + 2 * t;
-        if (s < nsub) {
-          const int m = s * 32 + lrow;
-          const int oy = (int)__umulhi((unsigned)m, g.mP), ox = m - oy * P;
-          const int yy = yc + oy;
-          const bool pok = m < R * P && ox < W && yy < H;
-          const int poff = (b * H + min(yy, H - 1)) * W + min(ox, W - 1);
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          const int pix = min(m, R * P - 1);
-          const char* ap0 = ring + wrapq(wrapq(ws + pix, Q), Q) * GP + lh * 16;
-          const char* ap1 = ring + wrapq(wrapq(ws + pix + P, Q), Q) * GP + lh * 16;
-          const char* ap2 = ring + wrapq(wrapq(ws + pix + 2 * P, Q), Q) * GP + lh * 16;
-          // two MFMAs per tap: the fragment reads run two taps ahead (three register sets)
-          bf16x8 fb[3][2], fa[3][2];
-          auto load_tap = [&](int tp, bf16x8 (&B)[2], bf16x8 (&A)[2]) __attribute__((always_inline)) {
-            const int dy = tp / 3, dx = tp - dy * 3;
-            const char* ap = (dy == 0 ? ap0 : dy == 1 ? ap1 : ap2) + dx * GP;
-            const char* wp = wbase + tp * 128 * GP;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-              B[ks] = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
-              A[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 32);
-            }
-          };
-          load_tap(0, fb[0], fa[0]);
-          load_tap(1, fb[1], fa[1]);
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
-            if (tp + 2 < 9) load_tap(tp + 2, fb[(tp + 2) % 3], fa[(tp + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tp % 3][ks], fb[tp % 3][ks], acc, 0, 0, 0);   // D[channel][pixel]
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#ifdef CX_RING_STAMPS
-          asm volatile("" ::"v"(acc[0]));
-#endif
-          RSTAMP(4)
-          bf16* yrow = y + (size_t)poff * ldy;
-#pragma unroll
-          for (int cc = 0; cc < 2; ++cc) {
-            const int n = cb0 * 32 + 8 * (2 * cc + lh);
-            float v[8];
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * cc + r4]), __float_as_uint(acc[8 * cc + 4 + r4]),
-                                                               false, false);
-              v[r4] = __uint_as_float(sw[0]);
-              v[4 + r4] = __uint_as_float(sw[1]);
-            }
-            float xf[8], dz[8];
-            {
-              asm volatile("" ::: "memory");
-              const float4 a0 = *reinterpret_cast<const float4*>(ecoef + n), a1 = *reinterpret_cast<const float4*>(ecoef + n + 4);
-              const float4 b0 = *reinterpret_cast<const float4*>(ecoef + 128 + n), b1 = *reinterpret_cast<const float4*>(ecoef + 128 + n + 4);
-              const float esc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-              const float esh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-              const uint32_t xw[4] = {xq[t][cc].u.x, xq[t][cc].u.y, xq[t][cc].u.z, xq[t][cc].u.w};
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                xf[e] = (e & 1) ? cx_bf_hi(xw[e >> 1]) : cx_bf_lo(xw[e >> 1]);
-                dz[e] = (pok && fmaf(xf[e], esc[e], esh[e]) > 0.f) ? v[e] : 0.f;
-                s1[0][cc][e] += dz[e];
-              }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s2[0][cc][e] = fmaf(dz[e], xf[e], s2[0][cc][e]);
-            U128 o;
-            {
-              asm volatile("" ::: "memory");
-              const float4 e0 = *reinterpret_cast<const float4*>(ecoef + 512 + n), e1 = *reinterpret_cast<const float4*>(ecoef + 512 + n + 4);
-              const float esl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-              o.u = make_uint4(cx_packbf(esl[0] * dz[0], esl[1] * dz[1]), cx_packbf(esl[2] * dz[2], esl[3] * dz[3]),
-                               cx_packbf(esl[4] * dz[4], esl[5] * dz[5]), cx_packbf(esl[6] * dz[6], esl[7] * dz[7]));
-            }
-            if (pok) *reinterpret_cast<uint4*>(yrow + n) = o.u;
-          }
-          RSTAMP(5)
-        }
-        // the same item of the next step: a whole step of lead.  Outside the validity branch: the compiler counts the requests
-        // younger than a register's own on EVERY path (vmcnt is one in-order counter), and a path that skips an item without
-        // requesting made every mask wait a vmcnt(0) -- a wait for the request made one item earlier.
-        issue_q(xq[t], bn, ycn, s);
-      }
-    } else {
 #pragma unroll 1
     for (int t = 0; t < MAX_ITEMS; ++t) {
       const int s = (wave >> 1) + 4 * t;
@@ -668,7 +549,6 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
         RSTAMP(5)
       }
     }
-    }
     __syncthreads();                                   // every wave is done with the oldest rows of the ring
     RSTAMP(6)
   }
@@ -683,7 +563,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     float* scratch = reinterpret_cast<float*>(wl);               // the weight slices are no longer read (ecoef stays)
     wg_stat_begin<NT / 64>(scratch, 128, tid, NT);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < 2; ++j) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc)
@@ -694,7 +574,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
           if (lrow == 8 * cc + e) { t1 = a; t2 = c; }
         }
       if (lrow < 16) {
-        const int n = (cb0 + j) * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
+        const int n = (2 * h2 + j) * 32 + 8 * (2 * (lrow >> 3) + lh) + (lrow & 7);
         wg_stat_put(scratch, 128, wave, n, t1, ecoef[384 + n] * (t2 - ecoef[256 + n] * t1));
       }
     }
@@ -702,20 +582,20 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
   }
 }
 
-template <int NCH, bool QUART>
+template <int NCH>
 int launch_ring_dgrad(const CxConv& p, hipStream_t st, const RingGeo& g) {
   const size_t smem = EC_BYTES + DW_BYTES + (size_t)(g.Q + 2) * GP;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_dgrad_kernel<NCH, QUART>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_dgrad_kernel<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr = true;
   }
   const int total = g.B * g.spi;
   const int grid = (total + g.steps_per_wg - 1) / g.steps_per_wg;
   if (const int e = stat_rows_check(p, grid)) return e;
-  CX_KTAG("conv3x3_ring_dgrad_kernel<%d, %d>", NCH, (int)QUART);
-  hipLaunchKernelGGL((conv3x3_ring_dgrad_kernel<NCH, QUART>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2,
+  CX_KTAG("conv3x3_ring_dgrad_kernel<%d>", NCH);
+  hipLaunchKernelGGL((conv3x3_ring_dgrad_kernel<NCH>), dim3(grid), dim3(NT), smem, st, (const bf16*)p.x, p.ldx, (const bf16*)p.x2,
                      p.ldx2, p.pa, p.pb, p.pc, (const bf16*)p.w, (const bf16*)p.ex, p.ldex, p.e_sc, p.e_sh, p.e_mu, p.e_r, p.e_scale,
                      (bf16*)p.y, p.ldy, p.stat_sum, p.stat_sq, p.stat_replicas, p.stat_rstride, p.stat_det, (bf16*)p.pro_out, p.ldpo, g);
   cx_tl_pro_out = p.pro_out ? 1 : 0;
@@ -1027,9 +907,7 @@ int cx_try_ring_dgrad(const CxConv& p, hipStream_t st, bool* handled) {
   if (spw < 1) spw = 1;
   g.steps_per_wg = spw;
   *handled = true;
-  static const int env_q = [] { const char* e = getenv("CX_RING_DGRAD_QUART"); return e ? atoi(e) : 1; }();
-  if (env_q) return need <= 1 ? launch_ring_dgrad<1, true>(p, st, g) : launch_ring_dgrad<2, true>(p, st, g);
-  return need <= 1 ? launch_ring_dgrad<1, false>(p, st, g) : launch_ring_dgrad<2, false>(p, st, g);
+  return need <= 1 ? launch_ring_dgrad<1>(p, st, g) : launch_ring_dgrad<2>(p, st, g);
 }
 
 int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {

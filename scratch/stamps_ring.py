@@ -7,7 +7,7 @@ shutil.copy("scratch/libstamp_ring.so", _lib.LIB_PATH)
 from chexpert_amd import ops
 dev = torch.device('cuda:0'); bf = torch.bfloat16; B = 256
 names = ["restart", "wait+stage", "barrier1", "issue", "items:multiply", "items:epilogue", "barrier2"]
-for hw, ctot in ((80, 256), (40, 512), (20, 1024), (10, 1024)):
+for hw, ctot in ((80, 256), (40, 512), (20, 1024)):
     z1 = (torch.randn(B, hw, hw, 128, device=dev) * 0.5).to(bf)
     buf = (torch.randn(B, hw, hw, ctot, device=dev) * 0.5).to(bf)
     gbuf = (torch.randn(B, hw, hw, ctot, device=dev) * 0.5).to(bf)
