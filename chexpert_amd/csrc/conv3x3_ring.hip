@@ -50,6 +50,21 @@ __device__ __forceinline__ float half_sum(float v) {      // sum over the 32 lan
   return v + __shfl_xor(v, 16);
 }
 
+#ifdef CX_RING_STAMPS
+// diagnostic build (scratch/stamps_ring.py): s_memtime sums per phase of the input-gradient kernel, wave 0 of each workgroup
+__device__ unsigned long long ring_stamps[1024 * 8];
+__device__ unsigned long long ring_fwd_stamps[1024 * 8];
+__device__ __forceinline__ unsigned long long rstamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define RSTAMP(i) { const unsigned long long t_ = rstamp(); st_acc[i] += t_ - st_prev; st_prev = t_; }
+#else
+#define RSTAMP(i)
+#endif
 template <int NCH, int DEPTH>
 __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __restrict__ x, int ldx, const float* __restrict__ sc,
                                                                 const float* __restrict__ sh, const bf16* __restrict__ wpk,
@@ -151,6 +166,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
     for (int j = 0; j < 8; ++j) s1[cc][j] = s2[cc][j] = 0.f;
   const int nsub = (R * P + 31) / 32;
   const char* wbase = wl + lrow * XP + lh * 16;
+#ifdef CX_RING_STAMPS
+  unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = rstamp(), st_steps = 0;
+#endif
 
   auto step = [&](int u, auto KI) __attribute__((always_inline)) {
     constexpr int k = decltype(KI)::value;
@@ -158,9 +176,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
     bool (&cv)[NCH] = pv[k];
     const int bv = div_spi(g, u), yc = (u - bv * g.spi) * R;
     const int b = bv >> g.ntx_shift, x0 = (bv - (b << g.ntx_shift)) * Wt;
+    RSTAMP(0)                                          // (between steps: restart of an image, loop overhead)
     write_rows(cur, cv, yc + 1, R);
+    RSTAMP(1)
     __syncthreads();                                   // the window of this step is complete
+    RSTAMP(2)
     issue_step(cur, cv, u + DEPTH);                    // in flight under the MFMAs of this and the next DEPTH-1 steps
+    RSTAMP(3)
     int slot0 = (yc - 1 - base_row) % (R + 2);
     if (slot0 < 0) slot0 += R + 2;
     const int ws = slot0 * P;
@@ -202,6 +224,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[gi % 3][j], fb[gi % 3][j], acc, 0, 0, 0);   // D[row = out channel][col = pixel]
         __builtin_amdgcn_sched_barrier(0);
       }
+#ifdef CX_RING_STAMPS
+      asm volatile("" ::"v"(acc[0]));
+#endif
+      RSTAMP(4)
       const int oy = (int)__umulhi((unsigned)m, g.mP), ox = m - oy * P;      // m / P without the ~20-instruction division
       const int yy = yc + oy;
       const bool valid = m < R * P && ox < Wt && x0 + ox < W && yy < H;
@@ -222,8 +248,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
         o.u = cx_pack8_stats(t, valid, true, s1[cc], s2[cc]);
         if (valid) *reinterpret_cast<uint4*>(yrow + 8 * (2 * cc + lh)) = o.u;
       }
+      RSTAMP(5)
     }
     __syncthreads();                                   // every wave is done with the oldest rows of the ring
+    RSTAMP(6)
+#ifdef CX_RING_STAMPS
+    ++st_steps;
+#endif
   };
 
   // One image (or the part of it in this workgroup's range) at a time: the window rows yc-1, yc of its first step are built
@@ -256,6 +287,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_ring_fwd_kernel(const bf16* __r
   }
   }
 
+#ifdef CX_RING_STAMPS
+  if (tid == 0 && blockIdx.x < 1024) {
+    for (int i = 0; i < 7; ++i) ring_fwd_stamps[blockIdx.x * 8 + i] = st_acc[i];
+    ring_fwd_stamps[blockIdx.x * 8 + 7] = st_steps;
+  }
+#endif
   if (stat_sum) {
     float* scratch = reinterpret_cast<float*>(wl);               // the weight slices are no longer read
     wg_stat_begin<NT / 64>(scratch, 32, tid, NT);
@@ -307,20 +344,6 @@ constexpr int DW_BYTES = DW_ROWS * GP;
 constexpr int EC_BYTES = 5 * 128 * 4 + 3 * 32 * 4;   // epilogue vectors [5][128] + AFFINE2 vectors [3][32]
 constexpr int MAX_ITEMS = 2;             // work items per wave and step
 
-#ifdef CX_RING_STAMPS
-// diagnostic build (scratch/stamps_ring.py): s_memtime sums per phase of the input-gradient kernel, wave 0 of each workgroup
-__device__ unsigned long long ring_stamps[1024 * 8];
-__device__ __forceinline__ unsigned long long rstamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define RSTAMP(i) { const unsigned long long t_ = rstamp(); st_acc[i] += t_ - st_prev; st_prev = t_; }
-#else
-#define RSTAMP(i)
-#endif
 template <int NCH>
 __global__ __launch_bounds__(NT, 1) void conv3x3_ring_dgrad_kernel(
     const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2, const float* __restrict__ ga,
@@ -960,5 +983,8 @@ int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
 #ifdef CX_RING_STAMPS
 extern "C" int dbg_ring_stamps(unsigned long long* host, int n_words) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ring_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int dbg_ring_fwd_stamps(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ring_fwd_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
 }
 #endif
