@@ -67,6 +67,9 @@ def build_parser():
     p.add_argument("--jitter", action="store_true", help="brightness / contrast jitter +-0.25 on the uint8 image (GPU)")
     p.add_argument("--num_workers", type=int, default=int(os.environ.get("CHEXPERT_NUM_WORKERS", "16")), help="decode / crop worker processes of the training loader (chexpert.py:77: "
                    "16); 0 = in-process")
+    p.add_argument("--cache_decoded", type=float, default=float(os.environ.get("CHEXPERT_CACHE_GB", "0")), metavar="GB",
+                   help="keep the decoded / resized / cropped training images in host shared memory (up to GB gigabytes; the "
+                        "reference's transform has no random step, so epochs after the first skip the JPEG decode)")
     return p
 
 
@@ -263,6 +266,8 @@ def main(argv=None):
         if not args.data_path:
             raise RuntimeError("pass --data_path <folder holding CheXpert-v1.0-small> or --synthetic N (no download here)")
         train_ds = ChexpertCSV(args.data_path, "train", args.resize, mini_data=args.mini_data)
+        if args.cache_decoded > 0 and not train_ds.enable_decoded_cache(int(args.cache_decoded * 2 ** 30)):
+            print("decoded-image cache off: %d images of %d^2 bytes exceed --cache_decoded %.1f GB" % (len(train_ds), train_ds.crop, args.cache_decoded))
         valid_ds = ChexpertCSV(args.data_path, "valid", args.resize, mini_data=args.mini_data)
     train_loader = None
     if args.train:
@@ -358,7 +363,8 @@ def main(argv=None):
             torch.cuda.synchronize()
             if rank == 0:        # input pipeline + step, end to end (the figure to hold against bench.py's device-resident rate)
                 print(json.dumps({"epoch": epoch, "images_per_sec": round(len(idx) * world / (time.perf_counter() - t_epoch), 1),
-                                  "loader_workers": args.num_workers}), flush=True)
+                                  "loader_workers": args.num_workers,
+                                  "decoded_cache_fill": round(train_ds.cache_fill(), 3) if hasattr(train_ds, "cache_fill") else None}), flush=True)
             run_eval("eval_results_step_%d" % args.step)
         train_loader.close()
     if args.evaluate_single_model:

@@ -78,11 +78,36 @@ class ChexpertCSV(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.data)
 
+    def enable_decoded_cache(self, max_bytes=None):
+        """Keep every decoded crop in ONE shared-memory uint8 table (N, 1, S, S): the reference's transform chain has no random
+        step (Resize + CenterCrop, chexpert.py:67-69), so an image decodes to the same bytes every epoch -- from the second epoch
+        on an item is a 100 KB copy instead of a JPEG decode + bilinear resize, and the loader's worker processes (which share the
+        table: fork, or torch's shared-memory handles under spawn) stop bounding the GPU.  CheXpert-small at 320x320 is 22.9 GB.
+        Returns False (cache off) when the table would exceed `max_bytes`."""
+        n, c = len(self), self.crop
+        need = n * c * c
+        if max_bytes is not None and need > max_bytes:
+            return False
+        self._cache = torch.empty((n, 1, c, c), dtype=torch.uint8).share_memory_()
+        self._have = torch.zeros(n, dtype=torch.uint8).share_memory_()      # 1 once row i of the table is complete
+        return True
+
+    def cache_fill(self):
+        """fraction of the table filled so far"""
+        return 0.0 if getattr(self, "_have", None) is None else float(self._have.float().mean())
+
     def __getitem__(self, i):
+        have = getattr(self, "_have", None)
+        if have is not None and have[i]:
+            return self._cache[i], self.targets[i], int(self.data.index[i])
         path = self.data.iloc[i, 0]                                     # 'Path' is the first column
         with Image.open(os.path.join(self.root, path)) as img:
             px = resize_center_crop(img, self.resize, self.crop)
-        return torch.from_numpy(px.copy()).unsqueeze(0), self.targets[i], int(self.data.index[i])
+        x = torch.from_numpy(px.copy()).unsqueeze(0)
+        if have is not None:
+            self._cache[i].copy_(x)                                     # (two workers decoding the same row write the same bytes)
+            have[i] = 1
+        return x, self.targets[i], int(self.data.index[i])
 
 
 def extract_patient_ids(dataset, idxs):

@@ -235,6 +235,21 @@ def bench(workers=(1, 4, 8, 16), n=512, batch=256, resize=320, seconds=6.0):
                     break
             out[w] = seen / (time.perf_counter() - t0)
             ld.close()
+        # the same loader over the decoded-image cache (ChexpertCSV.enable_decoded_cache): one pass fills the table, then timed
+        ds = ChexpertCSV(root, "train", resize=resize)
+        ds.enable_decoded_cache()
+        for w in (workers[-1], 4):
+            ld = RingLoader(ds, batch, num_workers=w, slots=4)
+            for _ in ld.batches(list(range(len(ds)))):
+                pass
+            idx = list(range(len(ds))) * 256
+            t0, seen = time.perf_counter(), 0
+            for x, t, i in ld.batches(idx):
+                seen += x.shape[0]
+                if time.perf_counter() - t0 > seconds:
+                    break
+            out["cached_%d" % w] = seen / (time.perf_counter() - t0)
+            ld.close()
     return out
 
 
@@ -248,4 +263,5 @@ if __name__ == "__main__":
     if a.bench:
         r = bench(tuple(int(w) for w in a.workers.split(",")))
         print(json.dumps({"metric": "decoded+resized+cropped images/sec (PIL, 390x320 JPEG -> 320x320 uint8)", "host_cores": os.cpu_count(),
-                          "by_workers": {str(k): round(v, 1) for k, v in r.items()}}))
+                          "by_workers": {str(k): round(v, 1) for k, v in r.items() if not str(k).startswith("cached")},
+                          "decoded_cache_by_workers": {str(k)[7:]: round(v, 1) for k, v in r.items() if str(k).startswith("cached")}}))

@@ -468,3 +468,27 @@ def test_dataset_logic_against_reference_fixture(tmp_path):
     pd.DataFrame({"Path": [r[0] for r in rec["valid_rows"][:5]]}).to_csv(tcsv, index=False)
     te = ChexpertCSV(str(tcsv), "test")
     assert len(te) == want["test_len"] and te.targets.tolist() == want["test_labels"]
+
+
+def test_decoded_image_cache_returns_the_same_bytes_without_decoding_again(tmp_path, monkeypatch):
+    """ChexpertCSV.enable_decoded_cache (the reference's transform chain, chexpert.py:67-69, has no random step): the second pass
+    over the data hands out the first pass's bytes and never opens a file; worker processes fill and read the one shared table."""
+    from chexpert_amd import data, loader
+    root = str(tmp_path)
+    loader.make_jpeg_folder(root, n=12, w=98, h=80)
+    ref = data.ChexpertCSV(root, "train", resize=64)
+    want = torch.stack([ref[i][0] for i in range(len(ref))])
+    ds = data.ChexpertCSV(root, "train", resize=64)
+    assert not ds.enable_decoded_cache(max_bytes=1000) and ds.cache_fill() == 0.0
+    assert ds.enable_decoded_cache(max_bytes=1 << 20)
+    ld = loader.RingLoader(ds, 5, num_workers=2, slots=2)
+    try:
+        got = torch.cat([x for x, _, _ in ld.batches(list(range(len(ds))))])
+        assert torch.equal(got, want) and ds.cache_fill() == 1.0
+        calls = []
+        monkeypatch.setattr(data, "resize_center_crop", lambda *a, **k: calls.append(1))      # (in this process)
+        assert torch.equal(torch.stack([ds[i][0] for i in range(len(ds))]), want) and not calls
+        got2 = torch.cat([x for x, _, _ in ld.batches(list(range(len(ds))))])               # workers: from the table they share
+        assert torch.equal(got2, want)
+    finally:
+        ld.close()
