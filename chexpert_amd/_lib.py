@@ -188,6 +188,10 @@ def lib():
             raise RuntimeError(
                 "chexpert_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        # torch first: its wheel carries its own libamdhip64 / libhsa-runtime64.  Loaded after this library (whose DT_NEEDED then
+        # resolves to /opt/rocm's copies) the process holds TWO HIP runtimes and every launch from here fails with "no
+        # ROCm-capable device" -- build() followed by smoke() in one process did exactly that.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
