@@ -492,3 +492,17 @@ def test_decoded_image_cache_returns_the_same_bytes_without_decoding_again(tmp_p
         assert torch.equal(got2, want)
     finally:
         ld.close()
+
+
+def test_library_and_torch_share_one_hip_runtime():
+    """Loading libchexpert_hip.so before torch pulled /opt/rocm's libamdhip64 in beside the copy inside the torch wheel: two HIP
+    runtimes in one process, and every launch from the library then failed with "no ROCm-capable device" (build() followed by
+    smoke() did that).  `_lib.lib()` imports torch first; a fresh interpreter that loads the library first must map ONE runtime."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from chexpert_amd import _lib\n_lib.lib()\nimport torch\n"
+            "print(len(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
