@@ -322,12 +322,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int ylo = dy == 2 ? 1 : 0, yhi = dy == 0 ? g.H - 2 : g.H - 1;      // image rows of the strip that are this dy's neighbours
 
   const int q16 = tid & 15, r32 = tid >> 4;             // chunk column, row (+ 32 i) of both images
+  // partial last N tile (N a multiple of 8: the 3x3 branches of the attention-augmented layers): this thread's dZ chunk lies past N ->
+  // it requests offset 0 and stages zeros, and the epilogue stores no row past N
+  const bool nok = n0 + q16 * 8 < p.N;
+  const uint32_t nmask = nok ? 0xffffffffu : 0u;
+  const int ncoef = nok ? n0 + q16 * 8 : 0;
   float ga[8], gb[8], gc[8], pa[8], pb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    ga[j] = GPRO == CX_PRO_AFFINE2 ? p.ga[n0 + q16 * 8 + j] : 1.f;
-    gb[j] = GPRO == CX_PRO_AFFINE2 ? p.gb[n0 + q16 * 8 + j] : 0.f;
-    gc[j] = GPRO == CX_PRO_AFFINE2 ? p.gc[n0 + q16 * 8 + j] : 0.f;
+    ga[j] = GPRO == CX_PRO_AFFINE2 ? p.ga[ncoef + j] : 1.f;
+    gb[j] = GPRO == CX_PRO_AFFINE2 ? p.gb[ncoef + j] : 0.f;
+    gc[j] = GPRO == CX_PRO_AFFINE2 ? p.gc[ncoef + j] : 0.f;
     pa[j] = XPRO == CX_PRO_AFFINE_RELU ? p.pa[c0 + q16 * 8 + j] : 1.f;
     pb[j] = XPRO == CX_PRO_AFFINE_RELU ? p.pb[c0 + q16 * 8 + j] : 0.f;
   }
@@ -364,8 +369,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto issue_g = [&](Regs& R, int i, int t) __attribute__((always_inline)) {
     const uint32_t e = tab[(t % 3) * W3_TAB + r32 + 32 * i];
     const uint32_t m = (uint32_t)((int)e >> 31), pix = e & 0x7fffffffu;
-    R.g[i] = ld16(Gb, (__umul24(pix, ldg2b) + gcol) & m);
-    if (GPRO == CX_PRO_AFFINE2) R.g2[i] = ld16(G2b, (__umul24(pix, ldg22b) + gcol) & m);
+    R.g[i] = ld16(Gb, (__umul24(pix, ldg2b) + gcol) & m & nmask);
+    if (GPRO == CX_PRO_AFFINE2) R.g2[i] = ld16(G2b, (__umul24(pix, ldg22b) + gcol) & m & nmask);
   };
   auto issue_x = [&](int i, int t) __attribute__((always_inline)) {
     const uint32_t e = tab[(t % 3) * W3_TAB + 64 + r32 + 32 * i];
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     fmaf(bf_hi(gw), ga[2 * j + 1], fmaf(bf_hi(y), gb[2 * j + 1], gc[2 * j + 1])));
     }
     if (j == 3) {
-      o &= (uint32_t)((int)tab[(t % 3) * W3_TAB + r32 + 32 * i] >> 31);
+      o &= (uint32_t)((int)tab[(t % 3) * W3_TAB + r32 + 32 * i] >> 31) & nmask;
       *reinterpret_cast<u32x4*>(Gt + (r32 + 32 * i) * W3_GP + q16 * 16) = o;
     }
   };
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wa * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        slab[((size_t)split * 9 + dy * 3 + dx) * nk + (size_t)n * p.K + c] = acc[i][dx][r];
+        if (n < p.N) slab[((size_t)split * 9 + dy * 3 + dx) * nk + (size_t)n * p.K + c] = acc[i][dx][r];
       }
 }
 
@@ -542,7 +547,7 @@ int launch3(const CxWgrad& p, hipStream_t st) {
   g.TP = p.B * p.H * g.P;
   g.mP = 0xffffffffu / (uint32_t)g.P + 1u;
   g.mH = 0xffffffffu / (uint32_t)p.H + 1u;
-  const int c_tiles = p.K / 128, n_tiles = p.N / 128;
+  const int c_tiles = p.K / 128, n_tiles = (p.N + 127) / 128;
   const int total_steps = (g.TP + PX - 1) / PX;
   const int splits = w3_splits(p);
   const int sps = (total_steps + splits - 1) / splits;
@@ -565,7 +570,7 @@ int launch3(const CxWgrad& p, hipStream_t st) {
 // pixel-range splits of the 3x3 kernel (shared by the dispatcher's workspace check and the launcher)
 static inline int w3_splits(const CxWgrad& p) {
   const int total_steps = (p.B * p.H * (p.W + 2) + PX - 1) / PX;
-  int splits = p.splits > 0 ? p.splits : 256 / ((p.K / 128) * (p.N / 128) * 3);
+  int splits = p.splits > 0 ? p.splits : 256 / ((p.K / 128) * ((p.N + 127) / 128) * 3);
   if (splits < 1) splits = 1;
   if (splits > total_steps) splits = total_steps;
   const int sps = (total_steps + splits - 1) / splits;
@@ -630,7 +635,9 @@ int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
     // the bottleneck 3x3 layers (wgrad3_kernel); padded positions, pixel indices and byte offsets must fit their fields
     static const int env3 = [] { const char* e = getenv("CX_WGRAD3"); return e ? atoi(e) : 1; }();
     const int on3 = g_wm_form == 0 ? 0 : env3;          // dbg_wgrad_mm_select(1, 0): the strip kernel
-    if (!on3 || (p.N % 128) || (p.K % 128) || p.W < 2 || p.H < 2) return 0;
+    // N: any multiple of 8 from 96 up (partial last tile; CX_WGRAD3_MIN_N, 0 = multiples of 128 only)
+    static const int min_n3 = [] { const char* e = getenv("CX_WGRAD3_MIN_N"); return e ? atoi(e) : 96; }();
+    if (!on3 || (p.N % 8) || ((p.N % 128) && (min_n3 <= 0 || p.N < min_n3)) || (p.K % 128) || p.W < 2 || p.H < 2) return 0;
     // its partial tiles leave through the slab workspace only (see the kernel's epilogue): without one the strip kernel runs
     if (!p.scratch || (long long)w3_splits(p) * 9 * p.N * p.K > p.scratch_floats) return 0;
     const unsigned long long tp = (unsigned long long)p.B * p.H * (p.W + 2);

@@ -213,6 +213,9 @@ def test_1x1_weight_gradient_against_torch(dev, select_w, form, K, N, gpro, xpro
     (128, 256, 0, 1, 1, 40, 40, 5),        # plain gradient operand, 1680 positions in five ranges (tails of the step pipeline)
     (128, 128, 2, 0, 5, 4, 6, 1),          # plain activation operand, tiny map (every row touches the zero rows)
     (128, 128, 2, 1, 2, 80, 80, 3),        # one padded row (82 positions) longer than a step
+    (128, 120, 2, 1, 2, 20, 20, 2),        # partial last N tile: the 3x3 branch of an attention-augmented transition (128 - 8 channels)
+    (256, 240, 0, 1, 3, 10, 12, 1),        # two N tiles, the second partial; plain gradient operand
+    (128, 104, 2, 0, 2, 9, 7, 3),          # partial tile, plain activation operand
 ])
 def test_3x3_weight_gradient_against_torch(dev, select_w, K, N, gpro, xpro, B, H, W, splits):
     """wgrad3_kernel: the three taps of a kernel row per workgroup, pixels walked in the zero-padded index space.  (It leaves its
