@@ -15,10 +15,13 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
-import torch
+# torch is imported by main() AFTER the launcher decision: a parent that only spawns the ranks (`python bench.py --gpus N` without
+# WORLD_SIZE) never imports it, so it cannot have touched HIP
+torch = None
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -72,21 +75,15 @@ class KernelTimer:
 
     def _timed(self, alg, fn, *a, **kw):
         """Events around the kernel of one call, filed under the kernel name the library reports for it (`only`: other kernels'
-        records are dropped).  A weight-gradient call with immediate reproducible sums is the kernel plus a slab-reduce launch: the
-        library records `em` right before that reduce (dbg_pre_reduce_event), so the figure is the kernel's own duration -- what
-        rocprofv3 reports for it -- not kernel + reduce."""
+        records are dropped).  The engines defer the slab sums of their weight gradients to one table-driven launch per pass
+        (ops.wgrad_defer_begin), so an entry point is ONE kernel launch between the two events -- what rocprofv3 reports for it."""
         e0, e1 = self._event(), self._event()
-        em = self._event()
         e0.record()
-        raw = self._raw()
-        raw.dbg_pre_reduce_event(ctypes.c_void_p(em.cuda_event))
         r = fn(*a, **kw)
-        taken = raw.dbg_pre_reduce_event_taken()
-        raw.dbg_pre_reduce_event(None)
         e1.record()
-        tag = raw.cx_last_kernel().decode()
+        tag = self._raw().cx_last_kernel().decode()
         if self.only is None or tag == self.only:
-            self.records.setdefault(tag, []).append((e0, em if taken else e1, alg))
+            self.records.setdefault(tag, []).append((e0, e1, alg))
         return r
 
     def _event(self):
@@ -102,8 +99,6 @@ class KernelTimer:
         if getattr(self, "_rawlib", None) is None:
             from chexpert_amd import _lib
             self._rawlib = ctypes.CDLL(_lib.LIB_PATH)
-            self._rawlib.dbg_pre_reduce_event.argtypes = [ctypes.c_void_p]
-            self._rawlib.dbg_pre_reduce_event_taken.restype = ctypes.c_int
             self._rawlib.cx_last_kernel.restype = ctypes.c_char_p
         return self._rawlib
 
@@ -124,7 +119,7 @@ def _committed(suffix, args):
         if suffix in f and f.endswith(".json"):
             j = json.load(open(os.path.join(d, f)))
             if j.get("workload_key", "densenet121:bf16:256:320") == key:
-                best = j
+                best = dict(j, _file="profiles/" + f)
     return best
 
 
@@ -142,7 +137,7 @@ def pmc_traffic(kernel, args):
     collected with rocprofv3 --pmc in their own runs); null when no pass was taken on this workload."""
     j = _committed("_pmc_traffic", args)
     k = None if j is None else _lookup(j["kernels"], kernel)
-    return None if k is None else k["hbm_bytes_per_launch"]
+    return (None, None) if k is None else (k["hbm_bytes_per_launch"], j["_file"])
 
 
 COPY_GUIDE_GBS = 6290.0        # MI355X_MICROARCH.md, chip-level parameters: float4 copy, 79 % of the 8 TB/s specification
@@ -218,7 +213,7 @@ def committed_counter(kernel, args, key):
     GRBM_GUI_ACTIVE, collected with rocprofv3 --pmc in its own run); null when no pass was taken on this workload."""
     j = _committed("_sq_counters", args)
     k = None if j is None else _lookup(j["kernels"], kernel)
-    return None if k is None else k.get(key)
+    return (None, None) if k is None else (k.get(key), j["_file"])
 
 
 def build_model(name, classes, size, dtype, dev):
@@ -301,6 +296,29 @@ def run_other_config(name, batch, size, opt_kind, classes, dev, steps=20, warmup
     return out
 
 
+def launcher_command(n, argv, port=None):
+    """`python bench.py --gpus N` without WORLD_SIZE: the command that starts the N ranks (one process per GPU over RCCL), exactly
+    what the driver runs for N > 1."""
+    if port is None:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv):
+    """Runs the ranks as a CHILD process and returns its exit code; rank 0's JSON line reaches stdout through the inherited pipe.
+    The parent has not imported torch, let alone initialised HIP (never exec from a process that has: it takes the box down)."""
+    assert "torch" not in sys.modules or torch is None, "the launcher parent must not have imported torch"
+    cmd = launcher_command(n, argv)
+    print("[bench] spawning %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,6 +338,11 @@ def main():
                     help="skip the BASELINE configs[2..4] that the headline run reports under config.other_configs (N = 1 only)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    global torch
+    import torch
     import torch.distributed as dist
     from chexpert_amd import ops, synth
     from chexpert_amd.optim import FusedAdam
@@ -328,8 +351,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        sys.exit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or without WORLD_SIZE)" % (
+            args.gpus, world, args.gpus))
     # CHEXPERT_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks share a device); the
     # driver's runs use RCCL ("nccl"), one rank per GPU
     backend = os.environ.get("CHEXPERT_BENCH_BACKEND", "nccl")
@@ -499,6 +522,8 @@ def main():
         value = world * args.batch * args.steps / dt
         avg_ms = ksum["ms"] / ksum["launches"]
         achieved = ksum["alg_bytes"] / (ksum["ms"] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(only, args)
+        mfma_util, mfma_src = committed_counter(only, args, "mfma_util")
         out = {
             "metric": "images/sec fwd+bwd %s %dx%d %s (per-GPU rate in config.images_per_sec_per_gpu)" % (
             "DenseNet121" if args.model == "densenet121" else args.model, args.size, args.size, args.dtype),
@@ -511,6 +536,7 @@ def main():
                                        "BASELINE configs[1]" if (args.model, args.dtype) == ("densenet121", "bf16") else
                                        "not the headline config", args.classes),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "rccl_ranks": (dist.get_world_size() if dp else 1), "collective_backend": (dist.get_backend() if dp else None),
                        "images_per_sec_per_gpu": round(value / world, 2),
                        "model_hbm_roofline_frac": round(value / world * (ALG_BYTES_FP32 if args.dtype == "fp32" else ALG_BYTES)[
                            args.model] / (HBM_PEAK_GBS * 1e9), 4),
@@ -522,10 +548,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": only, "launches_per_step": ksum["launches"] // args.steps,
                          "avg_launch_ms": round(avg_ms, 4), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(only, args), "alg_bytes_per_launch": round(ksum["alg_bytes"] / ksum["launches"]),
-                         "mfma_util": committed_counter(only, args, "mfma_util"),
-                         "timing": "hip events around each kernel launch (a slab reduce behind it excluded), eager replica of the timed steps" if (gstep is not None or dp)
-                         else "hip events around each kernel launch (a slab reduce behind it excluded) inside the timed region"},
+                         "traffic": traffic, "traffic_source": traffic_src and ("committed rocprofv3 --pmc pass %s (not measured in this run)" % traffic_src),
+                         "alg_bytes_per_launch": round(ksum["alg_bytes"] / ksum["launches"]),
+                         "mfma_util": mfma_util, "mfma_util_source": mfma_src and ("committed rocprofv3 --pmc pass %s (not measured in this run)" % mfma_src),
+                         "timing": "hip events around each kernel launch, eager replica of the timed steps" if (gstep is not None or dp)
+                         else "hip events around each kernel launch inside the timed region"},
         }
         headline = (args.model, args.dtype, world) == ("densenet121", "bf16", 1) and not dp
         if headline and not args.no_other_configs:

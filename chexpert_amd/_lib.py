@@ -28,7 +28,7 @@ class CxConv(C.Structure):
                 ("prologue", _i32), ("mode", _i32), ("epilogue", _i32), ("accumulate", _i32), ("tstride", _i32),
                 ("stat_replicas", _i32), ("stat_rstride", _i32), ("stat_det", _i32), ("dtype", _i32),
                 ("pro_out", _vp), ("ldpo", _i32), ("dil", _i32), ("emask", _vp),
-                ("x3", _vp), ("po_lo", _vp), ("po_mask", _vp)]
+                ("x3", _vp), ("po_lo", _vp), ("po_mask", _vp), ("kernel_hint", _i32), ("pad2_", _i32)]
 
 
 class CxWgrad(C.Structure):
@@ -38,7 +38,7 @@ class CxWgrad(C.Structure):
                 ("ldg", _i32), ("ldg2", _i32), ("ldx", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("g_prologue", _i32), ("x_prologue", _i32), ("mode", _i32), ("splits", _i32), ("dtype", _i32), ("dil", _i32),
-                ("scratch", _fp), ("scratch_floats", C.c_int64)]
+                ("scratch", _fp), ("scratch_floats", C.c_int64), ("kernel_hint", _i32), ("pad_", _i32)]
 
 
 WGRAD_BATCH_MAX = 24
@@ -207,7 +207,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name in ("cx_error_string", "cx_last_kernel") else C.c_int
-        if l.cx_abi_version() != 9:
+        if l.cx_abi_version() != 10:
             raise RuntimeError("chexpert_amd: ABI version mismatch")
         _lib = l
     return _lib

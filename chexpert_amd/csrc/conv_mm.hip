@@ -573,6 +573,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
+#ifdef CX_DIAG                                 // s_memtime stamp instantiations: diagnostic builds only (scratch/stamps_mm.py)
 static int g_mm_dbg = 0;
 extern "C" int dbg_conv_mm_stamps(unsigned long long* host, int n_words) {     // not part of the ABI
   if (!host) {
@@ -581,6 +582,7 @@ extern "C" int dbg_conv_mm_stamps(unsigned long long* host, int n_words) {     /
   }
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(conv_mm_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
 }
+#endif
 
 template <int WMW, int WNW, int PRO, int EPI>
 int launch(const CxConv& p, const Cls& c, hipStream_t st) {
@@ -595,6 +597,7 @@ int launch(const CxConv& p, const Cls& c, hipStream_t st) {
                               160 * 1024);
     attr_set = true;
   }
+#ifdef CX_DIAG
   if (g_mm_dbg && (PRO == CX_PRO_AFFINE_RELU || PRO == CX_PRO_NONE) && EPI == CX_EPI_STORE) {
     constexpr int DP = PRO == CX_PRO_NONE ? CX_PRO_NONE : CX_PRO_AFFINE_RELU;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mm_kernel<WMW, WNW, DP, CX_EPI_STORE, true>),
@@ -602,6 +605,7 @@ int launch(const CxConv& p, const Cls& c, hipStream_t st) {
     hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, DP, CX_EPI_STORE, true>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, c, n_tiles);
     return launch_status();
   }
+#endif
   CX_KTAG("conv_mm_kernel<%d, %d, %d, %d, false>%s", WMW, WNW, PRO, EPI, p.tstride > 1 ? " x parity classes" : "");
   hipLaunchKernelGGL((conv_mm_kernel<WMW, WNW, PRO, EPI>), dim3(m_tiles * n_tiles), dim3(G::NT), smem, st, p, c, n_tiles);
   return launch_status();
@@ -629,12 +633,7 @@ int launch_any(const CxConv& p, const Cls& c, hipStream_t st, int form) {
 
 }  // namespace
 
-static int g_mm_on = -1, g_mm_form = -1;       // diagnostic overrides (-1: environment CX_MM / CX_MM_FORM, else the default)
-// Not part of the ABI: lets the tests and micro-benchmarks pin the kernel choice (on = 0: conv_gemm.hip; form = 1 | 2 | 3: tile).
-extern "C" void dbg_conv_mm_select(int on, int form) {
-  g_mm_on = on;
-  g_mm_form = form;
-}
+// CxConv.kernel_hint (ABI 10) lets tests and micro-benchmarks pin the kernel choice per call (on = 0: conv_gemm.hip; form = 1 | 3: tile).
 
 // fewest k-steps per tile for which a shape with a partial last N tile is taken (CX_MM_MIN_STEPS)
 static int mm_min_steps() {
@@ -647,6 +646,7 @@ int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled) {
   *handled = false;
   static const int env_on0 = cx_diag_int("CX_MM", 1);
   static const int env_form0 = cx_diag_int("CX_MM_FORM", 0);
+  const int g_mm_on = (p.kernel_hint & 0xff) - 1, g_mm_form = ((p.kernel_hint >> 8) & 0xff) - 1;      // -1: not pinned
   const bool pjoin = p.prologue == CX_PRO_JOIN;      // (validated by cx_conv_gemm: 1x1, stride 1, K % 64 == 0, store epilogue)
   const int env_on = (p.epilogue == CX_EPI_JOIN || pjoin) ? 1 : g_mm_on >= 0 ? g_mm_on : env_on0;
   const int env_form = g_mm_form >= 0 ? g_mm_form : env_form0;

@@ -1401,6 +1401,8 @@ int unpool2_mask_t(const void* d, const void* x, const float* sc, const float* s
 // Measurement hook (not part of the ABI): an event handed over by dbg_pre_reduce_event is recorded once, on the stream of the next
 // slab reduce, BEFORE that reduce is launched -- so a caller bracketing a weight-gradient entry point with events can time the
 // producing kernel alone (bench.py's roofline figure is per kernel, as rocprofv3 reports it).
+// Diagnostic builds only (-DCX_DIAG): the product library exports no dbg_* symbol.
+#ifdef CX_DIAG
 static thread_local hipEvent_t g_pre_reduce_event = nullptr;
 static thread_local int g_pre_reduce_taken = 0;
 extern "C" void dbg_pre_reduce_event(void* ev) {
@@ -1408,6 +1410,7 @@ extern "C" void dbg_pre_reduce_event(void* ev) {
   g_pre_reduce_taken = 0;
 }
 extern "C" int dbg_pre_reduce_event_taken(void) { return g_pre_reduce_taken; }
+#endif
 
 // Deferred slab sums (cx_wgrad_defer): while the calling thread has deferral on, a weight-gradient launch leaves its partial tiles
 // in the caller's slab and only records what has to be added; cx_wgrad_defer_take hands the records to the caller, who runs them
@@ -1436,11 +1439,13 @@ int cx_dw_reduce_ld(float* dw, const float* slab, size_t total, int splits, int 
     g_defer.list.push_back(d);
     return 0;
   }
+#ifdef CX_DIAG
   if (g_pre_reduce_event) {
     (void)hipEventRecord(g_pre_reduce_event, st);
     g_pre_reduce_event = nullptr;
     g_pre_reduce_taken = 1;
   }
+#endif
   if (vec) {
     const size_t n4 = total / 4;
     hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, dw, slab, total, splits, cols, dw_ld);

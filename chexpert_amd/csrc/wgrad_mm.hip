@@ -621,25 +621,21 @@ int launch_form(const CxWgrad& p, hipStream_t st, int form) {
 
 }  // namespace
 
-static int g_wm_on = -1, g_wm_form = -1;       // diagnostic overrides (-1: environment CX_WGRAD_MM / CX_WGRAD_MM_FORM, else default)
-// Not part of the ABI: pins the kernel choice for tests and micro-benchmarks (on = 0: conv_wgrad.hip's kernels; form 1 | 2 | 3).
-extern "C" void dbg_wgrad_mm_select(int on, int form) {
-  g_wm_on = on;
-  g_wm_form = form;
-}
+// CxWgrad.kernel_hint (ABI 10) pins the kernel choice per call for tests and micro-benchmarks (on = 0: conv_wgrad.hip's kernels; form 1 | 2 | 3).
 
 // Called by cx_conv_wgrad after validation (bf16, MODE_CONV).
 int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
   *handled = false;
   static const int env_on0 = cx_diag_int("CX_WGRAD_MM", 1);
   static const int env_form0 = cx_diag_int("CX_WGRAD_MM_FORM", 0);
+  const int g_wm_on = (p.kernel_hint & 0xff) - 1, g_wm_form = ((p.kernel_hint >> 8) & 0xff) - 1;      // -1: not pinned
   const int on = g_wm_on >= 0 ? g_wm_on : env_on0;
   const int env_form = g_wm_form >= 0 ? g_wm_form : env_form0;
   if (!on || p.mode != CX_MODE_CONV) return 0;
   if (p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad == 1) {
     // the bottleneck 3x3 layers (wgrad3_kernel); padded positions, pixel indices and byte offsets must fit their fields
     static const int env3 = cx_diag_int("CX_WGRAD3", 1);
-    const int on3 = g_wm_form == 0 ? 0 : env3;          // dbg_wgrad_mm_select(1, 0): the strip kernel
+    const int on3 = g_wm_form == 0 ? 0 : env3;          // kernel_hint = CX_KERNEL_HINT(1, 0): the strip kernel
     // N: any multiple of 8 from 96 up (partial last tile; CX_WGRAD3_MIN_N, 0 = multiples of 128 only)
     static const int min_n3 = cx_diag_int("CX_WGRAD3_MIN_N", 96);
     if (!on3 || (p.N % 8) || ((p.N % 128) && (min_n3 <= 0 || p.N < min_n3)) || (p.K % 128) || p.W < 2 || p.H < 2) return 0;

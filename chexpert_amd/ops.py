@@ -202,12 +202,22 @@ def last_pro_out():
     return bool(lib().cx_last_pro_out())
 
 
+def kernel_hint(on=-1, form=-1):
+    """CxConv.kernel_hint / CxWgrad.kernel_hint (ABI 10; include/chexpert_hip.h CX_KERNEL_HINT): pins the kernel family (on = 0 the
+    generic kernels, 1 the tiled ones) and tile form of ONE call -- tests and micro-benchmarks only; 0 = the library picks."""
+    return (0 if on < 0 else on + 1) | ((0 if form < 0 else form + 1) << 8)
+
+
+KERNEL_HINT = 0          # default hint of the calls made while it is set (tests / scratch benchmarks: `ops.KERNEL_HINT = kernel_hint(1, 3)`)
+
+
 def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, prologue=PRO_NONE, pa=None, pb=None,
                  pc=None, x2=None, epilogue=EPI_STORE, stat_sum=None, stat_sq=None, ex=None, e_sc=None, e_sh=None,
                  e_mu=None, e_r=None, e_scale=None, accumulate=False, K=None, tstride=1, stat_replicas=1, stat_rstride=0,
-                 stat_det=False, pro_out=None, emask=None, x3=None, po_lo=None, po_mask=None, dil=1):
+                 stat_det=False, pro_out=None, emask=None, x3=None, po_lo=None, po_mask=None, dil=1, hint=None):
     require_cuda(x, w_packed, y)
     p = CxConv()
+    p.kernel_hint = KERNEL_HINT if hint is None else hint
     B, H, W, Cx, ldx = _nhwc(x)
     By, Ho, Wo, Cy, ldy = _nhwc(y)
     assert By == B and Cy == N
@@ -253,9 +263,10 @@ def _conv_params(x, w_packed, y, *, N, kh=1, kw=1, stride=1, pad=0, mode=MODE_CO
 
 
 def conv_wgrad(g, x, dw, *, kh=1, kw=1, stride=1, pad=0, mode=MODE_CONV, g_prologue=PRO_NONE, g2=None, ga=None, gb=None,
-               gc=None, x_prologue=PRO_NONE, pa=None, pb=None, splits=0, K=None, dil=1):
+               gc=None, x_prologue=PRO_NONE, pa=None, pb=None, splits=0, K=None, dil=1, hint=None):
     require_cuda(g, x, dw)
     p = CxWgrad()
+    p.kernel_hint = KERNEL_HINT if hint is None else hint
     p.dil = dil
     B, Ho, Wo, N, ldg = _nhwc(g)
     Bx, H, W, Cx, ldx = _nhwc(x)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CX_ABI_VERSION 9
+#define CX_ABI_VERSION 10
 
 enum { CX_EINVAL = -1, CX_EALIGN = -2, CX_ESHAPE = -3, CX_EUNSUPPORTED = -4, CX_ESTATROWS = -5 };
 
@@ -112,7 +112,14 @@ typedef struct CxConv {
   const int8_t* x3;
   int8_t* po_lo;
   uint8_t* po_mask;
+  /* ABI 10.  Per-call kernel selection for tests and micro-benchmarks (stateless: replaces the process-wide dbg_* selectors of      */
+  /* earlier ABIs).  0: the library picks.  Low byte 1: the generic implicit-GEMM kernels (conv_gemm.hip / conv_wgrad.hip),        */
+  /* 2: the tiled kernels (conv_mm.hip / wgrad_mm.hip) where the shape allows.  Second byte f + 1: tile form f (1 = 128 x 128,     */
+  /* 2 = 256 x 128 (weight gradient only), 3 = 128 x 256; weight gradient f = 0: the strip kernel for 3x3).  CX_KERNEL_HINT(on, f). */
+  int32_t kernel_hint;
+  int32_t pad2_;
 } CxConv;
+#define CX_KERNEL_HINT(on, form) ((((on) < 0) ? 0 : (on) + 1) | ((((form) < 0) ? 0 : (form) + 1) << 8))
 
 /* Weight gradient of the same convolution:  dW[n][c][ky][kx] += sum_m G[m][n] * A[m@tap][c]
  *   G = dY (prologue NONE or AFFINE2 with vectors ga/gb/gc over N, second tensor g2)
@@ -137,6 +144,8 @@ typedef struct CxWgrad {
   /* The library picks `splits`; 16 M floats cover every layer of the reference's networks at their benchmark batches.    */
   float* scratch;
   int64_t scratch_floats;
+  int32_t kernel_hint;                     /* ABI 10: as CxConv.kernel_hint                                      */
+  int32_t pad_;
 } CxWgrad;
 
 /* ABI 8.  The 3x3 weight gradients (K = 128 -> N = 32, stride 1, pad 1) of up to CX_WGRAD_BATCH_MAX dense layers of ONE dense block

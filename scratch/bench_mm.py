@@ -46,9 +46,9 @@ for L in layers:
         fl = 2.0 * M * K * N * taps
         res = []
         for on, form in [(0, 0), (1, 1), (1, 3), (-1, -1)]:
-            raw.dbg_conv_mm_select(on, form)
+            ops.KERNEL_HINT = ops.kernel_hint(on, form)
             us = timeit(fn)
             res.append("%6.1f us %5.0f TF" % (us, fl / us / 1e6))
         print("L%d %s K=%4d N=%4d taps=%d | generic %s | 128x128 %s | 128x256 %s | default %s" % (L, k, K, N, taps, *res), flush=True)
-    raw.dbg_conv_mm_select(-1, -1)
+    ops.KERNEL_HINT = ops.kernel_hint(-1, -1)
     del x4, x4b, y1, y1b, y4

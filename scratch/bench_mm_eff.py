@@ -37,7 +37,7 @@ for hw, cin, ce, cout in STAGES:
     for name, (fn, K, N) in cases.items():
         res = []
         for on, form in [(0, 0), (1, 1), (1, 3)]:
-            raw.dbg_conv_mm_select(on, form)
+            ops.KERNEL_HINT = ops.kernel_hint(on, form)
             try:
                 us = timeit(fn)
                 res.append("%6.1f us" % us)
@@ -45,4 +45,4 @@ for hw, cin, ce, cout in STAGES:
                 res.append("   fail  ")
         by = 2.0 * M * (K + N) * (2 if 'dgr' in name else 1)
         print("%3dx%-3d %s K=%4d N=%4d | generic %s | 128x128 %s | 128x256 %s | floor %.0f us" % (hw, hw, name, K, N, *res, by / 4.5e6), flush=True)
-    raw.dbg_conv_mm_select(-1, -1)
+    ops.KERNEL_HINT = ops.kernel_hint(-1, -1)

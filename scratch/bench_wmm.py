@@ -41,9 +41,9 @@ for L in layers:
         fl = 2.0 * M * K * N
         res = []
         for on, form in [(0, 0), (1, 0) if k == 'w2' else (1, 1), (1, 2), (1, 3), (-1, -1)]:
-            raw.dbg_wgrad_mm_select(on, form)
+            ops.KERNEL_HINT = ops.kernel_hint(on, form)
             us = timeit(fn)
             res.append("%6.1f us %5.0f TF" % (us, fl / us / 1e6))
         print("L%d %s K=%4d N=%4d | old %s | 128x128 (w2: strip) %s | 256x128 %s | 128x256 %s | default %s" % (L, k, K, N, *res), flush=True)
-    raw.dbg_wgrad_mm_select(-1, -1)
+    ops.KERNEL_HINT = ops.kernel_hint(-1, -1)
     del x4, x4b, y1, y1b

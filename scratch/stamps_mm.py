@@ -14,7 +14,7 @@ for L, kind in [(3, 'f2'), (3, 'f1'), (2, 'f2'), (4, 'f2')]:
     w1, w2 = t(4 * C * C), t(9 * C * C)
     one, zero = torch.ones(4 * C, device=dev), torch.zeros(4 * C, device=dev)
     for wm in (1, 3):
-        raw.dbg_conv_mm_select(1, wm)
+        ops.KERNEL_HINT = ops.kernel_hint(1, wm)
         raw.dbg_conv_mm_stamps(None, 1)
         for _ in range(2):
             if kind == 'f2':
@@ -33,4 +33,4 @@ for L, kind in [(3, 'f2'), (3, 'f1'), (2, 'f2'), (4, 'f2')]:
             med = np.median(per, 0)
             print("L%d %s form=%d wave %s: steps %.0f, cycles/step %.0f: step %.0f barrier %.0f (unused %.0f %.0f)" %
                   (L, kind, wm, "0" if wv == 0 else "last", np.median(v[:, 4]), med.sum(), *med), flush=True)
-    raw.dbg_conv_mm_select(-1, -1)
+    ops.KERNEL_HINT = ops.kernel_hint(-1, -1)

@@ -22,10 +22,12 @@ def dev():
 
 @pytest.fixture
 def select():
-    from chexpert_amd import _lib
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    yield lambda on, wm: raw.dbg_conv_mm_select(on, wm)
-    raw.dbg_conv_mm_select(-1, -1)
+    from chexpert_amd import ops as _ops          # per-call CxConv.kernel_hint (ABI 10), defaulted through ops.KERNEL_HINT
+
+    def sel(on, wm):
+        _ops.KERNEL_HINT = _ops.kernel_hint(on, wm)
+    yield sel
+    _ops.KERNEL_HINT = 0
 
 
 def bf(t):
@@ -172,10 +174,12 @@ def test_same_result_as_the_generic_kernel(dev, select):
 # ------------------------------------------------------------------------------------------------ weight gradient (wgrad_mm.hip)
 @pytest.fixture
 def select_w():
-    from chexpert_amd import _lib
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    yield lambda on, form: raw.dbg_wgrad_mm_select(on, form)
-    raw.dbg_wgrad_mm_select(-1, -1)
+    from chexpert_amd import ops as _ops
+
+    def sel(on, form):
+        _ops.KERNEL_HINT = _ops.kernel_hint(on, form)
+    yield sel
+    _ops.KERNEL_HINT = 0
 
 
 @pytest.mark.parametrize("form", [1, 2, 3])

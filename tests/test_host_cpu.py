@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libchexpert_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.lib().cx_abi_version() == 9
+    assert _lib.lib().cx_abi_version() == 10
     assert _lib.lib().cx_error_string(-3) == b"unsupported shape"
     # every binding passes exactly the parameters the header declares (a short argtypes list makes ctypes pass the rest as 32-bit
     # ints: truncated device pointers, i.e. a GPU memory fault instead of an error)
@@ -39,6 +39,11 @@ def test_product_library_never_reads_the_environment():
     from chexpert_amd import _lib
     und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in und, "libchexpert_hip.so imports getenv"
+    # ... and exports no debugging hook: the dbg_* selectors / event taps of earlier ABIs mutated process-wide state (kernel choice is
+    # the per-call CxConv.kernel_hint / CxWgrad.kernel_hint field since ABI 10; stamps and event taps exist in -DCX_DIAG builds only)
+    defined = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    dbg = [l.split()[-1] for l in defined.splitlines() if l.split() and l.split()[-1].startswith("dbg_")]
+    assert not dbg, "libchexpert_hip.so exports debug hooks: %s" % dbg
     csrc = os.path.join(ROOT, "chexpert_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
         if f.endswith((".hip", ".h")):
@@ -66,7 +71,7 @@ def test_validation_codes_without_launching():
     bt = _lib.CxWgradBatch()
     assert _lib.lib().cx_conv3x3_wgrad_batch(ctypes.byref(w), ctypes.byref(bt), None) == -1      # n = 0
     assert ctypes.sizeof(_lib.CxWgradBatch) == 5 * 8 * _lib.WGRAD_BATCH_MAX + 8
-    assert ctypes.sizeof(_lib.CxConv) == 15 * 8 + 24 * 4 + 8 + 8 + 8 + 3 * 8     # ... pro_out, ldpo + pad_, emask (ABI 8), x3, po_lo, po_mask (ABI 9)
+    assert ctypes.sizeof(_lib.CxConv) == 15 * 8 + 24 * 4 + 8 + 8 + 8 + 3 * 8 + 8     # ... pro_out, ldpo + pad_, emask (ABI 8), x3, po_lo, po_mask (ABI 9), kernel_hint + pad (ABI 10)
     assert _lib.lib().cx_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 1, 1.0, None) == -1
 
 
@@ -560,3 +565,39 @@ def test_library_and_torch_share_one_hip_runtime():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-800:]
     assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
+
+
+def test_bench_gpus_n_without_world_size_spawns_the_ranks_as_a_child():
+    """`python bench.py --gpus 2` (no WORLD_SIZE): the parent builds the two-rank torch.distributed.run command, runs it as a CHILD
+    process and relays its exit code -- without importing torch (so it cannot have initialised HIP: no exec / fork hazards)."""
+    code = r"""
+import json, os, subprocess, sys
+sys.path.insert(0, %r)
+os.environ.pop("WORLD_SIZE", None)
+calls = []
+def fake_call(cmd, **kw):
+    calls.append((list(cmd), "torch" in sys.modules, kw.get("env", {}).get("HSA_ENABLE_IPC_MODE_LEGACY")))
+    return 7
+subprocess.call = fake_call
+import bench
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"]
+try:
+    bench.main()
+    rc = None
+except SystemExit as e:
+    rc = e.code
+print(json.dumps({"rc": rc, "calls": calls, "torch_after": "torch" in sys.modules}))
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["rc"] == 7, "the child's exit code is the parent's"
+    assert len(out["calls"]) == 1
+    cmd, torch_loaded, ipc = out["calls"][0]
+    assert not torch_loaded and not out["torch_after"], "the launcher parent imported torch"
+    assert ipc == "0"
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
