@@ -407,6 +407,7 @@ int launch_bn(const CxConv& p, hipStream_t st) {
 
 }  // namespace
 
+int cx_try_pc_fwd(const CxConv& p, hipStream_t st, bool* handled);        // conv3x3_pc.hip
 int cx_try_ring_fwd(const CxConv& p, hipStream_t st, bool* handled);      // conv3x3_ring.hip
 int cx_try_strip_fwd(const CxConv& p, hipStream_t st, bool* handled);     // conv3x3_strip.hip
 int cx_try_ring_dgrad(const CxConv& p, hipStream_t st, bool* handled);    // conv3x3_ring.hip
@@ -504,7 +505,9 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
     if (p.ldx < p.K) return CX_ESHAPE;
     if (p.dil <= 1) {          // (a dilated convolution runs on the generic implicit GEMM below: the tiled kernels assume adjacent taps)
       bool handled = false;
-      int rc = cx_try_ring_fwd(p, st, &handled);
+      int rc = cx_try_pc_fwd(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_ring_fwd(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_strip_fwd(p, st, &handled);
       if (handled) return rc;

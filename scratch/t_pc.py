@@ -1,0 +1,69 @@
+"""conv3x3_pc_fwd_kernel (producer / consumer waves) against the ring kernel (kernel_hint form 7): outputs bit for bit, statistic sums
+to fp32 order; then timings of both on the DenseNet shapes at bs = 256."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chexpert_amd import ops, _lib
+import ctypes
+dev = torch.device('cuda:0'); bf = torch.bfloat16
+raw = ctypes.CDLL(_lib.LIB_PATH); raw.cx_last_kernel.restype = ctypes.c_char_p
+OLD = ops.kernel_hint(-1, 7)
+
+def run(B, H, W, ctot, off, hint, seed=0, ldx_extra=0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    z1 = (torch.randn(B, H, W, 128 + ldx_extra, generator=g) * 0.7).to(bf).to(dev)[..., :128]
+    buf = torch.full((B, H, W, ctot), 7.0, dtype=bf, device=dev)
+    w = (torch.randn(9 * 32 * 128, generator=g) * 0.05).to(bf).to(dev)
+    sc = (torch.rand(128, generator=g) + 0.5).to(dev); sh = (torch.randn(128, generator=g) * 0.3).to(dev)
+    cap = 1024
+    st = torch.zeros(2, cap * 32, device=dev)
+    rows = ops.conv_gemm(z1, w, buf[..., off:off + 32], N=32, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE_RELU, pa=sc, pb=sh, stat_sum=st[0], stat_sq=st[1],
+                         stat_det=True, stat_replicas=cap, stat_rstride=32, hint=hint)
+    name = raw.cx_last_kernel().decode()
+    s = st.view(2, cap, 32)[:, :rows].double().sum(1)
+    return buf, s, name
+
+ok = True
+for (B, H, W, ctot, off, ex) in [(2, 80, 80, 256, 64, 0), (3, 40, 40, 512, 480, 0), (5, 20, 20, 1024, 32, 0), (7, 10, 10, 64, 32, 0), (2, 16, 24, 96, 0, 128),
+                                 (1, 7, 9, 32, 0, 0), (9, 5, 4, 64, 32, 0), (300, 10, 10, 64, 0, 0), (130, 20, 20, 64, 32, 0), (17, 33, 66, 64, 32, 0),
+                                 (1, 1, 8, 32, 0, 0), (4, 2, 6, 32, 0, 0), (64, 64, 64, 64, 0, 0), (3, 70, 130, 32, 0, 0)]:
+    a, sa, na = run(B, H, W, ctot, off, 0, ldx_extra=ex)
+    b, sb, nb = run(B, H, W, ctot, off, OLD, ldx_extra=ex)
+    torch.cuda.synchronize()
+    same = torch.equal(a, b)
+    ds = ((sa - sb).abs() / (sb.abs() + 1e-3)).max().item()
+    print("B%d %dx%d ctot %d off %d: %s vs %s: equal %s, stat rel %.2e" % (B, H, W, ctot, off, na, nb, same, ds), flush=True)
+    ok &= same and ds < 1e-4 and "pc_fwd" in na
+    if not same:
+        d = (a.float() - b.float()).abs()
+        idx = d.flatten().argmax().item()
+        print("   max diff %.4f at flat %d (%s); n diff %d" % (d.max().item(), idx, tuple(torch.unravel_index(torch.tensor(idx), d.shape)), int((d > 0).sum())))
+print("ALL OK" if ok else "MISMATCH")
+if not ok or (len(sys.argv) > 1 and sys.argv[1] == "notime"):
+    sys.exit(0 if ok else 1)
+
+def timeit(fn, reps=20):
+    fn(); fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+for B in (256, 128):
+    for hw, ctot in ((80, 256), (40, 512), (20, 1024), (10, 1024)):
+        M = B * hw * hw
+        z1 = (torch.randn(B, hw, hw, 128, device=dev) * 0.5).to(bf)
+        buf = (torch.randn(B, hw, hw, ctot, device=dev) * 0.5).to(bf)
+        w = (torch.randn(9 * 32 * 128, device=dev) * 0.05).to(bf)
+        one, zero = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+        cap = 4096
+        st = torch.zeros(2, cap * 128, device=dev)
+        ys = buf[..., 64:96]
+        res = []
+        for hint in (0, OLD, 0, OLD):
+            f = lambda: ops.conv_gemm(z1, w, ys, N=32, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE_RELU, pa=one, pb=zero, stat_sum=st[0], stat_sq=st[1],
+                                      stat_det=True, stat_replicas=cap, stat_rstride=32, hint=hint)
+            res.append(timeit(f))
+        print("B%d %2dx%-2d fwd pc %6.1f / %6.1f us   ring %6.1f / %6.1f us   (bytes at 5 TB/s %5.1f us)" % (
+            B, hw, hw, res[0], res[2], res[1], res[3], 2.0 * M * (128 + 32) / 5e6), flush=True)
