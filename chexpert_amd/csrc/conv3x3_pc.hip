@@ -1,21 +1,26 @@
-// 3x3 stride-1 pad-1 forward of the dense layers (K = 128 -> N = 32), third generation: producer / consumer waves.
+// 3x3 stride-1 pad-1 forward of the dense layers (K = 128 -> N = 32), third generation: producer / consumer waves, the weights in
+// registers, the input channels split over the consumer waves.
 //
 // The ring kernel (conv3x3_ring.hip) runs its phases in series -- stage (BN + ReLU of the new rows into the ring), barrier, 72 MFMAs
-// per sub-tile, store epilogue, barrier -- with all eight waves in lock step: the matrix pipe's share of a step is a third and no
-// load is in flight while the rows are staged (2.0-2.2x the stream time of its own bytes, profiles/r04_*).  Its LDS is full (ring +
-// nine weight slices), so the next rows could not be staged beside the multiplication.
+// per sub-tile, store epilogue, barrier -- with all eight waves in lock step (2.0-2.2x the stream time of its own bytes,
+// profiles/r04_*).  A first producer / consumer form of it (four waves staging, four multiplying one sub-tile each, the weights
+// still in LDS; git history of this file) hid every load and ran no faster: with N = 32 an MFMA needs 1 KB of weights AND 1 KB of
+// pixels from LDS, four waves at two ds_read_b128 per MFMA saturate the LDS array (256 B/clk) on their own, the producers' writes
+// queue behind them (stamps: 52 cycles per MFMA, 430 per staged chunk; profiles/r05_stamps_pc.txt).
 //
-// Here the two waves of every SIMD have different jobs (roles split by wave number >= 4: MI355X_MICROARCH.md, "Two waves per SIMD"):
+// So the contraction is split the other way:
+//   * waves 0-3, CONSUMERS: wave w owns the input channels [32w, 32w + 32) of ALL nine taps -- 18 weight fragments = 72 VGPRs,
+//     loaded once per workgroup -- and multiplies them with every pixel of the step (four 32-pixel sub-tiles, four accumulators):
+//     ONE ds_read_b128 per MFMA, no weights in LDS at all.  The four partial sums of a sub-tile meet through LDS (64 KB of the room
+//     the weights left): wave t adds the partials of sub-tile t in wave order (a fixed order: results are reproducible) and runs
+//     the store epilogue (v_permlane32_swap -> 8 consecutive channels per lane, 16-byte stores, per-lane channel sums);
 //   * waves 4-7, PRODUCERS: keep DEPTH steps of new input rows in flight as plain 16-byte loads (registers), apply BN + ReLU and
-//     write the rows into the ring; their vector work issues beside the partner wave's MFMAs;
-//   * waves 0-3, CONSUMERS: one 32-pixel sub-tile per wave and step = 72 back-to-back MFMAs fed by two ds_read_b128 per MFMA (the
-//     LDS array's rate: 256 B/clk), then the store epilogue (v_permlane32_swap -> 8 consecutive channels per lane, 16-byte stores,
-//     per-lane channel sums).
-//   * ONE barrier per step: between barrier j and j+1 the consumers multiply step j while the producers write the rows of step j+1
-//     into ring slots step j does not read (ring of 2R+2 rows), and the loads of steps j+2.. stay in flight across the barrier.
-// What makes the room: 256-byte ring pixels / weight rows with the 16-byte chunks XOR-swizzled by the pixel (row) index instead of
-// the 272-byte padded pitch (conflict-free for the lane groups of ds_read_b128 and ds_write_b128 alike), and short steps
-// (R x P <= 128 flat pixels = at most four sub-tiles): 73.7 KB of weights + an 8-row ring of 42-pixel rows = 160.3 KB.
+//     write the rows into the ring (272-byte pixels: conflict-free without address arithmetic); their vector work issues beside
+//     the partner wave's MFMAs (roles split by wave number >= 4: MI355X_MICROARCH.md, "Two waves per SIMD");
+//   * two barriers per step: A_j (the rows of step j are staged) and B_j (the partial sums of step j are written).  Between A_j
+//     and B_j the consumers multiply step j, between B_j and A_j+1 they add and store it; the producers stage the rows of step
+//     j + 1 meanwhile (half before B_j, half after) into ring slots step j does not read (ring of 2R + 2 rows), and the loads
+//     of steps j + 2.. stay in flight across the barriers (raw s_barrier: no vmcnt drain).
 //
 // Row space.  The column tiles (image x tile) are stacked into ONE virtual row space with a zero separator row between them
 // (stride Hs = H + 1).  A workgroup owns the virtual rows [v0, v1); its step j reads virtual rows [a + jR - 2, a + jR + R),
@@ -32,10 +37,9 @@ namespace {
 
 constexpr int NT = 512;                  // threads: waves 0-3 consume, waves 4-7 produce
 constexpr int NPT = 256;                 // producer threads
-constexpr int PXB = 256;                 // bytes per ring pixel / weight row: 128 bf16, 16 chunks of 16 B, chunk c of row r at slot c ^ (r & 15)
-constexpr int W_ROWS = 9 * 32;
-constexpr int W_BYTES = W_ROWS * PXB;    // 73728
-constexpr int RING_PX_MAX = (160 * 1024 - W_BYTES) / PXB;     // 352 (the statistics scratch re-uses the weight area at the end)
+constexpr int XP = 272;                  // bytes per ring pixel: 128 bf16 + 16 pad (conflict-free ds_read_b128 / ds_write_b128)
+constexpr int PART_BYTES = 4 * 4 * 4 * 1024;   // partial sums: [wave 4][sub-tile 4][register quad 4][lane 64][16 B] = 64 KB
+constexpr int RING_PX_MAX = (160 * 1024 - PART_BYTES) / XP;     // 361
 
 struct PcGeo {
   int H, W, Wt, P, R, NR, Q;    // Wt: column-tile width, P = Wt + 2, NR = 2R + 2 ring rows, Q = NR * P ring pixels (+2 spare)
@@ -59,6 +63,9 @@ __device__ __forceinline__ float half_sum(float v) {      // sum over the 32 lan
   return v + __shfl_xor(v, 16);
 }
 
+#ifndef CX_PC_ABL
+#define CX_PC_ABL 0      // timing ablations of diagnostic builds (results wrong): 1 no MFMAs, 2 no output stores, 4 no input loads, 8 no BN + ReLU
+#endif
 #ifdef CX_PC_STAMPS
 // diagnostic build (scratch/stamps_pc.py): s_memtime sums per phase, wave 0 (consumer) and wave 4 (producer) of each workgroup
 __device__ unsigned long long pc_stamps[1024 * 16];
@@ -74,10 +81,9 @@ __device__ __forceinline__ unsigned long long pstamp() {
 #define PSTAMP(i)
 #endif
 
-// The step barrier, raw: __syncthreads() would add a full s_waitcnt vmcnt(0) -- the consumers' output stores and the producers' loads
-// in flight have nothing to do with the hand-off, which only needs the producers' LDS writes retired (lgkmcnt) before they arrive.
-__device__ __forceinline__ void bar_after_lds_writes() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void bar_plain() { asm volatile("s_barrier" ::: "memory"); }
+// The step barriers, raw: __syncthreads() adds a full s_waitcnt vmcnt(0) where stores are pending -- the consumers' output stores
+// have nothing to do with the hand-offs, which only need this wave's LDS writes retired (lgkmcnt) before it arrives.
+__device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NCH, int DEPTH>
 __global__ __launch_bounds__(NT, 1) void conv3x3_pc_fwd_kernel(const bf16* __restrict__ x, int ldx, const float* __restrict__ sc,
@@ -85,18 +91,14 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_pc_fwd_kernel(const bf16* __res
                                                               bf16* __restrict__ y, int ldy, float* stat_sum, float* stat_sq,
                                                               int stat_replicas, int stat_rstride, int stat_det, const PcGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* wl = smem;                                             // [9*32][256 B], swizzled
-  char* ring = smem + W_BYTES;                                 // [Q + 2][256 B], swizzled
+  char* part = smem;                                           // partial sums, 64 KB (the statistics scratch at the end)
+  char* ring = smem + PART_BYTES;                              // [Q + 2][272 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5;
   const int P = g.P, R = g.R, NR = g.NR, Q = g.Q, W = g.W, H = g.H, Wt = g.Wt, Hs = g.Hs;
 
-  // ---- one-time setup: weights [tap][n][k] -> LDS rows of 256 B (chunk c of row r at slot c ^ (r & 15)), ring zeroed
-  for (int i = tid; i < W_ROWS * 16; i += NT) {
-    const int row = i >> 4, c = i & 15;
-    *reinterpret_cast<uint4*>(wl + row * PXB + ((c ^ (row & 15)) << 4)) = *reinterpret_cast<const uint4*>(wpk + (size_t)row * 128 + c * 8);
-  }
-  for (int i = tid; i < (Q + 2) * (PXB / 16); i += NT) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
+  // ---- one-time setup: ring zeroed (the pad columns at the image edges are never written again)
+  for (int i = tid; i < (Q + 2) * (XP / 16); i += NT) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
   const unsigned v0 = (unsigned)(((unsigned long long)blockIdx.x * g.V) / (unsigned)g.nwg);
@@ -113,15 +115,22 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_pc_fwd_kernel(const bf16* __res
   // rows [a, e) of a pass; a step grid of its own: step j loads rows [a + jR, a + jR + R); steps 0 .. J-1 cover the output rows
   // [a - 1, a + JR - 1) >= [a, e).  Ring slot of virtual row a + r (r >= -R - 2): (r + 2 NR) mod NR, tracked incrementally by both
   // roles.  The roles are the OUTER branch (each walks both passes itself): merged inside the pass loop, the compiler's wait-count
-  // bookkeeping carried the producers' loads in flight into the consumers' code and made every sub-tile wait for the wave's own
-  // output stores (s_waitcnt vmcnt(0)).
+  // bookkeeping carries the producers' loads in flight into the consumers' code (every sub-tile then waits for the wave's own
+  // output stores: s_waitcnt vmcnt(0)).
   auto pass_range = [&](int pass, unsigned& a, unsigned& e, int& J) __attribute__((always_inline)) {
     a = pass == 0 ? v0 + rot : v0;
     e = pass == 0 ? v1 : v0 + rot;
     J = e > a ? (int)((e - a + 1 + R - 1) / R) : 0;
   };
+  // Barriers of a pass, the same 2J + 3 for both roles: A_-1, then B_j-1 and A_j for j = 0 .. J-1, B_J-1, end of pass.
   if (wave >= 4) {
     // ================================================================================================= producers
+#ifndef CX_PC_PRIO
+#define CX_PC_PRIO 2
+#endif
+    // static priority for the staging waves: beside a partner that streams MFMAs (each holds the SIMD's vector issue for 8 of its 32
+    // cycles, and the older wave wins every arbitration) their ~45 vector instructions per chunk crawled at 19 cycles each
+    __builtin_amdgcn_s_setprio(CX_PC_PRIO);
     const int ptid = tid - NPT;
     const int c8 = ptid & 15;                                // this thread's 16-byte channel chunk, the same for every slot
     float csc[8], csh[8];
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_pc_fwd_kernel(const bf16* __res
     // chunk slot i of this thread: chunk id ptid + 256 i -> (row of the step's R new rows, ring position in the row); the rest of a
     // chunk's address is per ROW: lane r of every producer wave works out row r of the step once (tile, image row, validity, byte
     // offset of the row's ring position 0) and the chunks fetch their row's word with ds_bpermute -- per chunk: one cross-lane read,
-    // one add, three bit tests (the divisions / 32-bit multiplies per chunk were a third of the producers' instructions)
+    // one add, three bit tests (divisions / 32-bit multiplies per chunk were a third of the producers' instructions)
     const int cpr = P * 16;
     int crow4[NCH], posoff[NCH];
     uint32_t coff[NCH];
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_pc_fwd_kernel(const bf16* __res
     m0 &= mrow;
     m1 &= mrow;
     const char* __restrict__ xb = reinterpret_cast<const char*>(x);
+    char* ringc = ring + c8 * 16;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       unsigned a, e;
@@ -179,154 +189,195 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_pc_fwd_kernel(const bf16* __res
           const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(crow4[i], word);
           const unsigned ok = w & (((w & 2u) ? m1 : m0) >> i) & 1u;
           pm |= ok << i;
-          pr[i] = *reinterpret_cast<const uint4*>(xb + (size_t)(ok ? (w & ~15u) + coff[i] : 0u));
+          if (CX_PC_ABL & 4) pr[i] = make_uint4(w, w, w, w);
+          else pr[i] = *reinterpret_cast<const uint4*>(xb + (size_t)(ok ? (w & ~15u) + coff[i] : 0u));
         }
       };
-      auto stage = [&](uint4 (&pr)[NCH], unsigned pm, int sb) __attribute__((always_inline)) {
+      // chunks [I0, I1) of a set -> ring.  Straight-line code (a per-chunk `if` becomes an exec-mask branch, and behind each the
+      // compiler re-waits for loads -- of the set just issued, too): a chunk past the step's rows goes to the spare pixel Q + 1,
+      // which only invalid outputs read
+      auto stage = [&](uint4 (&pr)[NCH], unsigned pm, int sb, auto I0, auto I1) __attribute__((always_inline)) {
         const int sbp = sb * P, wrap_from = (NR - sb) * 4;     // chunk rows >= NR - sb wrap to the ring's start
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          // straight-line code (a per-chunk `if` becomes an exec-mask branch, and behind each the compiler re-waits for loads
-          // -- of the set just issued, too): a chunk past the step's rows goes to the spare pixel Q + 1, which only invalid
-          // outputs read
-          uint4 o = cx_affine_relu8(pr[i], csc, csh);
+        for (int i = decltype(I0)::value; i < decltype(I1)::value; ++i) {
+          uint4 o = (CX_PC_ABL & 8) ? pr[i] : cx_affine_relu8(pr[i], csc, csh);
           const unsigned keep = 0u - ((pm >> i) & 1u);
           o.x &= keep; o.y &= keep; o.z &= keep; o.w &= keep;
           int pos = sbp + posoff[i] - (crow4[i] >= wrap_from ? Q : 0);
           pos = ((mrow >> i) & 1u) ? pos : Q + 1;
-          *reinterpret_cast<uint4*>(ring + pos * PXB + ((c8 ^ (pos & 15)) << 4)) = o;
+          *reinterpret_cast<uint4*>(ringc + pos * XP) = o;
         }
       };
+      using I_0 = std::integral_constant<int, 0>;
+      using I_H = std::integral_constant<int, NCH / 2>;
+      using I_N = std::integral_constant<int, NCH>;
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {                        // (set by set: the loop's counted waits assume the sets were requested in order)
         issue(pre[d], pvm[d], -1 + d);
         __builtin_amdgcn_sched_barrier(0);
       }
       int sb = (2 * NR - R) % NR;                              // slot of row a - R (the warm-up step's first row)
+      // warm-up rows, then barrier A_-1
+      stage(pre[0], pvm[0], sb, I_0{}, I_N{});
+      issue(pre[0], pvm[0], -1 + DEPTH);
+      sb += R;
+      if (sb >= NR) sb -= NR;
+      bar_lds();
       auto pstep = [&](int j, auto KI) __attribute__((always_inline)) {
         constexpr int k = decltype(KI)::value;
         PSTAMP(0)
-#ifdef CX_PC_STAMPS
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH * (DEPTH - 1)) : "memory");
-        PSTAMP(1)                                              // wait for the oldest set
-#endif
-        stage(pre[k], pvm[k], sb);
+        stage(pre[k], pvm[k], sb, I_0{}, I_H{});               // beside the consumers' multiplication of step j - 1
+        PSTAMP(1)
+        bar_lds();                                             // B_j-1
         PSTAMP(2)
-        issue(pre[k], pvm[k], j + DEPTH);                      // in flight across the next DEPTH barriers
+        stage(pre[k], pvm[k], sb, I_H{}, I_N{});               // beside their sums and stores
+        PSTAMP(3)
+        issue(pre[k], pvm[k], j + DEPTH);                      // in flight across the next 2 DEPTH barriers
         sb += R;
         if (sb >= NR) sb -= NR;
-        PSTAMP(3)
-        __syncthreads();
-        PSTAMP(4)                                // barrier j: the rows of step j are in the ring
+        PSTAMP(4)
+        bar_lds();                                             // A_j: the rows of step j are in the ring
+        PSTAMP(5)
       };
-      for (int j = -1; j < J; j += DEPTH) {
-        pstep(j, std::integral_constant<int, 0>());
-        if (DEPTH > 1) { if (j + 1 >= J) break; pstep(j + 1, std::integral_constant<int, 1 % DEPTH>()); }
-        if (DEPTH > 2) { if (j + 2 >= J) break; pstep(j + 2, std::integral_constant<int, 2 % DEPTH>()); }
+      for (int j = 0; j < J; j += DEPTH) {
+        pstep(j, std::integral_constant<int, 1 % DEPTH>());
+        if (DEPTH > 1) { if (j + 1 >= J) break; pstep(j + 1, std::integral_constant<int, 2 % DEPTH>()); }
+        if (DEPTH > 2) { if (j + 2 >= J) break; pstep(j + 2, std::integral_constant<int, 3 % DEPTH>()); }
       }
-      bar_plain();                                             // the pass is over: the ring is rebuilt by the next one
+      bar_lds();                                               // B_J-1
+      bar_lds();                                               // the pass is over: the ring is rebuilt by the next one
 #ifdef CX_PC_STAMPS
       if (tid == 256 && blockIdx.x < 1024) {
-        for (int i = 0; i < 5; ++i) pc_stamps[blockIdx.x * 16 + 8 + i] += st_acc[i];
-        pc_stamps[blockIdx.x * 16 + 15] += (unsigned long long)(J + 1);
+        for (int i = 0; i < 6; ++i) pc_stamps[blockIdx.x * 16 + 8 + i] += st_acc[i];
+        pc_stamps[blockIdx.x * 16 + 15] += (unsigned long long)J;
       }
 #endif
     }
   } else {
     // ================================================================================================= consumers
+    // weight fragments of this wave's 32 input channels: tap t, k-step ks (16 channels): A[row = out channel lrow][k = 8 lh .. + 8]
+    bf16x8 wf[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wf[t][ks] = *reinterpret_cast<const bf16x8*>(wpk + (size_t)(t * 32 + lrow) * 128 + wave * 32 + ks * 16 + lh * 8);
+    const int choff = (wave * 4 + lh) * 16;                    // this lane's 16 bytes of a ring pixel for k-step 0 (+ 32 for k-step 1)
+    // partial sums: register quad q of sub-tile tt from wave w at part[((w*4 + tt)*4 + q)*1024 + lane*16]
+    char* pw = part + wave * 16 * 1024 + lane * 16;            // this wave's partials (writer)
+    const char* pr_ = part + wave * 4 * 1024 + lane * 16;      // sub-tile `wave` of every wave (reader): + w * 16 KB + q * 1 KB
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       unsigned a, e;
       int J;
       pass_range(pass, a, e, J);
       if (J == 0) continue;
-      const int nsub = (R * P + 31) / 32;
-      // weight fragment of tap t, k-step ks: row t*32 + lrow, chunk 2 ks + lh -> slot (2 ks + lh) ^ (lrow & 15)
-      const char* wrow = wl + lrow * PXB;
-      const int wsw = ((lrow & 15) ^ lh) << 4;                 // ^ (ks << 5) per k-step
       int sb = (2 * NR - R - 2) % NR;                          // slot of row a + jR - 2 for j = -1
 #ifdef CX_PC_STAMPS
       unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = pstamp();
 #endif
-      bar_plain();                                             // barrier -1 (warm-up rows)
+      bar_lds();                                               // A_-1 (warm-up rows)
+      bar_lds();                                               // B_-1
       for (int j = 0; j < J; ++j) {
         sb += R;
         if (sb >= NR) sb -= NR;
         PSTAMP(0)
-        bar_plain();                                           // barrier j (this wave's fragment reads of step j-1 were consumed by its MFMAs)
+        bar_lds();                                             // A_j
         PSTAMP(1)
         const int ws = sb * P;
-        for (int s = wave; s < nsub; s += 4) {
-          f32x16 acc;
+        f32x16 acc[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          const int m = s * 32 + lrow;
-          const int pix = min(m, R * P - 1);
-          // ring pixel of tap (dy, dx): ws + pix + dy*P + dx (mod Q; + dx may run into the two spare pixels: invalid outputs only)
-          int pb[3];
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+        // ring pixel of tap (dy, dx) of sub-tile tt: ws + pix + dy*P + dx (mod Q; + dx may run into the two spare pixels: invalid
+        // outputs only); byte address of this lane's k-step-0 chunk
+        const char* bp[4][3];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int pix = min(tt * 32 + lrow, R * P - 1);
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             int f = ws + pix + dy * P;
             if (f >= Q) f -= Q;
             if (f >= Q) f -= Q;
-            pb[dy] = f;
+            bp[tt][dy] = ring + f * XP + choff;
           }
-          constexpr int G = 3, NG = 72 / G;
-          bf16x8 fa[3][G], fb[3][G];
-          auto load_grp = [&](int gi, bf16x8 (&A)[G], bf16x8 (&B)[G]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int jj = 0; jj < G; ++jj) {
-              const int f = gi * G + jj, t = f >> 3, ks = f & 7;
-              const int dy = t / 3, dx = t - dy * 3;
-              A[jj] = *reinterpret_cast<const bf16x8*>(wrow + t * 32 * PXB + (wsw ^ (ks << 5)));
-              const int p = pb[dy] + dx;
-              B[jj] = *reinterpret_cast<const bf16x8*>(ring + p * PXB + ((((p & 15) ^ lh) << 4) ^ (ks << 5)));
-            }
-          };
-          load_grp(0, fa[0], fb[0]);
-          load_grp(1, fa[1], fb[1]);
-#pragma unroll
-          for (int gi = 0; gi < NG; ++gi) {
-            if (gi + 2 < NG) load_grp(gi + 2, fa[(gi + 2) % 3], fb[(gi + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jj = 0; jj < G; ++jj)
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[gi % 3][jj], fb[gi % 3][jj], acc, 0, 0, 0);   // D[row = out channel][col = pixel]
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#ifdef CX_PC_STAMPS
-          asm volatile("" ::"v"(acc[0]));
-#endif
-          PSTAMP(2)
-          const unsigned oy = __umulhi((unsigned)m, g.mP), ox = (unsigned)m - oy * (unsigned)P;
-          const unsigned v = a + (unsigned)(j * R) - 1u + oy;                  // (a = 0, j = 0, oy = 0 wraps: fails v >= a)
-          const unsigned t = __umulhi(v, g.mHs), yy = v - t * (unsigned)Hs;
-          const int b = (int)(t >> g.ntx_shift), xc = (int)(t & (unsigned)(g.ntx - 1)) * Wt + (int)ox;
-          const bool valid = m < R * P && ox < (unsigned)Wt && xc < W && v >= a && v < e && yy < (unsigned)H;
-          bf16* yrow = y + (valid ? ((size_t)(b * H + (int)yy) * W + xc) * ldy : (size_t)0);
-#pragma unroll
-          for (int cc = 0; cc < 2; ++cc) {
-            // registers 8cc..8cc+3 / 8cc+4..8cc+7: channels 16cc + 4*lh + e / 16cc + 8 + 4*lh + e; the swap of the upper half of
-            // the first group with the lower half of the second leaves channels 8*(2cc+lh) .. +7 of this lane's pixel
-            U128 o;
-            float tv[8];
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * cc + r4]), __float_as_uint(acc[8 * cc + 4 + r4]),
-                                                               false, false);
-              tv[r4] = __uint_as_float(sw[0]);
-              tv[4 + r4] = __uint_as_float(sw[1]);
-            }
-            o.u = cx_pack8_stats(tv, valid, true, s1[cc], s2[cc]);
-            if (valid) *reinterpret_cast<uint4*>(yrow + 8 * (2 * cc + lh)) = o.u;
-          }
-          PSTAMP(3)
         }
+        // 18 (tap, k-step) groups of four MFMAs (one per sub-tile, the same weight fragment); the reads of group g + 1 go out before
+        // the MFMAs of group g (128 cycles ahead; a third register set does not fit beside 72 weight and 64 accumulator registers)
+        constexpr int NG = 18, NS = 2;
+        bf16x8 fb[NS][4];
+        auto load_grp = [&](int gi, bf16x8 (&B)[4]) __attribute__((always_inline)) {
+          const int t = gi >> 1, ks = gi & 1, dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) B[tt] = *reinterpret_cast<const bf16x8*>(bp[tt][dy] + dx * XP + ks * 32);
+        };
+#pragma unroll
+        for (int d = 0; d < NS - 1; ++d) load_grp(d, fb[d]);
+#pragma unroll
+        for (int gi = 0; gi < ((CX_PC_ABL & 1) ? 0 : NG); ++gi) {
+          if (gi + NS - 1 < NG) load_grp(gi + NS - 1, fb[(gi + NS - 1) % NS]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[gi >> 1][gi & 1], fb[gi % NS][tt], acc[tt], 0, 0, 0);   // D[row = out channel][col = pixel]
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        PSTAMP(2)
+        // partial sums -> LDS (lane-linear 16-byte pieces: conflict-free)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(pw + (tt * 4 + q) * 1024) = f32x4{acc[tt][4 * q], acc[tt][4 * q + 1], acc[tt][4 * q + 2], acc[tt][4 * q + 3]};
+        PSTAMP(3)
+        bar_lds();                                             // B_j
+        PSTAMP(4)
+        // sub-tile `wave`: the four partials in wave order
+        f32x16 sum;
+        {
+          f32x4 pq[4][4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pq[w][q] = *reinterpret_cast<const f32x4*>(pr_ + w * 16 * 1024 + q * 1024);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 t4 = ((pq[0][q] + pq[1][q]) + pq[2][q]) + pq[3][q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[4 * q + r] = t4[r];
+          }
+        }
+        const int m = wave * 32 + lrow;
+        const unsigned oy = __umulhi((unsigned)m, g.mP), ox = (unsigned)m - oy * (unsigned)P;
+        const unsigned v = a + (unsigned)(j * R) - 1u + oy;                  // (a = 0, j = 0, oy = 0 wraps: fails v < e)
+        const unsigned t = __umulhi(v, g.mHs), yy = v - t * (unsigned)Hs;
+        const int b = (int)(t >> g.ntx_shift), xc = (int)(t & (unsigned)(g.ntx - 1)) * Wt + (int)ox;
+        const bool valid = m < R * P && ox < (unsigned)Wt && xc < W && v >= a && v < e && yy < (unsigned)H;
+        bf16* yrow = y + (valid ? ((size_t)(b * H + (int)yy) * W + xc) * ldy : (size_t)0);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          // registers 8cc..8cc+3 / 8cc+4..8cc+7: channels 16cc + 4*lh + e / 16cc + 8 + 4*lh + e; the swap of the upper half of
+          // the first group with the lower half of the second leaves channels 8*(2cc+lh) .. +7 of this lane's pixel
+          U128 o;
+          float tv[8];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[8 * cc + r4]), __float_as_uint(sum[8 * cc + 4 + r4]),
+                                                             false, false);
+            tv[r4] = __uint_as_float(sw[0]);
+            tv[4 + r4] = __uint_as_float(sw[1]);
+          }
+          o.u = cx_pack8_stats(tv, valid, true, s1[cc], s2[cc]);
+          if (valid && !((CX_PC_ABL & 2) && o.u.x != 0x12345u)) *reinterpret_cast<uint4*>(yrow + 8 * (2 * cc + lh)) = o.u;
+        }
+        PSTAMP(5)
       }
-      bar_plain();                                             // the pass is over
+      bar_lds();                                               // the pass is over
 #ifdef CX_PC_STAMPS
       if (tid == 0 && blockIdx.x < 1024) {
-        for (int i = 0; i < 4; ++i) pc_stamps[blockIdx.x * 16 + i] += st_acc[i];
+        for (int i = 0; i < 6; ++i) pc_stamps[blockIdx.x * 16 + i] += st_acc[i];
         pc_stamps[blockIdx.x * 16 + 7] += (unsigned long long)J;
       }
 #endif
@@ -334,7 +385,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_pc_fwd_kernel(const bf16* __res
   }
 
   if (stat_sum) {
-    float* scratch = reinterpret_cast<float*>(wl);               // the weight slices are no longer read
+    float* scratch = reinterpret_cast<float*>(part);             // the partial sums are no longer read
     wg_stat_begin<NT / 64>(scratch, 32, tid, NT);
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -355,7 +406,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_pc_fwd_kernel(const bf16* __res
 
 template <int NCH, int DEPTH>
 int launch_pc(const CxConv& p, hipStream_t st, const PcGeo& g) {
-  const size_t smem = W_BYTES + (size_t)(g.Q + 2) * PXB;
+  const size_t smem = PART_BYTES + (size_t)(g.Q + 2) * XP;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pc_fwd_kernel<NCH, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -381,10 +432,13 @@ extern "C" int dbg_pc_stamps(unsigned long long* host, int n_words) {      // ho
 }
 #endif
 
-// Eligibility + launch, called from cx_conv_gemm ahead of the ring kernel.  CxConv.kernel_hint form 7 pins the ring kernel (tests, A/B).
+// Eligibility + launch, called from cx_conv_gemm ahead of the ring kernel -- ONLY when CxConv.kernel_hint asks for it (form 8): measured
+// on MI355X it ties the ring kernel on 80x80 / 40x40 maps and loses on smaller ones (profiles/r05_pc_fwd.txt: stamps and timing
+// ablations; the SIMD's vector issue -- ~45 instructions per staged 16-byte chunk beside the MFMAs -- is as long as the HBM time of a
+// step, whichever wave issues them).  It stays in the library as the measured alternative with its tests, not as a default.
 int cx_try_pc_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   *handled = false;
-  if (((p.kernel_hint >> 8) & 0xff) == 8) return 0;
+  if (((p.kernel_hint >> 8) & 0xff) != 9) return 0;
   if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1 || p.tstride > 1) return 0;
   if (p.K != 128 || p.N != 32 || p.prologue != CX_PRO_AFFINE_RELU || p.epilogue != CX_EPI_STORE || p.accumulate) return 0;
   if (p.W < 4 || p.H < 1) return 0;
@@ -417,5 +471,5 @@ int cx_try_pc_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   const int need = (R * g.P * 16 + NPT - 1) / NPT;
   if (need <= 4) return launch_pc<4, 3>(p, st, g);
   if (need <= 6) return launch_pc<6, 2>(p, st, g);
-  return launch_pc<8, 2>(p, st, g);
+  return launch_pc<8, 3>(p, st, g);
 }

@@ -16,7 +16,7 @@ for hw, ctot in ((80, 256), (40, 512), (20, 1024), (10, 1024)):
     st = torch.zeros(2, cap * 128, device=dev)
     ys = buf[..., 64:96]
     f = lambda: ops.conv_gemm(z1, w, ys, N=32, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE_RELU, pa=one, pb=zero, stat_sum=st[0], stat_sq=st[1],
-                              stat_det=True, stat_replicas=cap, stat_rstride=32)
+                              stat_det=True, stat_replicas=cap, stat_rstride=32, hint=ops.kernel_hint(-1, 8))
     for _ in range(3): f()
     torch.cuda.synchronize()
     raw.dbg_pc_stamps(None, 0)
@@ -26,9 +26,9 @@ for hw, ctot in ((80, 256), (40, 512), (20, 1024), (10, 1024)):
     raw.dbg_pc_stamps(host, 1024 * 16)
     a = np.frombuffer(host, dtype=np.uint64).reshape(1024, 16).astype(np.float64)[:256]
     a = a[a[:, 7] > 0]
-    c = np.median(a[:, :4] / a[:, 7:8], 0)
-    p = np.median(a[:, 8:13] / a[:, 15:16], 0)
-    print("%dx%d (%s, %.1f us): steps/wg %.0f | consumer per step %.0f: epilogue-to-barrier %.0f, barrier wait %.0f, multiply %.0f, epilogue %.0f | "
-          "producer per step %.0f: loop %.0f, wait loads %.0f, stage %.0f, issue %.0f, barrier %.0f" % (
-              hw, hw, _lib.lib().cx_last_kernel().decode(), e0.elapsed_time(e1) * 1e3, np.median(a[:, 7]), c.sum(), c[0], c[1], c[2], c[3],
-              p.sum(), p[0], p[1], p[2], p[3], p[4]), flush=True)
+    c = np.median(a[:, :6] / a[:, 7:8], 0)
+    p = np.median(a[:, 8:14] / a[:, 15:16], 0)
+    print("%dx%d (%s, %.1f us): steps/wg %.0f | consumer per step %.0f: loop %.0f, barrier A %.0f, multiply %.0f, partials out %.0f, barrier B %.0f, sum + epilogue %.0f | "
+          "producer per step %.0f: loop %.0f, stage 1st half %.0f, barrier B %.0f, stage 2nd half %.0f, issue %.0f, barrier A %.0f" % (
+              hw, hw, _lib.lib().cx_last_kernel().decode(), e0.elapsed_time(e1) * 1e3, np.median(a[:, 7]), c.sum(), c[0], c[1], c[2], c[3], c[4], c[5],
+              p.sum(), p[0], p[1], p[2], p[3], p[4], p[5]), flush=True)

@@ -6,7 +6,8 @@ from chexpert_amd import ops, _lib
 import ctypes
 dev = torch.device('cuda:0'); bf = torch.bfloat16
 raw = ctypes.CDLL(_lib.LIB_PATH); raw.cx_last_kernel.restype = ctypes.c_char_p
-OLD = ops.kernel_hint(-1, 7)
+OLD = 0
+NEW = ops.kernel_hint(-1, 8)
 
 def run(B, H, W, ctot, off, hint, seed=0, ldx_extra=0):
     g = torch.Generator(device='cpu').manual_seed(seed)
@@ -26,13 +27,16 @@ ok = True
 for (B, H, W, ctot, off, ex) in [(2, 80, 80, 256, 64, 0), (3, 40, 40, 512, 480, 0), (5, 20, 20, 1024, 32, 0), (7, 10, 10, 64, 32, 0), (2, 16, 24, 96, 0, 128),
                                  (1, 7, 9, 32, 0, 0), (9, 5, 4, 64, 32, 0), (300, 10, 10, 64, 0, 0), (130, 20, 20, 64, 32, 0), (17, 33, 66, 64, 32, 0),
                                  (1, 1, 8, 32, 0, 0), (4, 2, 6, 32, 0, 0), (64, 64, 64, 64, 0, 0), (3, 70, 130, 32, 0, 0)]:
-    a, sa, na = run(B, H, W, ctot, off, 0, ldx_extra=ex)
+    a, sa, na = run(B, H, W, ctot, off, NEW, ldx_extra=ex)
     b, sb, nb = run(B, H, W, ctot, off, OLD, ldx_extra=ex)
     torch.cuda.synchronize()
-    same = torch.equal(a, b)
+    # the pc kernel adds four per-wave partial sums (another fp32 order than the ring kernel's single chain): equal up to one bf16 ulp
+    # of an element here and there; the untouched channels of the buffer must be untouched
+    d_ = (a.float() - b.float()).abs()
+    same = bool((d_ <= 2.0 ** -7 * b.float().abs().clamp_min(2.0 ** -10)).all()) and float((d_ > 0).float().mean()) < 2e-3
     ds = ((sa - sb).abs() / (sb.abs() + 1e-3)).max().item()
-    print("B%d %dx%d ctot %d off %d: %s vs %s: equal %s, stat rel %.2e" % (B, H, W, ctot, off, na, nb, same, ds), flush=True)
-    ok &= same and ds < 1e-4 and "pc_fwd" in na
+    print("B%d %dx%d ctot %d off %d: %s vs %s: equal-to-an-ulp %s (%.1e of the elements differ), stat rel %.2e" % (B, H, W, ctot, off, na, nb, same, float((d_ > 0).float().mean()), ds), flush=True)
+    ok &= same and ds < 2e-4 and "pc_fwd" in na
     if not same:
         d = (a.float() - b.float()).abs()
         idx = d.flatten().argmax().item()
@@ -61,7 +65,7 @@ for B in (256, 128):
         st = torch.zeros(2, cap * 128, device=dev)
         ys = buf[..., 64:96]
         res = []
-        for hint in (0, OLD, 0, OLD):
+        for hint in (NEW, OLD, NEW, OLD):
             f = lambda: ops.conv_gemm(z1, w, ys, N=32, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE_RELU, pa=one, pb=zero, stat_sum=st[0], stat_sq=st[1],
                                       stat_det=True, stat_replicas=cap, stat_rstride=32, hint=hint)
             res.append(timeit(f))

@@ -152,6 +152,34 @@ def test_conv3x3_slice_output(dev, B, H, W, K, N, stride, pro):
     close(ssum.cpu(), got.sum((0, 2, 3)), rel=1e-4, what="sum")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 80, 80), (3, 40, 40), (5, 20, 20), (7, 10, 10), (1, 7, 9), (9, 5, 4), (300, 2, 66), (17, 33, 66), (1, 1, 8)])
+def test_conv3x3_producer_consumer_forward(dev, B, H, W):
+    """conv3x3_pc_fwd_kernel (csrc/conv3x3_pc.hip; CxConv.kernel_hint form 8: the measured alternative to the ring kernel -- staging
+    waves / multiplying waves, weights in registers, input channels split over the multiplying waves): the dense layer's 3x3
+    (torchvision `_DenseLayer.conv2` behind norm2 + relu2, as imported at models/attn_aug_conv.py:13) against F.conv2d, with the
+    deterministic statistic rows; image boundaries inside a workgroup's row range, column tiles, ranges starting inside an image."""
+    from chexpert_amd import _lib, ops
+    K, N = 128, 32
+    xb, x = nhwc_buf(5, B, H, W, K, dev)
+    w = bf(rnd(6, (N, K, 3, 3), -0.1, 0.1))
+    pa, pb = rnd(7, (K,), -0.3, 1.5), rnd(8, (K,), -0.5, 0.5)
+    a = bf(F.relu(x * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1)))
+    want = F.conv2d(a, w, padding=1)
+    buf = torch.full((B, H, W, 96 + N), -3.0, dtype=torch.bfloat16, device=dev)
+    cap = 512
+    st = torch.zeros(2, cap, N, device=dev)
+    rows = ops.conv_gemm(xb, ops.pack_weights(w.to(dev)), buf[..., 96:], N=N, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE_RELU, pa=pa.to(dev),
+                         pb=pb.to(dev), stat_sum=st[0], stat_sq=st[1], stat_det=True, stat_replicas=cap, stat_rstride=N,
+                         hint=ops.kernel_hint(-1, 8))
+    assert _lib.lib().cx_last_kernel().decode().startswith("conv3x3_pc_fwd_kernel")
+    got = to_nchw(buf[..., 96:])
+    close(got, want, what="y")
+    assert (buf[..., :96].float() == -3.0).all()
+    close(st[0, :rows].double().sum(0).float().cpu(), got.double().sum((0, 2, 3)).float(), rel=1e-4, what="sum")
+    close(st[1, :rows].double().sum(0).float().cpu(), (got.double() ** 2).sum((0, 2, 3)).float(), rel=1e-4, what="sumsq")
+    assert (st[:, rows:] == 0).all(), "rows past the reported count were written"
+
+
 def test_transition_pool2_commutes_with_conv(dev):
     from chexpert_amd import ops
     B, H, W, K, N = 2, 8, 12, 64, 96
