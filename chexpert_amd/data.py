@@ -50,7 +50,7 @@ class ChexpertCSV(torch.utils.data.Dataset):
         root = os.path.expanduser(root)
         if mode == "test":
             df = pd.read_csv(root, keep_default_na=True)
-            self.root = "."
+            self.root, self.csv_path = ".", root
             for a in self.attr_names:
                 df[a] = 0.0
         else:
@@ -58,7 +58,8 @@ class ChexpertCSV(torch.utils.data.Dataset):
             if not os.path.isdir(folder):
                 raise FileNotFoundError("%s not found (the dataset is not downloaded here; pass --synthetic N)" % folder)
             self.root = root
-            df = pd.read_csv(os.path.join(folder, "train.csv" if mode == "train" else "valid.csv"), keep_default_na=True)
+            self.csv_path = os.path.join(folder, "train.csv" if mode == "train" else "valid.csv")      # (also part of the decoded-cache key)
+            df = pd.read_csv(self.csv_path, keep_default_na=True)
             if mode == "train":
                 df[self.attr_names] = df[self.attr_names].fillna(0).replace(-1, 1)            # U-Ones
                 for k, v in (data_filter or {}).items():
@@ -96,20 +97,46 @@ class ChexpertCSV(torch.utils.data.Dataset):
         if node_shared and os.path.isdir("/dev/shm"):
             import atexit
             import hashlib
-            key = hashlib.sha1(("%s|%s|%s|%d|%d|%s" % (os.path.abspath(self.root), self.mode, self.resize, c, n,
-                                                         "|".join(map(str, self.data.index[:16])))).encode()).hexdigest()[:16]
+            # the key names the DATA, not only the folder: the index file's size and mtime go in, so a dataset regenerated in the same
+            # place does not map the previous run's pixels
+            csv = getattr(self, "csv_path", None)
+            try:
+                st_ = os.stat(csv) if csv else None
+                stamp = "%d|%d" % (st_.st_size, st_.st_mtime_ns) if st_ else "-"
+            except OSError:
+                stamp = "-"
+            key = hashlib.sha1(("%s|%s|%s|%d|%d|%s|%s" % (os.path.abspath(self.root), self.mode, self.resize, c, n, stamp,
+                                                            "|".join(map(str, self.data.index[:16])))).encode()).hexdigest()[:16]
             base = "/dev/shm/chexpert_amd_cache_%d_%s" % (os.getuid(), key)
+            owner = base + ".owner"                # pid of the creating process: a table whose creator is dead is stale
+            try:
+                pid = int(open(owner).read().strip() or 0)
+                os.kill(pid, 0)                    # raises when that process is gone
+            except FileNotFoundError:
+                pass
+            except (ValueError, ProcessLookupError):
+                # left behind by a creator that was killed (no atexit): nobody may trust its `.have` flags -- start over
+                for f in (base + ".have", base + ".rows", owner):
+                    try:
+                        os.unlink(f)
+                    except FileNotFoundError:
+                        pass
+            except PermissionError:
+                pass                               # alive, another user's: not ours to judge (the uid is in the name anyway)
             created = False
-            try:                                   # O_EXCL: exactly one process of the node creates (and later unlinks) the pair
+            try:                                   # O_EXCL: exactly one process of the node creates (and later unlinks) the files
                 os.close(os.open(base + ".have", os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600))
                 created = True
+                os.close(os.open(base + ".rows", os.O_CREAT | os.O_RDWR, 0o600))       # (torch.from_file would create it with the umask's mode)
+                with open(os.open(owner, os.O_CREAT | os.O_WRONLY | os.O_TRUNC, 0o600), "w") as f_:
+                    f_.write(str(os.getpid()))
             except FileExistsError:
                 pass
             # torch.from_file(shared=True) sizes the file (ftruncate: new bytes read as zero) and maps it
             self._have = torch.from_file(base + ".have", shared=True, size=n, dtype=torch.uint8)
             self._cache = torch.from_file(base + ".rows", shared=True, size=need, dtype=torch.uint8).view(n, 1, c, c)
             if created:
-                atexit.register(lambda: [os.unlink(f) for f in (base + ".have", base + ".rows") if os.path.exists(f)])
+                atexit.register(lambda: [os.unlink(f) for f in (base + ".have", base + ".rows", owner) if os.path.exists(f)])
             return True
         self._cache = torch.empty((n, 1, c, c), dtype=torch.uint8).share_memory_()
         self._have = torch.zeros(n, dtype=torch.uint8).share_memory_()      # 1 once row i of the table is complete

@@ -145,16 +145,29 @@ class SegmentedTrainStep:
                             pass
                     self._g, self.segs = None, []
                     raise
-        finally:
+        except BaseException as capture_error:
+            # the clean-up below touches the GPU; if the failed capture left the device in a state where that raises too, the caller
+            # must still see the ORIGINAL error (bench.py logs it and falls back to the eager step), chained, not replaced
             red.capture = None
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            with torch.no_grad():                                   # the warm-up steps really ran: put the buffers back either way
-                for b, v in saved:
-                    b.copy_(v)
-            if hasattr(model, "_nbt_pending"):
-                model._nbt_pending = nbt
+            try:
+                self._restore(s, saved, model, nbt)
+            except Exception as cleanup_error:
+                raise capture_error from cleanup_error
+            raise
+        red.capture = None
+        self._restore(s, saved, model, nbt)
         self.replays = 0
+
+    @staticmethod
+    def _restore(s, saved, model, nbt):
+        """Joins the capture stream and puts the buffers the warm-up steps changed back (they really ran)."""
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for b, v in saved:
+                b.copy_(v)
+        if hasattr(model, "_nbt_pending"):
+            model._nbt_pending = nbt
 
     def _begin(self):
         self._g = torch.cuda.CUDAGraph()

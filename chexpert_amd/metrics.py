@@ -29,8 +29,11 @@ def roc_curve(y_true, score):
     return fps / fps[-1], tps / tps[-1], thr
 
 
+_trapz = getattr(np, "trapezoid", None) or np.trapz      # NumPy >= 2.0 / 1.x
+
+
 def auc(x, y):
-    return float(np.trapezoid(y, x)) if not (np.any(np.isnan(x)) or np.any(np.isnan(y))) else float("nan")
+    return float(_trapz(y, x)) if not (np.any(np.isnan(x)) or np.any(np.isnan(y))) else float("nan")
 
 
 def precision_recall_curve(y_true, score):

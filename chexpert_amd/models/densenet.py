@@ -828,6 +828,11 @@ class _Engine:
                     # the kernels below then read it with identity coefficients
                     ops.dropout_slice_bwd(gs, xs, qa, qb, qc, self.drop_rate, self.drop_seed, bi * 256 + li)
                     qa, qb, qc = ws.ones[:g_], ws.zeros[:g_], ws.zeros[:g_]
+                    # the side stream's conv2 weight gradient reads `gs` AFTER this in-place rewrite: the event it waits on is taken
+                    # here, not before it (a separate side stream -- CHEXPERT_SERIAL_WGRAD=0 -- could otherwise read the slice
+                    # before or while it is rewritten)
+                    ev_q = torch.cuda.Event()
+                    ev_q.record(main)
                 rows = ops.conv_gemm(gs, self.w_bwd(layer.conv2), dz2, N=self.mid, kh=3, kw=3, pad=1, prologue=ops.PRO_AFFINE2, x2=xs,
                                      pa=qa, pb=qb, pc=qc, epilogue=ops.EPI_MASK, ex=y1, e_sc=v(n2[0]), e_sh=v(n2[1]), e_mu=v(n2[2]),
                                      e_r=v(n2[3]), e_scale=ws.ones[:self.mid], pro_out=dyc, **self._sp(ws, S2, self.mid))

@@ -154,7 +154,10 @@ class _Engine:
             stage_len += [len(L)] * len(L)
         ident = [b.downsample is None for b in self.blocks]
         long_id = [ident[i] and stage_len[i] >= 6 for i in range(n)]
-        self.keep_lo = [self.two_plane and i + 1 < n and long_id[i + 1] for i in range(n)]
+        # (CHEXPERT_STREAM_LO_MIN=<blocks>: the stage length from which the lo plane is kept, for measurements -- 1 = on every identity join)
+        lo_min = int(os.environ.get("CHEXPERT_STREAM_LO_MIN", "6"))
+        lo_id = [ident[i] and stage_len[i] >= lo_min for i in range(n)]
+        self.keep_lo = [self.two_plane and i + 1 < n and lo_id[i + 1] for i in range(n)]
         self.fuse_fwd = [self.two_plane and self.fwd_join_fuse and long_id[i] and i + 1 < n for i in range(n)]
         self.cifar = isinstance(model, WideResNet)              # 3x3 stride-1 stem, no max-pool, three stages (:311-404)
         # vector plan: [fwd-zero region | bwd-zero region | rest]

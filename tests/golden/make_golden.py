@@ -22,6 +22,7 @@ What it does
 Only data (inputs' seeds and expected outputs) is written; no reference source text is stored.
 """
 import json
+from collections import OrderedDict
 import os
 import sys
 import types
@@ -262,7 +263,7 @@ def gen_nets(out_dir, which):
     json.dump(counts, open(os.path.join(out_dir, "param_counts.json"), "w"), indent=1)
 
 
-def gen_smooth(out_dir, which):
+def gen_smooth(out_dir, which, yard_only=False):
     """Well-conditioned fixtures from the REAL reference at B = 8 (tests/golden/nets_smooth.json): the state of
     `synth.smooth_state_dict_` (BatchNorm gains in [0.8, 1.2], biases 2.5 / 1.0, kaiming-scale convolutions).  These are the
     fixtures the bf16 path is held to north_star's 1e-2 on, with literal bounds (the hash-weight fixtures of gen_nets amplify
@@ -330,17 +331,103 @@ def gen_smooth(out_dir, which):
         sd = synth.smooth_state_dict_(filled_sd(spec, 21), bias)
         x = synth.xray_batch(1234, B, S)
         t = synth.targets(99, B, n_cls)
-        run_net(model, sd, x, t, tag, out, fwd)
-        out[tag].update(B=B, S=S, n_classes=n_cls, sd_seed=21, x_seed=1234, t_seed=99, smooth_bias=bias)
+        if not yard_only:              # (`yardstick <tags>`: the reference's records stay, only the storage yardstick below is renewed)
+            run_net(model, sd, x, t, tag, out, fwd)
+            out[tag].update(B=B, S=S, n_classes=n_cls, sd_seed=21, x_seed=1234, t_seed=99, smooth_bias=bias)
         del model
         gc.collect()
-        if "efficientnet" not in tag:   # preview of what bf16 storage alone does to this fixture (informational)
+        if "efficientnet" not in tag:
+            # What bf16 STORAGE alone does to this fixture: the fp32 oracle with nothing but the tensors the HIP path stores rounded to
+            # bf16, against the reference's records -- train logits, loss, gradient norms of the weights / of the norm parameters.  An
+            # ill-conditioned fixture (aaresnet152: 47 softmax layers) is held to a multiple of THIS, not to a hand-set number.
             from oracle import step as ostep
-            _, lq, _ = ostep.train_step(lambda s, xx: fwd(s, xx, train=True, q=nets.bf16_storage), {k: v.clone() for k, v in sd.items()}, x, t)
+            lo_q, lq, gq = ostep.train_step(lambda s, xx: fwd(s, xx, train=True, q=nets.bf16_storage), {k: v.clone() for k, v in sd.items()}, x, t)
             want = torch.tensor(out[tag]["logits_train"])
             out[tag]["bf16_storage_logits_rel"] = float((lq - want).abs().max() / want.abs().max())
-            print("[%s] storage-rounded oracle vs reference: train logits %.2e of absmax" % (tag, out[tag]["bf16_storage_logits_rel"]))
+            gmax = max(r["l2"] for r in out[tag]["grads"].values())
+            dev_w, dev_n = 0.0, 0.0
+            for k, r in out[tag]["grads"].items():
+                if r["l2"] < 1e-3 * gmax or k not in gq:
+                    continue
+                d = abs(float(gq[k].double().norm()) / r["l2"] - 1.0)
+                if gq[k].dim() > 1:
+                    dev_w = max(dev_w, d)
+                else:
+                    dev_n = max(dev_n, d)
+            out[tag]["bf16_storage_yardstick"] = {"logits": out[tag]["bf16_storage_logits_rel"],
+                                                  "loss": abs(float(lo_q) - out[tag]["loss"]) / abs(out[tag]["loss"]),
+                                                  "weight_grad_norm": dev_w, "norm_grad_norm": dev_n}
+            print("[%s] storage-rounded oracle vs reference: %s" % (tag, out[tag]["bf16_storage_yardstick"]))
         json.dump(out, open(path, "w"))
+
+
+def gen_options(out_dir):
+    """Constructor options beyond the chexpert.py defaults, from the REAL reference on small networks (tests/golden/options.json;
+    tests/test_oracle_golden.py holds the oracle's branches to them): ResNet `replace_stride_with_dilation`, `groups` +
+    `width_per_group`, wide Bottlenecks (attn_aug_conv.py:218-220, :168, :183, :266-271), DenseNet `drop_rate` (:453, :479-481; eval
+    mode, and train mode with the keep decisions INJECTED through F.dropout -- torch's own random stream is not reproducible
+    elsewhere), `attn_params['relative'] = False` (:38, :76) and a value ratio of 0.4 (:417-427).  The parameter shapes are part of
+    the fixture: the oracle is driven by the state_dict alone."""
+    from models.attn_aug_conv import DenseNet, ResNet, Bottleneck
+    from oracle import nets
+    n_cls, out = 5, {}
+    cfg = (2, 2, 2, 2)
+
+    def attn(v=0.1, relative=True, hw=(64, 64)):
+        return {"k": 0.2, "v": v, "nh": 8, "relative": relative, "input_dims": hw}
+
+    P_DROP, SEED = 0.3, 777
+    jobs = {
+        "resnet_dilate_64_b2": (lambda: ResNet(Bottleneck, [1, 2, 1, 1], num_classes=n_cls, replace_stride_with_dilation=[False, True, True]), 2, 64,
+                                lambda s, x, train: nets.resnet_forward(s, x, (1, 2, 1, 1), train=train, dilate=(False, True, True))),
+        "resnet_groups4_w16_64_b2": (lambda: ResNet(Bottleneck, [1, 1, 1, 1], num_classes=n_cls, groups=4, width_per_group=16), 2, 64,
+                                     lambda s, x, train: nets.resnet_forward(s, x, (1, 1, 1, 1), train=train)),
+        "resnet_wide128_64_b2": (lambda: ResNet(Bottleneck, [1, 1, 1, 1], num_classes=n_cls, width_per_group=128), 2, 64,
+                                 lambda s, x, train: nets.resnet_forward(s, x, (1, 1, 1, 1), train=train)),
+        "densenet_drop_64_b4": (lambda: DenseNet(32, cfg, 64, drop_rate=P_DROP, num_classes=n_cls), 4, 64, None),
+        "aadensenet_norel_64_b2": (lambda: DenseNet(32, (6, 4, 2, 2), 64, num_classes=n_cls, attn_params=attn(relative=False)), 2, 64,
+                                   lambda s, x, train: nets.densenet_forward(s, x, (6, 4, 2, 2), train=train, nh=8)),
+        "aadensenet_v04_64_b2": (lambda: DenseNet(32, (6, 4, 2, 2), 64, num_classes=n_cls, attn_params=attn(v=0.4)), 2, 64,
+                                 lambda s, x, train: nets.densenet_forward(s, x, (6, 4, 2, 2), train=train, nh=8)),
+    }
+    for tag, (make, B, S, fwd) in jobs.items():
+        model = make()
+        shapes = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+        spec = OrderedDict((k, tuple(sh)) for k, sh in shapes)
+        sd = filled_sd(spec, 21)
+        x = synth.xray_batch(1234, B, S)
+        t = synth.targets(99, B, n_cls)
+        if fwd is None:
+            # drop_rate: eval applies no dropout; train with injected keep decisions (block b, layer l in forward order)
+            calls = []
+            real_dropout = nn.functional.dropout
+
+            def injected(y, p=0.5, training=True, inplace=False):
+                assert training and abs(p - P_DROP) < 1e-12
+                i = len(calls)
+                b, l = i // cfg[0] + 1, i % cfg[0] + 1          # (every block of this fixture has two layers)
+                calls.append((b, l))
+                Bn, C_, H_, W_ = y.shape
+                keep = nets.drop_keep(SEED, (b - 1) * 256 + (l - 1), (Bn, H_, W_, C_), p).permute(0, 3, 1, 2)
+                return torch.where(keep, y / (1 - p), torch.zeros(()))
+
+            def drop(b, l, y):
+                Bn, C_, H_, W_ = y.shape
+                keep = nets.drop_keep(SEED, (b - 1) * 256 + (l - 1), (Bn, H_, W_, C_), P_DROP).permute(0, 3, 1, 2)
+                return torch.where(keep, y / (1 - P_DROP), torch.zeros(()))
+            fwd = lambda s_, xx, train: nets.densenet_forward(s_, xx, cfg, train=train, drop=drop)
+            nn.functional.dropout = lambda y, p=0.5, training=True, inplace=False: (injected(y, p, training, inplace) if training else y)
+            try:
+                run_net(model, sd, x, t, tag, out, fwd)
+            finally:
+                nn.functional.dropout = real_dropout
+            assert calls == [(b, l) for b in range(1, 5) for l in range(1, cfg[0] + 1)], calls
+            out[tag].update(drop_rate=P_DROP, drop_seed=SEED)
+        else:
+            run_net(model, sd, x, t, tag, out, fwd)
+        out[tag].update(B=B, S=S, n_classes=n_cls, sd_seed=21, x_seed=1234, t_seed=99, shapes=shapes)
+        del model
+    json.dump(out, open(os.path.join(out_dir, "options.json"), "w"))
 
 
 def gen_dataset(out_dir):
@@ -509,6 +596,12 @@ if __name__ == "__main__":
             sys.exit(0)
     if "smooth" in which:              # python make_golden.py smooth [tag substrings]
         gen_smooth(HERE, [w for w in which if w != "smooth"])
+        sys.exit(0)
+    if "options" in which:             # python make_golden.py options
+        gen_options(HERE)
+        sys.exit(0)
+    if "yardstick" in which:           # python make_golden.py yardstick <tag substrings>: renew bf16_storage_* of recorded fixtures only
+        gen_smooth(HERE, [w for w in which if w != "yardstick"], yard_only=True)
         sys.exit(0)
     net_sel = [w for w in which if w not in ("aaconv", "auroc", "gradcam", "nets", "dataset")]
     if not which or "nets" in which or net_sel:

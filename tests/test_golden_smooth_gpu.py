@@ -156,10 +156,14 @@ CASES = {
     "densenet121_320_b8": (1e-2, 1e-2, 0.05, 0.05),
     "aadensenet121_320_b8": (1e-2, 1e-2, 0.05, 0.05),
     "resnet152_320_b8": (1e-2, 1e-2, 0.05, 0.05),
-    # aaresnet152 (not a BASELINE configuration): an ill-conditioned fixture -- across this round's kernel changes, each of them bit-exact
-    # or within accumulation order at kernel level, it moved between 4.7e-2 and 5.9e-2 (logits), 7e-3 and 9.5e-3 (loss), 9 % and 11 %
-    # (BatchNorm gains of layer1 / layer2); the bounds bracket that spread, the statement about the kernels is the fp32 mode's 7.5e-6
-    "aaresnet152_320_b8": (7e-2, 1.5e-2, 0.25, 0.15),
+    # aaresnet152 (not a BASELINE configuration): an ill-conditioned fixture, held to a multiple of what bf16 STORAGE alone does to it --
+    # None: the limits are YARD x the fixture's `bf16_storage_yardstick` (the fp32 oracle with nothing but the stored tensors rounded
+    # to bf16 against the reference: logits 5.1e-2, loss 6.0e-3, weight-gradient norms 9.9 %, norm-parameter norms 9.7 %; recorded by
+    # `make_golden.py yardstick`).  Not a hand-set number: round 4 widened hand-set bounds when the measurement moved 4.7e-2 -> 5.9e-2;
+    # the bisection asked for (profiles/r05_bisect_aares.txt) shows no switch owns that move -- single-plane stream 4.5e-2, default
+    # 4.9e-2, separate joins 5.0e-2, lo plane on EVERY join (strictly more precise) 6.2e-2 / 5.3e-2: the fixture amplifies any change of
+    # rounding or summation order by +-1e-2.  The statement about the kernels is the fp32 mode's 7.5e-6 (test_fp32_gpu.py).
+    "aaresnet152_320_b8": None,
     # EfficientNets: logits 4.5e-3 / 7.4e-3 (deterministic engine: the same at every batch geometry).  Gradient norms agree to 5 % except
     # the squeeze-excite reduce convolutions (blocks.*.6.1 / .3.1: 7.6 % on b0, 10.2 % on b4): ds = sum_hw du * swish(bn(y)) is a sum
     # with heavy cancellation over bf16-rounded du -- the same tensors are 1e-5 from the reference in the fp32 mode (test_fp32_gpu.py)
@@ -192,13 +196,23 @@ DIRECTION = {       # measured (x1 and at the BASELINE batch)            worst e
 }
 
 
+YARD = 2.0      # the HIP path also rounds the MFMA operands, which the storage yardstick does not model
+
+
+def _limits(tag, rec):
+    if CASES[tag] is not None:
+        return CASES[tag]
+    y = rec["bf16_storage_yardstick"]
+    return (YARD * y["logits"], YARD * y["loss"], YARD * y["weight_grad_norm"], YARD * y["norm_grad_norm"])
+
+
 @pytest.mark.parametrize("tag", list(CASES))
 def test_train_step_matches_reference_smooth_fixture(dev, golden, tag):
     rec = golden[tag]
     model, sd = _make(tag, rec["n_classes"])
     assert sum(p.numel() for p in model.parameters()) == rec["n_params"]
     model = model.to(dev)
-    _check_step(tag, rec, model, dev, 1, *CASES[tag])
+    _check_step(tag, rec, model, dev, 1, *_limits(tag, rec))
     after = model.state_dict()
     for k, r in rec["running"].items():                          # BatchNorm running statistics after the step
         f = after[k].detach().double().flatten().cpu()

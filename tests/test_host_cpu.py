@@ -541,7 +541,8 @@ a = data.ChexpertCSV(%r, "train", resize=64)
 b = data.ChexpertCSV(%r, "train", resize=64)
 assert a.enable_decoded_cache(max_bytes=1 << 20, node_shared=True) and b.enable_decoded_cache(max_bytes=1 << 20, node_shared=True)
 files = glob.glob("/dev/shm/chexpert_amd_cache_%%d_*" %% os.getuid())
-assert len(files) == 2, files
+assert sorted(f.rsplit(".", 1)[1] for f in files) == ["have", "owner", "rows"], files
+assert all((os.stat(f).st_mode & 0o777) == 0o600 for f in files), [oct(os.stat(f).st_mode) for f in files]
 x = [a[i][0].clone() for i in range(3)]
 assert b.cache_fill() == 0.5
 data.resize_center_crop = None                       # a decode through b would now raise
@@ -551,6 +552,25 @@ print("SHARED-OK")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SHARED-OK" in r.stdout, r.stderr[-2000:]
     assert not glob.glob("/dev/shm/chexpert_amd_cache_%d_*" % os.getuid()), "the creating process did not unlink the table"
+    # a creator that was killed leaves its files behind with `have` flags nobody may trust: the next run starts the table over
+    # (the owner file names a dead pid), and a dataset regenerated in the same folder gets another key (index file size / mtime)
+    code2 = r"""
+import sys, glob, os, signal
+sys.path.insert(0, %r)
+from chexpert_amd import data
+a = data.ChexpertCSV(%r, "train", resize=64)
+assert a.enable_decoded_cache(max_bytes=1 << 20, node_shared=True)
+if sys.argv[1] == "die":
+    a[0]; a[1]
+    assert a.cache_fill() > 0
+    os.kill(os.getpid(), signal.SIGKILL)
+print("FILL %%.3f" %% a.cache_fill())
+""" % (ROOT, root)
+    r = subprocess.run([sys.executable, "-c", code2, "die"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and len(glob.glob("/dev/shm/chexpert_amd_cache_%d_*" % os.getuid())) == 3, "the killed creator's files stay"
+    r = subprocess.run([sys.executable, "-c", code2, "next"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FILL 0.000" in r.stdout, (r.stdout, r.stderr[-1500:])
+    assert not glob.glob("/dev/shm/chexpert_amd_cache_%d_*" % os.getuid())
 
 
 def test_library_and_torch_share_one_hip_runtime():

@@ -173,12 +173,15 @@ def test_two_layers_per_pass_backward_equals_layer_by_layer(dev, monkeypatch, cf
     assert any(not torch.equal(res["all"][1][k], g) for k, g in res["0"][1].items()), "the pair schedule did not run"
 
 
-@pytest.mark.parametrize("dtype,p", [("bf16", 0.25), ("fp32", 0.5)])
-def test_drop_rate_matches_oracle_with_the_same_keep_decisions(dev, dtype, p):
+@pytest.mark.parametrize("dtype,p,serial", [("bf16", 0.25, "1"), ("fp32", 0.5, "1"), ("fp32", 0.5, "0"), ("bf16", 0.25, "0")])
+def test_drop_rate_matches_oracle_with_the_same_keep_decisions(dev, dtype, p, serial, monkeypatch):
     """DenseNet(drop_rate=p) (torchvision _DenseLayer: F.dropout on each layer's new features; attn_aug_conv.py:453, :479-481): the
     fused schedule with the in-place dropout kernels against the fp32 oracle fed the kernels' own keep decisions (a numpy
     restatement of the counter hash; torch's Philox stream cannot be reproduced outside torch).  Also: eval mode applies no
-    dropout, a second step draws other decisions, and the kept fraction is 1 - p."""
+    dropout, a second step draws other decisions, and the kept fraction is 1 - p.  serial = "0": the conv2 weight gradients on a
+    separate side stream (CHEXPERT_SERIAL_WGRAD=0) -- in fp32 mode they read the gradient slice the dropout backward rewrites in
+    place, so the side stream must wait for an event recorded AFTER that rewrite."""
+    monkeypatch.setenv("CHEXPERT_SERIAL_WGRAD", serial)
     from chexpert_amd import ops
     from chexpert_amd.models import DenseNet
     from oracle import nets, step

@@ -107,6 +107,62 @@ def test_densenet_bc_against_reference_fixture(tag, n):
         _summary_close(g, rec["grads"][k], rtol=2e-3, atol=1e-5 * gmax)
 
 
+OPTIONS = {
+    # tag -> oracle forward (the parameter shapes come from the fixture: these networks are driven by the state_dict alone)
+    "resnet_dilate_64_b2": lambda rec: (lambda s, x, train: nets.resnet_forward(s, x, (1, 2, 1, 1), train=train, dilate=(False, True, True))),
+    "resnet_groups4_w16_64_b2": lambda rec: (lambda s, x, train: nets.resnet_forward(s, x, (1, 1, 1, 1), train=train)),
+    "resnet_wide128_64_b2": lambda rec: (lambda s, x, train: nets.resnet_forward(s, x, (1, 1, 1, 1), train=train)),
+    "densenet_drop_64_b4": lambda rec: (lambda s, x, train: nets.densenet_forward(s, x, (2, 2, 2, 2), train=train, drop=_drop_fn(rec))),
+    "aadensenet_norel_64_b2": lambda rec: (lambda s, x, train: nets.densenet_forward(s, x, (6, 4, 2, 2), train=train, nh=8)),
+    "aadensenet_v04_64_b2": lambda rec: (lambda s, x, train: nets.densenet_forward(s, x, (6, 4, 2, 2), train=train, nh=8)),
+}
+
+
+def _drop_fn(rec):
+    p, seed = rec["drop_rate"], rec["drop_seed"]
+
+    def drop(b, l, y):
+        Bn, C_, H_, W_ = y.shape
+        keep = nets.drop_keep(seed, (b - 1) * 256 + (l - 1), (Bn, H_, W_, C_), p).permute(0, 3, 1, 2)
+        return torch.where(keep, y / (1 - p), torch.zeros(()))
+    return drop
+
+
+@pytest.mark.parametrize("tag", list(OPTIONS))
+def test_constructor_options_against_reference_fixture(tag):
+    """The oracle branches behind the constructor options (tests/golden/options.json, recorded from the real reference by
+    `make_golden.py options`): ResNet replace_stride_with_dilation / groups + width_per_group / wide Bottlenecks
+    (models/attn_aug_conv.py:218-220, :168, :183, :266-271), DenseNet drop_rate in eval mode and in train mode with the keep
+    decisions injected through F.dropout (:453, :479-481: after conv2, before the concatenation), attention without position
+    tables (`relative=False`, :38, :76) and a value ratio of 0.4 (:417-427).  The GPU tests of these options compare the HIP path
+    with exactly these oracle branches."""
+    from collections import OrderedDict
+    rec = json.load(open(os.path.join(G, "options.json")))[tag]
+    spec = OrderedDict((k, tuple(sh)) for k, sh in rec["shapes"])
+    assert len(spec) == rec["keys"]
+    fwd = OPTIONS[tag](rec)
+    sd = synth.fill_state_dict_(nets.zeros_state_dict(spec), rec["sd_seed"])
+    assert sum(v.numel() for k, v in sd.items() if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))) == rec["n_params"]
+    x = synth.xray_batch(rec["x_seed"], rec["B"], rec["S"])
+    t = synth.targets(rec["t_seed"], rec["B"], rec["n_classes"])
+    with torch.no_grad():
+        le = fwd({k: v.clone() for k, v in sd.items()}, x, False)
+    np.testing.assert_allclose(le.numpy(), np.array(rec["logits_eval"]), rtol=0, atol=2e-5)
+    loss, lt, grads = step.train_step(lambda s, xx: fwd(s, xx, True), sd, x, t)
+    np.testing.assert_allclose(lt.numpy(), np.array(rec["logits_train"]), rtol=0, atol=2e-5)
+    assert abs(float(loss) - rec["loss"]) < 2e-5
+    assert set(grads) == set(rec["grads"])
+    gmax = max(r["l2"] for r in rec["grads"].values())
+    for k, g in grads.items():
+        _summary_close(g, rec["grads"][k], rtol=2e-3, atol=1e-5 * gmax)
+    for k, r in rec["running"].items():
+        _summary_close(sd[k], r, rtol=1e-5, atol=1e-6)
+    if "drop" in tag:          # the fixture is a statement about dropout: without the decisions the train logits differ
+        _, lt0, _ = step.train_step(lambda s, xx: nets.densenet_forward(s, xx, (2, 2, 2, 2), train=True),
+                                    synth.fill_state_dict_(nets.zeros_state_dict(spec), rec["sd_seed"]), x, t)
+        assert (lt0 - torch.tensor(rec["logits_train"])).abs().max().item() > 1e-3
+
+
 def test_param_counts_match_reference_constructors():
     c = json.load(open(os.path.join(G, "param_counts.json")))
     assert nets.param_count(nets.densenet_spec(14)) == c["densenet121@14"] == 6968206
