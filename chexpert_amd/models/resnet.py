@@ -143,10 +143,12 @@ class _Engine:
                 self.blocks.append(blk)
         self.basic = model.block is BasicBlock                 # two 3x3 convolutions per block (attn_aug_conv.py:107-156)
         self.two_plane = self.stream_lo and not (model.block is BasicBlock) and self.dtype == torch.bfloat16
-        # Where the stream keeps its lo plane: on the outputs that feed an identity join of a LONG stage (>= 6 blocks: layer2 / layer3 of
-        # resnet152, 42 of its 50 joins).  The joins of the short stages, the downsample blocks' joins and the last one round to bf16 as
-        # before (8 roundings instead of 50: the stream's share of the logit error falls from 0.9e-2 to 0.36e-2); there the fused
-        # prologue does not pay either (layer1: N = 64 on a 256-wide tile; layer4: MFMA-bound) -- scratch/bench_join.py.
+        # Where the stream keeps its lo plane: on every output that feeds an identity join (round 5; 46 of resnet152's 50 joins --
+        # the four downsample blocks' outputs start a stage and are rounded once).  Round 4 kept it only through the long stages
+        # (layer2 / layer3: 42 joins) and measured 8.3e-3 on the reference fixture's train logits at 128 images; on every identity
+        # join it is 6.9e-3 for +0.36 ms of the 54.2 ms step (profiles/r05_resnet_margin.txt): kept, the 1e-2 bound then has 30 %
+        # of room instead of 17 %.  The FUSED form (the join in the prologue of the next conv1) stays with the long stages: it does
+        # not pay on layer1 (N = 64 on a 256-wide tile) nor layer4 (MFMA-bound) -- scratch/bench_join.py.
         # keep_lo[bi]: block bi's output has a lo plane;  fuse_fwd[bi]: its join runs in the prologue of block bi + 1's conv1.
         n = len(self.blocks)
         stage_len = []
@@ -155,7 +157,7 @@ class _Engine:
         ident = [b.downsample is None for b in self.blocks]
         long_id = [ident[i] and stage_len[i] >= 6 for i in range(n)]
         # (CHEXPERT_STREAM_LO_MIN=<blocks>: the stage length from which the lo plane is kept, for measurements -- 1 = on every identity join)
-        lo_min = int(os.environ.get("CHEXPERT_STREAM_LO_MIN", "6"))
+        lo_min = int(os.environ.get("CHEXPERT_STREAM_LO_MIN", "1"))
         lo_id = [ident[i] and stage_len[i] >= lo_min for i in range(n)]
         self.keep_lo = [self.two_plane and i + 1 < n and lo_id[i + 1] for i in range(n)]
         self.fuse_fwd = [self.two_plane and self.fwd_join_fuse and long_id[i] and i + 1 < n for i in range(n)]
