@@ -161,6 +161,10 @@ SIGNATURES = {
     "cx_gap_affine_act": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_int64, _vp],
     "cx_gap_affine_act_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_int64, _vp],
     "cx_se_fwd": [_vp] * 7 + [_i, _i, _i, _vp],
+    "cx_se_bwd_fused": [_vp] * 15 + [_i, _i, _i, _i, _vp, C.c_int64, _vp, C.c_int64, _vp],
+    "cx_se_bwd_fused_f32": [_vp] * 15 + [_i, _i, _i, _i, _vp, C.c_int64, _vp, C.c_int64, _vp],
+    "cx_gap_se_fwd": [_vp] * 10 + [_i, _i, _i, _i, _i, _vp, C.c_int64, _vp],
+    "cx_gap_se_fwd_f32": [_vp] * 10 + [_i, _i, _i, _i, _i, _vp, C.c_int64, _vp],
     "cx_se_bwd": [_vp] * 11 + [_i, _i, _i, _vp, C.c_int64, _vp],
     "cx_scale_act_bc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "cx_scale_act_bc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

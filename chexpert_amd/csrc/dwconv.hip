@@ -567,6 +567,10 @@ int launch_cfg(int which, const DwArgs& a, DwGeo g, hipStream_t st) {
   const int ntiles = g.B * g.tiles_y * g.tiles_x;
   int gx = 2048 / cblocks;                       // workgroups stay persistent: one flush of statistics / dW each
   if (gx < 64) gx = 64;
+  // a multiple of 8: workgroup (x, y) has linear id x + y * gx and XCD id % 8, so the channel blocks y of one pixel tile x then share
+  // an XCD -- a 32-channel block reads 64 bytes of a pixel, HALF a 128-byte line; with gx = 341 (C = 192) the two halves of every
+  // line went to two L2s and crossed the fabric twice (PMC: 1.9x the tensors' bytes on the 190x190 / 95x95 maps)
+  gx &= ~7;
   if (gx > ntiles) gx = ntiles;
   g.det = 0; g.rstride = g.C;
   if (which != 2 && a.stat_rows > 0 && a.s1) {       // one statistic row per blockIdx.x (every channel block writes its part of it)

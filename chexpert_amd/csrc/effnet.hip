@@ -345,27 +345,56 @@ __global__ void gap_affine_act_kernel(const T* __restrict__ x, const float* __re
   for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&pooled[(size_t)b * C + c], lds[c] * inv);
 }
 
-// SE excitation: h1 = W1 pooled + b1; s = sigmoid(W2 swish(h1) + b2)      one block per sample
+// SE excitation: h1 = W1 pooled + b1; s = sigmoid(W2 swish(h1) + b2)
+// Round 5: grid (sample, channel slice).  One 1024-thread block per sample left 192 of the 256 CUs idle at bs = 64 and walked each W1
+// row with ONE load in flight per lane (41 us per launch, 32 launches per B4 step).  Every block now computes the whole h1 of its
+// sample (R x C multiply-adds: cheap) with the sample's pooled vector in LDS and four W1 rows per wave in flight, then its slice of the
+// second product; block (b, 0) stores h1.  The sums keep their order (lane-strided partials, xor butterfly): bit-identical results.
 __global__ __launch_bounds__(1024) void se_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
                               const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h1, float* __restrict__ s,
-                              int C, int R) {
-  extern __shared__ float lds[];          // [R] swish(h1)
+                              int C, int R, int c_per_slice, const float* __restrict__ rows, int n_rows, float* __restrict__ pooled_out) {
+  extern __shared__ float lds[];          // [R] swish(h1) | [C] pooled of this sample
+  float* pl = lds + R;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int r = wave; r < R; r += nw) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a = fmaf(w1[(size_t)r * C + c], pooled[(size_t)b * C + c], a);
+  if (rows) {
+    // cx_gap_se_fwd: the pool's per-split partial means (row sp of sample b at rows[(sp * B + b) * C + c]) are added here, in row
+    // order, instead of by a launch of their own between the pool and this kernel; block (b, 0) leaves the sum for the backward pass
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float t = 0.f;
+      for (int sp = 0; sp < n_rows; ++sp) t += rows[((size_t)sp * gridDim.x + b) * C + c];
+      pl[c] = t;
+      if (blockIdx.y == 0) pooled_out[(size_t)b * C + c] = t;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) pl[c] = pooled[(size_t)b * C + c];
+  }
+  __syncthreads();
+  for (int r0 = wave * 4; r0 < R; r0 += nw * 4) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* wr[4];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
-    if (lane == 0) {
-      a += b1[r];
-      h1[(size_t)b * R + r] = a;
-      lds[r] = swishf_(a);
+    for (int j = 0; j < 4; ++j) wr[j] = w1 + (size_t)min(r0 + j, R - 1) * C;
+    for (int c = lane; c < C; c += 64) {
+      const float pv = pl[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = fmaf(wr[j][c], pv, a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) a[j] += __shfl_xor(a[j], d);
+      if (lane == 0 && r0 + j < R) {
+        const float v = a[j] + b1[r0 + j];
+        if (blockIdx.y == 0) h1[(size_t)b * R + r0 + j] = v;
+        lds[r0 + j] = swishf_(v);
+      }
     }
   }
   __syncthreads();
   // eight lanes per channel: a W2 row (R contiguous floats) is read 32 B at a time, the partial sums meet in a fixed butterfly
   const int l8 = threadIdx.x & 7;
-  for (int c = threadIdx.x >> 3; c < C; c += blockDim.x >> 3) {
+  const int c_lo = blockIdx.y * c_per_slice, c_hi = min(C, c_lo + c_per_slice);
+  for (int c = c_lo + (threadIdx.x >> 3); c < c_hi; c += blockDim.x >> 3) {
     float a = 0.f;
     for (int r = l8; r < R; r += 8) a = fmaf(w2[(size_t)c * R + r], lds[r], a);
     a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
@@ -567,7 +596,7 @@ __global__ __launch_bounds__(1024) void se_bwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(512) void se_bwd_a_kernel(const float* __restrict__ ds, const float* __restrict__ s,
                                                        const float* __restrict__ h1, const float* __restrict__ w2, float* dw2,
                                                        float* db2, float* __restrict__ part, int B, int C, int R, int CS,
-                                                       float* sl_w2, float* sl_b2) {
+                                                       float* sl_w2, float* sl_b2, const float* __restrict__ ds_rows, int n_rows) {
   extern __shared__ float lds[];          // [16][CS] dlogit2 of the slice, [16][R] a1 = swish(h1)
   float* dl2 = lds;
   float* a1 = lds + 16 * CS;
@@ -579,7 +608,14 @@ __global__ __launch_bounds__(512) void se_bwd_a_kernel(const float* __restrict__
     const int gi = i / ncs, cl = i - gi * ncs;
     const size_t at = (size_t)(b0 + gi) * C + cs0 + cl;
     const float sv = s[at];
-    dl2[gi * CS + cl] = ds[at] * sv * (1.f - sv);
+    float dsv;
+    if (ds_rows) {       // cx_se_bwd_fused: the reduce kernel's per-split partial sums, added here in row order (no launch between)
+      dsv = 0.f;
+      for (int sp = 0; sp < n_rows; ++sp) dsv += ds_rows[(size_t)sp * B * C + at];
+    } else {
+      dsv = ds[at];
+    }
+    dl2[gi * CS + cl] = dsv * sv * (1.f - sv);
   }
   __syncthreads();
   float* prow = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 * R;
@@ -1000,6 +1036,45 @@ int scale_rows_t(const void* g, const float* sample_scale, size_t rows_per_sampl
 
 }  // namespace
 
+static int se_fwd_launch(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B,
+                         int C, int R, const float* rows, int n_rows, float* pooled_out, void* stream) {
+  CX_KTAG("se_fwd_kernel");
+  if ((size_t)(R + C) * sizeof(float) > 64 * 1024) return CX_ESHAPE;
+  // channel slices so that B x slices fills the chip (each block repeats the first product: slices <= 8)
+  int slices = B >= 256 ? 1 : (256 + B - 1) / B;
+  if (slices > 8) slices = 8;
+  const int cps = ((C + slices - 1) / slices + 127) / 128 * 128;      // whole passes of the 128 channels a block's threads cover
+  slices = (C + cps - 1) / cps;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&se_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(se_fwd_kernel, dim3(B, slices), dim3(1024), (size_t)(R + C) * sizeof(float), as_stream(stream), pooled, w1, b1, w2, b2,
+                     h1, s, C, R, cps, rows, n_rows, pooled_out);
+  return launch_status();
+}
+
+// squeeze + excite as two launches: the pool's split rows are summed by the excitation kernel (no reduce launch between them)
+template <typename T>
+static int gap_se_fwd_t(const void* x, const float* sc, const float* sh, float* pooled, const float* w1, const float* b1, const float* w2,
+                        const float* b2, float* h1, float* s, int B, int HW, int C, int R, int act, float* scratch, int64_t scratch_floats,
+                        void* stream) {
+  if (!x || !sc || !sh || !pooled || !w1 || !b1 || !w2 || !b2 || !h1 || !s || R <= 0 || R > 1024 || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  int splits = 1024 / B;
+  if (splits < 1) splits = 1;
+  if (splits > HW / 16 + 1) splits = HW / 16 + 1;
+  if (!scratch || (int64_t)splits * B * C > scratch_floats) {          // no row workspace: the three-launch form (atomics)
+    if (const int e = gap_affine_act_t<T>(x, sc, sh, pooled, B, HW, C, act, scratch, scratch_floats, stream)) return e;
+    return cx_se_fwd(pooled, w1, b1, w2, b2, h1, s, B, C, R, stream);
+  }
+  const size_t smem = det_smem(C * sizeof(float), th, 1, true);
+  hipLaunchKernelGGL(gap_affine_act_kernel<T>, dim3(splits, B), dim3(th), smem, as_stream(stream), (const T*)x, sc, sh, pooled, HW, C, act,
+                     splits, scratch);
+  if (const int e = launch_status()) return e;
+  return se_fwd_launch(nullptr, w1, b1, w2, b2, h1, s, B, C, R, scratch, splits, pooled, stream);
+}
 extern "C" {
 
 int cx_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, void* stream) {
@@ -1059,9 +1134,18 @@ int cx_gap_affine_act_f32(const void* x, const float* sc, const float* sh, float
 int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
               int R, void* stream) {
   if (!pooled || !w1 || !b1 || !w2 || !b2 || !h1 || !s || R <= 0 || R > 1024) return CX_EINVAL;
-  CX_KTAG("se_fwd_kernel");
-  hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(1024), R * sizeof(float), as_stream(stream), pooled, w1, b1, w2, b2, h1, s, C, R);
-  return launch_status();
+  return se_fwd_launch(pooled, w1, b1, w2, b2, h1, s, B, C, R, nullptr, 0, nullptr, stream);
+}
+
+int cx_gap_se_fwd(const void* x, const float* sc, const float* sh, float* pooled, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* h1, float* s, int B, int HW, int C, int R, int act, float* scratch, int64_t scratch_floats,
+                  void* stream) {
+  return gap_se_fwd_t<bf16>(x, sc, sh, pooled, w1, b1, w2, b2, h1, s, B, HW, C, R, act, scratch, scratch_floats, stream);
+}
+int cx_gap_se_fwd_f32(const void* x, const float* sc, const float* sh, float* pooled, const float* w1, const float* b1, const float* w2,
+                      const float* b2, float* h1, float* s, int B, int HW, int C, int R, int act, float* scratch, int64_t scratch_floats,
+                      void* stream) {
+  return gap_se_fwd_t<float>(x, sc, sh, pooled, w1, b1, w2, b2, h1, s, B, HW, C, R, act, scratch, scratch_floats, stream);
 }
 
 int cx_scale_act_bc(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream) {
@@ -1089,10 +1173,12 @@ int cx_se_bwd_reduce_f32(const void* du, const void* x, const float* sc, const f
   return se_bwd_reduce_t<float>(du, x, sc, sh, ds, B, HW, C, scratch, scratch_floats, stream);
 }
 
-int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
-              float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, float* scratch, int64_t scratch_floats,
-              void* stream) {
-  if (!ds || !s || !h1 || !pooled || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpooled || R <= 0) return CX_EINVAL;
+// ds_rows != nullptr: the per-(image, channel) sums arrive as n_rows split rows (two-pass form only: returns CX_ESHAPE when it
+// cannot run, the caller then reduces the rows into ds and calls again without them)
+static int se_bwd_impl(const float* ds, const float* ds_rows, int n_rows, const float* s, const float* h1, const float* pooled, const float* w1,
+                       const float* w2, float* dw1, float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, float* scratch,
+                       int64_t scratch_floats, void* stream) {
+  if ((!ds && !ds_rows) || !s || !h1 || !pooled || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpooled || R <= 0) return CX_EINVAL;
   hipStream_t st = as_stream(stream);
   {
     // two-pass form: needs a workspace for the slabs (one per group of 16 images) and the slices' partial dh1 rows
@@ -1105,7 +1191,7 @@ int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* poo
       float* part = wsb + nslab;
       CX_KTAG("se_bwd_a_kernel");
       hipLaunchKernelGGL(se_bwd_a_kernel, dim3(groups, slices), dim3(512), smem_a, st, ds, s, h1, w2, dw2, db2, part, B, C, R, CS, s2,
-                         sb2);
+                         sb2, ds_rows, n_rows);
       hipLaunchKernelGGL(se_bwd_b_kernel, dim3(groups, slices), dim3(512), smem_b, st, (const float*)part, h1, pooled, w1, dw1, db1,
                          dpooled, B, C, R, CS, s1, sb1);
       if (const int e = launch_status()) return e;
@@ -1117,6 +1203,7 @@ int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* poo
       return e;
     }
   }
+  if (ds_rows) return CX_ESHAPE;
   // no workspace: one kernel, fp32 atomics for the weight gradients
   int G = (int)((120 * 1024) / ((size_t)(C + 2 * R) * sizeof(float)));      // images per workgroup: what 120 KB of LDS hold, at most 16
   if (G > 16) G = 16;
@@ -1132,6 +1219,59 @@ int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* poo
   hipLaunchKernelGGL(se_bwd_kernel, dim3(groups, (C + CS - 1) / CS), dim3(1024), smem, st, ds, s, h1, pooled, w1, w2,
                      dw1, db1, dw2, db2, dpooled, B, C, R, G, CS, nullptr, nullptr, nullptr, nullptr);
   return launch_status();
+}
+
+int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
+              float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, float* scratch, int64_t scratch_floats,
+              void* stream) {
+  return se_bwd_impl(ds, nullptr, 0, s, h1, pooled, w1, w2, dw1, db1, dw2, db2, dpooled, B, C, R, scratch, scratch_floats, stream);
+}
+
+}  // extern "C" (a template follows)
+
+// SELayer backward up to d pooled in three launches instead of four: the reduce kernel's split rows go straight into the first FC
+// pass (cx_se_bwd_reduce + cx_se_bwd with the rows summed by se_bwd_a_kernel); `ds` is only written when the fused form cannot run
+template <typename T>
+static int se_bwd_fused_t(const void* du, const void* x, const float* sc, const float* sh, float* ds, const float* s, const float* h1,
+                          const float* pooled, const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2, float* dpooled,
+                          int B, int HW, int C, int R, float* rows_scratch, int64_t rows_floats, float* scratch, int64_t scratch_floats,
+                          void* stream) {
+  if (!du || !x || !sc || !sh || !ds || C % 8 || C / 8 > 1024) return CX_EINVAL;
+  const int CP = C / 8, th = threads_for(CP);
+  int splits = 1024 / B;
+  if (splits < 1) splits = 1;
+  if (splits > HW / 16 + 1) splits = HW / 16 + 1;
+  const bool rows_ok = rows_scratch && (int64_t)splits * B * C <= rows_floats;
+  if (rows_ok) {
+    const size_t smem = det_smem(C * sizeof(float), th, 1, true);
+    hipLaunchKernelGGL(se_bwd_reduce_kernel<T>, dim3(splits, B), dim3(th), smem, as_stream(stream), (const T*)du, (const T*)x, sc, sh, ds, HW,
+                       C, splits, rows_scratch);
+    if (const int e = launch_status()) return e;
+    const int rc = se_bwd_impl(nullptr, rows_scratch, splits, s, h1, pooled, w1, w2, dw1, db1, dw2, db2, dpooled, B, C, R, scratch,
+                               scratch_floats, stream);
+    if (rc != CX_ESHAPE) return rc;
+    if (const int e = cx_rows_reduce(ds, rows_scratch, splits, B * C, B * C, 0, stream)) return e;      // (no slab workspace: the old sequence)
+  } else if (const int e = se_bwd_reduce_t<T>(du, x, sc, sh, ds, B, HW, C, rows_scratch, rows_floats, stream)) {
+    return e;
+  }
+  return se_bwd_impl(ds, nullptr, 0, s, h1, pooled, w1, w2, dw1, db1, dw2, db2, dpooled, B, C, R, scratch, scratch_floats, stream);
+}
+
+extern "C" {
+
+int cx_se_bwd_fused(const void* du, const void* x, const float* sc, const float* sh, float* ds, const float* s, const float* h1,
+                    const float* pooled, const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2, float* dpooled,
+                    int B, int HW, int C, int R, float* rows_scratch, int64_t rows_floats, float* scratch, int64_t scratch_floats,
+                    void* stream) {
+  return se_bwd_fused_t<bf16>(du, x, sc, sh, ds, s, h1, pooled, w1, w2, dw1, db1, dw2, db2, dpooled, B, HW, C, R, rows_scratch, rows_floats,
+                              scratch, scratch_floats, stream);
+}
+int cx_se_bwd_fused_f32(const void* du, const void* x, const float* sc, const float* sh, float* ds, const float* s, const float* h1,
+                        const float* pooled, const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2, float* dpooled,
+                        int B, int HW, int C, int R, float* rows_scratch, int64_t rows_floats, float* scratch, int64_t scratch_floats,
+                        void* stream) {
+  return se_bwd_fused_t<float>(du, x, sc, sh, ds, s, h1, pooled, w1, w2, dw1, db1, dw2, db2, dpooled, B, HW, C, R, rows_scratch, rows_floats,
+                               scratch, scratch_floats, stream);
 }
 
 int cx_se_act_bwd(const void* du, const void* x, const float* sc, const float* sh, const float* mean, const float* rstd, const float* s,

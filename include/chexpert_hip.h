@@ -504,9 +504,30 @@ int cx_gap_affine_act(const void* x, const float* sc, const float* sh, float* po
 /* SELayer FCs (:70-73): h1 = W1 pooled + b1, s = sigmoid(W2 swish(h1) + b2); and their backward                */
 int cx_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h1, float* s, int B, int C,
               int R, void* stream);
+/* ABI 10.  SELayer squeeze + excitation (:69-73) as TWO launches: cx_gap_affine_act's per-split partial means are added by the
+ * excitation kernel itself (in row order: reproducible), which also leaves pooled[b][c] for the backward pass -- the reduce launch
+ * between the two is gone (33 launches per EfficientNet-B4 step).  scratch as for cx_gap_affine_act; NULL / too small: the
+ * three-launch form with atomics.                                                                                        */
+int cx_gap_se_fwd(const void* x, const float* sc, const float* sh, float* pooled, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* h1, float* s, int B, int HW, int C, int R, int act, float* scratch, int64_t scratch_floats,
+                  void* stream);
+int cx_gap_se_fwd_f32(const void* x, const float* sc, const float* sh, float* pooled, const float* w1, const float* b1, const float* w2,
+                      const float* b2, float* h1, float* s, int B, int HW, int C, int R, int act, float* scratch, int64_t scratch_floats,
+                      void* stream);
 int cx_se_bwd(const float* ds, const float* s, const float* h1, const float* pooled, const float* w1, const float* w2, float* dw1,
               float* db1, float* dw2, float* db2, float* dpooled, int B, int C, int R, float* scratch, int64_t scratch_floats,
               void* stream);
+/* ABI 10.  cx_se_bwd_reduce + cx_se_bwd without the reduce launch between them: the split rows of ds[b][c] = sum_hw du * swish(x*sc+sh)
+ * (rows_scratch: splits * B * C floats, as for cx_se_bwd_reduce) are added, in row order, by the first FC pass.  `ds` (B x C) is written
+ * only when that form cannot run (no row / slab workspace: the four-launch sequence with what workspaces there are).            */
+int cx_se_bwd_fused(const void* du, const void* x, const float* sc, const float* sh, float* ds, const float* s, const float* h1,
+                    const float* pooled, const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2, float* dpooled,
+                    int B, int HW, int C, int R, float* rows_scratch, int64_t rows_floats, float* scratch, int64_t scratch_floats,
+                    void* stream);
+int cx_se_bwd_fused_f32(const void* du, const void* x, const float* sc, const float* sh, float* ds, const float* s, const float* h1,
+                        const float* pooled, const float* w1, const float* w2, float* dw1, float* db1, float* dw2, float* db2, float* dpooled,
+                        int B, int HW, int C, int R, float* rows_scratch, int64_t rows_floats, float* scratch, int64_t scratch_floats,
+                        void* stream);
 /* u = swish(x*sc+sh) * s[b][c] (s NULL: no SE scaling)                                                          */
 int cx_scale_act_bc(const void* x, const float* sc, const float* sh, const float* s, void* u, int B, int HW, int C, void* stream);
 int cx_se_bwd_reduce(const void* du, const void* x, const float* sc, const float* sh, float* ds, int B, int HW, int C, float* scratch,
