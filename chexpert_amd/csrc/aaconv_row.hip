@@ -415,13 +415,9 @@ __device__ __forceinline__ bf16x8 tr_frag_k(const char* tile, int pitch, int k0,
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const char* base = tile + (k0 + 8 * (g >> 1) + q) * pitch + (16 * (g & 1) + 4 * pp) * 2;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  U64 lo, hi;
-  lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
-  hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch));
-  bf16x8 r;
-  r[0] = lo.e[0]; r[1] = lo.e[1]; r[2] = lo.e[2]; r[3] = lo.e[3];
-  r[4] = hi.e[0]; r[5] = hi.e[1]; r[6] = hi.e[2]; r[7] = hi.e[3];
-  return r;
+  // (joined by a shuffle + bit cast: assembled element by element the compiler emits a v_bfi per dword on the loaded registers and
+  // waits for the read right where it is issued, not where the MFMA uses it -- common.h cx_join_tr)
+  return cx_join_tr(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch)));
 }
 
 template <int DVH, int WW>

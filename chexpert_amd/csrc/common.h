@@ -28,6 +28,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// the two 4-pixel halves of a transposing LDS read pair (ds_read_b64_tr_b16) as one MFMA operand, with no ALU instruction in between
+typedef short cx_s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 cx_join_tr(const s16x4 lo, const s16x4 hi) {
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 union U128 {
   uint4 u;
   bf16x8 h;

@@ -420,6 +420,376 @@ int launch_pc(const CxConv& p, hipStream_t st, const PcGeo& g) {
   return launch_status();
 }
 
+
+#ifndef CX_PCW_ABL
+#define CX_PCW_ABL 0     // timing ablations of diagnostic builds (results wrong): 1 no MFMAs, 2 fragment reads only in the first k-step, 4 no staging stores
+#endif
+// ================================================================================================= weight gradient
+// dW[n][k][dy][dx] += sum over pixels of dY[px][n] * relu(bn(y1))[px + (dy-1, dx-1)][k]      (K = 128, N = 32; conv3x3_ring.hip's
+// conv3x3_ring_wgrad_kernel and conv3x3_strip.hip hold the forms this one is measured against)
+// The same roles and row space as the forward kernel above, and a better fit for them: there is no per-step epilogue (the 36
+// accumulator tiles of a workgroup live in the consumers' registers until the end) and an MFMA needs ~1.1 KB of LDS fragments, not 2.
+//   * PRODUCERS (waves 4-7): the R new rows of y1 (BN + ReLU while staged; ring of 2R + 2 rows, 320-byte pixels: conflict-free for
+//     the transposing reads) and the R rows of dY of the NEXT step (two buffers of R x P pixels, 64-byte pixels); pad columns,
+//     separator rows and rows outside the workgroup's range are zeros in the dY buffers, so whatever the y1 ring holds beside
+//     them does not count;
+//   * CONSUMERS (waves 0-3): wave w owns input channels [32w, 32w + 32) of all nine taps: nine 32 x 32 accumulators.  The
+//     contraction runs over the flat padded pixels of the step in k-steps of 16: one dY^T fragment serves nine MFMAs, each with
+//     the y1 fragment of its tap's shifted window, all by ds_read_b64_tr_b16 (pixel-major images, the pixel is the contraction
+//     index); one barrier per step.
+//   * at the end the accumulators meet in LDS in OIHW order and leave as one coalesced partial tile per workgroup (slab sums).
+constexpr int AXP = 320;                 // y1 ring pitch: 128 bf16 + 64 B (four consecutive pixels of a transposing read: distinct banks)
+constexpr int GXP = 64;                  // dY pitch: 32 bf16
+
+// two transposing reads = the eight pixels of one MFMA operand.  The halves are joined by a vector shuffle + bit cast: assembled element
+// by element (`r[0] = lo.e[0]; ...`, as the older kernels do) the compiler emits a v_bfi per dword on the loaded registers -- and an
+// s_waitcnt lgkmcnt right behind the read it belongs to, i.e. every fragment read is waited for where it is ISSUED, not where it is used
+__device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  return cx_join_tr(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1)));
+}
+
+template <int NCA, int NCG, int DEPTH, bool g_affine2>
+__global__ __launch_bounds__(NT, 1) void conv3x3_pc_wgrad_kernel(const bf16* __restrict__ gsl, int ldg, const bf16* __restrict__ g2, int ldg2,
+                                                                const float* __restrict__ ga, const float* __restrict__ gb,
+                                                                const float* __restrict__ gc, const bf16* __restrict__ x, int ldx,
+                                                                const float* __restrict__ pa, const float* __restrict__ pb,
+                                                                float* __restrict__ dw, float* __restrict__ slab, const PcGeo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int P = g.P, R = g.R, NR = g.NR, Q = g.Q, W = g.W, H = g.H, Wt = g.Wt, Hs = g.Hs;
+  const int nk = (R * P + 15) / 16;
+  char* ring = smem;                                           // y1: [Q + 2][320 B]
+  char* gbuf = smem + (size_t)(Q + 2) * AXP;                   // dY: [2][nk * 16][64 B]
+  const int GB = nk * 16 * GXP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int i = tid; i < ((Q + 2) * AXP + 2 * GB) / 16; i += NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  const unsigned v0 = (unsigned)(((unsigned long long)blockIdx.x * g.V) / (unsigned)g.nwg);
+  const unsigned v1 = (unsigned)(((unsigned long long)(blockIdx.x + 1) * g.V) / (unsigned)g.nwg);
+  const unsigned nrows = v1 - v0;
+  const unsigned rot = (g.rot && nrows > (unsigned)(2 * R)) ? (blockIdx.x * 37u) % nrows : 0u;
+  auto pass_range = [&](int pass, unsigned& a, unsigned& e, int& J) __attribute__((always_inline)) {
+    a = pass == 0 ? v0 + rot : v0;
+    e = pass == 0 ? v1 : v0 + rot;
+    J = e > a ? (int)((e - a + 1 + R - 1) / R) : 0;
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // Barriers of a pass, the same J + 2 for both roles: one per step j = -1 .. J-1 (the rows of step j are staged), one at the end.
+  if (wave >= 4) {
+    // ================================================================================================= producers
+    // (no raised priority here, unlike the forward kernel: this kernel is bound by the CONSUMERS' instruction stream -- 72 MFMAs, 160
+    // transposing reads and their address arithmetic per step -- and the producers wait for them at the barrier half of the time;
+    // A/B on one box: 234 us with the producers at priority 2, 222 at equal priority, see below for the consumers at 2)
+    const int ptid = tid - NPT;
+    const int c8 = ptid & 15, cg = ptid & 3;
+    float csc[8], csh[8], qa[8], qb[8], qc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      csc[j] = pa[c8 * 8 + j]; csh[j] = pb[c8 * 8 + j];
+      qa[j] = g_affine2 ? ga[cg * 8 + j] : 1.f; qb[j] = g_affine2 ? gb[cg * 8 + j] : 0.f; qc[j] = g_affine2 ? gc[cg * 8 + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(csc[j]), "v"(csh[j]), "v"(qa[j]), "v"(qb[j]), "v"(qc[j]));
+    // y1 chunks: chunk id ptid + 256 i over R rows x P positions x 16 chunks; dY chunks: ... x 4 chunks (see the forward kernel: the
+    // per-row part of an address is worked out once per step by lane r and fetched with ds_bpermute)
+    const int cpa = P * 16, cpg = P * 4;
+    int arow4[NCA], aoff[NCA], grow4[NCG], goff[NCG];
+    uint32_t acof[NCA], gcof[NCG], gcof2[NCG];
+    unsigned am0 = 0, am1 = 0, amrow = 0, gm0 = 0, gm1 = 0, gmrow = 0;
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      const int cid = ptid + NPT * i;
+      const int cr = cid / cpa, cp = (cid - cr * cpa) >> 4;
+      arow4[i] = cr * 4;
+      aoff[i] = cr * P + cp;
+      acof[i] = ((uint32_t)cp * (uint32_t)ldx + (uint32_t)c8 * 8u) * 2u;
+      amrow |= cr < R ? (1u << i) : 0u;
+      am0 |= ((unsigned)(cp - 1) < (unsigned)W) ? (1u << i) : 0u;
+      am1 |= ((unsigned)(Wt - 1 + cp) < (unsigned)W) ? (1u << i) : 0u;
+    }
+    am0 &= amrow; am1 &= amrow;
+#pragma unroll
+    for (int i = 0; i < NCG; ++i) {
+      const int cid = ptid + NPT * i;
+      const int cr = cid / cpg, cp = (cid - cr * cpg) >> 2;
+      grow4[i] = cr * 4;
+      goff[i] = cr * P + cp;
+      gcof[i] = ((uint32_t)cp * (uint32_t)ldg + (uint32_t)cg * 8u) * 2u;
+      gcof2[i] = ((uint32_t)cp * (uint32_t)ldg2 + (uint32_t)cg * 8u) * 2u;
+      gmrow |= cr < R ? (1u << i) : 0u;
+      // dY: only this tile's OWN columns (positions 1 .. Wt): the halo positions belong to the neighbouring tile's sums
+      const bool own = cp >= 1 && cp <= Wt;
+      gm0 |= (own && (unsigned)(cp - 1) < (unsigned)W) ? (1u << i) : 0u;
+      gm1 |= (own && (unsigned)(Wt - 1 + cp) < (unsigned)W) ? (1u << i) : 0u;
+    }
+    gm0 &= gmrow; gm1 &= gmrow;
+    const char* __restrict__ xb = reinterpret_cast<const char*>(x);
+    const char* __restrict__ gsb = reinterpret_cast<const char*>(gsl);
+    const char* __restrict__ g2b = reinterpret_cast<const char*>(g2);
+    char* ringc = ring + c8 * 16;
+    char* gbufc = gbuf + cg * 16;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      unsigned a, e;
+      int J;
+      pass_range(pass, a, e, J);
+      if (J == 0) continue;
+      uint4 pra[DEPTH][NCA], prg[DEPTH][NCG], prg2[DEPTH][g_affine2 ? NCG : 1];
+      unsigned pma[DEPTH], pmg[DEPTH];
+      // step j: y1 rows [a + jR, a + jR + R) and dY rows [a + jR - 1, a + jR + R - 1) (the rows step j multiplies) -> registers
+      auto issue = [&](uint4 (&pa_)[NCA], uint4 (&pg_)[NCG], uint4 (&pg2_)[g_affine2 ? NCG : 1], unsigned& ma, unsigned& mg, int j) __attribute__((always_inline)) {
+        const unsigned va = a + (unsigned)(j * R) + (unsigned)lane, vg = va - 1u;
+        const unsigned ta = __umulhi(va, g.mHs), ya = va - ta * (unsigned)Hs;
+        const unsigned tg = __umulhi(vg, g.mHs), yg = vg - tg * (unsigned)Hs;
+        const unsigned live = (unsigned)(j < J) & (unsigned)(lane < R);
+        const unsigned aok = live & (unsigned)(va < g.V) & (unsigned)(ya < (unsigned)H) & ((unsigned)(j >= 0) | (unsigned)(va + 2u >= a));
+        const unsigned gok = live & (unsigned)(j >= 0) & (unsigned)(vg >= a) & (unsigned)(vg < e) & (unsigned)(yg < (unsigned)H);
+        const unsigned txa = ta & (unsigned)(g.ntx - 1), txg = tg & (unsigned)(g.ntx - 1);
+        const uint32_t pxa = ((ta >> g.ntx_shift) * (uint32_t)H + ya) * (uint32_t)W + txa * (uint32_t)Wt - 1u;
+        const uint32_t pxg = ((tg >> g.ntx_shift) * (uint32_t)H + yg) * (uint32_t)W + txg * (uint32_t)Wt - 1u;
+        const int worda = (int)((pxa * (uint32_t)ldx * 2u) | aok | (txa << 1));
+        const int wordg = (int)((pxg << 2) | gok | (txg << 1));           // (pixel index: the two dY tensors have their own pitches)
+        ma = 0; mg = 0;
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) {
+          const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(arow4[i], worda);
+          const unsigned ok = w & (((w & 2u) ? am1 : am0) >> i) & 1u;
+          ma |= ok << i;
+          pa_[i] = *reinterpret_cast<const uint4*>(xb + (size_t)(ok ? (w & ~15u) + acof[i] : 0u));
+        }
+#pragma unroll
+        for (int i = 0; i < NCG; ++i) {
+          const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(grow4[i], wordg);
+          const unsigned ok = w & (((w & 2u) ? gm1 : gm0) >> i) & 1u;
+          mg |= ok << i;
+          const uint32_t px = w >> 2;
+          pg_[i] = *reinterpret_cast<const uint4*>(gsb + (size_t)(ok ? px * (uint32_t)ldg * 2u + gcof[i] : 0u));
+          if constexpr (g_affine2) pg2_[i] = *reinterpret_cast<const uint4*>(g2b + (size_t)(ok ? px * (uint32_t)ldg2 * 2u + gcof2[i] : 0u));
+        }
+      };
+      auto stage = [&](uint4 (&pa_)[NCA], uint4 (&pg_)[NCG], uint4 (&pg2_)[g_affine2 ? NCG : 1], unsigned ma, unsigned mg, int sb, int gsel) __attribute__((always_inline)) {
+        const int sbp = sb * P, wrap_from = (NR - sb) * 4;
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) {
+          uint4 o = cx_affine_relu8(pa_[i], csc, csh);
+          const unsigned keep = 0u - ((ma >> i) & 1u);
+          o.x &= keep; o.y &= keep; o.z &= keep; o.w &= keep;
+          int pos = sbp + aoff[i] - (arow4[i] >= wrap_from ? Q : 0);
+          pos = ((amrow >> i) & 1u) ? pos : Q + 1;                          // (chunks past the step's rows: the spare pixel, kept zero)
+          if (!((amrow >> i) & 1u)) o = make_uint4(0, 0, 0, 0);
+          if (!(CX_PCW_ABL & 4) || o.x == 0x12345u) *reinterpret_cast<uint4*>(ringc + pos * AXP) = o;
+        }
+        char* gdst = gbufc + gsel * GB;
+#pragma unroll
+        for (int i = 0; i < NCG; ++i) {
+          uint4 o = pg_[i];
+          if constexpr (g_affine2) o = cx_affine2_8(pg_[i], pg2_[i], qa, qb, qc);
+          const unsigned keep = 0u - ((mg >> i) & 1u);
+          o.x &= keep; o.y &= keep; o.z &= keep; o.w &= keep;
+          if ((gmrow >> i) & 1u) *reinterpret_cast<uint4*>(gdst + goff[i] * GXP) = o;
+        }
+      };
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        issue(pra[d], prg[d], prg2[d], pma[d], pmg[d], -1 + d);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      int sb = (2 * NR - R) % NR;                              // slot of y1 row a - R (the warm-up step's first row)
+#ifdef CX_PC_STAMPS
+      unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = pstamp();
+#endif
+      auto pstep = [&](int j, auto KI) __attribute__((always_inline)) {
+        constexpr int k = decltype(KI)::value;
+        PSTAMP(0)
+#ifdef CX_PC_STAMPS
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NCA + NCG * (g_affine2 ? 2 : 1)) * (DEPTH - 1)) : "memory");
+        PSTAMP(1)
+#endif
+        stage(pra[k], prg[k], prg2[k], pma[k], pmg[k], sb, j & 1);
+        PSTAMP(2)
+        issue(pra[k], prg[k], prg2[k], pma[k], pmg[k], j + DEPTH);
+        sb += R;
+        if (sb >= NR) sb -= NR;
+        PSTAMP(3)
+        bar_lds();                                             // barrier j: the rows of step j are staged
+        PSTAMP(4)
+      };
+      for (int j = -1; j < J; j += DEPTH) {
+        pstep(j, std::integral_constant<int, 0>());
+        if (DEPTH > 1) { if (j + 1 >= J) break; pstep(j + 1, std::integral_constant<int, 1 % DEPTH>()); }
+        if (DEPTH > 2) { if (j + 2 >= J) break; pstep(j + 2, std::integral_constant<int, 2 % DEPTH>()); }
+      }
+      bar_lds();                                               // the pass is over
+#ifdef CX_PC_STAMPS
+      if (tid == 256 && blockIdx.x < 1024) {
+        for (int i = 0; i < 5; ++i) pc_stamps[blockIdx.x * 16 + 8 + i] += st_acc[i];
+        pc_stamps[blockIdx.x * 16 + 15] += (unsigned long long)(J + 1);
+      }
+#endif
+    }
+  } else {
+    // ================================================================================================= consumers
+    // transposing reads: lane 4q + p of a 16-lane group supplies row q (then q + 4) of its block, columns 4p .. 4p + 3; group gq: rows
+    // 8 (gq >> 1) + .., columns 16 (gq & 1) + ..  -> this lane's pixel inside a k-step and its byte offset inside a pixel
+#ifndef CX_PCW_CPRIO
+#define CX_PCW_CPRIO 2
+#endif
+    __builtin_amdgcn_s_setprio(CX_PCW_CPRIO);
+    const int gq = lane >> 4, rq = (lane & 15) >> 2, pp = lane & 3;
+    const int lpx = 8 * (gq >> 1) + rq;                        // second read: + 4
+    const int acol = (wave * 32 + 16 * (gq & 1) + 4 * pp) * 2; // y1 channels of this wave
+    const int gcol = (16 * (gq & 1) + 4 * pp) * 2;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      unsigned a, e;
+      int J;
+      pass_range(pass, a, e, J);
+      if (J == 0) continue;
+      int sb = (2 * NR - R - 2) % NR;                          // slot of y1 row a + jR - 2 for j = -1
+#ifdef CX_PC_STAMPS
+      unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = pstamp();
+#endif
+      bar_lds();                                               // barrier -1 (warm-up rows)
+      for (int j = 0; j < J; ++j) {
+        sb += R;
+        if (sb >= NR) sb -= NR;
+        PSTAMP(0)
+        bar_lds();                                             // barrier j
+        PSTAMP(1)
+        const char* gcur = gbuf + (j & 1) * GB + gcol;
+        // flat ring index of (dY pixel m, tap (dy, dx)): sb*P + m + dy*P + dx - 1 (mod Q; dx may run into the two spare pixels: zero)
+        const int wsm1 = sb * P - 1 + Q;
+        // The 3 nk groups (k-step, dy) of three MFMAs run as one software pipeline: the fragment reads of a group go out TWO groups
+        // (six MFMAs, ~190 cycles) ahead, across the k-step boundary -- one group ahead (the first form of this loop) every group
+        // waited out the LDS latency: 126 cycles per MFMA (profiles/r05_pc_wgrad.txt).  Register set = dy.
+        // byte offsets (ring-relative, this lane's column included) of the six rows a k-step's y1 fragments start from: (dy, half h).
+        // They advance by 16 pixels per k-step with ONE conditional wrap -- computed from scratch per k-step (two wraps and a
+        // multiply per address) the consumer issued ~100 vector instructions per nine MFMAs and was bound by them
+        int ab[3][2];
+        const int QA = Q * AXP, lim = QA + acol;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            int f = wsm1 + lpx + 4 * h + dy * P;
+            if (f >= Q) f -= Q;
+            if (f >= Q) f -= Q;
+            ab[dy][h] = (int)__umul24((unsigned)f, (unsigned)AXP) + acol;
+          }
+        auto addr = [&](int) __attribute__((always_inline)) {     // the next k-step
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int t = ab[dy][h] + 16 * AXP;
+              ab[dy][h] = t >= lim ? t - QA : t;
+            }
+        };
+        bf16x8 af[3][3], gf, gfn;
+        bool rd_on = true;
+        auto rd = [&](int dy) __attribute__((always_inline)) {
+          if ((CX_PCW_ABL & 2) && !rd_on) return;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) af[dy][dx] = tr_pair(ring + ab[dy][0] + dx * AXP, ring + ab[dy][1] + dx * AXP);
+        };
+#ifndef CX_PCW_SCHED
+#define CX_PCW_SCHED 1
+#endif
+        auto mm = [&](int dy) __attribute__((always_inline)) {
+          if (CX_PCW_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            if (CX_PCW_ABL & 1) { acc[dy * 3 + dx][0] += (float)af[dy][dx][0] + (float)gf[0]; continue; }
+            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, af[dy][dx], acc[dy * 3 + dx], 0, 0, 0);   // D[row = n][col = k]
+            // an MFMA holds the vector issue for 8 of its 32 cycles: the address arithmetic of the next k-step and the fragment reads
+            // issue in the gaps (one MFMA, then up to four VALU and two LDS instructions), not in a block between the MFMA triples
+            if (CX_PCW_SCHED == 1) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // DS read
+            }
+          }
+          if (CX_PCW_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+        };
+        gf = tr_pair(gcur + lpx * GXP, gcur + (lpx + 4) * GXP);
+        rd(0);
+        rd(1);
+        for (int ks = 0; ks < nk; ++ks) {
+          rd(2);                                               // (ks, 2), with this k-step's addresses
+          rd_on = false;
+          const int kn = ks + 1 < nk ? ks + 1 : ks;            // (the last k-step re-reads itself: no branch in the pipeline)
+          addr(kn);
+          mm(0);
+          gfn = tr_pair(gcur + (kn * 16 + lpx) * GXP, gcur + (kn * 16 + lpx + 4) * GXP);
+          rd(0);                                               // (ks + 1, 0)
+          mm(1);
+          rd(1);                                               // (ks + 1, 1)
+          mm(2);
+          gf = gfn;
+        }
+#ifdef CX_PC_STAMPS
+        asm volatile("" ::"v"(acc[8][0]));
+#endif
+        PSTAMP(2)
+      }
+      bar_lds();                                               // the pass is over
+#ifdef CX_PC_STAMPS
+      if (tid == 0 && blockIdx.x < 1024) {
+        for (int i = 0; i < 3; ++i) pc_stamps[blockIdx.x * 16 + i] += st_acc[i];
+        pc_stamps[blockIdx.x * 16 + 7] += (unsigned long long)J;
+      }
+#endif
+    }
+  }
+
+  // ---- the workgroup's partial dW in OIHW order through LDS (the rings are free), then one coalesced tile
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);                 // [32 n][128 k][9]
+  if (wave < 4) {
+    const int lrow = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        red[(n * 128 + wave * 32 + lrow) * 9 + t] = acc[t][r];
+      }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 32 * 128 * 9; idx += NT)
+    dw_out(dw, slab, (size_t)32 * 128 * 9, (int)blockIdx.x, (size_t)idx, red[idx]);
+}
+
+template <int NCA, int NCG, int DEPTH, bool A2>
+int launch_pc_wgrad_a(const CxWgrad& p, hipStream_t st, const PcGeo& g, size_t smem) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pc_wgrad_kernel<NCA, NCG, DEPTH, A2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const size_t wtotal = (size_t)32 * 128 * 9;
+  float* slab = dw_slab(p.scratch, p.scratch_floats, g.nwg, (long long)wtotal);
+  CX_KTAG("conv3x3_pc_wgrad_kernel<%d, %d, %d, %s>", NCA, NCG, DEPTH, A2 ? "true" : "false");
+  hipLaunchKernelGGL((conv3x3_pc_wgrad_kernel<NCA, NCG, DEPTH, A2>), dim3(g.nwg), dim3(NT), smem, st, (const bf16*)p.g, p.ldg,
+                     (const bf16*)(A2 ? p.g2 : p.g), A2 ? p.ldg2 : p.ldg, p.ga, p.gb, p.gc, (const bf16*)p.x, p.ldx, p.pa, p.pb, p.dw, slab, g);
+  if (const int e = launch_status()) return e;
+  return slab ? cx_dw_reduce(p.dw, slab, wtotal, g.nwg, st) : 0;
+}
+template <int NCA, int NCG, int DEPTH>
+int launch_pc_wgrad(const CxWgrad& p, hipStream_t st, const PcGeo& g, size_t smem) {
+  return p.g_prologue == CX_PRO_AFFINE2 ? launch_pc_wgrad_a<NCA, NCG, DEPTH, true>(p, st, g, smem)
+                                        : launch_pc_wgrad_a<NCA, NCG, DEPTH, false>(p, st, g, smem);
+}
+
 }  // namespace
 
 #ifdef CX_PC_STAMPS
@@ -472,4 +842,63 @@ int cx_try_pc_fwd(const CxConv& p, hipStream_t st, bool* handled) {
   if (need <= 4) return launch_pc<4, 3>(p, st, g);
   if (need <= 6) return launch_pc<6, 2>(p, st, g);
   return launch_pc<8, 3>(p, st, g);
+}
+
+// The dense layers' 3x3 weight gradient on producer / consumer waves; called from cx_conv_wgrad ahead of the ring / strip kernels.
+// CxWgrad.kernel_hint form 8 selects it (tests, A/B); form 7 pins the ring / strip kernels.
+// Like the forward kernel it is the MEASURED ALTERNATIVE, taken only when CxWgrad.kernel_hint asks for it (form 8): 222 us against
+// 219 for the ring kernel on 80x80 maps at bs = 256 (116 against 120 at bs = 128), 73 against 69 on 40x40, the DenseNet121 step 26.83 ms
+// with it against 26.87 without (three alternating runs on one box) -- profiles/r05_pc_wgrad.txt: the consumers' own stream
+// (72 MFMAs + 160 transposing reads + their addresses per step) takes ~85 cycles per MFMA whatever its order or priority.
+#ifndef CX_PCW_DEFAULT
+#define CX_PCW_DEFAULT 0
+#endif
+int cx_try_pc_wgrad(const CxWgrad& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  const int form = ((p.kernel_hint >> 8) & 0xff) - 1;          // 7: the ring / strip kernels, 8: this kernel
+  if (form == 7 || (!CX_PCW_DEFAULT && form != 8)) return 0;
+  if (p.mode != CX_MODE_CONV || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad != 1 || p.dil > 1) return 0;
+  if (p.K != 128 || p.N != 32 || p.x_prologue != CX_PRO_AFFINE_RELU || p.dtype != CX_DT_BF16) return 0;
+  if (p.g_prologue != CX_PRO_NONE && p.g_prologue != CX_PRO_AFFINE2) return 0;
+  if (p.W < 4 || p.H < 1) return 0;
+  {
+    unsigned long long ldm = (unsigned long long)(p.ldx > p.ldg ? p.ldx : p.ldg);
+    if (p.g_prologue == CX_PRO_AFFINE2 && (unsigned long long)p.ldg2 > ldm) ldm = (unsigned long long)p.ldg2;
+    if ((unsigned long long)p.B * p.H * p.W * ldm * 2ull >= (1ull << 32)) return 0;      // 32-bit chunk offsets in the kernel
+    if ((unsigned long long)p.B * p.H * p.W >= (1ull << 30)) return 0;                    // pixel index in the per-row word
+  }
+  PcGeo g;
+  g.H = p.H; g.W = p.W;
+  g.ntx = (p.W >= 64 && p.W % 2 == 0) ? 2 : 1;
+  g.ntx_shift = g.ntx - 1;
+  g.Wt = p.W / g.ntx;
+  g.P = g.Wt + 2;
+  g.Hs = p.H + 1;
+  // largest R with <= 8 y1 chunks / 2 dY chunks per producer thread (R x P <= 128 flat pixels = eight k-steps) and both images in LDS
+  int R = (8 * NPT) / (g.P * 16);
+  for (; R >= 1; --R) {
+    const int nk = (R * g.P + 15) / 16;
+    if ((size_t)((2 * R + 2) * g.P + 2) * AXP + (size_t)2 * nk * 16 * GXP <= 160 * 1024 && R * g.P * 4 <= 2 * NPT) break;
+  }
+  if (R < 1) return 0;
+  if (R > g.Hs) R = g.Hs;
+  g.R = R; g.NR = 2 * R + 2; g.Q = g.NR * g.P;
+  const unsigned long long V = (unsigned long long)p.B * g.ntx * g.Hs;
+  if (V * (unsigned long long)g.Hs >= (1ull << 32) || V + 4096 >= (1ull << 31)) return 0;
+  g.V = (unsigned)V;
+  g.mP = 0xffffffffu / (unsigned)g.P + 1u;
+  g.mHs = 0xffffffffu / (unsigned)g.Hs + 1u;
+  int nwg = 256;
+  if (V < (unsigned long long)nwg * 2 * R) nwg = (int)((V + 2 * R - 1) / (2 * R));
+  if (nwg < 1) nwg = 1;
+  g.nwg = nwg;
+  g.rot = 1;
+  const int nk = (R * g.P + 15) / 16;
+  const size_t smem0 = (size_t)(g.Q + 2) * AXP + (size_t)2 * nk * 16 * GXP;
+  const size_t smem = smem0 < (size_t)32 * 128 * 9 * 4 ? (size_t)32 * 128 * 9 * 4 : smem0;       // (the OIHW tile at the end)
+  *handled = true;
+  const int needa = (R * g.P * 16 + NPT - 1) / NPT;
+  if (needa <= 4) return launch_pc_wgrad<4, 1, 3>(p, st, g, smem);
+  if (needa <= 6) return launch_pc_wgrad<6, 2, 2>(p, st, g, smem);
+  return launch_pc_wgrad<8, 2, 2>(p, st, g, smem);
 }

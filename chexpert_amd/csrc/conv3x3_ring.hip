@@ -640,13 +640,9 @@ constexpr int WCOEF = 352 * 4;           // prologue vectors
 
 __device__ __forceinline__ bf16x8 tr2(const char* a0, const char* a1) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  U64 lo, hi;
-  lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-  hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
-  bf16x8 r;
-  r[0] = lo.e[0]; r[1] = lo.e[1]; r[2] = lo.e[2]; r[3] = lo.e[3];
-  r[4] = hi.e[0]; r[5] = hi.e[1]; r[6] = hi.e[2]; r[7] = hi.e[3];
-  return r;
+  // (joined by a shuffle + bit cast: assembled element by element the compiler emits a v_bfi per dword on the loaded registers and
+  // waits for the read right where it is issued, not where the MFMA uses it -- common.h cx_join_tr)
+  return cx_join_tr(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1)));
 }
 
 template <int NX, int NG>

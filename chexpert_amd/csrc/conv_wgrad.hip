@@ -41,13 +41,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int k0, i
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const char* base = tile + (k0 + 8 * (g >> 1) + q) * pitch + (ch0 + 16 * (g & 1) + 4 * pp) * 2;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  U64 lo, hi;
-  lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
-  hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch));
-  bf16x8 r;
-  r[0] = lo.e[0]; r[1] = lo.e[1]; r[2] = lo.e[2]; r[3] = lo.e[3];
-  r[4] = hi.e[0]; r[5] = hi.e[1]; r[6] = hi.e[2]; r[7] = hi.e[3];
-  return r;
+  // (joined by a shuffle + bit cast: assembled element by element the compiler emits a v_bfi per dword on the loaded registers and
+  // waits for the read right where it is issued, not where the MFMA uses it -- common.h cx_join_tr)
+  return cx_join_tr(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch)));
 }
 
 template <int BNW, int BCW, int GPRO, int XPRO, int MODE>
@@ -644,6 +640,7 @@ int launch_tile(const CxWgrad& p, hipStream_t st) {
 
 }  // namespace
 
+int cx_try_pc_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);      // conv3x3_pc.hip
 int cx_try_ring_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);    // conv3x3_ring.hip
 int cx_try_strip_wgrad(const CxWgrad& p, hipStream_t st, bool* handled);   // conv3x3_strip.hip
 
@@ -686,7 +683,9 @@ extern "C" int cx_conv_wgrad(const CxWgrad* pp, void* stream) {
       return CX_ESHAPE;
     if (wd == 1) {             // (a dilated convolution's weight gradient runs on the generic tile kernel below)
       bool handled = false;
-      int rc = cx_try_ring_wgrad(p, st, &handled);
+      int rc = cx_try_pc_wgrad(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_ring_wgrad(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_wgrad_mm(p, st, &handled);             // wide 1x1 and 3x3 (N % 128 == 0); the dense layers' N = 32 passes through
       if (handled) return rc;

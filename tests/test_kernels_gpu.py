@@ -180,6 +180,34 @@ def test_conv3x3_producer_consumer_forward(dev, B, H, W):
     assert (st[:, rows:] == 0).all(), "rows past the reported count were written"
 
 
+@pytest.mark.parametrize("B,H,W,a2", [(2, 80, 80, 0), (3, 40, 40, 1), (5, 20, 20, 0), (7, 10, 10, 1), (1, 7, 9, 1), (9, 5, 4, 0), (17, 33, 66, 1), (300, 10, 10, 0)])
+def test_conv3x3_producer_consumer_weight_gradient(dev, B, H, W, a2):
+    """conv3x3_pc_wgrad_kernel (csrc/conv3x3_pc.hip; CxWgrad.kernel_hint form 8: the measured alternative to the ring / strip weight-
+    gradient kernels): dW of the dense layer's 3x3 against torch's conv2d_weight on the bf16-rounded operands, with the dense gradient
+    slice and with the deferred BatchNorm correction (AFFINE2) applied while the gradient rows are staged; reproducible slab sums."""
+    from chexpert_amd import _lib, ops
+    ops.set_det_wgrad(True)
+    g_ = torch.Generator(device="cpu").manual_seed(11)
+    y1 = bf(torch.randn(B, H, W, 128, generator=g_) * 0.7).to(torch.bfloat16).to(dev)
+    gbuf = bf(torch.randn(B, H, W, 96, generator=g_) * 0.5).to(torch.bfloat16).to(dev)
+    xbuf = bf(torch.randn(B, H, W, 96, generator=g_) * 0.5).to(torch.bfloat16).to(dev)
+    gs, xs = gbuf[..., 64:96], xbuf[..., 32:64]
+    sc, sh = (torch.rand(128, generator=g_) + 0.5).to(dev), (torch.randn(128, generator=g_) * 0.3).to(dev)
+    qa, qb, qc = (torch.rand(32, generator=g_) + 0.5).to(dev), (torch.randn(32, generator=g_) * 0.2).to(dev), (torch.randn(32, generator=g_) * 0.1).to(dev)
+    kw = dict(g_prologue=ops.PRO_AFFINE2, g2=xs, ga=qa, gb=qb, gc=qc) if a2 else {}
+    outs = []
+    for _ in range(2):
+        dw = torch.zeros(32, 128, 3, 3, device=dev)
+        ops.conv_wgrad(gs, y1, dw, kh=3, kw=3, pad=1, x_prologue=ops.PRO_AFFINE_RELU, pa=sc, pb=sh, hint=ops.kernel_hint(-1, 8), **kw)
+        assert _lib.lib().cx_last_kernel().decode().startswith("conv3x3_pc_wgrad_kernel")
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]), "the slab sums are ordered: two runs give the same bits"
+    a = bf(F.relu(y1.float() * sc + sh)).permute(0, 3, 1, 2)
+    gy = bf(gs.float() * qa + xs.float() * qb + qc) if a2 else gs.float()
+    ref = torch.nn.grad.conv2d_weight(a, (32, 128, 3, 3), gy.permute(0, 3, 1, 2).contiguous(), padding=1)
+    assert (outs[0] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
 def test_transition_pool2_commutes_with_conv(dev):
     from chexpert_amd import ops
     B, H, W, K, N = 2, 8, 12, 64, 96
