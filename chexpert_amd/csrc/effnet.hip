@@ -359,9 +359,16 @@ __global__ __launch_bounds__(1024) void se_fwd_kernel(const float* __restrict__ 
   if (rows) {
     // cx_gap_se_fwd: the pool's per-split partial means (row sp of sample b at rows[(sp * B + b) * C + c]) are added here, in row
     // order, instead of by a launch of their own between the pool and this kernel; block (b, 0) leaves the sum for the backward pass
+    // (the order of cx_rows_reduce -- rows q, q + 64, ... first, then over q -- so that this form gives the same bits as the separate
+    // launch did: on the B4 fixture a 1e-7 change of the pooled means re-draws enough bf16 roundings downstream to move the train
+    // logits from 8.0e-3 to 1.2e-2 of the reference; both are draws of the same noise, but the recorded one stays)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float t = 0.f;
-      for (int sp = 0; sp < n_rows; ++sp) t += rows[((size_t)sp * gridDim.x + b) * C + c];
+      for (int q = 0; q < 64 && q < n_rows; ++q) {
+        float sa = 0.f;
+        for (int sp = q; sp < n_rows; sp += 64) sa += rows[((size_t)sp * gridDim.x + b) * C + c];
+        t += sa;
+      }
       pl[c] = t;
       if (blockIdx.y == 0) pooled_out[(size_t)b * C + c] = t;
     }
@@ -611,7 +618,11 @@ __global__ __launch_bounds__(512) void se_bwd_a_kernel(const float* __restrict__
     float dsv;
     if (ds_rows) {       // cx_se_bwd_fused: the reduce kernel's per-split partial sums, added here in row order (no launch between)
       dsv = 0.f;
-      for (int sp = 0; sp < n_rows; ++sp) dsv += ds_rows[(size_t)sp * B * C + at];
+      for (int q = 0; q < 64 && q < n_rows; ++q) {       // (cx_rows_reduce's order: the same bits as the separate launch)
+        float sa = 0.f;
+        for (int sp = q; sp < n_rows; sp += 64) sa += ds_rows[(size_t)sp * B * C + at];
+        dsv += sa;
+      }
     } else {
       dsv = ds[at];
     }

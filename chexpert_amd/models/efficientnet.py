@@ -16,6 +16,7 @@ per-element keep masks drawn on the GPU by `cx_dropout_mask_dev` from (model.dro
 independent of torch's RNG; the parity tests feed the drawn masks (`engine.last_masks`) to the oracle.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -123,7 +124,7 @@ class _Engine:
         self.dtype = getattr(model, "_storage_dtype", torch.bfloat16)
         # deterministic statistics and weight gradients (statistic rows summed in row order, slab sums, one owner per squeeze-excite
         # sum): two steps on the same batch give the same bits; CHEXPERT_DET=0 keeps the fp32 atomics
-        import os
+
         self.det = os.environ.get("CHEXPERT_DET", "1") != "0"
         self.flat = None
         self.device = None
@@ -348,9 +349,16 @@ class _Engine:
                                    c["ce"], c["k"], c["stride"], t["pad"], dcap, sp), "cx_dwconv_fwd")
             self._bn_coef(ws, bn_d, B * ho * wo, train, lib().cx_last_stat_rows() if det else None)
             # squeeze + excite (efficientnet.py:69-73) in two launches: the excitation kernel adds the pool's split rows itself
-            check(lb.cx_gap_se_fwd(ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(t["pooled"]), ptr(se[1].weight), ptr(se[1].bias),
-                                   ptr(se[3].weight), ptr(se[3].bias), ptr(t["h1"]), ptr(t["s"]), B, ho * wo, c["ce"], t["R"], 2, *rsc, sp),
-                  "cx_gap_se_fwd")
+            # (CHEXPERT_SE_FUSED=0: the separate pool / reduce / excitation launches, for A/B runs)
+            if os.environ.get("CHEXPERT_SE_FUSED", "1") == "0":
+                check(lb.cx_gap_affine_act(ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(t["pooled"]), B, ho * wo, c["ce"], 2,
+                                           *rsc, sp), "cx_gap_affine_act")
+                check(lb.cx_se_fwd(ptr(t["pooled"]), ptr(se[1].weight), ptr(se[1].bias), ptr(se[3].weight), ptr(se[3].bias), ptr(t["h1"]),
+                                   ptr(t["s"]), B, c["ce"], t["R"], sp), "cx_se_fwd")
+            else:
+              check(lb.cx_gap_se_fwd(ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(t["pooled"]), ptr(se[1].weight), ptr(se[1].bias),
+                                     ptr(se[3].weight), ptr(se[3].bias), ptr(t["h1"]), ptr(t["s"]), B, ho * wo, c["ce"], t["R"], 2, *rsc, sp),
+                    "cx_gap_se_fwd")
             check(lb.cx_scale_act_bc(ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(t["s"]), ptr(t["u"]), B, ho * wo, c["ce"], sp),
                   "cx_scale_act_bc")
             rows = ops.conv_gemm(t["u"], self.w_fwd(conv_p), t["yp"], N=c["cout"], **csp(Sp))
@@ -513,11 +521,18 @@ class _Engine:
             # ds[b][c] = sum_hw du * swish(bn(yd)) and the two FCs' backward (efficientnet.py:69-73): the reduce kernel's split rows go
             # straight into the first FC pass (cx_se_bwd_fused: no launch of their own)
             wsb, arena, dfr = ops._wgrad_ws(self.device)
-            check(lb.cx_se_bwd_fused(ptr(du), ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(ds), ptr(t["s"]), ptr(t["h1"]),
+            if os.environ.get("CHEXPERT_SE_FUSED", "1") == "0":
+                check(lb.cx_se_bwd_reduce(ptr(du), ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(ds), B, ho * wo, ce,
+                                          *((ptr(ws.slab[0]), self.SLAB) if det else (None, 0)), sp), "cx_se_bwd_reduce")
+                check(lb.cx_se_bwd(ptr(ds), ptr(t["s"]), ptr(t["h1"]), ptr(t["pooled"]), ptr(se[1].weight), ptr(se[3].weight),
+                                   ptr(G(se[1].weight)), ptr(G(se[1].bias)), ptr(G(se[3].weight)), ptr(G(se[3].bias)), ptr(dpl), B, ce, t["R"],
+                                   ptr(wsb), 0 if wsb is None else wsb.numel(), sp), "cx_se_bwd")
+            else:
+              check(lb.cx_se_bwd_fused(ptr(du), ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(ds), ptr(t["s"]), ptr(t["h1"]),
                                      ptr(t["pooled"]), ptr(se[1].weight), ptr(se[3].weight), ptr(G(se[1].weight)), ptr(G(se[1].bias)),
-                                     ptr(G(se[3].weight)), ptr(G(se[3].bias)), ptr(dpl), B, ho * wo, ce, t["R"],
-                                     *((ptr(ws.slab[0]), self.SLAB) if det else (None, 0)), ptr(wsb), 0 if wsb is None else wsb.numel(), sp),
-                  "cx_se_bwd_fused")
+                                       ptr(G(se[3].weight)), ptr(G(se[3].bias)), ptr(dpl), B, ho * wo, ce, t["R"],
+                                       *((ptr(ws.slab[0]), self.SLAB) if det else (None, 0)), ptr(wsb), 0 if wsb is None else wsb.numel(), sp),
+                    "cx_se_bwd_fused")
             ops._wgrad_used(arena, dfr)
             check(lb.cx_se_act_bwd(ptr(du), ptr(t["yd"]), ptr(v(ws, Sd.sc)), ptr(v(ws, Sd.sh)), ptr(v(ws, Sd.mean)), ptr(v(ws, Sd.rstd)),
                                    ptr(t["s"]), ptr(dpl), ptr(dzd), *ssp(Sd)[:2], B, ho * wo, ce, ssp(Sd)[2], sp), "cx_se_act_bwd")
