@@ -555,9 +555,9 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "%s %s 1xMI355X %dx%d bs=%d U-Ones labels (%s); %d classes; "
+            "config": {"workload": "%s %s %dxMI355X %dx%d bs=%d per GPU, U-Ones labels (%s); %d classes; "
                                    "random-init weights, synthetic uint8 X-rays" % (
-                                       args.model, args.dtype, args.size, args.size, args.batch,
+                                       args.model, args.dtype, world, args.size, args.size, args.batch,
                                        "BASELINE configs[1]" if (args.model, args.dtype) == ("densenet121", "bf16") else
                                        "not the headline config", args.classes),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
