@@ -421,7 +421,7 @@ __device__ __forceinline__ bf16x8 tr_frag_k(const char* tile, int pitch, int k0,
 }
 
 template <int DVH, int WW>
-__global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ __launch_bounds__(256, WW == 40 ? 3 : 2) void aa_attn_bwd_q_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                 const float* __restrict__ rel_w, const float* __restrict__ o,
                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                 float* __restrict__ dqkv, float* __restrict__ d_rel_h,
@@ -438,9 +438,15 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
   const int LH = 2 * H - 1;
   float* RH = lds;
   float* RW = RH + DKH * LH;
-  float* dRH = RW + DKH * LW;            // workgroup partials
-  float* dRW = dRH + DKH * LH;
-  float* Vt = dRW + DKH * LW;            // [64][DVH] fp32 (keys 40..63 zero)
+  // (round 5: three workgroups per CU instead of two -- 168 VGPRs under the launch bound, and the table-gradient partials no longer
+  // staged in LDS: every (d, rr) word has ONE owner thread that computes it once after the key loop, so it goes straight to the
+  // workgroup's slab row / the atomic; 62 -> 50 KB of LDS.  The kernel is bound by dependent vector issue at low occupancy.)
+  // The 20-wide maps keep the LDS staging of those words (their kernels are short: the owner's stride-LH stores straight to the slab cost
+  // +0.25 ms there, on the 40-wide maps they are amortised): STG.
+  constexpr bool STG = WW != 40;
+  float* dRH = RW + DKH * LW;            // (STG) workgroup partials
+  float* dRW = dRH + (STG ? DKH * LH : 0);
+  float* Vt = dRW + (STG ? DKH * LW : 0);   // [64][DVH] fp32 (keys 40..63 zero)
   float* Qs = Vt + 64 * DVH;             // [AQM][DKH + 1] scaled queries of the workgroup
   float* dwq = Qs + AQM * (DKH + 1);     // during the key loop dr2[ky][AQM] = d rh_q[ky]; then [AQM][WW + 1] d rw_q[kx]; at the very end
                                          // [AQM][DKH + 1] relative-term part of dq: AQM * max(H, WW + 1) floats
@@ -456,8 +462,9 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
   const int ic = qvalid ? i : HW - 1;
   const int qy = ic / WW, qx = ic - qy * WW;
   const bf16* base = qkv + (size_t)b * HW * g.ldq;
-  for (int t = tid; t < DKH * LH; t += NT) { RH[t] = rel_h[t]; dRH[t] = 0.f; }
-  for (int t = tid; t < DKH * LW; t += NT) { RW[t] = rel_w[t]; dRW[t] = 0.f; }
+  for (int t = tid; t < DKH * LH; t += NT) RH[t] = rel_h[t];
+  for (int t = tid; t < DKH * LW; t += NT) RW[t] = rel_w[t];
+  const size_t wg_ = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   for (int t = tid; t < 64 * KB_PITCH / 4; t += NT) reinterpret_cast<uint32_t*>(Kb)[t] = 0u;
   for (int t = tid; t < 64 * DVH; t += NT) Vt[t] = 0.f;
 
@@ -612,7 +619,9 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
       const int l0 = max(yy * WW - i0, 0), l1 = min((yy + 1) * WW - i0, AQM);
       for (int l = l0; l < l1; ++l) t = fmaf(dr2[ky * AQM + l], Qs[l * (DKH + 1) + d], t);
     }
-    dRH[d * LH + rr] += t;
+    if (STG) dRH[d * LH + rr] = t;
+    else if (slab_h) slab_h[wg_ * (DKH * LH) + d * LH + rr] = t;
+    else atomicAdd(&d_rel_h[d * LH + rr], t);
   }
   __syncthreads();                        // dr2 consumed: its space becomes dwq
   // d rw_q[kx] -> dq and d key_rel_w (owner-computes sums over the parked per-query columns)
@@ -638,7 +647,9 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
       if (kx >= 0 && kx < WW) t = fmaf(dwq[l * (WW + 1) + kx], Qs[l * (DKH + 1) + d], t);
       if (++xq == WW) xq = 0;
     }
-    dRW[d * LW + rr] += t;
+    if (STG) dRW[d * LW + rr] = t;
+    else if (slab_w) slab_w[wg_ * (DKH * LW) + d * LW + rr] = t;
+    else atomicAdd(&d_rel_w[d * LW + rr], t);
   }
   __syncthreads();
   // dq = (matrix part [query rows][d columns] + relative part [query lanes][d]) * scale, through LDS
@@ -656,10 +667,10 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_q_mfma_kernel(const bf16* __r
       }
     }
   }
-  {
-    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    for (int t = tid; t < DKH * LH; t += NT) { if (slab_h) slab_h[wg * (DKH * LH) + t] = dRH[t]; else atomicAdd(&d_rel_h[t], dRH[t]); }
-    for (int t = tid; t < DKH * LW; t += NT) { if (slab_w) slab_w[wg * (DKH * LW) + t] = dRW[t]; else atomicAdd(&d_rel_w[t], dRW[t]); }
+  if (STG) {
+    __syncthreads();
+    for (int t = tid; t < DKH * LH; t += NT) { if (slab_h) slab_h[wg_ * (DKH * LH) + t] = dRH[t]; else atomicAdd(&d_rel_h[t], dRH[t]); }
+    for (int t = tid; t < DKH * LW; t += NT) { if (slab_w) slab_w[wg_ * (DKH * LW) + t] = dRW[t]; else atomicAdd(&d_rel_w[t], dRW[t]); }
   }
 }
 
@@ -1077,7 +1088,7 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
   } else {
     static const bool q_row = cx_diag_set("CX_AA_Q_ROW");          // diagnostic: the per-query VALU kernel
     if ((WW == 40 || WW == 20) && !q_row) {
-      const size_t smem_m = (2 * tables + 64 * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1))) * 4 + 64 * KB_PITCH;
+      const size_t smem_m = ((WW == 40 ? 1 : 2) * tables + 64 * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1))) * 4 + 64 * KB_PITCH;
       static bool attr_m = false;
       if (!attr_m) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_mfma_kernel<DVH, WW>), hipFuncAttributeMaxDynamicSharedMemorySize,
