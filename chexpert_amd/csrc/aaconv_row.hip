@@ -421,7 +421,7 @@ __device__ __forceinline__ bf16x8 tr_frag_k(const char* tile, int pitch, int k0,
 }
 
 template <int DVH, int WW>
-__global__ __launch_bounds__(256, WW == 40 ? 3 : 2) void aa_attn_bwd_q_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                 const float* __restrict__ rel_w, const float* __restrict__ o,
                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                 float* __restrict__ dqkv, float* __restrict__ d_rel_h,
@@ -438,15 +438,11 @@ __global__ __launch_bounds__(256, WW == 40 ? 3 : 2) void aa_attn_bwd_q_mfma_kern
   const int LH = 2 * H - 1;
   float* RH = lds;
   float* RW = RH + DKH * LH;
-  // (round 5: three workgroups per CU instead of two -- 168 VGPRs under the launch bound, and the table-gradient partials no longer
-  // staged in LDS: every (d, rr) word has ONE owner thread that computes it once after the key loop, so it goes straight to the
-  // workgroup's slab row / the atomic; 62 -> 50 KB of LDS.  The kernel is bound by dependent vector issue at low occupancy.)
-  // The 20-wide maps keep the LDS staging of those words (their kernels are short: the owner's stride-LH stores straight to the slab cost
-  // +0.25 ms there, on the 40-wide maps they are amortised): STG.
-  constexpr bool STG = WW != 40;
-  float* dRH = RW + DKH * LW;            // (STG) workgroup partials
-  float* dRW = dRH + (STG ? DKH * LH : 0);
-  float* Vt = dRW + (STG ? DKH * LW : 0);   // [64][DVH] fp32 (keys 40..63 zero)
+  // (round 5: three workgroups per CU instead of two -- 168 VGPRs under the launch bound -- and the table-gradient sums moved from
+  // owner-computes vector loops (13 K instructions per wave, more than the whole key loop) to the matrix pipe, fp32 operands
+  // (v_mfma_f32_32x32x2_f32: exact products, fixed summation order): their results are staged IN PLACE of the tables they are
+  // the gradients of, which are dead by then, so the workgroup needs no separate partial-sum arrays: 62 -> 50 KB of LDS.)
+  float* Vt = RW + DKH * LW;             // [64][DVH] fp32 (keys 40..63 zero)
   float* Qs = Vt + 64 * DVH;             // [AQM][DKH + 1] scaled queries of the workgroup
   float* dwq = Qs + AQM * (DKH + 1);     // during the key loop dr2[ky][AQM] = d rh_q[ky]; then [AQM][WW + 1] d rw_q[kx]; at the very end
                                          // [AQM][DKH + 1] relative-term part of dq: AQM * max(H, WW + 1) floats
@@ -500,7 +496,6 @@ __global__ __launch_bounds__(256, WW == 40 ? 3 : 2) void aa_attn_bwd_q_mfma_kern
 #pragma unroll
     for (int d = 0; d < DKH; ++d) Qs[ql * (DKH + 1) + d] = qvalid ? q[d] : 0.f;
   }
-  const int qy_a = i0 / WW, qy_b = min(i0 + AQM - 1, HW - 1) / WW;
   __syncthreads();
 
   // this lane's key columns: kx = (e & 3) + 8 * (e >> 2) + 4 * lh for e < 16 (keys 0..31), 32 + (e - 16) + 4 * lh after
@@ -609,22 +604,47 @@ __global__ __launch_bounds__(256, WW == 40 ? 3 : 2) void aa_attn_bwd_q_mfma_kern
     if (lh == 0) dr2[ky * AQM + ql] = qvalid ? drh : 0.f;       // parked for the d key_rel_h sums after the loop
   }
   __syncthreads();
-  // d key_rel_h: thread owns table word (d, rr): every (query image row yy, key row ky) with ky - yy + H - 1 = rr
-  for (int oo = tid; oo < LH * DKH; oo += NT) {
-    const int rr = oo / DKH, d = oo - rr * DKH;
-    float t = 0.f;
-    for (int yy = qy_a; yy <= qy_b; ++yy) {
-      const int ky = rr + yy - (H - 1);
-      if (ky < 0 || ky >= H) continue;
-      const int l0 = max(yy * WW - i0, 0), l1 = min((yy + 1) * WW - i0, AQM);
-      for (int l = l0; l < l1; ++l) t = fmaf(dr2[ky * AQM + l], Qs[l * (DKH + 1) + d], t);
+  // Table gradients as skewed matrix products over the workgroup's AQM queries l, one 32-row tile of table columns rr per wave:
+  //   d key_rel_h[d][rr] = sum_l A[rr][l] Qs[l][d],  A[rr][l] = dr2[rr + yy(l) - (H-1)][l]      (yy = image row of query l)
+  //   d key_rel_w[d][rr] = sum_l A[rr][l] Qs[l][d],  A[rr][l] = dwq[l][rr + xq(l) - (W-1)]      (xq = image column of query l)
+  // v_mfma_f32_32x32x2_f32: lane (i = lane & 31, k = lane >> 5) supplies A[i][k] and B[k][j = lane & 31]; the 64 steps take
+  // queries l = 2 s + k in index order.  Output columns j >= DKH and rows rr past the table are never stored.
+  auto table_tile = [&](const bool by_row, const int L) __attribute__((always_inline)) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (wave * 32 < L) {
+      const int rr = wave * 32 + lrow;
+      int l = lh, yy = (i0 + lh) / WW, xq = (i0 + lh) - yy * WW;
+      const float* qcol = Qs + min(lrow, DKH);
+#pragma unroll 8
+      for (int s2 = 0; s2 < AQM / 2; ++s2) {
+        const int kk = by_row ? rr + yy - (H - 1) : rr + xq - (WW - 1);
+        const int kc = min(max(kk, 0), (by_row ? H : WW) - 1);
+        const float av = by_row ? dr2[kc * AQM + l] : dwq[l * (WW + 1) + kc];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk == kc ? av : 0.f, qcol[l * (DKH + 1)], acc, 0, 0, 0);
+        l += 2;
+        xq += 2;
+        if (xq >= WW) { xq -= WW; ++yy; }
+      }
     }
-    if (STG) dRH[d * LH + rr] = t;
-    else if (slab_h) slab_h[wg_ * (DKH * LH) + d * LH + rr] = t;
-    else atomicAdd(&d_rel_h[d * LH + rr], t);
+    return acc;
+  };
+  auto table_store = [&](const f32x16& acc, float* out, const int L) __attribute__((always_inline)) {
+    if (lrow < DKH) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (rr < L) out[lrow * L + rr] = acc[r];
+      }
+    }
+  };
+  {
+    const f32x16 th = table_tile(true, LH);
+    table_store(th, RH, LH);              // key_rel_h is no longer read: its gradient takes its place
   }
   __syncthreads();                        // dr2 consumed: its space becomes dwq
-  // d rw_q[kx] -> dq and d key_rel_w (owner-computes sums over the parked per-query columns)
+  // d rw_q[kx] -> dq and d key_rel_w
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
@@ -638,20 +658,9 @@ __global__ __launch_bounds__(256, WW == 40 ? 3 : 2) void aa_attn_bwd_q_mfma_kern
 #pragma unroll
     for (int d = 0; d < 10; ++d) dqr[d] = fmaf(dv_, RW[(10 * lh + d) * LW + rr], dqr[d]);
   }
-  for (int oo = tid; oo < LW * DKH; oo += NT) {        // thread owns table word (d, rr): every (query, kx) with kx - qx + W - 1 = rr
-    const int rr = oo / DKH, d = oo - rr * DKH;
-    int xq = i0 % WW;
-    float t = 0.f;
-    for (int l = 0; l < AQM; ++l) {
-      const int kx = xq + rr - (WW - 1);
-      if (kx >= 0 && kx < WW) t = fmaf(dwq[l * (WW + 1) + kx], Qs[l * (DKH + 1) + d], t);
-      if (++xq == WW) xq = 0;
-    }
-    if (STG) dRW[d * LW + rr] = t;
-    else if (slab_w) slab_w[wg_ * (DKH * LW) + d * LW + rr] = t;
-    else atomicAdd(&d_rel_w[d * LW + rr], t);
-  }
-  __syncthreads();
+  const f32x16 tw = table_tile(false, LW);
+  __syncthreads();                        // every wave is done with key_rel_w and dwq
+  table_store(tw, RW, LW);
   // dq = (matrix part [query rows][d columns] + relative part [query lanes][d]) * scale, through LDS
   float* dqx = dwq;                                     // [AQM][DKH + 1]
 #pragma unroll
@@ -667,11 +676,9 @@ __global__ __launch_bounds__(256, WW == 40 ? 3 : 2) void aa_attn_bwd_q_mfma_kern
       }
     }
   }
-  if (STG) {
-    __syncthreads();
-    for (int t = tid; t < DKH * LH; t += NT) { if (slab_h) slab_h[wg_ * (DKH * LH) + t] = dRH[t]; else atomicAdd(&d_rel_h[t], dRH[t]); }
-    for (int t = tid; t < DKH * LW; t += NT) { if (slab_w) slab_w[wg_ * (DKH * LW) + t] = dRW[t]; else atomicAdd(&d_rel_w[t], dRW[t]); }
-  }
+  // (RH and RW are adjacent: one flat range of DKH * (LH + LW) words, the layout of the slab row pair)
+  for (int t = tid; t < DKH * LH; t += NT) { if (slab_h) slab_h[wg_ * (DKH * LH) + t] = RH[t]; else atomicAdd(&d_rel_h[t], RH[t]); }
+  for (int t = tid; t < DKH * LW; t += NT) { if (slab_w) slab_w[wg_ * (DKH * LW) + t] = RW[t]; else atomicAdd(&d_rel_w[t], RW[t]); }
 }
 
 // ------------------------------------------------------------------------------------------------ key side on MFMA
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(256, WW == 40 ? 3 : 2) void aa_attn_bwd_q_mfma_kern
 // against ~50 of aa_attn_bwd_k_row_kernel.  Each key's sums run over the query tiles in index order inside one workgroup:
 // no atomics, nothing order-dependent.
 template <int DVH, int WW>
-__global__ __launch_bounds__(256) void aa_attn_bwd_k_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_bwd_k_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                 const float* __restrict__ rel_w, const float* __restrict__ o,
                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                 float* __restrict__ dqkv, const AAGeo g) {
@@ -942,7 +949,7 @@ __global__ __launch_bounds__(256) void aa_attn_bwd_k_mfma_kernel(const bf16* __r
 // Forward on the same tiles: S^T = K Q^T per key row by MFMA, online softmax per query over the lane's 20 (12) accumulator slots
 // and its partner half (the two halves of a query share the running maximum), p V on the vector pipe (DVH <= 6).
 template <int DVH, int WW>
-__global__ __launch_bounds__(256) void aa_attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ __launch_bounds__(256, (WW == 20 || DVH <= 2) ? 4 : 3) void aa_attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ rel_h,
                                                               const float* __restrict__ rel_w, float* __restrict__ o,
                                                               float* __restrict__ lse, const AAGeo g) {
   static_assert(WW == 40 || WW == 20, "key rows of 40 or 20");
@@ -1088,7 +1095,7 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
   } else {
     static const bool q_row = cx_diag_set("CX_AA_Q_ROW");          // diagnostic: the per-query VALU kernel
     if ((WW == 40 || WW == 20) && !q_row) {
-      const size_t smem_m = ((WW == 40 ? 1 : 2) * tables + 64 * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1))) * 4 + 64 * KB_PITCH;
+      const size_t smem_m = (tables + 64 * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1))) * 4 + 64 * KB_PITCH;
       static bool attr_m = false;
       if (!attr_m) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_mfma_kernel<DVH, WW>), hipFuncAttributeMaxDynamicSharedMemorySize,
