@@ -401,6 +401,9 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_k_row_kernel(const bf16* __res
 // operand layout by v_permlane32_swap and split into two bf16 terms (hi + lo: 2^-17 relative, dq is checked to 1e-3).
 // The relative-table gradients keep the owner-computes LDS sums of the row kernel.
 constexpr int AQM = 128;               // queries per workgroup (4 waves x 32)
+#ifndef AA_DS_TERMS
+#define AA_DS_TERMS 2                  // bf16 terms of dS in the dQ / dK products: 2 = hi + lo (2^-17 relative), 1 = hi only (2^-9)
+#endif
 constexpr int KB_PITCH = 80;           // bf16 key image: 32 d (20 used) + 16 B pad
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -442,12 +445,16 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
   // owner-computes vector loops (13 K instructions per wave, more than the whole key loop) to the matrix pipe, fp32 operands
   // (v_mfma_f32_32x32x2_f32: exact products, fixed summation order): their results are staged IN PLACE of the tables they are
   // the gradients of, which are dead by then, so the workgroup needs no separate partial-sum arrays: 62 -> 50 KB of LDS.)
-  float* Vt = RW + DKH * LW;             // [64][DVH] fp32 (keys 40..63 zero)
-  float* Qs = Vt + 64 * DVH;             // [AQM][DKH + 1] scaled queries of the workgroup
-  float* dwq = Qs + AQM * (DKH + 1);     // during the key loop dr2[ky][AQM] = d rh_q[ky]; then [AQM][WW + 1] d rw_q[kx]; at the very end
-                                         // [AQM][DKH + 1] relative-term part of dq: AQM * max(H, WW + 1) floats
+  constexpr int KR = WW == 40 ? 48 : 32; // rows of a key image: the row's keys, then zero rows up to the last one an operand read touches
+  constexpr int VR = WW == 40 ? 40 : 24; // rows of a value image
+  constexpr int DRP = AQM + 1;           // pitch of dr2 (the prologue's stores walk down a column)
+  float* Vt = RW + DKH * LW;             // 2 x [VR][DVH] fp32 (rows past the key row zero)
+  float* Qs = Vt + 2 * VR * DVH;         // [AQM][DKH + 1] scaled queries of the workgroup
+  float* dwq = Qs + AQM * (DKH + 1);     // before key row ky: dr2[ky][DRP] = rh_q[ky] (the relative row logit, from the prologue); after it:
+                                         // d rh_q[ky]; after the loop [AQM][WW + 1] d rw_q[kx]; at the very end [AQM][DKH + 1] relative-term
+                                         // part of dq: AQM * max(H, WW + 1) + H (rounded up to 4) floats
   float* dr2 = dwq;
-  char* Kb = reinterpret_cast<char*>(dwq + AQM * (H > WW + 1 ? H : WW + 1));     // bf16 [64 keys][KB_PITCH]
+  char* Kb = reinterpret_cast<char*>(dwq + AQM * (H > WW + 1 ? H : WW + 1) + ((H + 3) & ~3));     // 2 x bf16 [KR keys][KB_PITCH], 16-byte aligned
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5;
   const int ql = wave * 32 + lrow;                              // query of this lane inside the workgroup
@@ -461,8 +468,8 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
   for (int t = tid; t < DKH * LH; t += NT) RH[t] = rel_h[t];
   for (int t = tid; t < DKH * LW; t += NT) RW[t] = rel_w[t];
   const size_t wg_ = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-  for (int t = tid; t < 64 * KB_PITCH / 4; t += NT) reinterpret_cast<uint32_t*>(Kb)[t] = 0u;
-  for (int t = tid; t < 64 * DVH; t += NT) Vt[t] = 0.f;
+  for (int t = tid; t < 2 * KR * KB_PITCH / 4; t += NT) reinterpret_cast<uint32_t*>(Kb)[t] = 0u;
+  for (int t = tid; t < 2 * VR * DVH; t += NT) Vt[t] = 0.f;
 
   // the query: bf16 operand fragments (B operand of S^T = K Q^T: d = kk * 16 + lh * 8 + 0..7) and fp32 scaled copy
   float q[DKH];
@@ -499,16 +506,51 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
   __syncthreads();
 
   // this lane's key columns: kx = (e & 3) + 8 * (e >> 2) + 4 * lh for e < 16 (keys 0..31), 32 + (e - 16) + 4 * lh after
+  // (a rolled loop over d with the query read back from LDS: fully unrolled, the 400 table reads are hoisted and spilled)
   float rwl[NE], drwl[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
-    const int kc = kx < WW ? kx : WW - 1;
-    float a = 0.f;
+  for (int e = 0; e < NE; ++e) rwl[e] = drwl[e] = 0.f;
+  {
+    const float* rwb = RW - qx + WW - 1;
+#pragma unroll 1
+    for (int d = 0; d < DKH; ++d) {
+      const float qd = Qs[ql * (DKH + 1) + d];
 #pragma unroll
-    for (int d = 0; d < DKH; ++d) a = fmaf(q[d], RW[d * LW + kc - qx + WW - 1], a);
-    rwl[e] = kx < WW ? a * LOG2E : -1.0e30f;
-    drwl[e] = 0.f;
+      for (int e = 0; e < NE; ++e) {
+        const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+        rwl[e] = fmaf(qd, rwb[d * LW + (kx < WW ? kx : WW - 1)], rwl[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int kx = (e < 16 ? (e & 3) + 8 * (e >> 2) : 32 + (e - 16)) + 4 * lh;
+      rwl[e] = kx < WW ? rwl[e] * LOG2E : -1.0e30f;
+    }
+  }
+  // The relative row logits of the wave's 32 queries, rh_q[ky] = q . key_rel_h[:, ky - qy + H - 1] for every key row, on the matrix pipe
+  // (fp32 operands): T[q][c] = sum_d Qs[q][d] RH[d][c] over 32-column tiles of the table, entry (q, c) parked at dr2[c - (H-1) + qy(q)][q]
+  // where the key loop picks it up before it overwrites the slot with d rh_q[ky].
+  {
+    const int qw0 = i0 + wave * 32, qy0 = qw0 / WW, x0 = qw0 - qy0 * WW;
+    const float* qrow = Qs + (wave * 32 + lrow) * (DKH + 1) + lh;
+#pragma unroll 1
+    for (int t = 0; t * 32 < LH; ++t) {
+      const int c = t * 32 + lrow;
+      const float* rcol = RH + lh * LH + min(c, LH - 1);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < DKH / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[2 * s2], rcol[2 * s2 * LH], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qo = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        int yq = qy0 + (x0 + qo >= WW ? 1 : 0);
+        if (WW < 32) yq += x0 + qo >= 2 * WW ? 1 : 0;
+        const int ky = c - (H - 1) + yq;
+        if (c < LH && (unsigned)ky < (unsigned)H) dr2[ky * DRP + wave * 32 + qo] = acc[r];
+      }
+    }
   }
   f32x16 dqa;                            // D[q][d]: rows = the wave's queries, columns = d (lane & 31)
 #pragma unroll
@@ -530,22 +572,22 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
     kreg = *reinterpret_cast<const uint2*>(base + (j0 + sj) * g.ldq + kofs + sc * 4);
     vreg = base[(j0 + vj) * g.ldq + vofs + vd];
   };
-  auto store_keys = [&]() __attribute__((always_inline)) {
-    if (tid < WW * 5) *reinterpret_cast<uint2*>(Kb + sj * KB_PITCH + sc * 8) = kreg;
-    if (tid < WW * DVH) Vt[vj * DVH + vd] = bf2f(vreg);
+  auto store_keys = [&](const int img) __attribute__((always_inline)) {
+    if (tid < WW * 5) *reinterpret_cast<uint2*>(Kb + (img * KR + sj) * KB_PITCH + sc * 8) = kreg;
+    if (tid < WW * DVH) Vt[(img * VR + vj) * DVH + vd] = bf2f(vreg);
   };
   load_keys(0);
+  store_keys(0);                          // (the zero fill and the prologue's barrier are behind us)
+  load_keys(H > 1 ? 1 : 0);
+  const int r1 = 32 + min(lrow, KR - 33); // second tile's key row of this lane (rows past the image: its last zero row)
   for (int ky = 0; ky < H; ++ky) {
-    __syncthreads();                      // the previous row's readers are done (first row: zero fill done)
-    store_keys();
-    __syncthreads();
-    load_keys(ky + 1 < H ? ky + 1 : ky);  // in flight under this row's arithmetic
-    const char* Kc = Kb;
-    const float* Vc = Vt;
+    __syncthreads();                      // image ky & 1 is complete, and nobody reads the other one (row ky - 1) any more
+    store_keys((ky + 1) & 1);             // row ky + 1, requested a row ago
+    load_keys(ky + 2 < H ? ky + 2 : H - 1);  // in flight under this row's arithmetic
+    const char* Kc = Kb + (ky & 1) * (KR * KB_PITCH);
+    const float* Vc = Vt + (ky & 1) * (VR * DVH);
     const int r = ky - qy + H - 1;
-    float rhv = 0.f;
-#pragma unroll
-    for (int d = 0; d < DKH; ++d) rhv = fmaf(q[d], RH[d * LH + r], rhv);
+    const float rhv = dr2[ky * DRP + ql];
     const float rhl = qvalid ? fmaf(rhv, LOG2E, -Ll) : -1.0e30f;         // (rows past the map: p = 0)
 
     // S^T tiles: keys 0..31 and 32..63
@@ -557,7 +599,7 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
       const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kc + lrow * KB_PITCH + kk * 32 + lh * 16);
       st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], st0, 0, 0, 0);
       if (WW == 40) {
-        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kc + (32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kc + r1 * KB_PITCH + kk * 32 + lh * 16);
         st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], st1, 0, 0, 0);
       }
     }
@@ -591,17 +633,17 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         hi.u[j] = pk_bf16(v[2 * j], v[2 * j + 1]);
-        lo.u[j] = pk_bf16(v[2 * j] - __uint_as_float(hi.u[j] << 16), v[2 * j + 1] - __uint_as_float(hi.u[j] & 0xffff0000u));
+        if (AA_DS_TERMS > 1) lo.u[j] = pk_bf16(v[2 * j] - __uint_as_float(hi.u[j] << 16), v[2 * j + 1] - __uint_as_float(hi.u[j] & 0xffff0000u));
       }
       const bf16x8 kt = tr_frag_k(Kc, KB_PITCH, g16 * 16, lane);
       dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi.h, kt, dqa, 0, 0, 0);
-      dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo.h, kt, dqa, 0, 0, 0);
+      if (AA_DS_TERMS > 1) dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo.h, kt, dqa, 0, 0, 0);
     }
     // key row complete: d rh_q[ky] of the query (both lane halves) folds into dq now and is parked for the d key_rel_h sums
     drh += __shfl_xor(drh, 32);
 #pragma unroll
     for (int d = 0; d < 10; ++d) dqr[d] = fmaf(drh, RH[(10 * lh + d) * LH + r], dqr[d]);
-    if (lh == 0) dr2[ky * AQM + ql] = qvalid ? drh : 0.f;       // parked for the d key_rel_h sums after the loop
+    if (lh == 0) dr2[ky * DRP + ql] = qvalid ? drh : 0.f;       // parked for the d key_rel_h sums after the loop
   }
   __syncthreads();
   // Table gradients as skewed matrix products over the workgroup's AQM queries l, one 32-row tile of table columns rr per wave:
@@ -621,7 +663,7 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
       for (int s2 = 0; s2 < AQM / 2; ++s2) {
         const int kk = by_row ? rr + yy - (H - 1) : rr + xq - (WW - 1);
         const int kc = min(max(kk, 0), (by_row ? H : WW) - 1);
-        const float av = by_row ? dr2[kc * AQM + l] : dwq[l * (WW + 1) + kc];
+        const float av = by_row ? dr2[kc * DRP + l] : dwq[l * (WW + 1) + kc];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk == kc ? av : 0.f, qcol[l * (DKH + 1)], acc, 0, 0, 0);
         l += 2;
         xq += 2;
@@ -921,11 +963,11 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         hi.u[jj] = pk_bf16(w[2 * jj], w[2 * jj + 1]);
-        lo.u[jj] = pk_bf16(w[2 * jj] - __uint_as_float(hi.u[jj] << 16), w[2 * jj + 1] - __uint_as_float(hi.u[jj] & 0xffff0000u));
+        if (AA_DS_TERMS > 1) lo.u[jj] = pk_bf16(w[2 * jj] - __uint_as_float(hi.u[jj] << 16), w[2 * jj + 1] - __uint_as_float(hi.u[jj] & 0xffff0000u));
       }
       const bf16x8 qt = tr_frag_k(Qi + bq * 32 * KB_PITCH, KB_PITCH, g16 * 16, lane);
       dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi.h, qt, dka, 0, 0, 0);
-      dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo.h, qt, dka, 0, 0, 0);
+      if (AA_DS_TERMS > 1) dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo.h, qt, dka, 0, 0, 0);
     }
     __syncthreads();
   }
@@ -1095,7 +1137,8 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
   } else {
     static const bool q_row = cx_diag_set("CX_AA_Q_ROW");          // diagnostic: the per-query VALU kernel
     if ((WW == 40 || WW == 20) && !q_row) {
-      const size_t smem_m = (tables + 64 * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1))) * 4 + 64 * KB_PITCH;
+      const size_t smem_m = (tables + 2 * (WW == 40 ? 40 : 24) * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1)) + ((g.H + 3) & ~3)) * 4 +
+                            2 * (WW == 40 ? 48 : 32) * KB_PITCH;
       static bool attr_m = false;
       if (!attr_m) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_mfma_kernel<DVH, WW>), hipFuncAttributeMaxDynamicSharedMemorySize,
