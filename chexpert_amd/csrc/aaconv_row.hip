@@ -398,29 +398,68 @@ __global__ __launch_bounds__(AQ) void aa_attn_bwd_k_row_kernel(const bf16* __res
 // one tile:  S^T = K Q^T  (keys in accumulator rows, queries in lanes: lane (q, half) sees 16 + 4 of the row's 40 keys, always the
 // same columns kx, so its relative-column logits rw_q[kx] and their gradients are 20 registers indexed at compile time),
 // then per element  p = exp(S + rh + rw - lse),  ds = p (dO . v - delta),  and  dQ += dS K  with dS moved from accumulator to
-// operand layout by v_permlane32_swap and split into two bf16 terms (hi + lo: 2^-17 relative, dq is checked to 1e-3).
-// The relative-table gradients keep the owner-computes LDS sums of the row kernel.
+// operand layout by v_permlane32_swap as one fp16 term (see aa_op below; dq is checked to 1e-3).
+// The relative-table gradients are skewed matrix products on the same pipe after the key loop.
 constexpr int AQM = 128;               // queries per workgroup (4 waves x 32)
-#ifndef AA_DS_TERMS
-#define AA_DS_TERMS 2                  // bf16 terms of dS in the dQ / dK products: 2 = hi + lo (2^-17 relative), 1 = hi only (2^-9)
-#endif
 constexpr int KB_PITCH = 80;           // bf16 key image: 32 d (20 used) + 16 B pad
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Operand type of the two backward kernels' matrix products.  q and k arrive as bf16; dS = p (dP - delta) is produced in fp32 and has
+// to become a 16-bit operand of dQ += dS K / dK += dS^T Q.  As bf16 that costs 2^-9 per term (measured 1.3e-3 / 1.7e-3 rms on dq / dk --
+// as much as rounding the RESULT to bf16) unless it is split into hi + lo terms (rounds 3-4: 2^-17, at +20 vector instructions and one
+// more MFMA per 16 keys).  As fp16 one term carries 2^-12: q and k convert exactly (8-bit mantissas; magnitudes below 6e-5 land on
+// the fp16 subnormal grid, 3e-8 absolute; saturated at +-65504), the products and their fp32 sums are the same numbers the bf16 MFMA
+// of the forward produced, and v_cvt_pk_f16_f32 costs what v_cvt_pk_bf16_f32 does.  AA_BWD_F16 = 0 restores bf16 hi + lo.
+#ifndef AA_BWD_F16
+#define AA_BWD_F16 1
+#endif
+#if AA_BWD_F16
+typedef _Float16 aa_op;
+typedef f16x8 aa_opx8;
+#define AA_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define AA_DS_TERMS 1
+__device__ __forceinline__ aa_op aa_to_op(float v) { return (aa_op)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+__device__ __forceinline__ uint32_t pk_op(float a, float b) {
+  union { f16x2v h; uint32_t u; } o;
+  o.h = __builtin_convertvector(f32x2v{a, b}, f16x2v);
+  return o.u;
+}
+// four bf16 (as loaded) -> four operand elements
+__device__ __forceinline__ uint2 aa_ops_of_bf4(const uint2 v) {
+  return make_uint2(pk_op(__builtin_amdgcn_fmed3f(cx_bf_lo(v.x), -65504.f, 65504.f), __builtin_amdgcn_fmed3f(cx_bf_hi(v.x), -65504.f, 65504.f)),
+                    pk_op(__builtin_amdgcn_fmed3f(cx_bf_lo(v.y), -65504.f, 65504.f), __builtin_amdgcn_fmed3f(cx_bf_hi(v.y), -65504.f, 65504.f)));
+}
+#else
+typedef bf16 aa_op;
+typedef bf16x8 aa_opx8;
+#define AA_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#ifndef AA_DS_TERMS
+#define AA_DS_TERMS 2                  // bf16 terms of dS in the dQ / dK products: 2 = hi + lo (2^-17 relative), 1 = hi only (2^-9)
+#endif
+__device__ __forceinline__ aa_op aa_to_op(float v) { return f2bf(v); }
+__device__ __forceinline__ uint32_t pk_op(float a, float b) {
   union { bf16x2v h; uint32_t u; } o;
   o.h = __builtin_convertvector(f32x2v{a, b}, bf16x2v);
   return o.u;
 }
-__device__ __forceinline__ bf16x8 tr_frag_k(const char* tile, int pitch, int k0, int lane) {
+__device__ __forceinline__ uint2 aa_ops_of_bf4(const uint2 v) { return v; }
+#endif
+__device__ __forceinline__ float aa_lo_of(float v, uint32_t packed, int half) {        // v - (element `half` of `packed` as a float)
+  union { uint32_t u; aa_op e[2]; } o;
+  o.u = packed;
+  return v - (float)o.e[half];
+}
+__device__ __forceinline__ aa_opx8 tr_frag_k(const char* tile, int pitch, int k0, int lane) {
   // B operand of D[q][d] += dS[q][k] K[k][d]: this lane gets column d = lane & 31, keys k0 + 8 * (lane >> 5) + 0..7
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const char* base = tile + (k0 + 8 * (g >> 1) + q) * pitch + (16 * (g & 1) + 4 * pp) * 2;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   // (joined by a shuffle + bit cast: assembled element by element the compiler emits a v_bfi per dword on the loaded registers and
   // waits for the read right where it is issued, not where the MFMA uses it -- common.h cx_join_tr)
-  return cx_join_tr(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch)));
+  return __builtin_bit_cast(aa_opx8, cx_join_tr(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * pitch))));
 }
 
 template <int DVH, int WW>
@@ -474,21 +513,21 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
   // the query: bf16 operand fragments (B operand of S^T = K Q^T: d = kk * 16 + lh * 8 + 0..7) and fp32 scaled copy
   float q[DKH];
   const float scale = rsqrtf((float)DKH);
-  bf16x8 qf[2];
+  aa_opx8 qf[2];
   {
     const bf16* qp = base + (size_t)ic * g.ldq + n * DKH;
-    bf16 qb[DKH];
+    aa_op qb[DKH];
 #pragma unroll
     for (int d = 0; d < DKH; d += 4) {
       U64 v;
       v.u = *reinterpret_cast<const uint2*>(qp + d);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { qb[d + e] = v.e[e]; q[d + e] = bf2f(v.e[e]) * scale; }
+      for (int e = 0; e < 4; ++e) { qb[d + e] = aa_to_op(bf2f(v.e[e])); q[d + e] = bf2f(v.e[e]) * scale; }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       qf[0][e] = lh ? qb[8 + e] : qb[e];
-      qf[1][e] = (lh == 0 && e < 4) ? qb[16 + e] : f2bf(0.f);
+      qf[1][e] = (lh == 0 && e < 4) ? qb[16 + e] : aa_to_op(0.f);
     }
   }
   float dO[DVH], delta = 0.f;
@@ -573,7 +612,7 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
     vreg = base[(j0 + vj) * g.ldq + vofs + vd];
   };
   auto store_keys = [&](const int img) __attribute__((always_inline)) {
-    if (tid < WW * 5) *reinterpret_cast<uint2*>(Kb + (img * KR + sj) * KB_PITCH + sc * 8) = kreg;
+    if (tid < WW * 5) *reinterpret_cast<uint2*>(Kb + (img * KR + sj) * KB_PITCH + sc * 8) = aa_ops_of_bf4(kreg);
     if (tid < WW * DVH) Vt[(img * VR + vj) * DVH + vd] = bf2f(vreg);
   };
   load_keys(0);
@@ -596,11 +635,11 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
     for (int e = 0; e < 16; ++e) st0[e] = st1[e] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kc + lrow * KB_PITCH + kk * 32 + lh * 16);
-      st0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kk], st0, 0, 0, 0);
+      const aa_opx8 k0 = *reinterpret_cast<const aa_opx8*>(Kc + lrow * KB_PITCH + kk * 32 + lh * 16);
+      st0 = AA_MFMA(k0, qf[kk], st0, 0, 0, 0);
       if (WW == 40) {
-        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kc + r1 * KB_PITCH + kk * 32 + lh * 16);
-        st1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kk], st1, 0, 0, 0);
+        const aa_opx8 k1 = *reinterpret_cast<const aa_opx8*>(Kc + r1 * KB_PITCH + kk * 32 + lh * 16);
+        st1 = AA_MFMA(k1, qf[kk], st1, 0, 0, 0);
       }
     }
     float ds[NE], drh = 0.f;
@@ -629,15 +668,15 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
         v[r4] = __uint_as_float(sw[0]);
         v[4 + r4] = __uint_as_float(sw[1]);
       }
-      union { bf16x8 h; uint32_t u[4]; } hi, lo;
+      union { aa_opx8 h; uint32_t u[4]; } hi, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        hi.u[j] = pk_bf16(v[2 * j], v[2 * j + 1]);
-        if (AA_DS_TERMS > 1) lo.u[j] = pk_bf16(v[2 * j] - __uint_as_float(hi.u[j] << 16), v[2 * j + 1] - __uint_as_float(hi.u[j] & 0xffff0000u));
+        hi.u[j] = pk_op(v[2 * j], v[2 * j + 1]);
+        if (AA_DS_TERMS > 1) lo.u[j] = pk_op(aa_lo_of(v[2 * j], hi.u[j], 0), aa_lo_of(v[2 * j + 1], hi.u[j], 1));
       }
-      const bf16x8 kt = tr_frag_k(Kc, KB_PITCH, g16 * 16, lane);
-      dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi.h, kt, dqa, 0, 0, 0);
-      if (AA_DS_TERMS > 1) dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo.h, kt, dqa, 0, 0, 0);
+      const aa_opx8 kt = tr_frag_k(Kc, KB_PITCH, g16 * 16, lane);
+      dqa = AA_MFMA(hi.h, kt, dqa, 0, 0, 0);
+      if (AA_DS_TERMS > 1) dqa = AA_MFMA(lo.h, kt, dqa, 0, 0, 0);
     }
     // key row complete: d rh_q[ky] of the query (both lane halves) folds into dq now and is parked for the d key_rel_h sums
     drh += __shfl_xor(drh, 32);
@@ -778,12 +817,12 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
   for (int t = tid; t < LH * 32; t += NT) {
     const int r = t >> 5, d = t & 31;
     const float v = d < DKH ? rel_h[d * LH + r] : 0.f;
-    const bf16 hi = f2bf(v);
-    *reinterpret_cast<bf16*>(RHhi + r * KB_PITCH + d * 2) = hi;
-    *reinterpret_cast<bf16*>(RHlo + r * KB_PITCH + d * 2) = f2bf(v - bf2f(hi));
+    const aa_op hi = aa_to_op(v);
+    *reinterpret_cast<aa_op*>(RHhi + r * KB_PITCH + d * 2) = hi;
+    *reinterpret_cast<aa_op*>(RHlo + r * KB_PITCH + d * 2) = aa_to_op(v - (float)hi);
   }
   // key_rel_w columns 32 * wave + lrow as B-operand fragments (k = d), hi + lo
-  bf16x8 rwhi[2], rwlo[2];
+  aa_opx8 rwhi[2], rwlo[2];
   {
     const int rr = min(32 * wave + lrow, LW - 1);
 #pragma unroll
@@ -792,28 +831,28 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
       for (int e = 0; e < 8; ++e) {
         const int d = kk * 16 + lh * 8 + e;
         const float v = (d < DKH && wave < NGT) ? rel_w[d * LW + rr] : 0.f;
-        const bf16 hi = f2bf(v);
+        const aa_op hi = aa_to_op(v);
         rwhi[kk][e] = hi;
-        rwlo[kk][e] = f2bf(v - bf2f(hi));
+        rwlo[kk][e] = aa_to_op(v - (float)hi);
       }
   }
   // the key: operand fragments (B operand of S = Q K^T: d = kk * 16 + lh * 8 + 0..7) and the fp32 values
-  bf16x8 kf[2];
+  aa_opx8 kf[2];
   float v[DVH], dv[DVH];
   {
     const bf16* kp = base + (size_t)jc * g.ldq + g.dk + n * DKH;
-    bf16 kb[DKH];
+    aa_op kb[DKH];
 #pragma unroll
     for (int d = 0; d < DKH; d += 4) {
       U64 u;
       u.u = *reinterpret_cast<const uint2*>(kp + d);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) kb[d + e] = u.e[e];
+      for (int e = 0; e < 4; ++e) kb[d + e] = aa_to_op(bf2f(u.e[e]));
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       kf[0][e] = lh ? kb[8 + e] : kb[e];
-      kf[1][e] = (lh == 0 && e < 4) ? kb[16 + e] : f2bf(0.f);
+      kf[1][e] = (lh == 0 && e < 4) ? kb[16 + e] : aa_to_op(0.f);
     }
 #pragma unroll
     for (int d = 0; d < DVH; ++d) { v[d] = bf2f(base[(size_t)jc * g.ldq + 2 * g.dk + n * DVH + d]); dv[d] = 0.f; }
@@ -845,7 +884,7 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
   auto store_tile = [&](int u) __attribute__((always_inline)) {
     const int bq = u % 3;
     if (tid < 160) {
-      *reinterpret_cast<uint2*>(Qi + (bq * 32 + sq) * KB_PITCH + sc * 8) = qreg;
+      *reinterpret_cast<uint2*>(Qi + (bq * 32 + sq) * KB_PITCH + sc * 8) = aa_ops_of_bf4(qreg);
     } else if (tid < 192) {
 #pragma unroll
       for (int d = 0; d < DP; ++d) Dd[(bq * 32 + sq) * DP + d] = dreg[d];
@@ -865,9 +904,9 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, rwhi[kk], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, rwlo[kk], acc, 0, 0, 0);
+        const aa_opx8 a = *reinterpret_cast<const aa_opx8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+        acc = AA_MFMA(a, rwhi[kk], acc, 0, 0, 0);
+        acc = AA_MFMA(a, rwlo[kk], acc, 0, 0, 0);
       }
       const int kb = 32 * role + lrow - (WW - 1) + m;                 // kx = kb + qo - WW * wraps
       float* gdst = Gs + (bt * 32 + 4 * lh) * GP;
@@ -887,11 +926,11 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
       const int rrow = min(ky0 - (y0 + dmax) + H - 1 + lrow, LH - 1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(RHhi + rrow * KB_PITCH + kk * 32 + lh * 16);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(RHlo + rrow * KB_PITCH + kk * 32 + lh * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc, 0, 0, 0);
+        const aa_opx8 a = *reinterpret_cast<const aa_opx8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+        const aa_opx8 bh = *reinterpret_cast<const aa_opx8*>(RHhi + rrow * KB_PITCH + kk * 32 + lh * 16);
+        const aa_opx8 bl = *reinterpret_cast<const aa_opx8*>(RHlo + rrow * KB_PITCH + kk * 32 + lh * 16);
+        acc = AA_MFMA(a, bh, acc, 0, 0, 0);
+        acc = AA_MFMA(a, bl, acc, 0, 0, 0);
       }
       // column n of the product is key row ky0 + n - (dmax - wraps): stored at n - dmax + wraps + 2, read at kyl + 2
       if (lrow < NKR + 2) {
@@ -929,8 +968,8 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
     for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[kk], st, 0, 0, 0);
+      const aa_opx8 a = *reinterpret_cast<const aa_opx8*>(Qi + (bq * 32 + lrow) * KB_PITCH + kk * 32 + lh * 16);
+      st = AA_MFMA(a, kf[kk], st, 0, 0, 0);
     }
     const float* gp = Gs + (bt * 32 + 4 * lh) * GP + kxl;
     const float* up = Us + (bt * 32 + 4 * lh) * UP + kyl + 2;
@@ -959,15 +998,15 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
         w[r4] = __uint_as_float(sw[0]);
         w[4 + r4] = __uint_as_float(sw[1]);
       }
-      union { bf16x8 h; uint32_t u[4]; } hi, lo;
+      union { aa_opx8 h; uint32_t u[4]; } hi, lo;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        hi.u[jj] = pk_bf16(w[2 * jj], w[2 * jj + 1]);
-        if (AA_DS_TERMS > 1) lo.u[jj] = pk_bf16(w[2 * jj] - __uint_as_float(hi.u[jj] << 16), w[2 * jj + 1] - __uint_as_float(hi.u[jj] & 0xffff0000u));
+        hi.u[jj] = pk_op(w[2 * jj], w[2 * jj + 1]);
+        if (AA_DS_TERMS > 1) lo.u[jj] = pk_op(aa_lo_of(w[2 * jj], hi.u[jj], 0), aa_lo_of(w[2 * jj + 1], hi.u[jj], 1));
       }
-      const bf16x8 qt = tr_frag_k(Qi + bq * 32 * KB_PITCH, KB_PITCH, g16 * 16, lane);
-      dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi.h, qt, dka, 0, 0, 0);
-      if (AA_DS_TERMS > 1) dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo.h, qt, dka, 0, 0, 0);
+      const aa_opx8 qt = tr_frag_k(Qi + bq * 32 * KB_PITCH, KB_PITCH, g16 * 16, lane);
+      dka = AA_MFMA(hi.h, qt, dka, 0, 0, 0);
+      if (AA_DS_TERMS > 1) dka = AA_MFMA(lo.h, qt, dka, 0, 0, 0);
     }
     __syncthreads();
   }
