@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int d = kk * 16 + lh * 8 + e;
-        const float v = (d < DKH && wave < NGT) ? rel_w[d * LW + rr] : 0.f;
+        const float v = (d < DKH && wave < NGT) ? rel_w[d * LW + rr] * sl : 0.f;      // (the logit scale rides on the table operand)
         const aa_op hi = aa_to_op(v);
         rwhi[kk][e] = hi;
         rwlo[kk][e] = aa_to_op(v - (float)hi);
@@ -910,13 +910,22 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
       }
       const int kb = 32 * role + lrow - (WW - 1) + m;                 // kx = kb + qo - WW * wraps
       float* gdst = Gs + (bt * 32 + 4 * lh) * GP;
+      // (W = 40: a tile starts at a column that is a multiple of 8, so whether query qo + 4 lh is past the end of its image row
+      // is the same for both lane halves and all four queries of an accumulator group -- a scalar per group, not a compare and a
+      // select per entry)
+      const int jw = (WW - x0) >> 3;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int qo = (e & 3) + 8 * (e >> 2);
-        int kx = kb + qo;
-        kx -= m + qo >= WW ? WW : 0;
-        if (WW < 32) kx -= m + qo >= 2 * WW ? WW : 0;
-        gdst[qo * GP + ((unsigned)kx < (unsigned)WW ? kx : WW)] = acc[e] * sl;
+        int kx;
+        if (WW == 40) {
+          kx = kb + (qo - ((e >> 2) >= jw ? WW : 0));
+        } else {
+          kx = kb + qo;
+          kx -= m + qo >= WW ? WW : 0;
+          kx -= m + qo >= 2 * WW ? WW : 0;
+        }
+        gdst[qo * GP + min((unsigned)kx, (unsigned)WW)] = acc[e];
       }
     } else if (role == 3) {
       f32x16 acc;
@@ -936,11 +945,17 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
       if (lrow < NKR + 2) {
         float* udst = Us + (bt * 32 + 4 * lh) * UP + lrow - dmax + 2;
         const float* nl = Ls + bq * 32 + 4 * lh;
+        const int jw = (WW - x0) >> 3;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int qo = (e & 3) + 8 * (e >> 2);
-          int c = m + qo >= WW ? 1 : 0;
-          if (WW < 32) c += m + qo >= 2 * WW ? 1 : 0;
+          int c;
+          if (WW == 40) {
+            c = (e >> 2) >= jw ? 1 : 0;                                // (scalar, see the G table)
+          } else {
+            c = m + qo >= WW ? 1 : 0;
+            c += m + qo >= 2 * WW ? 1 : 0;
+          }
           c = min(c, dmax);                                            // (queries past the map wrap further: same window, nl = -1e30)
           udst[qo * UP + c] = fmaf(acc[e], sl, nl[qo]);
         }
