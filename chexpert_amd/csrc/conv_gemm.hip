@@ -415,6 +415,7 @@ int cx_try_strip_dgrad(const CxConv& p, hipStream_t st, bool* handled);
 int cx_try_pw_dgrad(const CxConv& p, hipStream_t st, bool* handled);        // conv1x1_dgrad.hip
 int cx_try_pw_fwd(const CxConv& p, hipStream_t st, bool* handled);          // conv1x1_fwd.hip
 int cx_try_pw_fwdk(const CxConv& p, hipStream_t st, bool* handled);         // conv1x1_fwdk.hip
+int cx_try_pw_xs(const CxConv& p, hipStream_t st, bool* handled);           // conv1x1_xs.hip
 int cx_try_stem_fwd(const CxConv& p, hipStream_t st, bool* handled);        // conv_stem.hip
 int cx_conv_gemm_f32(const CxConv& p, hipStream_t st);                      // conv_f32.hip
 int cx_try_conv_mm(const CxConv& p, hipStream_t st, bool* handled);         // conv_mm.hip
@@ -520,6 +521,8 @@ extern "C" int cx_conv_gemm(const CxConv* pp, void* stream) {
       rc = cx_try_pw_fwd(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_pw_fwdk(p, st, &handled);
+      if (handled) return rc;
+      rc = cx_try_pw_xs(p, st, &handled);
       if (handled) return rc;
       rc = cx_try_conv_mm(p, st, &handled);
       if (handled) return rc;

@@ -197,6 +197,11 @@ def last_stat_rows():
     return lib().cx_last_stat_rows()
 
 
+def last_kernel():
+    """The kernel instantiation the most recent conv / weight-gradient call of this thread dispatched to, as rocprofv3 spells it."""
+    return lib().cx_last_kernel().decode()
+
+
 def last_pro_out():
     """True when the last conv_gemm of this thread wrote its `pro_out` side tensor (the selected kernel supports it)."""
     return bool(lib().cx_last_pro_out())
