@@ -115,7 +115,8 @@ typedef struct CxConv {
   /* ABI 10.  Per-call kernel selection for tests and micro-benchmarks (stateless: replaces the process-wide dbg_* selectors of      */
   /* earlier ABIs).  0: the library picks.  Low byte 1: the generic implicit-GEMM kernels (conv_gemm.hip / conv_wgrad.hip),        */
   /* 2: the tiled kernels (conv_mm.hip / wgrad_mm.hip) where the shape allows.  Second byte f + 1: tile form f (1 = 128 x 128,     */
-  /* 2 = 256 x 128 (weight gradient only), 3 = 128 x 256; weight gradient f = 0: the strip kernel for 3x3).  CX_KERNEL_HINT(on, f). */
+  /* 2 = 256 x 128 (weight gradient only), 3 = 128 x 256; weight gradient f = 0: the strip kernel for 3x3; f = 5: the activation-   */
+  /* stationary 1x1 kernel, conv1x1_xs.hip, or an error; f = 7 / 8: ring / producer-consumer 3x3 forms).  CX_KERNEL_HINT(on, f).     */
   int32_t kernel_hint;
   int32_t pad2_;
 } CxConv;
