@@ -23,6 +23,7 @@
 
 namespace {
 
+// (timing ablations behind -DXS_ABL: bit 0 drops the chunk epilogue, bit 1 the weight stream -- profiles/r05_xs_kernel.txt)
 #ifndef XS_ABL
 #define XS_ABL 0
 #endif
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        if (kk == 1 && !(XS_ABL & 2)) {                                 // the next step's weights (requested a step ago) to the free stage, the one after requested
+        if (kk == 1 && !(XS_ABL & 2)) {                // the next step's weights (requested a step ago) to the free stage, the one after requested
           store_w((t + 1) & 1);
           issue_w(t + 2);
         }
@@ -256,10 +257,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     }
-    if (XS_ABL & 1) { float t = 0.f;
+    if (XS_ABL & 1) {                                  // (keeps the accumulators alive when the epilogue is ablated)
+      float t = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
-      if (t == 1.2345f) Y[0] = f2bf(t); }
+      if (t == 1.2345f) Y[0] = f2bf(t);
+    }
     if (want_stats) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
