@@ -452,6 +452,28 @@ __device__ __forceinline__ float aa_lo_of(float v, uint32_t packed, int half) { 
   o.u = packed;
   return v - (float)o.e[half];
 }
+// dS is proportional to the gradient dO that arrives at the attention output, and a training step's dO can be anywhere (1e-3 .. 1e-8:
+// loss averaging, depth): as an fp16 operand dS = p (dO . v - delta) would sink into the subnormals (6e-8) and flush.  Both backward
+// kernels therefore scale dO and delta by a power of two that brings the workgroup's largest |dO| into [1, 2) -- exact -- carry the
+// factor through everything that is linear in dS (dQ, dK, dV, the table gradients) and remove it at the outputs.  bf16 operands
+// (AA_BWD_F16 = 0) have fp32's exponent range and the factor is 1.
+struct AaScale { float up, down; };
+__device__ __forceinline__ AaScale aa_scale_of(const float amax) {
+  AaScale r;
+  const uint32_t eb = (__float_as_uint(amax) >> 23) & 0xffu;
+  const bool ok = AA_BWD_F16 && eb >= 1u && eb <= 253u;
+  r.up = ok ? __uint_as_float((254u - eb) << 23) : 1.f;       // 2^(127 - eb): amax * up in [1, 2)
+  r.down = ok ? __uint_as_float(eb << 23) : 1.f;
+  return r;
+}
+// workgroup maximum of a non-negative value through four LDS words (256 threads); contains one barrier
+__device__ __forceinline__ float aa_wg_max(float v, float* slot, const int lane, const int wave) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  if (lane == 0) slot[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
+}
 __device__ __forceinline__ aa_opx8 tr_frag_k(const char* tile, int pitch, int k0, int lane) {
   // B operand of D[q][d] += dS[q][k] K[k][d]: this lane gets column d = lane & 31, keys k0 + 8 * (lane >> 5) + 0..7
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
@@ -494,6 +516,7 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
                                          // part of dq: AQM * max(H, WW + 1) + H (rounded up to 4) floats
   float* dr2 = dwq;
   char* Kb = reinterpret_cast<char*>(dwq + AQM * (H > WW + 1 ? H : WW + 1) + ((H + 3) & ~3));     // 2 x bf16 [KR keys][KB_PITCH], 16-byte aligned
+  float* Smax = reinterpret_cast<float*>(Kb + 2 * KR * KB_PITCH);                                  // 4 words: the waves' largest |dO|
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5;
   const int ql = wave * 32 + lrow;                              // query of this lane inside the workgroup
@@ -542,7 +565,14 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
 #pragma unroll
     for (int d = 0; d < DKH; ++d) Qs[ql * (DKH + 1) + d] = qvalid ? q[d] : 0.f;
   }
-  __syncthreads();
+  // the workgroup's gradient scale (see AaScale): dS and everything summed from it carry `up` until the outputs
+  float amax = 0.f;
+#pragma unroll
+  for (int d = 0; d < DVH; ++d) amax = fmaxf(amax, fabsf(dO[d]));
+  const AaScale gs = aa_scale_of(aa_wg_max(amax, Smax, lane, wave));       // (its barrier also publishes Qs, the tables and the zero fill)
+#pragma unroll
+  for (int d = 0; d < DVH; ++d) dO[d] *= gs.up;
+  delta *= gs.up;
 
   // this lane's key columns: kx = (e & 3) + 8 * (e >> 2) + 4 * lh for e < 16 (keys 0..31), 32 + (e - 16) + 4 * lh after
   // (a rolled loop over d with the query read back from LDS: fully unrolled, the 400 table reads are hoisted and spilled)
@@ -716,7 +746,7 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (rr < L) out[lrow * L + rr] = acc[r];
+        if (rr < L) out[lrow * L + rr] = acc[r] * gs.down;
       }
     }
   };
@@ -753,7 +783,7 @@ __global__ __launch_bounds__(256, 3) void aa_attn_bwd_q_mfma_kernel(const bf16* 
       const int qq = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (i0 + qq < HW) {
         float* dqp = dqkv + ((size_t)b * HW + i0 + qq) * (2 * g.dk + g.dv) + n * DKH;
-        dqp[lrow] = (dqa[r] + dqx[qq * (DKH + 1) + lrow]) * scale;
+        dqp[lrow] = (dqa[r] + dqx[qq * (DKH + 1) + lrow]) * (scale * gs.down);
       }
     }
   }
@@ -799,6 +829,7 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
   float* Ls = Dd + 3 * 32 * DP;                                              // 3 x [32]: -lse * log2(e) of the tile's queries (-1e30 past the map)
   char* RHhi = reinterpret_cast<char*>(Ls + 3 * 32);                         // bf16 [LH][KB_PITCH]: key_rel_h^T, hi and lo parts
   char* RHlo = RHhi + (size_t)LH * KB_PITCH;
+  float* Smax = reinterpret_cast<float*>(RHlo + (size_t)LH * KB_PITCH);       // 4 words: the waves' largest |dO|
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5;
   const int bn = blockIdx.y, b = bn / g.nh, n = bn - b * g.nh;
@@ -813,6 +844,17 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
   const float sl = scale * LOG2E;
   const int ntl = (HW + 31) / 32;
 
+  // the gradient scale of this (image, head) (see AaScale): every query's dO meets this workgroup's keys
+  AaScale gs;
+  {
+    float amax = 0.f;
+    const float* dob = d_o + (size_t)b * HW * g.dv + n * DVH;
+    for (int t = tid; t < HW * DVH; t += NT) {
+      const int i = t / DVH, d = t - i * DVH;
+      amax = fmaxf(amax, fabsf(dob[(size_t)i * g.dv + d]));
+    }
+    gs = aa_scale_of(aa_wg_max(amax, Smax, lane, wave));
+  }
   for (int t = tid; t < 3 * 32 * KB_PITCH / 4; t += NT) reinterpret_cast<uint32_t*>(Qi)[t] = 0u;
   for (int t = tid; t < LH * 32; t += NT) {
     const int r = t >> 5, d = t & 31;
@@ -876,8 +918,8 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
       const float* dp = d_o + ((size_t)b * HW + i) * g.dv + n * DVH;
       float de = 0.f;
 #pragma unroll
-      for (int d = 0; d < DVH; ++d) { dreg[d] = dp[d]; de = fmaf(dp[d], op[d], de); }
-      dreg[DVH] = de;
+      for (int d = 0; d < DVH; ++d) { dreg[d] = dp[d] * gs.up; de = fmaf(dp[d], op[d], de); }
+      dreg[DVH] = de * gs.up;
       lreg = u * 32 + sq < HW ? -lse[(size_t)bn * HW + i] * LOG2E : -1.0e30f;
     }
   };
@@ -1031,13 +1073,13 @@ __global__ __launch_bounds__(256, (WW == 40 && DVH <= 2) ? 4 : 3) void aa_attn_b
   if (kvalid && lh == 0) {
     float* op = dqkv + ((size_t)b * HW + j) * ctot + 2 * g.dk + n * DVH;
 #pragma unroll
-    for (int d = 0; d < DVH; ++d) op[d] = dv[d];
+    for (int d = 0; d < DVH; ++d) op[d] = dv[d] * gs.down;
   }
   if (lrow < DKH) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kk = j0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (kk < HW) dqkv[((size_t)b * HW + kk) * ctot + g.dk + n * DKH + lrow] = dka[r] * scale;
+      if (kk < HW) dqkv[((size_t)b * HW + kk) * ctot + g.dk + n * DKH + lrow] = dka[r] * (scale * gs.down);
     }
   }
 }
@@ -1192,7 +1234,7 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
     static const bool q_row = cx_diag_set("CX_AA_Q_ROW");          // diagnostic: the per-query VALU kernel
     if ((WW == 40 || WW == 20) && !q_row) {
       const size_t smem_m = (tables + 2 * (WW == 40 ? 40 : 24) * DVH + (size_t)AQM * (DKH + 1 + (g.H > WW + 1 ? g.H : WW + 1)) + ((g.H + 3) & ~3)) * 4 +
-                            2 * (WW == 40 ? 48 : 32) * KB_PITCH;
+                            2 * (WW == 40 ? 48 : 32) * KB_PITCH + 16;
       static bool attr_m = false;
       if (!attr_m) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aa_attn_bwd_q_mfma_kernel<DVH, WW>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1210,7 +1252,7 @@ int launch_row(int which, const void* qkv, const float* rel_h, const float* rel_
     if ((WW == 40 || WW == 20) && !k_row) {
       constexpr int NKR = 127 / WW + 2;
       const size_t smem_k = (size_t)3 * 32 * KB_PITCH + ((size_t)2 * 32 * (WW + 1) + 2 * 32 * (NKR + 6) + 3 * 32 * (DVH + 1) + 3 * 32) * 4 +
-                            (size_t)2 * (2 * g.H - 1) * KB_PITCH;
+                            (size_t)2 * (2 * g.H - 1) * KB_PITCH + 16;
       hipLaunchKernelGGL((aa_attn_bwd_k_mfma_kernel<DVH, WW>), dim3((g.H * WW + 127) / 128, g.B * g.nh), dim3(256), smem_k, st,
                          (const bf16*)qkv, rel_h, rel_w, o, d_o, lse, dqkv, g);
     } else {

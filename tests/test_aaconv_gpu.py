@@ -363,3 +363,36 @@ def test_out_projection_forward_backward(dev, dv, det):
     assert (dO.cpu() - dO_want).abs().max().item() < 1e-4 * dO_want.abs().max().item()
     assert ((dW.cpu() - dw0).view(dv, dv) - dW_want).abs().max().item() < 1e-4 * dW_want.abs().max().item()
     ops.set_det_wgrad(False)
+
+
+@pytest.mark.parametrize("B,H,W,dv", [(1, 40, 40, 8), (2, 20, 20, 24)])
+def test_attention_backward_is_invariant_to_the_gradient_magnitude(dev, B, H, W, dv):
+    """The matrix products of the two backward kernels take dS = p (dO . v - delta) as a 16-bit operand (fp16: csrc/aaconv_row.hip,
+    aa_op): a training step's dO can be 1e-8 as well as 1e+3, so both kernels scale it by a power of two per workgroup and unscale
+    their outputs.  With dO multiplied by 2^-24 or 2^+12 every output is EXACTLY the scaled output of the unscaled call."""
+    from chexpert_amd import ops
+    nh, dk = 8, 160
+    Cq = 2 * dk + dv
+    qkv = bf(synth.uniform(1, (B, H, W, Cq), -1.5, 1.5)).to(torch.bfloat16).to(dev)
+    rel_h = (synth.uniform(2, (dk // nh, 2 * H - 1), -1, 1) + dk ** -0.5).to(dev)
+    rel_w = (synth.uniform(3, (dk // nh, 2 * W - 1), -1, 1) + dk ** -0.5).to(dev)
+    d_o = synth.uniform(4, (B, H * W, dv), -1, 1).to(dev)
+    o = torch.zeros(B, H * W, dv, device=dev)
+    lse = torch.zeros(B * nh, H * W, device=dev)
+    ops.aa_attention_fwd(qkv, rel_h, rel_w, o, lse, nh, dk, dv)
+
+    def run(g):
+        dqkv = torch.zeros(B, H * W, Cq, device=dev)
+        drh, drw = torch.zeros_like(rel_h), torch.zeros_like(rel_w)
+        ops.aa_attention_bwd(qkv, rel_h, rel_w, o, g, lse, dqkv, drh, drw, nh, dk, dv)
+        return dqkv, drh, drw
+
+    base = run(d_o)
+    assert all(torch.isfinite(t).all().item() for t in base) and base[0][..., :dk].abs().max().item() > 0
+    for s in (2.0 ** -24, 2.0 ** 12):
+        got = run(d_o * s)
+        assert torch.equal(got[0], base[0] * s), "dqkv at gradient scale %g: max rel diff %.3e" % (
+            s, ((got[0] - base[0] * s).abs().max() / (base[0].abs().max() * s)).item())
+        for a, b_, what in zip(got[1:], base[1:], ("d key_rel_h", "d key_rel_w")):
+            # (this direct call has no slab workspace: the workgroups' table partials meet in fp32 atomics, whose order varies)
+            close(a.cpu() / s, b_.cpu(), 1e-5, what)
