@@ -287,22 +287,35 @@ __global__ __launch_bounds__(64 * WA * WB) __attribute__((amdgpu_waves_per_eu(2,
 // (dy = 0 / 2 at y = 0 / H - 1) are zero rows of the strip.  What a padded position is (real pixel or zero, and which pixel) comes
 // from a small LDS table that 136 threads fill three steps ahead (two exact divisions by multiplication per entry), so a staged
 // chunk costs one table read, one multiply-add and one AND.  Per step: 24 MFMAs per wave against 16 staged chunks per thread pair.
+//
+// Stride 2 (S2; the first 3x3 of a ResNet stage, the 3x3 branch of an attention-augmented transition): the same workgroup, the pixels
+// walked in the padded OUTPUT index space (each output row is Wo + 1 positions, position 0 a zero), and the activation row
+// 2 oy + dy - 1 staged DE-INTERLEAVED as two strips -- even columns 2 ox, odd columns 2 ox + 1 -- so that the three taps of the kernel
+// row are again unit shifts: dx = 1 reads the even strip at the position, dx = 2 the odd strip at the position, dx = 0 the odd strip
+// one position to the left (column 2 ox - 1; the pad position makes ox = 0 read zeros).  The generic kernel (conv_wgrad.hip) gave
+// every (tap, 64-channel tile) its own workgroup: dZ staged and transformed 36 times for a 256-channel layer instead of 6.
 struct W3Geo {
-  int B, H, W, P, TP;              // P = W + 2 positions per padded row, TP = B * H * P positions
-  uint32_t mP, mH;                 // ceil(2^32 / P), ceil(2^32 / H): q / P == umulhi(q, mP) for q * P < 2^32
+  int B, H, W, P, TP;              // P positions per padded row (stride 1: W + 2; stride 2: Wo + 1), TP = B * (rows) * P positions
+  uint32_t mP, mH;                 // ceil(2^32 / P), ceil(2^32 / rows per image): q / P == umulhi(q, mP) for q * P < 2^32
+  int Ho, Wo;                      // stride 2: the gradient's image (rows per image = Ho); stride 1: == H, W
 };
 
 constexpr int W3_GP = 128 * 2 + 64, W3_XP = 128 * 2 + 64;
 constexpr int W3_XROWS = 68;       // 66 strip rows used (64 + the two dx neighbours), padded
-constexpr int W3_STAGE = PX * W3_GP + W3_XROWS * W3_XP;
-constexpr int W3_TAB = 64 + W3_XROWS;
+template <bool S2>
+struct W3L {
+  static constexpr int NSTRIP = S2 ? 2 : 1;
+  static constexpr int STAGE = PX * W3_GP + NSTRIP * W3_XROWS * W3_XP;
+  static constexpr int TAB = 64 + NSTRIP * W3_XROWS;
+};
 
-template <int GPRO, int XPRO>
+template <int GPRO, int XPRO, bool S2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3_kernel(const CxWgrad p, const W3Geo g, const int c_tiles,
                                                                                               const int n_tiles, const int total_steps,
                                                                                               const int steps_per_split,
                                                                                               float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int W3_STAGE = W3L<S2>::STAGE, W3_TAB = W3L<S2>::TAB;
   uint32_t* tab = reinterpret_cast<uint32_t*>(smem + 2 * W3_STAGE);          // [3][W3_TAB]: bit 31 = real pixel, low bits = its index
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave >> 2, wb = wave & 3;             // 64 n x 32 c x 3 taps per wave
@@ -345,15 +358,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // table of step t (absolute): entries 0..63 = the dZ positions, 64.. = the strip positions
   auto fill_table = [&](int t) __attribute__((always_inline)) {
     if (tid < W3_TAB) {
-      const int q = tid < 64 ? t * PX + tid : t * PX + (tid - 64) + xshift;
-      bool ok = q >= 0 && q < g.TP;
-      const uint32_t qc = ok ? (uint32_t)q : 0u;
-      const uint32_t R = __umulhi(qc, g.mP);             // padded row = b * H + y
-      const uint32_t xp = qc - R * g.P;
-      const uint32_t y = R - __umulhi(R, g.mH) * g.H;
-      ok = ok && (xp - 1u) < (uint32_t)g.W;
-      if (tid >= 64) ok = ok && (int)y >= ylo && (int)y <= yhi;
-      tab[(t % 3) * W3_TAB + tid] = ok ? (0x80000000u | (R * g.W + xp - 1u)) : 0u;
+      if (!S2) {
+        const int q = tid < 64 ? t * PX + tid : t * PX + (tid - 64) + xshift;
+        bool ok = q >= 0 && q < g.TP;
+        const uint32_t qc = ok ? (uint32_t)q : 0u;
+        const uint32_t R = __umulhi(qc, g.mP);             // padded row = b * H + y
+        const uint32_t xp = qc - R * g.P;
+        const uint32_t y = R - __umulhi(R, g.mH) * g.H;
+        ok = ok && (xp - 1u) < (uint32_t)g.W;
+        if (tid >= 64) ok = ok && (int)y >= ylo && (int)y <= yhi;
+        tab[(t % 3) * W3_TAB + tid] = ok ? (0x80000000u | (R * g.W + xp - 1u)) : 0u;
+      } else {
+        // entries 0..63: dZ positions; 64..131: even strip (row j = position j of the step); 132..199: odd strip (row j = position j - 1)
+        const int odd = tid >= 64 + W3_XROWS;
+        const int j = tid < 64 ? tid : tid - 64 - odd * W3_XROWS;
+        const int q = t * PX + j - odd;
+        bool ok = q >= 0 && q < g.TP && (tid < 64 || j < 64 + odd);
+        const uint32_t qc = ok ? (uint32_t)q : 0u;
+        const uint32_t R = __umulhi(qc, g.mP);             // padded output row = b * Ho + oy
+        const uint32_t xp = qc - R * g.P;
+        ok = ok && xp >= 1u;
+        const uint32_t bimg = __umulhi(R, g.mH);
+        const uint32_t oy = R - bimg * g.Ho;
+        uint32_t pix = R * g.Wo + xp - 1u;
+        if (tid >= 64) {
+          const int iy = 2 * (int)oy + dy - 1, ix = 2 * ((int)xp - 1) + odd;
+          ok = ok && iy >= 0 && iy < g.H && ix < g.W;
+          pix = (bimg * g.H + (uint32_t)(iy < 0 ? 0 : iy)) * g.W + (uint32_t)(ix < 0 ? 0 : ix);
+        }
+        tab[(t % 3) * W3_TAB + tid] = ok ? (0x80000000u | pix) : 0u;
+      }
     }
   };
 
@@ -361,15 +395,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     u32x4 g[2], g2[2];
   };
   Regs set0, set1;
-  u32x4 xreg[3];                       // [2]: strip rows 64, 65 (threads 0..31)
+  u32x4 xreg[S2 ? 6 : 3];              // [2]: strip rows 64, 65 (threads 0..31); stride 2: [3..5] the odd strip
   auto issue_g = [&](Regs& R, int i, int t) __attribute__((always_inline)) {
     const uint32_t e = tab[(t % 3) * W3_TAB + r32 + 32 * i];
     const uint32_t m = (uint32_t)((int)e >> 31), pix = e & 0x7fffffffu;
     R.g[i] = ld16(Gb, (__umul24(pix, ldg2b) + gcol) & m & nmask);
     if (GPRO == CX_PRO_AFFINE2) R.g2[i] = ld16(G2b, (__umul24(pix, ldg22b) + gcol) & m & nmask);
   };
+  // strip chunk i: rows r32 + 32 (i % 3) of strip i / 3 (stride 1: one strip, i = 0..2)
   auto issue_x = [&](int i, int t) __attribute__((always_inline)) {
-    const uint32_t e = tab[(t % 3) * W3_TAB + 64 + r32 + 32 * i];
+    const uint32_t e = tab[(t % 3) * W3_TAB + 64 + (i / 3) * W3_XROWS + r32 + 32 * (i % 3)];
     const uint32_t m = (uint32_t)((int)e >> 31), pix = e & 0x7fffffffu;
     xreg[i] = ld16(Xb, (__umul24(pix, ldx2b) + xcol) & m);
   };
@@ -396,17 +431,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       o[j] = relu_pk(packbf(fmaf(bf_lo(x), pa[2 * j], pb[2 * j]), fmaf(bf_hi(x), pa[2 * j + 1], pb[2 * j + 1])));
     }
     if (j == 3) {
-      o &= (uint32_t)((int)tab[(t % 3) * W3_TAB + 64 + r32 + 32 * i] >> 31);
-      *reinterpret_cast<u32x4*>(Xt + (r32 + 32 * i) * W3_XP + q16 * 16) = o;
+      const int row = (i / 3) * W3_XROWS + r32 + 32 * (i % 3);
+      o &= (uint32_t)((int)tab[(t % 3) * W3_TAB + 64 + row] >> 31);
+      *reinterpret_cast<u32x4*>(Xt + row * W3_XP + q16 * 16) = o;
       if (reissue) issue_x(i, t + 1);
     }
   };
-  // the whole third strip chunk (rows 64, 65) of threads 0..31
+  // the whole third chunk of a strip (rows 64, 65) of threads 0..31 (stride 2: only the odd strip has a row 64)
   auto extra_x = [&](char* Xt, int t, bool reissue) __attribute__((always_inline)) {
     if (tid < 32) {
       u32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) unit_x(2, j, o, Xt, t, reissue);
+      for (int j = 0; j < 4; ++j) unit_x(S2 ? 5 : 2, j, o, Xt, t, reissue);
     }
   };
 
@@ -433,8 +469,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       bf16x8 af[2], bfr[3];
       af[0] = tr_frag(Gt, W3_GP, kk * 16, wa * 64, lane);
       af[1] = tr_frag(Gt, W3_GP, kk * 16, wa * 64 + 32, lane);
+      if (!S2) {
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) bfr[dx] = tr_frag(Xt, W3_XP, kk * 16 + dx, wb * 32, lane);
+        for (int dx = 0; dx < 3; ++dx) bfr[dx] = tr_frag(Xt, W3_XP, kk * 16 + dx, wb * 32, lane);
+      } else {
+        bfr[0] = tr_frag(Xt + W3_XROWS * W3_XP, W3_XP, kk * 16, wb * 32, lane);           // odd strip, one position to the left
+        bfr[1] = tr_frag(Xt, W3_XP, kk * 16, wb * 32, lane);                              // even strip
+        bfr[2] = tr_frag(Xt + W3_XROWS * W3_XP, W3_XP, kk * 16 + 1, wb * 32, lane);       // odd strip
+      }
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         acc[q & 1][q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q & 1], bfr[q >> 1], acc[q & 1][q >> 1], 0, 0, 0);
@@ -446,6 +488,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           // 16 dword units (8 dZ, 8 strip) on slots 3..18, the extra strip chunk on slot 20
           if (slot >= 3 && slot < 11) unit_g(Rc, (slot - 3) >> 2, (slot - 3) & 3, o, Gn, t + 1);
           if (slot >= 11 && slot < 19) unit_x((slot - 11) >> 2, (slot - 11) & 3, o, Xn, t + 1, ISSUE);
+          if (S2) {                                          // the odd strip's two full chunks on the four free slots, two units each
+            const int f = slot == 19 ? 0 : slot == 21 ? 1 : slot == 22 ? 2 : slot == 23 ? 3 : -1;
+            if (f >= 0) {
+              unit_x(3 + (f >> 1), 2 * (f & 1), o, Xn, t + 1, ISSUE);
+              unit_x(3 + (f >> 1), 2 * (f & 1) + 1, o, Xn, t + 1, ISSUE);
+            }
+          }
           if (slot == 20) extra_x(Xn, t + 1, ISSUE);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -464,7 +513,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     issue_g(set0, 1, step0);
     issue_x(0, step0);
     issue_x(1, step0);
-    if (tid < 32) issue_x(2, step0);
+    if (S2) {
+      issue_x(3, step0);
+      issue_x(4, step0);
+    }
+    if (tid < 32) issue_x(S2 ? 5 : 2, step0);
     if (nsteps > 1) {
       issue_g(set1, 0, step0 + 1);
       issue_g(set1, 1, step0 + 1);
@@ -475,6 +528,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int u = 0; u < 8; ++u) unit_g(set0, u >> 2, u & 3, o, smem, step0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) unit_x(u >> 2, u & 3, o, smem + PX * W3_GP, step0, nsteps > 1);
+      if (S2) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) unit_x(3 + (u >> 2), u & 3, o, smem + PX * W3_GP, step0, nsteps > 1);
+      }
       extra_x(smem + PX * W3_GP, step0, nsteps > 1);
     }
     __syncthreads();
@@ -536,21 +593,23 @@ __global__ __launch_bounds__(256) void dw3_reduce_kernel(float* __restrict__ dw,
 
 static inline int w3_splits(const CxWgrad& p);
 
-template <int GPRO, int XPRO>
+template <int GPRO, int XPRO, bool S2>
 int launch3(const CxWgrad& p, hipStream_t st) {
   W3Geo g;
-  g.B = p.B, g.H = p.H, g.W = p.W, g.P = p.W + 2;
-  g.TP = p.B * p.H * g.P;
+  g.B = p.B, g.H = p.H, g.W = p.W;
+  g.Ho = S2 ? p.Ho : p.H, g.Wo = S2 ? p.Wo : p.W;
+  g.P = S2 ? p.Wo + 1 : p.W + 2;
+  g.TP = p.B * g.Ho * g.P;
   g.mP = 0xffffffffu / (uint32_t)g.P + 1u;
-  g.mH = 0xffffffffu / (uint32_t)p.H + 1u;
+  g.mH = 0xffffffffu / (uint32_t)g.Ho + 1u;
   const int c_tiles = p.K / 128, n_tiles = (p.N + 127) / 128;
   const int total_steps = (g.TP + PX - 1) / PX;
   const int splits = w3_splits(p);
   const int sps = (total_steps + splits - 1) / splits;
-  const size_t smem = 2 * W3_STAGE + 3 * W3_TAB * 4;
+  const size_t smem = 2 * W3L<S2>::STAGE + 3 * W3L<S2>::TAB * 4;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<GPRO, XPRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<GPRO, XPRO, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
   const size_t nk = (size_t)p.N * p.K;
@@ -558,8 +617,8 @@ int launch3(const CxWgrad& p, hipStream_t st) {
   // the sum below runs at once, behind the kernel on the same stream: in stream order the region is free again when this call
   // returns, so a deferring caller (ops._wgrad_used) must not advance its arena past it -- and must not see the previous launch's figure
   cx_tl_slab_floats_v = 0;
-  CX_KTAG("wgrad3_kernel<%d, %d>", GPRO, XPRO);
-  hipLaunchKernelGGL((wgrad3_kernel<GPRO, XPRO>), dim3(c_tiles * n_tiles * 3 * splits), dim3(512), smem, st, p, g, c_tiles, n_tiles, total_steps,
+  CX_KTAG("wgrad3_kernel<%d, %d, %s>", GPRO, XPRO, S2 ? "true" : "false");
+  hipLaunchKernelGGL((wgrad3_kernel<GPRO, XPRO, S2>), dim3(c_tiles * n_tiles * 3 * splits), dim3(512), smem, st, p, g, c_tiles, n_tiles, total_steps,
                      sps, slab);
   if (const int e = launch_status()) return e;
   hipLaunchKernelGGL(dw3_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, p.dw, slab, nk, splits);
@@ -568,7 +627,7 @@ int launch3(const CxWgrad& p, hipStream_t st) {
 
 // pixel-range splits of the 3x3 kernel (shared by the dispatcher's workspace check and the launcher)
 static inline int w3_splits(const CxWgrad& p) {
-  const int total_steps = (p.B * p.H * (p.W + 2) + PX - 1) / PX;
+  const int total_steps = ((p.stride == 2 ? p.B * p.Ho * (p.Wo + 1) : p.B * p.H * (p.W + 2)) + PX - 1) / PX;
   int splits = p.splits > 0 ? p.splits : 256 / ((p.K / 128) * ((p.N + 127) / 128) * 3);
   if (splits < 1) splits = 1;
   if (splits > total_steps) splits = total_steps;
@@ -628,7 +687,7 @@ int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
   const int on = g_wm_on >= 0 ? g_wm_on : env_on0;
   const int env_form = g_wm_form >= 0 ? g_wm_form : env_form0;
   if (!on || p.mode != CX_MODE_CONV) return 0;
-  if (p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad == 1) {
+  if (p.kh == 3 && p.kw == 3 && (p.stride == 1 || p.stride == 2) && p.pad == 1) {
     // the bottleneck 3x3 layers (wgrad3_kernel); padded positions, pixel indices and byte offsets must fit their fields
     static const int env3 = cx_diag_int("CX_WGRAD3", 1);
     const int on3 = g_wm_form == 0 ? 0 : env3;          // kernel_hint = CX_KERNEL_HINT(1, 0): the strip kernel
@@ -637,8 +696,16 @@ int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
     if (!on3 || (p.N % 8) || ((p.N % 128) && (min_n3 <= 0 || p.N < min_n3)) || (p.K % 128) || p.W < 2 || p.H < 2) return 0;
     // its partial tiles leave through the slab workspace only (see the kernel's epilogue): without one the strip kernel runs
     if (!p.scratch || (long long)w3_splits(p) * 9 * p.N * p.K > p.scratch_floats) return 0;
-    const unsigned long long tp = (unsigned long long)p.B * p.H * (p.W + 2);
-    if (tp * (p.W + 2) >= (1ull << 32) || (unsigned long long)p.B * p.H * p.H >= (1ull << 32) || tp >= (1ull << 24)) return 0;
+    const bool s2 = p.stride == 2;
+    if (s2 && (p.Ho != (p.H - 1) / 2 + 1 || p.Wo != (p.W - 1) / 2 + 1)) return 0;
+    // measured at 128 images (scratch/bench_w3s2.py): 226 / 178 / 212 us against the generic kernel's 374 / 378 / 338 on the three
+    // attention-augmented transitions (K = 256 / 512 / 1024), 121 / 125 against 228 on ResNet152's layer3.0 / layer4.0 (K = 256 / 512),
+    // but 255 against 241 on layer2.0 (K = 128 on the 80x80 map: one channel tile, the strips of the large map staged by 3 x 85
+    // workgroups each) -- taken from two channel tiles up unless the call pins the form
+    if (s2 && p.K < 256 && g_wm_form != 3) return 0;
+    const unsigned long long pw = s2 ? p.Wo + 1 : p.W + 2, ph = s2 ? p.Ho : p.H;
+    const unsigned long long tp = (unsigned long long)p.B * ph * pw;
+    if (tp * pw >= (1ull << 32) || (unsigned long long)p.B * ph * ph >= (1ull << 32) || tp >= (1ull << 24)) return 0;
     int ldm = p.ldg > p.ldx ? p.ldg : p.ldx;
     if (p.g_prologue == CX_PRO_AFFINE2 && p.ldg2 > ldm) ldm = p.ldg2;
     if (ldm >= (1 << 23) || (unsigned long long)p.B * p.H * p.W * ldm * 2 >= (1ull << 32)) return 0;
@@ -646,8 +713,14 @@ int cx_try_wgrad_mm(const CxWgrad& p, hipStream_t st, bool* handled) {
     if (p.g_prologue != CX_PRO_NONE && !g2_) return 0;
     if (p.x_prologue != CX_PRO_NONE && p.x_prologue != CX_PRO_AFFINE_RELU) return 0;
     *handled = true;
-    if (p.x_prologue == CX_PRO_AFFINE_RELU) return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU>(p, st) : launch3<CX_PRO_NONE, CX_PRO_AFFINE_RELU>(p, st);
-    return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_NONE>(p, st) : launch3<CX_PRO_NONE, CX_PRO_NONE>(p, st);
+    if (s2) {
+      if (p.x_prologue == CX_PRO_AFFINE_RELU)
+        return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU, true>(p, st) : launch3<CX_PRO_NONE, CX_PRO_AFFINE_RELU, true>(p, st);
+      return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_NONE, true>(p, st) : launch3<CX_PRO_NONE, CX_PRO_NONE, true>(p, st);
+    }
+    if (p.x_prologue == CX_PRO_AFFINE_RELU)
+      return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_AFFINE_RELU, false>(p, st) : launch3<CX_PRO_NONE, CX_PRO_AFFINE_RELU, false>(p, st);
+    return g2_ ? launch3<CX_PRO_AFFINE2, CX_PRO_NONE, false>(p, st) : launch3<CX_PRO_NONE, CX_PRO_NONE, false>(p, st);
   }
   if (p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0) return 0;
   if ((p.N % 8) || (p.K % 8) || p.K < 64) return 0;

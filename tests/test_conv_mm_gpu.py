@@ -247,6 +247,42 @@ def test_3x3_weight_gradient_against_torch(dev, select_w, K, N, gpro, xpro, B, H
     ops.WGRAD_SCRATCH_FLOATS = keep
 
 
+@pytest.mark.parametrize("K,N,gpro,xpro,B,H,W,splits", [
+    (128, 128, 2, 1, 2, 10, 10, 0),        # 5 x 5 gradient image: 60 padded positions, one ragged step
+    (256, 120, 2, 1, 2, 20, 20, 2),        # the 3x3 branch of an attention-augmented transition (partial N tile), two channel tiles
+    (128, 128, 0, 1, 3, 16, 24, 3),        # plain gradient operand, non-square
+    (128, 256, 2, 0, 2, 9, 11, 1),         # odd sizes: the last input row / column has no odd-column / odd-row partner
+    (256, 256, 2, 1, 1, 40, 40, 4),        # ResNet layer3.0.conv2 at one image: 420 positions in four ranges
+    (128, 128, 2, 1, 2, 130, 6, 5),        # tall narrow map: a padded row of 4 positions
+])
+def test_3x3_stride2_weight_gradient_against_torch(dev, select_w, K, N, gpro, xpro, B, H, W, splits):
+    """wgrad3_kernel<.., S2>: the stride-2 3x3 layers (the first 3x3 of a ResNet stage, the 3x3 branch of an attention-augmented
+    transition) -- pixels walked in the padded OUTPUT index space, the activation row staged as an even-column and an odd-column strip
+    so that the taps of a kernel row are unit shifts again; against torch and against the generic kernel it replaces on these shapes."""
+    from chexpert_amd import ops
+    keep, ops.WGRAD_SCRATCH_FLOATS = ops.WGRAD_SCRATCH_FLOATS, 16 << 20
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gb_, g = nhwc(50, B, Ho, Wo, N + 32, dev)
+    g2b, g2 = nhwc(51, B, Ho, Wo, N, dev)
+    xb, x = nhwc(52, B, H, W, K + 64, dev)
+    ga, gbv, gc = rnd(53, (N,), 0.5, 1.5), rnd(54, (N,), -0.3, 0.3), rnd(55, (N,), -0.2, 0.2)
+    pa, pb = rnd(56, (K,), -0.3, 1.5), rnd(57, (K,), -0.5, 0.5)
+    G = bf(g[:, :N] * cv(ga) + g2 * cv(gbv) + cv(gc)) if gpro else g[:, :N]
+    A = bf(F.relu(x[:, 32:32 + K] * cv(pa) + cv(pb))) if xpro else x[:, 32:32 + K]
+    want = torch.nn.grad.conv2d_weight(A, (N, K, 3, 3), G, stride=2, padding=1)
+    outs = []
+    for on, form in ((1, 3), (0, 0)):       # wgrad3_kernel, then conv_wgrad.hip's generic kernel
+        select_w(on, form)
+        dw0 = rnd(58, (N, K, 3, 3), -1, 1)
+        dw = dw0.clone().to(dev)
+        ops.conv_wgrad(gb_[..., :N], xb[..., 32:32 + K], dw, kh=3, kw=3, stride=2, pad=1, g_prologue=gpro, g2=g2b if gpro else None,
+                       ga=ga.to(dev), gb=gbv.to(dev), gc=gc.to(dev), x_prologue=xpro, pa=pa.to(dev), pb=pb.to(dev), splits=splits if on else 0)
+        assert ops.last_kernel().startswith("wgrad3_kernel" if on else "wgrad_kernel"), ops.last_kernel()
+        outs.append(dw.cpu() - dw0)
+        close(outs[-1], want, rel=2e-3, what="dW (%s)" % ops.last_kernel())
+    ops.WGRAD_SCRATCH_FLOATS = keep
+
+
 # ------------------------------------------------------------------------------------------------ differential checks on random shapes
 def test_random_shapes_agree_with_the_kernels_they_replace(dev, select, select_w):
     """conv_mm against the generic implicit GEMM, wgrad_mm / wgrad3 against conv_wgrad.hip's kernels, on shapes drawn at random
